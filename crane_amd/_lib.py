@@ -1,0 +1,108 @@
+"""ctypes binding of include/crane_mi355.h.
+
+The HIP library is the product: importing a model class without it raises
+(there is no CPU fallback, by design).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrane_mi355.so")
+
+CM_ABI_VERSION = 1
+CM_OK = 0
+STATUS_NAMES = {0: "CM_OK", -1: "CM_ERR_INVALID", -2: "CM_ERR_IO", -3: "CM_ERR_UNSUPPORTED",
+                -4: "CM_ERR_DEVICE", -5: "CM_ERR_OOM", -6: "CM_ERR_RANGE"}
+
+# every symbol include/crane_mi355.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "cm_create", "cm_create_synthetic", "cm_destroy", "cm_last_error", "cm_last_global_error",
+    "cm_tp_unique_id", "cm_num_layers", "cm_vocab_size", "cm_hidden_size", "cm_max_seq_len",
+    "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_forward_step",
+    "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
+    "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
+    "cm_decode_batch", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
+]
+
+
+class CmOpts(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device", C.c_int32), ("tp_rank", C.c_int32),
+        ("tp_size", C.c_int32), ("tp_unique_id", C.c_void_p), ("max_seq_len", C.c_uint32),
+        ("max_seqs", C.c_uint32), ("kv_block_size", C.c_uint32), ("kv_pool_tokens", C.c_uint64),
+        ("kv_dtype", C.c_int32), ("use_graph", C.c_int32), ("prefill_chunk", C.c_uint32),
+        ("prefill_split", C.c_int32), ("reserved", C.c_uint32 * 8),
+    ]
+
+
+class CmGenConfig(C.Structure):
+    _fields_ = [
+        ("max_new_tokens", C.c_uint32), ("temperature", C.c_float), ("top_p", C.c_float),
+        ("repetition_penalty", C.c_float), ("repeat_last_n", C.c_uint32),
+        ("eos_token_id", C.c_int64 * 4), ("sync_every", C.c_uint32), ("reserved", C.c_uint32 * 7),
+    ]
+
+
+TOKEN_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)
+
+
+class CraneError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libcrane_mi355.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C crane_amd/csrc). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp, u32p, f32p = C.c_void_p, P(C.c_uint32), P(C.c_float)
+    lib.cm_create.argtypes = [C.c_char_p, P(CmOpts), P(vp)]
+    lib.cm_create_synthetic.argtypes = [C.c_char_p, C.c_uint64, P(CmOpts), P(vp)]
+    lib.cm_destroy.argtypes = [vp]
+    lib.cm_destroy.restype = None
+    lib.cm_last_error.argtypes = [vp]
+    lib.cm_last_error.restype = C.c_char_p
+    lib.cm_last_global_error.restype = C.c_char_p
+    lib.cm_tp_unique_id.argtypes = [vp]
+    for n in ("cm_num_layers", "cm_vocab_size", "cm_hidden_size", "cm_max_seq_len"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = C.c_size_t
+    for n in ("cm_kv_bytes", "cm_weight_bytes"):
+        getattr(lib, n).argtypes = [vp]
+        getattr(lib, n).restype = C.c_uint64
+    lib.cm_decode_bytes_per_token.argtypes = [vp, C.c_size_t]
+    lib.cm_decode_bytes_per_token.restype = C.c_uint64
+    lib.cm_forward_step.argtypes = [vp, u32p, C.c_size_t, C.c_size_t, f32p]
+    lib.cm_forward_step_greedy.argtypes = [vp, u32p, C.c_size_t, C.c_size_t, u32p]
+    lib.cm_clear_kv.argtypes = [vp]
+    lib.cm_clear_kv.restype = None
+    lib.cm_warmup.argtypes = [vp]
+    lib.cm_generate.argtypes = [vp, u32p, C.c_size_t, P(CmGenConfig), u32p, P(C.c_size_t), TOKEN_CB, vp]
+    lib.cm_seq_alloc.argtypes = [vp, P(C.c_int32)]
+    lib.cm_seq_free.argtypes = [vp, C.c_int32]
+    lib.cm_seq_fork.argtypes = [vp, C.c_int32, P(C.c_int32)]
+    lib.cm_seq_len.argtypes = [vp, C.c_int32]
+    lib.cm_seq_len.restype = C.c_int64
+    lib.cm_seq_truncate.argtypes = [vp, C.c_int32, C.c_size_t]
+    lib.cm_seq_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, u32p]
+    lib.cm_decode_batch.argtypes = [vp, P(C.c_int32), u32p, C.c_size_t, f32p, u32p]
+    lib.cm_bench_decode.argtypes = [vp, C.c_uint32, C.c_size_t, u32p, f32p]
+    lib.cm_bench_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, f32p, P(C.c_uint64)]
+    lib.cm_debug_fill_kv.argtypes = [vp, C.c_size_t, C.c_uint64]
+    lib.cm_debug_read.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
+    _lib = lib
+    return lib

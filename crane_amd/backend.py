@@ -1,0 +1,298 @@
+"""Python mirror of the reference's model-side interface, on top of the C ABI.
+
+Method names, argument meaning and error behaviour follow
+
+* ``trait ModelBackend``      crane-serve/src/engine/backend.rs:30-147
+* ``trait ModelForCausalLM``  crane-core/src/generation/based.rs:5-34
+* ``struct GenerationConfig`` crane-core/src/generation/mod.rs:62-99
+* ``qwen3::Model``            crane-core/src/models/qwen3/model.rs:45-349
+
+so the parity tests read like the reference's own.  Host Rust is not
+available in this image; INTEGRATION.md has the Rust shim that binds the same
+C ABI.  All compute happens in ``libcrane_mi355.so`` (HIP); this module never
+touches the oracle and has no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class GenerationConfig:
+    """generation/mod.rs:62-99 (same field names and defaults)."""
+    max_new_tokens: int = 245
+    temperature: Optional[float] = 0.67
+    top_p: Optional[float] = 1.0
+    repetition_penalty: float = 1.0
+    repeat_last_n: int = 5
+    do_sample: bool = False          # never read by the reference either
+    pad_token_id: Optional[int] = None
+    eos_token_id: Optional[int] = None
+    report_speed: bool = False
+    enable_thinking: Optional[bool] = None
+
+    @classmethod
+    def with_max_tokens(cls, n: int) -> "GenerationConfig":
+        return cls(max_new_tokens=n)
+
+    @classmethod
+    def greedy(cls, n: int, eos_token_id: Optional[int] = None) -> "GenerationConfig":
+        """temperature: None selects arg-max (qwen3/model.rs:284)."""
+        return cls(max_new_tokens=n, temperature=None, top_p=None, eos_token_id=eos_token_id)
+
+
+class TokenStreamer:
+    """generation/streamer.rs:7-10."""
+
+    def append(self, token_id: int) -> None:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def finalize(self) -> None:  # pragma: no cover - interface
+        pass
+
+
+class ListStreamer(TokenStreamer):
+    def __init__(self):
+        self.tokens: List[int] = []
+        self.finalized = False
+
+    def append(self, token_id: int) -> None:
+        self.tokens.append(int(token_id))
+
+    def finalize(self) -> None:
+        self.finalized = True
+
+
+def _u32(ids: Sequence[int]):
+    arr = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32))
+    return arr, arr.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Model:
+    """One replica / TP rank of the MI355X inference path (qwen3::Model + ModelBackend)."""
+
+    def __init__(self, handle, lib):
+        self._h = handle
+        self._lib = lib
+        self.vocab_size = int(lib.cm_vocab_size(handle))
+        self.hidden_size = int(lib.cm_hidden_size(handle))
+        self._eos: List[int] = []
+
+    # -- construction -------------------------------------------------------
+    @staticmethod
+    def _opts(device=0, max_seq_len=0, max_seqs=0, kv_block_size=0, kv_pool_tokens=0, use_graph=0,
+              tp_rank=0, tp_size=1, tp_unique_id: Optional[bytes] = None, prefill_chunk=0, prefill_split=0):
+        o = _lib.CmOpts()
+        o.abi_version = _lib.CM_ABI_VERSION
+        o.device, o.tp_rank, o.tp_size = device, tp_rank, tp_size
+        o.max_seq_len, o.max_seqs, o.kv_block_size = max_seq_len, max_seqs, kv_block_size
+        o.kv_pool_tokens, o.use_graph = kv_pool_tokens, use_graph
+        o.prefill_chunk, o.prefill_split = prefill_chunk, prefill_split
+        keep = None
+        if tp_unique_id is not None:
+            keep = C.create_string_buffer(bytes(tp_unique_id), 128)
+            o.tp_unique_id = C.cast(keep, C.c_void_p)
+        return o, keep
+
+    @classmethod
+    def from_pretrained(cls, model_dir: str, **kw) -> "Model":
+        """Model::new / from_pretrained (qwen3/model.rs:45-106)."""
+        lib = _lib.load()
+        o, keep = cls._opts(**kw)
+        h = C.c_void_p()
+        rc = lib.cm_create(model_dir.encode(), C.byref(o), C.byref(h))
+        if rc != 0:
+            raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
+        m = cls(h, lib)
+        try:
+            with open(f"{model_dir}/config.json") as f:
+                e = json.load(f).get("eos_token_id")
+            if isinstance(e, int):
+                m._eos = [e]
+            elif isinstance(e, list):
+                m._eos = [int(x) for x in e]
+        except OSError:
+            pass
+        return m
+
+    @classmethod
+    def synthetic(cls, config: dict, seed: int = 0, **kw) -> "Model":
+        lib = _lib.load()
+        o, keep = cls._opts(**kw)
+        h = C.c_void_p()
+        rc = lib.cm_create_synthetic(json.dumps(config).encode(), seed, C.byref(o), C.byref(h))
+        if rc != 0:
+            raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
+        return cls(h, lib)
+
+    def close(self):
+        if self._h:
+            self._lib.cm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise _lib.CraneError(rc, self._lib.cm_last_error(self._h).decode())
+
+    # -- ModelBackend (backend.rs:30-147) -------------------------------------
+    def forward_step(self, input_ids: Sequence[int], start_pos: int) -> np.ndarray:
+        """Logits of the last position, shape [1, 1, vocab] like qwen3."""
+        arr, p = _u32(input_ids)
+        out = np.empty(self.vocab_size, dtype=np.float32)
+        self._check(self._lib.cm_forward_step(self._h, p, arr.size, start_pos,
+                                              out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out.reshape(1, 1, -1)
+
+    def forward_step_greedy(self, input_ids: Sequence[int], start_pos: int) -> int:
+        arr, p = _u32(input_ids)
+        t = C.c_uint32()
+        self._check(self._lib.cm_forward_step_greedy(self._h, p, arr.size, start_pos, C.byref(t)))
+        return int(t.value)
+
+    def clear_kv_cache(self) -> None:
+        self._lib.cm_clear_kv(self._h)
+
+    def num_layers(self) -> int:
+        return int(self._lib.cm_num_layers(self._h))
+
+    def device(self) -> str:
+        return "rocm:0"
+
+    def dtype(self) -> str:
+        return "bf16"
+
+    def eos_token_id(self) -> List[int]:
+        return list(self._eos)
+
+    def warmup(self) -> None:
+        self._check(self._lib.cm_warmup(self._h))
+
+    def supports_kv_swap(self) -> bool:
+        return True      # via paged sequences instead of tensor swaps
+
+    def supports_batch_decode(self) -> bool:
+        return True
+
+    def active_kv_cache_bytes(self) -> int:
+        return int(self._lib.cm_kv_bytes(self._h))
+
+    # -- paged sequences (replace get/set_kv_caches + pad/stack/extract) -------
+    def seq_alloc(self) -> int:
+        s = C.c_int32()
+        self._check(self._lib.cm_seq_alloc(self._h, C.byref(s)))
+        return int(s.value)
+
+    def seq_free(self, seq: int) -> None:
+        self._check(self._lib.cm_seq_free(self._h, seq))
+
+    def seq_fork(self, src: int) -> int:
+        s = C.c_int32()
+        self._check(self._lib.cm_seq_fork(self._h, src, C.byref(s)))
+        return int(s.value)
+
+    def seq_len(self, seq: int) -> int:
+        return int(self._lib.cm_seq_len(self._h, seq))
+
+    def seq_truncate(self, seq: int, new_len: int) -> None:
+        self._check(self._lib.cm_seq_truncate(self._h, seq, new_len))
+
+    def seq_forward(self, seq: int, input_ids: Sequence[int], start_pos: int, want_logits=True):
+        arr, p = _u32(input_ids)
+        out = np.empty(self.vocab_size, dtype=np.float32) if want_logits else None
+        t = C.c_uint32()
+        self._check(self._lib.cm_seq_forward(
+            self._h, seq, p, arr.size, start_pos,
+            out.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, C.byref(t)))
+        return out, int(t.value)
+
+    def step_batch_decode(self, seqs: Sequence[int], tokens: Sequence[int], want_logits=True):
+        """step_batch_decode (backend.rs:107-121): returns ([N,1,V] logits or None, greedy ids [N])."""
+        n = len(seqs)
+        sa = np.ascontiguousarray(np.asarray(seqs, dtype=np.int32))
+        ta, tp_ = _u32(tokens)
+        out = np.empty((n, self.vocab_size), dtype=np.float32) if want_logits else None
+        g = np.empty(n, dtype=np.uint32)
+        self._check(self._lib.cm_decode_batch(
+            self._h, sa.ctypes.data_as(C.POINTER(C.c_int32)), tp_, n,
+            out.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None,
+            g.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return (out.reshape(n, 1, -1) if want_logits else None), g
+
+    # -- ModelForCausalLM (based.rs:5-34; qwen3/model.rs:275-349) ---------------
+    def generate(self, input_ids: Sequence[int], config: GenerationConfig,
+                 streamer: Optional[TokenStreamer] = None, sync_every: int = 1) -> List[int]:
+        """Returns prompt ++ generated tokens (qwen3/model.rs:348)."""
+        arr, p = _u32(input_ids)
+        g = _lib.CmGenConfig()
+        g.max_new_tokens = config.max_new_tokens
+        g.temperature = -1.0 if config.temperature is None else float(config.temperature)
+        g.top_p = -1.0 if config.top_p is None else float(config.top_p)
+        g.repetition_penalty = float(config.repetition_penalty)
+        g.repeat_last_n = config.repeat_last_n
+        eos = [config.eos_token_id] if config.eos_token_id is not None else self._eos
+        for i in range(4):
+            g.eos_token_id[i] = int(eos[i]) if i < len(eos) else -1
+        g.sync_every = sync_every
+        out = np.empty(arr.size + config.max_new_tokens, dtype=np.uint32)
+        n_out = C.c_size_t(0)
+
+        def _cb(_user, tok):
+            if streamer is not None:
+                streamer.append(int(tok))
+            return 0
+
+        cb = _lib.TOKEN_CB(_cb)
+        rc = self._lib.cm_generate(self._h, p, arr.size, C.byref(g),
+                                   out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_out), cb, None)
+        if streamer is not None:
+            streamer.finalize()
+        self._check(rc)
+        return [int(t) for t in out[:n_out.value]]
+
+    # -- measurement hooks --------------------------------------------------------
+    def bench_decode(self, first_token: int, k: int):
+        toks = np.empty(k, dtype=np.uint32)
+        ms = C.c_float()
+        self._check(self._lib.cm_bench_decode(self._h, first_token, k,
+                                              toks.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(ms)))
+        return toks, float(ms.value)
+
+    _KERNEL_NAMES = {"qkv": "gemv<rmsnorm,store>", "o": "gemv<plain,resadd>", "gate_up": "gemv<rmsnorm,silu_mul>",
+                     "down": "gemv<plain,resadd>", "lm_head": "gemv<rmsnorm,argmax>"}
+
+    def bench_kernel(self, which: str, iters: int = 360) -> dict:
+        ms = C.c_float()
+        b = C.c_uint64()
+        self._check(self._lib.cm_bench_kernel(self._h, which.encode(), iters, C.byref(ms), C.byref(b)))
+        return {"kernel": f"{which}: {self._KERNEL_NAMES.get(which, which)}", "ms": float(ms.value), "bytes": int(b.value)}
+
+    def debug_fill_kv(self, ctx: int, seed: int = 0) -> None:
+        self._check(self._lib.cm_debug_fill_kv(self._h, ctx, seed))
+
+    def debug_read(self, what: str, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.float32)
+        self._check(self._lib.cm_debug_read(self._h, what.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out
+
+    def decode_bytes_per_token(self, ctx: int) -> int:
+        return int(self._lib.cm_decode_bytes_per_token(self._h, ctx))
+
+    def weight_bytes(self) -> int:
+        return int(self._lib.cm_weight_bytes(self._h))
+
+
+# the reference's adapter name for this family (backend.rs:609-748)
+Qwen3Backend = Model

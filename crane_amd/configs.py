@@ -1,0 +1,46 @@
+"""Named model configurations (HF ``config.json`` dictionaries).
+
+Shapes from SURVEY.md section 8 (values tagged [external] there are the
+HF-published ones).  ``tiny*`` configs are CPU-oracle-sized test models; the
+first mirrors the reference's own unit-test config
+(``crane-core/src/models/qwen3/modeling.rs:1386-1403``) scaled to dims the HIP
+kernels accept (hidden/head_dim multiples of 64).
+"""
+from __future__ import annotations
+
+import copy
+
+_QWEN3_COMMON = dict(
+    model_type="qwen3", rms_norm_eps=1e-6, rope_theta=1_000_000.0, attention_bias=False,
+    use_qk_norm=True, max_position_embeddings=40960, torch_dtype="bfloat16",
+)
+
+CONFIGS = {
+    "qwen3-0.6b": dict(_QWEN3_COMMON, vocab_size=151936, hidden_size=1024, intermediate_size=3072,
+                       num_hidden_layers=28, num_attention_heads=16, num_key_value_heads=8,
+                       head_dim=128, tie_word_embeddings=True),
+    "qwen3-8b": dict(_QWEN3_COMMON, vocab_size=151936, hidden_size=4096, intermediate_size=12288,
+                     num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8,
+                     head_dim=128, tie_word_embeddings=False),
+    # small shapes for CPU-oracle parity
+    "tiny-qwen3": dict(_QWEN3_COMMON, vocab_size=512, hidden_size=256, intermediate_size=512,
+                       num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       head_dim=128, tie_word_embeddings=True, max_position_embeddings=4096),
+    "tiny-qwen3-untied": dict(_QWEN3_COMMON, vocab_size=1000, hidden_size=512, intermediate_size=1536,
+                              num_hidden_layers=3, num_attention_heads=8, num_key_value_heads=2,
+                              head_dim=128, tie_word_embeddings=False, max_position_embeddings=4096),
+    "small-qwen3": dict(_QWEN3_COMMON, vocab_size=8192, hidden_size=1024, intermediate_size=3072,
+                        num_hidden_layers=4, num_attention_heads=16, num_key_value_heads=8,
+                        head_dim=128, tie_word_embeddings=True, max_position_embeddings=8192),
+}
+
+
+def get_config(name: str) -> dict:
+    if name not in CONFIGS:
+        raise KeyError(f"unknown config {name!r}; have {sorted(CONFIGS)}")
+    return copy.deepcopy(CONFIGS[name])
+
+
+def synthetic_prompt(n: int, vocab: int):
+    """ids[i] = (7 i + 3) mod V  -- the pattern of qwen3_5/prefill.rs:249."""
+    return [(7 * i + 3) % vocab for i in range(n)]

@@ -1,0 +1,210 @@
+// extern "C" surface (include/crane_mi355.h): translates C++ exceptions into status codes
+// + per-handle error strings (anyhow::Result on the Rust side).
+#include <cstring>
+#include <string>
+
+#include "model.h"
+#include "safetensors.h"
+#include "tp.h"
+
+using cm::CmError;
+using cm::Model;
+
+struct cm_model { Model m; };
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guard(cm_model* h, F&& f) {
+    try {
+        if (h) (void)hipSetDevice(h->m.dev);
+        f();
+        return CM_OK;
+    } catch (const CmError& e) {
+        if (h) h->m.err = e.what(); else g_err = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        if (h) h->m.err = e.what(); else g_err = e.what();
+        return CM_ERR_INVALID;
+    } catch (...) {
+        if (h) h->m.err = "unknown error"; else g_err = "unknown error";
+        return CM_ERR_INVALID;
+    }
+}
+
+extern "C" {
+
+int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out) {
+    if (!model_dir || !out) { g_err = "null argument"; return CM_ERR_INVALID; }
+    *out = nullptr;
+    cm_model* h = nullptr;
+    int rc = guard(nullptr, [&] {
+        std::string cfg;
+        try { cfg = cmst::read_text(std::string(model_dir) + "/config.json"); }
+        catch (const std::exception& e) { throw CmError(CM_ERR_IO, e.what()); }
+        h = new cm_model();
+        h->m.init_common(cfg, opts);
+        cm::load_from_dir(h->m, model_dir);
+        h->m.alloc_runtime();
+    });
+    if (rc != CM_OK) { delete h; return rc; }
+    *out = h;
+    return CM_OK;
+}
+
+int cm_create_synthetic(const char* config_json, uint64_t seed, const cm_opts* opts, cm_model** out) {
+    if (!config_json || !out) { g_err = "null argument"; return CM_ERR_INVALID; }
+    *out = nullptr;
+    cm_model* h = nullptr;
+    int rc = guard(nullptr, [&] {
+        h = new cm_model();
+        h->m.init_common(config_json, opts);
+        cm::load_synthetic(h->m, seed);
+        h->m.alloc_runtime();
+    });
+    if (rc != CM_OK) { delete h; return rc; }
+    *out = h;
+    return CM_OK;
+}
+
+void cm_destroy(cm_model* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->m.dev);
+    delete h;
+}
+
+const char* cm_last_error(const cm_model* h) { return h ? h->m.err.c_str() : g_err.c_str(); }
+const char* cm_last_global_error(void) { return g_err.c_str(); }
+
+int cm_tp_unique_id(void* out128) {
+    if (!out128) { g_err = "null argument"; return CM_ERR_INVALID; }
+    return guard(nullptr, [&] { cm::Rccl::unique_id(out128); });
+}
+
+size_t cm_num_layers(const cm_model* h) { return h ? (size_t)h->m.cfg.L : 0; }
+size_t cm_vocab_size(const cm_model* h) { return h ? (size_t)h->m.cfg.V : 0; }
+size_t cm_hidden_size(const cm_model* h) { return h ? (size_t)h->m.cfg.H : 0; }
+size_t cm_max_seq_len(const cm_model* h) { return h ? (size_t)h->m.max_seq : 0; }
+uint64_t cm_kv_bytes(const cm_model* h) { return h ? h->m.kv_bytes() : 0; }
+uint64_t cm_weight_bytes(const cm_model* h) { return h ? h->m.weight_bytes : 0; }
+uint64_t cm_decode_bytes_per_token(const cm_model* h, size_t ctx) { return h ? h->m.decode_bytes_per_token(ctx) : 0; }
+
+int cm_forward_step(cm_model* h, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (!logits_out) throw CmError(CM_ERR_INVALID, "logits_out is null");
+        h->m.forward(0, ids, n, start_pos, logits_out, nullptr);
+    });
+}
+
+int cm_forward_step_greedy(cm_model* h, const uint32_t* ids, size_t n, size_t start_pos, uint32_t* token_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (!token_out) throw CmError(CM_ERR_INVALID, "token_out is null");
+        h->m.forward(0, ids, n, start_pos, nullptr, token_out);
+    });
+}
+
+void cm_clear_kv(cm_model* h) {
+    if (!h) return;
+    (void)guard(h, [&] { h->m.seq_truncate(0, 0); });
+}
+
+int cm_warmup(cm_model* h) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        // generate(&[45, 546, 456], max 5) then clear (qwen3/model.rs:261-267)
+        uint32_t prompt[3] = {45u % (uint32_t)h->m.cfg.V, 546u % (uint32_t)h->m.cfg.V, 456u % (uint32_t)h->m.cfg.V};
+        uint32_t out[8];
+        size_t n = 0;
+        cm_gen_config g;
+        memset(&g, 0, sizeof g);
+        g.max_new_tokens = 5; g.temperature = -1.f; g.top_p = -1.f; g.repetition_penalty = 1.f;
+        for (int i = 0; i < 4; ++i) g.eos_token_id[i] = -1;
+        h->m.generate(prompt, 3, &g, out, &n, nullptr, nullptr);
+        h->m.seq_truncate(0, 0);
+    });
+}
+
+int cm_generate(cm_model* h, const uint32_t* prompt, size_t n_prompt, const cm_gen_config* cfg, uint32_t* tokens_out,
+                size_t* n_out, cm_token_cb cb, void* user) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.generate(prompt, n_prompt, cfg, tokens_out, n_out, cb, user); });
+}
+
+int cm_seq_alloc(cm_model* h, int32_t* seq_out) {
+    if (!h || !seq_out) return CM_ERR_INVALID;
+    return guard(h, [&] { *seq_out = h->m.seq_alloc(); });
+}
+int cm_seq_free(cm_model* h, int32_t seq) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { (void)h->m.seq(seq); h->m.seq_free(seq); });
+}
+int cm_seq_fork(cm_model* h, int32_t src, int32_t* seq_out) {
+    if (!h || !seq_out) return CM_ERR_INVALID;
+    return guard(h, [&] { *seq_out = h->m.seq_fork(src); });
+}
+int64_t cm_seq_len(const cm_model* h, int32_t seq) {
+    if (!h || seq < 0 || seq >= (int32_t)h->m.seqs.size() || !h->m.seqs[(size_t)seq].used) return -1;
+    return h->m.seqs[(size_t)seq].len;
+}
+int cm_seq_truncate(cm_model* h, int32_t seq, size_t new_len) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.seq_truncate(seq, new_len); });
+}
+int cm_seq_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out,
+                   uint32_t* greedy_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.forward(seq, ids, n, start_pos, logits_out, greedy_out); });
+}
+
+int cm_decode_batch(cm_model* h, const int32_t* seqs, const uint32_t* last_tokens, size_t n, float* logits_out,
+                    uint32_t* greedy_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (!seqs || !last_tokens || n == 0) throw CmError(CM_ERR_INVALID, "empty batch");
+        // Round 1: sequences are stepped one after another on the paged cache (no padding,
+        // no KV copies -- already cheaper than pad/stack/extract); a true M>1 GEMV batch is next.
+        const size_t V = (size_t)h->m.cfg.V;
+        for (size_t i = 0; i < n; ++i) {
+            const int64_t len = cm_seq_len(h, seqs[i]);
+            if (len < 0) throw CmError(CM_ERR_INVALID, "invalid sequence handle in batch");
+            h->m.forward(seqs[i], &last_tokens[i], 1, (size_t)len, logits_out ? logits_out + i * V : nullptr,
+                         greedy_out ? greedy_out + i : nullptr);
+        }
+    });
+}
+
+int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.bench_decode(first_token, k, tokens_out, ms_out); });
+}
+
+int cm_bench_kernel(cm_model* h, const char* which, size_t iters, float* ms_out, uint64_t* bytes_out) {
+    if (!h || !which) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.bench_kernel(which, iters, ms_out, bytes_out); });
+}
+
+int cm_debug_fill_kv(cm_model* h, size_t ctx, uint64_t seed) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.debug_fill_kv(ctx, seed); });
+}
+
+int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
+    if (!h || !what || !out) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        const float* src = nullptr;
+        size_t avail = 0;
+        const std::string w = what;
+        if (w == "hidden") { src = h->m.x; avail = (size_t)h->m.cfg.H; }
+        else if (w == "logits") { src = h->m.logits; avail = (size_t)h->m.V_l * h->m.tp; }
+        else if (w == "attn") { src = h->m.attn; avail = (size_t)h->m.Hq_l * h->m.cfg.D; }
+        else if (w == "qkv") { src = h->m.qkv; avail = (size_t)(h->m.Hq_l + 2 * h->m.Hkv_l) * h->m.cfg.D; }
+        else throw CmError(CM_ERR_INVALID, "unknown buffer name");
+        if (n > avail) throw CmError(CM_ERR_RANGE, "read beyond buffer");
+        CM_HIP(hipStreamSynchronize(h->m.stream));
+        CM_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Device-side helpers shared by all gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cm {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> f32 (bit tricks; RNE on the way down, finite inputs) ---------
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xFFFF0000u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- streaming (non-temporal) 16-byte load: weights are read once ----------
+__device__ __forceinline__ u32x4 ld_nt16(const void* p) {
+    return __builtin_nontemporal_load((const u32x4*)p);
+}
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+
+// ---- DPP cross-lane (no LDS traffic) ----------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 16 lanes ("row"); every lane of the row gets it
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+// full 64-lane sum, result wave-uniform
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// ---- synthetic weights (crane_amd/synth.py) ------------------------------------
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ float synth_val(uint32_t idx, uint32_t tseed, float mul, float off) {
+    uint32_t h = fmix32(idx * 0x9E3779B1u + tseed);
+    int c = (int)((h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + (h >> 24)) - 510;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fadd_rn(off, __fmul_rn((float)c, mul));   // no FMA contraction: must match numpy bit-for-bit
+#else
+    volatile float prod = (float)c * mul;
+    return off + prod;
+#endif
+}
+
+// decode-step state living in HBM so a captured hipGraph can be replayed
+struct StepState {
+    uint32_t token;     // token to feed this step
+    int32_t pos;        // its KV position
+    uint32_t next;      // arg-max result of this step
+    int32_t pad;
+};
+
+}  // namespace cm

@@ -1,0 +1,59 @@
+// Host-visible launch interface of the gfx950 kernels (internal; the public ABI is
+// include/crane_mi355.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_common.h"
+
+namespace cm {
+
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
+enum { EPI_STORE = 0, EPI_RESADD = 1, EPI_SILUMUL = 2, EPI_ARGMAX = 3 };
+
+struct GemvArgs {
+    const uint16_t* W;     // [N, ldw] bf16, K contiguous
+    const float* x;        // [K] f32
+    const uint16_t* nw;    // [K] bf16 RMSNorm weight (PRO_RMSNORM)
+    float* y;              // output (see epilogues)
+    const float* res;      // [N] residual (EPI_RESADD); may alias y
+    float* pmax;           // [grid] (EPI_ARGMAX)
+    int* pidx;             // [grid]
+    int N, K, ldw;
+    int idx_base;          // added to row index for arg-max (vocab shard offset)
+    float eps;
+};
+
+struct AttnDecArgs {
+    const float* qkv;            // [(Hq + 2 Hkv) * D] f32, this token
+    const uint16_t* qnw;         // [D] bf16 or null
+    const uint16_t* knw;
+    const float* cos;            // [max_pos, D/2] f32
+    const float* sin;
+    const StepState* st;
+    const int32_t* block_table;  // [max_pages_per_seq]
+    uint16_t* kpool;             // this layer: [pages][Hkv][PAGE][D] bf16
+    uint16_t* vpool;
+    float* part_o;               // [Hq][nsplit][D]
+    float* part_ml;              // [Hq][nsplit][2]
+    int Hkv, page;
+    float eps, scale;
+};
+
+// ---- decode ----
+int gemv_rows_per_group(int K);
+int gemv_grid(int N, int K, int num_cu);
+void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s);
+void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s);
+void launch_set_state(StepState* st, uint32_t token, int32_t pos, hipStream_t s);
+void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
+                         int ring_mask, int advance, hipStream_t s);
+bool launch_attn_decode(const AttnDecArgs& a, int nrep, int nsplit, float* out, hipStream_t s);
+
+// ---- synthetic weights / utility ----
+// dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))
+void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncols, int row0, int col0,
+                       int full_cols, uint32_t tseed, float mul, float off, hipStream_t s);
+void launch_kv_fill(uint16_t* pool, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
+                    hipStream_t s);
+
+}  // namespace cm

@@ -1,0 +1,48 @@
+// Utility kernels: deterministic synthetic weights (crane_amd/synth.py), synthetic KV fill.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+__global__ void synth_fill_kernel(uint16_t* __restrict__ dst, size_t dst_row_stride, int nrows, int ncols,
+                                  int row0, int col0, int full_cols, uint32_t tseed, float mul, float off) {
+    const size_t total = (size_t)nrows * ncols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ncols), c = (int)(i % ncols);
+        const uint32_t idx = (uint32_t)((size_t)(row0 + r) * full_cols + (col0 + c));
+        dst[(size_t)r * dst_row_stride + c] = f32_to_bf16(synth_val(idx, tseed, mul, off));
+    }
+}
+
+void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncols, int row0, int col0,
+                       int full_cols, uint32_t tseed, float mul, float off, hipStream_t s) {
+    const size_t total = (size_t)nrows * ncols;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 32);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(blocks), dim3(256), 0, s, dst, dst_row_stride, nrows, ncols,
+                       row0, col0, full_cols, tseed, mul, off);
+}
+
+// pool: [n_pages][page_elems]; fill the listed pages with N(0,1)-like bf16 values
+__global__ void kv_fill_kernel(uint16_t* __restrict__ pool, const int32_t* __restrict__ pages, int npages,
+                               size_t page_elems, uint32_t tseed) {
+    const size_t total = (size_t)npages * page_elems;
+    const float mul = 1.0f / 147.80054f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / page_elems);
+        const size_t e = i % page_elems;
+        pool[(size_t)pages[p] * page_elems + e] = f32_to_bf16(synth_val((uint32_t)i, tseed, mul, 0.f));
+    }
+}
+
+void launch_kv_fill(uint16_t* pool, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
+                    hipStream_t s) {
+    const size_t total = (size_t)npages * page_elems;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kv_fill_kernel, dim3(blocks), dim3(256), 0, s, pool, pages, npages, page_elems, tseed);
+}
+
+}  // namespace cm

@@ -1,0 +1,554 @@
+// Host runtime: see model.h.  One Model = one replica (or one TP rank) on one GPU, with
+// its own HIP stream; nothing global, so N handles = N replicas
+// (ModelBackend is `Send`, never shared: crane-serve/src/lib.rs:1129-1132).
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "json_min.h"
+#include "tp.h"
+
+namespace cm {
+
+template <typename T>
+T* Model::dalloc(size_t n, bool count_weight) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    CM_HIP(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    if (count_weight) weight_bytes += bytes;
+    return (T*)p;
+}
+template uint16_t* Model::dalloc<uint16_t>(size_t, bool);
+template float* Model::dalloc<float>(size_t, bool);
+template int* Model::dalloc<int>(size_t, bool);
+
+Model::~Model() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    rccl.reset();
+    for (void* p : allocs) (void)hipFree(p);
+    if (h_bt) (void)hipHostFree(h_bt);
+    if (h_st) (void)hipHostFree(h_st);
+    if (h_ring) (void)hipHostFree(h_ring);
+    if (h_logits) (void)hipHostFree(h_logits);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------
+void Model::init_common(const std::string& config_json, const cm_opts* o) {
+    if (o) {
+        opts = *o;
+        if (opts.abi_version != 0 && opts.abi_version != CM_ABI_VERSION)
+            throw CmError(CM_ERR_INVALID, "cm_opts.abi_version mismatch");
+    }
+    cmjson::ValuePtr j;
+    try {
+        j = cmjson::parse(config_json);
+    } catch (const std::exception& e) {
+        throw CmError(CM_ERR_IO, std::string("config.json: ") + e.what());
+    }
+    if (j->kind != cmjson::Value::Obj) throw CmError(CM_ERR_IO, "config.json: not an object");
+    const cmjson::Value* root = j.get();
+    // VLM checkpoints nest the LM config under text_config
+    if (root->has("text_config") && !root->has("hidden_size")) root = root->get("text_config");
+    cfg.model_type = root->string("model_type", "qwen3");
+    cfg.V = (int)root->integer("vocab_size", 0);
+    cfg.H = (int)root->integer("hidden_size", 0);
+    cfg.I = (int)root->integer("intermediate_size", 0);
+    cfg.L = (int)root->integer("num_hidden_layers", 0);
+    cfg.Hq = (int)root->integer("num_attention_heads", 0);
+    cfg.Hkv = (int)root->integer("num_key_value_heads", cfg.Hq);
+    cfg.max_pos = (int)root->integer("max_position_embeddings", 0);
+    cfg.eps = (float)root->number("rms_norm_eps", 1e-6);
+    cfg.theta = root->number("rope_theta", 1e6);                 // default_rope_theta modeling.rs:107
+    cfg.attention_bias = root->boolean("attention_bias", false);
+    cfg.qk_norm = root->boolean("use_qk_norm", true);            // default true modeling.rs:111
+    cfg.tie = root->boolean("tie_word_embeddings", true);        // default true modeling.rs:113
+    cfg.D = root->has("head_dim") ? (int)root->integer("head_dim", 0) : (cfg.Hq ? cfg.H / cfg.Hq : 0);
+    cfg.eos = root->has("eos_token_id") && root->get("eos_token_id")->kind == cmjson::Value::Num
+                  ? root->integer("eos_token_id", -1) : -1;
+    if (cfg.V <= 0 || cfg.H <= 0 || cfg.I <= 0 || cfg.L <= 0 || cfg.Hq <= 0 || cfg.Hkv <= 0 || cfg.max_pos <= 0)
+        throw CmError(CM_ERR_IO, "config.json: missing required field");
+    if (cfg.model_type != "qwen3")
+        throw CmError(CM_ERR_UNSUPPORTED, "model_type '" + cfg.model_type + "' not implemented (qwen3 dense only so far)");
+    if (cfg.attention_bias) throw CmError(CM_ERR_UNSUPPORTED, "attention_bias not implemented");
+    if (cfg.D != 128) throw CmError(CM_ERR_UNSUPPORTED, "head_dim != 128 not implemented");
+    if (cfg.H % 8 || cfg.I % 8) throw CmError(CM_ERR_UNSUPPORTED, "hidden/intermediate must be multiples of 8");
+    if (cfg.Hq % cfg.Hkv) throw CmError(CM_ERR_INVALID, "num_attention_heads % num_key_value_heads != 0");
+
+    dev = opts.device;
+    CM_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    CM_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+    tp = opts.tp_size > 0 ? opts.tp_size : 1;
+    rank = opts.tp_rank;
+    if (rank < 0 || rank >= tp) throw CmError(CM_ERR_INVALID, "tp_rank out of range");
+    if (cfg.Hq % tp || cfg.I % tp || (cfg.I / tp) % 8)
+        throw CmError(CM_ERR_INVALID, "tp_size must divide heads and intermediate size");
+    if (!(cfg.Hkv % tp == 0 || tp % cfg.Hkv == 0))
+        throw CmError(CM_ERR_INVALID, "tp_size incompatible with num_key_value_heads");
+    Hq_l = cfg.Hq / tp;
+    if (cfg.Hkv >= tp) { Hkv_l = cfg.Hkv / tp; kvh0 = rank * Hkv_l; }
+    else { Hkv_l = 1; kvh0 = rank * cfg.Hkv / tp; }          // KV heads replicated tp/Hkv times
+    nrep = Hq_l / Hkv_l;
+    if (!(nrep == 1 || nrep == 2 || nrep == 3 || nrep == 4 || nrep == 6 || nrep == 8))
+        throw CmError(CM_ERR_UNSUPPORTED, "GQA group size not instantiated");
+    I_l = cfg.I / tp;
+    V_l = (cfg.V + tp - 1) / tp;
+    v0 = rank * V_l;
+
+    page = opts.kv_block_size ? (int)opts.kv_block_size : 64;
+    max_seq = opts.max_seq_len ? (int)opts.max_seq_len : std::min(cfg.max_pos, 32768);
+    if (max_seq > cfg.max_pos) max_seq = cfg.max_pos;
+    max_pages_per_seq = (max_seq + page - 1) / page;
+    const int max_seqs = opts.max_seqs ? (int)opts.max_seqs : 8;
+    n_pages = opts.kv_pool_tokens ? (int64_t)((opts.kv_pool_tokens + page - 1) / page)
+                                  : (int64_t)max_seqs * max_pages_per_seq;
+    if (n_pages < max_pages_per_seq) n_pages = max_pages_per_seq;
+    nsplit = std::max(1, std::min(64, num_cu / std::max(1, Hkv_l)));
+    use_graph = opts.use_graph >= 0;
+    if (opts.kv_dtype != CM_KV_BF16) throw CmError(CM_ERR_UNSUPPORTED, "kv_dtype f32 not implemented yet");
+    seqs.resize((size_t)max_seqs + 1);
+    seqs[0].used = true;
+}
+
+void Model::alloc_runtime() {
+    const int H = cfg.H, D = cfg.D;
+    x = dalloc<float>(H);
+    y = dalloc<float>(H);
+    qkv = dalloc<float>((size_t)(Hq_l + 2 * Hkv_l) * D);
+    attn = dalloc<float>((size_t)Hq_l * D);
+    hbuf = dalloc<float>(I_l);
+    logits = dalloc<float>((size_t)V_l * tp);
+    part_o = dalloc<float>((size_t)Hq_l * nsplit * D);
+    part_ml = dalloc<float>((size_t)Hq_l * nsplit * 2);
+    const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+    lm_grid = gemv_grid(v_eff, H, num_cu);
+    pmax = dalloc<float>((size_t)lm_grid * tp);
+    pidx = dalloc<int>((size_t)lm_grid * tp);
+    st = (StepState*)dalloc<int>(sizeof(StepState) / sizeof(int));
+    ring = (uint32_t*)dalloc<int>(RING);
+    CM_HIP(hipMemsetAsync(st, 0, sizeof(StepState), stream));
+    CM_HIP(hipHostMalloc((void**)&h_st, sizeof(StepState)));
+    CM_HIP(hipHostMalloc((void**)&h_ring, RING * sizeof(uint32_t)));
+    CM_HIP(hipHostMalloc((void**)&h_logits, (size_t)V_l * tp * sizeof(float)));
+    CM_HIP(hipHostMalloc((void**)&h_bt, (size_t)max_pages_per_seq * sizeof(int32_t)));
+    d_bt = dalloc<int>(max_pages_per_seq);
+    CM_HIP(hipMemsetAsync(d_bt, 0, (size_t)max_pages_per_seq * sizeof(int32_t), stream));
+
+    // KV pool
+    page_elems = (size_t)Hkv_l * page * D;
+    const size_t pool_elems = (size_t)cfg.L * 2 * n_pages * page_elems;
+    kv_pool = dalloc<uint16_t>(pool_elems);
+    free_pages.resize((size_t)n_pages);
+    for (int64_t i = 0; i < n_pages; ++i) free_pages[(size_t)i] = (int32_t)(n_pages - 1 - i);
+    page_ref.assign((size_t)n_pages, 0);
+
+    // RoPE tables exactly as RotaryEmbedding::new (modules/rotary.rs:29-46):
+    // inv_freq in f64 then cast to f32; freqs = pos(f32) * inv(f32); cos/sin in f32.
+    const int half = D / 2;
+    std::vector<float> inv(half), hc((size_t)max_seq * half), hs((size_t)max_seq * half);
+    for (int i = 0; i < half; ++i) inv[i] = (float)(1.0 / std::pow(cfg.theta, (double)(2 * i) / (double)D));
+    for (int p = 0; p < max_seq; ++p)
+        for (int i = 0; i < half; ++i) {
+            const float f = (float)p * inv[i];
+            hc[(size_t)p * half + i] = cosf(f);
+            hs[(size_t)p * half + i] = sinf(f);
+        }
+    cos = dalloc<float>(hc.size());
+    sin = dalloc<float>(hs.size());
+    CM_HIP(hipMemcpy(cos, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
+    CM_HIP(hipMemcpy(sin, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    if (tp > 1) {
+        rccl.reset(new Rccl());
+        rccl->init(tp, rank, opts.tp_unique_id, stream);
+    }
+    CM_HIP(hipStreamSynchronize(stream));
+}
+
+// ------------------------------------------------------------------------------------
+// paged KV allocator + sequences
+// ------------------------------------------------------------------------------------
+Seq& Model::seq(int s) {
+    if (s < 0 || s >= (int)seqs.size() || !seqs[(size_t)s].used) throw CmError(CM_ERR_INVALID, "invalid sequence handle");
+    return seqs[(size_t)s];
+}
+
+int Model::seq_alloc() {
+    for (size_t i = 1; i < seqs.size(); ++i)
+        if (!seqs[i].used) { seqs[i] = Seq(); seqs[i].used = true; return (int)i; }
+    throw CmError(CM_ERR_OOM, "no free sequence slot (raise cm_opts.max_seqs)");
+}
+
+void Model::seq_truncate(int s, size_t new_len) {
+    Seq& q = seq(s);
+    if ((int64_t)new_len > q.len) throw CmError(CM_ERR_RANGE, "truncate beyond cached length");
+    const size_t keep = (new_len + page - 1) / page;
+    while (q.pages.size() > keep) {
+        const int32_t p = q.pages.back();
+        q.pages.pop_back();
+        if (--page_ref[(size_t)p] == 0) free_pages.push_back(p);
+    }
+    q.len = (int64_t)new_len;
+    if (active_seq == s) active_pages_uploaded = std::min(active_pages_uploaded, q.pages.size());
+}
+
+void Model::seq_free(int s) {
+    if (s == 0) { seq_truncate(0, 0); return; }
+    seq_truncate(s, 0);
+    seqs[(size_t)s].used = false;
+    if (active_seq == s) active_seq = -1;
+}
+
+int Model::seq_fork(int src) {
+    Seq& a = seq(src);
+    const int d = seq_alloc();
+    Seq& b = seqs[(size_t)d];
+    b.len = a.len;
+    b.pages = a.pages;
+    for (int32_t p : b.pages) page_ref[(size_t)p]++;
+    // copy-on-write of the last, partially filled page: both forks will append into it
+    if (!b.pages.empty() && (a.len % page) != 0) {
+        if (free_pages.empty()) { seq_free(d); throw CmError(CM_ERR_OOM, "KV pool exhausted"); }
+        const int32_t oldp = b.pages.back();
+        const int32_t newp = free_pages.back();
+        free_pages.pop_back();
+        page_ref[(size_t)newp] = 1;
+        page_ref[(size_t)oldp]--;
+        b.pages.back() = newp;
+        const size_t pitch = (size_t)n_pages * page_elems * sizeof(uint16_t);
+        CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_elems, pitch, kv_pool + (size_t)oldp * page_elems, pitch,
+                                page_elems * sizeof(uint16_t), (size_t)cfg.L * 2, hipMemcpyDeviceToDevice, stream));
+    }
+    return d;
+}
+
+void Model::ensure_pages(int s, int64_t upto_len) {
+    Seq& q = seq(s);
+    if (upto_len > max_seq) throw CmError(CM_ERR_RANGE, "sequence longer than max_seq_len");
+    const size_t need = (size_t)((upto_len + page - 1) / page);
+    // a shared (forked) last page must not be appended into
+    while (q.pages.size() < need) {
+        if (free_pages.empty()) throw CmError(CM_ERR_OOM, "KV pool exhausted");
+        const int32_t p = free_pages.back();
+        free_pages.pop_back();
+        page_ref[(size_t)p] = 1;
+        q.pages.push_back(p);
+    }
+}
+
+void Model::activate(int s) {
+    Seq& q = seq(s);
+    if (active_seq != s) {
+        CM_HIP(hipStreamSynchronize(stream));    // pinned mirror is about to be rewritten
+        active_seq = s;
+        active_pages_uploaded = 0;
+    }
+    if (active_pages_uploaded < q.pages.size()) {
+        const size_t a = active_pages_uploaded, n = q.pages.size() - a;
+        memcpy(h_bt + a, q.pages.data() + a, n * sizeof(int32_t));
+        CM_HIP(hipMemcpyAsync(d_bt + a, h_bt + a, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        active_pages_uploaded = q.pages.size();
+    }
+}
+
+uint64_t Model::kv_bytes() const {
+    uint64_t pages_used = 0;
+    for (auto r : page_ref) if (r > 0) ++pages_used;
+    return pages_used * page_elems * sizeof(uint16_t) * 2ull * (uint64_t)cfg.L;
+}
+
+uint64_t Model::decode_bytes_per_token(size_t ctx) const {
+    // 2 B x every weight element once + KV read at ctx (this rank's shard)
+    const uint64_t H = cfg.H, D = cfg.D;
+    uint64_t per_layer = (uint64_t)(Hq_l + 2 * Hkv_l) * D * H + H * (uint64_t)Hq_l * D + 3ull * I_l * H + 2 * H +
+                         (cfg.qk_norm ? 2 * D : 0);
+    const uint64_t v_eff = (uint64_t)std::max(0, std::min(V_l, cfg.V - v0));
+    uint64_t params = per_layer * cfg.L + v_eff * H + H /*final norm*/ + H /*embedding row*/;
+    uint64_t kv = (uint64_t)cfg.L * 2 * Hkv_l * D * ctx * 2;
+    return params * 2 + kv;
+}
+
+// ------------------------------------------------------------------------------------
+// decode step
+// ------------------------------------------------------------------------------------
+void Model::enqueue_decode_step(bool advance) {
+    const int H = cfg.H, D = cfg.D;
+    hipStream_t s = stream;
+    launch_embed_row(embed, st, x, H, cfg.V, s);
+    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    for (int li = 0; li < cfg.L; ++li) {
+        const LayerW& w = layers[(size_t)li];
+        GemvArgs g{};
+        // (1) RMSNorm + merged QKV projection
+        g.W = w.qkv; g.x = x; g.nw = w.ln1; g.y = qkv; g.N = qkv_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
+        launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+        // (2) QK-norm + RoPE + KV append + paged split-KV attention
+        AttnDecArgs a{};
+        a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
+        a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
+        a.Hkv = Hkv_l; a.page = page; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+        if (!launch_attn_decode(a, nrep, nsplit, attn, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size");
+        // (3) o_proj + residual
+        g = GemvArgs{};
+        g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
+        if (tp == 1) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+        else {
+            g.y = y; g.res = x;
+            launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+            rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
+        }
+        // (4) RMSNorm + gate||up + SiLU*mul
+        g = GemvArgs{};
+        g.W = w.gate_up; g.x = x; g.nw = w.ln2; g.y = hbuf; g.N = 2 * I_l; g.K = H; g.ldw = H; g.eps = cfg.eps;
+        launch_gemv(PRO_RMSNORM, EPI_SILUMUL, g, gemv_grid(g.N, g.K, num_cu), s);
+        // (5) down_proj + residual
+        g = GemvArgs{};
+        g.W = w.down; g.x = hbuf; g.N = H; g.K = I_l; g.ldw = I_l;
+        if (tp == 1) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+        else {
+            g.y = y; g.res = x;
+            launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+            rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
+        }
+    }
+    // final norm + lm_head (last position only, modeling.rs:1024-1035) + arg-max
+    const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+    GemvArgs g{};
+    g.W = lm_head; g.x = x; g.nw = norm; g.y = logits + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H;
+    g.eps = cfg.eps; g.pmax = pmax + (size_t)rank * lm_grid; g.pidx = pidx + (size_t)rank * lm_grid; g.idx_base = v0;
+    launch_gemv(PRO_RMSNORM, EPI_ARGMAX, g, lm_grid, s);
+    if (tp > 1) {
+        rccl->all_gather(pmax + (size_t)rank * lm_grid, pmax, (size_t)lm_grid * sizeof(float), s);
+        rccl->all_gather(pidx + (size_t)rank * lm_grid, pidx, (size_t)lm_grid * sizeof(int), s);
+    }
+    launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, s);
+}
+
+void Model::run_decode_step(bool advance) {
+    (void)advance;   // the device state always advances; hosts that drive positions overwrite it
+    ++ring_count;    // host mirror of st->pad (ring write index)
+    if (use_graph && tp == 1) {
+        if (!graph_ok && graph == nullptr) {
+            hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed);
+            if (e == hipSuccess) {
+                bool threw = false;
+                try { enqueue_decode_step(true); } catch (...) { threw = true; }
+                e = hipStreamEndCapture(stream, &graph);
+                if (!threw && e == hipSuccess && graph) e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+                graph_ok = !threw && e == hipSuccess && graph_exec != nullptr;
+            }
+            if (!graph_ok) { use_graph = false; (void)hipGetLastError(); }
+        }
+        if (graph_ok) { CM_HIP(hipGraphLaunch(graph_exec, stream)); return; }
+    }
+    enqueue_decode_step(true);
+}
+
+void Model::fetch_logits(float* out) {
+    if (tp > 1) rccl->all_gather(logits + (size_t)rank * V_l, logits, (size_t)V_l * sizeof(float), stream);
+    CM_HIP(hipMemcpyAsync(h_logits, logits, (size_t)V_l * tp * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    memcpy(out, h_logits, (size_t)cfg.V * sizeof(float));
+}
+
+// ------------------------------------------------------------------------------------
+// forward_step (ModelBackend::forward_step, backend.rs:41; Model::forward_step model.rs:177-184)
+// ------------------------------------------------------------------------------------
+void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out, uint32_t* greedy_out) {
+    if (n == 0 || ids == nullptr) throw CmError(CM_ERR_INVALID, "empty input");
+    Seq& q = seq(s);
+    if ((int64_t)start_pos > q.len) throw CmError(CM_ERR_RANGE, "start_pos beyond cached length");
+    if (start_pos + n > (size_t)max_seq) throw CmError(CM_ERR_RANGE, "start_pos + n exceeds max_seq_len");
+    for (size_t i = 0; i < n; ++i)
+        if (ids[i] >= (uint32_t)cfg.V) throw CmError(CM_ERR_RANGE, "token id >= vocab_size");
+    if ((int64_t)start_pos < q.len) seq_truncate(s, start_pos);   // re-prefill over an old suffix
+    // appending into a page shared with a fork is not allowed: fork already copied the partial page
+    ensure_pages(s, (int64_t)(start_pos + n));
+    activate(s);
+    for (size_t i = 0; i < n; ++i) {
+        launch_set_state(st, ids[i], (int32_t)(start_pos + i), stream);
+        run_decode_step(true);
+    }
+    q.len = (int64_t)(start_pos + n);
+    if (greedy_out) {
+        CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
+        CM_HIP(hipStreamSynchronize(stream));
+        *greedy_out = h_st->next;
+    }
+    if (logits_out) fetch_logits(logits_out);
+    if (!greedy_out && !logits_out) CM_HIP(hipStreamSynchronize(stream));
+}
+
+// ------------------------------------------------------------------------------------
+// ModelForCausalLM::generate (based.rs:7-31; qwen3/model.rs:275-349)
+// ------------------------------------------------------------------------------------
+static bool is_eos(const cm_gen_config& g, uint32_t t) {
+    for (int i = 0; i < 4; ++i) if (g.eos_token_id[i] >= 0 && (uint32_t)g.eos_token_id[i] == t) return true;
+    return false;
+}
+
+void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_config* gc, uint32_t* out, size_t* n_out,
+                     cm_token_cb cb, void* user) {
+    if (!gc || !out || !n_out) throw CmError(CM_ERR_INVALID, "null argument");
+    if (n_prompt == 0) throw CmError(CM_ERR_INVALID, "empty prompt");
+    const cm_gen_config g = *gc;
+    if (g.temperature >= 0.f)
+        throw CmError(CM_ERR_UNSUPPORTED, "sampling (temperature >= 0) not implemented: greedy only (temperature < 0 == None)");
+    if (n_prompt + g.max_new_tokens > (size_t)max_seq) throw CmError(CM_ERR_RANGE, "prompt + max_new_tokens exceeds max_seq_len");
+    seq_truncate(0, 0);                                   // self.clear_kv_cache() (model.rs:281)
+    size_t n = n_prompt;
+    memcpy(out, prompt, n_prompt * sizeof(uint32_t));
+    *n_out = n;
+    if (g.max_new_tokens == 0) return;
+    const bool penalty = std::fabs(g.repetition_penalty - 1.0f) >= 1.1920929e-7f && g.repetition_penalty > 0.f;
+    std::vector<float> lg;
+    if (penalty) lg.resize((size_t)cfg.V);
+
+    auto host_pick = [&](std::vector<float>& l) -> uint32_t {
+        // candle_transformers::utils::apply_repeat_penalty over the last repeat_last_n tokens (model.rs:306-315)
+        const size_t start_at = n > g.repeat_last_n ? n - g.repeat_last_n : 0;
+        std::vector<uint32_t> seen;
+        for (size_t i = start_at; i < n; ++i) {
+            const uint32_t t = out[i];
+            if (t >= (uint32_t)cfg.V || std::find(seen.begin(), seen.end(), t) != seen.end()) continue;
+            seen.push_back(t);
+            l[t] = l[t] >= 0.f ? l[t] / g.repetition_penalty : l[t] * g.repetition_penalty;
+        }
+        uint32_t best = 0;
+        for (uint32_t i = 1; i < (uint32_t)cfg.V; ++i) if (l[i] > l[best]) best = i;   // first max
+        return best;
+    };
+
+    // step 0: whole prompt at start_pos 0 (model.rs:299-304)
+    uint32_t tok = 0;
+    if (penalty) { forward(0, prompt, n_prompt, 0, lg.data(), nullptr); tok = host_pick(lg); }
+    else forward(0, prompt, n_prompt, 0, nullptr, &tok);
+    size_t produced = 0;
+    bool stop = false;
+    auto emit = [&](uint32_t t) {
+        out[n++] = t; ++produced;
+        if (is_eos(g, t)) { stop = true; return; }          // EOS is pushed, then loop breaks (model.rs:318-327)
+        if (cb && cb(user, t) != 0) stop = true;
+    };
+    emit(tok);
+    if (penalty) {
+        while (!stop && produced < g.max_new_tokens) {
+            forward(0, &out[n - 1], 1, n - 1, lg.data(), nullptr);
+            emit(host_pick(lg));
+        }
+    } else {
+        // device-chained greedy decode: the arg-max kernel feeds the next step's token/pos in HBM
+        const size_t chunk = g.sync_every ? g.sync_every : 1;
+        Seq& q = seq(0);
+        while (!stop && produced < g.max_new_tokens) {
+            const size_t want = std::min(chunk, (size_t)g.max_new_tokens - produced);
+            ensure_pages(0, (int64_t)(q.len + (int64_t)want));
+            activate(0);
+            launch_set_state(st, out[n - 1], (int32_t)q.len, stream);
+            const uint32_t ring0 = ring_count;
+            for (size_t i = 0; i < want; ++i) run_decode_step(true);
+            CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            CM_HIP(hipStreamSynchronize(stream));
+            size_t used = 0;
+            for (size_t i = 0; i < want && !stop; ++i) { emit(h_ring[(ring0 + i) & (RING - 1)]); ++used; }
+            q.len += (int64_t)used;     // tokens decoded past an EOS/stop stay beyond len and are overwritten later
+        }
+    }
+    *n_out = n;
+}
+
+void Model::bench_decode(uint32_t first, size_t k, uint32_t* toks, float* ms) {
+    if (k == 0 || k > (size_t)RING) throw CmError(CM_ERR_INVALID, "k must be in 1..4096");
+    Seq& q = seq(0);
+    ensure_pages(0, q.len + (int64_t)k);
+    activate(0);
+    launch_set_state(st, first, (int32_t)q.len, stream);
+    const uint32_t ring0 = ring_count;
+    hipEvent_t e0, e1;
+    CM_HIP(hipEventCreate(&e0));
+    CM_HIP(hipEventCreate(&e1));
+    CM_HIP(hipEventRecord(e0, stream));
+    for (size_t i = 0; i < k; ++i) run_decode_step(true);
+    CM_HIP(hipEventRecord(e1, stream));
+    CM_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    CM_HIP(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms) *ms = t;
+    q.len += (int64_t)k;
+    if (toks) {
+        CM_HIP(hipMemcpy(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; ++i) toks[i] = h_ring[(ring0 + i) & (RING - 1)];
+    }
+}
+
+void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint64_t* bytes) {
+    if (iters == 0) throw CmError(CM_ERR_INVALID, "iters == 0");
+    const int H = cfg.H, D = cfg.D;
+    const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+    uint64_t b = 0;
+    auto one = [&](size_t i) {
+        const LayerW& w = layers[i % (size_t)cfg.L];
+        GemvArgs g{};
+        g.eps = cfg.eps;
+        if (which == "qkv") {
+            g.W = w.qkv; g.x = x; g.nw = w.ln1; g.y = qkv; g.N = (Hq_l + 2 * Hkv_l) * D; g.K = H; g.ldw = H;
+            launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), stream);
+        } else if (which == "o") {
+            g.W = w.o; g.x = attn; g.y = y; g.res = x; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
+            launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), stream);
+        } else if (which == "gate_up") {
+            g.W = w.gate_up; g.x = x; g.nw = w.ln2; g.y = hbuf; g.N = 2 * I_l; g.K = H; g.ldw = H;
+            launch_gemv(PRO_RMSNORM, EPI_SILUMUL, g, gemv_grid(g.N, g.K, num_cu), stream);
+        } else if (which == "down") {
+            g.W = w.down; g.x = hbuf; g.y = y; g.res = x; g.N = H; g.K = I_l; g.ldw = I_l;
+            launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), stream);
+        } else if (which == "lm_head") {
+            g.W = lm_head; g.x = x; g.nw = norm; g.y = logits + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H;
+            g.pmax = pmax + (size_t)rank * lm_grid; g.pidx = pidx + (size_t)rank * lm_grid; g.idx_base = v0;
+            launch_gemv(PRO_RMSNORM, EPI_ARGMAX, g, lm_grid, stream);
+        } else throw CmError(CM_ERR_INVALID, "unknown kernel name");
+        b = (uint64_t)g.N * g.K * 2 + (uint64_t)g.K * 4 + (g.nw ? (uint64_t)g.K * 2 : 0);
+    };
+    for (size_t i = 0; i < std::min<size_t>(iters, 8); ++i) one(i);      // warm-up
+    hipEvent_t e0, e1;
+    CM_HIP(hipEventCreate(&e0));
+    CM_HIP(hipEventCreate(&e1));
+    CM_HIP(hipEventRecord(e0, stream));
+    for (size_t i = 0; i < iters; ++i) one(i);
+    CM_HIP(hipEventRecord(e1, stream));
+    CM_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    CM_HIP(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (ms) *ms = t / (float)iters;
+    if (bytes) *bytes = b;
+}
+
+void Model::debug_fill_kv(size_t ctx, uint64_t seed) {
+    seq_truncate(0, 0);
+    ensure_pages(0, (int64_t)ctx);
+    activate(0);
+    Seq& q = seq(0);
+    for (int li = 0; li < cfg.L; ++li) {
+        launch_kv_fill(kpool(li), d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
+        launch_kv_fill(vpool(li), d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
+    }
+    CM_HIP(hipStreamSynchronize(stream));
+    q.len = (int64_t)ctx;
+}
+
+}  // namespace cm

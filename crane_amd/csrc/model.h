@@ -1,0 +1,155 @@
+// Host runtime of the MI355X inference path: model object, paged KV-cache allocator,
+// sequences, decode hipGraph, autoregressive loop.  Internal C++; the public surface is
+// include/crane_mi355.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/crane_mi355.h"
+#include "kernels.h"
+
+namespace cm {
+
+struct CmError : std::runtime_error {
+    int code;
+    CmError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define CM_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            throw cm::CmError(_e == hipErrorOutOfMemory ? CM_ERR_OOM : CM_ERR_DEVICE,         \
+                              std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+// config.json (qwen3/modeling.rs:94-130 and defaults)
+struct Config {
+    std::string model_type = "qwen3";
+    int V = 0, H = 0, I = 0, L = 0, Hq = 0, Hkv = 0, D = 0, max_pos = 0;
+    float eps = 1e-6f;
+    double theta = 1e6;
+    bool tie = true, qk_norm = true, attention_bias = false;
+    long long eos = -1;
+};
+
+struct LayerW {
+    uint16_t* qkv = nullptr;      // [(Hq_l + 2 Hkv_l) D, H]     merged (modeling.rs:187-204)
+    uint16_t* o = nullptr;        // [H, Hq_l D]                 K-slice of o_proj under TP
+    uint16_t* gate_up = nullptr;  // [2 I_l, H] rows interleaved gate_j, up_j
+    uint16_t* down = nullptr;     // [H, I_l]
+    uint16_t* ln1 = nullptr;      // [H]
+    uint16_t* ln2 = nullptr;
+    uint16_t* qn = nullptr;       // [D] or null
+    uint16_t* kn = nullptr;
+};
+
+struct Seq {
+    bool used = false;
+    int64_t len = 0;                 // cached tokens
+    std::vector<int32_t> pages;      // page ids, one per kv_block_size tokens
+};
+
+struct Rccl;   // dlopen'ed RCCL entry points + communicator (tp.cpp)
+
+struct Model {
+    Config cfg;
+    cm_opts opts{};
+    int dev = 0, num_cu = 256;
+    int tp = 1, rank = 0;
+    // local (per-rank) shard geometry
+    int Hq_l = 0, Hkv_l = 0, I_l = 0, V_l = 0, v0 = 0, kvh0 = 0, nrep = 1;
+    int page = 64, max_seq = 0, max_pages_per_seq = 0, nsplit = 32;
+    int64_t n_pages = 0;
+    hipStream_t stream = nullptr;
+
+    // weights
+    uint16_t* embed = nullptr;     // [V, H] replicated
+    uint16_t* lm_head = nullptr;   // [V_l, H] (points into embed when tied)
+    uint16_t* norm = nullptr;
+    std::vector<LayerW> layers;
+    float* cos = nullptr;
+    float* sin = nullptr;
+    uint64_t weight_bytes = 0;
+    std::vector<void*> allocs;
+
+    // paged KV pool: [L][2][n_pages][Hkv_l][page][D] bf16
+    uint16_t* kv_pool = nullptr;
+    size_t page_elems = 0;
+    std::vector<int32_t> free_pages;
+    std::vector<int32_t> page_ref;
+    std::vector<Seq> seqs;
+    int32_t* d_bt = nullptr;       // active block table on device [max_pages_per_seq]
+    int32_t* h_bt = nullptr;       // pinned mirror
+    int active_seq = -1;
+    size_t active_pages_uploaded = 0;
+
+    // decode scratch (f32)
+    float* x = nullptr;        // [H] residual stream
+    float* y = nullptr;        // [H] TP partial
+    float* qkv = nullptr;      // [(Hq_l+2Hkv_l) D]
+    float* attn = nullptr;     // [Hq_l D]
+    float* hbuf = nullptr;     // [I_l]
+    float* logits = nullptr;   // [V_l * tp] (gathered under TP)
+    float* part_o = nullptr;
+    float* part_ml = nullptr;
+    float* pmax = nullptr;
+    int* pidx = nullptr;
+    int lm_grid = 0;
+    StepState* st = nullptr;
+    uint32_t* ring = nullptr;          // device token ring
+    static constexpr int RING = 4096;
+    uint32_t ring_count = 0;           // host mirror of StepState.pad
+    StepState* h_st = nullptr;         // pinned
+    uint32_t* h_ring = nullptr;        // pinned
+    float* h_logits = nullptr;         // pinned [V]
+
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_ok = false;
+    bool use_graph = true;
+
+    std::unique_ptr<Rccl> rccl;
+    std::string err;
+
+    ~Model();
+
+    // ---- construction ----
+    void init_common(const std::string& config_json, const cm_opts* o);
+    void alloc_runtime();
+    template <typename T> T* dalloc(size_t n, bool count_weight = false);
+
+    // ---- kv / sequences ----
+    uint16_t* kpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 0) * n_pages * page_elems; }
+    uint16_t* vpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 1) * n_pages * page_elems; }
+    int seq_alloc();
+    void seq_free(int s);
+    int seq_fork(int src);
+    void seq_truncate(int s, size_t new_len);
+    void ensure_pages(int s, int64_t upto_len);
+    void activate(int s);
+    Seq& seq(int s);
+    uint64_t kv_bytes() const;
+
+    // ---- forward ----
+    void enqueue_decode_step(bool advance);     // one token from st->token at st->pos
+    void run_decode_step(bool advance);         // graph replay or eager
+    void forward(int s, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out, uint32_t* greedy_out);
+    void generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_config* g, uint32_t* out, size_t* n_out,
+                  cm_token_cb cb, void* user);
+    void bench_decode(uint32_t first, size_t k, uint32_t* toks, float* ms);
+    void debug_fill_kv(size_t ctx, uint64_t seed);
+    void bench_kernel(const std::string& which, size_t iters, float* ms, uint64_t* bytes);
+    uint64_t decode_bytes_per_token(size_t ctx) const;
+    void fetch_logits(float* out);
+};
+
+// loaders (loader.cpp)
+void load_from_dir(Model& m, const std::string& dir);
+void load_synthetic(Model& m, uint64_t seed);
+
+}  // namespace cm

@@ -1,0 +1,206 @@
+/*
+ * crane_mi355.h -- C ABI of the MI355X-native transformer inference path.
+ *
+ * Drop-in boundary for lucasjinreal/Crane's model hot path.  Each entry point
+ * replaces one method of the two Rust traits the reference routes every token
+ * through (citations are into the reference tree):
+ *
+ *   B1  trait ModelForCausalLM      crane-core/src/generation/based.rs:5-34
+ *   B2  trait ModelBackend          crane-serve/src/engine/backend.rs:30-147
+ *
+ * and the inherent methods of crane-core/src/models/qwen3/model.rs:45-349
+ * (qwen3_5/model.rs twin).  The reference exports no extern "C" host API
+ * today; INTEGRATION.md shows the `impl ModelBackend for Mi355Backend` shim a
+ * maintainer adds on the Rust side (bindgen/`extern "C"` block) -- it is
+ * 1:1 with this header.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every output buffer;
+ *   - every function returns CM_OK (0) or a negative cm_status; the message
+ *     for the last failure on a handle is cm_last_error(handle) (maps to
+ *     anyhow!(..) on the Rust side); creation failures use
+ *     cm_last_global_error();
+ *   - a cm_model is NOT thread-safe (matches `&mut self`); it may be moved
+ *     between threads (matches `Send`); N handles = N replicas, no globals;
+ *   - the library owns device weights, the paged KV-cache pool, the
+ *     autoregressive loop and the sampler; tokenizer / chat template stay on
+ *     the caller's side (B2 tokenizer()/eos_token_id()).
+ */
+#ifndef CRANE_MI355_H
+#define CRANE_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CM_ABI_VERSION 1
+
+typedef enum cm_status {
+    CM_OK = 0,
+    CM_ERR_INVALID = -1,      /* bad argument / shape / state                 */
+    CM_ERR_IO = -2,           /* model dir / config / safetensors problem     */
+    CM_ERR_UNSUPPORTED = -3,  /* architecture or option not implemented       */
+    CM_ERR_DEVICE = -4,       /* HIP / RCCL runtime error                     */
+    CM_ERR_OOM = -5,          /* KV pool or HBM exhausted                     */
+    CM_ERR_RANGE = -6         /* position / token id out of range             */
+} cm_status;
+
+typedef enum cm_kv_dtype { CM_KV_BF16 = 0, CM_KV_F32 = 1 } cm_kv_dtype;
+
+/* Options of Model::new / select_device / create_backend
+ * (qwen3/model.rs:45-106, crane-serve/src/lib.rs:432-499,
+ *  crane-serve/src/engine/model_factory.rs:471-586).  Zero-initialise and set
+ * what you need: 0 always means "default". */
+typedef struct cm_opts {
+    uint32_t abi_version;      /* CM_ABI_VERSION                                     */
+    int32_t  device;           /* HIP device ordinal of THIS rank (default 0)        */
+    int32_t  tp_rank;          /* tensor-parallel rank   (default 0)                 */
+    int32_t  tp_size;          /* tensor-parallel degree (default 1)                 */
+    const void* tp_unique_id;  /* 128-byte id from cm_tp_unique_id(), same on all ranks */
+    uint32_t max_seq_len;      /* longest sequence (0: min(max_position_embeddings, 32768)) */
+    uint32_t max_seqs;         /* concurrently allocated sequences (default 8)       */
+    uint32_t kv_block_size;    /* tokens per KV page (default 64)                    */
+    uint64_t kv_pool_tokens;   /* pool capacity in tokens (0: max_seqs*max_seq_len)  */
+    int32_t  kv_dtype;         /* cm_kv_dtype                                        */
+    int32_t  use_graph;        /* 0 default(on), 1 on, -1 off: hipGraph decode step  */
+    uint32_t prefill_chunk;    /* tokens per prefill chunk (default 2048,            */
+                               /*   PREFILL_CHUNK_SIZE engine/mod.rs:65)             */
+    int32_t  prefill_split;    /* activation split terms for MFMA GEMMs: 0/2 = bf16x2 (parity), 1 = bf16 */
+    uint32_t reserved[8];
+} cm_opts;
+
+typedef struct cm_model cm_model;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Model::new / from_pretrained (qwen3/model.rs:45-106): reads config.json and
+ * every *.safetensors (sharded index honoured, utils/utils.rs:16-57) from
+ * `model_dir`, merges QKV and gate||up at load (modeling.rs:187-204,582-588),
+ * ties lm_head to the embedding when the config says so (modeling.rs:786-794). */
+int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out);
+
+/* Same model object from a config.json *string* with deterministic synthetic
+ * bf16 weights generated on the device (crane_amd/synth.py documents the
+ * generator; used by the benchmarks -- there is no network for checkpoints). */
+int cm_create_synthetic(const char* config_json, uint64_t seed, const cm_opts* opts, cm_model** out);
+
+void cm_destroy(cm_model* m);
+
+const char* cm_last_error(const cm_model* m);
+const char* cm_last_global_error(void);
+
+/* 128-byte RCCL unique id for opts.tp_unique_id (rank 0 creates, the caller
+ * broadcasts it, e.g. over torch.distributed / the engine's own channel). */
+int cm_tp_unique_id(void* out128);
+
+/* ---- introspection (ModelBackend::num_layers/dtype/..., backend.rs:47-60) --- */
+size_t cm_num_layers(const cm_model* m);
+size_t cm_vocab_size(const cm_model* m);
+size_t cm_hidden_size(const cm_model* m);
+size_t cm_max_seq_len(const cm_model* m);
+/* active_kv_cache_bytes (backend.rs:83-87, qwen3/model.rs:201) */
+uint64_t cm_kv_bytes(const cm_model* m);
+/* bytes of weights resident in HBM on this rank */
+uint64_t cm_weight_bytes(const cm_model* m);
+/* algorithmic HBM bytes one decode step reads at context `ctx` on this rank
+ * (SURVEY.md section 8(d) formula; used by bench.py's roofline object) */
+uint64_t cm_decode_bytes_per_token(const cm_model* m, size_t ctx);
+
+/* ---- single-sequence path (the implicit sequence of B1/B2) ----------------- */
+
+/* ModelBackend::forward_step / Model::forward_step (backend.rs:41,
+ * qwen3/model.rs:177-184).  Processes `n` tokens at KV position `start_pos`
+ * (n > 1: chunked MFMA prefill; n == 1: decode step) and writes the logits of
+ * the LAST position only -- that is all the reference ever produces
+ * (modeling.rs:1032-1035) -- as `vocab` f32 values to host buffer `logits_out`. */
+int cm_forward_step(cm_model* m, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out);
+
+/* Engine greedy fast path (engine/sampling.rs:191-210 + gpu_argmax,
+ * kernels/cuda/fused_ops.cu:251-382): same forward, device arg-max
+ * (lowest index wins ties), 4-byte result. */
+int cm_forward_step_greedy(cm_model* m, const uint32_t* ids, size_t n, size_t start_pos, uint32_t* token_out);
+
+/* ModelBackend::clear_kv_cache (backend.rs:44) */
+void cm_clear_kv(cm_model* m);
+
+/* ModelBackend::warmup (backend.rs:60; qwen3/model.rs:261-267:
+ * generate(&[45,546,456], 5 tokens) then clear). */
+int cm_warmup(cm_model* m);
+
+/* ---- generation loop (B1) --------------------------------------------------- */
+
+/* GenerationConfig (generation/mod.rs:62-99).  temperature < 0 means None
+ * (greedy arg-max: qwen3/model.rs:284); sampling with temperature >= 0 is
+ * "next" tier (device sampler) and returns CM_ERR_UNSUPPORTED for now. */
+typedef struct cm_gen_config {
+    uint32_t max_new_tokens;
+    float    temperature;        /* < 0 : None */
+    float    top_p;              /* < 0 : None */
+    float    repetition_penalty; /* 1.0 : off (model.rs:306-315) */
+    uint32_t repeat_last_n;
+    int64_t  eos_token_id[4];    /* -1 : unused slot (multi-id EOS: qwen3_5/model.rs:871-877) */
+    uint32_t sync_every;         /* greedy w/o penalty: tokens enqueued per host sync (0: 1) */
+    uint32_t reserved[7];
+} cm_gen_config;
+
+/* TokenStreamer::append (generation/streamer.rs:7-10); return non-zero to stop. */
+typedef int (*cm_token_cb)(void* user, uint32_t token);
+
+/* ModelForCausalLM::generate (based.rs:7-31, qwen3/model.rs:275-349): clears
+ * the KV cache, feeds the whole prompt at start_pos 0, then one token per
+ * step; returns prompt ++ generated in `tokens_out` (capacity >= n_prompt +
+ * max_new_tokens); `*n_out` = total length. */
+int cm_generate(cm_model* m, const uint32_t* prompt, size_t n_prompt, const cm_gen_config* cfg,
+                uint32_t* tokens_out, size_t* n_out, cm_token_cb cb, void* user);
+
+/* ---- paged-KV sequences (replaces get/set_kv_caches + pad/stack/extract:
+ *      backend.rs:66-147, qwen3/modeling.rs:1094-1378) ------------------------- */
+
+/* Sequence 0 always exists: it is the implicit sequence of cm_forward_step. */
+int cm_seq_alloc(cm_model* m, int32_t* seq_out);
+int cm_seq_free(cm_model* m, int32_t seq);
+/* share the prefix pages of `src` (copy-on-write of the last partial page) */
+int cm_seq_fork(cm_model* m, int32_t src, int32_t* seq_out);
+/* tokens currently cached for `seq` (cache_seq_len, modeling.rs:1121-1127) */
+int64_t cm_seq_len(const cm_model* m, int32_t seq);
+/* drop cached tokens beyond `new_len` (preemption / re-prefill, engine/mod.rs:430-504) */
+int cm_seq_truncate(cm_model* m, int32_t seq, size_t new_len);
+
+/* forward_step on an explicit sequence */
+int cm_seq_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos,
+                   float* logits_out /* [vocab] or NULL */, uint32_t* greedy_out /* or NULL */);
+
+/* step_batch_decode (backend.rs:107-121, modeling.rs:1202-1234): one token
+ * for each of `n` sequences at their own positions, no padding, no mask.
+ * logits_out [n, vocab] (or NULL), greedy_out [n] (or NULL). */
+int cm_decode_batch(cm_model* m, const int32_t* seqs, const uint32_t* last_tokens, size_t n,
+                    float* logits_out, uint32_t* greedy_out);
+
+/* ---- measurement hooks (bench.py / tests) ----------------------------------- */
+
+/* Enqueue `k` greedy decode steps for sequence 0 starting from its current
+ * last token, timing the region with HIP events on the model's own stream.
+ * Returns tokens in `tokens_out[k]`, total milliseconds in *ms_out. */
+int cm_bench_decode(cm_model* m, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out);
+
+/* Launch one hot-path kernel `iters` times back to back, cycling over the layers so every
+ * launch streams different weights from HBM (no L2 / Infinity-Cache reuse), timed with HIP
+ * events on the model's stream.  which: "qkv" | "o" | "gate_up" | "down" | "lm_head".
+ * *ms_out = average milliseconds per launch, *bytes_out = algorithmic bytes per launch. */
+int cm_bench_kernel(cm_model* m, const char* which, size_t iters, float* ms_out, uint64_t* bytes_out);
+
+/* Fill sequence 0's KV cache with deterministic synthetic K/V up to `ctx`
+ * tokens without running prefill (bench set-up only). */
+int cm_debug_fill_kv(cm_model* m, size_t ctx, uint64_t seed);
+
+/* Copy an internal device buffer to host for kernel-level parity tests.
+ * what: "hidden" (f32 [H] residual after the last forward), "logits". */
+int cm_debug_read(cm_model* m, const char* what, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRANE_MI355_H */
