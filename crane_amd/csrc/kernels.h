@@ -31,11 +31,11 @@ struct AttnDecArgs {
     const float* sin;
     const StepState* st;
     const int32_t* block_table;  // [max_pages_per_seq]
-    uint16_t* kpool;             // this layer: [pages][Hkv][PAGE][D] bf16
-    uint16_t* vpool;
+    void* kpool;                 // this layer: [pages][Hkv][PAGE][D] bf16 (or f32)
+    void* vpool;
     float* part_o;               // [Hq][nsplit][D]
     float* part_ml;              // [Hq][nsplit][2]
-    int Hkv, page;
+    int Hkv, page, max_pages;
     float eps, scale;
 };
 
@@ -47,13 +47,13 @@ void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H,
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, hipStream_t s);
-bool launch_attn_decode(const AttnDecArgs& a, int nrep, int nsplit, float* out, hipStream_t s);
+bool launch_attn_decode(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s);
 
 // ---- synthetic weights / utility ----
 // dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))
 void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncols, int row0, int col0,
                        int full_cols, uint32_t tseed, float mul, float off, hipStream_t s);
-void launch_kv_fill(uint16_t* pool, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
+void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s);
 
 }  // namespace cm

@@ -24,8 +24,9 @@ void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncol
                        row0, col0, full_cols, tseed, mul, off);
 }
 
-// pool: [n_pages][page_elems]; fill the listed pages with N(0,1)-like bf16 values
-__global__ void kv_fill_kernel(uint16_t* __restrict__ pool, const int32_t* __restrict__ pages, int npages,
+// pool: [n_pages][page_elems]; fill the listed pages with N(0,1)-like bf16-representable values
+template <typename T>
+__global__ void kv_fill_kernel(T* __restrict__ pool, const int32_t* __restrict__ pages, int npages,
                                size_t page_elems, uint32_t tseed) {
     const size_t total = (size_t)npages * page_elems;
     const float mul = 1.0f / 147.80054f;
@@ -33,16 +34,19 @@ __global__ void kv_fill_kernel(uint16_t* __restrict__ pool, const int32_t* __res
          i += (size_t)gridDim.x * blockDim.x) {
         const int p = (int)(i / page_elems);
         const size_t e = i % page_elems;
-        pool[(size_t)pages[p] * page_elems + e] = f32_to_bf16(synth_val((uint32_t)i, tseed, mul, 0.f));
+        const uint16_t b = f32_to_bf16(synth_val((uint32_t)i, tseed, mul, 0.f));
+        if constexpr (sizeof(T) == 2) pool[(size_t)pages[p] * page_elems + e] = b;
+        else pool[(size_t)pages[p] * page_elems + e] = bf16_to_f32(b);
     }
 }
 
-void launch_kv_fill(uint16_t* pool, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
+void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s) {
     const size_t total = (size_t)npages * page_elems;
     int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kv_fill_kernel, dim3(blocks), dim3(256), 0, s, pool, pages, npages, page_elems, tseed);
+    if (f32) hipLaunchKernelGGL(kv_fill_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)pool, pages, npages, page_elems, tseed);
+    else hipLaunchKernelGGL(kv_fill_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed);
 }
 
 }  // namespace cm

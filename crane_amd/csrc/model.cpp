@@ -116,7 +116,9 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (n_pages < max_pages_per_seq) n_pages = max_pages_per_seq;
     nsplit = std::max(1, std::min(64, num_cu / std::max(1, Hkv_l)));
     use_graph = opts.use_graph >= 0;
-    if (opts.kv_dtype != CM_KV_BF16) throw CmError(CM_ERR_UNSUPPORTED, "kv_dtype f32 not implemented yet");
+    if (opts.kv_dtype != CM_KV_BF16 && opts.kv_dtype != CM_KV_F32) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
+    kv_f32 = opts.kv_dtype == CM_KV_F32;
+    kv_esize = kv_f32 ? 4 : 2;
     seqs.resize((size_t)max_seqs + 1);
     seqs[0].used = true;
 }
@@ -148,7 +150,7 @@ void Model::alloc_runtime() {
     // KV pool
     page_elems = (size_t)Hkv_l * page * D;
     const size_t pool_elems = (size_t)cfg.L * 2 * n_pages * page_elems;
-    kv_pool = dalloc<uint16_t>(pool_elems);
+    kv_pool = (uint8_t*)dalloc<uint16_t>(pool_elems * (kv_esize / 2));
     free_pages.resize((size_t)n_pages);
     for (int64_t i = 0; i < n_pages; ++i) free_pages[(size_t)i] = (int32_t)(n_pages - 1 - i);
     page_ref.assign((size_t)n_pages, 0);
@@ -226,9 +228,9 @@ int Model::seq_fork(int src) {
         page_ref[(size_t)newp] = 1;
         page_ref[(size_t)oldp]--;
         b.pages.back() = newp;
-        const size_t pitch = (size_t)n_pages * page_elems * sizeof(uint16_t);
-        CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_elems, pitch, kv_pool + (size_t)oldp * page_elems, pitch,
-                                page_elems * sizeof(uint16_t), (size_t)cfg.L * 2, hipMemcpyDeviceToDevice, stream));
+        const size_t pitch = (size_t)n_pages * page_elems * kv_esize;
+        CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_elems * kv_esize, pitch, kv_pool + (size_t)oldp * page_elems * kv_esize, pitch,
+                                page_elems * kv_esize, (size_t)cfg.L * 2, hipMemcpyDeviceToDevice, stream));
     }
     return d;
 }
@@ -265,7 +267,7 @@ void Model::activate(int s) {
 uint64_t Model::kv_bytes() const {
     uint64_t pages_used = 0;
     for (auto r : page_ref) if (r > 0) ++pages_used;
-    return pages_used * page_elems * sizeof(uint16_t) * 2ull * (uint64_t)cfg.L;
+    return pages_used * page_elems * kv_esize * 2ull * (uint64_t)cfg.L;
 }
 
 uint64_t Model::decode_bytes_per_token(size_t ctx) const {
@@ -275,7 +277,7 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
                          (cfg.qk_norm ? 2 * D : 0);
     const uint64_t v_eff = (uint64_t)std::max(0, std::min(V_l, cfg.V - v0));
     uint64_t params = per_layer * cfg.L + v_eff * H + H /*final norm*/ + H /*embedding row*/;
-    uint64_t kv = (uint64_t)cfg.L * 2 * Hkv_l * D * ctx * 2;
+    uint64_t kv = (uint64_t)cfg.L * 2 * Hkv_l * D * ctx * kv_esize;
     return params * 2 + kv;
 }
 
@@ -297,8 +299,8 @@ void Model::enqueue_decode_step(bool advance) {
         AttnDecArgs a{};
         a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
         a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
-        a.Hkv = Hkv_l; a.page = page; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-        if (!launch_attn_decode(a, nrep, nsplit, attn, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size");
+        a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+        if (!launch_attn_decode(a, nrep, nsplit, kv_f32, attn, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size");
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
@@ -544,8 +546,8 @@ void Model::debug_fill_kv(size_t ctx, uint64_t seed) {
     activate(0);
     Seq& q = seq(0);
     for (int li = 0; li < cfg.L; ++li) {
-        launch_kv_fill(kpool(li), d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
-        launch_kv_fill(vpool(li), d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
+        launch_kv_fill(kpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
+        launch_kv_fill(vpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
     }
     CM_HIP(hipStreamSynchronize(stream));
     q.len = (int64_t)ctx;

@@ -77,9 +77,11 @@ struct Model {
     uint64_t weight_bytes = 0;
     std::vector<void*> allocs;
 
-    // paged KV pool: [L][2][n_pages][Hkv_l][page][D] bf16
-    uint16_t* kv_pool = nullptr;
+    // paged KV pool: [L][2][n_pages][Hkv_l][page][D] bf16 (or f32: cm_opts.kv_dtype)
+    uint8_t* kv_pool = nullptr;
     size_t page_elems = 0;
+    size_t kv_esize = 2;
+    bool kv_f32 = false;
     std::vector<int32_t> free_pages;
     std::vector<int32_t> page_ref;
     std::vector<Seq> seqs;
@@ -124,8 +126,8 @@ struct Model {
     template <typename T> T* dalloc(size_t n, bool count_weight = false);
 
     // ---- kv / sequences ----
-    uint16_t* kpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 0) * n_pages * page_elems; }
-    uint16_t* vpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 1) * n_pages * page_elems; }
+    void* kpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 0) * n_pages * page_elems * kv_esize; }
+    void* vpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 1) * n_pages * page_elems * kv_esize; }
     int seq_alloc();
     void seq_free(int s);
     int seq_fork(int src);

@@ -1,0 +1,93 @@
+"""ctypes wrapper of oracle/c/libqwen3_cpu.so (TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py).
+
+``time_decode`` is bench.py's ``cpu_baseline`` leg: the C port of the reference's CPU decode
+path (kind "port": the reference itself needs a Rust toolchain + candle 0.11, both absent) timed
+on the host cores for a bounded number of decode steps of the SAME workload.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "c", "libqwen3_cpu.so")
+
+
+class QcCfg(C.Structure):
+    _fields_ = [("V", C.c_int), ("H", C.c_int), ("I", C.c_int), ("L", C.c_int), ("Hq", C.c_int),
+                ("Hkv", C.c_int), ("D", C.c_int), ("max_seq", C.c_int), ("eps", C.c_float),
+                ("theta", C.c_double), ("tie", C.c_int), ("qk_norm", C.c_int), ("kv_bf16", C.c_int)]
+
+
+def _lib():
+    lib = C.CDLL(SO)
+    lib.qc_create.argtypes = [C.POINTER(QcCfg), C.c_uint64]
+    lib.qc_create.restype = C.c_void_p
+    lib.qc_destroy.argtypes = [C.c_void_p]
+    lib.qc_forward.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.qc_fill_kv.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    lib.qc_num_threads.restype = C.c_int
+    return lib
+
+
+class CQwen3:
+    def __init__(self, cfg: dict, seed: int = 0, max_seq: int = 2048, kv_bf16: bool = False):
+        self.lib = _lib()
+        D = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
+        c = QcCfg(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"],
+                  cfg["num_attention_heads"], cfg["num_key_value_heads"], D, max_seq,
+                  cfg.get("rms_norm_eps", 1e-6), cfg.get("rope_theta", 1e6),
+                  int(cfg.get("tie_word_embeddings", True)), int(cfg.get("use_qk_norm", True)), int(kv_bf16))
+        self.V = cfg["vocab_size"]
+        self.h = self.lib.qc_create(C.byref(c), seed)
+
+    def forward(self, ids, start_pos: int) -> np.ndarray:
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32))
+        out = np.empty(self.V, dtype=np.float32)
+        rc = self.lib.qc_forward(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size, start_pos,
+                                 out.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != 0:
+            raise RuntimeError(f"qc_forward failed: {rc}")
+        return out
+
+    def fill_kv(self, ctx: int, seed: int = 1):
+        self.lib.qc_fill_kv(self.h, ctx, seed)
+
+    def threads(self) -> int:
+        return int(self.lib.qc_num_threads())
+
+    def close(self):
+        if self.h:
+            self.lib.qc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def time_decode(model_name: str, ctx: int, budget_s: float = 20.0) -> dict:
+    from crane_amd import configs
+    cfg = configs.get_config(model_name)
+    t0 = time.perf_counter()
+    m = CQwen3(cfg, seed=0, max_seq=ctx + 64, kv_bf16=True)
+    t_build = time.perf_counter() - t0
+    m.fill_kv(ctx, 1)
+    tok, n, dt = 3, 0, 0.0
+    m.forward([tok], ctx)                      # untimed warm-up step (page-in)
+    while n < 32 and dt < budget_s:
+        t1 = time.perf_counter()
+        lg = m.forward([tok], ctx + 1 + n)
+        dt += time.perf_counter() - t1
+        tok = int(lg.argmax())
+        n += 1
+    thr = m.threads()
+    m.close()
+    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": thr, "kind": "port",
+            "sample": f"{n} greedy decode steps of {model_name} at context {ctx} (bf16-stored weights, f32 compute, "
+                      f"OpenMP over {thr} host threads; weight synthesis {t_build:.1f}s excluded)"}

@@ -1,0 +1,37 @@
+"""The C port (oracle/c) and the numpy oracle are independent restatements; they must agree."""
+import os
+
+import numpy as np
+import pytest
+
+from crane_amd import configs, synth
+from oracle import c_oracle
+from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+
+pytestmark = pytest.mark.skipif(not os.path.exists(c_oracle.SO), reason="oracle/c not built (run __graft_entry__.build())")
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
+def test_c_port_matches_numpy_oracle(name):
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, 0)
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w)
+    c = c_oracle.CQwen3(cfg, seed=0, max_seq=128)
+    ids = configs.synthetic_prompt(11, cfg["vocab_size"])
+    a, b = o.forward(ids, 0), c.forward(ids, 0)
+    assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
+    a, b = o.forward([7], 11), c.forward([7], 11)
+    assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
+    assert int(a.argmax()) == int(b.argmax())
+    c.close()
+
+
+def test_c_port_kv_rounding_mode():
+    cfg = configs.get_config("tiny-qwen3")
+    w = synth.synth_weights_f32(cfg, 0)
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    c = c_oracle.CQwen3(cfg, seed=0, max_seq=64, kv_bf16=True)
+    ids = configs.synthetic_prompt(9, cfg["vocab_size"])
+    a, b = o.forward(ids, 0), c.forward(ids, 0)
+    assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
+    c.close()

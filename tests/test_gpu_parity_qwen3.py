@@ -14,8 +14,10 @@ from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
 
 pytestmark = pytest.mark.gpu
 
-REL_F32 = 1e-3      # vs pure-f32 reference forward (north_star)
-REL_SAME = 2e-4     # vs oracle with identical KV rounding
+REL_SAME = 2e-4     # vs the oracle with the same KV rounding (bf16 cache = model dtype, kv_cache.rs:38-101)
+REL_F32 = 4e-3      # bf16-KV path vs the pure-f32 CPU forward: one bf16 epsilon (2^-8).  A 1-token
+                    # context returns bf16(v) exactly, i.e. up to 2^-9 relative on every element;
+                    # the 1e-3 north-star bar is asserted on the f32-KV configuration below.
 
 
 def rel(a, ref):
@@ -46,6 +48,22 @@ def test_decode_logits_match_oracle(pair):
         assert rel(got[0, 0], a) < REL_SAME, (pos, rel(got[0, 0], a))
         assert rel(got[0, 0], b) < REL_F32, (pos, rel(got[0, 0], b))
         assert int(got[0, 0].argmax()) == int(b.argmax())
+
+
+def test_f32_kv_meets_north_star_bar():
+    """kv_dtype=f32: logits within 1e-3 relative of the pure-f32 CPU forward (measured ~1e-6)."""
+    cfg = configs.get_config("tiny-qwen3-untied")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
+    try:
+        ids = configs.synthetic_prompt(20, cfg["vocab_size"])
+        worst = 0.0
+        for pos, t in enumerate(ids):
+            worst = max(worst, rel(m.forward_step([t], pos)[0, 0], o.forward([t], pos)))
+        assert worst < 1e-4, worst
+    finally:
+        m.close()
 
 
 def test_prompt_forward_and_greedy(pair):
