@@ -125,6 +125,19 @@ def main():
                  "frac": round(step_gbs / HBM_PEAK_GBS, 4), "bytes_per_token_per_gpu": bytes_tok_rank,
                  "event_ms_per_step": round(ev_ms / K, 4)}
 
+    # prefill throughput (second half of BASELINE.json's metric): one 1024-token prompt, MFMA path
+    prefill = None
+    try:
+        import numpy as np
+        ids = configs.synthetic_prompt(1024, cfg["vocab_size"])
+        m.clear_kv_cache(); m.forward_step_greedy(ids, 0)            # warm-up (allocates chunk buffers)
+        m.clear_kv_cache()
+        tp0 = time.perf_counter(); m.forward_step_greedy(ids, 0); tp1 = time.perf_counter()
+        prefill = {"tokens": 1024, "ms": round((tp1 - tp0) * 1e3, 3), "tokens_per_s": round(1024 / (tp1 - tp0), 1),
+                   "activations": "bf16x2 split (parity mode)"}
+    except Exception as e:
+        prefill = {"error": str(e)}
+
     cpu = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.model, ctx)
@@ -140,7 +153,7 @@ def main():
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
                                    f"bf16 weights + bf16 paged KV, f32 activations",
                        "parallelism": f"tp{n}", "graph": not args.no_graph},
-            "roofline": roof, "roofline_step": roof_step, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     m.close()

@@ -39,6 +39,53 @@ struct AttnDecArgs {
     float eps, scale;
 };
 
+// ---- prefill (S > 1) ----
+enum { GEPI_STORE = 0, GEPI_RESADD = 1, GEPI_SILUMUL = 2 };
+
+struct GemmArgs {
+    const uint16_t* A_hi;   // [Mpad, K] bf16 activations (hi term)
+    const uint16_t* A_lo;   // [Mpad, K] lo term or null (plain bf16 activations)
+    const uint16_t* W;      // [N, K] bf16
+    float* C;               // GEPI_STORE: C[m*ldc+n] = acc; GEPI_RESADD: C[m*ldc+n] += acc
+    uint16_t* H_hi;         // GEPI_SILUMUL: [M, N/2] bf16 hi (+lo) of silu(gate)*up
+    uint16_t* H_lo;
+    int M, N, K, ldc;
+};
+
+struct QkRopeArgs {
+    const float* qkv;            // [S, (Hq + 2 Hkv) D] f32
+    const uint16_t* qnw;
+    const uint16_t* knw;
+    const float* cos;
+    const float* sin;
+    const int32_t* block_table;
+    void* kpool;
+    void* vpool;
+    uint16_t* q_hi;              // [Spad, Hq, D] bf16, scaled by 1/sqrt(D)
+    uint16_t* q_lo;
+    int Hq, Hkv, page, start_pos;
+    float eps, scale;
+};
+
+struct AttnPreArgs {
+    const uint16_t* q_hi;
+    const uint16_t* q_lo;
+    const int32_t* block_table;
+    const void* kpool;
+    const void* vpool;
+    uint16_t* out_hi;            // [Spad, Hq * D] bf16 hi (+lo) -> A operand of the o_proj GEMM
+    uint16_t* out_lo;
+    int S, Hq, Hkv, nrep, page, start_pos;
+};
+
+void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
+void launch_rmsnorm_rows(const float* x, const uint16_t* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
+                         hipStream_t s);
+void launch_qknorm_rope_kv(const QkRopeArgs& a, int S, bool kv_f32, hipStream_t s);
+void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
+bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+void launch_attn_prefill(const AttnPreArgs& a, bool kv_f32, hipStream_t s);
+
 // ---- decode ----
 int gemv_rows_per_group(int K);
 int gemv_grid(int N, int K, int num_cu);

@@ -1,1 +1,413 @@
+// Prefill (S > 1) kernels for gfx950: MFMA-bound.
+//
+// Replaces the S>1 branch of Qwen3Model::decode (reference qwen3/modeling.rs:984-1036): candle
+// GEMMs + an O(S*L) materialised score matrix with an additive -1e9 mask (modeling.rs:493-532,
+// 1000-1017), or the CPU flash_attn path (modeling.rs:422-456).  Here:
+//   * every projection is one bf16 MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  with f32 accumulate;
+//     the ACTIVATION operand is carried as a 2-term bf16 split (hi = bf16(x), lo = bf16(x-hi)),
+//     so activations keep ~16 mantissa bits and logits stay within the 1e-3 parity bar
+//     against the f32 CPU reference (plain bf16 activations measure 1.7e-3 on 12 layers);
+//     cm_opts.prefill_split = 1 selects plain bf16 (half the MFMA work);
+//   * attention is a causal flash kernel over the paged KV cache: S^T = K.Q^T
+//     (mfma 16x16x32), online softmax with lane-local row statistics, O^T = V^T.P^T
+//     (mfma 16x16x16, V fragments through ds_read_b64_tr_b16), nothing O(S*L) in HBM.
+#include "dev_common.h"
 #include "kernels.h"
+
+namespace cm {
+
+// ---------------------------------------------------------------------------------------------
+// small row kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_rows_kernel(const uint16_t* __restrict__ emb, const uint32_t* __restrict__ ids,
+                                  float* __restrict__ x, int H, int V) {
+    const int row = blockIdx.x;
+    uint32_t tok = ids[row];
+    if (tok >= (uint32_t)V) tok = 0;
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {
+        const u32x2 p = *(const u32x2*)(emb + (size_t)tok * H + i);
+        *(f32x4*)(x + (size_t)row * H + i) = (f32x4){bf16_lo(p[0]), bf16_hi(p[0]), bf16_lo(p[1]), bf16_hi(p[1])};
+    }
+}
+
+__device__ __forceinline__ void split_store4(uint16_t* hi, uint16_t* lo, size_t off, const float v[4]) {
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = f32_to_bf16(v[i]);
+        l[i] = f32_to_bf16(v[i] - bf16_to_f32(h[i]));
+    }
+    *(u32x2*)(hi + off) = (u32x2){(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+    if (lo) *(u32x2*)(lo + off) = (u32x2){(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+}
+
+// one block per token row: out = x * w / sqrt(mean(x^2)+eps) -> bf16 hi (+ lo)
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const uint16_t* __restrict__ w,
+                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                           int H, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (size_t)row * H;
+    float ss = 0.f;
+    for (int i = tid * 4; i < H; i += 1024) {
+        const f32x4 v = *(const f32x4*)(xr + i);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)H + eps);
+    for (int i = tid * 4; i < H; i += 1024) {
+        const f32x4 v = *(const f32x4*)(xr + i);
+        const u32x2 ww = *(const u32x2*)(w + i);
+        const float o[4] = {v[0] * r * bf16_lo(ww[0]), v[1] * r * bf16_hi(ww[0]), v[2] * r * bf16_lo(ww[1]),
+                            v[3] * r * bf16_hi(ww[1])};
+        split_store4(hi, lo, (size_t)row * H + i, o);
+    }
+}
+
+// grid (S, Hq + 2 Hkv), block 64: per-head RMSNorm(q,k) BEFORE RoPE (modeling.rs:341-359),
+// q scaled by 1/sqrt(D) -> bf16 hi/lo [S, Hq, D]; k, v -> paged cache at position start+s.
+template <bool KVF32>
+__global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
+    constexpr int D = 128;
+    const int s = blockIdx.x, item = blockIdx.y, lane = threadIdx.x;
+    const int Hq = a.Hq, Hkv = a.Hkv;
+    const int pos = a.start_pos + s;
+    const float* src = a.qkv + (size_t)s * (Hq + 2 * Hkv) * D + (size_t)item * D;
+    float x1 = src[lane], x2 = src[lane + 64];
+    const bool is_q = item < Hq, is_k = !is_q && item < Hq + Hkv;
+    if (is_q || is_k) {
+        const uint16_t* nw = is_q ? a.qnw : a.knw;
+        if (nw) {
+            const float ss = wave_sum(x1 * x1 + x2 * x2);
+            const float r = 1.0f / sqrtf(ss / (float)D + a.eps);
+            x1 = x1 * r * bf16_to_f32(nw[lane]);
+            x2 = x2 * r * bf16_to_f32(nw[lane + 64]);
+        }
+        const float c = a.cos[(size_t)pos * (D / 2) + lane], sn = a.sin[(size_t)pos * (D / 2) + lane];
+        const float o1 = x1 * c - x2 * sn, o2 = x1 * sn + x2 * c;
+        x1 = o1; x2 = o2;
+    }
+    if (is_q) {
+        x1 *= a.scale; x2 *= a.scale;
+        const size_t off = ((size_t)s * Hq + item) * D;
+        const uint16_t h1 = f32_to_bf16(x1), h2 = f32_to_bf16(x2);
+        a.q_hi[off + lane] = h1; a.q_hi[off + lane + 64] = h2;
+        a.q_lo[off + lane] = f32_to_bf16(x1 - bf16_to_f32(h1));
+        a.q_lo[off + lane + 64] = f32_to_bf16(x2 - bf16_to_f32(h2));
+    } else {
+        const int kvh = is_k ? item - Hq : item - Hq - Hkv;
+        void* pool = is_k ? a.kpool : a.vpool;
+        const int page = a.block_table[pos / a.page];
+        const size_t off = ((size_t)(page * Hkv + kvh) * a.page + (pos % a.page)) * D;
+        if (KVF32) { ((float*)pool)[off + lane] = x1; ((float*)pool)[off + lane + 64] = x2; }
+        else { ((uint16_t*)pool)[off + lane] = f32_to_bf16(x1); ((uint16_t*)pool)[off + lane + 64] = f32_to_bf16(x2); }
+    }
+}
+
+__global__ void add_rows_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 a = ((const f32x4*)x)[i];
+        const f32x4 b = ((const f32x4*)y)[i];
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        ((f32x4*)x)[i] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA GEMM, 128x128x32 tiles, 4 waves (2x2), each wave 64x64 = 4x4 mfma_f32_16x16x32_bf16.
+//   A: activation hi (+lo) [Mpad, K] row-major; W: [N, K] row-major (both K-contiguous, so both
+//   MFMA operands are plain 16-byte row segments); f32 accumulate.
+//   Register-staged double-buffered LDS (row stride 40 elements = 80 B: the 16 rows of a fragment
+//   read fall on 16 distinct 16-B bank slots).
+// ---------------------------------------------------------------------------------------------
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 40;
+
+template <int SPLIT, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][SPLIT][GBM * GLD];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][GBN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_m = (a.M + GBM - 1) / GBM;
+    // XCD-aware order: blocks that share a weight tile (same n-tile, different m-tile) get
+    // consecutive logical ids AND the same XCD (hardware places block b on XCD b % 8)
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;
+    const int tn = bid / tiles_m, tm = bid % tiles_m;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int K = a.K;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging map: chunk c = tid + 256*i (i<2): row = c >> 2, 16-byte k-chunk = c & 3
+    u32x4 ra[SPLIT][2], rb[2];
+    auto g_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 8;
+            ra[0][i] = ld16(a.A_hi + (size_t)(m0 + row) * K + k0 + kc);
+            if (SPLIT == 2) ra[SPLIT - 1][i] = ld16(a.A_lo + (size_t)(m0 + row) * K + k0 + kc);
+            rb[i] = ld_nt16(a.W + (size_t)(n0 + row) * K + k0 + kc);
+        }
+    };
+    auto s_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 8;
+            *(u32x4*)&As[buf][0][row * GLD + kc] = ra[0][i];
+            if (SPLIT == 2) *(u32x4*)&As[buf][SPLIT - 1][row * GLD + kc] = ra[SPLIT - 1][i];
+            *(u32x4*)&Bs[buf][row * GLD + kc] = rb[i];
+        }
+    };
+
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+    const int nk = K / GBK;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) g_load((kt + 1) * GBK);
+        bf16x8 bfrag[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfrag[j] = *(const bf16x8*)&Bs[buf][(wc * 64 + j * 16 + fr) * GLD + fk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 ah = *(const bf16x8*)&As[buf][0][(wr * 64 + i * 16 + fr) * GLD + fk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfrag[j], acc[i][j], 0, 0, 0);
+            if (SPLIT == 2) {
+                const bf16x8 al = *(const bf16x8*)&As[buf][SPLIT - 1][(wr * 64 + i * 16 + fr) * GLD + fk];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfrag[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) s_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C layout of mfma 16x16: col = lane & 15 (n), row = (lane >> 4) * 4 + reg (m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const float v = acc[i][j][r];
+                if (EPI == GEPI_STORE) {
+                    if (m < a.M) a.C[(size_t)m * a.ldc + n] = v;
+                } else if (EPI == GEPI_RESADD) {
+                    if (m < a.M) a.C[(size_t)m * a.ldc + n] += v;
+                } else {   // GEPI_SILUMUL: even column = gate_j, odd column = up_j
+                    const float up = dpp_mov<0xB1>(v);          // lane ^ 1
+                    if (((lane & 1) == 0) && m < a.M) {
+                        const float h = (v / (1.0f + expf(-v))) * up;
+                        const size_t off = (size_t)m * (a.N / 2) + (n >> 1);
+                        const uint16_t hh = f32_to_bf16(h);
+                        a.H_hi[off] = hh;
+                        if (a.H_lo) a.H_lo[off] = f32_to_bf16(h - bf16_to_f32(hh));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// causal flash attention over the paged cache.  grid (ceil(S/64), Hq), 4 waves x 16 query rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int VLD = 144;   // V tile row stride in LDS (elements): 288 B keeps the 4 key rows of a
+                           // tr-read group on disjoint banks
+
+template <bool KVF32>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
+    constexpr int D = 128, KT = 64;
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[KVF32 ? 2 : 1][KT * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, kvh = h / a.nrep;
+    const int qb = blockIdx.x * 64;                 // first query row of this block
+    const int qrow = qb + wave * 16 + sub;          // this lane's query row (as Q^T column / stats owner)
+    const int qrow_c = qrow < a.S ? qrow : a.S - 1; // clamp for loads
+    const int qpos = a.start_pos + qrow;
+
+    // Q^T fragments: B operand of S^T = K.Q^T : lane holds Q[q = sub][dims g*8 + 32*ks ..+8]
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const size_t off = ((size_t)qrow_c * a.Hq + h) * D + ks * 32 + g * 8;
+        qh[ks] = *(const bf16x8*)(a.q_hi + off);
+        ql[ks] = *(const bf16x8*)(a.q_lo + off);
+    }
+    f32x4 o[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int last_q = min(qb + 63, a.S - 1);
+    const int kv_end = a.start_pos + last_q + 1;            // tokens [0, kv_end) are visible to this block
+    for (int t0 = 0; t0 < kv_end; t0 += KT) {
+        __syncthreads();                                   // previous tile's V fully consumed
+        // ---- stage V tile (64 tokens x 128 dims) into LDS, shared by the 4 waves ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, tok = c >> 4, d8 = (c & 15) * 8;
+            const int t = min(t0 + tok, kv_end - 1);
+            const int page = a.block_table[t / a.page];
+            const size_t off = ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + d8;
+            if (KVF32) {
+                const f32x4 v0 = *(const f32x4*)((const float*)a.vpool + off);
+                const f32x4 v1 = *(const f32x4*)((const float*)a.vpool + off + 4);
+                const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t h0 = f32_to_bf16(vv[2 * e]), h1 = f32_to_bf16(vv[2 * e + 1]);
+                    hi[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                    lo[e] = pack_bf16x2(vv[2 * e] - bf16_to_f32(h0), vv[2 * e + 1] - bf16_to_f32(h1));
+                }
+                *(u32x4*)&Vs[0][tok * VLD + d8] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+                *(u32x4*)&Vs[KVF32 ? 1 : 0][tok * VLD + d8] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+            } else {
+                *(u32x4*)&Vs[0][tok * VLD + d8] = ld16((const uint16_t*)a.vpool + off);
+            }
+        }
+        // ---- S^T = K . Q^T for 4 sub-tiles of 16 tokens: rows = tokens, cols = queries ----
+        f32x4 s[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            s[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int t = min(t0 + tt * 16 + sub, kv_end - 1);          // this lane's K row (A operand row)
+            const int page = a.block_table[t / a.page];
+            const size_t kb = ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 kh, kl;
+                if (KVF32) {
+                    const f32x4 k0 = *(const f32x4*)((const float*)a.kpool + kb + ks * 32);
+                    const f32x4 k1 = *(const f32x4*)((const float*)a.kpool + kb + ks * 32 + 4);
+                    const float kk[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint16_t hh = f32_to_bf16(kk[e]);
+                        kh[e] = (short)hh;
+                        kl[e] = (short)f32_to_bf16(kk[e] - bf16_to_f32(hh));
+                    }
+                } else {
+                    kh = *(const bf16x8*)((const uint16_t*)a.kpool + kb + ks * 32);
+                }
+                s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], s[tt], 0, 0, 0);
+                s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], s[tt], 0, 0, 0);
+                if (KVF32) s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], s[tt], 0, 0, 0);
+            }
+        }
+        // ---- causal mask + online softmax (row statistics live in the lanes with the same `sub`) ----
+        float mt = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + tt * 16 + g * 4 + r;
+                if (t > qpos) s[tt][r] = -INFINITY;
+                mt = fmaxf(mt, s[tt][r]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);               // finite: token 0 is visible to every query
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+        bf16x4 ph[4], pl[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(s[tt][r] - m_new);      // exp(-inf) = 0 for masked tokens
+                psum += p;
+                const uint16_t hh = f32_to_bf16(p);
+                ph[tt][r] = (short)hh;
+                pl[tt][r] = (short)f32_to_bf16(p - bf16_to_f32(hh));
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) { o[nt][0] *= alpha; o[nt][1] *= alpha; o[nt][2] *= alpha; o[nt][3] *= alpha; }
+        __syncthreads();                                   // V tile visible
+        // ---- O^T += V^T . P^T : A = V^T fragment (tr-read), B = P^T fragment (registers) ----
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const uint16_t* vp = &Vs[0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
+                const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, ph[tt], o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, pl[tt], o[nt], 0, 0, 0);
+                if (KVF32) {
+                    const uint16_t* vq = &Vs[KVF32 ? 1 : 0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
+                    const bf16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vq);
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vl, ph[tt], o[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- finalize: l over the 4 lane groups; O^T rows = dims nt*16 + g*4 + r, col = query `sub` ----
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_run;
+    if (qrow < a.S) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+            split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s) {
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(S), dim3(256), 0, s, emb, ids, x, H, V);
+}
+void launch_rmsnorm_rows(const float* x, const uint16_t* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, s, x, w, hi, lo, H, eps);
+}
+void launch_qknorm_rope_kv(const QkRopeArgs& a, int S, bool kv_f32, hipStream_t s) {
+    dim3 grid(S, a.Hq + 2 * a.Hkv);
+    if (kv_f32) hipLaunchKernelGGL(qknorm_rope_kv_kernel<true>, grid, dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(qknorm_rope_kv_kernel<false>, grid, dim3(64), 0, s, a);
+}
+void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;
+    int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, x, y, n4);
+}
+bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
+    if (a.N % GBN != 0 || a.K % GBK != 0) return false;
+    const int tiles = ((a.M + GBM - 1) / GBM) * (a.N / GBN);
+    const bool split = a.A_lo != nullptr;
+#define CM_GEMM(SP, EP) hipLaunchKernelGGL((gemm_bf16_kernel<SP, EP>), dim3(tiles), dim3(256), 0, s, a)
+    if (split) {
+        if (epi == GEPI_STORE) CM_GEMM(2, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(2, GEPI_RESADD); else CM_GEMM(2, GEPI_SILUMUL);
+    } else {
+        if (epi == GEPI_STORE) CM_GEMM(1, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(1, GEPI_RESADD); else CM_GEMM(1, GEPI_SILUMUL);
+    }
+#undef CM_GEMM
+    return true;
+}
+void launch_attn_prefill(const AttnPreArgs& a, bool kv_f32, hipStream_t s) {
+    dim3 grid((a.S + 63) / 64, a.Hq);
+    if (kv_f32) hipLaunchKernelGGL(attn_prefill_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn_prefill_kernel<false>, grid, dim3(256), 0, s, a);
+}
+
+}  // namespace cm

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "json_min.h"
@@ -35,6 +36,7 @@ Model::~Model() {
     if (h_st) (void)hipHostFree(h_st);
     if (h_ring) (void)hipHostFree(h_ring);
     if (h_logits) (void)hipHostFree(h_logits);
+    if (h_ids) (void)hipHostFree(h_ids);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -324,7 +326,13 @@ void Model::enqueue_decode_step(bool advance) {
             rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
         }
     }
+    enqueue_lm_head(advance);
+}
+
+void Model::enqueue_lm_head(bool advance) {
     // final norm + lm_head (last position only, modeling.rs:1024-1035) + arg-max
+    const int H = cfg.H;
+    hipStream_t s = stream;
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     GemvArgs g{};
     g.W = lm_head; g.x = x; g.nw = norm; g.y = logits + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H;
@@ -335,6 +343,97 @@ void Model::enqueue_decode_step(bool advance) {
         rccl->all_gather(pidx + (size_t)rank * lm_grid, pidx, (size_t)lm_grid * sizeof(int), s);
     }
     launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, s);
+}
+
+// ------------------------------------------------------------------------------------
+// prefill (S > 1): MFMA GEMMs + causal flash attention over the paged cache
+// ------------------------------------------------------------------------------------
+void Model::ensure_prefill_buffers() {
+    if (pX) return;
+    const int H = cfg.H, D = cfg.D;
+    chunk = opts.prefill_chunk ? (int)opts.prefill_chunk : 2048;      // PREFILL_CHUNK_SIZE engine/mod.rs:65
+    if (chunk > max_seq) chunk = max_seq;
+    if (chunk < 1) chunk = 1;
+    chunk_pad = (chunk + 127) / 128 * 128;
+    prefill_split2 = opts.prefill_split != 1;
+    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    prefill_ok = (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0);
+    if (!prefill_ok) return;
+    pX = dalloc<float>((size_t)chunk * H);
+    if (tp > 1) pY = dalloc<float>((size_t)chunk * H);
+    pQKV = dalloc<float>((size_t)chunk * qkv_rows);
+    auto z = [&](size_t n) {
+        uint16_t* p = dalloc<uint16_t>(n);
+        CM_HIP(hipMemsetAsync(p, 0, n * sizeof(uint16_t), stream));
+        return p;
+    };
+    pXN_hi = z((size_t)chunk_pad * H); pXN_lo = z((size_t)chunk_pad * H);
+    pQ_hi = z((size_t)chunk_pad * Hq_l * D); pQ_lo = z((size_t)chunk_pad * Hq_l * D);
+    pAT_hi = z((size_t)chunk_pad * Hq_l * D); pAT_lo = z((size_t)chunk_pad * Hq_l * D);
+    pHH_hi = z((size_t)chunk_pad * I_l); pHH_lo = z((size_t)chunk_pad * I_l);
+    d_ids = (uint32_t*)dalloc<int>(chunk);
+    CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
+}
+
+void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
+    const int H = cfg.H, D = cfg.D;
+    hipStream_t s = stream;
+    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    const bool sp2 = prefill_split2;
+    for (size_t off = 0; off < n; off += (size_t)chunk) {
+        const int S = (int)std::min<size_t>((size_t)chunk, n - off);
+        const int sp = (int)(start_pos + off);
+        CM_HIP(hipStreamSynchronize(s));                       // h_ids reuse
+        memcpy(h_ids, ids + off, (size_t)S * sizeof(uint32_t));
+        CM_HIP(hipMemcpyAsync(d_ids, h_ids, (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, s);
+        for (int li = 0; li < cfg.L; ++li) {
+            const LayerW& w = layers[(size_t)li];
+            launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+            GemmArgs g{};
+            g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
+            g.M = S; g.N = qkv_rows; g.K = H;
+            if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+            QkRopeArgs q{};
+            q.qkv = pQKV; q.qnw = w.qn; q.knw = w.kn; q.cos = cos; q.sin = sin; q.block_table = d_bt;
+            q.kpool = kpool(li); q.vpool = vpool(li); q.q_hi = pQ_hi; q.q_lo = pQ_lo;
+            q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = sp; q.eps = cfg.eps;
+            q.scale = (float)(1.0 / std::sqrt((double)D));
+            launch_qknorm_rope_kv(q, S, kv_f32, s);
+            AttnPreArgs at{};
+            at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = d_bt; at.kpool = kpool(li); at.vpool = vpool(li);
+            at.out_hi = pAT_hi; at.out_lo = pAT_lo; at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
+            at.page = page; at.start_pos = sp;
+            launch_attn_prefill(at, kv_f32, s);
+            g = GemmArgs{};
+            g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
+            if (tp == 1) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+            else {
+                g.C = pY; launch_gemm(g, GEPI_STORE, s);
+                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+                launch_add_rows(pX, pY, (size_t)S * H, s);
+            }
+            launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+            g = GemmArgs{};
+            g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
+            g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
+            launch_gemm(g, GEPI_SILUMUL, s);
+            g = GemmArgs{};
+            g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
+            if (tp == 1) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+            else {
+                g.C = pY; launch_gemm(g, GEPI_STORE, s);
+                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+                launch_add_rows(pX, pY, (size_t)S * H, s);
+            }
+        }
+        if (off + (size_t)S >= n) {     // last chunk: logits of the LAST position only (modeling.rs:1032-1035)
+            CM_HIP(hipMemcpyAsync(x, pX + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            launch_set_state(st, ids[n - 1], (int32_t)(start_pos + n - 1), s);
+            ++ring_count;
+            enqueue_lm_head(true);
+        }
+    }
 }
 
 void Model::run_decode_step(bool advance) {
@@ -378,9 +477,18 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     // appending into a page shared with a fork is not allowed: fork already copied the partial page
     ensure_pages(s, (int64_t)(start_pos + n));
     activate(s);
-    for (size_t i = 0; i < n; ++i) {
-        launch_set_state(st, ids[i], (int32_t)(start_pos + i), stream);
-        run_decode_step(true);
+    bool use_prefill = false;
+    if (n >= 2 && getenv("CM_NO_PREFILL") == nullptr) {
+        ensure_prefill_buffers();
+        use_prefill = prefill_ok;
+    }
+    if (use_prefill) {
+        prefill(ids, n, start_pos);
+    } else {
+        for (size_t i = 0; i < n; ++i) {     // token-serial path (also the parity cross-check of prefill)
+            launch_set_state(st, ids[i], (int32_t)(start_pos + i), stream);
+            run_decode_step(true);
+        }
     }
     q.len = (int64_t)(start_pos + n);
     if (greedy_out) {

@@ -110,6 +110,19 @@ struct Model {
     uint32_t* h_ring = nullptr;        // pinned
     float* h_logits = nullptr;         // pinned [V]
 
+    // prefill scratch (allocated on first use; sized for one chunk)
+    int chunk = 2048, chunk_pad = 2048;
+    bool prefill_ok = false, prefill_split2 = true;
+    float* pX = nullptr;        // [chunk, H] f32 residual stream
+    float* pY = nullptr;        // [chunk, H] TP partial
+    float* pQKV = nullptr;      // [chunk, qkv_rows] f32
+    uint16_t *pXN_hi = nullptr, *pXN_lo = nullptr;     // [chunk_pad, H]
+    uint16_t *pQ_hi = nullptr, *pQ_lo = nullptr;       // [chunk_pad, Hq_l D]
+    uint16_t *pAT_hi = nullptr, *pAT_lo = nullptr;     // [chunk_pad, Hq_l D]
+    uint16_t *pHH_hi = nullptr, *pHH_lo = nullptr;     // [chunk_pad, I_l]
+    uint32_t* d_ids = nullptr;
+    uint32_t* h_ids = nullptr;
+
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ok = false;
@@ -139,6 +152,9 @@ struct Model {
 
     // ---- forward ----
     void enqueue_decode_step(bool advance);     // one token from st->token at st->pos
+    void enqueue_lm_head(bool advance);         // final norm + lm_head + arg-max on x
+    void ensure_prefill_buffers();
+    void prefill(const uint32_t* ids, size_t n, size_t start_pos);   // active sequence, pages ensured
     void run_decode_step(bool advance);         // graph replay or eager
     void forward(int s, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out, uint32_t* greedy_out);
     void generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_config* g, uint32_t* out, size_t* n_out,

@@ -141,19 +141,28 @@ void qc_destroy(qc_model* m) {
     free(m);
 }
 
-/* y[n] = W[n,:] . x  (bf16 weights, f32 accumulate), rows split over the host cores */
+/* y[n] = W[n,:] . x  (bf16 weights, f32 accumulate), rows split over the host cores.
+ * 16 independent lane accumulators (fixed order) so the compiler can use SIMD without
+ * re-associating a single float chain. */
 static void gemv(const uint16_t* W, const float* x, float* y, int N, int K) {
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
         const uint16_t* w = W + (size_t)n * K;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float acc[16];
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
         int k = 0;
-        for (; k + 4 <= K; k += 4) {
-            a0 += bf2f(w[k]) * x[k]; a1 += bf2f(w[k + 1]) * x[k + 1];
-            a2 += bf2f(w[k + 2]) * x[k + 2]; a3 += bf2f(w[k + 3]) * x[k + 3];
+        for (; k + 16 <= K; k += 16) {
+            for (int j = 0; j < 16; ++j) {
+                uint32_t u = ((uint32_t)w[k + j]) << 16;
+                float f;
+                memcpy(&f, &u, 4);
+                acc[j] += f * x[k + j];
+            }
         }
-        for (; k < K; ++k) a0 += bf2f(w[k]) * x[k];
-        y[n] = (a0 + a1) + (a2 + a3);
+        for (; k < K; ++k) acc[k & 15] += bf2f(w[k]) * x[k];
+        float s8[8];
+        for (int j = 0; j < 8; ++j) s8[j] = acc[j] + acc[j + 8];
+        y[n] = ((s8[0] + s8[4]) + (s8[1] + s8[5])) + ((s8[2] + s8[6]) + (s8[3] + s8[7]));
     }
 }
 

@@ -33,5 +33,7 @@ def test_c_port_kv_rounding_mode():
     c = c_oracle.CQwen3(cfg, seed=0, max_seq=64, kv_bf16=True)
     ids = configs.synthetic_prompt(9, cfg["vocab_size"])
     a, b = o.forward(ids, 0), c.forward(ids, 0)
-    assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
+    # both sides round K/V to bf16 from values that differ in the last f32 bit, so a few elements
+    # land on the other side of a bf16 tie (2^-9 on those elements, ~1e-4 on logits)
+    assert np.abs(a - b).max() / np.abs(a).max() < 2e-4
     c.close()
