@@ -173,9 +173,15 @@ void Model::alloc_runtime() {
     CM_HIP(hipMemcpy(cos, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
     CM_HIP(hipMemcpy(sin, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    if (tp > 1) {
+    // CM_FORCE_RCCL=1 (debug): route the tp=1 reductions through a 1-rank RCCL communicator so the
+    // collective code path can be exercised on a single GPU.
+    const bool force_cc = tp == 1 && getenv("CM_FORCE_RCCL") != nullptr;
+    if (tp > 1 || force_cc) {
         rccl.reset(new Rccl());
-        rccl->init(tp, rank, opts.tp_unique_id, stream);
+        UniqueId self_id;
+        const void* id = opts.tp_unique_id;
+        if (force_cc && !id) { Rccl::unique_id(&self_id); id = &self_id; }
+        rccl->init(tp, rank, id, stream);
     }
     CM_HIP(hipStreamSynchronize(stream));
 }
@@ -306,7 +312,7 @@ void Model::enqueue_decode_step(bool advance) {
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
-        if (tp == 1) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+        if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
         else {
             g.y = y; g.res = x;
             launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
@@ -319,7 +325,7 @@ void Model::enqueue_decode_step(bool advance) {
         // (5) down_proj + residual
         g = GemvArgs{};
         g.W = w.down; g.x = hbuf; g.N = H; g.K = I_l; g.ldw = I_l;
-        if (tp == 1) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+        if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
         else {
             g.y = y; g.res = x;
             launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
@@ -338,7 +344,7 @@ void Model::enqueue_lm_head(bool advance) {
     g.W = lm_head; g.x = x; g.nw = norm; g.y = logits + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H;
     g.eps = cfg.eps; g.pmax = pmax + (size_t)rank * lm_grid; g.pidx = pidx + (size_t)rank * lm_grid; g.idx_base = v0;
     launch_gemv(PRO_RMSNORM, EPI_ARGMAX, g, lm_grid, s);
-    if (tp > 1) {
+    if (rccl) {
         rccl->all_gather(pmax + (size_t)rank * lm_grid, pmax, (size_t)lm_grid * sizeof(float), s);
         rccl->all_gather(pidx + (size_t)rank * lm_grid, pidx, (size_t)lm_grid * sizeof(int), s);
     }
@@ -360,7 +366,7 @@ void Model::ensure_prefill_buffers() {
     prefill_ok = (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0);
     if (!prefill_ok) return;
     pX = dalloc<float>((size_t)chunk * H);
-    if (tp > 1) pY = dalloc<float>((size_t)chunk * H);
+    if (rccl) pY = dalloc<float>((size_t)chunk * H);
     pQKV = dalloc<float>((size_t)chunk * qkv_rows);
     auto z = [&](size_t n) {
         uint16_t* p = dalloc<uint16_t>(n);
@@ -407,7 +413,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             launch_attn_prefill(at, kv_f32, s);
             g = GemmArgs{};
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
-            if (tp == 1) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+            if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
                 rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
@@ -420,7 +426,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             launch_gemm(g, GEPI_SILUMUL, s);
             g = GemmArgs{};
             g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
-            if (tp == 1) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+            if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
                 rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
@@ -439,7 +445,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
 void Model::run_decode_step(bool advance) {
     (void)advance;   // the device state always advances; hosts that drive positions overwrite it
     ++ring_count;    // host mirror of st->pad (ring write index)
-    if (use_graph && tp == 1) {
+    if (use_graph && !rccl) {
         if (!graph_ok && graph == nullptr) {
             hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {
@@ -457,7 +463,7 @@ void Model::run_decode_step(bool advance) {
 }
 
 void Model::fetch_logits(float* out) {
-    if (tp > 1) rccl->all_gather(logits + (size_t)rank * V_l, logits, (size_t)V_l * sizeof(float), stream);
+    if (rccl) rccl->all_gather(logits + (size_t)rank * V_l, logits, (size_t)V_l * sizeof(float), stream);
     CM_HIP(hipMemcpyAsync(h_logits, logits, (size_t)V_l * tp * sizeof(float), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
     memcpy(out, h_logits, (size_t)cfg.V * sizeof(float));

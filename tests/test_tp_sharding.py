@@ -1,0 +1,111 @@
+"""Tensor-parallel plan: world_size-2 (and 4) gloo runs on CPU.
+
+Each rank slices the synthetic checkpoint with crane_amd.tp.shard_plan / shard_weights (the same
+arithmetic csrc/loader.cpp uses), runs the oracle's layer math on its shard, all-reduces the
+row-parallel partial sums with gloo, all-gathers the vocab-sharded logits -- and must reproduce the
+unsharded oracle.  Correct-by-construction evidence for the RCCL path, which cannot be run here.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, cfg_name, qh):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from crane_amd import configs, synth, tp
+    from oracle import qwen3_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = configs.get_config(cfg_name)
+        w = synth.synth_weights_f32(cfg, 0)
+        plan = tp.shard_plan(cfg, world, rank)
+        sw = tp.shard_weights(cfg, w, plan)
+        c = O.Qwen3Config.from_json(cfg)
+        D, H = c.hd, c.hidden_size
+        ids = configs.synthetic_prompt(9, c.vocab_size)
+        cos, sin = O.rotary_tables(D, 64, c.rope_theta)
+        S = len(ids)
+        x = w["model.embed_tokens.weight"][np.asarray(ids)].astype(np.float32)
+
+        def allreduce(a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            dist.all_reduce(t)
+            return t.numpy()
+
+        for li in range(c.num_hidden_layers):
+            p = f"model.layers.{li}."
+            xn = O.rms_norm(x, w[p + "input_layernorm.weight"], c.rms_norm_eps)
+            hq, hkv = len(plan.q_heads), len(plan.kv_heads)
+            q = (xn @ sw[p + "self_attn.q_proj.weight"].T).reshape(S, hq, D)
+            k = (xn @ sw[p + "self_attn.k_proj.weight"].T).reshape(S, hkv, D)
+            v = (xn @ sw[p + "self_attn.v_proj.weight"].T).reshape(S, hkv, D)
+            q = O.rope_thd(O.rms_norm(q, w[p + "self_attn.q_norm.weight"], c.rms_norm_eps), cos[:S], sin[:S])
+            k = O.rope_thd(O.rms_norm(k, w[p + "self_attn.k_norm.weight"], c.rms_norm_eps), cos[:S], sin[:S])
+            att = O.naive_gqa_attention(q.transpose(1, 0, 2), k.transpose(1, 0, 2), v.transpose(1, 0, 2),
+                                        1.0 / np.sqrt(D), causal_offset=0)          # local heads only
+            att = att.transpose(1, 0, 2).reshape(S, hq * D)
+            x = x + allreduce(att @ sw[p + "self_attn.o_proj.weight"].T)            # all-reduce #1
+            xn = O.rms_norm(x, w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
+            h = O.silu(xn @ sw[p + "mlp.gate_proj.weight"].T) * (xn @ sw[p + "mlp.up_proj.weight"].T)
+            x = x + allreduce(h @ sw[p + "mlp.down_proj.weight"].T)                 # all-reduce #2
+        last = O.rms_norm(x[-1:], w["model.norm.weight"], c.rms_norm_eps)
+        head = sw.get("lm_head.weight")
+        if head is None:                                                            # tied: rows of the embedding
+            head = w["model.embed_tokens.weight"][plan.vocab.start:plan.vocab.stop]
+        local = (last @ head.T)[0]
+        v_l = (c.vocab_size + world - 1) // world
+        buf = np.zeros(v_l, np.float32); buf[:local.size] = local
+        gathered = [torch.zeros(v_l) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(buf))
+        logits = np.concatenate([g.numpy() for g in gathered])[:c.vocab_size]
+        if rank == 0:
+            ref = O.Qwen3Oracle(c, w).forward(ids, 0)
+            qh.put(float(np.abs(logits - ref).max() / np.abs(ref).max()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg_name,world", [("tiny-qwen3", 2), ("tiny-qwen3-untied", 2), ("tiny-qwen3-untied", 4)])
+def test_tp_plan_reproduces_unsharded_forward(cfg_name, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    qh = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg_name, qh)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    err = qh.get(timeout=5)
+    assert err < 1e-5, err
+
+
+def test_plan_shapes_for_headline_models():
+    from crane_amd import configs, tp
+    c8 = configs.get_config("qwen3-8b")
+    p = tp.shard_plan(c8, 8, 3)
+    assert list(p.q_heads) == [12, 13, 14, 15] and list(p.kv_heads) == [3] and p.n_rep == 4
+    assert len(p.inter) == 1536 and len(p.vocab) == 18992
+    # Hkv=4 < tp=8 -> KV head r//2 replicated on two ranks, 3 q heads each (27B geometry)
+    c27 = dict(c8, num_attention_heads=24, num_key_value_heads=4, intermediate_size=17408, vocab_size=248320)
+    for r in range(8):
+        p = tp.shard_plan(c27, 8, r)
+        assert list(p.kv_heads) == [r // 2] and list(p.q_heads) == [3 * r, 3 * r + 1, 3 * r + 2] and p.n_rep == 3
+        assert all(h // 6 == r // 2 for h in p.q_heads)          # every local q head maps to the local KV head
+    with pytest.raises(ValueError):
+        tp.shard_plan(c8, 3, 0)
