@@ -233,3 +233,29 @@ def test_prefill_f32_kv_and_plain_bf16_modes():
         assert rel(got, ref) < 2e-2 and int(got.argmax()) == int(ref.argmax())
     finally:
         m.close()
+
+
+def test_rccl_code_path_single_rank():
+    """CM_FORCE_RCCL=1: the tp=1 reductions go through a 1-rank RCCL communicator (dlopen, unique-id ABI,
+    all-reduce + all-gather on the model's stream).  Results must equal the collective-free path."""
+    import os
+    cfg = configs.get_config("tiny-qwen3-untied")
+    ids = configs.synthetic_prompt(40, cfg["vocab_size"])
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2)
+    try:
+        a = m.forward_step(ids, 0)[0, 0]
+        a2 = m.forward_step([7], 40)[0, 0]
+    finally:
+        m.close()
+    os.environ["CM_FORCE_RCCL"] = "1"
+    try:
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2)
+        try:
+            b = m.forward_step(ids, 0)[0, 0]
+            b2 = m.forward_step([7], 40)[0, 0]
+            toks = m.generate(ids[:5], GenerationConfig.greedy(6), sync_every=3)
+        finally:
+            m.close()
+    finally:
+        del os.environ["CM_FORCE_RCCL"]
+    assert rel(b, a) < 1e-6 and rel(b2, a2) < 1e-6 and len(toks) == 11
