@@ -35,6 +35,31 @@ CONFIGS = {
 }
 
 
+_QWEN35_COMMON = dict(
+    model_type="qwen3_5_text", rms_norm_eps=1e-6, attention_bias=False, hidden_act="silu",
+    linear_conv_kernel_dim=4, full_attention_interval=4, attn_output_gate=True, torch_dtype="bfloat16",
+    rope_parameters=dict(rope_type="default", rope_theta=10_000_000.0, partial_rotary_factor=0.25,
+                         mrope_section=[11, 11, 10], mrope_interleaved=True),
+)
+CONFIGS.update({
+    # Qwen3.5-0.8B (values tagged [external] there)
+    "qwen3.5-0.8b": dict(_QWEN35_COMMON, vocab_size=248320, hidden_size=1024, intermediate_size=3584,
+                         num_hidden_layers=24, num_attention_heads=8, num_key_value_heads=2, head_dim=256,
+                         linear_key_head_dim=128, linear_value_head_dim=128, linear_num_key_heads=16,
+                         linear_num_value_heads=16, tie_word_embeddings=True, max_position_embeddings=262144),
+    # Qwen3.8-27B: fully pinned by the reference (qwen3_5/config.rs:298-324,332-364)
+    "qwen3.8-27b": dict(_QWEN35_COMMON, vocab_size=248320, hidden_size=5120, intermediate_size=17408,
+                        num_hidden_layers=64, num_attention_heads=24, num_key_value_heads=4, head_dim=256,
+                        linear_key_head_dim=128, linear_value_head_dim=128, linear_num_key_heads=16,
+                        linear_num_value_heads=48, tie_word_embeddings=False, max_position_embeddings=262144),
+    # CPU-oracle sized hybrid: 3 GDN + 1 full layer, twice; value heads = 2 x key heads (interleaved pairing)
+    "tiny-qwen3.5": dict(_QWEN35_COMMON, vocab_size=512, hidden_size=256, intermediate_size=512,
+                         num_hidden_layers=8, num_attention_heads=4, num_key_value_heads=2, head_dim=256,
+                         linear_key_head_dim=128, linear_value_head_dim=128, linear_num_key_heads=2,
+                         linear_num_value_heads=4, tie_word_embeddings=False, max_position_embeddings=4096),
+})
+
+
 def get_config(name: str) -> dict:
     if name not in CONFIGS:
         raise KeyError(f"unknown config {name!r}; have {sorted(CONFIGS)}")

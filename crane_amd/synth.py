@@ -135,10 +135,56 @@ def qwen3_specs(cfg: dict) -> List[Spec]:
     return sp
 
 
+def qwen3_5_specs(cfg: dict) -> List[Spec]:
+    """Qwen 3.5/3.6/3.8 text model (HF names; shape contract: reference tests/test_qwen35_family_shapes.py:68-131).
+    Block / QK norms are stored as w with the model applying (1 + w); the GDN gated norm is a plain weight.
+    A_log ~ 0.1 N(0,1) - 2 and linear ~ N(0, 1/sqrt(fan_in)) follow the reference's RandWeights
+    (crane-core/src/models/qwen3_5/prefill.rs:151-183)."""
+    t = cfg.get("text_config", cfg)
+    H, I, V = t["hidden_size"], t["intermediate_size"], t["vocab_size"]
+    Hq, Hkv, D = t["num_attention_heads"], t["num_key_value_heads"], t["head_dim"]
+    NK, NV = t["linear_num_key_heads"], t["linear_num_value_heads"]
+    K, Vd, ker = t["linear_key_head_dim"], t["linear_value_head_dim"], t.get("linear_conv_kernel_dim", 4)
+    KD, VD = NK * K, NV * Vd
+    interval = t.get("full_attention_interval", 4)
+    sH = 1 / math.sqrt(H)
+    sp: List[Spec] = [("model.embed_tokens.weight", (V, H), 1.0, 0.0)]
+    for i in range(t["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        if (i + 1) % interval == 0:
+            sp += [(p + "self_attn.q_proj.weight", (Hq * D * 2, H), sH, 0.0),
+                   (p + "self_attn.k_proj.weight", (Hkv * D, H), sH, 0.0),
+                   (p + "self_attn.v_proj.weight", (Hkv * D, H), sH, 0.0),
+                   (p + "self_attn.o_proj.weight", (H, Hq * D), 1 / math.sqrt(Hq * D), 0.0),
+                   (p + "self_attn.q_norm.weight", (D,), 0.1, 0.0),
+                   (p + "self_attn.k_norm.weight", (D,), 0.1, 0.0)]
+        else:
+            sp += [(p + "linear_attn.in_proj_qkv.weight", (2 * KD + VD, H), sH, 0.0),
+                   (p + "linear_attn.in_proj_z.weight", (VD, H), sH, 0.0),
+                   (p + "linear_attn.in_proj_b.weight", (NV, H), sH, 0.0),
+                   (p + "linear_attn.in_proj_a.weight", (NV, H), sH, 0.0),
+                   (p + "linear_attn.conv1d.weight", (2 * KD + VD, 1, ker), 0.5, 0.0),
+                   (p + "linear_attn.A_log", (NV,), 0.1, -2.0),
+                   (p + "linear_attn.dt_bias", (NV,), 0.1, 0.0),
+                   (p + "linear_attn.norm.weight", (Vd,), 0.1, 1.0),
+                   (p + "linear_attn.out_proj.weight", (H, VD), 1 / math.sqrt(VD), 0.0)]
+        sp += [(p + "mlp.gate_proj.weight", (I, H), sH, 0.0),
+               (p + "mlp.up_proj.weight", (I, H), sH, 0.0),
+               (p + "mlp.down_proj.weight", (H, I), 1 / math.sqrt(I), 0.0),
+               (p + "input_layernorm.weight", (H,), 0.1, 0.0),
+               (p + "post_attention_layernorm.weight", (H,), 0.1, 0.0)]
+    sp.append(("model.norm.weight", (H,), 0.1, 0.0))
+    if not t.get("tie_word_embeddings", cfg.get("tie_word_embeddings", False)):
+        sp.append(("lm_head.weight", (V, H), sH, 0.0))
+    return sp
+
+
 def specs_for(cfg: dict) -> List[Spec]:
     mt = cfg.get("model_type", "qwen3")
     if mt == "qwen3":
         return qwen3_specs(cfg)
+    if mt in ("qwen3_5", "qwen3_5_text"):
+        return qwen3_5_specs(cfg)
     raise ValueError(f"no synthetic spec for model_type {mt!r}")
 
 
