@@ -91,7 +91,9 @@ struct StepState {
     uint32_t token;     // token to feed this step
     int32_t pos;        // its KV position
     uint32_t next;      // arg-max result of this step
-    int32_t pad;
+    int32_t pad;        // token-ring write index
+    int32_t slot;       // active sequence slot (indexes the per-sequence GDN state pools)
+    int32_t rsv[3];
 };
 
 }  // namespace cm

@@ -13,7 +13,7 @@ enum { EPI_STORE = 0, EPI_RESADD = 1, EPI_SILUMUL = 2, EPI_ARGMAX = 3 };
 struct GemvArgs {
     const uint16_t* W;     // [N, ldw] bf16, K contiguous
     const float* x;        // [K] f32
-    const uint16_t* nw;    // [K] bf16 RMSNorm weight (PRO_RMSNORM)
+    const float* nw;       // [K] f32 RMSNorm weight, (1 + w) already folded for Qwen3.5 (PRO_RMSNORM)
     float* y;              // output (see epilogues)
     const float* res;      // [N] residual (EPI_RESADD); may alias y
     float* pmax;           // [grid] (EPI_ARGMAX)
@@ -24,19 +24,38 @@ struct GemvArgs {
 };
 
 struct AttnDecArgs {
-    const float* qkv;            // [(Hq + 2 Hkv) * D] f32, this token
-    const uint16_t* qnw;         // [D] bf16 or null
-    const uint16_t* knw;
-    const float* cos;            // [max_pos, D/2] f32
+    const float* qkv;            // projection output of this token (f32)
+    const float* qnw;            // [D] f32 (1 + w folded for Qwen3.5) or null
+    const float* knw;
+    const float* cos;            // [max_pos, rot/2] f32
     const float* sin;
+    const float* gate;           // [Hq * D] f32 output gate (Qwen3.5: y * sigmoid(gate)) or null
     const StepState* st;
     const int32_t* block_table;  // [max_pages_per_seq]
     void* kpool;                 // this layer: [pages][Hkv][PAGE][D] bf16 (or f32)
     void* vpool;
     float* part_o;               // [Hq][nsplit][D]
     float* part_ml;              // [Hq][nsplit][2]
-    int Hkv, page, max_pages;
+    int q_off, k_off, v_off;     // element offsets of q / k / v inside qkv
+    int Hkv, page, max_pages, rot_dim;
     float eps, scale;
+};
+
+// Gated Delta Net layer state machine (kernels_gdn.hip)
+struct GdnArgs {
+    const float* proj;           // [S, proj_stride] f32: qkv (conv_dim) | z (NV*V) | b (NV) | a (NV)
+    const float* conv_w;         // [conv_dim, 4] f32
+    float* conv_pool;            // [slots][gdn_layers][2 (parity)][conv_dim][3] f32
+    float* state_pool;           // [slots][gdn_layers][NV][K][V] f32
+    const float* A_log;          // [NV]
+    const float* dt_bias;        // [NV]
+    const float* gnorm_w;        // [V] plain RMSNormGated weight
+    float* out;                  // [S, out_stride] f32 gated-normed y
+    const StepState* st;         // decode: start_pos and slot are read from device state
+    int proj_stride, out_stride;
+    int start_pos, slot;         // used when st == nullptr (prefill)
+    int S, NV, vpg, key_dim, layer_idx, gdn_layers;
+    float eps;
 };
 
 // ---- prefill (S > 1) ----
@@ -54,8 +73,8 @@ struct GemmArgs {
 
 struct QkRopeArgs {
     const float* qkv;            // [S, (Hq + 2 Hkv) D] f32
-    const uint16_t* qnw;
-    const uint16_t* knw;
+    const float* qnw;
+    const float* knw;
     const float* cos;
     const float* sin;
     const int32_t* block_table;
@@ -79,7 +98,7 @@ struct AttnPreArgs {
 };
 
 void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
-void launch_rmsnorm_rows(const float* x, const uint16_t* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
+void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
                          hipStream_t s);
 void launch_qknorm_rope_kv(const QkRopeArgs& a, int S, bool kv_f32, hipStream_t s);
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
@@ -91,10 +110,12 @@ int gemv_rows_per_group(int K);
 int gemv_grid(int N, int K, int num_cu);
 void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s);
 void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s);
-void launch_set_state(StepState* st, uint32_t token, int32_t pos, hipStream_t s);
+void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, hipStream_t s);
-bool launch_attn_decode(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s);
+bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s);
+void launch_gdn(const GdnArgs& a, hipStream_t s);
+void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hipStream_t s);
 
 // ---- synthetic weights / utility ----
 // dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))

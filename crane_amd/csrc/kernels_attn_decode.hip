@@ -1,0 +1,295 @@
+// Paged split-KV decode attention (GQA-grouped) for head_dim 128 (Qwen3) and 256 (Qwen3.5/3.8).
+//
+//   prologue : per-head RMSNorm(q), RMSNorm(k) BEFORE RoPE (qwen3/modeling.rs:341-359;
+//              qwen3_5/modeling.rs:464-468 with the (1+w) weights folded at load), rotate-half RoPE
+//              over the first `rot` dims only (rot == D for Qwen3; partial MRoPE, rot = D/4, for
+//              Qwen3.5: qwen3_5/modeling.rs:263-279), q scaled by 1/sqrt(D), K/V appended to the
+//              paged cache in the model dtype (modules/kv_cache.rs:38-101, qwen3_5/kv_cache.rs:92-97)
+//   main     : online softmax over this block's tokens (the math of candle's cpu flash_attn used at
+//              qwen3/modeling.rs:380-420; GQA by integer division)
+//   combine  : merge the nsplit partials; Qwen3.5 multiplies by sigmoid(gate) here
+//              (qwen3_5/modeling.rs:516-522)
+//   layout   : K/V page = [Hkv][PAGE][D]; a token row (D*2 bytes) is read by D/8 lanes x 16 B,
+//              64/(D/8) rows per wave, 4 waves per block; grid (nsplit, Hkv).
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+template <int D, int NREP, bool KVF32>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
+    constexpr int LPR = D / 8;            // lanes per token row
+    constexpr int RPW = 64 / LPR;         // rows per wave
+    constexpr int CT = 4 * RPW;           // tokens per block chunk
+    constexpr int EPL = D / 64;           // prologue elements per lane
+    __shared__ __attribute__((aligned(16))) float qs[NREP][D];
+    __shared__ __attribute__((aligned(16))) float knew[D];
+    __shared__ __attribute__((aligned(16))) float vnew[D];
+    __shared__ __attribute__((aligned(16))) float tmp[4][D];        // per-wave scratch for the rope pairing
+    __shared__ float red_m[CT][NREP];
+    __shared__ float red_l[CT][NREP];
+    __shared__ __attribute__((aligned(16))) float red_o[CT][NREP][D];
+
+    const int split = blockIdx.x, kvh = blockIdx.y, nsplit = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane / LPR, sub = lane % LPR, dimbase = sub * 8;
+    const int Hq = a.Hkv * NREP;
+
+    // Token -> block mapping is INTERLEAVED: chunk j of split s covers tokens
+    // [CT*(s + nsplit*j), +CT).  The first two chunks of every block are known without reading
+    // `pos`: their block-table entries and K/V rows are requested first (pos, q, RoPE rows load
+    // meanwhile); validity (t <= pos) is a mask.  Perfectly balanced for any context length.
+    const int tok_in_chunk = wave * RPW + r;
+    auto kv_off = [&](int t) -> size_t {
+        int pi = t / a.page;
+        pi = pi < a.max_pages ? pi : a.max_pages - 1;     // speculative loads stay inside the table
+        const int page = a.block_table[pi];
+        return ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + dimbase;
+    };
+    struct KV8 { u32x4 a, b; };
+    auto ld_kv = [&](const void* pool, size_t off) -> KV8 {
+        KV8 v;
+        if (KVF32) { v.a = ld16((const float*)pool + off); v.b = ld16((const float*)pool + off + 4); }
+        else { v.a = ld16((const uint16_t*)pool + off); v.b = v.a; }
+        return v;
+    };
+    KV8 kq[2], vq[2];
+    int tt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        tt[u] = CT * (split + nsplit * u) + tok_in_chunk;
+        const size_t off = kv_off(tt[u]);
+        kq[u] = ld_kv(a.kpool, off);
+        vq[u] = ld_kv(a.vpool, off);
+    }
+    const int pos = a.st->pos;
+    const int L = pos + 1;
+    const bool owner = ((pos / CT) % nsplit) == split;
+    const int rot = a.rot_dim, hrot = rot >> 1;
+
+    // ---- prologue: q heads of this group, new k, new v (one wave per item) ----
+    for (int item = wave; item < NREP + 2; item += 4) {
+        const float* src;
+        const float* nw = nullptr;
+        if (item < NREP) { src = a.qkv + a.q_off + (size_t)(kvh * NREP + item) * D; nw = a.qnw; }
+        else if (item == NREP) { src = a.qkv + a.k_off + (size_t)kvh * D; nw = a.knw; }
+        else { src = a.qkv + a.v_off + (size_t)kvh * D; }
+        float xv[EPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { xv[j] = src[lane + 64 * j]; ss += xv[j] * xv[j]; }
+        if (item <= NREP) {
+            if (nw != nullptr) {
+                ss = wave_sum(ss);
+                const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) xv[j] = xv[j] * rr * nw[lane + 64 * j];
+            }
+            // rotate-half inside the first `rot` dims: partner of d is d +/- rot/2
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) tmp[wave][lane + 64 * j] = xv[j];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int d = lane + 64 * j;
+                if (d < rot) {
+                    const int i = d < hrot ? d : d - hrot;
+                    const float c = a.cos[(size_t)pos * hrot + i], s = a.sin[(size_t)pos * hrot + i];
+                    const float lo = tmp[wave][i], hi = tmp[wave][i + hrot];
+                    xv[j] = d < hrot ? lo * c - hi * s : lo * s + hi * c;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (item < NREP) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) qs[item][lane + 64 * j] = xv[j] * a.scale;
+        } else {
+            float* dst = (item == NREP) ? knew : vnew;
+            void* pool = (item == NREP) ? a.kpool : a.vpool;
+            const size_t eoff = owner ? ((size_t)(a.block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int d = lane + 64 * j;
+                if (KVF32) {
+                    dst[d] = xv[j];
+                    if (owner) ((float*)pool)[eoff + d] = xv[j];
+                } else {
+                    const uint16_t b = f32_to_bf16(xv[j]);
+                    dst[d] = bf16_to_f32(b);
+                    if (owner) ((uint16_t*)pool)[eoff + d] = b;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    float qr[NREP][8];
+#pragma unroll
+    for (int h = 0; h < NREP; ++h) {
+        const f32x4 q0 = *(const f32x4*)&qs[h][dimbase];
+        const f32x4 q1 = *(const f32x4*)&qs[h][dimbase + 4];
+        qr[h][0] = q0[0]; qr[h][1] = q0[1]; qr[h][2] = q0[2]; qr[h][3] = q0[3];
+        qr[h][4] = q1[0]; qr[h][5] = q1[1]; qr[h][6] = q1[2]; qr[h][7] = q1[3];
+    }
+    float m[NREP], l[NREP], acc[NREP][8];
+#pragma unroll
+    for (int h = 0; h < NREP; ++h) {
+        m[h] = -INFINITY; l[h] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+    }
+
+    auto consume = [&](const KV8& kqv, const KV8& vqv, int t) {
+        const bool valid = t < L;
+        float kf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (KVF32) {
+                kf[e] = __uint_as_float(kqv.a[e]); kf[4 + e] = __uint_as_float(kqv.b[e]);
+                vf[e] = __uint_as_float(vqv.a[e]); vf[4 + e] = __uint_as_float(vqv.b[e]);
+            } else {
+                kf[2 * e] = bf16_lo(kqv.a[e]); kf[2 * e + 1] = bf16_hi(kqv.a[e]);
+                vf[2 * e] = bf16_lo(vqv.a[e]); vf[2 * e + 1] = bf16_hi(vqv.a[e]);
+            }
+        }
+        if (t == pos) {   // the token appended by this very step: values from LDS
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[e] = knew[dimbase + e]; vf[e] = vnew[dimbase + e]; }
+        }
+#pragma unroll
+        for (int h = 0; h < NREP; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qr[h][e] * kf[e];
+            s = row16_sum(s);
+            if (LPR == 32) s += __shfl_xor(s, 16);
+            if (valid) {
+                const float mn = fmaxf(m[h], s);
+                const float alpha = expf(m[h] - mn);
+                const float p = expf(s - mn);
+                l[h] = l[h] * alpha + p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[h][e] = acc[h][e] * alpha + p * vf[e];
+                m[h] = mn;
+            }
+        }
+    };
+    consume(kq[0], vq[0], tt[0]);
+    consume(kq[1], vq[1], tt[1]);
+    // remaining chunks (long contexts): two chunks per iteration, block-uniform bounds
+    for (int j = 2; CT * (split + nsplit * j) < L; j += 2) {
+        const bool second = CT * (split + nsplit * (j + 1)) < L;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            tt[u] = CT * (split + nsplit * (j + u)) + tok_in_chunk;
+            if (u == 0 || second) {
+                const size_t off = kv_off(tt[u]);
+                kq[u] = ld_kv(a.kpool, off);
+                vq[u] = ld_kv(a.vpool, off);
+            }
+        }
+        consume(kq[0], vq[0], tt[0]);
+        if (second) consume(kq[1], vq[1], tt[1]);
+    }
+
+    // ---- combine the CT (wave,row) streams of this block ----
+    const int slot = wave * RPW + r;
+#pragma unroll
+    for (int h = 0; h < NREP; ++h) {
+        if (sub == 0) { red_m[slot][h] = m[h]; red_l[slot][h] = l[h]; }
+        *(f32x4*)&red_o[slot][h][dimbase] = (f32x4){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+        *(f32x4*)&red_o[slot][h][dimbase + 4] = (f32x4){acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
+    }
+    __syncthreads();
+    for (int it = tid; it < NREP * D; it += 256) {
+        const int h = it / D, d = it % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) M = fmaxf(M, red_m[i][h]);
+        float O = 0.f, Ls = 0.f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const float w = expf(red_m[i][h] - M);
+                O += w * red_o[i][h][d];
+                Ls += w * red_l[i][h];
+            }
+        }
+        const size_t ph = (size_t)(kvh * NREP + h) * nsplit + split;
+        a.part_o[ph * D + d] = O;
+        if (d == 0) { a.part_ml[ph * 2] = M; a.part_ml[ph * 2 + 1] = Ls; }
+    }
+}
+
+// grid = Hq, block = 256: out[h, d] = sum_s e^{m_s-M} o_s[d] / sum_s e^{m_s-M} l_s  (* sigmoid(gate))
+template <int D>
+__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ part_o,
+                                                                  const float* __restrict__ part_ml,
+                                                                  const float* __restrict__ gate,
+                                                                  float* __restrict__ out, int nsplit) {
+    constexpr int NH = 256 / D;                  // thread groups that split the `s` range
+    __shared__ float w_s[64];
+    __shared__ float inv_l;
+    __shared__ float half_o[D];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        float mm = -INFINITY, ll = 0.f;
+        if (lane < nsplit) {
+            const u32x2 v = *(const u32x2*)(part_ml + ((size_t)h * nsplit + lane) * 2);
+            mm = __uint_as_float(v[0]); ll = __uint_as_float(v[1]);
+        }
+        const float M = wave_max(mm);
+        const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
+        const float Ls = wave_sum(w * ll);
+        w_s[lane] = w;
+        if (lane == 0) inv_l = 1.0f / Ls;
+    }
+    __syncthreads();
+    const int d = tid % D, grp = tid / D;
+    const int per = (nsplit + NH - 1) / NH;
+    const int s0 = grp * per, s1 = min(nsplit, s0 + per);
+    float O = 0.f;
+    const float* po = part_o + (size_t)h * nsplit * D + d;
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) O += w_s[s] * po[(size_t)s * D];
+    if (NH == 2) {
+        if (grp) half_o[d] = O;
+        __syncthreads();
+        if (grp) return;
+        O += half_o[d];
+    }
+    float v = O * inv_l;
+    if (gate != nullptr) v *= 1.0f / (1.0f + expf(-gate[(size_t)h * D + d]));
+    out[(size_t)h * D + d] = v;
+}
+
+template <int D>
+static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, hipStream_t s) {
+    dim3 grid(nsplit, a.Hkv), block(256);
+#define CM_ATTN_CASE(N) \
+    case N: if (kv_f32) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((attn_decode_split_kernel<D, N, false>), grid, block, 0, s, a); return true;
+    switch (nrep) {
+        CM_ATTN_CASE(1) CM_ATTN_CASE(2) CM_ATTN_CASE(3) CM_ATTN_CASE(4) CM_ATTN_CASE(6) CM_ATTN_CASE(8)
+        default: return false;
+    }
+#undef CM_ATTN_CASE
+}
+
+bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s) {
+    if (D == 128) {
+        if (!launch_split<128>(a, nrep, nsplit, kv_f32, s)) return false;
+        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep), dim3(256), 0, s, a.part_o, a.part_ml,
+                           a.gate, out, nsplit);
+    } else if (D == 256) {
+        if (!launch_split<256>(a, nrep, nsplit, kv_f32, s)) return false;
+        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep), dim3(256), 0, s, a.part_o, a.part_ml,
+                           a.gate, out, nsplit);
+    } else {
+        return false;
+    }
+    return true;
+}
+
+}  // namespace cm

@@ -31,8 +31,8 @@ __global__ void embed_row_kernel(const uint16_t* __restrict__ emb, const StepSta
     }
 }
 
-__global__ void set_state_kernel(StepState* st, uint32_t token, int32_t pos) {
-    st->token = token; st->pos = pos;
+__global__ void set_state_kernel(StepState* st, uint32_t token, int32_t pos, int32_t slot) {
+    st->token = token; st->pos = pos; st->slot = slot;
 }
 
 // =====================================================================================
@@ -87,12 +87,11 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
 
     // ---- stage x (L2-resident, tiny) into LDS; fused RMSNorm statistics ----
     float ss = 0.f;
-    auto stage_one = [&](int k4, const f32x4& vin, const u32x2& win) {
+    auto stage_one = [&](int k4, const f32x4& vin, const f32x4& win) {
         f32x4 v = vin;
         if (PRO == PRO_RMSNORM) {
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-            v[0] *= bf16_lo(win[0]); v[1] *= bf16_hi(win[0]);
-            v[2] *= bf16_lo(win[1]); v[3] *= bf16_hi(win[1]);
+            v[0] *= win[0]; v[1] *= win[1]; v[2] *= win[2]; v[3] *= win[3];
         }
         const int k = k4 << 2;
         const int c = k >> 9, j = k & 511;
@@ -101,19 +100,19 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
     const int n4 = K >> 2;                       // K % 8 == 0
     int k4 = tid;
     for (; k4 + 768 < n4; k4 += 1024) {          // 4 independent loads in flight per thread
-        f32x4 v[4]; u32x2 w[4];
+        f32x4 v[4]; f32x4 w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = *(const f32x4*)(a.x + ((k4 + i * 256) << 2));
-            if (PRO == PRO_RMSNORM) w[i] = *(const u32x2*)(a.nw + ((k4 + i * 256) << 2));
+            if (PRO == PRO_RMSNORM) w[i] = *(const f32x4*)(a.nw + ((k4 + i * 256) << 2));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) stage_one(k4 + i * 256, v[i], w[i]);
     }
     for (; k4 < n4; k4 += 256) {
         f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
-        u32x2 w = {0, 0};
-        if (PRO == PRO_RMSNORM) w = *(const u32x2*)(a.nw + (k4 << 2));
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (PRO == PRO_RMSNORM) w = *(const f32x4*)(a.nw + (k4 << 2));
         stage_one(k4, v, w);
     }
     if (KGUARD) {                                 // zero the K..Kpad tail
@@ -253,237 +252,6 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
 }
 
 // =====================================================================================
-// paged split-KV decode attention (GQA-grouped), D = 128
-//   prologue : per-head RMSNorm(q), RMSNorm(k) BEFORE RoPE (modeling.rs:341-359), rotate-half
-//              RoPE at `pos` (rotary.rs:372-409), scale q by 1/sqrt(D) (modeling.rs:465),
-//              append k,v (bf16 = model dtype) to the paged cache (kv_cache.rs:38-101)
-//   main     : online softmax over this block's token range (the math of candle's cpu
-//              flash_attn used at modeling.rs:380-420; GQA by integer division)
-//   layout   : K/V page = [Hkv][PAGE][D] bf16; a 16-lane row reads one token row
-//              (16 lanes x 16 B = 256 B contiguous), 4 rows per wave, 4 waves per block.
-// grid (nsplit, Hkv); partial (m, l, o) per (head, split) -> attn_decode_combine_kernel.
-// =====================================================================================
-template <int NREP, bool KVF32>
-__global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
-    constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) float qs[NREP][D];
-    __shared__ __attribute__((aligned(16))) float knew[D];
-    __shared__ __attribute__((aligned(16))) float vnew[D];
-    __shared__ float red_m[16][NREP];
-    __shared__ float red_l[16][NREP];
-    __shared__ __attribute__((aligned(16))) float red_o[16][NREP][D];
-
-    const int split = blockIdx.x, kvh = blockIdx.y, nsplit = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane >> 4, sub = lane & 15, dimbase = sub * 8;
-    const int Hq = a.Hkv * NREP;
-
-    // Token -> block mapping is INTERLEAVED: chunk j of split s covers tokens
-    // [16*(s + nsplit*j), +16), token = chunk base + 4*wave + row.  The first two chunks of
-    // every block are therefore known without reading `pos`, so their block-table entries and
-    // K/V rows are requested before anything else (pos, q, RoPE tables load meanwhile);
-    // validity (t <= pos) is applied as a mask afterwards.  Perfectly balanced for any L.
-    const int tok_in_chunk = wave * 4 + r;
-    auto kv_off = [&](int t) -> size_t {
-        int pi = t / a.page;
-        pi = pi < a.max_pages ? pi : a.max_pages - 1;     // speculative loads stay inside the table
-        const int page = a.block_table[pi];
-        return ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + dimbase;
-    };
-    // KV element type: bf16 (model dtype, default) or f32 (cm_opts.kv_dtype = CM_KV_F32)
-    struct KV8 { u32x4 a, b; };
-    auto ld_kv = [&](const void* pool, size_t off) -> KV8 {
-        KV8 r;
-        if (KVF32) { r.a = ld16((const float*)pool + off); r.b = ld16((const float*)pool + off + 4); }
-        else { r.a = ld16((const uint16_t*)pool + off); r.b = r.a; }
-        return r;
-    };
-    KV8 kq[2], vq[2];
-    int tt[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        tt[u] = 16 * (split + nsplit * u) + tok_in_chunk;
-        const size_t off = kv_off(tt[u]);
-        kq[u] = ld_kv(a.kpool, off);
-        vq[u] = ld_kv(a.vpool, off);
-    }
-    const int pos = a.st->pos;
-    const int L = pos + 1;
-    const bool owner = ((pos >> 4) % nsplit) == split;
-
-    // ---- prologue: q heads of this group, new k, new v ----
-    for (int item = wave; item < NREP + 2; item += 4) {
-        const float* src;
-        const uint16_t* nw = nullptr;
-        if (item < NREP) { src = a.qkv + (size_t)(kvh * NREP + item) * D; nw = a.qnw; }
-        else if (item == NREP) { src = a.qkv + (size_t)(Hq + kvh) * D; nw = a.knw; }
-        else { src = a.qkv + (size_t)(Hq + a.Hkv + kvh) * D; }
-        float x1 = src[lane], x2 = src[lane + 64];
-        if (item <= NREP) {
-            const float c = a.cos[(size_t)pos * (D / 2) + lane];
-            const float s = a.sin[(size_t)pos * (D / 2) + lane];
-            if (nw != nullptr) {
-                const float w1 = bf16_to_f32(nw[lane]), w2 = bf16_to_f32(nw[lane + 64]);
-                float ss = wave_sum(x1 * x1 + x2 * x2);
-                float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
-                x1 = x1 * rr * w1;
-                x2 = x2 * rr * w2;
-            }
-            const float o1 = x1 * c - x2 * s;
-            const float o2 = x1 * s + x2 * c;
-            x1 = o1; x2 = o2;
-        }
-        if (item < NREP) {
-            qs[item][lane] = x1 * a.scale;
-            qs[item][lane + 64] = x2 * a.scale;
-        } else {
-            float* dst = (item == NREP) ? knew : vnew;
-            void* pool = (item == NREP) ? a.kpool : a.vpool;
-            const size_t eoff = owner ? ((size_t)(a.block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
-            if (KVF32) {
-                dst[lane] = x1; dst[lane + 64] = x2;
-                if (owner) { float* p = (float*)pool + eoff; p[lane] = x1; p[lane + 64] = x2; }
-            } else {
-                const uint16_t b1 = f32_to_bf16(x1), b2 = f32_to_bf16(x2);
-                dst[lane] = bf16_to_f32(b1);
-                dst[lane + 64] = bf16_to_f32(b2);
-                if (owner) { uint16_t* p = (uint16_t*)pool + eoff; p[lane] = b1; p[lane + 64] = b2; }
-            }
-        }
-    }
-    __syncthreads();
-
-    float qr[NREP][8];
-#pragma unroll
-    for (int h = 0; h < NREP; ++h) {
-        const f32x4 q0 = *(const f32x4*)&qs[h][dimbase];
-        const f32x4 q1 = *(const f32x4*)&qs[h][dimbase + 4];
-        qr[h][0] = q0[0]; qr[h][1] = q0[1]; qr[h][2] = q0[2]; qr[h][3] = q0[3];
-        qr[h][4] = q1[0]; qr[h][5] = q1[1]; qr[h][6] = q1[2]; qr[h][7] = q1[3];
-    }
-    float m[NREP], l[NREP], acc[NREP][8];
-#pragma unroll
-    for (int h = 0; h < NREP; ++h) {
-        m[h] = -INFINITY; l[h] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
-    }
-
-    auto consume = [&](const KV8& kqv, const KV8& vqv, int t) {
-        const bool valid = t < L;
-        float kf[8], vf[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (KVF32) {
-                kf[e] = __uint_as_float(kqv.a[e]); kf[4 + e] = __uint_as_float(kqv.b[e]);
-                vf[e] = __uint_as_float(vqv.a[e]); vf[4 + e] = __uint_as_float(vqv.b[e]);
-            } else {
-                kf[2 * e] = bf16_lo(kqv.a[e]); kf[2 * e + 1] = bf16_hi(kqv.a[e]);
-                vf[2 * e] = bf16_lo(vqv.a[e]); vf[2 * e + 1] = bf16_hi(vqv.a[e]);
-            }
-        }
-        if (t == pos) {   // the token appended by this very step: values from LDS
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[e] = knew[dimbase + e]; vf[e] = vnew[dimbase + e]; }
-        }
-#pragma unroll
-        for (int h = 0; h < NREP; ++h) {
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += qr[h][e] * kf[e];
-            s = row16_sum(s);
-            if (valid) {
-                const float mn = fmaxf(m[h], s);
-                const float alpha = expf(m[h] - mn);
-                const float p = expf(s - mn);
-                l[h] = l[h] * alpha + p;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[h][e] = acc[h][e] * alpha + p * vf[e];
-                m[h] = mn;
-            }
-        }
-    };
-    consume(kq[0], vq[0], tt[0]);
-    consume(kq[1], vq[1], tt[1]);
-    // remaining chunks (long contexts): two chunks per iteration, block-uniform bounds
-    for (int j = 2; 16 * (split + nsplit * j) < L; j += 2) {
-        const bool second = 16 * (split + nsplit * (j + 1)) < L;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            tt[u] = 16 * (split + nsplit * (j + u)) + tok_in_chunk;
-            if (u == 0 || second) {
-                const size_t off = kv_off(tt[u]);
-                kq[u] = ld_kv(a.kpool, off);
-                vq[u] = ld_kv(a.vpool, off);
-            }
-        }
-        consume(kq[0], vq[0], tt[0]);
-        if (second) consume(kq[1], vq[1], tt[1]);
-    }
-
-    // ---- combine the 16 (wave,row) streams of this block ----
-    const int slot = wave * 4 + r;
-#pragma unroll
-    for (int h = 0; h < NREP; ++h) {
-        if (sub == 0) { red_m[slot][h] = m[h]; red_l[slot][h] = l[h]; }
-        *(f32x4*)&red_o[slot][h][dimbase] = (f32x4){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
-        *(f32x4*)&red_o[slot][h][dimbase + 4] = (f32x4){acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
-    }
-    __syncthreads();
-    for (int it = tid; it < NREP * D; it += 256) {
-        const int h = it / D, d = it % D;
-        float M = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) M = fmaxf(M, red_m[i][h]);
-        float O = 0.f, Ls = 0.f;
-        if (M > -INFINITY) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float w = expf(red_m[i][h] - M);
-                O += w * red_o[i][h][d];
-                Ls += w * red_l[i][h];
-            }
-        }
-        const size_t ph = (size_t)(kvh * NREP + h) * nsplit + split;
-        a.part_o[ph * D + d] = O;
-        if (d == 0) { a.part_ml[ph * 2] = M; a.part_ml[ph * 2 + 1] = Ls; }
-    }
-}
-
-// grid = Hq, block = 256: out[h, d] = sum_s e^{m_s-M} o_s[d] / sum_s e^{m_s-M} l_s   (nsplit <= 64)
-__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ part_o,
-                                                                  const float* __restrict__ part_ml,
-                                                                  float* __restrict__ out, int nsplit) {
-    constexpr int D = 128;
-    __shared__ float w_s[64];
-    __shared__ float inv_l;
-    __shared__ float half_o[D];
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (tid < 64) {
-        float mm = -INFINITY, ll = 0.f;
-        if (lane < nsplit) {
-            const u32x2 v = *(const u32x2*)(part_ml + ((size_t)h * nsplit + lane) * 2);
-            mm = __uint_as_float(v[0]); ll = __uint_as_float(v[1]);
-        }
-        const float M = wave_max(mm);
-        const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
-        const float Ls = wave_sum(w * ll);
-        w_s[lane] = w;
-        if (lane == 0) inv_l = 1.0f / Ls;
-    }
-    __syncthreads();
-    const int d = tid & (D - 1), half = tid >> 7;
-    const int s0 = half * ((nsplit + 1) / 2), s1 = half ? nsplit : (nsplit + 1) / 2;
-    float O = 0.f;
-    const float* po = part_o + (size_t)h * nsplit * D + d;
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) O += w_s[s] * po[(size_t)s * D];
-    if (half) half_o[d] = O;
-    __syncthreads();
-    if (!half) out[(size_t)h * D + d] = (O + half_o[d]) * inv_l;
-}
-
-// =====================================================================================
 // host-side launchers
 // =====================================================================================
 // (rows per group, chunks per batch, software-pipelined) per K-shape class; overridable for
@@ -552,27 +320,12 @@ void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s) {
 void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s) {
     hipLaunchKernelGGL(embed_row_kernel, dim3((H / 4 + 255) / 256), dim3(256), 0, s, emb, st, x, H, V);
 }
-void launch_set_state(StepState* st, uint32_t token, int32_t pos, hipStream_t s) {
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, token, pos);
+void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, hipStream_t s) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, token, pos, slot);
 }
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, hipStream_t s) {
     hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pmax, pidx, n, st, ring, ring_mask, advance);
-}
-
-bool launch_attn_decode(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s) {
-    dim3 grid(nsplit, a.Hkv), block(256);
-#define CM_ATTN_CASE(N) \
-    case N: if (kv_f32) hipLaunchKernelGGL((attn_decode_split_kernel<N, true>), grid, block, 0, s, a); \
-            else hipLaunchKernelGGL((attn_decode_split_kernel<N, false>), grid, block, 0, s, a); break;
-    switch (nrep) {
-        CM_ATTN_CASE(1) CM_ATTN_CASE(2) CM_ATTN_CASE(3) CM_ATTN_CASE(4) CM_ATTN_CASE(6) CM_ATTN_CASE(8)
-        default: return false;
-    }
-#undef CM_ATTN_CASE
-    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(a.Hkv * nrep), dim3(256), 0, s,
-                       a.part_o, a.part_ml, out, nsplit);
-    return true;
 }
 
 }  // namespace cm

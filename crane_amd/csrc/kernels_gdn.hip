@@ -1,0 +1,128 @@
+// Gated Delta Net (Qwen 3.5 / 3.6 / 3.8 linear-attention layers) -- decode step and sequential prefill.
+//
+// One kernel per layer does everything between the input projection GEMV/GEMM and the output
+// projection (reference: ops/gdn/layer.rs:122-182 = ~12 candle launches for the conv alone,
+// ops/gdn/conv.rs:63-73):
+//   causal depthwise conv1d (k = 4) + SiLU with rolling state        ops/gdn/conv.rs:23-101
+//   split q|k|v, key-head -> value-head expansion (HF "Interleaved")  ops/gdn/layer.rs:184-238
+//   L2-norm(q), L2-norm(k) (eps 1e-6), q * 1/sqrt(K)                   ops/gdn/backend.rs:26-56,100-108
+//   beta = sigmoid(b), g = -exp(A_log) * softplus(a + dt_bias)         ops/gdn/backend.rs:197-211
+//   S *= exp(g); kv = S^T k; delta = (v - kv) beta; S += k (x) delta; y = S^T q   backend.rs:90-156,
+//                                                                      kernels/cuda/gdn.cu:83-124
+//   RmsNormGated: rms_norm(y, w) * silu(z)  (plain weight)             ops/gdn/norm.rs:39-45
+// State is f32 (ops/gdn/cache.rs:12-13).  HBM-bound at decode: 2 * K * V * 4 B per value head per
+// token (read + write of the state), 0.5 flop/byte.
+//
+// Layout: one block per value head, one thread per state COLUMN v (V = 128 threads); the column's
+// K = 128 state values live in registers across the two passes (kv needs all of k before the
+// update); S[k][v] is stored [K][V] so a wave reads/writes 256 contiguous bytes per k.
+// Conv state is double-buffered by position parity so that the blocks of one key-head group (which
+// share q/k channels) never read a window another block is rolling.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// grid = NV value heads, block = 128 threads.  Processes S tokens sequentially (S = 1 at decode).
+__global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
+    constexpr int K = 128, V = 128, KER = 4;
+    __shared__ float qs[K], ks[K];
+    __shared__ float red[8];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = h / a.vpg;                                  // Interleaved: value head h uses key head h / vpg
+    const int cq = kh * K + tid, ck = a.key_dim + kh * K + tid, cv = 2 * a.key_dim + h * V + tid;
+    const int conv_dim = 2 * a.key_dim + a.NV * V;
+    const int proj_stride = a.proj_stride;
+    const bool writer = (h % a.vpg) == 0;                      // one block per key-head group rolls the q/k windows
+
+    // conv weights of my three channels, state column in registers
+    float wq[KER], wk[KER], wv[KER];
+#pragma unroll
+    for (int j = 0; j < KER; ++j) { wq[j] = a.conv_w[cq * KER + j]; wk[j] = a.conv_w[ck * KER + j]; wv[j] = a.conv_w[cv * KER + j]; }
+    const int start_pos = a.st ? a.st->pos : a.start_pos;
+    const int slot = a.st ? a.st->slot : a.slot;
+    float* conv_state = a.conv_pool + ((size_t)slot * a.gdn_layers + a.layer_idx) * 2 * conv_dim * (KER - 1);
+    const int par_in = start_pos & 1;
+    const float* cs_in = conv_state + (size_t)par_in * conv_dim * (KER - 1);
+    float hq[KER - 1], hk[KER - 1], hv[KER - 1];
+#pragma unroll
+    for (int j = 0; j < KER - 1; ++j) {
+        hq[j] = cs_in[cq * (KER - 1) + j]; hk[j] = cs_in[ck * (KER - 1) + j]; hv[j] = cs_in[cv * (KER - 1) + j];
+    }
+    float* Sg = a.state_pool + (((size_t)slot * a.gdn_layers + a.layer_idx) * a.NV + h) * K * V;
+    float S[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) S[k] = Sg[k * V + tid];
+    const float neg_exp_a = -expf(a.A_log[h]);
+    const float dtb = a.dt_bias[h];
+    const float gw = a.gnorm_w[tid];
+    const float qscale = 0.08838834764831845f;                 // 1/sqrt(128)
+
+    for (int t = 0; t < a.S; ++t) {
+        const float* pr = a.proj + (size_t)t * proj_stride;
+        // ---- conv + SiLU; roll the windows ----
+        const float xq = pr[cq], xk = pr[ck], xv = pr[cv];
+        float q = hq[0] * wq[0] + hq[1] * wq[1] + hq[2] * wq[2] + xq * wq[3];
+        float k = hk[0] * wk[0] + hk[1] * wk[1] + hk[2] * wk[2] + xk * wk[3];
+        float v = hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + xv * wv[3];
+        hq[0] = hq[1]; hq[1] = hq[2]; hq[2] = xq;
+        hk[0] = hk[1]; hk[1] = hk[2]; hk[2] = xk;
+        hv[0] = hv[1]; hv[1] = hv[2]; hv[2] = xv;
+        q = silu_f(q); k = silu_f(k); v = silu_f(v);
+        // ---- L2 norms over the key head (128 threads = 2 waves) ----
+        float sq = wave_sum(q * q), sk = wave_sum(k * k);
+        __syncthreads();                                        // previous iteration done with qs/ks/red
+        if (lane == 0) { red[wave] = sq; red[2 + wave] = sk; }
+        __syncthreads();
+        q = q / sqrtf(red[0] + red[1] + 1e-6f) * qscale;
+        k = k / sqrtf(red[2] + red[3] + 1e-6f);
+        qs[tid] = q; ks[tid] = k;
+        // ---- gates ----
+        const float beta = 1.0f / (1.0f + expf(-pr[conv_dim + a.NV * V + h]));
+        const float av = pr[conv_dim + a.NV * V + a.NV + h] + dtb;
+        const float g = neg_exp_a * logf(1.0f + expf(av));
+        const float decay = expf(g);
+        __syncthreads();
+        // ---- recurrence on my column ----
+        float kv = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) { S[kk] *= decay; kv += S[kk] * ks[kk]; }
+        const float delta = (v - kv) * beta;
+        float y = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) { S[kk] += ks[kk] * delta; y += S[kk] * qs[kk]; }
+        // ---- gated RMSNorm over the value head ----
+        const float sy = wave_sum(y * y);
+        if (lane == 0) red[4 + wave] = sy;
+        __syncthreads();
+        const float rms = 1.0f / sqrtf((red[4] + red[5]) / (float)V + a.eps);
+        const float z = pr[conv_dim + h * V + tid];
+        a.out[(size_t)t * a.out_stride + h * V + tid] = y * rms * gw * silu_f(z);
+    }
+    // ---- write back state and conv windows (other parity buffer) ----
+#pragma unroll
+    for (int k = 0; k < K; ++k) Sg[k * V + tid] = S[k];
+    float* cs_out = conv_state + (size_t)((start_pos + a.S) & 1) * conv_dim * (KER - 1);
+#pragma unroll
+    for (int j = 0; j < KER - 1; ++j) {
+        if (writer) { cs_out[cq * (KER - 1) + j] = hq[j]; cs_out[ck * (KER - 1) + j] = hk[j]; }
+        cs_out[cv * (KER - 1) + j] = hv[j];
+    }
+}
+
+void launch_gdn(const GdnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gdn_kernel, dim3(a.NV), dim3(128), 0, s, a);
+}
+
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n, float add) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_to_f32(src[i]) + add;
+}
+void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hipStream_t s) {
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, src, dst, n, add);
+}
+
+}  // namespace cm

@@ -42,7 +42,7 @@ __device__ __forceinline__ void split_store4(uint16_t* hi, uint16_t* lo, size_t 
 }
 
 // one block per token row: out = x * w / sqrt(mean(x^2)+eps) -> bf16 hi (+ lo)
-__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const uint16_t* __restrict__ w,
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
                                                            int H, float eps) {
     __shared__ float red[4];
@@ -59,9 +59,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
     const float r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)H + eps);
     for (int i = tid * 4; i < H; i += 1024) {
         const f32x4 v = *(const f32x4*)(xr + i);
-        const u32x2 ww = *(const u32x2*)(w + i);
-        const float o[4] = {v[0] * r * bf16_lo(ww[0]), v[1] * r * bf16_hi(ww[0]), v[2] * r * bf16_lo(ww[1]),
-                            v[3] * r * bf16_hi(ww[1])};
+        const f32x4 ww = *(const f32x4*)(w + i);
+        const float o[4] = {v[0] * r * ww[0], v[1] * r * ww[1], v[2] * r * ww[2], v[3] * r * ww[3]};
         split_store4(hi, lo, (size_t)row * H + i, o);
     }
 }
@@ -78,12 +77,12 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
     float x1 = src[lane], x2 = src[lane + 64];
     const bool is_q = item < Hq, is_k = !is_q && item < Hq + Hkv;
     if (is_q || is_k) {
-        const uint16_t* nw = is_q ? a.qnw : a.knw;
+        const float* nw = is_q ? a.qnw : a.knw;
         if (nw) {
             const float ss = wave_sum(x1 * x1 + x2 * x2);
             const float r = 1.0f / sqrtf(ss / (float)D + a.eps);
-            x1 = x1 * r * bf16_to_f32(nw[lane]);
-            x2 = x2 * r * bf16_to_f32(nw[lane + 64]);
+            x1 = x1 * r * nw[lane];
+            x2 = x2 * r * nw[lane + 64];
         }
         const float c = a.cos[(size_t)pos * (D / 2) + lane], sn = a.sin[(size_t)pos * (D / 2) + lane];
         const float o1 = x1 * c - x2 * sn, o2 = x1 * sn + x2 * c;
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
 void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s) {
     hipLaunchKernelGGL(embed_rows_kernel, dim3(S), dim3(256), 0, s, emb, ids, x, H, V);
 }
-void launch_rmsnorm_rows(const float* x, const uint16_t* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
+void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
                          hipStream_t s) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, s, x, w, hi, lo, H, eps);
 }

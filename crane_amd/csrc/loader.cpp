@@ -32,6 +32,7 @@ struct Source {
     virtual void fetch(const std::string& name, int rows, int full_cols, int row0, int nrows, int col0, int ncols,
                        uint16_t* dst, size_t dst_stride) = 0;
     virtual bool has(const std::string& name) = 0;
+    virtual bool synthetic() const { return false; }
 };
 
 struct SynthSource : Source {
@@ -39,6 +40,7 @@ struct SynthSource : Source {
     uint64_t seed;
     SynthSource(Model& mm, uint64_t s) : m(mm), seed(s) {}
     bool has(const std::string&) override { return true; }
+    bool synthetic() const override { return true; }
     void spec(const std::string& name, double& std, float& off) {
         const Config& c = m.cfg;
         off = 0.f;
@@ -46,8 +48,14 @@ struct SynthSource : Source {
             const size_t n = strlen(suf);
             return name.size() >= n && name.compare(name.size() - n, n, suf) == 0;
         };
+        const bool hy = c.hybrid;
         if (ends("embed_tokens.weight")) std = 1.0;
-        else if (ends("norm.weight") || ends("layernorm.weight")) { std = 0.1; off = 1.0f; }
+        else if (ends("linear_attn.norm.weight")) { std = 0.1; off = 1.0f; }
+        else if (ends("norm.weight") || ends("layernorm.weight")) { std = 0.1; off = hy ? 0.0f : 1.0f; }
+        else if (ends("conv1d.weight")) std = 0.5;
+        else if (ends("A_log")) { std = 0.1; off = -2.0f; }
+        else if (ends("dt_bias")) std = 0.1;
+        else if (ends("linear_attn.out_proj.weight")) std = 1.0 / std::sqrt((double)c.value_dim());
         else if (ends("o_proj.weight")) std = 1.0 / std::sqrt((double)(c.Hq * c.D));
         else if (ends("down_proj.weight")) std = 1.0 / std::sqrt((double)c.I);
         else std = 1.0 / std::sqrt((double)c.H);      // q/k/v/gate/up/lm_head: fan_in = H
@@ -103,48 +111,99 @@ struct FileSource : Source {
     }
 };
 
+// small tensors the kernels want in f32 (norm weights with the Qwen3.5 "+1" folded in, conv taps, A_log, dt_bias):
+// fetched as bf16 like everything else, then widened on the device
+float* fetch_f32(Model& m, Source& src, const std::string& name, int n, float add) {
+    uint16_t* tmp = m.dalloc<uint16_t>((size_t)n);
+    src.fetch(name, 1, n, 0, 1, 0, n, tmp, (size_t)n);
+    float* out = m.dalloc<float>((size_t)n, true);
+    launch_bf16_to_f32(tmp, out, (size_t)n, add, m.stream);
+    return out;
+}
+
 void build(Model& m, Source& src) {
     const Config& c = m.cfg;
     const int H = c.H, D = c.D, I = c.I;
+    const float off = c.norm_off;
+    // Qwen3.5 checkpoints keep the LM under `model.language_model.` (VLM) or `model.` (text-only);
+    // prefix probing as qwen3_5/model.rs:65-74
+    std::string pre = "model.";
+    if (c.hybrid && !src.synthetic()) {
+        for (const char* cand : {"model.language_model.", "language_model.", "model.", ""}) {
+            if (src.has(std::string(cand) + "embed_tokens.weight")) { pre = cand; break; }
+        }
+    }
     m.embed = m.dalloc<uint16_t>((size_t)c.V * H, true);
-    src.fetch("model.embed_tokens.weight", c.V, H, 0, c.V, 0, H, m.embed, (size_t)H);
-    m.norm = m.dalloc<uint16_t>((size_t)H, true);
-    src.fetch("model.norm.weight", 1, H, 0, 1, 0, H, m.norm, (size_t)H);
+    src.fetch(pre + "embed_tokens.weight", c.V, H, 0, c.V, 0, H, m.embed, (size_t)H);
+    m.norm = fetch_f32(m, src, pre + "norm.weight", H, off);
     const int v_eff = std::max(0, std::min(m.V_l, c.V - m.v0));
-    const bool have_head = !c.tie && src.has("lm_head.weight");
-    if (!c.tie && !have_head) throw CmError(CM_ERR_IO, "tie_word_embeddings=false but lm_head.weight is missing");
+    std::string head_name = "lm_head.weight";
+    bool have_head = !c.tie && src.has(head_name);
+    if (!c.tie && !have_head && c.hybrid && src.has(pre + "lm_head.weight")) { head_name = pre + "lm_head.weight"; have_head = true; }
+    if (!c.tie && !have_head) {
+        if (c.hybrid) {}   // falls back to tied, like qwen3_5/model.rs:106-123
+        else throw CmError(CM_ERR_IO, "tie_word_embeddings=false but lm_head.weight is missing");
+    }
     if (have_head) {
         m.lm_head = m.dalloc<uint16_t>((size_t)std::max(1, v_eff) * H, true);
-        if (v_eff > 0) src.fetch("lm_head.weight", c.V, H, m.v0, v_eff, 0, H, m.lm_head, (size_t)H);
+        if (v_eff > 0) src.fetch(head_name, c.V, H, m.v0, v_eff, 0, H, m.lm_head, (size_t)H);
     } else {
         m.lm_head = m.embed + (size_t)m.v0 * H;     // tied: same tensor, no copy
     }
     m.layers.resize((size_t)c.L);
     const int qd = m.Hq_l * D, kd = m.Hkv_l * D;
+    int gdn_idx = 0;
     for (int li = 0; li < c.L; ++li) {
         LayerW& w = m.layers[(size_t)li];
-        const std::string p = "model.layers." + std::to_string(li) + ".";
-        w.qkv = m.dalloc<uint16_t>((size_t)(qd + 2 * kd) * H, true);
-        src.fetch(p + "self_attn.q_proj.weight", c.Hq * D, H, m.rank * qd, qd, 0, H, w.qkv, (size_t)H);
-        src.fetch(p + "self_attn.k_proj.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H, w.qkv + (size_t)qd * H, (size_t)H);
-        src.fetch(p + "self_attn.v_proj.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H, w.qkv + (size_t)(qd + kd) * H, (size_t)H);
-        w.o = m.dalloc<uint16_t>((size_t)H * qd, true);
-        src.fetch(p + "self_attn.o_proj.weight", H, c.Hq * D, 0, H, m.rank * qd, qd, w.o, (size_t)qd);
-        if (c.qk_norm && src.has(p + "self_attn.q_norm.weight")) {
-            w.qn = m.dalloc<uint16_t>((size_t)D, true);
-            w.kn = m.dalloc<uint16_t>((size_t)D, true);
-            src.fetch(p + "self_attn.q_norm.weight", 1, D, 0, 1, 0, D, w.qn, (size_t)D);
-            src.fetch(p + "self_attn.k_norm.weight", 1, D, 0, 1, 0, D, w.kn, (size_t)D);
+        const std::string p = pre + "layers." + std::to_string(li) + ".";
+        w.full = c.layer_full(li);
+        if (w.full && !c.hybrid) {
+            w.qkv = m.dalloc<uint16_t>((size_t)(qd + 2 * kd) * H, true);
+            src.fetch(p + "self_attn.q_proj.weight", c.Hq * D, H, m.rank * qd, qd, 0, H, w.qkv, (size_t)H);
+            src.fetch(p + "self_attn.k_proj.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H, w.qkv + (size_t)qd * H, (size_t)H);
+            src.fetch(p + "self_attn.v_proj.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H, w.qkv + (size_t)(qd + kd) * H, (size_t)H);
+        } else if (w.full) {
+            // q_proj rows are per head [q (D) | gate (D)] (qwen3_5/modeling.rs:428-455); HBM layout here is
+            // [all q | all gate | k | v] so q/gate are contiguous vectors for the attention kernel
+            w.qkv = m.dalloc<uint16_t>((size_t)(2 * qd + 2 * kd) * H, true);
+            for (int h = 0; h < c.Hq; ++h) {
+                src.fetch(p + "self_attn.q_proj.weight", c.Hq * 2 * D, H, h * 2 * D, D, 0, H, w.qkv + (size_t)h * D * H, (size_t)H);
+                src.fetch(p + "self_attn.q_proj.weight", c.Hq * 2 * D, H, h * 2 * D + D, D, 0, H, w.qkv + (size_t)(qd + h * D) * H, (size_t)H);
+            }
+            src.fetch(p + "self_attn.k_proj.weight", c.Hkv * D, H, 0, kd, 0, H, w.qkv + (size_t)(2 * qd) * H, (size_t)H);
+            src.fetch(p + "self_attn.v_proj.weight", c.Hkv * D, H, 0, kd, 0, H, w.qkv + (size_t)(2 * qd + kd) * H, (size_t)H);
+        }
+        if (w.full) {
+            w.o = m.dalloc<uint16_t>((size_t)H * qd, true);
+            src.fetch(p + "self_attn.o_proj.weight", H, c.Hq * D, 0, H, m.rank * qd, qd, w.o, (size_t)qd);
+            if (c.qk_norm && src.has(p + "self_attn.q_norm.weight")) {
+                w.qn = fetch_f32(m, src, p + "self_attn.q_norm.weight", D, off);
+                w.kn = fetch_f32(m, src, p + "self_attn.k_norm.weight", D, off);
+            }
+        } else {
+            w.gdn_idx = gdn_idx++;
+            const int cd = c.conv_dim(), vd = c.value_dim(), nv = c.NV;
+            const int rows = cd + vd + 2 * nv, rows_pad = (rows + 127) / 128 * 128;
+            w.in_proj = m.dalloc<uint16_t>((size_t)rows_pad * H, true);
+            CM_HIP(hipMemsetAsync(w.in_proj, 0, (size_t)rows_pad * H * sizeof(uint16_t), m.stream));
+            src.fetch(p + "linear_attn.in_proj_qkv.weight", cd, H, 0, cd, 0, H, w.in_proj, (size_t)H);
+            src.fetch(p + "linear_attn.in_proj_z.weight", vd, H, 0, vd, 0, H, w.in_proj + (size_t)cd * H, (size_t)H);
+            src.fetch(p + "linear_attn.in_proj_b.weight", nv, H, 0, nv, 0, H, w.in_proj + (size_t)(cd + vd) * H, (size_t)H);
+            src.fetch(p + "linear_attn.in_proj_a.weight", nv, H, 0, nv, 0, H, w.in_proj + (size_t)(cd + vd + nv) * H, (size_t)H);
+            w.out_proj = m.dalloc<uint16_t>((size_t)H * vd, true);
+            src.fetch(p + "linear_attn.out_proj.weight", H, vd, 0, H, 0, vd, w.out_proj, (size_t)vd);
+            w.conv_w = fetch_f32(m, src, p + "linear_attn.conv1d.weight", cd * c.conv_k, 0.f);   // [conv_dim, 1, k]
+            w.A_log = fetch_f32(m, src, p + "linear_attn.A_log", nv, 0.f);
+            w.dt_bias = fetch_f32(m, src, p + "linear_attn.dt_bias", nv, 0.f);
+            w.gnorm = fetch_f32(m, src, p + "linear_attn.norm.weight", c.Vd, 0.f);              // plain weight (norm.rs:39-45)
         }
         w.gate_up = m.dalloc<uint16_t>((size_t)2 * m.I_l * H, true);
         src.fetch(p + "mlp.gate_proj.weight", I, H, m.rank * m.I_l, m.I_l, 0, H, w.gate_up, (size_t)2 * H);
         src.fetch(p + "mlp.up_proj.weight", I, H, m.rank * m.I_l, m.I_l, 0, H, w.gate_up + H, (size_t)2 * H);
         w.down = m.dalloc<uint16_t>((size_t)H * m.I_l, true);
         src.fetch(p + "mlp.down_proj.weight", H, I, 0, H, m.rank * m.I_l, m.I_l, w.down, (size_t)m.I_l);
-        w.ln1 = m.dalloc<uint16_t>((size_t)H, true);
-        w.ln2 = m.dalloc<uint16_t>((size_t)H, true);
-        src.fetch(p + "input_layernorm.weight", 1, H, 0, 1, 0, H, w.ln1, (size_t)H);
-        src.fetch(p + "post_attention_layernorm.weight", 1, H, 0, 1, 0, H, w.ln2, (size_t)H);
+        w.ln1 = fetch_f32(m, src, p + "input_layernorm.weight", H, off);
+        w.ln2 = fetch_f32(m, src, p + "post_attention_layernorm.weight", H, off);
     }
     CM_HIP(hipStreamSynchronize(m.stream));
 }

@@ -77,10 +77,46 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
                   ? root->integer("eos_token_id", -1) : -1;
     if (cfg.V <= 0 || cfg.H <= 0 || cfg.I <= 0 || cfg.L <= 0 || cfg.Hq <= 0 || cfg.Hkv <= 0 || cfg.max_pos <= 0)
         throw CmError(CM_ERR_IO, "config.json: missing required field");
-    if (cfg.model_type != "qwen3")
-        throw CmError(CM_ERR_UNSUPPORTED, "model_type '" + cfg.model_type + "' not implemented (qwen3 dense only so far)");
+    cfg.rot_dim = cfg.D;
+    if (cfg.model_type == "qwen3_5" || cfg.model_type == "qwen3_5_text") {
+        // TextConfig (qwen3_5/config.rs:47-110); tie_word_embeddings defaults to FALSE here (:80-81)
+        cfg.hybrid = true;
+        cfg.norm_off = 1.0f;
+        cfg.qk_norm = true;
+        cfg.tie = root->has("tie_word_embeddings") ? root->boolean("tie_word_embeddings", false)
+                                                   : j->boolean("tie_word_embeddings", false);
+        cfg.interval = (int)root->integer("full_attention_interval", 4);
+        cfg.conv_k = (int)root->integer("linear_conv_kernel_dim", 4);
+        cfg.Kd = (int)root->integer("linear_key_head_dim", 0);
+        cfg.Vd = (int)root->integer("linear_value_head_dim", 0);
+        cfg.NK = (int)root->integer("linear_num_key_heads", 0);
+        cfg.NV = (int)root->integer("linear_num_value_heads", 0);
+        cfg.attn_gate = root->boolean("attn_output_gate", true);
+        double prf = 0.25;
+        cfg.theta = 1e7;
+        if (const cmjson::Value* rp = root->get("rope_parameters")) {
+            cfg.theta = rp->number("rope_theta", 1e7);
+            prf = rp->number("partial_rotary_factor", 0.25);
+        }
+        cfg.rot_dim = (int)((double)cfg.D * prf);                  // config.rs:226-229
+        if (const cmjson::Value* lt = root->get("layer_types")) {   // HF spelling; must agree with the interval rule
+            for (size_t i = 0; i < lt->arr.size() && (int)i < cfg.L; ++i) {
+                const bool full = lt->arr[i]->str == "full_attention";
+                if (full != (((int)i + 1) % cfg.interval == 0))
+                    throw CmError(CM_ERR_UNSUPPORTED, "layer_types does not follow full_attention_interval");
+            }
+        }
+        if (cfg.Kd != 128 || cfg.Vd != 128 || cfg.conv_k != 4)
+            throw CmError(CM_ERR_UNSUPPORTED, "GDN kernel is built for head dims 128/128 and conv kernel 4");
+        if (cfg.NK <= 0 || cfg.NV % cfg.NK) throw CmError(CM_ERR_INVALID, "linear_num_value_heads % linear_num_key_heads != 0");
+        if (!cfg.attn_gate) throw CmError(CM_ERR_UNSUPPORTED, "attn_output_gate=false not implemented");
+        if (cfg.rot_dim <= 0 || cfg.rot_dim % 2 || cfg.rot_dim > cfg.D) throw CmError(CM_ERR_INVALID, "bad partial_rotary_factor");
+        if (opts.tp_size > 1) throw CmError(CM_ERR_UNSUPPORTED, "tensor parallel Qwen3.5 not implemented yet");
+    } else if (cfg.model_type != "qwen3") {
+        throw CmError(CM_ERR_UNSUPPORTED, "model_type '" + cfg.model_type + "' not implemented (qwen3, qwen3_5)");
+    }
     if (cfg.attention_bias) throw CmError(CM_ERR_UNSUPPORTED, "attention_bias not implemented");
-    if (cfg.D != 128) throw CmError(CM_ERR_UNSUPPORTED, "head_dim != 128 not implemented");
+    if (cfg.D != 128 && cfg.D != 256) throw CmError(CM_ERR_UNSUPPORTED, "head_dim must be 128 or 256");
     if (cfg.H % 8 || cfg.I % 8) throw CmError(CM_ERR_UNSUPPORTED, "hidden/intermediate must be multiples of 8");
     if (cfg.Hq % cfg.Hkv) throw CmError(CM_ERR_INVALID, "num_attention_heads % num_key_value_heads != 0");
 
@@ -129,8 +165,21 @@ void Model::alloc_runtime() {
     const int H = cfg.H, D = cfg.D;
     x = dalloc<float>(H);
     y = dalloc<float>(H);
-    qkv = dalloc<float>((size_t)(Hq_l + 2 * Hkv_l) * D);
-    attn = dalloc<float>((size_t)Hq_l * D);
+    gdn_layers = 0;
+    for (int i = 0; i < cfg.L; ++i) if (!cfg.layer_full(i)) ++gdn_layers;
+    in_proj_rows = cfg.hybrid ? cfg.conv_dim() + cfg.value_dim() + 2 * cfg.NV : 0;
+    in_proj_pad = (in_proj_rows + 127) / 128 * 128;
+    const size_t attn_rows = (size_t)(cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
+    qkv = dalloc<float>(std::max(attn_rows, (size_t)in_proj_pad));
+    attn = dalloc<float>(std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0)));
+    if (gdn_layers > 0) {
+        conv_slot_elems = (size_t)gdn_layers * 2 * cfg.conv_dim() * (cfg.conv_k - 1);
+        state_slot_elems = (size_t)gdn_layers * cfg.NV * cfg.Kd * cfg.Vd;
+        conv_pool = dalloc<float>(conv_slot_elems * seqs.size());
+        state_pool = dalloc<float>(state_slot_elems * seqs.size());
+        CM_HIP(hipMemsetAsync(conv_pool, 0, conv_slot_elems * seqs.size() * sizeof(float), stream));
+        CM_HIP(hipMemsetAsync(state_pool, 0, state_slot_elems * seqs.size() * sizeof(float), stream));
+    }
     hbuf = dalloc<float>(I_l);
     logits = dalloc<float>((size_t)V_l * tp);
     part_o = dalloc<float>((size_t)Hq_l * nsplit * D);
@@ -151,7 +200,10 @@ void Model::alloc_runtime() {
 
     // KV pool
     page_elems = (size_t)Hkv_l * page * D;
-    const size_t pool_elems = (size_t)cfg.L * 2 * n_pages * page_elems;
+    kv_index.assign((size_t)cfg.L, -1);
+    n_kv_layers = 0;
+    for (int i = 0; i < cfg.L; ++i) if (cfg.layer_full(i)) kv_index[(size_t)i] = n_kv_layers++;
+    const size_t pool_elems = (size_t)n_kv_layers * 2 * n_pages * page_elems;
     kv_pool = (uint8_t*)dalloc<uint16_t>(pool_elems * (kv_esize / 2));
     free_pages.resize((size_t)n_pages);
     for (int64_t i = 0; i < n_pages; ++i) free_pages[(size_t)i] = (int32_t)(n_pages - 1 - i);
@@ -159,9 +211,13 @@ void Model::alloc_runtime() {
 
     // RoPE tables exactly as RotaryEmbedding::new (modules/rotary.rs:29-46):
     // inv_freq in f64 then cast to f32; freqs = pos(f32) * inv(f32); cos/sin in f32.
-    const int half = D / 2;
+    // Qwen3.5: MRotaryEmbedding::new (qwen3_5/modeling.rs:106-124) computes base^e in F32 over rot_dim.
+    const int half = cfg.rot_dim / 2;
     std::vector<float> inv(half), hc((size_t)max_seq * half), hs((size_t)max_seq * half);
-    for (int i = 0; i < half; ++i) inv[i] = (float)(1.0 / std::pow(cfg.theta, (double)(2 * i) / (double)D));
+    for (int i = 0; i < half; ++i) {
+        if (cfg.hybrid) inv[i] = 1.0f / powf((float)cfg.theta, (float)i * 2.0f / (float)cfg.rot_dim);
+        else inv[i] = (float)(1.0 / std::pow(cfg.theta, (double)(2 * i) / (double)D));
+    }
     for (int p = 0; p < max_seq; ++p)
         for (int i = 0; i < half; ++i) {
             const float f = (float)p * inv[i];
@@ -203,6 +259,12 @@ int Model::seq_alloc() {
 void Model::seq_truncate(int s, size_t new_len) {
     Seq& q = seq(s);
     if ((int64_t)new_len > q.len) throw CmError(CM_ERR_RANGE, "truncate beyond cached length");
+    if (gdn_layers > 0 && (int64_t)new_len != q.len) {
+        // a recurrent (GDN) state cannot be rewound: only "clear" is possible, like the reference,
+        // which re-prefills from scratch after preemption (engine/mod.rs:430-504)
+        if (new_len != 0) throw CmError(CM_ERR_UNSUPPORTED, "Gated-Delta-Net state cannot be truncated to a non-zero length");
+        reset_gdn_state(s);
+    }
     const size_t keep = (new_len + page - 1) / page;
     while (q.pages.size() > keep) {
         const int32_t p = q.pages.back();
@@ -211,6 +273,12 @@ void Model::seq_truncate(int s, size_t new_len) {
     }
     q.len = (int64_t)new_len;
     if (active_seq == s) active_pages_uploaded = std::min(active_pages_uploaded, q.pages.size());
+}
+
+void Model::reset_gdn_state(int slot) {
+    if (gdn_layers == 0) return;
+    CM_HIP(hipMemsetAsync(conv_pool + conv_slot_elems * (size_t)slot, 0, conv_slot_elems * sizeof(float), stream));
+    CM_HIP(hipMemsetAsync(state_pool + state_slot_elems * (size_t)slot, 0, state_slot_elems * sizeof(float), stream));
 }
 
 void Model::seq_free(int s) {
@@ -227,6 +295,12 @@ int Model::seq_fork(int src) {
     b.len = a.len;
     b.pages = a.pages;
     for (int32_t p : b.pages) page_ref[(size_t)p]++;
+    if (gdn_layers > 0) {      // recurrent + conv state travel with the sequence
+        CM_HIP(hipMemcpyAsync(conv_pool + conv_slot_elems * (size_t)d, conv_pool + conv_slot_elems * (size_t)src,
+                              conv_slot_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        CM_HIP(hipMemcpyAsync(state_pool + state_slot_elems * (size_t)d, state_pool + state_slot_elems * (size_t)src,
+                              state_slot_elems * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
     // copy-on-write of the last, partially filled page: both forks will append into it
     if (!b.pages.empty() && (a.len % page) != 0) {
         if (free_pages.empty()) { seq_free(d); throw CmError(CM_ERR_OOM, "KV pool exhausted"); }
@@ -238,7 +312,7 @@ int Model::seq_fork(int src) {
         b.pages.back() = newp;
         const size_t pitch = (size_t)n_pages * page_elems * kv_esize;
         CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_elems * kv_esize, pitch, kv_pool + (size_t)oldp * page_elems * kv_esize, pitch,
-                                page_elems * kv_esize, (size_t)cfg.L * 2, hipMemcpyDeviceToDevice, stream));
+                                page_elems * kv_esize, (size_t)n_kv_layers * 2, hipMemcpyDeviceToDevice, stream));
     }
     return d;
 }
@@ -275,18 +349,28 @@ void Model::activate(int s) {
 uint64_t Model::kv_bytes() const {
     uint64_t pages_used = 0;
     for (auto r : page_ref) if (r > 0) ++pages_used;
-    return pages_used * page_elems * kv_esize * 2ull * (uint64_t)cfg.L;
+    return pages_used * page_elems * kv_esize * 2ull * (uint64_t)n_kv_layers;
 }
 
 uint64_t Model::decode_bytes_per_token(size_t ctx) const {
-    // 2 B x every weight element once + KV read at ctx (this rank's shard)
+    // 2 B x every weight element once + KV read at ctx (+ GDN state read+write), this rank
     const uint64_t H = cfg.H, D = cfg.D;
-    uint64_t per_layer = (uint64_t)(Hq_l + 2 * Hkv_l) * D * H + H * (uint64_t)Hq_l * D + 3ull * I_l * H + 2 * H +
-                         (cfg.qk_norm ? 2 * D : 0);
+    const uint64_t mlp = 3ull * I_l * H + 2 * H;
+    uint64_t w_elems = 0, extra = 0;
+    for (int i = 0; i < cfg.L; ++i) {
+        if (cfg.layer_full(i)) {
+            const uint64_t qrows = (uint64_t)(cfg.hybrid ? 2 * Hq_l : Hq_l) * D;
+            w_elems += (qrows + 2ull * Hkv_l * D) * H + H * (uint64_t)Hq_l * D + (cfg.qk_norm ? 2 * D : 0) + mlp;
+            extra += 2ull * Hkv_l * D * ctx * kv_esize;
+        } else {
+            w_elems += (uint64_t)in_proj_rows * H + H * (uint64_t)cfg.value_dim() + mlp;
+            extra += 2ull * cfg.NV * cfg.Kd * cfg.Vd * 4 + 2ull * cfg.conv_dim() * (cfg.conv_k - 1) * 4 +
+                     (uint64_t)cfg.conv_dim() * cfg.conv_k * 4;
+        }
+    }
     const uint64_t v_eff = (uint64_t)std::max(0, std::min(V_l, cfg.V - v0));
-    uint64_t params = per_layer * cfg.L + v_eff * H + H /*final norm*/ + H /*embedding row*/;
-    uint64_t kv = (uint64_t)cfg.L * 2 * Hkv_l * D * ctx * kv_esize;
-    return params * 2 + kv;
+    w_elems += v_eff * H + H /*final norm*/ + H /*embedding row*/;
+    return w_elems * 2 + extra;
 }
 
 // ------------------------------------------------------------------------------------
@@ -296,19 +380,37 @@ void Model::enqueue_decode_step(bool advance) {
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
     launch_embed_row(embed, st, x, H, cfg.V, s);
-    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
         GemvArgs g{};
+        if (!w.full) {
+            // ---- Gated Delta Net layer (ops/gdn/layer.rs:122-182): in_proj GEMV, fused GDN kernel, out_proj GEMV ----
+            g.W = w.in_proj; g.x = x; g.nw = w.ln1; g.y = qkv; g.N = in_proj_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
+            launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+            GdnArgs ga{};
+            ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
+            ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
+            ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+            ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
+            launch_gdn(ga, s);
+            g = GemvArgs{};
+            g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K; g.y = x; g.res = x;
+            launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s);
+        } else {
         // (1) RMSNorm + merged QKV projection
         g.W = w.qkv; g.x = x; g.nw = w.ln1; g.y = qkv; g.N = qkv_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
         launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
-        // (2) QK-norm + RoPE + KV append + paged split-KV attention
+        // (2) QK-norm + RoPE + KV append + paged split-KV attention (+ sigmoid output gate for Qwen3.5)
         AttnDecArgs a{};
         a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
         a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
+        a.q_off = 0;
+        a.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; a.v_off = a.k_off + Hkv_l * D;
+        a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr;
+        a.rot_dim = cfg.rot_dim;
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-        if (!launch_attn_decode(a, nrep, nsplit, kv_f32, attn, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size");
+        if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
@@ -318,6 +420,7 @@ void Model::enqueue_decode_step(bool advance) {
             launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
             rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
         }
+        }   // full-attention layer
         // (4) RMSNorm + gate||up + SiLU*mul
         g = GemvArgs{};
         g.W = w.gate_up; g.x = x; g.nw = w.ln2; g.y = hbuf; g.N = 2 * I_l; g.K = H; g.ldw = H; g.eps = cfg.eps;
@@ -363,7 +466,7 @@ void Model::ensure_prefill_buffers() {
     chunk_pad = (chunk + 127) / 128 * 128;
     prefill_split2 = opts.prefill_split != 1;
     const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
-    prefill_ok = (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0);
+    prefill_ok = !cfg.hybrid && (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0);
     if (!prefill_ok) return;
     pX = dalloc<float>((size_t)chunk * H);
     if (rccl) pY = dalloc<float>((size_t)chunk * H);
@@ -435,7 +538,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         }
         if (off + (size_t)S >= n) {     // last chunk: logits of the LAST position only (modeling.rs:1032-1035)
             CM_HIP(hipMemcpyAsync(x, pX + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-            launch_set_state(st, ids[n - 1], (int32_t)(start_pos + n - 1), s);
+            launch_set_state(st, ids[n - 1], (int32_t)(start_pos + n - 1), active_seq, s);
             ++ring_count;
             enqueue_lm_head(true);
         }
@@ -492,7 +595,7 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
         prefill(ids, n, start_pos);
     } else {
         for (size_t i = 0; i < n; ++i) {     // token-serial path (also the parity cross-check of prefill)
-            launch_set_state(st, ids[i], (int32_t)(start_pos + i), stream);
+            launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, stream);
             run_decode_step(true);
         }
     }
@@ -571,7 +674,7 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
             const size_t want = std::min(chunk, (size_t)g.max_new_tokens - produced);
             ensure_pages(0, (int64_t)(q.len + (int64_t)want));
             activate(0);
-            launch_set_state(st, out[n - 1], (int32_t)q.len, stream);
+            launch_set_state(st, out[n - 1], (int32_t)q.len, 0, stream);
             const uint32_t ring0 = ring_count;
             for (size_t i = 0; i < want; ++i) run_decode_step(true);
             CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -589,7 +692,7 @@ void Model::bench_decode(uint32_t first, size_t k, uint32_t* toks, float* ms) {
     Seq& q = seq(0);
     ensure_pages(0, q.len + (int64_t)k);
     activate(0);
-    launch_set_state(st, first, (int32_t)q.len, stream);
+    launch_set_state(st, first, (int32_t)q.len, 0, stream);
     const uint32_t ring0 = ring_count;
     hipEvent_t e0, e1;
     CM_HIP(hipEventCreate(&e0));
@@ -616,7 +719,9 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     uint64_t b = 0;
     auto one = [&](size_t i) {
-        const LayerW& w = layers[i % (size_t)cfg.L];
+        size_t li = i % (size_t)cfg.L;
+        if ((which == "qkv" || which == "o") && !layers[li].full) li = (size_t)(cfg.interval - 1);
+        const LayerW& w = layers[li];
         GemvArgs g{};
         g.eps = cfg.eps;
         if (which == "qkv") {
@@ -660,6 +765,7 @@ void Model::debug_fill_kv(size_t ctx, uint64_t seed) {
     activate(0);
     Seq& q = seq(0);
     for (int li = 0; li < cfg.L; ++li) {
+        if (!cfg.layer_full(li)) continue;
         launch_kv_fill(kpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
         launch_kv_fill(vpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
     }

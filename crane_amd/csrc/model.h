@@ -35,6 +35,17 @@ struct Config {
     double theta = 1e6;
     bool tie = true, qk_norm = true, attention_bias = false;
     long long eos = -1;
+    // Qwen 3.5 / 3.6 / 3.8 hybrid (qwen3_5/config.rs:47-254)
+    bool hybrid = false;            // false: qwen3 dense
+    int rot_dim = 0;                // rotary slice of the head (== D for qwen3)
+    int interval = 4;               // full_attention_interval
+    int NK = 0, NV = 0, Kd = 0, Vd = 0, conv_k = 4;
+    bool attn_gate = false;
+    float norm_off = 0.f;           // Qwen35RmsNorm: weight = 1 + w (folded at load)
+    int key_dim() const { return NK * Kd; }
+    int value_dim() const { return NV * Vd; }
+    int conv_dim() const { return 2 * key_dim() + value_dim(); }
+    bool layer_full(int i) const { return !hybrid || ((i + 1) % interval) == 0; }
 };
 
 struct LayerW {
@@ -42,10 +53,20 @@ struct LayerW {
     uint16_t* o = nullptr;        // [H, Hq_l D]                 K-slice of o_proj under TP
     uint16_t* gate_up = nullptr;  // [2 I_l, H] rows interleaved gate_j, up_j
     uint16_t* down = nullptr;     // [H, I_l]
-    uint16_t* ln1 = nullptr;      // [H]
-    uint16_t* ln2 = nullptr;
-    uint16_t* qn = nullptr;       // [D] or null
-    uint16_t* kn = nullptr;
+    float* ln1 = nullptr;         // [H] f32, (1 + w) folded for Qwen3.5
+    float* ln2 = nullptr;
+    float* qn = nullptr;          // [D] or null
+    float* kn = nullptr;
+    // Qwen3.5: full-attention layers store qkv as [q (Hq D) | gate (Hq D) | k | v] rows;
+    // GDN layers use the fields below instead of qkv / o
+    bool full = true;
+    int gdn_idx = -1;             // index among the GDN layers
+    uint16_t* in_proj = nullptr;  // [conv_dim + VD + 2 NV (padded to 128), H]: qkv | z | b | a
+    uint16_t* out_proj = nullptr; // [H, VD]
+    float* conv_w = nullptr;      // [conv_dim, 4]
+    float* A_log = nullptr;       // [NV]
+    float* dt_bias = nullptr;     // [NV]
+    float* gnorm = nullptr;       // [Vd] plain RMSNormGated weight
 };
 
 struct Seq {
@@ -70,7 +91,7 @@ struct Model {
     // weights
     uint16_t* embed = nullptr;     // [V, H] replicated
     uint16_t* lm_head = nullptr;   // [V_l, H] (points into embed when tied)
-    uint16_t* norm = nullptr;
+    float* norm = nullptr;
     std::vector<LayerW> layers;
     float* cos = nullptr;
     float* sin = nullptr;
@@ -89,6 +110,13 @@ struct Model {
     int32_t* h_bt = nullptr;       // pinned mirror
     int active_seq = -1;
     size_t active_pages_uploaded = 0;
+
+    // per-sequence GDN state pools (Qwen3.5): [slots][gdn_layers][...]
+    int gdn_layers = 0, in_proj_rows = 0, in_proj_pad = 0;
+    float* conv_pool = nullptr;
+    float* state_pool = nullptr;
+    size_t conv_slot_elems = 0, state_slot_elems = 0;
+    void reset_gdn_state(int slot);
 
     // decode scratch (f32)
     float* x = nullptr;        // [H] residual stream
@@ -139,8 +167,10 @@ struct Model {
     template <typename T> T* dalloc(size_t n, bool count_weight = false);
 
     // ---- kv / sequences ----
-    void* kpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 0) * n_pages * page_elems * kv_esize; }
-    void* vpool(int layer) const { return kv_pool + ((size_t)layer * 2 + 1) * n_pages * page_elems * kv_esize; }
+    std::vector<int> kv_index;     // layer -> index among the softmax-attention layers (-1: GDN layer)
+    int n_kv_layers = 0;
+    void* kpool(int layer) const { return kv_pool + ((size_t)kv_index[(size_t)layer] * 2 + 0) * n_pages * page_elems * kv_esize; }
+    void* vpool(int layer) const { return kv_pool + ((size_t)kv_index[(size_t)layer] * 2 + 1) * n_pages * page_elems * kv_esize; }
     int seq_alloc();
     void seq_free(int s);
     int seq_fork(int src);

@@ -1,0 +1,133 @@
+"""Qwen 3.5 hybrid (Gated Delta Net + gated softmax attention): oracle KATs / HF golden (CPU) and
+HIP-path parity through the C ABI (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from crane_amd import configs, synth
+from oracle import qwen3_5_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32 = np.float32
+
+
+def rel(a, ref):
+    return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+
+def _load():
+    g = np.load(os.path.join(GOLD, "qwen3_5_tiny-qwen3.5.npz"))
+    cfg = configs.get_config("tiny-qwen3.5")
+    return g, cfg, synth.synth_weights_f32(cfg, seed=int(g["seed"][0]))
+
+
+# ---------------------------------------------------------------- CPU: oracle pinned ----------
+def test_derived_dims_of_qwen38_27b():
+    """qwen3_5/config.rs:332-364: q_proj rows 12288, conv_dim 10240, value_dim 6144, key_dim 2048, rot_dim 64,
+    16 full layers at ratio 3:1."""
+    c = O.Qwen35Config.from_json(configs.get_config("qwen3.8-27b"))
+    assert c.num_attention_heads * c.head_dim * 2 == 12288
+    assert (c.conv_dim, c.value_dim, c.key_dim, c.rot_dim) == (10240, 6144, 2048, 64)
+    full = [i for i in range(c.num_hidden_layers) if c.layer_is_full(i)]
+    assert len(full) == 16 and full[0] == 3 and all(b - a == 4 for a, b in zip(full, full[1:]))
+
+
+def test_unit_offset_and_gated_norm_formulas():
+    """crane-core/tests/qwen3_5_norms.rs:72-231: block norm = x/rms*(1+w); L2-norm = x/sqrt(sum+eps);
+    gated norm = rms_norm(y, w) * silu(z) with a PLAIN weight."""
+    def values(n, seed):
+        return np.array([(((i * 37 + seed * 11) % 97) / 97.0 - 0.5) * 4.0 for i in range(n)], dtype=F32)
+    x, w = values(48, 1).reshape(3, 16), values(16, 2) * F32(0.1)
+    got = O.rms_norm_1p(x, w, 1e-6)
+    for r in range(3):
+        ms = float(np.mean(x[r].astype(np.float64) ** 2))
+        assert np.abs(got[r] - x[r] / np.sqrt(ms + 1e-6) * (1 + w)).max() < 1e-5
+    n = O.l2_norm(x)
+    assert np.allclose(np.sum(n * n, axis=-1), np.sum(x * x, -1) / (np.sum(x * x, -1) + 1e-6), atol=1e-5)
+    z = values(48, 3).reshape(3, 16)
+    gn = O.rms_norm_plain(x, w + 1, 1e-6) * O.silu(z)
+    assert np.allclose(gn, (x / np.sqrt(np.mean(x * x, -1, keepdims=True) + 1e-6)) * (w + 1) * (z / (1 + np.exp(-z))), atol=1e-5)
+
+
+def test_conv_chunked_equals_decode_steps():
+    """ops/gdn/conv.rs:135-328 (chunk / decode equivalence, tol 1e-6) exercised through the layer: a prompt fed
+    as one chunk, as two chunks, or token by token must give the same logits (also the GDN state hand-over)."""
+    g, cfg, w = _load()
+    c = O.Qwen35Config.from_json(cfg)
+    ids = g["prompt"].tolist()
+    a = O.Qwen35Oracle(c, w).forward(ids, 0)
+    o2 = O.Qwen35Oracle(c, w)
+    o2.forward(ids[:7], 0)
+    b = o2.forward(ids[7:], 7)
+    o3 = O.Qwen35Oracle(c, w)
+    for i, t in enumerate(ids):
+        d = o3.forward([t], i)
+    assert rel(b, a) < 1e-5 and rel(d, a) < 1e-5
+
+
+def test_interleaved_head_pairing():
+    """ops/gdn/layer.rs:280-326: with 2 key heads and v_per_group 2, value heads [0,1] pair with key head 0 and
+    [2,3] with key head 1 (HF 'Interleaved' order = repeat_interleave)."""
+    k = np.array([[[10.0], [20.0]]], dtype=F32)            # [S=1, NK=2, K=1]
+    assert np.repeat(k, 2, axis=1)[0, :, 0].tolist() == [10.0, 10.0, 20.0, 20.0]
+
+
+def test_oracle_matches_hf_golden():
+    g, cfg, w = _load()
+    o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+    ids = g["prompt"].tolist()
+    assert rel(o.forward(ids, 0), g["prefill_logits"]) < 2e-5
+    assert rel(o.forward(g["decode_token"].tolist(), len(ids)), g["decode_logits"]) < 2e-5
+    assert o.generate(ids, len(g["greedy_tokens"]) - len(ids)) == g["greedy_tokens"].tolist()
+
+
+# ---------------------------------------------------------------- GPU: HIP path ----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["f32", "bf16"])
+def test_hip_qwen35_matches_hf_golden_and_oracle(kv):
+    from crane_amd.backend import GenerationConfig, Model
+    g, cfg, w = _load()
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=3, kv_dtype=kv)
+    try:
+        ids = g["prompt"].tolist()
+        tol = 1e-4 if kv == "f32" else 4e-3
+        assert rel(m.forward_step(ids, 0)[0, 0], g["prefill_logits"]) < tol
+        assert rel(m.forward_step(g["decode_token"].tolist(), len(ids))[0, 0], g["decode_logits"]) < tol
+        n_new = len(g["greedy_tokens"]) - len(ids)
+        assert m.generate(ids, GenerationConfig.greedy(n_new)) == g["greedy_tokens"].tolist()
+        assert m.generate(ids, GenerationConfig.greedy(n_new), sync_every=4) == g["greedy_tokens"].tolist()
+        # longer run against the oracle, crossing a KV page (64) on the full-attention layers
+        o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w, kv_dtype=kv)
+        long_ids = configs.synthetic_prompt(80, cfg["vocab_size"])
+        m.clear_kv_cache()
+        assert rel(m.forward_step(long_ids, 0)[0, 0], o.forward(long_ids, 0)) < (1e-4 if kv == "f32" else 5e-4)
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_hip_qwen35_sequences_and_state():
+    """per-sequence GDN state: fork copies it, clear resets it, truncation to a non-zero length is refused."""
+    from crane_amd._lib import CraneError
+    from crane_amd.backend import Model
+    g, cfg, w = _load()
+    o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4, kv_dtype="f32")
+    try:
+        ids = g["prompt"].tolist()
+        s1 = m.seq_alloc()
+        m.seq_forward(s1, ids, 0)
+        s2 = m.seq_fork(s1)
+        l1, _ = m.seq_forward(s1, [11], len(ids))
+        l2, _ = m.seq_forward(s2, [23], len(ids))
+        o.forward(ids, 0); r1 = o.forward([11], len(ids))
+        o.forward(ids, 0); r2 = o.forward([23], len(ids))
+        assert rel(l1, r1) < 1e-4 and rel(l2, r2) < 1e-4
+        with pytest.raises(CraneError):
+            m.seq_truncate(s1, 5)
+        m.seq_truncate(s1, 0)
+        l3, _ = m.seq_forward(s1, ids, 0)                     # state really was reset
+        assert rel(l3, o.forward(ids, 0)) < 1e-4
+    finally:
+        m.close()
