@@ -83,6 +83,7 @@ struct QkRopeArgs {
     uint16_t* q_hi;              // [Spad, Hq, D] bf16, scaled by 1/sqrt(D)
     uint16_t* q_lo;
     int Hq, Hkv, page, start_pos;
+    int row_stride, q_off, k_off, v_off, rot_dim;   // layout of one token's projection row
     float eps, scale;
 };
 
@@ -94,16 +95,19 @@ struct AttnPreArgs {
     const void* vpool;
     uint16_t* out_hi;            // [Spad, Hq * D] bf16 hi (+lo) -> A operand of the o_proj GEMM
     uint16_t* out_lo;
+    const float* gate;           // [S, gate_stride] f32 (Qwen3.5 output gate) or null
+    int gate_stride;
     int S, Hq, Hkv, nrep, page, start_pos;
 };
 
 void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
 void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
                          hipStream_t s);
-void launch_qknorm_rope_kv(const QkRopeArgs& a, int S, bool kv_f32, hipStream_t s);
+void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, bool kv_f32, hipStream_t s);
+void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
-void launch_attn_prefill(const AttnPreArgs& a, bool kv_f32, hipStream_t s);
+void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s);
 
 // ---- decode ----
 int gemv_rows_per_group(int K);

@@ -65,43 +65,74 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
     }
 }
 
-// grid (S, Hq + 2 Hkv), block 64: per-head RMSNorm(q,k) BEFORE RoPE (modeling.rs:341-359),
-// q scaled by 1/sqrt(D) -> bf16 hi/lo [S, Hq, D]; k, v -> paged cache at position start+s.
-template <bool KVF32>
+// grid (S, Hq + 2 Hkv), block 64: per-head RMSNorm(q,k) BEFORE RoPE (qwen3/modeling.rs:341-359,
+// qwen3_5/modeling.rs:464-468), rotate-half over the first rot_dim dims, q scaled by 1/sqrt(D)
+// -> bf16 hi/lo [S, Hq, D]; k, v -> paged cache at position start+s.
+template <int D, bool KVF32>
 __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
-    constexpr int D = 128;
+    constexpr int EPL = D / 64;
+    __shared__ float tmp[D];
     const int s = blockIdx.x, item = blockIdx.y, lane = threadIdx.x;
     const int Hq = a.Hq, Hkv = a.Hkv;
     const int pos = a.start_pos + s;
-    const float* src = a.qkv + (size_t)s * (Hq + 2 * Hkv) * D + (size_t)item * D;
-    float x1 = src[lane], x2 = src[lane + 64];
     const bool is_q = item < Hq, is_k = !is_q && item < Hq + Hkv;
+    const int kvh = is_k ? item - Hq : item - Hq - Hkv;
+    const float* src = a.qkv + (size_t)s * a.row_stride +
+                       (is_q ? a.q_off + item * D : (is_k ? a.k_off + kvh * D : a.v_off + kvh * D));
+    float xv[EPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) { xv[j] = src[lane + 64 * j]; ss += xv[j] * xv[j]; }
     if (is_q || is_k) {
         const float* nw = is_q ? a.qnw : a.knw;
         if (nw) {
-            const float ss = wave_sum(x1 * x1 + x2 * x2);
+            ss = wave_sum(ss);
             const float r = 1.0f / sqrtf(ss / (float)D + a.eps);
-            x1 = x1 * r * nw[lane];
-            x2 = x2 * r * nw[lane + 64];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) xv[j] = xv[j] * r * nw[lane + 64 * j];
         }
-        const float c = a.cos[(size_t)pos * (D / 2) + lane], sn = a.sin[(size_t)pos * (D / 2) + lane];
-        const float o1 = x1 * c - x2 * sn, o2 = x1 * sn + x2 * c;
-        x1 = o1; x2 = o2;
+        const int rot = a.rot_dim, hrot = rot >> 1;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) tmp[lane + 64 * j] = xv[j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int d = lane + 64 * j;
+            if (d < rot) {
+                const int i = d < hrot ? d : d - hrot;
+                const float c = a.cos[(size_t)pos * hrot + i], sn = a.sin[(size_t)pos * hrot + i];
+                const float lo = tmp[i], hi = tmp[i + hrot];
+                xv[j] = d < hrot ? lo * c - hi * sn : lo * sn + hi * c;
+            }
+        }
     }
     if (is_q) {
-        x1 *= a.scale; x2 *= a.scale;
         const size_t off = ((size_t)s * Hq + item) * D;
-        const uint16_t h1 = f32_to_bf16(x1), h2 = f32_to_bf16(x2);
-        a.q_hi[off + lane] = h1; a.q_hi[off + lane + 64] = h2;
-        a.q_lo[off + lane] = f32_to_bf16(x1 - bf16_to_f32(h1));
-        a.q_lo[off + lane + 64] = f32_to_bf16(x2 - bf16_to_f32(h2));
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const float x = xv[j] * a.scale;
+            const uint16_t h = f32_to_bf16(x);
+            a.q_hi[off + lane + 64 * j] = h;
+            a.q_lo[off + lane + 64 * j] = f32_to_bf16(x - bf16_to_f32(h));
+        }
     } else {
-        const int kvh = is_k ? item - Hq : item - Hq - Hkv;
         void* pool = is_k ? a.kpool : a.vpool;
         const int page = a.block_table[pos / a.page];
         const size_t off = ((size_t)(page * Hkv + kvh) * a.page + (pos % a.page)) * D;
-        if (KVF32) { ((float*)pool)[off + lane] = x1; ((float*)pool)[off + lane + 64] = x2; }
-        else { ((uint16_t*)pool)[off + lane] = f32_to_bf16(x1); ((uint16_t*)pool)[off + lane + 64] = f32_to_bf16(x2); }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            if (KVF32) ((float*)pool)[off + lane + 64 * j] = xv[j];
+            else ((uint16_t*)pool)[off + lane + 64 * j] = f32_to_bf16(xv[j]);
+        }
+    }
+}
+
+// f32 rows -> bf16 hi (+lo) rows (A operand of the next GEMM)
+__global__ void split_rows_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        const float o[4] = {v[0], v[1], v[2], v[3]};
+        split_store4(hi, lo, i * 4, o);
     }
 }
 
@@ -224,12 +255,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 // ---------------------------------------------------------------------------------------------
 // causal flash attention over the paged cache.  grid (ceil(S/64), Hq), 4 waves x 16 query rows.
 // ---------------------------------------------------------------------------------------------
-constexpr int VLD = 144;   // V tile row stride in LDS (elements): 288 B keeps the 4 key rows of a
-                           // tr-read group on disjoint banks
-
-template <bool KVF32>
+// V tile row stride in LDS = D + 16 elements: the 4 key rows of a tr-read group land on disjoint banks
+template <int D, bool KVF32>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
-    constexpr int D = 128, KT = 64;
+    constexpr int KT = 64, VLD = D + 16, NKS = D / 32, NNT = D / 16;
     __shared__ __attribute__((aligned(16))) uint16_t Vs[KVF32 ? 2 : 1][KT * VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, g = lane >> 4;
@@ -240,26 +269,26 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     const int qpos = a.start_pos + qrow;
 
     // Q^T fragments: B operand of S^T = K.Q^T : lane holds Q[q = sub][dims g*8 + 32*ks ..+8]
-    bf16x8 qh[4], ql[4];
+    bf16x8 qh[NKS], ql[NKS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
         const size_t off = ((size_t)qrow_c * a.Hq + h) * D + ks * 32 + g * 8;
         qh[ks] = *(const bf16x8*)(a.q_hi + off);
         ql[ks] = *(const bf16x8*)(a.q_lo + off);
     }
-    f32x4 o[8];
+    f32x4 o[NNT];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NNT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
     const int last_q = min(qb + 63, a.S - 1);
     const int kv_end = a.start_pos + last_q + 1;            // tokens [0, kv_end) are visible to this block
     for (int t0 = 0; t0 < kv_end; t0 += KT) {
         __syncthreads();                                   // previous tile's V fully consumed
-        // ---- stage V tile (64 tokens x 128 dims) into LDS, shared by the 4 waves ----
+        // ---- stage V tile (64 tokens x D dims) into LDS, shared by the 4 waves ----
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, tok = c >> 4, d8 = (c & 15) * 8;
+        for (int i = 0; i < (KT * D / 8) / 256; ++i) {
+            const int c = tid + 256 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
             const int t = min(t0 + tok, kv_end - 1);
             const int page = a.block_table[t / a.page];
             const size_t off = ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + d8;
@@ -289,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
             const int page = a.block_table[t / a.page];
             const size_t kb = ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + g * 8;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 bf16x8 kh, kl;
                 if (KVF32) {
                     const f32x4 k0 = *(const f32x4*)((const float*)a.kpool + kb + ks * 32);
@@ -338,13 +367,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) { o[nt][0] *= alpha; o[nt][1] *= alpha; o[nt][2] *= alpha; o[nt][3] *= alpha; }
+        for (int nt = 0; nt < NNT; ++nt) { o[nt][0] *= alpha; o[nt][1] *= alpha; o[nt][2] *= alpha; o[nt][3] *= alpha; }
         __syncthreads();                                   // V tile visible
         // ---- O^T += V^T . P^T : A = V^T fragment (tr-read), B = P^T fragment (registers) ----
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < NNT; ++nt) {
                 const uint16_t* vp = &Vs[0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
                 const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
                 o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, ph[tt], o[nt], 0, 0, 0);
@@ -363,8 +392,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     const float inv = 1.0f / l_run;
     if (qrow < a.S) {
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            const float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+        for (int nt = 0; nt < NNT; ++nt) {
+            float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+            if (a.gate != nullptr) {        // Qwen3.5: y * sigmoid(gate) (qwen3_5/modeling.rs:556-561)
+                const f32x4 gv = *(const f32x4*)(a.gate + (size_t)qrow * a.gate_stride + h * D + nt * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= 1.0f / (1.0f + expf(-gv[r]));
+            }
             split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
         }
     }
@@ -380,10 +414,20 @@ void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t*
                          hipStream_t s) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, s, x, w, hi, lo, H, eps);
 }
-void launch_qknorm_rope_kv(const QkRopeArgs& a, int S, bool kv_f32, hipStream_t s) {
+void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, bool kv_f32, hipStream_t s) {
     dim3 grid(S, a.Hq + 2 * a.Hkv);
-    if (kv_f32) hipLaunchKernelGGL(qknorm_rope_kv_kernel<true>, grid, dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(qknorm_rope_kv_kernel<false>, grid, dim3(64), 0, s, a);
+    if (D == 128) {
+        if (kv_f32) hipLaunchKernelGGL((qknorm_rope_kv_kernel<128, true>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((qknorm_rope_kv_kernel<128, false>), grid, dim3(64), 0, s, a);
+    } else {
+        if (kv_f32) hipLaunchKernelGGL((qknorm_rope_kv_kernel<256, true>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((qknorm_rope_kv_kernel<256, false>), grid, dim3(64), 0, s, a);
+    }
+}
+void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;
+    int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, x, hi, lo, n4);
 }
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s) {
     const size_t n4 = n / 4;
@@ -403,10 +447,15 @@ bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
 #undef CM_GEMM
     return true;
 }
-void launch_attn_prefill(const AttnPreArgs& a, bool kv_f32, hipStream_t s) {
+void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s) {
     dim3 grid((a.S + 63) / 64, a.Hq);
-    if (kv_f32) hipLaunchKernelGGL(attn_prefill_kernel<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attn_prefill_kernel<false>, grid, dim3(256), 0, s, a);
+    if (D == 128) {
+        if (kv_f32) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (kv_f32) hipLaunchKernelGGL((attn_prefill_kernel<256, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<256, false>), grid, dim3(256), 0, s, a);
+    }
 }
 
 }  // namespace cm

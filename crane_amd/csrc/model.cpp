@@ -465,12 +465,14 @@ void Model::ensure_prefill_buffers() {
     if (chunk < 1) chunk = 1;
     chunk_pad = (chunk + 127) / 128 * 128;
     prefill_split2 = opts.prefill_split != 1;
-    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
-    prefill_ok = !cfg.hybrid && (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0);
+    const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
+    prefill_ok = (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0) &&
+                 (!cfg.hybrid || cfg.value_dim() % 32 == 0);
     if (!prefill_ok) return;
     pX = dalloc<float>((size_t)chunk * H);
     if (rccl) pY = dalloc<float>((size_t)chunk * H);
-    pQKV = dalloc<float>((size_t)chunk * qkv_rows);
+    pQKV = dalloc<float>((size_t)chunk * std::max(qkv_rows, in_proj_pad));
+    if (cfg.hybrid) pGY = dalloc<float>((size_t)chunk * cfg.value_dim());
     auto z = [&](size_t n) {
         uint16_t* p = dalloc<uint16_t>(n);
         CM_HIP(hipMemsetAsync(p, 0, n * sizeof(uint16_t), stream));
@@ -478,7 +480,8 @@ void Model::ensure_prefill_buffers() {
     };
     pXN_hi = z((size_t)chunk_pad * H); pXN_lo = z((size_t)chunk_pad * H);
     pQ_hi = z((size_t)chunk_pad * Hq_l * D); pQ_lo = z((size_t)chunk_pad * Hq_l * D);
-    pAT_hi = z((size_t)chunk_pad * Hq_l * D); pAT_lo = z((size_t)chunk_pad * Hq_l * D);
+    const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
+    pAT_hi = z((size_t)chunk_pad * at_cols); pAT_lo = z((size_t)chunk_pad * at_cols);
     pHH_hi = z((size_t)chunk_pad * I_l); pHH_lo = z((size_t)chunk_pad * I_l);
     d_ids = (uint32_t*)dalloc<int>(chunk);
     CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
@@ -487,7 +490,7 @@ void Model::ensure_prefill_buffers() {
 void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
-    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     const bool sp2 = prefill_split2;
     for (size_t off = 0; off < n; off += (size_t)chunk) {
         const int S = (int)std::min<size_t>((size_t)chunk, n - off);
@@ -500,6 +503,32 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             const LayerW& w = layers[(size_t)li];
             launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
             GemmArgs g{};
+            if (!w.full) {
+                // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
+                g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
+                g.M = S; g.N = in_proj_pad; g.K = H;
+                if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+                GdnArgs ga{};
+                ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
+                ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.st = nullptr;
+                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+                ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
+                ga.slot = active_seq;
+                // the conv windows are double-buffered by position parity: every launch must advance an ODD
+                // number of positions, so an even chunk is scanned as (S-1) + 1
+                int done = 0;
+                while (done < S) {
+                    const int part = ((S - done) % 2 == 1) ? (S - done) : (S - done - 1);
+                    ga.proj = pQKV + (size_t)done * in_proj_pad; ga.out = pGY + (size_t)done * cfg.value_dim();
+                    ga.start_pos = sp + done; ga.S = part;
+                    launch_gdn(ga, s);
+                    done += part;
+                }
+                launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
+                g = GemmArgs{};
+                g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
+                g.C = pX; launch_gemm(g, GEPI_RESADD, s);
+            } else {
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
             g.M = S; g.N = qkv_rows; g.K = H;
             if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
@@ -507,13 +536,16 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             q.qkv = pQKV; q.qnw = w.qn; q.knw = w.kn; q.cos = cos; q.sin = sin; q.block_table = d_bt;
             q.kpool = kpool(li); q.vpool = vpool(li); q.q_hi = pQ_hi; q.q_lo = pQ_lo;
             q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = sp; q.eps = cfg.eps;
+            q.row_stride = qkv_rows; q.q_off = 0; q.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; q.v_off = q.k_off + Hkv_l * D;
+            q.rot_dim = cfg.rot_dim;
             q.scale = (float)(1.0 / std::sqrt((double)D));
-            launch_qknorm_rope_kv(q, S, kv_f32, s);
+            launch_qknorm_rope_kv(q, D, S, kv_f32, s);
             AttnPreArgs at{};
             at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = d_bt; at.kpool = kpool(li); at.vpool = vpool(li);
             at.out_hi = pAT_hi; at.out_lo = pAT_lo; at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
             at.page = page; at.start_pos = sp;
-            launch_attn_prefill(at, kv_f32, s);
+            at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
+            launch_attn_prefill(at, D, kv_f32, s);
             g = GemmArgs{};
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
@@ -522,6 +554,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
                 launch_add_rows(pX, pY, (size_t)S * H, s);
             }
+            }   // full-attention layer
             launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
             g = GemmArgs{};
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;

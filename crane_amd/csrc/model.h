@@ -148,6 +148,7 @@ struct Model {
     uint16_t *pQ_hi = nullptr, *pQ_lo = nullptr;       // [chunk_pad, Hq_l D]
     uint16_t *pAT_hi = nullptr, *pAT_lo = nullptr;     // [chunk_pad, Hq_l D]
     uint16_t *pHH_hi = nullptr, *pHH_lo = nullptr;     // [chunk_pad, I_l]
+    float* pGY = nullptr;       // [chunk, value_dim] f32 GDN output (Qwen3.5)
     uint32_t* d_ids = nullptr;
     uint32_t* h_ids = nullptr;
 

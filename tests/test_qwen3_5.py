@@ -131,3 +131,29 @@ def test_hip_qwen35_sequences_and_state():
         assert rel(l3, o.forward(ids, 0)) < 1e-4
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 19, 64, 130])
+def test_hip_qwen35_prefill_equals_token_serial(n):
+    """MFMA prefill (in_proj GEMM + sequential delta-rule scan + D=256 gated flash attention) == token-serial
+    GEMV path == oracle; even/odd lengths exercise the conv-window parity split."""
+    from crane_amd.backend import Model
+    g, cfg, w = _load()
+    o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32", prefill_chunk=96)
+    try:
+        ids = configs.synthetic_prompt(n, cfg["vocab_size"])
+        a = m.forward_step(ids, 0)[0, 0]
+        nxt = m.forward_step([5], n)[0, 0]
+        os.environ["CM_NO_PREFILL"] = "1"
+        try:
+            m.clear_kv_cache()
+            b = m.forward_step(ids, 0)[0, 0]
+        finally:
+            del os.environ["CM_NO_PREFILL"]
+        ref = o.forward(ids, 0)
+        assert rel(a, b) < 1e-4 and rel(a, ref) < 1e-4
+        assert rel(nxt, o.forward([5], n)) < 1e-4
+    finally:
+        m.close()
