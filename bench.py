@@ -118,6 +118,17 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "bytes_per_launch": kb["bytes"], "us_per_launch": round(kb["ms"] * 1e3, 3)}
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+        # PMC traffic cannot be collected inside this process: it comes from the committed rocprofv3 --pmc passes
+        # (profiles/r01_pmc_traffic_decode.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch
+        try:
+            if args.model == "qwen3-8b":
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_decode.json")))
+                for r in pm["kernels"]:
+                    if "gemv_bf16_kernel<1, 2," in r["kernel"]:
+                        roof["traffic"] = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
+                        roof["traffic_source"] = "profiles/r01_pmc_traffic_decode.json"
+        except Exception:
+            pass
     except Exception as e:
         roof = {"bound": "hbm", "error": str(e)}
     step_gbs = bytes_tok_rank / (ms_per_step * 1e-3) / 1e9

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 8;
             ra[0][i] = ld16(a.A_hi + (size_t)(m0 + row) * K + k0 + kc);
             if (SPLIT == 2) ra[SPLIT - 1][i] = ld16(a.A_lo + (size_t)(m0 + row) * K + k0 + kc);
-            rb[i] = ld_nt16(a.W + (size_t)(n0 + row) * K + k0 + kc);
+            rb[i] = ld16(a.W + (size_t)(n0 + row) * K + k0 + kc);   // cacheable: other m-tiles of this XCD reuse the weight tile from L2
         }
     };
     auto s_store = [&](int buf) {
