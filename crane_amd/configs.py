@@ -60,6 +60,28 @@ CONFIGS.update({
 })
 
 
+def _vl(text: dict, vision: dict, image_token_id: int) -> dict:
+    t = dict(text)
+    tie = t.pop("tie_word_embeddings", False)
+    return dict(model_type="qwen3_5", text_config=t, vision_config=vision, tie_word_embeddings=tie,
+                image_token_id=image_token_id, vision_start_token_id=image_token_id - 1,
+                vision_end_token_id=image_token_id + 1, torch_dtype="bfloat16")
+
+
+_VISION_COMMON = dict(model_type="qwen3_5_vision", hidden_act="gelu_pytorch_tanh", in_channels=3, patch_size=16,
+                      temporal_patch_size=2, spatial_merge_size=2)
+CONFIGS.update({
+    # Qwen3-VL-2B-class tower ([external]): depth 24, hidden 1024, 16 heads, inter 4096, pos-emb 2304;
+    # text side = the reference's LIVE VL text model (qwen3_5/vlm.rs): Qwen3.5-0.8B
+    "qwen3.5-vl-0.8b": _vl(CONFIGS["qwen3.5-0.8b"],
+                           dict(_VISION_COMMON, depth=24, hidden_size=1024, num_heads=16, intermediate_size=4096,
+                                out_hidden_size=1024, num_position_embeddings=2304), 248056),
+    "tiny-qwen3.5-vl": _vl(CONFIGS["tiny-qwen3.5"],
+                           dict(_VISION_COMMON, depth=2, hidden_size=256, num_heads=4, intermediate_size=512,
+                                out_hidden_size=256, num_position_embeddings=64), 500),
+})
+
+
 def get_config(name: str) -> dict:
     if name not in CONFIGS:
         raise KeyError(f"unknown config {name!r}; have {sorted(CONFIGS)}")

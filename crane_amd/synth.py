@@ -179,8 +179,39 @@ def qwen3_5_specs(cfg: dict) -> List[Spec]:
     return sp
 
 
+def qwen3_5_vl_specs(cfg: dict) -> List[Spec]:
+    """Qwen 3.5-VL: language model under `model.language_model.` (prefix probing, qwen3_5/model.rs:65-74) +
+    vision tower under `model.visual.` (qwen3_5/vlm.rs:125; shapes: tests/test_qwen35_family_shapes.py:104-131)."""
+    t, v = cfg["text_config"], cfg["vision_config"]
+    text = dict(t, tie_word_embeddings=cfg.get("tie_word_embeddings", t.get("tie_word_embeddings", False)))
+    sp = [((n.replace("model.", "model.language_model.", 1) if n.startswith("model.") else n), s, sd, o)
+          for n, s, sd, o in qwen3_5_specs(text)]
+    VH, VI, P, T, C = v["hidden_size"], v["intermediate_size"], v["patch_size"], v["temporal_patch_size"], v.get("in_channels", 3)
+    M = v.get("spatial_merge_size", 2) ** 2
+    p = "model.visual."
+    sp += [(p + "patch_embed.proj.weight", (VH, C, T, P, P), 1 / math.sqrt(C * T * P * P), 0.0),
+           (p + "patch_embed.proj.bias", (VH,), 0.1, 0.0),
+           (p + "pos_embed.weight", (v["num_position_embeddings"], VH), 0.5, 0.0)]
+    for i in range(v["depth"]):
+        b = f"{p}blocks.{i}."
+        sp += [(b + "norm1.weight", (VH,), 0.1, 1.0), (b + "norm1.bias", (VH,), 0.1, 0.0),
+               (b + "norm2.weight", (VH,), 0.1, 1.0), (b + "norm2.bias", (VH,), 0.1, 0.0),
+               (b + "attn.qkv.weight", (3 * VH, VH), 1 / math.sqrt(VH), 0.0), (b + "attn.qkv.bias", (3 * VH,), 0.1, 0.0),
+               (b + "attn.proj.weight", (VH, VH), 1 / math.sqrt(VH), 0.0), (b + "attn.proj.bias", (VH,), 0.1, 0.0),
+               (b + "mlp.linear_fc1.weight", (VI, VH), 1 / math.sqrt(VH), 0.0), (b + "mlp.linear_fc1.bias", (VI,), 0.1, 0.0),
+               (b + "mlp.linear_fc2.weight", (VH, VI), 1 / math.sqrt(VI), 0.0), (b + "mlp.linear_fc2.bias", (VH,), 0.1, 0.0)]
+    m = p + "merger."
+    sp += [(m + "norm.weight", (VH,), 0.1, 1.0), (m + "norm.bias", (VH,), 0.1, 0.0),
+           (m + "linear_fc1.weight", (VH * M, VH * M), 1 / math.sqrt(VH * M), 0.0), (m + "linear_fc1.bias", (VH * M,), 0.1, 0.0),
+           (m + "linear_fc2.weight", (v["out_hidden_size"], VH * M), 1 / math.sqrt(VH * M), 0.0),
+           (m + "linear_fc2.bias", (v["out_hidden_size"],), 0.1, 0.0)]
+    return sp
+
+
 def specs_for(cfg: dict) -> List[Spec]:
     mt = cfg.get("model_type", "qwen3")
+    if "vision_config" in cfg and "text_config" in cfg:
+        return qwen3_5_vl_specs(cfg)
     if mt == "qwen3":
         return qwen3_specs(cfg)
     if mt in ("qwen3_5", "qwen3_5_text"):

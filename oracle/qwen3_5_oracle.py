@@ -181,6 +181,8 @@ class Qwen35Oracle:
         q = rms_norm_1p(q, w[p + "q_norm.weight"], c.rms_norm_eps)          # (:464-465)
         k = rms_norm_1p(k, w[p + "k_norm.weight"], c.rms_norm_eps)
         cos, sin = self.cos[start:start + S], self.sin[start:start + S]
+        if getattr(self, "_rope_override", None) is not None:
+            cos, sin = self._rope_override
         q = apply_partial_rope(q, cos, sin, c.rot_dim)
         k = apply_partial_rope(k, cos, sin, c.rot_dim)
         k, v = k.transpose(1, 0, 2), v.transpose(1, 0, 2)
@@ -235,12 +237,27 @@ class Qwen35Oracle:
         yn = rms_norm_plain(y.reshape(-1, V), w[p + "norm.weight"], c.rms_norm_eps) * silu(z.reshape(-1, V))
         return (yn.reshape(S, NV * V) @ w[p + "out_proj.weight"].T).astype(F32)
 
-    def forward(self, input_ids: Sequence[int], start_pos: int) -> np.ndarray:
-        """Logits [V] of the LAST position (model.rs:504-510)."""
+    def mrope_cos_sin(self, pos3: np.ndarray, mrope_section=(11, 11, 10)):
+        """cos_sin_with_position_ids (modeling.rs:156-245): INDEX-interleaved MRoPE -- column i of the
+        half-rot table is served by axis i % 3 (T, H, W) until that axis' section runs out, else by T."""
+        half = self.cfg.rot_dim // 2
+        axis_of = np.zeros(half, dtype=np.int64)
+        for dim, offset in ((1, 1), (2, 2)):
+            limit = min(mrope_section[dim] * 3, half)
+            axis_of[offset:limit:3] = dim
+        cols = np.arange(half)
+        rows = np.asarray(pos3, dtype=np.int64)[axis_of, :].T            # [S, half]
+        return self.cos[rows, cols[None, :]], self.sin[rows, cols[None, :]]
+
+    def forward(self, input_ids: Sequence[int], start_pos: int, embeds: Optional[np.ndarray] = None,
+                pos3: Optional[np.ndarray] = None) -> np.ndarray:
+        """Logits [V] of the LAST position (model.rs:504-510).  `embeds` [S,H] replaces the embedding lookup and
+        `pos3` [3,S] the rotary positions (forward_embeds, model.rs:430-462) -- KV/cache index stays start_pos."""
         c, w = self.cfg, self.w
         if start_pos == 0:
             self.clear_kv_cache()
-        h = self.embed[np.asarray(input_ids, dtype=np.int64)].astype(F32)
+        h = (self.embed[np.asarray(input_ids, dtype=np.int64)] if embeds is None else embeds).astype(F32)
+        self._rope_override = None if pos3 is None else self.mrope_cos_sin(pos3)
         for li in range(c.num_hidden_layers):
             p = f"{self.p}layers.{li}."
             xn = rms_norm_1p(h, w[p + "input_layernorm.weight"], c.rms_norm_eps)
