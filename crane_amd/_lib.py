@@ -23,7 +23,7 @@ EXPORTS = [
     "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
-    "cm_decode_batch", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
+    "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
 ]
 
 
@@ -100,6 +100,10 @@ def load():
     lib.cm_seq_truncate.argtypes = [vp, C.c_int32, C.c_size_t]
     lib.cm_seq_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, u32p]
     lib.cm_decode_batch.argtypes = [vp, P(C.c_int32), u32p, C.c_size_t, f32p, u32p]
+    lib.cm_image_token_id.argtypes = [vp]
+    lib.cm_image_token_id.restype = C.c_int64
+    lib.cm_vision_encode.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, P(C.c_size_t)]
+    lib.cm_vlm_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, u32p, C.c_size_t, f32p, u32p]
     lib.cm_bench_decode.argtypes = [vp, C.c_uint32, C.c_size_t, u32p, f32p]
     lib.cm_bench_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, f32p, P(C.c_uint64)]
     lib.cm_debug_fill_kv.argtypes = [vp, C.c_size_t, C.c_uint64]

@@ -264,6 +264,33 @@ class Model:
         self._check(rc)
         return [int(t) for t in out[:n_out.value]]
 
+    # -- vision-language (qwen3_5/vision.rs, vlm.rs) ----------------------------------
+    def image_token_id(self) -> int:
+        return int(self._lib.cm_image_token_id(self._h))
+
+    def encode_images(self, pixel_values: np.ndarray, grid_thw) -> np.ndarray:
+        """Qwen3_5VLModel::encode_images -> [n_patches / merge^2, out_hidden] f32."""
+        pv = np.ascontiguousarray(pixel_values, dtype=np.float32)
+        g = np.ascontiguousarray(np.asarray(grid_thw, dtype=np.uint32).reshape(-1, 3))
+        rows = C.c_size_t(0)
+        out = np.empty((pv.shape[0], self.hidden_size), dtype=np.float32)       # upper bound on rows
+        self._check(self._lib.cm_vision_encode(self._h, pv.ctypes.data_as(C.POINTER(C.c_float)), pv.shape[0],
+                                               g.ctypes.data_as(C.POINTER(C.c_uint32)), g.shape[0],
+                                               out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rows)))
+        return out.reshape(-1)[: rows.value * self.hidden_size].reshape(rows.value, self.hidden_size).copy()
+
+    def vlm_forward(self, input_ids: Sequence[int], pixel_values: np.ndarray, grid_thw, start_pos: int = 0, seq: int = 0):
+        """Qwen3_5VLModel::forward (vlm.rs:250-285): logits [V] of the last position and its arg-max."""
+        arr, p = _u32(input_ids)
+        pv = np.ascontiguousarray(pixel_values, dtype=np.float32)
+        g = np.ascontiguousarray(np.asarray(grid_thw, dtype=np.uint32).reshape(-1, 3))
+        out = np.empty(self.vocab_size, dtype=np.float32)
+        t = C.c_uint32()
+        self._check(self._lib.cm_vlm_forward(self._h, seq, p, arr.size, start_pos, pv.ctypes.data_as(C.POINTER(C.c_float)),
+                                             pv.shape[0], g.ctypes.data_as(C.POINTER(C.c_uint32)), g.shape[0],
+                                             out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(t)))
+        return out, int(t.value)
+
     # -- measurement hooks --------------------------------------------------------
     def bench_decode(self, first_token: int, k: int):
         toks = np.empty(k, dtype=np.uint32)

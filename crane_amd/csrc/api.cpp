@@ -175,6 +175,27 @@ int cm_decode_batch(cm_model* h, const int32_t* seqs, const uint32_t* last_token
     });
 }
 
+int64_t cm_image_token_id(const cm_model* h) { return (h && h->m.vcfg.present) ? (int64_t)h->m.vcfg.image_token : -1; }
+
+int cm_vision_encode(cm_model* h, const float* pixel_values, size_t n_patches, const uint32_t* grid_thw, size_t n_images,
+                     float* features_out, size_t* rows_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        const int rows = h->m.vision_encode(pixel_values, n_patches, grid_thw, n_images);
+        if (rows_out) *rows_out = (size_t)rows;
+        if (features_out) {
+            CM_HIP(hipStreamSynchronize(h->m.stream));
+            CM_HIP(hipMemcpy(features_out, h->m.vFeat, (size_t)rows * h->m.vcfg.out_hidden * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+int cm_vlm_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, const float* pixel_values,
+                   size_t n_patches, const uint32_t* grid_thw, size_t n_images, float* logits_out, uint32_t* greedy_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.vlm_forward(seq, ids, n, start_pos, pixel_values, n_patches, grid_thw, n_images, logits_out, greedy_out); });
+}
+
 int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
     if (!h) return CM_ERR_INVALID;
     return guard(h, [&] { h->m.bench_decode(first_token, k, tokens_out, ms_out); });

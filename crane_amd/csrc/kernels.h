@@ -59,7 +59,7 @@ struct GdnArgs {
 };
 
 // ---- prefill (S > 1) ----
-enum { GEPI_STORE = 0, GEPI_RESADD = 1, GEPI_SILUMUL = 2 };
+enum { GEPI_STORE = 0, GEPI_RESADD = 1, GEPI_SILUMUL = 2, GEPI_ACT_SPLIT = 3 };
 
 struct GemmArgs {
     const uint16_t* A_hi;   // [Mpad, K] bf16 activations (hi term)
@@ -68,6 +68,8 @@ struct GemmArgs {
     float* C;               // GEPI_STORE: C[m*ldc+n] = acc; GEPI_RESADD: C[m*ldc+n] += acc
     uint16_t* H_hi;         // GEPI_SILUMUL: [M, N/2] bf16 hi (+lo) of silu(gate)*up
     uint16_t* H_lo;
+    const float* bias;      // [N] f32 added before the epilogue, or null
+    int act;                // GEPI_ACT_SPLIT: 0 identity, 1 gelu (tanh form), 2 gelu (erf form)
     int M, N, K, ldc;
 };
 
@@ -84,6 +86,8 @@ struct QkRopeArgs {
     uint16_t* q_lo;
     int Hq, Hkv, page, start_pos;
     int row_stride, q_off, k_off, v_off, rot_dim;   // layout of one token's projection row
+    const int32_t* pos3;         // MRoPE positions (T, H, W): pos3[axis * pos3_stride + s], or null (position = start_pos + s)
+    int pos3_stride, sec_h, sec_w;   // mrope_section[1], [2]
     float eps, scale;
 };
 
@@ -98,6 +102,7 @@ struct AttnPreArgs {
     const float* gate;           // [S, gate_stride] f32 (Qwen3.5 output gate) or null
     int gate_stride;
     int S, Hq, Hkv, nrep, page, start_pos;
+    int causal, kv_lo, kv_hi;    // causal = 0: bidirectional over tokens [kv_lo, kv_hi) (ViT frame)
 };
 
 void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
@@ -109,12 +114,20 @@ void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s);
 
+// ---- vision tower (kernels_vision.hip) ----
+void launch_layernorm_rows(const float* x, const float* w, const float* b, uint16_t* hi, uint16_t* lo, int N, int H, float eps,
+                           hipStream_t s);
+void launch_pos_embed_add(float* x, const uint16_t* table, const int32_t* idx, const float* wts, int N, int H, hipStream_t s);
+void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, float* kpool,
+                        float* vpool, int N, int heads, float scale, hipStream_t s);
+void launch_splice_rows(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s);
+
 // ---- decode ----
 int gemv_rows_per_group(int K);
 int gemv_grid(int N, int K, int num_cu);
 void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s);
 void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s);
-void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, hipStream_t s);
+void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, hipStream_t s);
 bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s);

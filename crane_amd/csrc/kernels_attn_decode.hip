@@ -33,7 +33,6 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     const int split = blockIdx.x, kvh = blockIdx.y, nsplit = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane / LPR, sub = lane % LPR, dimbase = sub * 8;
-    const int Hq = a.Hkv * NREP;
 
     // Token -> block mapping is INTERLEAVED: chunk j of split s covers tokens
     // [CT*(s + nsplit*j), +CT).  The first two chunks of every block are known without reading
@@ -63,6 +62,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
         vq[u] = ld_kv(a.vpool, off);
     }
     const int pos = a.st->pos;
+    const int rpos = pos + a.st->rsv[0];          // rotary position = cache position + MRoPE delta (vlm.rs:294-301)
     const int L = pos + 1;
     const bool owner = ((pos / CT) % nsplit) == split;
     const int rot = a.rot_dim, hrot = rot >> 1;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
                 const int d = lane + 64 * j;
                 if (d < rot) {
                     const int i = d < hrot ? d : d - hrot;
-                    const float c = a.cos[(size_t)pos * hrot + i], s = a.sin[(size_t)pos * hrot + i];
+                    const float c = a.cos[(size_t)rpos * hrot + i], s = a.sin[(size_t)rpos * hrot + i];
                     const float lo = tmp[wave][i], hi = tmp[wave][i + hrot];
                     xv[j] = d < hrot ? lo * c - hi * s : lo * s + hi * c;
                 }

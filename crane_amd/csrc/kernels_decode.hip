@@ -31,8 +31,8 @@ __global__ void embed_row_kernel(const uint16_t* __restrict__ emb, const StepSta
     }
 }
 
-__global__ void set_state_kernel(StepState* st, uint32_t token, int32_t pos, int32_t slot) {
-    st->token = token; st->pos = pos; st->slot = slot;
+__global__ void set_state_kernel(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta) {
+    st->token = token; st->pos = pos; st->slot = slot; st->rsv[0] = rope_delta;
 }
 
 // =====================================================================================
@@ -320,8 +320,8 @@ void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s) {
 void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s) {
     hipLaunchKernelGGL(embed_row_kernel, dim3((H / 4 + 255) / 256), dim3(256), 0, s, emb, st, x, H, V);
 }
-void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, hipStream_t s) {
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, token, pos, slot);
+void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, token, pos, slot, rope_delta);
 }
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, hipStream_t s) {

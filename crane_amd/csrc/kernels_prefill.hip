@@ -100,7 +100,12 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
             const int d = lane + 64 * j;
             if (d < rot) {
                 const int i = d < hrot ? d : d - hrot;
-                const float c = a.cos[(size_t)pos * hrot + i], sn = a.sin[(size_t)pos * hrot + i];
+                int rp = pos;
+                if (a.pos3 != nullptr) {   // index-interleaved MRoPE (qwen3_5/modeling.rs:156-245): column i -> axis i % 3
+                    const int ax = (i % 3 == 1 && i < 3 * a.sec_h) ? 1 : ((i % 3 == 2 && i < 3 * a.sec_w) ? 2 : 0);
+                    rp = a.pos3[ax * a.pos3_stride + s];
+                }
+                const float c = a.cos[(size_t)rp * hrot + i], sn = a.sin[(size_t)rp * hrot + i];
                 const float lo = tmp[i], hi = tmp[i + hrot];
                 xv[j] = d < hrot ? lo * c - hi * sn : lo * sn + hi * c;
             }
@@ -232,11 +237,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
-                const float v = acc[i][j][r];
+                float v = acc[i][j][r];
+                if (a.bias != nullptr) v += a.bias[n];
                 if (EPI == GEPI_STORE) {
                     if (m < a.M) a.C[(size_t)m * a.ldc + n] = v;
                 } else if (EPI == GEPI_RESADD) {
                     if (m < a.M) a.C[(size_t)m * a.ldc + n] += v;
+                } else if (EPI == GEPI_ACT_SPLIT) {   // H[m, n] = act(v) as bf16 hi (+lo): A operand of the next GEMM
+                    if (m < a.M) {
+                        float h = v;
+                        if (a.act == 1) h = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+                        else if (a.act == 2) h = 0.5f * v * (1.0f + erff(v * 0.7071067811865476f));
+                        const size_t off = (size_t)m * a.N + n;
+                        const uint16_t hh = f32_to_bf16(h);
+                        a.H_hi[off] = hh;
+                        if (a.H_lo) a.H_lo[off] = f32_to_bf16(h - bf16_to_f32(hh));
+                    }
                 } else {   // GEPI_SILUMUL: even column = gate_j, odd column = up_j
                     const float up = dpp_mov<0xB1>(v);          // lane ^ 1
                     if (((lane & 1) == 0) && m < a.M) {
@@ -282,8 +298,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int last_q = min(qb + 63, a.S - 1);
-    const int kv_end = a.start_pos + last_q + 1;            // tokens [0, kv_end) are visible to this block
-    for (int t0 = 0; t0 < kv_end; t0 += KT) {
+    // causal: tokens [0, start_pos + last_q] ; window (ViT frame): tokens [kv_lo, kv_hi), bidirectional
+    const int kv_end = a.causal ? a.start_pos + last_q + 1 : a.kv_hi;
+    for (int t0 = a.causal ? 0 : a.kv_lo; t0 < kv_end; t0 += KT) {
         __syncthreads();                                   // previous tile's V fully consumed
         // ---- stage V tile (64 tokens x D dims) into LDS, shared by the 4 waves ----
 #pragma unroll
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = t0 + tt * 16 + g * 4 + r;
-                if (t > qpos) s[tt][r] = -INFINITY;
+                if (a.causal ? (t > qpos) : (t >= kv_end)) s[tt][r] = -INFINITY;
                 mt = fmaxf(mt, s[tt][r]);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 16));
@@ -440,16 +457,20 @@ bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
     const bool split = a.A_lo != nullptr;
 #define CM_GEMM(SP, EP) hipLaunchKernelGGL((gemm_bf16_kernel<SP, EP>), dim3(tiles), dim3(256), 0, s, a)
     if (split) {
-        if (epi == GEPI_STORE) CM_GEMM(2, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(2, GEPI_RESADD); else CM_GEMM(2, GEPI_SILUMUL);
+        if (epi == GEPI_STORE) CM_GEMM(2, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(2, GEPI_RESADD);
+        else if (epi == GEPI_ACT_SPLIT) CM_GEMM(2, GEPI_ACT_SPLIT); else CM_GEMM(2, GEPI_SILUMUL);
     } else {
-        if (epi == GEPI_STORE) CM_GEMM(1, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(1, GEPI_RESADD); else CM_GEMM(1, GEPI_SILUMUL);
+        if (epi == GEPI_STORE) CM_GEMM(1, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(1, GEPI_RESADD);
+        else if (epi == GEPI_ACT_SPLIT) CM_GEMM(1, GEPI_ACT_SPLIT); else CM_GEMM(1, GEPI_SILUMUL);
     }
 #undef CM_GEMM
     return true;
 }
 void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s) {
     dim3 grid((a.S + 63) / 64, a.Hq);
-    if (D == 128) {
+    if (D == 64) {
+        hipLaunchKernelGGL((attn_prefill_kernel<64, true>), grid, dim3(256), 0, s, a);     // ViT: f32 K/V scratch
+    } else if (D == 128) {
         if (kv_f32) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, dim3(256), 0, s, a);
     } else {

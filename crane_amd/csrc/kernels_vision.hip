@@ -1,0 +1,112 @@
+// Vision-tower (Qwen 3.5-VL ViT) row kernels; the projections reuse the MFMA GEMM of
+// kernels_prefill.hip (bias / GELU epilogues) and the bidirectional per-frame attention reuses
+// attn_prefill_kernel<64> in window mode.  Reference: crane-core/src/models/qwen3_5/vision.rs.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+__device__ __forceinline__ void split_store4v(uint16_t* hi, uint16_t* lo, size_t off, const float v[4]) {
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = f32_to_bf16(v[i]); l[i] = f32_to_bf16(v[i] - bf16_to_f32(h[i])); }
+    *(u32x2*)(hi + off) = (u32x2){(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+    if (lo) *(u32x2*)(lo + off) = (u32x2){(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+}
+
+// LayerNorm with bias, eps 1e-6 (vision.rs:195-203,250-255): one block per row -> bf16 hi (+lo)
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, uint16_t* __restrict__ hi,
+                                                             uint16_t* __restrict__ lo, int H, float eps) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (size_t)row * H;
+    float s = 0.f;
+    for (int i = tid * 4; i < H; i += 1024) { const f32x4 v = *(const f32x4*)(xr + i); s += v[0] + v[1] + v[2] + v[3]; }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mu = ((red[0] + red[1]) + (red[2] + red[3])) / (float)H;
+    float q = 0.f;
+    for (int i = tid * 4; i < H; i += 1024) {
+        const f32x4 v = *(const f32x4*)(xr + i);
+        q += (v[0] - mu) * (v[0] - mu) + (v[1] - mu) * (v[1] - mu) + (v[2] - mu) * (v[2] - mu) + (v[3] - mu) * (v[3] - mu);
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float r = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)H + eps);
+    for (int i = tid * 4; i < H; i += 1024) {
+        const f32x4 v = *(const f32x4*)(xr + i);
+        const f32x4 ww = *(const f32x4*)(w + i), bb = *(const f32x4*)(b + i);
+        const float o[4] = {(v[0] - mu) * r * ww[0] + bb[0], (v[1] - mu) * r * ww[1] + bb[1],
+                            (v[2] - mu) * r * ww[2] + bb[2], (v[3] - mu) * r * ww[3] + bb[3]};
+        split_store4v(hi, lo, (size_t)row * H + i, o);
+    }
+}
+
+// x[n, :] += sum_k wts[k][n] * table[idx[k][n], :]   (fast_pos_embed_interpolate, vision.rs:382-489; the
+// block-major permutation is folded into idx/wts on the host)
+__global__ void pos_embed_add_kernel(float* __restrict__ x, const uint16_t* __restrict__ table, const int32_t* __restrict__ idx,
+                                     const float* __restrict__ wts, int N, int H) {
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += wts[k * N + n] * bf16_to_f32(table[(size_t)idx[k * N + n] * H + i]);
+        x[(size_t)n * H + i] += acc;
+    }
+}
+
+// grid (N, 3 * heads), block 64 (one lane per head dim, hd == 64): q/k get q*cos + rotate_half(q)*sin over the
+// whole head (vision.rs:86-106); q scaled by 1/sqrt(hd) -> bf16 hi/lo [N, heads, hd]; k, v -> f32 scratch in the
+// paged layout [page][heads][64 tokens][hd] with an identity block table.
+__global__ __launch_bounds__(64) void vit_rope_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
+                                                         const float* __restrict__ sn, uint16_t* __restrict__ q_hi,
+                                                         uint16_t* __restrict__ q_lo, float* __restrict__ kpool,
+                                                         float* __restrict__ vpool, int heads, float scale) {
+    constexpr int HD = 64;
+    const int n = blockIdx.x, item = blockIdx.y, d = threadIdx.x;
+    const int which = item / heads, h = item % heads;            // 0 q, 1 k, 2 v  (reshape (N, 3, heads, hd))
+    const float x = qkv[(size_t)n * 3 * heads * HD + (size_t)item * HD + d];
+    float o = x;
+    if (which < 2) {
+        const float partner = __shfl_xor(x, 32);                 // rotate_half: d < 32 -> -x[d+32], else x[d-32]
+        const float rh = d < 32 ? -partner : partner;
+        o = x * cs[(size_t)n * HD + d] + rh * sn[(size_t)n * HD + d];
+    }
+    if (which == 0) {
+        o *= scale;
+        const size_t off = ((size_t)n * heads + h) * HD + d;
+        const uint16_t hh = f32_to_bf16(o);
+        q_hi[off] = hh; q_lo[off] = f32_to_bf16(o - bf16_to_f32(hh));
+    } else {
+        float* pool = which == 1 ? kpool : vpool;
+        pool[((size_t)((n >> 6) * heads + h) * 64 + (n & 63)) * HD + d] = o;
+    }
+}
+
+// dst[s, :] = src[map[s], :] where map[s] >= 0  (splice_image_features, vlm.rs:433-468)
+__global__ void splice_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ map, int H) {
+    const int s = blockIdx.x;
+    const int m = map[s];
+    if (m < 0) return;
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) *(f32x4*)(dst + (size_t)s * H + i) = *(const f32x4*)(src + (size_t)m * H + i);
+}
+
+void launch_layernorm_rows(const float* x, const float* w, const float* b, uint16_t* hi, uint16_t* lo, int N, int H, float eps,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(N), dim3(256), 0, s, x, w, b, hi, lo, H, eps);
+}
+void launch_pos_embed_add(float* x, const uint16_t* table, const int32_t* idx, const float* wts, int N, int H, hipStream_t s) {
+    hipLaunchKernelGGL(pos_embed_add_kernel, dim3(N), dim3(256), 0, s, x, table, idx, wts, N, H);
+}
+void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, float* kpool,
+                        float* vpool, int N, int heads, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(vit_rope_kv_kernel, dim3(N, 3 * heads), dim3(64), 0, s, qkv, cs, sn, q_hi, q_lo, kpool, vpool, heads, scale);
+}
+void launch_splice_rows(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s) {
+    hipLaunchKernelGGL(splice_rows_kernel, dim3(S), dim3(256), 0, s, dst, src, map, H);
+}
+
+}  // namespace cm

@@ -49,6 +49,18 @@ struct SynthSource : Source {
             return name.size() >= n && name.compare(name.size() - n, n, suf) == 0;
         };
         const bool hy = c.hybrid;
+        if (name.compare(0, 13, "model.visual.") == 0) {         // crane_amd/synth.py qwen3_5_vl_specs
+            const VisionCfg& v = m.vcfg;
+            const int MH = v.hidden * v.merge * v.merge;
+            if (ends("norm.weight") || ends("norm1.weight") || ends("norm2.weight")) { std = 0.1; off = 1.0f; }
+            else if (ends(".bias")) std = 0.1;
+            else if (ends("pos_embed.weight")) std = 0.5;
+            else if (ends("patch_embed.proj.weight")) std = 1.0 / std::sqrt((double)v.patch_dim());
+            else if (ends("mlp.linear_fc2.weight")) std = 1.0 / std::sqrt((double)v.inter);
+            else if (ends("merger.linear_fc1.weight") || ends("merger.linear_fc2.weight")) std = 1.0 / std::sqrt((double)MH);
+            else std = 1.0 / std::sqrt((double)v.hidden);
+            return;
+        }
         if (ends("embed_tokens.weight")) std = 1.0;
         else if (ends("linear_attn.norm.weight")) { std = 0.1; off = 1.0f; }
         else if (ends("norm.weight") || ends("layernorm.weight")) { std = 0.1; off = hy ? 0.0f : 1.0f; }
@@ -127,7 +139,7 @@ void build(Model& m, Source& src) {
     const float off = c.norm_off;
     // Qwen3.5 checkpoints keep the LM under `model.language_model.` (VLM) or `model.` (text-only);
     // prefix probing as qwen3_5/model.rs:65-74
-    std::string pre = "model.";
+    std::string pre = (src.synthetic() && m.vcfg.present) ? "model.language_model." : "model.";
     if (c.hybrid && !src.synthetic()) {
         for (const char* cand : {"model.language_model.", "language_model.", "model.", ""}) {
             if (src.has(std::string(cand) + "embed_tokens.weight")) { pre = cand; break; }
@@ -204,6 +216,34 @@ void build(Model& m, Source& src) {
         src.fetch(p + "mlp.down_proj.weight", H, I, 0, H, m.rank * m.I_l, m.I_l, w.down, (size_t)m.I_l);
         w.ln1 = fetch_f32(m, src, p + "input_layernorm.weight", H, off);
         w.ln2 = fetch_f32(m, src, p + "post_attention_layernorm.weight", H, off);
+    }
+    if (m.vcfg.present) {
+        // vision tower under `model.visual.` (qwen3_5/vlm.rs:125)
+        const VisionCfg& v = m.vcfg;
+        const std::string vp = "model.visual.";
+        const int VH = v.hidden, VI = v.inter, PD = v.patch_dim(), MH = VH * v.merge * v.merge;
+        auto mat = [&](const std::string& n, int rows, int cols) {
+            uint16_t* p = m.dalloc<uint16_t>((size_t)rows * cols, true);
+            src.fetch(n, rows, cols, 0, rows, 0, cols, p, (size_t)cols);
+            return p;
+        };
+        m.vw.patch_w = mat(vp + "patch_embed.proj.weight", VH, PD);       // [VH, C, T, P, P] flattened
+        m.vw.patch_b = fetch_f32(m, src, vp + "patch_embed.proj.bias", VH, 0.f);
+        m.vw.pos_table = mat(vp + "pos_embed.weight", v.num_pos, VH);
+        m.vw.blocks.resize((size_t)v.depth);
+        for (int i = 0; i < v.depth; ++i) {
+            VisionBlockW& b = m.vw.blocks[(size_t)i];
+            const std::string bp = vp + "blocks." + std::to_string(i) + ".";
+            b.n1w = fetch_f32(m, src, bp + "norm1.weight", VH, 0.f); b.n1b = fetch_f32(m, src, bp + "norm1.bias", VH, 0.f);
+            b.n2w = fetch_f32(m, src, bp + "norm2.weight", VH, 0.f); b.n2b = fetch_f32(m, src, bp + "norm2.bias", VH, 0.f);
+            b.qkv_w = mat(bp + "attn.qkv.weight", 3 * VH, VH); b.qkv_b = fetch_f32(m, src, bp + "attn.qkv.bias", 3 * VH, 0.f);
+            b.proj_w = mat(bp + "attn.proj.weight", VH, VH); b.proj_b = fetch_f32(m, src, bp + "attn.proj.bias", VH, 0.f);
+            b.fc1_w = mat(bp + "mlp.linear_fc1.weight", VI, VH); b.fc1_b = fetch_f32(m, src, bp + "mlp.linear_fc1.bias", VI, 0.f);
+            b.fc2_w = mat(bp + "mlp.linear_fc2.weight", VH, VI); b.fc2_b = fetch_f32(m, src, bp + "mlp.linear_fc2.bias", VH, 0.f);
+        }
+        m.vw.mn_w = fetch_f32(m, src, vp + "merger.norm.weight", VH, 0.f); m.vw.mn_b = fetch_f32(m, src, vp + "merger.norm.bias", VH, 0.f);
+        m.vw.mfc1_w = mat(vp + "merger.linear_fc1.weight", MH, MH); m.vw.mfc1_b = fetch_f32(m, src, vp + "merger.linear_fc1.bias", MH, 0.f);
+        m.vw.mfc2_w = mat(vp + "merger.linear_fc2.weight", v.out_hidden, MH); m.vw.mfc2_b = fetch_f32(m, src, vp + "merger.linear_fc2.bias", v.out_hidden, 0.f);
     }
     CM_HIP(hipStreamSynchronize(m.stream));
 }

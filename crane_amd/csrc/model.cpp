@@ -59,7 +59,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     const cmjson::Value* root = j.get();
     // VLM checkpoints nest the LM config under text_config
     if (root->has("text_config") && !root->has("hidden_size")) root = root->get("text_config");
-    cfg.model_type = root->string("model_type", "qwen3");
+    cfg.model_type = root->string("model_type", j->string("model_type", "qwen3"));
     cfg.V = (int)root->integer("vocab_size", 0);
     cfg.H = (int)root->integer("hidden_size", 0);
     cfg.I = (int)root->integer("intermediate_size", 0);
@@ -99,6 +99,32 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
             prf = rp->number("partial_rotary_factor", 0.25);
         }
         cfg.rot_dim = (int)((double)cfg.D * prf);                  // config.rs:226-229
+        if (const cmjson::Value* rp = root->get("rope_parameters"))
+            if (const cmjson::Value* ms = rp->get("mrope_section"))
+                for (size_t i = 0; i < ms->arr.size() && i < 3; ++i) cfg.mrope_sec[i] = (int)ms->arr[i]->num;
+        if (const cmjson::Value* vc = j->get("vision_config")) {     // VisionConfig (qwen3_5/config.rs:120-160)
+            if (vc->kind == cmjson::Value::Obj) {
+                vcfg.present = true;
+                vcfg.depth = (int)vc->integer("depth", 0);
+                vcfg.hidden = (int)vc->integer("hidden_size", 0);
+                vcfg.heads = (int)vc->integer("num_heads", 0);
+                vcfg.inter = (int)vc->integer("intermediate_size", 0);
+                vcfg.patch = (int)vc->integer("patch_size", 16);
+                vcfg.tpatch = (int)vc->integer("temporal_patch_size", 2);
+                vcfg.merge = (int)vc->integer("spatial_merge_size", 2);
+                vcfg.in_ch = (int)vc->integer("in_channels", 3);
+                vcfg.out_hidden = (int)vc->integer("out_hidden_size", 0);
+                vcfg.num_pos = (int)vc->integer("num_position_embeddings", 0);
+                vcfg.act = vc->string("hidden_act", "gelu_pytorch_tanh") == "gelu_pytorch_tanh" ? 1 : 2;
+                const char* mg = getenv("CM_VISION_MERGER_GELU");
+                vcfg.merger_act = (mg && std::string(mg) == "erf") ? 2 : 1;
+                vcfg.image_token = j->integer("image_token_id", -1);
+                if (vcfg.depth <= 0 || vcfg.heads <= 0 || vcfg.hidden % vcfg.heads) throw CmError(CM_ERR_IO, "bad vision_config");
+                if (vcfg.hidden / vcfg.heads != 64) throw CmError(CM_ERR_UNSUPPORTED, "vision head_dim must be 64 (72 not implemented)");
+                const int side = (int)std::lround(std::sqrt((double)vcfg.num_pos));
+                if (side * side != vcfg.num_pos) throw CmError(CM_ERR_IO, "num_position_embeddings is not a perfect square");
+            }
+        }
         if (const cmjson::Value* lt = root->get("layer_types")) {   // HF spelling; must agree with the interval rule
             for (size_t i = 0; i < lt->arr.size() && (int)i < cfg.L; ++i) {
                 const bool full = lt->arr[i]->str == "full_attention";
@@ -272,6 +298,7 @@ void Model::seq_truncate(int s, size_t new_len) {
         if (--page_ref[(size_t)p] == 0) free_pages.push_back(p);
     }
     q.len = (int64_t)new_len;
+    if (new_len == 0) q.rope_delta = 0;
     if (active_seq == s) active_pages_uploaded = std::min(active_pages_uploaded, q.pages.size());
 }
 
@@ -293,6 +320,7 @@ int Model::seq_fork(int src) {
     const int d = seq_alloc();
     Seq& b = seqs[(size_t)d];
     b.len = a.len;
+    b.rope_delta = a.rope_delta;
     b.pages = a.pages;
     for (int32_t p : b.pages) page_ref[(size_t)p]++;
     if (gdn_layers > 0) {      // recurrent + conv state travel with the sequence
@@ -499,6 +527,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         memcpy(h_ids, ids + off, (size_t)S * sizeof(uint32_t));
         CM_HIP(hipMemcpyAsync(d_ids, h_ids, (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, s);
+        if (splice_map_dev) launch_splice_rows(pX, vFeat, splice_map_dev + off, S, H, s);   // image rows over <|image_pad|>
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
             launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
@@ -537,13 +566,14 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             q.kpool = kpool(li); q.vpool = vpool(li); q.q_hi = pQ_hi; q.q_lo = pQ_lo;
             q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = sp; q.eps = cfg.eps;
             q.row_stride = qkv_rows; q.q_off = 0; q.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; q.v_off = q.k_off + Hkv_l * D;
-            q.rot_dim = cfg.rot_dim;
+            q.rot_dim = cfg.rot_dim; q.pos3 = pos3_dev ? pos3_dev + off : nullptr; q.pos3_stride = pos3_stride;
+            q.sec_h = cfg.mrope_sec[1]; q.sec_w = cfg.mrope_sec[2];
             q.scale = (float)(1.0 / std::sqrt((double)D));
             launch_qknorm_rope_kv(q, D, S, kv_f32, s);
             AttnPreArgs at{};
             at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = d_bt; at.kpool = kpool(li); at.vpool = vpool(li);
             at.out_hi = pAT_hi; at.out_lo = pAT_lo; at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
-            at.page = page; at.start_pos = sp;
+            at.page = page; at.start_pos = sp; at.causal = 1;
             at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
             launch_attn_prefill(at, D, kv_f32, s);
             g = GemmArgs{};
@@ -571,7 +601,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         }
         if (off + (size_t)S >= n) {     // last chunk: logits of the LAST position only (modeling.rs:1032-1035)
             CM_HIP(hipMemcpyAsync(x, pX + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-            launch_set_state(st, ids[n - 1], (int32_t)(start_pos + n - 1), active_seq, s);
+            launch_set_state(st, ids[n - 1], (int32_t)(start_pos + n - 1), active_seq, seqs[(size_t)active_seq].rope_delta, s);
             ++ring_count;
             enqueue_lm_head(true);
         }
@@ -628,7 +658,7 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
         prefill(ids, n, start_pos);
     } else {
         for (size_t i = 0; i < n; ++i) {     // token-serial path (also the parity cross-check of prefill)
-            launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, stream);
+            launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, q.rope_delta, stream);
             run_decode_step(true);
         }
     }
@@ -707,7 +737,7 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
             const size_t want = std::min(chunk, (size_t)g.max_new_tokens - produced);
             ensure_pages(0, (int64_t)(q.len + (int64_t)want));
             activate(0);
-            launch_set_state(st, out[n - 1], (int32_t)q.len, 0, stream);
+            launch_set_state(st, out[n - 1], (int32_t)q.len, 0, q.rope_delta, stream);
             const uint32_t ring0 = ring_count;
             for (size_t i = 0; i < want; ++i) run_decode_step(true);
             CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -725,7 +755,7 @@ void Model::bench_decode(uint32_t first, size_t k, uint32_t* toks, float* ms) {
     Seq& q = seq(0);
     ensure_pages(0, q.len + (int64_t)k);
     activate(0);
-    launch_set_state(st, first, (int32_t)q.len, 0, stream);
+    launch_set_state(st, first, (int32_t)q.len, 0, q.rope_delta, stream);
     const uint32_t ring0 = ring_count;
     hipEvent_t e0, e1;
     CM_HIP(hipEventCreate(&e0));

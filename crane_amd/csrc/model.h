@@ -42,6 +42,7 @@ struct Config {
     int NK = 0, NV = 0, Kd = 0, Vd = 0, conv_k = 4;
     bool attn_gate = false;
     float norm_off = 0.f;           // Qwen35RmsNorm: weight = 1 + w (folded at load)
+    int mrope_sec[3] = {11, 11, 10};
     int key_dim() const { return NK * Kd; }
     int value_dim() const { return NV * Vd; }
     int conv_dim() const { return 2 * key_dim() + value_dim(); }
@@ -72,7 +73,29 @@ struct LayerW {
 struct Seq {
     bool used = false;
     int64_t len = 0;                 // cached tokens
+    int32_t rope_delta = 0;          // MRoPE counter - cache position (non-zero after an image prompt)
     std::vector<int32_t> pages;      // page ids, one per kv_block_size tokens
+};
+
+// Qwen 3.5-VL vision tower (qwen3_5/config.rs VisionConfig; qwen3_5/vision.rs)
+struct VisionCfg {
+    bool present = false;
+    int depth = 0, hidden = 0, heads = 0, inter = 0, patch = 16, tpatch = 2, merge = 2, in_ch = 3, out_hidden = 0, num_pos = 0;
+    int act = 1;          // block MLP: 1 = gelu_pytorch_tanh, 2 = gelu (erf)
+    int merger_act = 1;   // PatchMerger `xs.gelu()` (vision.rs:276): tanh form in the reference, erf in HF (CM_VISION_MERGER_GELU=erf)
+    long long image_token = -1;
+    int patch_dim() const { return in_ch * tpatch * patch * patch; }
+};
+struct VisionBlockW {
+    float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr;
+    uint16_t *qkv_w = nullptr, *proj_w = nullptr, *fc1_w = nullptr, *fc2_w = nullptr;
+    float *qkv_b = nullptr, *proj_b = nullptr, *fc1_b = nullptr, *fc2_b = nullptr;
+};
+struct VisionW {
+    uint16_t* patch_w = nullptr; float* patch_b = nullptr; uint16_t* pos_table = nullptr;
+    std::vector<VisionBlockW> blocks;
+    float *mn_w = nullptr, *mn_b = nullptr;
+    uint16_t *mfc1_w = nullptr, *mfc2_w = nullptr; float *mfc1_b = nullptr, *mfc2_b = nullptr;
 };
 
 struct Rccl;   // dlopen'ed RCCL entry points + communicator (tp.cpp)
@@ -110,6 +133,21 @@ struct Model {
     int32_t* h_bt = nullptr;       // pinned mirror
     int active_seq = -1;
     size_t active_pages_uploaded = 0;
+
+    // vision tower (Qwen3.5-VL)
+    VisionCfg vcfg;
+    VisionW vw;
+    int v_cap = 0;                 // patches the vision scratch is sized for
+    float *vX = nullptr, *vQKV = nullptr, *vFeat = nullptr, *vCos = nullptr, *vSin = nullptr, *vK = nullptr, *vV = nullptr, *vPix = nullptr, *vW4 = nullptr;
+    uint16_t *vA_hi = nullptr, *vA_lo = nullptr, *vB_hi = nullptr, *vB_lo = nullptr, *vQ_hi = nullptr, *vQ_lo = nullptr;
+    int32_t *vIdx = nullptr, *vBt = nullptr, *dMap = nullptr, *dPos3 = nullptr;
+    const int32_t* pos3_dev = nullptr;   // set only while a VLM prefill runs
+    const int32_t* splice_map_dev = nullptr;
+    int pos3_stride = 0;
+    void ensure_vision_buffers(int n_patches);
+    int vision_encode(const float* pix, size_t n_patches, const uint32_t* grid, size_t n_img);   // -> vFeat, returns rows
+    void vlm_forward(int s, const uint32_t* ids, size_t n, size_t start_pos, const float* pix, size_t n_patches,
+                     const uint32_t* grid, size_t n_img, float* logits_out, uint32_t* greedy_out);
 
     // per-sequence GDN state pools (Qwen3.5): [slots][gdn_layers][...]
     int gdn_layers = 0, in_proj_rows = 0, in_proj_pad = 0;

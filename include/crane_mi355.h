@@ -179,6 +179,25 @@ int cm_seq_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size
 int cm_decode_batch(cm_model* m, const int32_t* seqs, const uint32_t* last_tokens, size_t n,
                     float* logits_out, uint32_t* greedy_out);
 
+/* ---- vision-language path (Qwen 3.5-VL; reference crane-core/src/models/qwen3_5/{vision,vlm}.rs) -------- */
+
+/* image placeholder token of the checkpoint (config.json image_token_id), -1 when the model has no vision tower */
+int64_t cm_image_token_id(const cm_model* m);
+
+/* Qwen3_5VisionModel::forward (vision.rs:558-584).  pixel_values: host f32 [n_patches, C*T*P*P] exactly as
+ * PreprocessorConfig::process emits them (processor.rs:114-210: merge-block-major rows, (channel, temporal, y, x)
+ * inside a row); grid_thw: host u32 [n_images, 3].  Writes the merged image tokens
+ * [n_patches / merge^2, out_hidden] (f32) to features_out (may be NULL) and their count to rows_out. */
+int cm_vision_encode(cm_model* m, const float* pixel_values, size_t n_patches, const uint32_t* grid_thw, size_t n_images,
+                     float* features_out, size_t* rows_out);
+
+/* Qwen3_5VLModel::forward (vlm.rs:250-285) on sequence `seq`: encodes the images, splices their rows over the
+ * image placeholder tokens of `ids` (splice_image_features, vlm.rs:433-468), builds the 3-axis MRoPE positions
+ * (build_position_ids, vlm.rs:190-241) and prefills.  Later cm_seq_forward / cm_forward_step / cm_generate-style
+ * decode calls on the same sequence continue with the MRoPE counter (decode_step, vlm.rs:294-301). */
+int cm_vlm_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, const float* pixel_values,
+                   size_t n_patches, const uint32_t* grid_thw, size_t n_images, float* logits_out, uint32_t* greedy_out);
+
 /* ---- measurement hooks (bench.py / tests) ----------------------------------- */
 
 /* Enqueue `k` greedy decode steps for sequence 0 starting from its current

@@ -1,0 +1,114 @@
+"""Qwen 3.5-VL: vision tower + VLM glue.  CPU: oracle vs HF golden and the reference's position / layout KATs.
+GPU: HIP path (C ABI) vs oracle (reference GELU form) and vs the HF golden (erf form)."""
+import os
+
+import numpy as np
+import pytest
+
+from crane_amd import configs, synth
+from oracle import qwen3_5_vision_oracle as VO
+from oracle.qwen3_5_oracle import Qwen35Config, Qwen35Oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen3_5_vl_tiny.npz")
+
+
+def rel(a, ref):
+    return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+
+def _setup():
+    g = np.load(GOLD)
+    cfg = configs.get_config("tiny-qwen3.5-vl")
+    w = synth.synth_weights_f32(cfg, int(g["seed"][0]))
+    text_w = {k.replace("model.language_model.", "model."): v for k, v in w.items() if not k.startswith("model.visual.")}
+    return g, cfg, w, text_w
+
+
+def _oracle_vlm(cfg, w, text_w, ids, pix, grid, merger_gelu, n_new=0):
+    vo = VO.VisionOracle(cfg["vision_config"], w, merger_gelu=merger_gelu)
+    feat = vo.forward(pix, grid)
+    IMG = cfg["image_token_id"]
+    pos3, nxt = VO.build_position_ids(ids, grid, IMG, cfg["vision_config"]["spatial_merge_size"])
+    o = Qwen35Oracle(Qwen35Config.from_json(cfg), text_w)
+    emb = VO.splice_image_features(ids, o.embed[np.array(ids)], feat, IMG)
+    logits = o.forward(ids, 0, embeds=emb, pos3=pos3)
+    toks, lg, p = [], logits, nxt
+    for i in range(n_new):
+        t = int(np.argmax(lg)); toks.append(t)
+        lg = o.forward([t], len(ids) + i, pos3=np.array([[p]] * 3)); p += 1
+    return feat, logits, toks
+
+
+def test_position_ids_kat():
+    """vlm.rs:190-241: text tokens advance all three axes; an image span of (t,h,w)=(1,2,3) merged tokens gets
+    (base, base + row, base + col) and the next text position is base + max(t, h, w)."""
+    IMG = 9
+    pos, nxt = VO.build_position_ids([1, 2, IMG, IMG, IMG, IMG, IMG, IMG, 3], [[1, 4, 6]], IMG, 2)
+    assert pos[:, :2].tolist() == [[0, 1]] * 3
+    assert pos[0, 2:8].tolist() == [2] * 6
+    assert pos[1, 2:8].tolist() == [2, 2, 2, 3, 3, 3] and pos[2, 2:8].tolist() == [2, 3, 4, 2, 3, 4]
+    assert pos[:, 8].tolist() == [5, 5, 5] and nxt == 6
+
+
+def test_block_major_patch_order_kat():
+    """processor.rs:282-329: for a 2x4-patch image the raster patch ids appear in merge-block-major order
+    [0,1,4,5,2,3,6,7]; rot_pos_emb / pos-embed use the same order (vision.rs:468-489,502-526)."""
+    h, w, m = 2, 4, 2
+    order = [(br * m + ir) * w + bc * m + ic for br in range(h // m) for bc in range(w // m) for ir in range(m) for ic in range(m)]
+    assert order == [0, 1, 4, 5, 2, 3, 6, 7]
+    cfg = configs.get_config("tiny-qwen3.5-vl")
+    vo = VO.VisionOracle(cfg["vision_config"], synth.synth_weights_f32(cfg, 0))
+    rot = vo.rot_pos_emb([[1, 2, 4]])
+    quarter = rot.shape[1] // 2
+    rows = np.round(rot[:, 0] / rot[1, 0] if rot[1, 0] else rot[:, 0])       # column 0 carries row * inv_freq[0] (= row)
+    assert rot[:, 0].tolist() == [0, 0, 1, 1, 0, 0, 1, 1] and rot[:, quarter].tolist() == [0, 1, 0, 1, 2, 3, 2, 3]
+
+
+def test_vision_shape_kat():
+    """crane-core/tests/qwen3_5_vision.rs:56-85: N patches in -> N/4 merged tokens of out_hidden width."""
+    cfg = configs.get_config("tiny-qwen3.5-vl")
+    vo = VO.VisionOracle(cfg["vision_config"], synth.synth_weights_f32(cfg, 0))
+    pix = np.zeros((6 * 6, 1536), np.float32)
+    assert vo.forward(pix, [[1, 6, 6]]).shape == (9, cfg["vision_config"]["out_hidden_size"])
+
+
+def test_oracle_matches_hf_golden():
+    g, cfg, w, text_w = _setup()
+    feat, logits, toks = _oracle_vlm(cfg, w, text_w, g["input_ids"].tolist(), g["pixel_values"], g["grid_thw"].tolist(), "erf", 6)
+    assert rel(feat, g["features"]) < 2e-5 and rel(logits, g["prefill_logits"]) < 2e-5
+    assert toks == g["greedy_tokens"].tolist()[len(g["input_ids"]):]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gelu", ["tanh", "erf"])
+def test_hip_vision_and_vlm(gelu):
+    from crane_amd.backend import Model
+    g, cfg, w, text_w = _setup()
+    ids, pix, grid = g["input_ids"].tolist(), g["pixel_values"], g["grid_thw"].tolist()
+    if gelu == "erf":
+        os.environ["CM_VISION_MERGER_GELU"] = "erf"
+    try:
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
+    finally:
+        os.environ.pop("CM_VISION_MERGER_GELU", None)
+    try:
+        assert m.image_token_id() == cfg["image_token_id"]
+        feat_ref, logits_ref, toks_ref = _oracle_vlm(cfg, w, text_w, ids, pix, grid, gelu, 6)
+        feat = m.encode_images(pix, grid)
+        assert feat.shape == feat_ref.shape and rel(feat, feat_ref) < 1e-4
+        logits, nxt = m.vlm_forward(ids, pix, grid)
+        assert rel(logits, logits_ref) < 1e-4 and nxt == toks_ref[0]
+        toks, pos = [nxt], len(ids)
+        for _ in range(5):                                  # decode continues with the MRoPE counter
+            toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+        assert toks == toks_ref
+        if gelu == "erf":                                   # independent implementation (HF)
+            assert rel(feat, g["features"]) < 1e-4 and rel(logits, g["prefill_logits"]) < 1e-4
+            assert toks == g["greedy_tokens"].tolist()[len(ids):]
+        # a text-only prompt on the same checkpoint still works (positions T == H == W)
+        m.clear_kv_cache()
+        o = Qwen35Oracle(Qwen35Config.from_json(cfg), text_w)
+        t_ids = configs.synthetic_prompt(11, 400)
+        assert rel(m.forward_step(t_ids, 0)[0, 0], o.forward(t_ids, 0)) < 1e-4
+    finally:
+        m.close()
