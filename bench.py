@@ -78,7 +78,9 @@ def main():
 
     cfg = configs.get_config(args.model)
     K, W, ctx = args.steps, args.warmup, args.ctx
-    m = Model.synthetic(cfg, seed=0, device=local_rank if world > 1 else 0,
+    import torch
+    ndev = max(1, torch.cuda.device_count())
+    m = Model.synthetic(cfg, seed=0, device=(local_rank % ndev) if world > 1 else 0,
                         max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1,
                         use_graph=-1 if args.no_graph else 0,
                         tp_rank=rank if world > 1 else 0, tp_size=world, tp_unique_id=uid)

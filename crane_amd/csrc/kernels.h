@@ -37,6 +37,7 @@ struct AttnDecArgs {
     float* part_o;               // [Hq][nsplit][D]
     float* part_ml;              // [Hq][nsplit][2]
     int q_off, k_off, v_off;     // element offsets of q / k / v inside qkv
+    int qkv_stride, bt_stride;   // batched step: per-sequence strides of qkv rows and block tables
     int Hkv, page, max_pages, rot_dim;
     float eps, scale;
 };
@@ -55,6 +56,7 @@ struct GdnArgs {
     int proj_stride, out_stride;
     int start_pos, slot;         // used when st == nullptr (prefill)
     int S, NV, vpg, key_dim, layer_idx, gdn_layers;
+    int n_seq, batch_proj_stride, batch_out_stride;   // batched decode step (grid.y)
     float eps;
 };
 
@@ -122,15 +124,31 @@ void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint
                         float* vpool, int N, int heads, float scale, hipStream_t s);
 void launch_splice_rows(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s);
 
+// ---- batched decode (kernels_decode_batch.hip) ----
+struct GemvBArgs {
+    const uint16_t* W;     // [N, ldw] bf16
+    const float* x;        // [MB, ldx] f32
+    const float* nw;       // [K] f32 RMSNorm weight (PRO_RMSNORM)
+    float* y;              // [MB, ldy]
+    const float* res;      // [MB, ldy] (EPI_RESADD)
+    float* pmax;           // [MB, grid] (EPI_ARGMAX)
+    int* pidx;
+    int N, K, ldw, ldx, ldy, n_seq, idx_base;
+    float eps;
+};
+int gemvb_grid(int N);
+void launch_gemvb(int pro, int epi, const GemvBArgs& a, hipStream_t s);
+
 // ---- decode ----
 int gemv_rows_per_group(int K);
 int gemv_grid(int N, int K, int num_cu);
 void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s);
-void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s);
+void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, int n_seq, hipStream_t s);
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
-                         int ring_mask, int advance, hipStream_t s);
-bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s);
+                         int ring_mask, int advance, int n_seq, hipStream_t s);
+bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, int out_stride, int n_seq,
+                        hipStream_t s);
 void launch_gdn(const GdnArgs& a, hipStream_t s);
 void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hipStream_t s);
 

@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     __shared__ __attribute__((aligned(16))) float red_o[CT][NREP][D];
 
     const int split = blockIdx.x, kvh = blockIdx.y, nsplit = gridDim.x;
+    const int bq = blockIdx.z;                    // sequence of a batched step (0 on the single-sequence path)
+    const StepState* st = a.st + bq;
+    const int32_t* block_table = a.block_table + (size_t)bq * a.bt_stride;
+    const float* qkv = a.qkv + (size_t)bq * a.qkv_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane / LPR, sub = lane % LPR, dimbase = sub * 8;
 
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     auto kv_off = [&](int t) -> size_t {
         int pi = t / a.page;
         pi = pi < a.max_pages ? pi : a.max_pages - 1;     // speculative loads stay inside the table
-        const int page = a.block_table[pi];
+        const int page = block_table[pi];
         return ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + dimbase;
     };
     struct KV8 { u32x4 a, b; };
@@ -61,8 +65,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
         kq[u] = ld_kv(a.kpool, off);
         vq[u] = ld_kv(a.vpool, off);
     }
-    const int pos = a.st->pos;
-    const int rpos = pos + a.st->rsv[0];          // rotary position = cache position + MRoPE delta (vlm.rs:294-301)
+    const int pos = st->pos;
+    const int rpos = pos + st->rsv[0];          // rotary position = cache position + MRoPE delta (vlm.rs:294-301)
     const int L = pos + 1;
     const bool owner = ((pos / CT) % nsplit) == split;
     const int rot = a.rot_dim, hrot = rot >> 1;
@@ -71,9 +75,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     for (int item = wave; item < NREP + 2; item += 4) {
         const float* src;
         const float* nw = nullptr;
-        if (item < NREP) { src = a.qkv + a.q_off + (size_t)(kvh * NREP + item) * D; nw = a.qnw; }
-        else if (item == NREP) { src = a.qkv + a.k_off + (size_t)kvh * D; nw = a.knw; }
-        else { src = a.qkv + a.v_off + (size_t)kvh * D; }
+        if (item < NREP) { src = qkv + a.q_off + (size_t)(kvh * NREP + item) * D; nw = a.qnw; }
+        else if (item == NREP) { src = qkv + a.k_off + (size_t)kvh * D; nw = a.knw; }
+        else { src = qkv + a.v_off + (size_t)kvh * D; }
         float xv[EPL];
         float ss = 0.f;
 #pragma unroll
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
         } else {
             float* dst = (item == NREP) ? knew : vnew;
             void* pool = (item == NREP) ? a.kpool : a.vpool;
-            const size_t eoff = owner ? ((size_t)(a.block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
+            const size_t eoff = owner ? ((size_t)(block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 const int d = lane + 64 * j;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
                 Ls += w * red_l[i][h];
             }
         }
-        const size_t ph = (size_t)(kvh * NREP + h) * nsplit + split;
+        const size_t ph = ((size_t)bq * a.Hkv * NREP + (size_t)(kvh * NREP + h)) * nsplit + split;
         a.part_o[ph * D + d] = O;
         if (d == 0) { a.part_ml[ph * 2] = M; a.part_ml[ph * 2 + 1] = Ls; }
     }
@@ -227,12 +231,18 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
                                                                   const float* __restrict__ gate,
-                                                                  float* __restrict__ out, int nsplit) {
+                                                                  float* __restrict__ out, int nsplit, int gate_stride,
+                                                                  int out_stride) {
     constexpr int NH = 256 / D;                  // thread groups that split the `s` range
     __shared__ float w_s[64];
     __shared__ float inv_l;
     __shared__ float half_o[D];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int bq = blockIdx.y, nh = gridDim.x;
+    part_o += (size_t)bq * nh * nsplit * D;
+    part_ml += (size_t)bq * nh * nsplit * 2;
+    out += (size_t)bq * out_stride;
+    if (gate != nullptr) gate += (size_t)bq * gate_stride;
     if (tid < 64) {
         float mm = -INFINITY, ll = 0.f;
         if (lane < nsplit) {
@@ -265,8 +275,8 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
 }
 
 template <int D>
-static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, hipStream_t s) {
-    dim3 grid(nsplit, a.Hkv), block(256);
+static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, int n_seq, hipStream_t s) {
+    dim3 grid(nsplit, a.Hkv, n_seq), block(256);
 #define CM_ATTN_CASE(N) \
     case N: if (kv_f32) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, true>), grid, block, 0, s, a); \
             else hipLaunchKernelGGL((attn_decode_split_kernel<D, N, false>), grid, block, 0, s, a); return true;
@@ -277,15 +287,16 @@ static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32
 #undef CM_ATTN_CASE
 }
 
-bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, hipStream_t s) {
+bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, int out_stride, int n_seq,
+                        hipStream_t s) {
     if (D == 128) {
-        if (!launch_split<128>(a, nrep, nsplit, kv_f32, s)) return false;
-        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep), dim3(256), 0, s, a.part_o, a.part_ml,
-                           a.gate, out, nsplit);
+        if (!launch_split<128>(a, nrep, nsplit, kv_f32, n_seq, s)) return false;
+        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+                           a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else if (D == 256) {
-        if (!launch_split<256>(a, nrep, nsplit, kv_f32, s)) return false;
-        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep), dim3(256), 0, s, a.part_o, a.part_ml,
-                           a.gate, out, nsplit);
+        if (!launch_split<256>(a, nrep, nsplit, kv_f32, n_seq, s)) return false;
+        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+                           a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else {
         return false;
     }

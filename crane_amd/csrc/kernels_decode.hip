@@ -21,13 +21,14 @@ namespace cm {
 // =====================================================================================
 __global__ void embed_row_kernel(const uint16_t* __restrict__ emb, const StepState* __restrict__ st,
                                  float* __restrict__ x, int H, int V) {
-    uint32_t tok = st->token;
+    const int bq = blockIdx.y;                                    // batched step: one row per sequence
+    uint32_t tok = st[bq].token;
     if (tok >= (uint32_t)V) tok = 0;   // host validates ids; device stays in-bounds regardless
     int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i < H) {
         u32x2 p = *(const u32x2*)(emb + (size_t)tok * H + i);
         f32x4 o = {bf16_lo(p[0]), bf16_hi(p[0]), bf16_lo(p[1]), bf16_hi(p[1])};
-        *(f32x4*)(x + i) = o;
+        *(f32x4*)(x + (size_t)bq * H + i) = o;
     }
 }
 
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
                                                            int advance) {
     __shared__ float sm[256];
     __shared__ int si[256];
+    pmax += (size_t)blockIdx.x * n; pidx += (size_t)blockIdx.x * n; st += blockIdx.x;   // batched step: one block per sequence
     float b = -INFINITY; int bi = 0x7FFFFFFF;
     for (int i = threadIdx.x; i < n; i += 256) {
         float v = pmax[i]; int ix = pidx[i];
@@ -317,15 +319,15 @@ void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s) {
     }
 }
 
-void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, hipStream_t s) {
-    hipLaunchKernelGGL(embed_row_kernel, dim3((H / 4 + 255) / 256), dim3(256), 0, s, emb, st, x, H, V);
+void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, int n_seq, hipStream_t s) {
+    hipLaunchKernelGGL(embed_row_kernel, dim3((H / 4 + 255) / 256, n_seq), dim3(256), 0, s, emb, st, x, H, V);
 }
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s) {
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, token, pos, slot, rope_delta);
 }
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
-                         int ring_mask, int advance, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(256), 0, s, pmax, pidx, n, st, ring, ring_mask, advance);
+                         int ring_mask, int advance, int n_seq, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(n_seq), dim3(256), 0, s, pmax, pidx, n, st, ring, ring_mask, advance);
 }
 
 }  // namespace cm

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
     __shared__ float qs[K], ks[K];
     __shared__ float red[8];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bq = blockIdx.y;                                 // sequence of a batched decode step (0 otherwise)
     const int kh = h / a.vpg;                                  // Interleaved: value head h uses key head h / vpg
     const int cq = kh * K + tid, ck = a.key_dim + kh * K + tid, cv = 2 * a.key_dim + h * V + tid;
     const int conv_dim = 2 * a.key_dim + a.NV * V;
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
     float wq[KER], wk[KER], wv[KER];
 #pragma unroll
     for (int j = 0; j < KER; ++j) { wq[j] = a.conv_w[cq * KER + j]; wk[j] = a.conv_w[ck * KER + j]; wv[j] = a.conv_w[cv * KER + j]; }
-    const int start_pos = a.st ? a.st->pos : a.start_pos;
-    const int slot = a.st ? a.st->slot : a.slot;
+    const int start_pos = a.st ? a.st[bq].pos : a.start_pos;
+    const int slot = a.st ? a.st[bq].slot : a.slot;
     float* conv_state = a.conv_pool + ((size_t)slot * a.gdn_layers + a.layer_idx) * 2 * conv_dim * (KER - 1);
     const int par_in = start_pos & 1;
     const float* cs_in = conv_state + (size_t)par_in * conv_dim * (KER - 1);
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
     const float qscale = 0.08838834764831845f;                 // 1/sqrt(128)
 
     for (int t = 0; t < a.S; ++t) {
-        const float* pr = a.proj + (size_t)t * proj_stride;
+        const float* pr = a.proj + (size_t)bq * a.batch_proj_stride + (size_t)t * proj_stride;
         // ---- conv + SiLU; roll the windows ----
         const float xq = pr[cq], xk = pr[ck], xv = pr[cv];
         float q = hq[0] * wq[0] + hq[1] * wq[1] + hq[2] * wq[2] + xq * wq[3];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
         __syncthreads();
         const float rms = 1.0f / sqrtf((red[4] + red[5]) / (float)V + a.eps);
         const float z = pr[conv_dim + h * V + tid];
-        a.out[(size_t)t * a.out_stride + h * V + tid] = y * rms * gw * silu_f(z);
+        a.out[(size_t)bq * a.batch_out_stride + (size_t)t * a.out_stride + h * V + tid] = y * rms * gw * silu_f(z);
     }
     // ---- write back state and conv windows (other parity buffer) ----
 #pragma unroll
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
 }
 
 void launch_gdn(const GdnArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gdn_kernel, dim3(a.NV), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(gdn_kernel, dim3(a.NV, a.n_seq > 0 ? a.n_seq : 1), dim3(128), 0, s, a);
 }
 
 __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n, float add) {

@@ -37,6 +37,9 @@ Model::~Model() {
     if (h_ring) (void)hipHostFree(h_ring);
     if (h_logits) (void)hipHostFree(h_logits);
     if (h_ids) (void)hipHostFree(h_ids);
+    if (h_stb) (void)hipHostFree(h_stb);
+    if (h_btb) (void)hipHostFree(h_btb);
+    if (h_logitsb) (void)hipHostFree(h_logitsb);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -407,7 +410,7 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
 void Model::enqueue_decode_step(bool advance) {
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
-    launch_embed_row(embed, st, x, H, cfg.V, s);
+    launch_embed_row(embed, st, x, H, cfg.V, 1, s);
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
@@ -420,7 +423,7 @@ void Model::enqueue_decode_step(bool advance) {
             ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
             ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
             ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
-            ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
+            ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
             launch_gdn(ga, s);
             g = GemvArgs{};
             g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K; g.y = x; g.res = x;
@@ -438,7 +441,7 @@ void Model::enqueue_decode_step(bool advance) {
         a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr;
         a.rot_dim = cfg.rot_dim;
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-        if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
@@ -479,7 +482,7 @@ void Model::enqueue_lm_head(bool advance) {
         rccl->all_gather(pmax + (size_t)rank * lm_grid, pmax, (size_t)lm_grid * sizeof(float), s);
         rccl->all_gather(pidx + (size_t)rank * lm_grid, pidx, (size_t)lm_grid * sizeof(int), s);
     }
-    launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, s);
+    launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, 1, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -542,7 +545,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.st = nullptr;
                 ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
-                ga.slot = active_seq;
+                ga.slot = active_seq; ga.n_seq = 1;
                 // the conv windows are double-buffered by position parity: every launch must advance an ODD
                 // number of positions, so an even chunk is scanned as (S-1) + 1
                 int done = 0;
@@ -633,6 +636,109 @@ void Model::fetch_logits(float* out) {
     CM_HIP(hipMemcpyAsync(h_logits, logits, (size_t)V_l * tp * sizeof(float), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
     memcpy(out, h_logits, (size_t)cfg.V * sizeof(float));
+}
+
+// ------------------------------------------------------------------------------------
+// batched decode step: step_batch_decode (backend.rs:107-121, qwen3/modeling.rs:1202-1234) without padding,
+// masks or KV copies -- up to MAXB sequences share ONE pass over the weights
+// ------------------------------------------------------------------------------------
+void Model::ensure_batch_buffers() {
+    if (stb) return;
+    const int H = cfg.H, D = cfg.D;
+    const size_t attn_rows = (size_t)(cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
+    ldq = (int)std::max(attn_rows, (size_t)in_proj_pad);
+    const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
+    stb = (StepState*)dalloc<int>(MAXB * sizeof(StepState) / sizeof(int));
+    d_btb = dalloc<int>((size_t)MAXB * max_pages_per_seq);
+    xb = dalloc<float>((size_t)MAXB * H);
+    qkvb = dalloc<float>((size_t)MAXB * ldq);
+    attnb = dalloc<float>((size_t)MAXB * at_cols);
+    hbb = dalloc<float>((size_t)MAXB * I_l);
+    logitsb = dalloc<float>((size_t)MAXB * cfg.V);
+    part_ob = dalloc<float>((size_t)MAXB * Hq_l * nsplit * D);
+    part_mlb = dalloc<float>((size_t)MAXB * Hq_l * nsplit * 2);
+    const int g = gemvb_grid(cfg.V);
+    pmaxb = dalloc<float>((size_t)MAXB * g);
+    pidxb = dalloc<int>((size_t)MAXB * g);
+    CM_HIP(hipHostMalloc((void**)&h_stb, MAXB * sizeof(StepState)));
+    CM_HIP(hipHostMalloc((void**)&h_btb, (size_t)MAXB * max_pages_per_seq * sizeof(int32_t)));
+    CM_HIP(hipHostMalloc((void**)&h_logitsb, (size_t)MAXB * cfg.V * sizeof(float)));
+    CM_HIP(hipMemsetAsync(d_btb, 0, (size_t)MAXB * max_pages_per_seq * sizeof(int32_t), stream));
+}
+
+void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out) {
+    if (rccl) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
+    ensure_batch_buffers();
+    const int H = cfg.H, D = cfg.D;
+    hipStream_t s = stream;
+    const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
+    const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
+    for (size_t g0 = 0; g0 < n; g0 += MAXB) {
+        const int nb = (int)std::min<size_t>(MAXB, n - g0);
+        CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
+        for (int b = 0; b < nb; ++b) {
+            const int sidx = sq[g0 + b];
+            Seq& q = seq(sidx);
+            for (int c = 0; c < b; ++c) if (sq[g0 + c] == sidx) throw CmError(CM_ERR_INVALID, "sequence appears twice in one batch");
+            if (toks[g0 + b] >= (uint32_t)cfg.V) throw CmError(CM_ERR_RANGE, "token id >= vocab_size");
+            if (q.len + 1 > max_seq) throw CmError(CM_ERR_RANGE, "sequence longer than max_seq_len");
+            ensure_pages(sidx, q.len + 1);
+            StepState& hs = h_stb[b];
+            memset(&hs, 0, sizeof hs);
+            hs.token = toks[g0 + b]; hs.pos = (int32_t)q.len; hs.slot = sidx; hs.rsv[0] = q.rope_delta;
+            memcpy(h_btb + (size_t)b * max_pages_per_seq, q.pages.data(), q.pages.size() * sizeof(int32_t));
+        }
+        CM_HIP(hipMemcpyAsync(stb, h_stb, (size_t)nb * sizeof(StepState), hipMemcpyHostToDevice, s));
+        CM_HIP(hipMemcpyAsync(d_btb, h_btb, (size_t)nb * max_pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        launch_embed_row(embed, stb, xb, H, cfg.V, nb, s);
+        auto gb = [&](int pro, int epi, const uint16_t* W, const float* xin, int ldx, const float* nw, float* y, int ldy, int N, int K) {
+            GemvBArgs g{};
+            g.W = W; g.x = xin; g.nw = nw; g.y = y; g.res = y; g.N = N; g.K = K; g.ldw = K; g.ldx = ldx; g.ldy = ldy; g.n_seq = nb;
+            g.eps = cfg.eps;
+            launch_gemvb(pro, epi, g, s);
+        };
+        for (int li = 0; li < cfg.L; ++li) {
+            const LayerW& w = layers[(size_t)li];
+            if (!w.full) {
+                gb(PRO_RMSNORM, EPI_STORE, w.in_proj, xb, H, w.ln1, qkvb, ldq, in_proj_rows, H);
+                GdnArgs ga{};
+                ga.proj = qkvb; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
+                ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attnb; ga.st = stb;
+                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+                ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
+                ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
+                launch_gdn(ga, s);
+                gb(PRO_PLAIN, EPI_RESADD, w.out_proj, attnb, (int)at_cols, nullptr, xb, H, H, cfg.value_dim());
+            } else {
+                gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
+                AttnDecArgs a{};
+                a.qkv = qkvb; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = stb; a.block_table = d_btb;
+                a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_ob; a.part_ml = part_mlb;
+                a.q_off = 0; a.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; a.v_off = a.k_off + Hkv_l * D;
+                a.gate = cfg.hybrid ? qkvb + (size_t)Hq_l * D : nullptr;
+                a.qkv_stride = ldq; a.bt_stride = max_pages_per_seq; a.rot_dim = cfg.rot_dim;
+                a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+                if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
+            }
+            gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
+            gb(PRO_PLAIN, EPI_RESADD, w.down, hbb, I_l, nullptr, xb, H, H, I_l);
+        }
+        GemvBArgs g{};
+        g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb; g.N = cfg.V; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
+        g.eps = cfg.eps; g.pmax = pmaxb; g.pidx = pidxb;
+        launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, s);
+        launch_argmax_final(pmaxb, pidxb, gemvb_grid(cfg.V), stb, ring, RING - 1, 0, nb, s);
+        CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
+        if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));
+        CM_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < nb; ++b) {
+            seq(sq[g0 + b]).len += 1;
+            if (greedy_out) greedy_out[g0 + b] = h_stb[b].next;
+        }
+        if (logits_out) memcpy(logits_out + g0 * (size_t)cfg.V, h_logitsb, (size_t)nb * cfg.V * sizeof(float));
+        if (active_seq >= 0) { /* the single-sequence table is untouched */ }
+    }
 }
 
 // ------------------------------------------------------------------------------------

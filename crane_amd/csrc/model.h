@@ -190,6 +190,19 @@ struct Model {
     uint32_t* d_ids = nullptr;
     uint32_t* h_ids = nullptr;
 
+    // batched decode scratch (<= 8 sequences per step)
+    static constexpr int MAXB = 8;
+    StepState* stb = nullptr;          // device [MAXB]
+    StepState* h_stb = nullptr;        // pinned [MAXB]
+    int32_t* d_btb = nullptr;          // device [MAXB][max_pages_per_seq]
+    int32_t* h_btb = nullptr;          // pinned
+    float *xb = nullptr, *qkvb = nullptr, *attnb = nullptr, *hbb = nullptr, *logitsb = nullptr, *part_ob = nullptr, *part_mlb = nullptr, *pmaxb = nullptr;
+    int* pidxb = nullptr;
+    float* h_logitsb = nullptr;
+    int ldq = 0;
+    void ensure_batch_buffers();
+    void decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out);
+
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ok = false;

@@ -259,3 +259,40 @@ def test_rccl_code_path_single_rank():
     finally:
         del os.environ["CM_FORCE_RCCL"]
     assert rel(b, a) < 1e-6 and rel(b2, a2) < 1e-6 and len(toks) == 11
+
+
+@pytest.mark.parametrize("nseq", [2, 3, 8, 11])
+def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
+    """step_batch_decode (backend.rs:107-121): N sequences of different lengths, one token each, ONE pass over the
+    weights (gemvb kernels) -- no padding / masks; every row must equal that sequence's own single-step result."""
+    cfg, w, m = pair
+    if nseq > 3:
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=12, kv_dtype="f32")
+    V = cfg["vocab_size"]
+    try:
+        oracles, seqs, lens = [], [], []
+        for i in range(nseq):
+            n = 3 + 5 * i + (60 if i == 1 else 0)              # ragged lengths, one crossing a page
+            ids = [(11 * i + 7 * k + 3) % V for k in range(n)]
+            o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16" if nseq <= 3 else "f32")
+            o.forward(ids, 0)
+            s = m.seq_alloc()
+            m.seq_forward(s, ids, 0, want_logits=False)
+            oracles.append(o); seqs.append(s); lens.append(n)
+        toks = [(5 + i) % V for i in range(nseq)]
+        for step in range(2):
+            lg, greedy = m.step_batch_decode(seqs, toks)
+            assert lg.shape == (nseq, 1, V)
+            nxt = []
+            for i in range(nseq):
+                ref = oracles[i].forward([toks[i]], lens[i] + step)
+                assert rel(lg[i, 0], ref) < (REL_SAME if nseq <= 3 else 1e-4), (i, step)
+                assert int(greedy[i]) == int(lg[i, 0].argmax())
+                nxt.append(int(ref.argmax()))
+            toks = nxt
+        for s in seqs:
+            assert m.seq_len(s) == lens[seqs.index(s)] + 2
+            m.seq_free(s)
+    finally:
+        if nseq > 3:
+            m.close()

@@ -157,3 +157,32 @@ def test_hip_qwen35_prefill_equals_token_serial(n):
         assert rel(nxt, o.forward([5], n)) < 1e-4
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_hip_qwen35_batched_decode():
+    """batched step on the hybrid model: per-sequence GDN state slots + per-sequence KV pages in one pass."""
+    from crane_amd.backend import Model
+    g, cfg, w = _load()
+    V = cfg["vocab_size"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=6, kv_dtype="f32")
+    try:
+        oracles, seqs, lens = [], [], []
+        for i in range(5):
+            n = 4 + 9 * i
+            ids = [(13 * i + 7 * k + 3) % V for k in range(n)]
+            o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+            o.forward(ids, 0)
+            s = m.seq_alloc(); m.seq_forward(s, ids, 0, want_logits=False)
+            oracles.append(o); seqs.append(s); lens.append(n)
+        toks = [(5 + i) % V for i in range(5)]
+        for step in range(3):
+            lg, greedy = m.step_batch_decode(seqs, toks)
+            nxt = []
+            for i in range(5):
+                ref = oracles[i].forward([toks[i]], lens[i] + step)
+                assert rel(lg[i, 0], ref) < 1e-4, (i, step)
+                nxt.append(int(ref.argmax()))
+            toks = nxt
+    finally:
+        m.close()
