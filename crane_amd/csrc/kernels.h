@@ -136,8 +136,8 @@ struct GemvBArgs {
     int N, K, ldw, ldx, ldy, n_seq, idx_base;
     float eps;
 };
-int gemvb_grid(int N);
-void launch_gemvb(int pro, int epi, const GemvBArgs& a, hipStream_t s);
+int gemvb_grid(int N, int K, int num_cu);
+void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
 
 // ---- decode ----
 int gemv_rows_per_group(int K);

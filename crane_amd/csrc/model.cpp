@@ -657,7 +657,7 @@ void Model::ensure_batch_buffers() {
     logitsb = dalloc<float>((size_t)MAXB * cfg.V);
     part_ob = dalloc<float>((size_t)MAXB * Hq_l * nsplit * D);
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * nsplit * 2);
-    const int g = gemvb_grid(cfg.V);
+    const int g = gemvb_grid(cfg.V, H, num_cu);
     pmaxb = dalloc<float>((size_t)MAXB * g);
     pidxb = dalloc<int>((size_t)MAXB * g);
     CM_HIP(hipHostMalloc((void**)&h_stb, MAXB * sizeof(StepState)));
@@ -695,7 +695,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             GemvBArgs g{};
             g.W = W; g.x = xin; g.nw = nw; g.y = y; g.res = y; g.N = N; g.K = K; g.ldw = K; g.ldx = ldx; g.ldy = ldy; g.n_seq = nb;
             g.eps = cfg.eps;
-            launch_gemvb(pro, epi, g, s);
+            launch_gemvb(pro, epi, g, gemvb_grid(N, K, num_cu), s);
         };
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
@@ -727,8 +727,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         GemvBArgs g{};
         g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb; g.N = cfg.V; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
         g.eps = cfg.eps; g.pmax = pmaxb; g.pidx = pidxb;
-        launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, s);
-        launch_argmax_final(pmaxb, pidxb, gemvb_grid(cfg.V), stb, ring, RING - 1, 0, nb, s);
+        const int lmg = gemvb_grid(cfg.V, H, num_cu);
+        launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+        launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s);
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
         if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));
         CM_HIP(hipStreamSynchronize(s));
