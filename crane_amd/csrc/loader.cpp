@@ -67,7 +67,7 @@ struct SynthSource : Source {
         else if (ends("conv1d.weight")) std = 0.5;
         else if (ends("A_log")) { std = 0.1; off = -2.0f; }
         else if (ends("dt_bias")) std = 0.1;
-        else if (ends("linear_attn.out_proj.weight")) std = 1.0 / std::sqrt((double)c.value_dim());
+        else if (ends("linear_attn.out_proj.weight")) std = 1.0 / std::sqrt((double)(c.NV_g * c.Vd));
         else if (ends("o_proj.weight")) std = 1.0 / std::sqrt((double)(c.Hq * c.D));
         else if (ends("down_proj.weight")) std = 1.0 / std::sqrt((double)c.I);
         else std = 1.0 / std::sqrt((double)c.H);      // q/k/v/gate/up/lm_head: fan_in = H
@@ -125,9 +125,10 @@ struct FileSource : Source {
 
 // small tensors the kernels want in f32 (norm weights with the Qwen3.5 "+1" folded in, conv taps, A_log, dt_bias):
 // fetched as bf16 like everything else, then widened on the device
-float* fetch_f32(Model& m, Source& src, const std::string& name, int n, float add) {
+float* fetch_f32(Model& m, Source& src, const std::string& name, int n, float add, int total = -1, int start = 0) {
+    if (total < 0) total = n;
     uint16_t* tmp = m.dalloc<uint16_t>((size_t)n);
-    src.fetch(name, 1, n, 0, 1, 0, n, tmp, (size_t)n);
+    src.fetch(name, 1, total, 0, 1, start, n, tmp, (size_t)n);
     float* out = m.dalloc<float>((size_t)n, true);
     launch_bf16_to_f32(tmp, out, (size_t)n, add, m.stream);
     return out;
@@ -178,12 +179,13 @@ void build(Model& m, Source& src) {
             // q_proj rows are per head [q (D) | gate (D)] (qwen3_5/modeling.rs:428-455); HBM layout here is
             // [all q | all gate | k | v] so q/gate are contiguous vectors for the attention kernel
             w.qkv = m.dalloc<uint16_t>((size_t)(2 * qd + 2 * kd) * H, true);
-            for (int h = 0; h < c.Hq; ++h) {
-                src.fetch(p + "self_attn.q_proj.weight", c.Hq * 2 * D, H, h * 2 * D, D, 0, H, w.qkv + (size_t)h * D * H, (size_t)H);
-                src.fetch(p + "self_attn.q_proj.weight", c.Hq * 2 * D, H, h * 2 * D + D, D, 0, H, w.qkv + (size_t)(qd + h * D) * H, (size_t)H);
+            for (int h = 0; h < m.Hq_l; ++h) {
+                const int hg = m.rank * m.Hq_l + h;                 // checkpoint head index of local head h
+                src.fetch(p + "self_attn.q_proj.weight", c.Hq * 2 * D, H, hg * 2 * D, D, 0, H, w.qkv + (size_t)h * D * H, (size_t)H);
+                src.fetch(p + "self_attn.q_proj.weight", c.Hq * 2 * D, H, hg * 2 * D + D, D, 0, H, w.qkv + (size_t)(qd + h * D) * H, (size_t)H);
             }
-            src.fetch(p + "self_attn.k_proj.weight", c.Hkv * D, H, 0, kd, 0, H, w.qkv + (size_t)(2 * qd) * H, (size_t)H);
-            src.fetch(p + "self_attn.v_proj.weight", c.Hkv * D, H, 0, kd, 0, H, w.qkv + (size_t)(2 * qd + kd) * H, (size_t)H);
+            src.fetch(p + "self_attn.k_proj.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H, w.qkv + (size_t)(2 * qd) * H, (size_t)H);
+            src.fetch(p + "self_attn.v_proj.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H, w.qkv + (size_t)(2 * qd + kd) * H, (size_t)H);
         }
         if (w.full) {
             w.o = m.dalloc<uint16_t>((size_t)H * qd, true);
@@ -194,19 +196,36 @@ void build(Model& m, Source& src) {
             }
         } else {
             w.gdn_idx = gdn_idx++;
-            const int cd = c.conv_dim(), vd = c.value_dim(), nv = c.NV;
+            // local (this rank) and checkpoint-wide dims; rank r owns key heads [r NK, (r+1) NK) and their value heads
+            const int cd = c.conv_dim(), vd = c.value_dim(), nv = c.NV, kdl = c.key_dim();
+            const int KDg = c.NK_g * c.Kd, VDg = c.NV_g * c.Vd, CDg = 2 * KDg + VDg, r = m.rank;
             const int rows = cd + vd + 2 * nv, rows_pad = (rows + 127) / 128 * 128;
             w.in_proj = m.dalloc<uint16_t>((size_t)rows_pad * H, true);
             CM_HIP(hipMemsetAsync(w.in_proj, 0, (size_t)rows_pad * H * sizeof(uint16_t), m.stream));
-            src.fetch(p + "linear_attn.in_proj_qkv.weight", cd, H, 0, cd, 0, H, w.in_proj, (size_t)H);
-            src.fetch(p + "linear_attn.in_proj_z.weight", vd, H, 0, vd, 0, H, w.in_proj + (size_t)cd * H, (size_t)H);
-            src.fetch(p + "linear_attn.in_proj_b.weight", nv, H, 0, nv, 0, H, w.in_proj + (size_t)(cd + vd) * H, (size_t)H);
-            src.fetch(p + "linear_attn.in_proj_a.weight", nv, H, 0, nv, 0, H, w.in_proj + (size_t)(cd + vd + nv) * H, (size_t)H);
+            const std::string qn = p + "linear_attn.in_proj_qkv.weight";
+            src.fetch(qn, CDg, H, r * kdl, kdl, 0, H, w.in_proj, (size_t)H);                                   // q
+            src.fetch(qn, CDg, H, KDg + r * kdl, kdl, 0, H, w.in_proj + (size_t)kdl * H, (size_t)H);           // k
+            src.fetch(qn, CDg, H, 2 * KDg + r * vd, vd, 0, H, w.in_proj + (size_t)(2 * kdl) * H, (size_t)H);   // v
+            src.fetch(p + "linear_attn.in_proj_z.weight", VDg, H, r * vd, vd, 0, H, w.in_proj + (size_t)cd * H, (size_t)H);
+            src.fetch(p + "linear_attn.in_proj_b.weight", c.NV_g, H, r * nv, nv, 0, H, w.in_proj + (size_t)(cd + vd) * H, (size_t)H);
+            src.fetch(p + "linear_attn.in_proj_a.weight", c.NV_g, H, r * nv, nv, 0, H, w.in_proj + (size_t)(cd + vd + nv) * H, (size_t)H);
             w.out_proj = m.dalloc<uint16_t>((size_t)H * vd, true);
-            src.fetch(p + "linear_attn.out_proj.weight", H, vd, 0, H, 0, vd, w.out_proj, (size_t)vd);
-            w.conv_w = fetch_f32(m, src, p + "linear_attn.conv1d.weight", cd * c.conv_k, 0.f);   // [conv_dim, 1, k]
-            w.A_log = fetch_f32(m, src, p + "linear_attn.A_log", nv, 0.f);
-            w.dt_bias = fetch_f32(m, src, p + "linear_attn.dt_bias", nv, 0.f);
+            src.fetch(p + "linear_attn.out_proj.weight", H, VDg, 0, H, r * vd, vd, w.out_proj, (size_t)vd);
+            // conv taps [conv_dim, 1, k] -> the three channel ranges of this rank, contiguous in [q | k | v] order
+            const int ck = c.conv_k;
+            const std::string cn = p + "linear_attn.conv1d.weight";
+            if (m.tp == 1) {
+                w.conv_w = fetch_f32(m, src, cn, cd * ck, 0.f);
+            } else {
+                uint16_t* tmp = m.dalloc<uint16_t>((size_t)cd * ck);
+                src.fetch(cn, 1, CDg * ck, 0, 1, (r * kdl) * ck, kdl * ck, tmp, (size_t)kdl * ck);
+                src.fetch(cn, 1, CDg * ck, 0, 1, (KDg + r * kdl) * ck, kdl * ck, tmp + (size_t)kdl * ck, (size_t)kdl * ck);
+                src.fetch(cn, 1, CDg * ck, 0, 1, (2 * KDg + r * vd) * ck, vd * ck, tmp + (size_t)2 * kdl * ck, (size_t)vd * ck);
+                w.conv_w = m.dalloc<float>((size_t)cd * ck, true);
+                launch_bf16_to_f32(tmp, w.conv_w, (size_t)cd * ck, 0.f, m.stream);
+            }
+            w.A_log = fetch_f32(m, src, p + "linear_attn.A_log", nv, 0.f, c.NV_g, r * nv);
+            w.dt_bias = fetch_f32(m, src, p + "linear_attn.dt_bias", nv, 0.f, c.NV_g, r * nv);
             w.gnorm = fetch_f32(m, src, p + "linear_attn.norm.weight", c.Vd, 0.f);              // plain weight (norm.rs:39-45)
         }
         w.gate_up = m.dalloc<uint16_t>((size_t)2 * m.I_l * H, true);

@@ -140,7 +140,14 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
         if (cfg.NK <= 0 || cfg.NV % cfg.NK) throw CmError(CM_ERR_INVALID, "linear_num_value_heads % linear_num_key_heads != 0");
         if (!cfg.attn_gate) throw CmError(CM_ERR_UNSUPPORTED, "attn_output_gate=false not implemented");
         if (cfg.rot_dim <= 0 || cfg.rot_dim % 2 || cfg.rot_dim > cfg.D) throw CmError(CM_ERR_INVALID, "bad partial_rotary_factor");
-        if (opts.tp_size > 1) throw CmError(CM_ERR_UNSUPPORTED, "tensor parallel Qwen3.5 not implemented yet");
+        cfg.NK_g = cfg.NK; cfg.NV_g = cfg.NV;
+        if (opts.tp_size > 1) {
+            // TP for the hybrid family (new design): each rank owns NK/tp key heads and the NV/tp value
+            // heads paired with them (HF "Interleaved" order keeps a key head's value heads contiguous)
+            if (cfg.NK % opts.tp_size || cfg.NV % opts.tp_size)
+                throw CmError(CM_ERR_INVALID, "tp_size must divide linear_num_key_heads and linear_num_value_heads");
+            cfg.NK /= opts.tp_size; cfg.NV /= opts.tp_size;
+        }
     } else if (cfg.model_type != "qwen3") {
         throw CmError(CM_ERR_UNSUPPORTED, "model_type '" + cfg.model_type + "' not implemented (qwen3, qwen3_5)");
     }
@@ -426,8 +433,13 @@ void Model::enqueue_decode_step(bool advance) {
             ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
             launch_gdn(ga, s);
             g = GemvArgs{};
-            g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K; g.y = x; g.res = x;
-            launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s);
+            g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K;
+            if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+            else {
+                g.y = y; g.res = x;
+                launch_gemv(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+                rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
+            }
         } else {
         // (1) RMSNorm + merged QKV projection
         g.W = w.qkv; g.x = x; g.nw = w.ln1; g.y = qkv; g.N = qkv_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
@@ -448,7 +460,7 @@ void Model::enqueue_decode_step(bool advance) {
         if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
         else {
             g.y = y; g.res = x;
-            launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+            launch_gemv(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
             rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
         }
         }   // full-attention layer
@@ -462,7 +474,7 @@ void Model::enqueue_decode_step(bool advance) {
         if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
         else {
             g.y = y; g.res = x;
-            launch_gemv(PRO_PLAIN, rank == 0 ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+            launch_gemv(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
             rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
         }
     }
@@ -482,7 +494,8 @@ void Model::enqueue_lm_head(bool advance) {
         rccl->all_gather(pmax + (size_t)rank * lm_grid, pmax, (size_t)lm_grid * sizeof(float), s);
         rccl->all_gather(pidx + (size_t)rank * lm_grid, pidx, (size_t)lm_grid * sizeof(int), s);
     }
-    launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, 1, s);
+    if (rccl && rccl->fake) launch_argmax_final(pmax + (size_t)rank * lm_grid, pidx + (size_t)rank * lm_grid, lm_grid, st, ring, RING - 1, advance ? 1 : 0, 1, s);
+    else launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, 1, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -559,7 +572,12 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
                 g = GemmArgs{};
                 g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
-                g.C = pX; launch_gemm(g, GEPI_RESADD, s);
+                if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+                else {
+                    g.C = pY; launch_gemm(g, GEPI_STORE, s);
+                    rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+                    launch_add_rows(pX, pY, (size_t)S * H, s);
+                }
             } else {
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
             g.M = S; g.N = qkv_rows; g.K = H;

@@ -39,7 +39,8 @@ struct Config {
     bool hybrid = false;            // false: qwen3 dense
     int rot_dim = 0;                // rotary slice of the head (== D for qwen3)
     int interval = 4;               // full_attention_interval
-    int NK = 0, NV = 0, Kd = 0, Vd = 0, conv_k = 4;
+    int NK = 0, NV = 0, Kd = 0, Vd = 0, conv_k = 4;   // NK / NV are THIS RANK's head counts under TP
+    int NK_g = 0, NV_g = 0;                           // checkpoint-wide head counts
     bool attn_gate = false;
     float norm_off = 0.f;           // Qwen35RmsNorm: weight = 1 + w (folded at load)
     int mrope_sec[3] = {11, 11, 10};

@@ -2,6 +2,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -60,6 +61,7 @@ void Rccl::unique_id(void* out128) {
 }
 
 void Rccl::init(int n, int r, const void* unique_id128, hipStream_t) {
+    if (getenv("CM_TP_FAKE") != nullptr) { fake = true; nranks = n; rank = r; return; }
     if (!unique_id128) throw CmError(CM_ERR_INVALID, "tp_size > 1 needs cm_opts.tp_unique_id");
     load();
     nranks = n; rank = r;
@@ -69,10 +71,15 @@ void Rccl::init(int n, int r, const void* unique_id128, hipStream_t) {
 }
 
 void Rccl::all_reduce_sum_f32(const float* send, float* recv, size_t count, hipStream_t s) {
+    if (fake) {
+        if (send != recv) (void)hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, s);
+        return;
+    }
     CM_NCCL(p_all_reduce(send, recv, count, kNcclFloat32, kNcclSum, comm, s));
 }
 
 void Rccl::all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s) {
+    if (fake) return;
     CM_NCCL(p_all_gather(send, recv, bytes_per_rank, kNcclInt8, comm, s));
 }
 

@@ -19,6 +19,8 @@ struct Rccl {
     void* lib = nullptr;
     void* comm = nullptr;
     int nranks = 1, rank = 0;
+    bool fake = false;     // CM_TP_FAKE=1 (debug): no communicator; all-reduce = local copy, all-gather = no-op, so one
+                           // process can run ONE rank's shard and be compared with the oracle on the same shard
     // resolved entry points
     int (*p_get_unique_id)(void*) = nullptr;
     int (*p_comm_init_rank)(void**, int, /*ncclUniqueId by value*/ UniqueId, int) = nullptr;

@@ -20,6 +20,8 @@ class ShardPlan:
     inter: range          # intermediate (MLP) columns
     vocab: range          # lm_head rows
     n_rep: int
+    gdn_key_heads: range = range(0)     # Qwen3.5 Gated-Delta-Net key heads owned by this rank
+    gdn_value_heads: range = range(0)   # ... and the value heads paired with them (HF interleaved order)
 
     @property
     def reduces_per_layer(self) -> int:
@@ -41,9 +43,15 @@ def shard_plan(cfg: dict, tp: int, rank: int) -> ShardPlan:
     else:
         hkv_l, kv0 = 1, rank * Hkv // tp
     v_l = (V + tp - 1) // tp
+    gk, gv = range(0), range(0)
+    if "linear_num_key_heads" in cfg:
+        NK, NV = cfg["linear_num_key_heads"], cfg["linear_num_value_heads"]
+        if NK % tp or NV % tp:
+            raise ValueError("tp must divide linear_num_key_heads and linear_num_value_heads")
+        gk, gv = range(rank * NK // tp, (rank + 1) * NK // tp), range(rank * NV // tp, (rank + 1) * NV // tp)
     return ShardPlan(tp, rank, range(rank * hq_l, (rank + 1) * hq_l), range(kv0, kv0 + hkv_l),
                      range(rank * (I // tp), (rank + 1) * (I // tp)),
-                     range(min(V, rank * v_l), min(V, (rank + 1) * v_l)), hq_l // hkv_l)
+                     range(min(V, rank * v_l), min(V, (rank + 1) * v_l)), hq_l // hkv_l, gk, gv)
 
 
 def shard_weights(cfg: dict, w: dict, plan: ShardPlan) -> dict:
@@ -53,8 +61,27 @@ def shard_weights(cfg: dict, w: dict, plan: ShardPlan) -> dict:
     ks = slice(plan.kv_heads.start * D, plan.kv_heads.stop * D)
     ins = slice(plan.inter.start, plan.inter.stop)
     out = {}
+    hybrid = "linear_num_key_heads" in cfg
+    if hybrid:
+        K, Vd = cfg["linear_key_head_dim"], cfg["linear_value_head_dim"]
+        KDg = cfg["linear_num_key_heads"] * K
+        kq = slice(plan.gdn_key_heads.start * K, plan.gdn_key_heads.stop * K)
+        vv = slice(plan.gdn_value_heads.start * Vd, plan.gdn_value_heads.stop * Vd)
+        nvs = slice(plan.gdn_value_heads.start, plan.gdn_value_heads.stop)
+        import numpy as np
     for name, t in w.items():
-        if name.endswith("q_proj.weight"):
+        if hybrid and name.endswith("self_attn.q_proj.weight"):
+            out[name] = t[plan.q_heads.start * 2 * D:plan.q_heads.stop * 2 * D]     # per-head [q | gate] rows
+        elif hybrid and (name.endswith("in_proj_qkv.weight") or name.endswith("conv1d.weight")):
+            out[name] = np.concatenate([t[kq], t[KDg + kq.start:KDg + kq.stop], t[2 * KDg + vv.start:2 * KDg + vv.stop]], axis=0)
+        elif hybrid and name.endswith("in_proj_z.weight"):
+            out[name] = t[vv]
+        elif hybrid and (name.endswith("in_proj_b.weight") or name.endswith("in_proj_a.weight")
+                         or name.endswith("A_log") or name.endswith("dt_bias")):
+            out[name] = t[nvs]
+        elif hybrid and name.endswith("linear_attn.out_proj.weight"):
+            out[name] = t[:, vv]
+        elif name.endswith("q_proj.weight"):
             out[name] = t[qs]
         elif name.endswith("k_proj.weight") or name.endswith("v_proj.weight"):
             out[name] = t[ks]

@@ -159,6 +159,7 @@ class Qwen35Oracle:
         self.lm_head = w["lm_head.weight"] if ("lm_head.weight" in w and not c.tie_word_embeddings) else self.embed
         self.norm = w[prefix + "norm.weight"]
         self.cos, self.sin = mrope_tables(c.rot_dim, max_pos or c.max_position_embeddings, c.rope_theta)
+        self.allreduce = lambda t: t      # tensor-parallel tests plug a gloo all-reduce in here (row-parallel partial sums)
         self.clear_kv_cache()
 
     def clear_kv_cache(self):
@@ -261,11 +262,11 @@ class Qwen35Oracle:
         for li in range(c.num_hidden_layers):
             p = f"{self.p}layers.{li}."
             xn = rms_norm_1p(h, w[p + "input_layernorm.weight"], c.rms_norm_eps)
-            h = h + (self._full_attn(li, xn, start_pos) if c.layer_is_full(li) else self._gdn(li, xn))
+            h = h + self.allreduce(self._full_attn(li, xn, start_pos) if c.layer_is_full(li) else self._gdn(li, xn))
             xn = rms_norm_1p(h, w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
             gate = xn @ w[p + "mlp.gate_proj.weight"].T
             up = xn @ w[p + "mlp.up_proj.weight"].T
-            h = h + ((silu(gate) * up) @ w[p + "mlp.down_proj.weight"].T).astype(F32)
+            h = h + self.allreduce(((silu(gate) * up) @ w[p + "mlp.down_proj.weight"].T).astype(F32))
         last = rms_norm_1p(h[-1:], self.norm, c.rms_norm_eps)
         return (last @ self.lm_head.T).astype(F32)[0]
 

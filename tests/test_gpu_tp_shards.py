@@ -1,0 +1,68 @@
+"""One TP rank at a time on ONE GPU (CM_TP_FAKE=1: collectives are local no-ops): the C++ loader's shard of every
+weight + the kernels running on local head counts must reproduce the oracle evaluated on the SAME shard with an
+identity all-reduce.  Together with the gloo tests (real all-reduce on the same plan) this covers the TP path that
+cannot be run on a single-GPU box."""
+import os
+
+import numpy as np
+import pytest
+
+from crane_amd import configs, synth, tp
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, ref):
+    return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+
+def _run_rank(cfg, rank, world, ids):
+    from crane_amd.backend import Model
+    os.environ["CM_TP_FAKE"] = "1"
+    try:
+        m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
+                            tp_unique_id=b"\0" * 128)
+    finally:
+        del os.environ["CM_TP_FAKE"]
+    try:
+        a = m.forward_step(ids, 0)[0, 0]
+        b = m.forward_step([5], len(ids))[0, 0]
+        return a, b
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dense_rank_shards(world):
+    from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+    cfg = configs.get_config("tiny-qwen3-untied")                     # 8 q heads, 2 kv heads (replicated at tp=4)
+    w = synth.synth_weights_f32(cfg, 0)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    for rank in range(world):
+        plan = tp.shard_plan(cfg, world, rank)
+        sw = tp.shard_weights(cfg, w, plan)
+        local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads),
+                     intermediate_size=len(plan.inter))
+        o = Qwen3Oracle(Qwen3Config.from_json(local), sw)
+        got_a, got_b = _run_rank(cfg, rank, world, ids)
+        v = slice(plan.vocab.start, plan.vocab.stop)
+        assert rel(got_a[v], o.forward(ids, 0)) < 1e-4 and rel(got_b[v], o.forward([5], len(ids))) < 1e-4
+
+
+def test_hybrid_rank_shards():
+    from oracle import qwen3_5_oracle as O5
+    cfg = configs.get_config("tiny-qwen3.5")
+    w = synth.synth_weights_f32(cfg, 0)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    for rank in range(2):
+        plan = tp.shard_plan(cfg, 2, rank)
+        sw = tp.shard_weights(cfg, w, plan)
+        local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads),
+                     linear_num_key_heads=len(plan.gdn_key_heads), linear_num_value_heads=len(plan.gdn_value_heads),
+                     tie_word_embeddings=True)
+        sw["model.embed_tokens.weight"] = w["model.embed_tokens.weight"]
+        o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(local), sw)
+        o.lm_head = w["lm_head.weight"][plan.vocab.start:plan.vocab.stop]
+        got_a, got_b = _run_rank(cfg, rank, 2, ids)
+        v = slice(plan.vocab.start, plan.vocab.stop)
+        assert rel(got_a[v], o.forward(ids, 0)) < 1e-4 and rel(got_b[v], o.forward([5], len(ids))) < 1e-4

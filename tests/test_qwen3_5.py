@@ -186,3 +186,29 @@ def test_hip_qwen35_batched_decode():
             toks = nxt
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_hip_qwen38_27b_geometry():
+    """Real Qwen3.8-27B layer geometry (qwen3_5/config.rs:298-324: H 5120, 24q/4kv x 256, 16 key / 48 value GDN heads,
+    I 17408) with 4 layers and a small vocabulary so the CPU oracle stays fast -- the analogue of the reference's
+    crane-core/tests/qwen3_5_gqa_grouped_decode.rs (algebra at 27B geometry).  Exercises n_rep = 6, 3 value heads per
+    key head, K = 5120 / 17408 GEMV chunk counts, decode + MFMA prefill + batched decode."""
+    from crane_amd.backend import Model
+    cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=3, kv_dtype="f32")
+    try:
+        ids = configs.synthetic_prompt(37, cfg["vocab_size"])
+        assert rel(m.forward_step(ids, 0)[0, 0], o.forward(ids, 0)) < 1e-4            # prefill path
+        for pos, t in enumerate([5, 9, 2], start=37):                                   # decode path
+            assert rel(m.forward_step([t], pos)[0, 0], o.forward([t], pos)) < 1e-4
+        o2 = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+        s1, s2 = m.seq_alloc(), m.seq_alloc()
+        m.seq_forward(s1, ids[:11], 0, want_logits=False); m.seq_forward(s2, ids[:20], 0, want_logits=False)
+        lg, _ = m.step_batch_decode([s1, s2], [7, 8])                                   # batched path
+        o2.forward(ids[:11], 0); assert rel(lg[0, 0], o2.forward([7], 11)) < 1e-4
+        o2.forward(ids[:20], 0); assert rel(lg[1, 0], o2.forward([8], 20)) < 1e-4
+    finally:
+        m.close()

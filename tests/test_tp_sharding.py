@@ -109,3 +109,71 @@ def test_plan_shapes_for_headline_models():
         assert all(h // 6 == r // 2 for h in p.q_heads)          # every local q head maps to the local KV head
     with pytest.raises(ValueError):
         tp.shard_plan(c8, 3, 0)
+
+
+def _worker35(rank, world, port, qh):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from crane_amd import configs, synth, tp
+    from oracle import qwen3_5_oracle as O5
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = configs.get_config("tiny-qwen3.5")
+        w = synth.synth_weights_f32(cfg, 0)
+        plan = tp.shard_plan(cfg, world, rank)
+        sw = tp.shard_weights(cfg, w, plan)
+        local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads),
+                     linear_num_key_heads=len(plan.gdn_key_heads), linear_num_value_heads=len(plan.gdn_value_heads),
+                     tie_word_embeddings=True)               # local head = this rank's vocab rows, gathered below
+        sw["model.embed_tokens.weight"] = w["model.embed_tokens.weight"]
+        o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(local), sw)
+        o.lm_head = w["lm_head.weight"][plan.vocab.start:plan.vocab.stop]
+
+        def allreduce(a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            dist.all_reduce(t)
+            return t.numpy()
+        o.allreduce = allreduce
+        ids = configs.synthetic_prompt(9, cfg["vocab_size"])
+        outs = [o.forward(ids, 0), o.forward([5], 9)]          # prefill chunk + one decode step (state hand-over)
+        v_l = (cfg["vocab_size"] + world - 1) // world
+        full = []
+        for local_logits in outs:
+            buf = np.zeros(v_l, np.float32); buf[:local_logits.size] = local_logits
+            gathered = [torch.zeros(v_l) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(buf))
+            full.append(np.concatenate([g.numpy() for g in gathered])[:cfg["vocab_size"]])
+        if rank == 0:
+            ref = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), w)
+            r0, r1 = ref.forward(ids, 0), ref.forward([5], 9)
+            qh.put(max(float(np.abs(full[0] - r0).max() / np.abs(r0).max()), float(np.abs(full[1] - r1).max() / np.abs(r1).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp_plan_hybrid_gdn_reproduces_unsharded_forward():
+    """Qwen3.5 hybrid under TP=2: GDN key/value heads, conv channels, gates, [q|gate] rows and out_proj columns
+    sharded as csrc/loader.cpp does; 2 all-reduces per layer; prefill + decode (recurrent state stays rank-local)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    qh = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker35, args=(r, 2, port, qh)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert qh.get(timeout=5) < 1e-5
+
+
+def test_plan_shapes_qwen38_27b_tp8():
+    from crane_amd import configs, tp
+    c = configs.get_config("qwen3.8-27b")
+    for r in range(8):
+        p = tp.shard_plan(c, 8, r)
+        assert list(p.gdn_key_heads) == [2 * r, 2 * r + 1] and list(p.gdn_value_heads) == list(range(6 * r, 6 * r + 6))
+        assert all(v // 3 in p.gdn_key_heads for v in p.gdn_value_heads)      # interleaved pairing stays rank-local
+        assert list(p.kv_heads) == [r // 2] and len(p.q_heads) == 3 and len(p.inter) == 2176 and len(p.vocab) == 31040
