@@ -23,7 +23,7 @@ EXPORTS = [
     "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
-    "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
+    "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
 ]
 
 
@@ -41,7 +41,16 @@ class CmGenConfig(C.Structure):
     _fields_ = [
         ("max_new_tokens", C.c_uint32), ("temperature", C.c_float), ("top_p", C.c_float),
         ("repetition_penalty", C.c_float), ("repeat_last_n", C.c_uint32),
-        ("eos_token_id", C.c_int64 * 4), ("sync_every", C.c_uint32), ("reserved", C.c_uint32 * 7),
+        ("eos_token_id", C.c_int64 * 4), ("sync_every", C.c_uint32), ("top_k", C.c_uint32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+        ("frequency_penalty", C.c_float), ("presence_penalty", C.c_float), ("reserved", C.c_uint32 * 2),
+    ]
+
+
+class CmSampleParams(C.Structure):
+    _fields_ = [
+        ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_uint32), ("repetition_penalty", C.c_float),
+        ("frequency_penalty", C.c_float), ("presence_penalty", C.c_float), ("repeat_last_n", C.c_uint32),
+        ("draw", C.c_uint32), ("seed", C.c_uint64), ("reserved", C.c_uint32 * 6),
     ]
 
 
@@ -104,6 +113,9 @@ def load():
     lib.cm_image_token_id.restype = C.c_int64
     lib.cm_vision_encode.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, P(C.c_size_t)]
     lib.cm_vlm_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, u32p, C.c_size_t, f32p, u32p]
+    lib.cm_sample.argtypes = [vp, P(CmSampleParams), u32p, C.c_size_t, u32p]
+    lib.cm_topk.argtypes = [vp, f32p, C.c_size_t, C.c_uint32, u32p, f32p]
+    lib.cm_read_logits.argtypes = [vp, f32p]
     lib.cm_bench_decode.argtypes = [vp, C.c_uint32, C.c_size_t, u32p, f32p]
     lib.cm_bench_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, f32p, P(C.c_uint64)]
     lib.cm_debug_fill_kv.argtypes = [vp, C.c_size_t, C.c_uint64]

@@ -37,6 +37,11 @@ class GenerationConfig:
     eos_token_id: Optional[int] = None
     report_speed: bool = False
     enable_thinking: Optional[bool] = None
+    # sampler knobs of the serving engine (crane-serve/src/engine/sampling.rs SamplingParams), not in generation/mod.rs
+    top_k: int = 0
+    frequency_penalty: float = 0.0
+    presence_penalty: float = 0.0
+    seed: int = 299792458
 
     @classmethod
     def with_max_tokens(cls, n: int) -> "GenerationConfig":
@@ -248,6 +253,9 @@ class Model:
         for i in range(4):
             g.eos_token_id[i] = int(eos[i]) if i < len(eos) else -1
         g.sync_every = sync_every
+        g.top_k = int(config.top_k)
+        g.seed_lo, g.seed_hi = int(config.seed) & 0xFFFFFFFF, (int(config.seed) >> 32) & 0xFFFFFFFF
+        g.frequency_penalty, g.presence_penalty = float(config.frequency_penalty), float(config.presence_penalty)
         out = np.empty(arr.size + config.max_new_tokens, dtype=np.uint32)
         n_out = C.c_size_t(0)
 
@@ -263,6 +271,42 @@ class Model:
             streamer.finalize()
         self._check(rc)
         return [int(t) for t in out[:n_out.value]]
+
+    # -- device sampler (crane-serve/src/engine/sampling.rs, crane_core::ops::topk_indices) --------------
+    def sample(self, context: Sequence[int] = (), temperature: float = 0.0, top_p: float = 0.0, top_k: int = 0,
+               repetition_penalty: float = 1.0, frequency_penalty: float = 0.0, presence_penalty: float = 0.0,
+               repeat_last_n: int = 0, seed: int = 299792458, draw: int = 0) -> int:
+        """Sequence::sample on the HBM-resident logits of the last forward call (penalties applied in place)."""
+        sp = _lib.CmSampleParams()
+        sp.temperature, sp.top_p, sp.top_k = float(temperature), float(top_p), int(top_k)
+        sp.repetition_penalty, sp.frequency_penalty, sp.presence_penalty = float(repetition_penalty), float(frequency_penalty), float(presence_penalty)
+        sp.repeat_last_n, sp.draw, sp.seed = int(repeat_last_n), int(draw), int(seed)
+        tok = C.c_uint32(0)
+        if len(context):
+            arr, p = _u32(context)
+            n = arr.size
+        else:
+            p, n = None, 0
+        self._check(self._lib.cm_sample(self._h, C.byref(sp), p, n, C.byref(tok)))
+        return int(tok.value)
+
+    def topk(self, k: int, logits: Optional[np.ndarray] = None):
+        """topk_indices: exact top-k (value desc, index asc).  logits None -> the last forward's logits."""
+        idx = np.empty(k, dtype=np.uint32)
+        val = np.empty(k, dtype=np.float32)
+        if logits is not None:
+            lg = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1)
+            lp, n = lg.ctypes.data_as(C.POINTER(C.c_float)), lg.size
+        else:
+            lp, n = None, 0
+        self._check(self._lib.cm_topk(self._h, lp, n, k, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      val.ctypes.data_as(C.POINTER(C.c_float))))
+        return idx, val
+
+    def read_logits(self) -> np.ndarray:
+        out = np.empty(self.vocab_size, dtype=np.float32)
+        self._check(self._lib.cm_read_logits(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     # -- vision-language (qwen3_5/vision.rs, vlm.rs) ----------------------------------
     def image_token_id(self) -> int:

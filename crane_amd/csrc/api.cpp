@@ -197,6 +197,27 @@ int cm_vlm_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size
     return guard(h, [&] { h->m.vlm_forward(seq, ids, n, start_pos, pixel_values, n_patches, grid_thw, n_images, logits_out, greedy_out); });
 }
 
+int cm_sample(cm_model* h, const cm_sample_params* p, const uint32_t* context, size_t n_context, uint32_t* token_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (!p || !token_out) throw cm::CmError(CM_ERR_INVALID, "null argument");
+        *token_out = h->m.sample(*p, context, n_context);
+    });
+}
+
+int cm_topk(cm_model* h, const float* logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.topk(logits, n, k, idx_out, val_out); });
+}
+
+int cm_read_logits(cm_model* h, float* logits_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (!logits_out) throw cm::CmError(CM_ERR_INVALID, "null argument");
+        h->m.fetch_logits(logits_out);
+    });
+}
+
 int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
     if (!h) return CM_ERR_INVALID;
     return guard(h, [&] { h->m.bench_decode(first_token, k, tokens_out, ms_out); });

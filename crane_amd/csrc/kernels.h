@@ -159,4 +159,15 @@ void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncol
 void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s);
 
+// sampler (kernels_sample.hip)
+int topk_pad(int k);
+int topk_blocks(int n);
+void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* idx_out, float* val_out, hipStream_t s);
+void launch_penalties(float* logits, const uint32_t* ids, const uint32_t* counts, int n, float rp, bool true_div, float fp, float pp,
+                      int V, hipStream_t s);
+void launch_sample_topk(const uint32_t* idx, const float* val, int k, float temperature, float top_p, uint64_t seed, uint32_t draw,
+                        uint32_t* token_out, hipStream_t s);
+void launch_gumbel_full(const float* logits, int V, float temperature, uint64_t seed, uint32_t draw, float* pmax, int* pidx, int blocks,
+                        uint32_t* token_out, hipStream_t s);
+
 }  // namespace cm

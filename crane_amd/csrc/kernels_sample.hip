@@ -1,0 +1,210 @@
+// Device-side sampler: replaces the host path of crane-serve/src/engine/sampling.rs:169-373 (a [V] f32 D2H copy
+// + ~24 ms host sort per token at V = 250 K, sampling.rs:25-27) and the RDNA-tuned top-k of
+// crane-core/kernels/cuda/topk.cu with gfx950 kernels working on the logits already resident in HBM.
+//   penalties : apply_penalties_inplace (sampling.rs:422-478): per distinct context token
+//               logit = logit >= 0 ? logit / rp : logit * rp ;  logit -= count * freq + presence
+//   top-k     : exact, total order "value descending, index ascending", -0.0 == +0.0
+//               (topk.cu:70-81 key = order_preserving_u32(v) << 32 | ~idx); two-stage bitonic sort in LDS
+//   sample    : sampling.rs:246-345: softmax(top-k logits / T), top-p mask (keep i if cumsum[i] <= p or
+//               cumsum[i-1] <= p), Gumbel-max  argmax(logit / T - log(-log u)), u ~ U(1e-7, 0.999)  (:382-392)
+// The uniform stream is a counter-based hash (seed, draw, lane); candle's StdRng stream is not reproduced -- the
+// reference pins no sampled token anywhere (SURVEY 8c "parity unpinned").
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+__device__ __forceinline__ unsigned long long topk_key(float v, uint32_t idx) {
+    if (v == 0.0f) v = 0.0f;                                   // -0.0 -> +0.0
+    uint32_t b = __float_as_uint(v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);            // order-preserving map
+    return ((unsigned long long)b << 32) | (unsigned long long)(~idx);
+}
+
+// descending bitonic sort of n (power of two) keys in LDS by one block
+__device__ void bitonic_desc(unsigned long long* s, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;              // "up" blocks hold descending runs
+                    if (up ? (a < b) : (a > b)) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int TK_SLICE = 4096;
+
+// stage 1: block b sorts logits[b*4096 .. +4096) and emits its kp best keys
+__global__ __launch_bounds__(1024) void topk_stage1_kernel(const float* __restrict__ logits, int n, int kp,
+                                                           unsigned long long* __restrict__ cand) {
+    __shared__ unsigned long long s[TK_SLICE];
+    const int base = blockIdx.x * TK_SLICE;
+    for (int i = threadIdx.x; i < TK_SLICE; i += blockDim.x) {
+        const int g = base + i;
+        s[i] = g < n ? topk_key(logits[g], (uint32_t)g) : 0ull;   // 0 sorts below every real key
+    }
+    __syncthreads();
+    bitonic_desc(s, TK_SLICE);
+    for (int i = threadIdx.x; i < kp; i += blockDim.x) cand[(size_t)blockIdx.x * kp + i] = s[i];
+}
+
+// stage 2: one block folds all candidates, keeping the running best kp at the front
+__global__ __launch_bounds__(1024) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int kp, int k,
+                                                           uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                           const float* __restrict__ logits) {
+    __shared__ unsigned long long s[TK_SLICE];
+    int consumed = 0;
+    for (int i = threadIdx.x; i < TK_SLICE; i += blockDim.x) s[i] = 0ull;
+    __syncthreads();
+    bool first = true;
+    while (consumed < ncand || first) {
+        const int room = first ? TK_SLICE : TK_SLICE - kp;
+        const int off = first ? 0 : kp;
+        for (int i = threadIdx.x; i < room; i += blockDim.x) s[off + i] = (consumed + i < ncand) ? cand[consumed + i] : 0ull;
+        consumed += room;
+        first = false;
+        __syncthreads();
+        bitonic_desc(s, TK_SLICE);
+    }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint32_t id = ~(uint32_t)(s[i] & 0xFFFFFFFFull);
+        idx_out[i] = id;
+        val_out[i] = logits[id];
+    }
+}
+
+__global__ void penalties_kernel(float* __restrict__ logits, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts,
+                                 int n, float rp, float rp_inv, int true_div, float fp, float pp, int V) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = ids[i];
+    if (t >= (uint32_t)V) return;
+    float v = logits[t];
+    // sampling.rs:452 divides through candle's `Tensor / f64` == multiply by (f32)(1/rp); the single-request
+    // generate() path (candle_transformers apply_repeat_penalty, model.rs:306-315) uses a true division
+    if (rp != 1.0f) v = v >= 0.f ? (true_div ? __fdiv_rn(v, rp) : __fmul_rn(v, rp_inv)) : __fmul_rn(v, rp);
+    if (fp != 0.0f || pp != 0.0f) v = __fsub_rn(v, __fadd_rn(__fmul_rn((float)counts[i], fp), pp));
+    logits[t] = v;
+}
+
+__device__ __forceinline__ float uniform_open(uint32_t seed_lo, uint32_t seed_hi, uint32_t draw, uint32_t i) {
+    uint32_t h = fmix32(seed_lo ^ (i * 0x9E3779B1u));
+    h = fmix32(h ^ seed_hi ^ (draw * 0x85EBCA6Bu));
+    const float u01 = (float)(h >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+    return 1e-7f + u01 * (0.999f - 1e-7f);                             // rand_like(1e-7, 0.999)
+}
+
+// one wave: k <= 64 candidates (sorted, best first)
+__global__ __launch_bounds__(64) void sample_topk_kernel(const uint32_t* __restrict__ idx, const float* __restrict__ val, int k,
+                                                         float temperature, float top_p, uint32_t seed_lo, uint32_t seed_hi,
+                                                         uint32_t draw, uint32_t* __restrict__ token_out) {
+    const int lane = threadIdx.x;
+    const bool act = lane < k;
+    const float lg = act ? val[lane] : -INFINITY;
+    const float scaled = act ? lg / temperature : -INFINITY;
+    bool keep = act;
+    if (top_p > 0.f && top_p < 1.f) {
+        const float mx = wave_max(scaled);
+        const float e = act ? expf(scaled - mx) : 0.f;
+        const float sum = wave_sum(e);
+        const float p = e / sum;
+        float c = p;                                                   // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float t = __shfl_up(c, d);
+            if (lane >= d) c += t;
+        }
+        const float prev = __shfl_up(c, 1);
+        keep = act && ((c <= top_p) || (lane > 0 && prev <= top_p));
+        if (__ballot(keep) == 0ull) keep = (lane == 0);               // degenerate p < p_0: keep the best token
+    }
+    const float u = uniform_open(seed_lo, seed_hi, draw, (uint32_t)lane);
+    float score = keep ? scaled - logf(-logf(u)) : -INFINITY;
+    // arg-max over the wave, lowest lane wins ties
+    float best = score; int bl = lane;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const float ob = __shfl_xor(best, d); const int ol = __shfl_xor(bl, d);
+        if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }
+    }
+    if (lane == 0) token_out[0] = idx[bl];
+}
+
+// full-vocabulary Gumbel-max (top_k == 0 and no top_p): phase 1 per block, phase 2 = gumbel_final_kernel
+__global__ __launch_bounds__(256) void gumbel_full_kernel(const float* __restrict__ logits, int V, float temperature, uint32_t seed_lo,
+                                                          uint32_t seed_hi, uint32_t draw, float* __restrict__ pmax,
+                                                          int* __restrict__ pidx) {
+    __shared__ float sm[256];
+    __shared__ int si[256];
+    float b = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+        const float s = logits[i] / temperature - logf(-logf(uniform_open(seed_lo, seed_hi, draw, (uint32_t)i)));
+        if (s > b || (s == b && i < bi)) { b = s; bi = i; }
+    }
+    sm[threadIdx.x] = b; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = sm[threadIdx.x + s]; const int ix = si[threadIdx.x + s];
+            if (v > sm[threadIdx.x] || (v == sm[threadIdx.x] && ix < si[threadIdx.x])) { sm[threadIdx.x] = v; si[threadIdx.x] = ix; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { pmax[blockIdx.x] = sm[0]; pidx[blockIdx.x] = si[0]; }
+}
+
+__global__ __launch_bounds__(256) void gumbel_final_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx, int n,
+                                                           uint32_t* __restrict__ token_out) {
+    __shared__ float sm[256];
+    __shared__ int si[256];
+    float b = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = pmax[i]; const int ix = pidx[i];
+        if (v > b || (v == b && ix < bi)) { b = v; bi = ix; }
+    }
+    sm[threadIdx.x] = b; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = sm[threadIdx.x + s]; const int ix = si[threadIdx.x + s];
+            if (v > sm[threadIdx.x] || (v == sm[threadIdx.x] && ix < si[threadIdx.x])) { sm[threadIdx.x] = v; si[threadIdx.x] = ix; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) token_out[0] = (uint32_t)si[0];
+}
+
+int topk_pad(int k) { int p = 1; while (p < k) p <<= 1; return p; }
+int topk_blocks(int n) { return (n + TK_SLICE - 1) / TK_SLICE; }
+
+void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* idx_out, float* val_out, hipStream_t s) {
+    const int kp = topk_pad(k), nb = topk_blocks(n);
+    hipLaunchKernelGGL(topk_stage1_kernel, dim3(nb), dim3(1024), 0, s, logits, n, kp, cand);
+    hipLaunchKernelGGL(topk_stage2_kernel, dim3(1), dim3(1024), 0, s, cand, nb * kp, kp, k, idx_out, val_out, logits);
+}
+void launch_penalties(float* logits, const uint32_t* ids, const uint32_t* counts, int n, float rp, bool true_div, float fp, float pp,
+                      int V, hipStream_t s) {
+    if (n <= 0) return;
+    const float rp_inv = (float)(1.0 / (double)rp);
+    hipLaunchKernelGGL(penalties_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, ids, counts, n, rp, rp_inv, true_div ? 1 : 0, fp,
+                       pp, V);
+}
+void launch_sample_topk(const uint32_t* idx, const float* val, int k, float temperature, float top_p, uint64_t seed, uint32_t draw,
+                        uint32_t* token_out, hipStream_t s) {
+    hipLaunchKernelGGL(sample_topk_kernel, dim3(1), dim3(64), 0, s, idx, val, k, temperature, top_p, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), draw, token_out);
+}
+void launch_gumbel_full(const float* logits, int V, float temperature, uint64_t seed, uint32_t draw, float* pmax, int* pidx, int blocks,
+                        uint32_t* token_out, hipStream_t s) {
+    hipLaunchKernelGGL(gumbel_full_kernel, dim3(blocks), dim3(256), 0, s, logits, V, temperature, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       draw, pmax, pidx);
+    hipLaunchKernelGGL(gumbel_final_kernel, dim3(1), dim3(256), 0, s, pmax, pidx, blocks, token_out);
+}
+
+}  // namespace cm

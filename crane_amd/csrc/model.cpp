@@ -25,6 +25,7 @@ T* Model::dalloc(size_t n, bool count_weight) {
 template uint16_t* Model::dalloc<uint16_t>(size_t, bool);
 template float* Model::dalloc<float>(size_t, bool);
 template int* Model::dalloc<int>(size_t, bool);
+template uint32_t* Model::dalloc<uint32_t>(size_t, bool);
 
 Model::~Model() {
     if (stream) (void)hipStreamSynchronize(stream);
@@ -40,6 +41,10 @@ Model::~Model() {
     if (h_stb) (void)hipHostFree(h_stb);
     if (h_btb) (void)hipHostFree(h_btb);
     if (h_logitsb) (void)hipHostFree(h_logitsb);
+    if (h_pen) (void)hipHostFree(h_pen);
+    if (h_tk) (void)hipHostFree(h_tk);
+    if (tk_cand) (void)hipFree(tk_cand);
+    if (tk_in) (void)hipFree(tk_in);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -485,6 +490,7 @@ void Model::enqueue_lm_head(bool advance) {
     // final norm + lm_head (last position only, modeling.rs:1024-1035) + arg-max
     const int H = cfg.H;
     hipStream_t s = stream;
+    logits_gathered = false;
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     GemvArgs g{};
     g.W = lm_head; g.x = x; g.nw = norm; g.y = logits + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H;
@@ -650,7 +656,7 @@ void Model::run_decode_step(bool advance) {
 }
 
 void Model::fetch_logits(float* out) {
-    if (rccl) rccl->all_gather(logits + (size_t)rank * V_l, logits, (size_t)V_l * sizeof(float), stream);
+    gather_logits();
     CM_HIP(hipMemcpyAsync(h_logits, logits, (size_t)V_l * tp * sizeof(float), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
     memcpy(out, h_logits, (size_t)cfg.V * sizeof(float));
@@ -810,36 +816,38 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
     if (!gc || !out || !n_out) throw CmError(CM_ERR_INVALID, "null argument");
     if (n_prompt == 0) throw CmError(CM_ERR_INVALID, "empty prompt");
     const cm_gen_config g = *gc;
-    if (g.temperature >= 0.f)
-        throw CmError(CM_ERR_UNSUPPORTED, "sampling (temperature >= 0) not implemented: greedy only (temperature < 0 == None)");
     if (n_prompt + g.max_new_tokens > (size_t)max_seq) throw CmError(CM_ERR_RANGE, "prompt + max_new_tokens exceeds max_seq_len");
     seq_truncate(0, 0);                                   // self.clear_kv_cache() (model.rs:281)
     size_t n = n_prompt;
     memcpy(out, prompt, n_prompt * sizeof(uint32_t));
     *n_out = n;
     if (g.max_new_tokens == 0) return;
-    const bool penalty = std::fabs(g.repetition_penalty - 1.0f) >= 1.1920929e-7f && g.repetition_penalty > 0.f;
-    std::vector<float> lg;
-    if (penalty) lg.resize((size_t)cfg.V);
-
-    auto host_pick = [&](std::vector<float>& l) -> uint32_t {
-        // candle_transformers::utils::apply_repeat_penalty over the last repeat_last_n tokens (model.rs:306-315)
-        const size_t start_at = n > g.repeat_last_n ? n - g.repeat_last_n : 0;
-        std::vector<uint32_t> seen;
-        for (size_t i = start_at; i < n; ++i) {
-            const uint32_t t = out[i];
-            if (t >= (uint32_t)cfg.V || std::find(seen.begin(), seen.end(), t) != seen.end()) continue;
-            seen.push_back(t);
-            l[t] = l[t] >= 0.f ? l[t] / g.repetition_penalty : l[t] * g.repetition_penalty;
-        }
-        uint32_t best = 0;
-        for (uint32_t i = 1; i < (uint32_t)cfg.V; ++i) if (l[i] > l[best]) best = i;   // first max
-        return best;
+    // LogitsProcessor::new(seed, temperature, top_p) (model.rs:289-297): None or ~0 temperature == ArgMax
+    const bool sampling = g.temperature >= 1e-7f;
+    const bool penalty = (std::fabs(g.repetition_penalty - 1.0f) >= 1.1920929e-7f && g.repetition_penalty > 0.f) ||
+                         g.frequency_penalty != 0.f || g.presence_penalty != 0.f;
+    const bool device_pick = sampling || penalty;
+    cm_sample_params sp{};
+    sp.temperature = sampling ? g.temperature : 0.f;
+    sp.top_p = g.top_p; sp.top_k = g.top_k;
+    sp.repetition_penalty = (std::fabs(g.repetition_penalty - 1.0f) >= 1.1920929e-7f) ? g.repetition_penalty : 1.0f;
+    sp.frequency_penalty = g.frequency_penalty; sp.presence_penalty = g.presence_penalty;
+    sp.repeat_last_n = g.repeat_last_n;
+    sp.seed = ((uint64_t)g.seed_hi << 32) | g.seed_lo;
+    if (sp.seed == 0) sp.seed = 299792458ull;
+    // penalties (apply_repeat_penalty over the last repeat_last_n tokens, model.rs:306-315), top-k / top-p /
+    // temperature and the draw all run on the logits resident in HBM (model_sample.cpp)
+    sp.repeat_last_n = 0;
+    auto device_sample = [&]() -> uint32_t {
+        const size_t w = std::min(n, (size_t)g.repeat_last_n);       // tokens.len().saturating_sub(repeat_last_n) (model.rs:307)
+        const uint32_t t = sample(sp, out + (n - w), w, true);
+        ++sp.draw;
+        return t;
     };
 
     // step 0: whole prompt at start_pos 0 (model.rs:299-304)
     uint32_t tok = 0;
-    if (penalty) { forward(0, prompt, n_prompt, 0, lg.data(), nullptr); tok = host_pick(lg); }
+    if (device_pick) { forward(0, prompt, n_prompt, 0, nullptr, nullptr); tok = device_sample(); }
     else forward(0, prompt, n_prompt, 0, nullptr, &tok);
     size_t produced = 0;
     bool stop = false;
@@ -849,10 +857,10 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
         if (cb && cb(user, t) != 0) stop = true;
     };
     emit(tok);
-    if (penalty) {
+    if (device_pick) {
         while (!stop && produced < g.max_new_tokens) {
-            forward(0, &out[n - 1], 1, n - 1, lg.data(), nullptr);
-            emit(host_pick(lg));
+            forward(0, &out[n - 1], 1, n - 1, nullptr, nullptr);
+            emit(device_sample());
         }
     } else {
         // device-chained greedy decode: the arg-max kernel feeds the next step's token/pos in HBM

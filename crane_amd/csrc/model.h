@@ -204,6 +204,23 @@ struct Model {
     void ensure_batch_buffers();
     void decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out);
 
+    // device sampler scratch (model_sample.cpp; allocated on first use)
+    unsigned long long* tk_cand = nullptr; size_t tk_cand_cap = 0;
+    float* tk_in = nullptr; size_t tk_in_cap = 0;
+    uint32_t* tk_idx = nullptr;        // [512]
+    float* tk_val = nullptr;           // [512]
+    uint32_t* d_pen = nullptr;         // [2][PEN_CAP] distinct ids, counts
+    uint32_t* h_pen = nullptr;         // pinned
+    uint32_t* d_tok = nullptr;
+    uint32_t* h_tk = nullptr;          // pinned [1 + 512 + 512]
+    float* sm_pmax = nullptr; int* sm_pidx = nullptr;
+    static constexpr int PEN_CAP = 8192;
+    void ensure_sampler();
+    void gather_logits();              // TP: all-gather the vocab shards into `logits`
+    void topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out);
+    uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false);
+    bool logits_gathered = false;
+
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_ok = false;

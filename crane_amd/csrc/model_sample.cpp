@@ -1,0 +1,126 @@
+// Host side of the device sampler: Sequence::sample (crane-serve/src/engine/sampling.rs:169-373) with every
+// [V]-sized step on the GPU.  Only the <= repeat_last_n context ids go up and one u32 comes back per token.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+#include "kernels.h"
+#include "model.h"
+#include "tp.h"
+
+namespace cm {
+
+static constexpr int SM_BLOCKS = 256;
+
+void Model::ensure_sampler() {
+    if (tk_idx) return;
+    tk_idx = dalloc<uint32_t>(512);
+    tk_val = dalloc<float>(512);
+    d_pen = dalloc<uint32_t>(2 * (size_t)PEN_CAP);
+    d_tok = dalloc<uint32_t>(1);
+    sm_pmax = dalloc<float>(SM_BLOCKS);
+    sm_pidx = dalloc<int>(SM_BLOCKS);
+    CM_HIP(hipHostMalloc((void**)&h_pen, 2 * (size_t)PEN_CAP * sizeof(uint32_t)));
+    CM_HIP(hipHostMalloc((void**)&h_tk, (1 + 512 + 512) * sizeof(uint32_t)));
+}
+
+void Model::gather_logits() {
+    if (rccl && !logits_gathered) {
+        rccl->all_gather(logits + (size_t)rank * V_l, logits, (size_t)V_l * sizeof(float), stream);
+        logits_gathered = true;
+    }
+}
+
+void Model::topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out) {
+    if (!idx_out) throw CmError(CM_ERR_INVALID, "null argument");
+    ensure_sampler();
+    const float* src = logits;
+    if (host_logits) {
+        if (n == 0 || n > (size_t)1 << 30) throw CmError(CM_ERR_RANGE, "n out of range");
+        if (n > tk_in_cap) {
+            if (tk_in) (void)hipFree(tk_in);
+            tk_in = nullptr; tk_in_cap = 0;
+            CM_HIP(hipMalloc((void**)&tk_in, n * sizeof(float)));
+            tk_in_cap = n;
+        }
+        CM_HIP(hipMemcpyAsync(tk_in, host_logits, n * sizeof(float), hipMemcpyHostToDevice, stream));
+        src = tk_in;
+    } else {
+        gather_logits();
+        n = (size_t)cfg.V;
+    }
+    if (k == 0 || k > 512 || (size_t)k > n) throw CmError(CM_ERR_RANGE, "k must be in 1..min(512, n)");
+    const size_t need = (size_t)topk_blocks((int)n) * (size_t)topk_pad((int)k);
+    if (need > tk_cand_cap) {
+        if (tk_cand) (void)hipFree(tk_cand);
+        tk_cand = nullptr; tk_cand_cap = 0;
+        CM_HIP(hipMalloc((void**)&tk_cand, need * sizeof(unsigned long long)));
+        tk_cand_cap = need;
+    }
+    launch_topk(src, (int)n, (int)k, tk_cand, tk_idx, tk_val, stream);
+    CM_HIP(hipMemcpyAsync(h_tk + 1, tk_idx, k * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipMemcpyAsync(h_tk + 1 + 512, tk_val, k * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    memcpy(idx_out, h_tk + 1, k * sizeof(uint32_t));
+    if (val_out) memcpy(val_out, h_tk + 1 + 512, k * sizeof(float));
+}
+
+uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div) {
+    ensure_sampler();
+    gather_logits();
+    const int V = cfg.V;
+    // ---- penalties over the window (sampling.rs:422-478): distinct ids + counts, applied on the device ----
+    const bool rep = p.repetition_penalty != 1.0f && p.repetition_penalty > 0.f;      // strict sentinel (sampling.rs:431)
+    const bool fp = p.frequency_penalty != 0.f || p.presence_penalty != 0.f;
+    if ((rep || fp) && ctx && n_ctx) {
+        const size_t start = (p.repeat_last_n && n_ctx > p.repeat_last_n) ? n_ctx - p.repeat_last_n : 0;
+        std::unordered_map<uint32_t, uint32_t> pos;
+        int nd = 0;
+        for (size_t i = start; i < n_ctx; ++i) {
+            const uint32_t t = ctx[i];
+            if (t >= (uint32_t)V) continue;
+            auto it = pos.find(t);
+            if (it != pos.end()) { h_pen[PEN_CAP + it->second]++; continue; }
+            if (nd == PEN_CAP) throw CmError(CM_ERR_RANGE, "more than 8192 distinct tokens in the penalty window");
+            pos.emplace(t, (uint32_t)nd);
+            h_pen[nd] = t; h_pen[PEN_CAP + nd] = 1; ++nd;
+        }
+        if (nd) {
+            CM_HIP(hipMemcpyAsync(d_pen, h_pen, (size_t)nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            CM_HIP(hipMemcpyAsync(d_pen + PEN_CAP, h_pen + PEN_CAP, (size_t)nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            launch_penalties(logits, d_pen, d_pen + PEN_CAP, nd, rep ? p.repetition_penalty : 1.0f, true_div, p.frequency_penalty,
+                             p.presence_penalty, V, stream);
+        }
+    }
+    auto need_cand = [&](int k) {
+        const size_t need = (size_t)topk_blocks(V) * (size_t)topk_pad(k);
+        if (need > tk_cand_cap) {
+            if (tk_cand) (void)hipFree(tk_cand);
+            tk_cand = nullptr; tk_cand_cap = 0;
+            CM_HIP(hipMalloc((void**)&tk_cand, need * sizeof(unsigned long long)));
+            tk_cand_cap = need;
+        }
+    };
+    if (!(p.temperature > 0.f)) {                                  // greedy: arg-max, first index on ties
+        need_cand(1);
+        launch_topk(logits, V, 1, tk_cand, d_tok, tk_val, stream);
+    } else {
+        const bool top_p_active = p.top_p > 0.f && p.top_p < 1.f;
+        int k = (int)p.top_k;
+        if (k == 0 && top_p_active) k = 64;                        // CRANE_TOPP_FALLBACK_TOPK default (sampling.rs:263-267)
+        k = std::min(std::min(k, 64), V);                          // sampling.rs:268
+        if (k > 0 && k < V) {
+            need_cand(k);
+            launch_topk(logits, V, k, tk_cand, tk_idx, tk_val, stream);
+            launch_sample_topk(tk_idx, tk_val, k, p.temperature, top_p_active ? p.top_p : 0.f, p.seed, p.draw, d_tok, stream);
+        } else {
+            launch_gumbel_full(logits, V, p.temperature, p.seed, p.draw, sm_pmax, sm_pidx, SM_BLOCKS, d_tok, stream);
+        }
+    }
+    CM_HIP(hipMemcpyAsync(h_tk, d_tok, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    return h_tk[0];
+}
+
+}  // namespace cm

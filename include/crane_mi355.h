@@ -143,7 +143,11 @@ typedef struct cm_gen_config {
     uint32_t repeat_last_n;
     int64_t  eos_token_id[4];    /* -1 : unused slot (multi-id EOS: qwen3_5/model.rs:871-877) */
     uint32_t sync_every;         /* greedy w/o penalty: tokens enqueued per host sync (0: 1) */
-    uint32_t reserved[7];
+    uint32_t top_k;              /* 0 : unset (64 when top_p is active; sampling.rs:263-268) */
+    uint32_t seed_lo, seed_hi;   /* sampling seed (based.rs GenerationConfig has none: candle seeds 299792458) */
+    float    frequency_penalty;  /* 0 : off (sampling.rs:456-470) */
+    float    presence_penalty;   /* 0 : off */
+    uint32_t reserved[2];
 } cm_gen_config;
 
 /* TokenStreamer::append (generation/streamer.rs:7-10); return non-zero to stop. */
@@ -155,6 +159,35 @@ typedef int (*cm_token_cb)(void* user, uint32_t token);
  * max_new_tokens); `*n_out` = total length. */
 int cm_generate(cm_model* m, const uint32_t* prompt, size_t n_prompt, const cm_gen_config* cfg,
                 uint32_t* tokens_out, size_t* n_out, cm_token_cb cb, void* user);
+
+/* ---- device-side sampler (replaces crane-serve/src/engine/sampling.rs:169-373 and
+ *      crane_core::ops::topk_indices, crane-core/src/ops/mod.rs + kernels/cuda/topk.cu) ---- */
+
+typedef struct cm_sample_params {
+    float    temperature;        /* <= 0 : greedy (sampling.rs:214-217) */
+    float    top_p;              /* <= 0 or >= 1 : off */
+    uint32_t top_k;              /* 0 : off; clamped to min(64, vocab) like sampling.rs:268 */
+    float    repetition_penalty; /* 1 : off */
+    float    frequency_penalty;  /* 0 : off */
+    float    presence_penalty;   /* 0 : off */
+    uint32_t repeat_last_n;      /* penalty window over the tail of `context` (0: whole context) */
+    uint32_t draw;               /* counter of the uniform stream; callers pass the step index */
+    uint64_t seed;
+    uint32_t reserved[6];
+} cm_sample_params;
+
+/* Sequence::sample (sampling.rs:169): sample the next token from the logits of the LAST forward call, which
+ * are still resident in HBM (no [V] D2H copy).  Penalties are applied IN PLACE to those device logits over
+ * the last `repeat_last_n` tokens of `context` (apply_penalties_inplace, sampling.rs:422-478). */
+int cm_sample(cm_model* m, const cm_sample_params* p, const uint32_t* context, size_t n_context, uint32_t* token_out);
+
+/* crane_core::ops::topk_indices: exact top-k, total order value-descending / index-ascending, -0.0 == +0.0
+ * (rocm_kernels.rs:86-200).  `logits` = host vector of length n, or NULL for the last forward's logits
+ * (n ignored).  1 <= k <= min(512, n).  `val_out` may be NULL. */
+int cm_topk(cm_model* m, const float* logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out);
+
+/* copy the (possibly penalised) device logits of the last forward call back to the host: [vocab] */
+int cm_read_logits(cm_model* m, float* logits_out);
 
 /* ---- paged-KV sequences (replaces get/set_kv_caches + pad/stack/extract:
  *      backend.rs:66-147, qwen3/modeling.rs:1094-1378) ------------------------- */
