@@ -23,7 +23,8 @@ EXPORTS = [
     "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
-    "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
+    "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
+    "cm_engine_step", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read",
 ]
 
 
@@ -52,6 +53,31 @@ class CmSampleParams(C.Structure):
         ("frequency_penalty", C.c_float), ("presence_penalty", C.c_float), ("repeat_last_n", C.c_uint32),
         ("draw", C.c_uint32), ("seed", C.c_uint64), ("reserved", C.c_uint32 * 6),
     ]
+
+
+class CmEngineOpts(C.Structure):
+    _fields_ = [("max_running", C.c_uint32), ("repeat_last_n", C.c_uint32), ("seed", C.c_uint64), ("reserved", C.c_uint32 * 8)]
+
+
+class CmRequest(C.Structure):
+    _fields_ = [
+        ("tokens", C.POINTER(C.c_uint32)), ("n_tokens", C.c_size_t), ("max_tokens", C.c_uint32), ("temperature", C.c_float),
+        ("top_p", C.c_float), ("top_k", C.c_uint32), ("repetition_penalty", C.c_float), ("frequency_penalty", C.c_float),
+        ("presence_penalty", C.c_float), ("eos_token_id", C.c_int64 * 4), ("seed", C.c_uint64), ("reserved", C.c_uint32 * 4),
+    ]
+
+
+class CmEngineEvent(C.Structure):
+    _fields_ = [
+        ("req_id", C.c_uint64), ("kind", C.c_uint32), ("token", C.c_uint32), ("finish_reason", C.c_uint32),
+        ("prompt_tokens", C.c_uint32), ("completion_tokens", C.c_uint32), ("error", C.c_int32),
+    ]
+
+
+class CmEngineStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("waiting", "running", "completed", "failed", "preemptions", "prompt_tokens",
+                                          "completion_tokens", "prefill_steps", "decode_rounds", "free_pages", "total_pages")] + \
+               [("reserved", C.c_uint64 * 5)]
 
 
 TOKEN_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)
@@ -116,6 +142,16 @@ def load():
     lib.cm_sample.argtypes = [vp, P(CmSampleParams), u32p, C.c_size_t, u32p]
     lib.cm_topk.argtypes = [vp, f32p, C.c_size_t, C.c_uint32, u32p, f32p]
     lib.cm_read_logits.argtypes = [vp, f32p]
+    lib.cm_engine_create.argtypes = [vp, P(CmEngineOpts), P(vp)]
+    lib.cm_engine_destroy.argtypes = [vp]
+    lib.cm_engine_destroy.restype = None
+    lib.cm_engine_submit.argtypes = [vp, P(CmRequest), P(C.c_uint64)]
+    lib.cm_engine_cancel.argtypes = [vp, C.c_uint64]
+    lib.cm_engine_step.argtypes = [vp, P(CmEngineEvent), C.c_size_t, P(C.c_size_t)]
+    lib.cm_engine_has_work.argtypes = [vp]
+    lib.cm_engine_get_stats.argtypes = [vp, P(CmEngineStats)]
+    lib.cm_engine_last_error.argtypes = [vp]
+    lib.cm_engine_last_error.restype = C.c_char_p
     lib.cm_bench_decode.argtypes = [vp, C.c_uint32, C.c_size_t, u32p, f32p]
     lib.cm_bench_kernel.argtypes = [vp, C.c_char_p, C.c_size_t, f32p, P(C.c_uint64)]
     lib.cm_debug_fill_kv.argtypes = [vp, C.c_size_t, C.c_uint64]

@@ -12,6 +12,8 @@ using cm::Model;
 
 struct cm_model { Model m; };
 
+namespace cm { Model& model_of(cm_model* h) { return h->m; } }
+
 static thread_local std::string g_err;
 
 template <typename F>

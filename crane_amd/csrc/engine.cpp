@@ -1,0 +1,321 @@
+// Continuous-batching engine on the paged KV pool -- the caller of the hot path.
+//
+// Mirrors the scheduling core of the reference:
+//   Scheduler::schedule            crane-serve/src/engine/scheduler.rs:67-98   (prefill priority, FIFO)
+//   InferenceEngine::accept_request engine/mod.rs:525-599  (reject long prompts, clamp max_tokens)
+//   step_prefill                   engine/mod.rs:643-731   (whole prompt, sample first token, promote)
+//   step_decode_batch              engine/mod.rs:822-1057  (one token for every running sequence)
+//   evict_if_needed                engine/mod.rs:430-504   (victim = longest running sequence, back of the queue,
+//                                                           effective_max_running capped until one finishes)
+//   Sequence::should_stop / finish_reason  engine/sequence.rs:75-125
+//   sampling::sample               engine/sampling.rs:169-373 (context = last repeat_last_n tokens)
+// What is different by design: sequences own KV pages, so a decode round is cm_decode_batch over page tables --
+// there is no swap_in/swap_out, pad_and_stack_kv_caches or extract_batch_kv; the budget is the page pool itself
+// (free pages) instead of tracked bytes; a preempted sequence keeps its generated tokens and re-prefills
+// prompt ++ generated (the reference truncates to the prompt and re-emits).
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <unordered_map>
+
+#include "model.h"
+
+namespace cm {
+
+Model& model_of(cm_model* h);    // api.cpp
+
+struct Request {
+    uint64_t id = 0;
+    int seq = -1;                       // model sequence handle while running
+    std::vector<uint32_t> tokens;       // prompt ++ generated (Sequence::tokens)
+    size_t prompt_len = 0;
+    uint32_t max_tokens = 0;
+    cm_sample_params sp{};
+    bool greedy_plain = false;          // temperature <= 0 and no penalties: the arg-max of the step itself
+    int64_t eos[4] = {-1, -1, -1, -1};
+    bool cancelled = false;
+
+    size_t num_generated() const { return tokens.size() - prompt_len; }
+    bool last_is_eos() const {
+        if (tokens.empty()) return false;
+        for (int i = 0; i < 4; ++i) if (eos[i] >= 0 && (uint32_t)eos[i] == tokens.back()) return true;
+        return false;
+    }
+    bool should_stop() const { return num_generated() >= max_tokens || last_is_eos(); }     // sequence.rs:75-86
+};
+
+struct Engine {
+    cm_model* handle = nullptr;
+    Model* m = nullptr;
+    cm_engine_opts opts{};
+    size_t max_running = 0;
+    long effective_max_running = -1;    // Scheduler::effective_max_running (None == -1)
+    uint64_t next_id = 1;
+    std::deque<uint64_t> waiting, running;
+    std::unordered_map<uint64_t, Request> reqs;
+    std::deque<cm_engine_event> events;
+    cm_engine_stats stats{};
+    std::string err;
+
+    Request& req(uint64_t id) { return reqs.at(id); }
+
+    void emit_token(const Request& r, uint32_t t) {
+        cm_engine_event e{}; e.req_id = r.id; e.kind = CM_EV_TOKEN; e.token = t; events.push_back(e);
+    }
+    void release(Request& r) {
+        if (r.seq >= 0) { m->seq_free(r.seq); r.seq = -1; }
+    }
+    void drop(uint64_t id) {
+        waiting.erase(std::remove(waiting.begin(), waiting.end(), id), waiting.end());
+        running.erase(std::remove(running.begin(), running.end(), id), running.end());
+        reqs.erase(id);
+    }
+    void finish(uint64_t id, uint32_t reason) {                     // finish_sequence (engine/mod.rs:1265-1316)
+        Request& r = req(id);
+        cm_engine_event e{};
+        e.req_id = id; e.kind = CM_EV_FINISHED; e.finish_reason = reason;
+        e.prompt_tokens = (uint32_t)r.prompt_len; e.completion_tokens = (uint32_t)r.num_generated();
+        events.push_back(e);
+        if (reason != CM_FINISH_CANCELLED) { stats.completed++; stats.completion_tokens += r.num_generated(); }
+        release(r);
+        drop(id);
+        effective_max_running = -1;                                  // the cap is lifted when a sequence finishes
+    }
+    void fail(uint64_t id, int code, const std::string& msg) {      // send_error (engine/mod.rs:1256-1263)
+        cm_engine_event e{}; e.req_id = id; e.kind = CM_EV_ERROR; e.error = code; events.push_back(e);
+        err = msg;
+        stats.failed++;
+        auto it = reqs.find(id);
+        if (it != reqs.end()) { release(it->second); drop(id); }
+    }
+
+    size_t pages_for(size_t len) const { return (len + (size_t)m->page - 1) / (size_t)m->page; }
+
+    // evict_if_needed (engine/mod.rs:430-504): free pages by preempting the longest running sequence(s)
+    bool make_room(size_t need_pages, uint64_t keep) {
+        bool evicted = false;
+        while (m->free_pages.size() < need_pages) {
+            uint64_t victim = 0; size_t vlen = 0; bool found = false;
+            for (uint64_t id : running) {
+                if (id == keep) continue;
+                const size_t l = req(id).tokens.size();
+                if (!found || l > vlen) { victim = id; vlen = l; found = true; }
+            }
+            if (!found) break;
+            Request& v = req(victim);
+            release(v);
+            running.erase(std::remove(running.begin(), running.end(), victim), running.end());
+            waiting.push_back(victim);                               // back, not front: no thrashing
+            stats.preemptions++;
+            evicted = true;
+        }
+        if (evicted) effective_max_running = (long)running.size() + (keep && std::find(running.begin(), running.end(), keep) == running.end() ? 1 : 0);
+        return m->free_pages.size() >= need_pages;
+    }
+
+    uint32_t pick(Request& r, float* dev_logits, uint32_t greedy_tok) {
+        if (r.greedy_plain) return greedy_tok;                       // sampling.rs:191-210 fast path
+        const size_t w = std::min(r.tokens.size(), (size_t)opts.repeat_last_n);     // sampling.rs:217
+        cm_sample_params sp = r.sp;
+        sp.repeat_last_n = 0;
+        sp.draw = (uint32_t)r.num_generated();
+        return m->sample(sp, r.tokens.data() + (r.tokens.size() - w), w, false, dev_logits);
+    }
+
+    void step_prefill(uint64_t id) {
+        Request& r = req(id);
+        try {
+            if (r.seq < 0) r.seq = m->seq_alloc();
+            if (!make_room(pages_for(r.tokens.size() + 1), id))
+                throw CmError(CM_ERR_OOM, "prompt does not fit in the KV pool");
+            uint32_t greedy = 0;
+            m->forward(r.seq, r.tokens.data(), r.tokens.size(), 0, nullptr, &greedy);
+            stats.prefill_steps++;
+            const uint32_t t = pick(r, nullptr, greedy);
+            r.tokens.push_back(t);
+            emit_token(r, t);
+            if (r.should_stop()) finish(id, r.last_is_eos() ? CM_FINISH_STOP : CM_FINISH_LENGTH);
+            else running.push_back(id);                              // promote_to_running
+        } catch (const CmError& e) {
+            fail(id, e.code, e.what());
+        }
+    }
+
+    void step_decode(std::vector<uint64_t> batch) {
+        // every sequence appends one token: make sure the pages exist, evicting if the pool is short
+        size_t reserved = 0;
+        for (size_t i = 0; i < batch.size();) {
+            Request& r = req(batch[i]);
+            if (r.seq < 0) { ++i; continue; }                        // preempted by an earlier iteration
+            const size_t have = m->seq(r.seq).pages.size(), want = pages_for(r.tokens.size());
+            const size_t need = want > have ? want - have : 0;
+            if (need == 0 || make_room(reserved + need, batch[i])) { reserved += need; ++i; continue; }
+            fail(batch[i], CM_ERR_OOM, "KV pool exhausted");
+            batch.erase(batch.begin() + (long)i);
+        }
+        batch.erase(std::remove_if(batch.begin(), batch.end(), [&](uint64_t id) {
+            return std::find(running.begin(), running.end(), id) == running.end(); }), batch.end());   // preempted above
+        if (batch.empty()) return;
+        stats.decode_rounds++;
+        try {
+            if (batch.size() == 1 || m->rccl) {
+                // step_decode_sequential (engine/mod.rs:1064-1170): graph-replayed single-sequence step
+                for (uint64_t id : batch) {
+                    Request& r = req(id);
+                    uint32_t greedy = 0;
+                    m->forward(r.seq, &r.tokens.back(), 1, r.tokens.size() - 1, nullptr, &greedy);
+                    const uint32_t t = pick(r, nullptr, greedy);
+                    r.tokens.push_back(t);
+                    emit_token(r, t);
+                }
+            } else {
+                std::vector<int32_t> sq(batch.size());
+                std::vector<uint32_t> toks(batch.size()), greedy(batch.size()), out(batch.size());
+                for (size_t i = 0; i < batch.size(); ++i) { sq[i] = req(batch[i]).seq; toks[i] = req(batch[i]).tokens.back(); }
+                const std::function<void(size_t, int)> after = [&](size_t g0, int nb) {
+                    for (int b = 0; b < nb; ++b) {
+                        Request& r = req(batch[g0 + (size_t)b]);
+                        out[g0 + (size_t)b] = r.greedy_plain ? m->h_stb[b].next
+                                                             : pick(r, m->logitsb + (size_t)b * m->cfg.V, 0);
+                    }
+                };
+                m->decode_batch(sq.data(), toks.data(), batch.size(), nullptr, greedy.data(), &after);
+                for (size_t i = 0; i < batch.size(); ++i) {
+                    Request& r = req(batch[i]);
+                    r.tokens.push_back(out[i]);
+                    emit_token(r, out[i]);
+                }
+            }
+        } catch (const CmError& e) {
+            // batch-decode errors fail every live sequence of the batch (engine/mod.rs:945-954)
+            for (uint64_t id : batch) if (reqs.count(id)) fail(id, e.code, e.what());
+            return;
+        }
+        for (uint64_t id : batch) {
+            Request& r = req(id);
+            if (r.should_stop()) finish(id, r.last_is_eos() ? CM_FINISH_STOP : CM_FINISH_LENGTH);
+        }
+    }
+
+    void step() {
+        // check_cancelled (engine/mod.rs:601-620)
+        std::vector<uint64_t> gone;
+        for (auto& kv : reqs) if (kv.second.cancelled) gone.push_back(kv.first);
+        for (uint64_t id : gone) finish(id, CM_FINISH_CANCELLED);
+        // Scheduler::schedule (scheduler.rs:67-98)
+        const size_t cap = effective_max_running >= 0 ? (size_t)effective_max_running : max_running;
+        if (running.size() < cap && !waiting.empty()) {
+            const uint64_t id = waiting.front(); waiting.pop_front();
+            step_prefill(id);
+        } else if (!running.empty()) {
+            step_decode(std::vector<uint64_t>(running.begin(), running.end()));
+        } else if (!waiting.empty()) {
+            const uint64_t id = waiting.front(); waiting.pop_front();
+            step_prefill(id);
+        }
+    }
+};
+
+}  // namespace cm
+
+struct cm_engine { cm::Engine e; };
+
+using cm::CmError;
+
+extern "C" {
+
+int cm_engine_create(cm_model* m, const cm_engine_opts* opts, cm_engine** out) {
+    if (!m || !out) return CM_ERR_INVALID;
+    cm_engine* h = new cm_engine();
+    h->e.handle = m;
+    h->e.m = &cm::model_of(m);
+    if (opts) h->e.opts = *opts;
+    if (h->e.opts.repeat_last_n == 0) h->e.opts.repeat_last_n = 64;
+    const size_t slots = h->e.m->seqs.size() > 1 ? h->e.m->seqs.size() - 1 : 1;
+    h->e.max_running = h->e.opts.max_running ? std::min<size_t>(h->e.opts.max_running, slots) : slots;
+    if (h->e.opts.seed == 0) h->e.opts.seed = 299792458ull;
+    h->e.stats.total_pages = (uint64_t)h->e.m->n_pages;
+    *out = h;
+    return CM_OK;
+}
+
+void cm_engine_destroy(cm_engine* h) {
+    if (!h) return;
+    for (auto& kv : h->e.reqs) if (kv.second.seq >= 0) { try { h->e.m->seq_free(kv.second.seq); } catch (...) {} }
+    delete h;
+}
+
+int cm_engine_submit(cm_engine* h, const cm_request* r, uint64_t* id_out) {
+    if (!h || !r || !id_out) return CM_ERR_INVALID;
+    cm::Engine& e = h->e;
+    if (!r->tokens || r->n_tokens == 0) { e.err = "empty prompt"; e.stats.failed++; return CM_ERR_INVALID; }
+    if (r->n_tokens > (size_t)e.m->max_seq - 1) {
+        e.err = "Prompt length (" + std::to_string(r->n_tokens) + ") exceeds server max_seq_len (" + std::to_string(e.m->max_seq) + ")";
+        e.stats.failed++;
+        return CM_ERR_RANGE;
+    }
+    for (size_t i = 0; i < r->n_tokens; ++i)
+        if (r->tokens[i] >= (uint32_t)e.m->cfg.V) { e.err = "token id >= vocab_size"; e.stats.failed++; return CM_ERR_RANGE; }
+    cm::Request q;
+    q.id = e.next_id++;
+    q.tokens.assign(r->tokens, r->tokens + r->n_tokens);
+    q.prompt_len = r->n_tokens;
+    q.max_tokens = (uint32_t)std::min<size_t>(r->max_tokens, (size_t)e.m->max_seq - r->n_tokens);   // effective_max_tokens
+    memcpy(q.eos, r->eos_token_id, sizeof q.eos);
+    q.sp.temperature = r->temperature < 0.f ? 1.0f : r->temperature;     // None -> 1.0 (sampling.rs:229)
+    q.sp.top_p = r->top_p; q.sp.top_k = r->top_k;
+    q.sp.repetition_penalty = r->repetition_penalty == 0.f ? 1.0f : r->repetition_penalty;
+    q.sp.frequency_penalty = r->frequency_penalty; q.sp.presence_penalty = r->presence_penalty;
+    q.sp.seed = r->seed ? r->seed : (e.opts.seed ^ (q.id * 0x9E3779B97F4A7C15ull));
+    q.greedy_plain = !(q.sp.temperature > 0.f) && q.sp.repetition_penalty == 1.0f && q.sp.frequency_penalty == 0.f &&
+                     q.sp.presence_penalty == 0.f;
+    *id_out = q.id;
+    e.stats.prompt_tokens += r->n_tokens;
+    e.waiting.push_back(q.id);
+    e.reqs.emplace(q.id, std::move(q));
+    return CM_OK;
+}
+
+int cm_engine_cancel(cm_engine* h, uint64_t id) {
+    if (!h) return CM_ERR_INVALID;
+    auto it = h->e.reqs.find(id);
+    if (it == h->e.reqs.end()) { h->e.err = "unknown request id"; return CM_ERR_INVALID; }
+    it->second.cancelled = true;
+    return CM_OK;
+}
+
+int cm_engine_step(cm_engine* h, cm_engine_event* ev, size_t cap, size_t* n) {
+    if (!h || !n || (cap && !ev)) return CM_ERR_INVALID;
+    cm::Engine& e = h->e;
+    int rc = CM_OK;
+    if (e.events.size() < cap || cap == 0) {
+        try {
+            (void)hipSetDevice(e.m->dev);
+            e.step();
+        } catch (const CmError& x) { e.err = x.what(); rc = x.code; }
+        catch (const std::exception& x) { e.err = x.what(); rc = CM_ERR_INVALID; }
+    }
+    size_t k = 0;
+    while (k < cap && !e.events.empty()) { ev[k++] = e.events.front(); e.events.pop_front(); }
+    *n = k;
+    return rc;
+}
+
+int cm_engine_has_work(const cm_engine* h) {
+    if (!h) return 0;
+    return (!h->e.waiting.empty() || !h->e.running.empty() || !h->e.events.empty()) ? 1 : 0;
+}
+
+int cm_engine_get_stats(const cm_engine* h, cm_engine_stats* out) {
+    if (!h || !out) return CM_ERR_INVALID;
+    *out = h->e.stats;
+    out->waiting = h->e.waiting.size();
+    out->running = h->e.running.size();
+    out->free_pages = h->e.m->free_pages.size();
+    out->total_pages = (uint64_t)h->e.m->n_pages;
+    return CM_OK;
+}
+
+const char* cm_engine_last_error(const cm_engine* h) { return h ? h->e.err.c_str() : "null engine"; }
+
+}  // extern "C"

@@ -690,7 +690,8 @@ void Model::ensure_batch_buffers() {
     CM_HIP(hipMemsetAsync(d_btb, 0, (size_t)MAXB * max_pages_per_seq * sizeof(int32_t), stream));
 }
 
-void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out) {
+void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out,
+                         const std::function<void(size_t, int)>* after_group) {
     if (rccl) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
     ensure_batch_buffers();
     const int H = cfg.H, D = cfg.D;
@@ -762,7 +763,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             if (greedy_out) greedy_out[g0 + b] = h_stb[b].next;
         }
         if (logits_out) memcpy(logits_out + g0 * (size_t)cfg.V, h_logitsb, (size_t)nb * cfg.V * sizeof(float));
-        if (active_seq >= 0) { /* the single-sequence table is untouched */ }
+        if (after_group) (*after_group)(g0, nb);
     }
 }
 

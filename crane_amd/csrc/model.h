@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -202,7 +203,9 @@ struct Model {
     float* h_logitsb = nullptr;
     int ldq = 0;
     void ensure_batch_buffers();
-    void decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out);
+    // after_group(g0, nb): called once per <= MAXB group after the stream is idle; logitsb[b * V] (b < nb) is valid
+    void decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out,
+                      const std::function<void(size_t, int)>* after_group = nullptr);
 
     // device sampler scratch (model_sample.cpp; allocated on first use)
     unsigned long long* tk_cand = nullptr; size_t tk_cand_cap = 0;
@@ -218,7 +221,7 @@ struct Model {
     void ensure_sampler();
     void gather_logits();              // TP: all-gather the vocab shards into `logits`
     void topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out);
-    uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false);
+    uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false, float* dev_logits = nullptr);
     bool logits_gathered = false;
 
     hipGraph_t graph = nullptr;

@@ -66,9 +66,10 @@ void Model::topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_o
     if (val_out) memcpy(val_out, h_tk + 1 + 512, k * sizeof(float));
 }
 
-uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div) {
+uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div, float* dev_logits) {
     ensure_sampler();
-    gather_logits();
+    float* logits = dev_logits ? dev_logits : this->logits;      // a row of the batched step, or the last forward's logits
+    if (!dev_logits) gather_logits();
     const int V = cfg.V;
     // ---- penalties over the window (sampling.rs:422-478): distinct ids + counts, applied on the device ----
     const bool rep = p.repetition_penalty != 1.0f && p.repetition_penalty > 0.f;      // strict sentinel (sampling.rs:431)

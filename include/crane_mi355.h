@@ -231,6 +231,71 @@ int cm_vision_encode(cm_model* m, const float* pixel_values, size_t n_patches, c
 int cm_vlm_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, const float* pixel_values,
                    size_t n_patches, const uint32_t* grid_thw, size_t n_images, float* logits_out, uint32_t* greedy_out);
 
+/* ---- continuous-batching engine on the paged KV pool ------------------------------
+ * Replaces InferenceEngine's scheduling core (crane-serve/src/engine/mod.rs:622-1057 execute_step /
+ * step_prefill / step_decode_batch / evict_if_needed) and Scheduler (scheduler.rs:67-98): FIFO, prefill-priority
+ * (one whole prompt per step while running < max_running), otherwise ONE batched decode round over every running
+ * sequence.  No pad/stack/extract KV copies: sequences own pages.  Tokenizer, HTTP and channels stay with the
+ * caller; the engine speaks token ids and events.  Not thread-safe (like `&mut self`, backend.rs:30). */
+typedef struct cm_engine cm_engine;
+
+typedef struct cm_engine_opts {
+    uint32_t max_running;        /* Scheduler::max_running (scheduler.rs:31); 0: max_seqs - 1 */
+    uint32_t repeat_last_n;      /* penalty window; 0: 64 (engine/mod.rs:588) */
+    uint64_t seed;               /* base of the per-request sampling seeds (sampling.rs:480-491 uses the clock) */
+    uint32_t reserved[8];
+} cm_engine_opts;
+
+/* EngineRequest (engine/types.rs:11-24) */
+typedef struct cm_request {
+    const uint32_t* tokens;      /* prompt */
+    size_t   n_tokens;
+    uint32_t max_tokens;
+    float    temperature;        /* < 0 : None (== 1.0, sampled); 0 : greedy (sampling.rs:180-183) */
+    float    top_p;              /* < 0 : None */
+    uint32_t top_k;              /* 0 : None */
+    float    repetition_penalty; /* 1 : off */
+    float    frequency_penalty;
+    float    presence_penalty;
+    int64_t  eos_token_id[4];    /* -1 : unused */
+    uint64_t seed;               /* 0 : derived from cm_engine_opts.seed and the request id */
+    uint32_t reserved[4];
+} cm_request;
+
+enum { CM_EV_TOKEN = 0, CM_EV_FINISHED = 1, CM_EV_ERROR = 2 };
+enum { CM_FINISH_NONE = 0, CM_FINISH_STOP = 1, CM_FINISH_LENGTH = 2, CM_FINISH_CANCELLED = 3 };
+
+/* EngineResponse (engine/types.rs:53-66) without the detokenised text */
+typedef struct cm_engine_event {
+    uint64_t req_id;
+    uint32_t kind;               /* CM_EV_* */
+    uint32_t token;              /* CM_EV_TOKEN */
+    uint32_t finish_reason;      /* CM_EV_FINISHED: CM_FINISH_* (Sequence::finish_reason, sequence.rs:117-125) */
+    uint32_t prompt_tokens;      /* CM_EV_FINISHED */
+    uint32_t completion_tokens;  /* CM_EV_FINISHED */
+    int32_t  error;              /* CM_EV_ERROR: cm_status */
+} cm_engine_event;
+
+typedef struct cm_engine_stats {
+    uint64_t waiting, running, completed, failed, preemptions;
+    uint64_t prompt_tokens, completion_tokens, prefill_steps, decode_rounds;
+    uint64_t free_pages, total_pages;
+    uint64_t reserved[5];
+} cm_engine_stats;
+
+int  cm_engine_create(cm_model* m, const cm_engine_opts* opts, cm_engine** out);
+void cm_engine_destroy(cm_engine* e);
+/* accept_request (engine/mod.rs:525-599): rejects empty prompts and prompts longer than max_seq_len,
+ * clamps max_tokens to max_seq_len - prompt_len (effective_max_tokens :507-513). */
+int  cm_engine_submit(cm_engine* e, const cm_request* r, uint64_t* req_id_out);
+int  cm_engine_cancel(cm_engine* e, uint64_t req_id);
+/* One scheduling decision + its execution (Scheduler::schedule + execute_step).  Writes up to `cap` events and
+ * keeps the rest queued for the next call; *n_events = 0 with no work left means idle. */
+int  cm_engine_step(cm_engine* e, cm_engine_event* events, size_t cap, size_t* n_events);
+int  cm_engine_has_work(const cm_engine* e);
+int  cm_engine_get_stats(const cm_engine* e, cm_engine_stats* out);
+const char* cm_engine_last_error(const cm_engine* e);
+
 /* ---- measurement hooks (bench.py / tests) ----------------------------------- */
 
 /* Enqueue `k` greedy decode steps for sequence 0 starting from its current

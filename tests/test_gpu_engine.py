@@ -1,0 +1,168 @@
+"""GPU: the continuous-batching engine (engine.cpp) -- scheduling rules of crane-serve/src/engine/scheduler.rs:67-98,
+stop rules of sequence.rs:75-125, preemption of engine/mod.rs:430-504 -- checked against single-request generate()."""
+import numpy as np
+import pytest
+
+from crane_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name="tiny-qwen3", **kw):
+    from crane_amd.backend import Model
+    kw.setdefault("max_seq_len", 256)
+    kw.setdefault("max_seqs", 8)
+    kw.setdefault("kv_dtype", "f32")
+    return Model.synthetic(configs.get_config(name), seed=0, **kw)
+
+
+def _prompts(V, n):
+    return [[(7 * i + 3 + 11 * j) % V for i in range(5 + 3 * j)] for j in range(n)]
+
+
+def _reference_greedy(m, prompt, n, eos=()):
+    from crane_amd.backend import GenerationConfig
+    out = m.generate(prompt, GenerationConfig.greedy(n, eos_token_id=eos[0] if eos else None))
+    return out[len(prompt):]
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3.5"])
+def test_engine_greedy_matches_single_request_generate(name):
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model(name)
+    try:
+        prompts = _prompts(m.vocab_size, 5)
+        lens = [6, 11, 3, 9, 14]
+        want = [_reference_greedy(m, p, n) for p, n in zip(prompts, lens)]
+        m.clear_kv_cache()
+        eng = InferenceEngine(m, max_running=4)
+        ids = [eng.submit(p, GenerationParams.greedy(n)) for p, n in zip(prompts, lens)]
+        toks, done = eng.run_until_idle()
+        for rid, w, p in zip(ids, want, prompts):
+            assert toks[rid] == w
+            assert done[rid].kind == "finished" and done[rid].finish_reason == "length"
+            assert done[rid].prompt_tokens == len(p) and done[rid].completion_tokens == len(w)
+        st = eng.stats()
+        assert st["completed"] == 5 and st["failed"] == 0 and st["waiting"] == 0 and st["running"] == 0
+        assert st["prefill_steps"] == 5 and st["free_pages"] == st["total_pages"]
+        assert st["completion_tokens"] == sum(lens)
+        eng.close()
+    finally:
+        m.close()
+
+
+def test_schedule_is_prefill_priority_then_batched_decode():
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model()
+    try:
+        eng = InferenceEngine(m, max_running=2)
+        prompts = _prompts(m.vocab_size, 3)
+        a, b, c = (eng.submit(p, GenerationParams.greedy(n)) for p, n in zip(prompts, [3, 5, 2]))
+        ev = eng.step(); assert [(e.req_id, e.kind) for e in ev] == [(a, "token")]          # prefill a
+        ev = eng.step(); assert [(e.req_id, e.kind) for e in ev] == [(b, "token")]          # prefill b (running 1 < 2)
+        ev = eng.step(); assert [(e.req_id, e.kind) for e in ev] == [(a, "token"), (b, "token")]   # decode round, c waits
+        ev = eng.step()                                                                       # a reaches 3 tokens
+        assert [(e.req_id, e.kind) for e in ev] == [(a, "token"), (b, "token"), (a, "finished")]
+        ev = eng.step(); assert [(e.req_id, e.kind) for e in ev] == [(c, "token")]          # slot free: prefill c
+        ev = eng.step()
+        assert [(e.req_id, e.kind) for e in ev] == [(b, "token"), (c, "token"), (c, "finished")]
+        toks, done = eng.run_until_idle()
+        assert done[b].completion_tokens == 5 and not eng.has_work()
+        eng.close()
+    finally:
+        m.close()
+
+
+def test_stop_rules_eos_and_zero_max_tokens():
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model()
+    try:
+        p = _prompts(m.vocab_size, 1)[0]
+        free = _reference_greedy(m, p, 8)
+        eos = free[3]
+        first = free.index(eos)
+        m.clear_kv_cache()
+        eng = InferenceEngine(m)
+        r1 = eng.submit(p, GenerationParams.greedy(8, eos_token_id=[999999 % m.vocab_size, eos]))
+        r2 = eng.submit(p, GenerationParams.greedy(0))          # prefill still samples one token (engine/mod.rs:716-731)
+        toks, done = eng.run_until_idle()
+        assert toks[r1] == free[:first + 1] and done[r1].finish_reason == "stop"            # EOS is emitted, then stop
+        assert toks[r2] == free[:1] and done[r2].finish_reason == "length" and done[r2].completion_tokens == 1
+        eng.close()
+    finally:
+        m.close()
+
+
+def test_submit_rejections_and_cancel():
+    from crane_amd._lib import CraneError
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model()
+    try:
+        eng = InferenceEngine(m)
+        with pytest.raises(CraneError):
+            eng.submit([], GenerationParams.greedy(4))
+        with pytest.raises(CraneError, match="exceeds server max_seq_len"):
+            eng.submit([1] * 300, GenerationParams.greedy(4))
+        with pytest.raises(CraneError):
+            eng.submit([m.vocab_size], GenerationParams.greedy(4))
+        assert eng.stats()["failed"] == 3
+        # max_tokens is clamped to max_seq_len - prompt_len (effective_max_tokens, engine/mod.rs:507-513)
+        long = eng.submit([1] * 250, GenerationParams.greedy(1000))
+        other = eng.submit([2, 3, 4], GenerationParams.greedy(50))
+        eng.step(); eng.step(); eng.step()
+        eng.cancel(other)
+        toks, done = eng.run_until_idle()
+        assert done[other].finish_reason == "cancelled" and done[other].completion_tokens == 2 and other not in toks
+        assert done[long].completion_tokens == 6 and done[long].finish_reason == "length" and len(toks[long]) == 4
+        assert eng.stats()["free_pages"] == eng.stats()["total_pages"]
+        eng.close()
+    finally:
+        m.close()
+
+
+def test_preemption_when_the_page_pool_runs_out():
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    # 6 pages of 64 tokens: three sequences growing past 128 tokens cannot all stay resident
+    m = _model(kv_pool_tokens=6 * 64, max_seqs=4)
+    try:
+        prompts = [[(5 * i + j) % m.vocab_size for i in range(60)] for j in range(3)]
+        want = [_reference_greedy(m, p, 80) for p in prompts]
+        m.clear_kv_cache()
+        eng = InferenceEngine(m, max_running=3)
+        ids = [eng.submit(p, GenerationParams.greedy(80)) for p in prompts]
+        toks, done = eng.run_until_idle()
+        st = eng.stats()
+        assert st["preemptions"] >= 1 and st["completed"] == 3 and st["failed"] == 0
+        assert st["free_pages"] == st["total_pages"]
+        for rid, w in zip(ids, want):
+            assert toks[rid] == w and done[rid].finish_reason == "length"
+        eng.close()
+    finally:
+        m.close()
+
+
+def test_sampled_requests_are_seeded_and_bounded():
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model()
+    try:
+        prompts = _prompts(m.vocab_size, 4)
+
+        def run(seed):
+            eng = InferenceEngine(m, seed=seed)
+            ids = [eng.submit(p, GenerationParams(max_tokens=12, temperature=30.0, top_p=0.95, top_k=40, repetition_penalty=1.05))
+                   for p in prompts]
+            toks, done = eng.run_until_idle()
+            eng.close()
+            return [toks[i] for i in ids]
+
+        a, b, c = run(1), run(1), run(2)
+        assert a == b and a != c
+        assert all(0 <= t < m.vocab_size for seq in a for t in seq) and all(len(s) == 12 for s in a)
+        # top_k = 1 with any temperature == greedy; penalties off
+        eng = InferenceEngine(m)
+        rid = eng.submit(prompts[0], GenerationParams(max_tokens=10, temperature=0.7, top_p=None, top_k=1, repetition_penalty=1.0))
+        toks, _ = eng.run_until_idle()
+        eng.close()
+        assert toks[rid] == _reference_greedy(m, prompts[0], 10)
+    finally:
+        m.close()
