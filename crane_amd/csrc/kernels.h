@@ -7,7 +7,7 @@
 
 namespace cm {
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_ATTNCOMB = 2 };
 enum { EPI_STORE = 0, EPI_RESADD = 1, EPI_SILUMUL = 2, EPI_ARGMAX = 3 };
 
 struct GemvArgs {
@@ -21,6 +21,10 @@ struct GemvArgs {
     int N, K, ldw;
     int idx_base;          // added to row index for arg-max (vocab shard offset)
     float eps;
+    // PRO_ATTNCOMB: x = part_o [Hq][ns][D] of attn_decode_head_kernel, merged while staging
+    const float* part_ml = nullptr;   // [Hq][ns][2]
+    const float* gate = nullptr;      // [Hq * D] or null
+    int ns = 0, dshift = 0;           // D == 1 << dshift
 };
 
 struct AttnDecArgs {
@@ -135,6 +139,10 @@ struct GemvBArgs {
     int* pidx;
     int N, K, ldw, ldx, ldy, n_seq, idx_base;
     float eps;
+    // PRO_ATTNCOMB (see GemvArgs): x = part_o [MB][Hq][ns][D], ldx = Hq * ns * D
+    const float* part_ml = nullptr;   // [MB][Hq][ns][2]
+    const float* gate = nullptr;      // [MB][gate_stride]
+    int ns = 0, dshift = 0, gate_stride = 0;
 };
 int gemvb_grid(int N, int K, int num_cu);
 void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
@@ -147,6 +155,7 @@ void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H,
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, int n_seq, hipStream_t s);
+bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, bool kv_f32, int n_seq, hipStream_t s);
 bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, int out_stride, int n_seq,
                         hipStream_t s);
 void launch_gdn(const GdnArgs& a, hipStream_t s);

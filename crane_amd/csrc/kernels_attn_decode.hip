@@ -274,6 +274,228 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
     out[(size_t)h * D + d] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Short/medium-context variant: ONE 1024-thread block per (token split, q head).  At context ~1K the split
+// kernel above is pure fixed latency (2 chunks per block) followed by a second fixed-latency combine launch;
+// here 16 waves keep PF chunks of K/V rows in flight each, the CT row streams are merged inside the block, and
+// the few (NS <= 4) per-head partials are merged by the o_proj GEMV's x-staging prologue (PRO_ATTNCOMB) -- the
+// combine launch disappears.  blockIdx.y -> (kv head = y % Hkv, head-in-group = y / Hkv): blocks round-robin
+// over the 8 XCDs, so with Hkv = 8 the NREP q heads that share a KV head run on the SAME XCD and share its L2.
+// ---------------------------------------------------------------------------------------------------------
+template <int D, bool KVF32>
+__global__ __launch_bounds__(1024) void attn_decode_head_kernel(AttnDecArgs a, int nrep) {
+    constexpr int LPR = D / 8, RPW = 64 / LPR, NW = 16, CT = NW * RPW, EPL = D / 64;
+    constexpr int PF = KVF32 ? 2 : 4;                 // chunks of K/V rows in flight per wave
+    constexpr int NP = 1024 / D;                      // thread groups of the in-block merge
+    __shared__ __attribute__((aligned(16))) float qs[D];
+    __shared__ __attribute__((aligned(16))) float knew[D];
+    __shared__ __attribute__((aligned(16))) float vnew[D];
+    __shared__ __attribute__((aligned(16))) float tmp[3][D];
+    __shared__ float red_m[CT];
+    __shared__ float red_l[CT];
+    __shared__ __attribute__((aligned(16))) float red_o[CT][D];
+    __shared__ float red2[NP][D];
+    __shared__ float red2l[NP];
+
+    const int split = blockIdx.x, NS = gridDim.x;
+    const int kvh = blockIdx.y % a.Hkv, hin = blockIdx.y / a.Hkv, head = kvh * nrep + hin;
+    const int bq = blockIdx.z;
+    const StepState* st = a.st + bq;
+    const int32_t* block_table = a.block_table + (size_t)bq * a.bt_stride;
+    const float* qkv = a.qkv + (size_t)bq * a.qkv_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane / LPR, sub = lane % LPR, dimbase = sub * 8;
+    const int tok_in_chunk = wave * RPW + r;
+    auto kv_off = [&](int t) -> size_t {
+        int pi = t / a.page;
+        pi = pi < a.max_pages ? pi : a.max_pages - 1;
+        const int page = block_table[pi];
+        return ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + dimbase;
+    };
+    struct KV8 { u32x4 a, b; };
+    auto ld_kv = [&](const void* pool, size_t off) -> KV8 {
+        KV8 v;
+        if (KVF32) { v.a = ld16((const float*)pool + off); v.b = ld16((const float*)pool + off + 4); }
+        else { v.a = ld16((const uint16_t*)pool + off); v.b = v.a; }
+        return v;
+    };
+    KV8 kq[PF], vq[PF];
+    int tt[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {                     // speculative: independent of pos
+        tt[u] = CT * (split + NS * u) + tok_in_chunk;
+        const size_t off = kv_off(tt[u]);
+        kq[u] = ld_kv(a.kpool, off);
+        vq[u] = ld_kv(a.vpool, off);
+    }
+    const int pos = st->pos;
+    const int rpos = pos + st->rsv[0];
+    const int L = pos + 1;
+    const bool owner = hin == 0 && ((pos / CT) % NS) == split;
+    const int rot = a.rot_dim, hrot = rot >> 1;
+
+    if (wave < 3) {                                    // wave 0: q head, wave 1: new k, wave 2: new v
+        const int item = wave;
+        const float* src;
+        const float* nw = nullptr;
+        if (item == 0) { src = qkv + a.q_off + (size_t)head * D; nw = a.qnw; }
+        else if (item == 1) { src = qkv + a.k_off + (size_t)kvh * D; nw = a.knw; }
+        else { src = qkv + a.v_off + (size_t)kvh * D; }
+        float xv[EPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { xv[j] = src[lane + 64 * j]; ss += xv[j] * xv[j]; }
+        if (item <= 1) {
+            if (nw != nullptr) {
+                ss = wave_sum(ss);
+                const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) xv[j] = xv[j] * rr * nw[lane + 64 * j];
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) tmp[item][lane + 64 * j] = xv[j];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int d = lane + 64 * j;
+                if (d < rot) {
+                    const int i = d < hrot ? d : d - hrot;
+                    const float c = a.cos[(size_t)rpos * hrot + i], s = a.sin[(size_t)rpos * hrot + i];
+                    const float lo = tmp[item][i], hi = tmp[item][i + hrot];
+                    xv[j] = d < hrot ? lo * c - hi * s : lo * s + hi * c;
+                }
+            }
+        }
+        if (item == 0) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) qs[lane + 64 * j] = xv[j] * a.scale;
+        } else {
+            float* dst = (item == 1) ? knew : vnew;
+            void* pool = (item == 1) ? a.kpool : a.vpool;
+            const size_t eoff = owner ? ((size_t)(block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int d = lane + 64 * j;
+                if (KVF32) {
+                    dst[d] = xv[j];
+                    if (owner) ((float*)pool)[eoff + d] = xv[j];
+                } else {
+                    const uint16_t b = f32_to_bf16(xv[j]);
+                    dst[d] = bf16_to_f32(b);
+                    if (owner) ((uint16_t*)pool)[eoff + d] = b;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    float qr[8];
+    {
+        const f32x4 q0 = *(const f32x4*)&qs[dimbase];
+        const f32x4 q1 = *(const f32x4*)&qs[dimbase + 4];
+        qr[0] = q0[0]; qr[1] = q0[1]; qr[2] = q0[2]; qr[3] = q0[3];
+        qr[4] = q1[0]; qr[5] = q1[1]; qr[6] = q1[2]; qr[7] = q1[3];
+    }
+    float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+
+    auto consume = [&](const KV8& kqv, const KV8& vqv, int t) {
+        float kf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (KVF32) {
+                kf[e] = __uint_as_float(kqv.a[e]); kf[4 + e] = __uint_as_float(kqv.b[e]);
+                vf[e] = __uint_as_float(vqv.a[e]); vf[4 + e] = __uint_as_float(vqv.b[e]);
+            } else {
+                kf[2 * e] = bf16_lo(kqv.a[e]); kf[2 * e + 1] = bf16_hi(kqv.a[e]);
+                vf[2 * e] = bf16_lo(vqv.a[e]); vf[2 * e + 1] = bf16_hi(vqv.a[e]);
+            }
+        }
+        if (t == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[e] = knew[dimbase + e]; vf[e] = vnew[dimbase + e]; }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += qr[e] * kf[e];
+        s = row16_sum(s);
+        if (LPR == 32) s += __shfl_xor(s, 16);
+        if (t < L) {
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn);
+            const float p = expf(s - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + p * vf[e];
+            m = mn;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) consume(kq[u], vq[u], tt[u]);
+    for (int j = PF; CT * (split + NS * j) < L; j += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            tt[u] = CT * (split + NS * (j + u)) + tok_in_chunk;
+            if (CT * (split + NS * (j + u)) < L) {            // block-uniform
+                const size_t off = kv_off(tt[u]);
+                kq[u] = ld_kv(a.kpool, off);
+                vq[u] = ld_kv(a.vpool, off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (CT * (split + NS * (j + u)) < L) consume(kq[u], vq[u], tt[u]);
+    }
+
+    // ---- merge the CT row streams of this block ----
+    const int slot = wave * RPW + r;
+    if (sub == 0) { red_m[slot] = m; red_l[slot] = l; }
+    *(f32x4*)&red_o[slot][dimbase] = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)&red_o[slot][dimbase + 4] = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+    __syncthreads();
+    const int d = tid % D, part = tid / D;
+    float M = -INFINITY;
+#pragma unroll 8
+    for (int i = 0; i < CT; ++i) M = fmaxf(M, red_m[i]);
+    float O = 0.f, Ls = 0.f;
+    if (M > -INFINITY) {
+        constexpr int PER = CT / NP;
+#pragma unroll
+        for (int i = part * PER; i < (part + 1) * PER; ++i) {
+            const float w = expf(red_m[i] - M);
+            O += w * red_o[i][d];
+            Ls += w * red_l[i];
+        }
+    }
+    red2[part][d] = O;
+    if (d == 0) red2l[part] = Ls;
+    __syncthreads();
+    if (part == 0) {
+        float Ot = 0.f, Lt = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { Ot += red2[p][d]; Lt += red2l[p]; }
+        const size_t ph = ((size_t)bq * a.Hkv * nrep + (size_t)head) * NS + split;
+        a.part_o[ph * D + d] = Ot;
+        if (d == 0) { a.part_ml[ph * 2] = M; a.part_ml[ph * 2 + 1] = Lt; }
+    }
+}
+
+bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, bool kv_f32, int n_seq, hipStream_t s) {
+    dim3 grid(ns, a.Hkv * nrep, n_seq), block(1024);
+    if (D == 128) {
+        if (kv_f32) hipLaunchKernelGGL((attn_decode_head_kernel<128, true>), grid, block, 0, s, a, nrep);
+        else hipLaunchKernelGGL((attn_decode_head_kernel<128, false>), grid, block, 0, s, a, nrep);
+    } else if (D == 256) {
+        if (kv_f32) hipLaunchKernelGGL((attn_decode_head_kernel<256, true>), grid, block, 0, s, a, nrep);
+        else hipLaunchKernelGGL((attn_decode_head_kernel<256, false>), grid, block, 0, s, a, nrep);
+    } else {
+        return false;
+    }
+    return true;
+}
+
 template <int D>
 static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, int n_seq, hipStream_t s) {
     dim3 grid(nsplit, a.Hkv, n_seq), block(256);

@@ -98,20 +98,47 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
         const int c = k >> 9, j = k & 511;
         ((f32x4*)xs)[c * 128 + ((j >> 2) & 1) * 64 + (j >> 3)] = v;
     };
+    // PRO_ATTNCOMB: x is not materialised -- it is the merge of the NS per-head partials left by
+    // attn_decode_head_kernel: x[h*D + d] = sum_s e^{m_s - M} o_s[d] / sum_s e^{m_s - M} l_s  (* sigmoid(gate))
+    auto xload = [&](int k4i) -> f32x4 {
+        if (PRO != PRO_ATTNCOMB) return *(const f32x4*)(a.x + (k4i << 2));
+        const int k = k4i << 2, h = k >> a.dshift, d = k & ((1 << a.dshift) - 1);
+        const float* ml = a.part_ml + (size_t)h * a.ns * 2;
+        const float* po = a.x + ((size_t)h * a.ns << a.dshift) + d;
+        float M = -INFINITY;
+        for (int s2 = 0; s2 < a.ns; ++s2) M = fmaxf(M, ml[2 * s2]);
+        float Ls = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < a.ns; ++s2) {
+            const float mm = ml[2 * s2];
+            const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
+            Ls += w * ml[2 * s2 + 1];
+            const f32x4 p = *(const f32x4*)(po + ((size_t)s2 << a.dshift));
+            o[0] += w * p[0]; o[1] += w * p[1]; o[2] += w * p[2]; o[3] += w * p[3];
+        }
+        const float inv = 1.0f / Ls;
+        o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+        if (a.gate != nullptr) {
+            const f32x4 g = *(const f32x4*)(a.gate + k);
+            o[0] *= 1.0f / (1.0f + expf(-g[0])); o[1] *= 1.0f / (1.0f + expf(-g[1]));
+            o[2] *= 1.0f / (1.0f + expf(-g[2])); o[3] *= 1.0f / (1.0f + expf(-g[3]));
+        }
+        return o;
+    };
     const int n4 = K >> 2;                       // K % 8 == 0
     int k4 = tid;
     for (; k4 + 768 < n4; k4 += 1024) {          // 4 independent loads in flight per thread
         f32x4 v[4]; f32x4 w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = *(const f32x4*)(a.x + ((k4 + i * 256) << 2));
+            v[i] = xload(k4 + i * 256);
             if (PRO == PRO_RMSNORM) w[i] = *(const f32x4*)(a.nw + ((k4 + i * 256) << 2));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) stage_one(k4 + i * 256, v[i], w[i]);
     }
     for (; k4 < n4; k4 += 256) {
-        f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
+        f32x4 v = xload(k4);
         f32x4 w = {0.f, 0.f, 0.f, 0.f};
         if (PRO == PRO_RMSNORM) w = *(const f32x4*)(a.nw + (k4 << 2));
         stage_one(k4, v, w);
@@ -306,6 +333,11 @@ int gemv_grid(int N, int K, int num_cu) {
 }
 
 void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s) {
+    if (pro == PRO_ATTNCOMB) {          // only o_proj uses it (row-parallel under TP: store, else residual add)
+        if (epi == EPI_STORE) launch_gemv_t<PRO_ATTNCOMB, EPI_STORE>(a, grid, s);
+        else launch_gemv_t<PRO_ATTNCOMB, EPI_RESADD>(a, grid, s);
+        return;
+    }
     if (pro == PRO_PLAIN) {
         if (epi == EPI_STORE) launch_gemv_t<PRO_PLAIN, EPI_STORE>(a, grid, s);
         else if (epi == EPI_RESADD) launch_gemv_t<PRO_PLAIN, EPI_RESADD>(a, grid, s);

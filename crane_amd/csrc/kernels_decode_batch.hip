@@ -44,6 +44,28 @@ __global__ __launch_bounds__(512, 2) void gemvb_kernel(GemvBArgs a) {
             const int m = e / (tk / 4), k4 = e % (tk / 4), k = k4 << 2;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < tile) {
+                if (PRO == PRO_ATTNCOMB) {            // merge the per-head partials of attn_decode_head_kernel
+                    const int kk = k0 + k, h = kk >> a.dshift, d = kk & ((1 << a.dshift) - 1);
+                    const float* ml = a.part_ml + ((size_t)m * (a.K >> a.dshift) + h) * a.ns * 2;
+                    const float* po = a.x + (size_t)m * a.ldx + ((size_t)h * a.ns << a.dshift) + d;
+                    float M = -INFINITY;
+                    for (int s2 = 0; s2 < a.ns; ++s2) M = fmaxf(M, ml[2 * s2]);
+                    float Ls = 0.f;
+                    for (int s2 = 0; s2 < a.ns; ++s2) {
+                        const float mm = ml[2 * s2];
+                        const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
+                        Ls += w * ml[2 * s2 + 1];
+                        const f32x4 p = *(const f32x4*)(po + ((size_t)s2 << a.dshift));
+                        v[0] += w * p[0]; v[1] += w * p[1]; v[2] += w * p[2]; v[3] += w * p[3];
+                    }
+                    const float inv = 1.0f / Ls;
+                    v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+                    if (a.gate != nullptr) {
+                        const f32x4 g = *(const f32x4*)(a.gate + (size_t)m * a.gate_stride + kk);
+                        v[0] *= 1.0f / (1.0f + expf(-g[0])); v[1] *= 1.0f / (1.0f + expf(-g[1]));
+                        v[2] *= 1.0f / (1.0f + expf(-g[2])); v[3] *= 1.0f / (1.0f + expf(-g[3]));
+                    }
+                } else
                 v = *(const f32x4*)(a.x + (size_t)m * a.ldx + k0 + k);
                 if (PRO == PRO_RMSNORM) {
                     if (count) {
@@ -211,6 +233,11 @@ static void launch_gemvb_t(const GemvBArgs& a, int grid, hipStream_t s) {
 }
 
 void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s) {
+    if (pro == PRO_ATTNCOMB) {
+        if (epi == EPI_STORE) launch_gemvb_t<PRO_ATTNCOMB, EPI_STORE>(a, grid, s);
+        else launch_gemvb_t<PRO_ATTNCOMB, EPI_RESADD>(a, grid, s);
+        return;
+    }
     if (pro == PRO_PLAIN) {
         if (epi == EPI_STORE) launch_gemvb_t<PRO_PLAIN, EPI_STORE>(a, grid, s);
         else if (epi == EPI_RESADD) launch_gemvb_t<PRO_PLAIN, EPI_RESADD>(a, grid, s);

@@ -29,8 +29,10 @@ template uint32_t* Model::dalloc<uint32_t>(size_t, bool);
 
 Model::~Model() {
     if (stream) (void)hipStreamSynchronize(stream);
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
+    for (int v = 0; v < 2; ++v) {
+        if (graph_exec[v]) (void)hipGraphExecDestroy(graph_exec[v]);
+        if (graph[v]) (void)hipGraphDestroy(graph[v]);
+    }
     rccl.reset();
     for (void* p : allocs) (void)hipFree(p);
     if (h_bt) (void)hipHostFree(h_bt);
@@ -194,6 +196,8 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
                                   : (int64_t)max_seqs * max_pages_per_seq;
     if (n_pages < max_pages_per_seq) n_pages = max_pages_per_seq;
     nsplit = std::max(1, std::min(64, num_cu / std::max(1, Hkv_l)));
+    if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
+    if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     use_graph = opts.use_graph >= 0;
     if (opts.kv_dtype != CM_KV_BF16 && opts.kv_dtype != CM_KV_F32) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
     kv_f32 = opts.kv_dtype == CM_KV_F32;
@@ -458,14 +462,19 @@ void Model::enqueue_decode_step(bool advance) {
         a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr;
         a.rot_dim = cfg.rot_dim;
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-        if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        const bool heads = attn_variant == 1;      // short context: per-head blocks, merge fused into o_proj's prologue
+        if (heads) {
+            if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
+        } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
-        if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+        const int opro = heads ? PRO_ATTNCOMB : PRO_PLAIN;
+        if (heads) { g.x = part_o; g.part_ml = part_ml; g.gate = a.gate; g.ns = attn_ns; g.dshift = D == 128 ? 7 : 8; }
+        if (!rccl) { g.y = x; g.res = x; launch_gemv(opro, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
         else {
             g.y = y; g.res = x;
-            launch_gemv(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+            launch_gemv(opro, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
             rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
         }
         }   // full-attention layer
@@ -635,22 +644,25 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
     }
 }
 
-void Model::run_decode_step(bool advance) {
+void Model::run_decode_step(bool advance, int64_t ctx_len) {
     (void)advance;   // the device state always advances; hosts that drive positions overwrite it
     ++ring_count;    // host mirror of st->pad (ring write index)
+    // attention variant by context length (host-known): one captured graph per variant
+    attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
+    const int v = attn_variant;
     if (use_graph && !rccl) {
-        if (!graph_ok && graph == nullptr) {
+        if (!graph_ok[v] && graph[v] == nullptr) {
             hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {
                 bool threw = false;
                 try { enqueue_decode_step(true); } catch (...) { threw = true; }
-                e = hipStreamEndCapture(stream, &graph);
-                if (!threw && e == hipSuccess && graph) e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
-                graph_ok = !threw && e == hipSuccess && graph_exec != nullptr;
+                e = hipStreamEndCapture(stream, &graph[v]);
+                if (!threw && e == hipSuccess && graph[v]) e = hipGraphInstantiate(&graph_exec[v], graph[v], nullptr, nullptr, 0);
+                graph_ok[v] = !threw && e == hipSuccess && graph_exec[v] != nullptr;
             }
-            if (!graph_ok) { use_graph = false; (void)hipGetLastError(); }
+            if (!graph_ok[v]) { use_graph = false; (void)hipGetLastError(); }
         }
-        if (graph_ok) { CM_HIP(hipGraphLaunch(graph_exec, stream)); return; }
+        if (graph_ok[v]) { CM_HIP(hipGraphLaunch(graph_exec[v], stream)); return; }
     }
     enqueue_decode_step(true);
 }
@@ -701,6 +713,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     for (size_t g0 = 0; g0 < n; g0 += MAXB) {
         const int nb = (int)std::min<size_t>(MAXB, n - g0);
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
+        int64_t longest = 0;
+        for (int b = 0; b < nb; ++b) longest = std::max(longest, seq(sq[g0 + b]).len + 1);
+        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max;
         for (int b = 0; b < nb; ++b) {
             const int sidx = sq[g0 + b];
             Seq& q = seq(sidx);
@@ -743,8 +758,17 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 a.gate = cfg.hybrid ? qkvb + (size_t)Hq_l * D : nullptr;
                 a.qkv_stride = ldq; a.bt_stride = max_pages_per_seq; a.rot_dim = cfg.rot_dim;
                 a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+                if (heads_b) {
+                    if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
+                    GemvBArgs g{};
+                    g.W = w.o; g.x = part_ob; g.y = xb; g.res = xb; g.N = H; g.K = Hq_l * D; g.ldw = g.K; g.ldx = Hq_l * attn_ns * D; g.ldy = H;
+                    g.n_seq = nb; g.eps = cfg.eps; g.part_ml = part_mlb; g.gate = a.gate; g.gate_stride = ldq; g.ns = attn_ns;
+                    g.dshift = D == 128 ? 7 : 8;
+                    launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
+                } else {
                 if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
+                }
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
             gb(PRO_PLAIN, EPI_RESADD, w.down, hbb, I_l, nullptr, xb, H, H, I_l);
@@ -791,7 +815,7 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     } else {
         for (size_t i = 0; i < n; ++i) {     // token-serial path (also the parity cross-check of prefill)
             launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, q.rope_delta, stream);
-            run_decode_step(true);
+            run_decode_step(true, (int64_t)(start_pos + i + 1));
         }
     }
     q.len = (int64_t)(start_pos + n);
@@ -873,7 +897,7 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
             activate(0);
             launch_set_state(st, out[n - 1], (int32_t)q.len, 0, q.rope_delta, stream);
             const uint32_t ring0 = ring_count;
-            for (size_t i = 0; i < want; ++i) run_decode_step(true);
+            for (size_t i = 0; i < want; ++i) run_decode_step(true, q.len + (int64_t)i + 1);
             CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CM_HIP(hipStreamSynchronize(stream));
             size_t used = 0;
@@ -895,7 +919,7 @@ void Model::bench_decode(uint32_t first, size_t k, uint32_t* toks, float* ms) {
     CM_HIP(hipEventCreate(&e0));
     CM_HIP(hipEventCreate(&e1));
     CM_HIP(hipEventRecord(e0, stream));
-    for (size_t i = 0; i < k; ++i) run_decode_step(true);
+    for (size_t i = 0; i < k; ++i) run_decode_step(true, q.len + (int64_t)i + 1);
     CM_HIP(hipEventRecord(e1, stream));
     CM_HIP(hipEventSynchronize(e1));
     float t = 0.f;

@@ -224,9 +224,13 @@ struct Model {
     uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false, float* dev_logits = nullptr);
     bool logits_gathered = false;
 
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_ok = false;
+    hipGraph_t graph[2] = {nullptr, nullptr};          // one captured decode step per attention variant
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    bool graph_ok[2] = {false, false};
+    int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj
+    int attn_ns = 2;               // token splits per head of variant 1
+    int64_t attn_heads_max = 0;    // contexts up to this many tokens use variant 1 (CM_ATTN_HEADS_MAX; 0 = never: measured
+                                   // slower on MI355X at every context tried)
     bool use_graph = true;
 
     std::unique_ptr<Rccl> rccl;
@@ -258,7 +262,7 @@ struct Model {
     void enqueue_lm_head(bool advance);         // final norm + lm_head + arg-max on x
     void ensure_prefill_buffers();
     void prefill(const uint32_t* ids, size_t n, size_t start_pos);   // active sequence, pages ensured
-    void run_decode_step(bool advance);         // graph replay or eager
+    void run_decode_step(bool advance, int64_t ctx_len);   // graph replay or eager; ctx_len = tokens attended (pos + 1)
     void forward(int s, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out, uint32_t* greedy_out);
     void generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_config* g, uint32_t* out, size_t* n_out,
                   cm_token_cb cb, void* user);

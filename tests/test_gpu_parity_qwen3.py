@@ -163,7 +163,9 @@ def test_error_behaviour(pair):
     with pytest.raises(CraneError):
         Model.synthetic(dict(cfg, model_type="llama"))
     with pytest.raises(CraneError):
-        m.generate([1, 2], GenerationConfig.with_max_tokens(4))   # sampling not implemented -> loud error
+        m.generate([1, 2], GenerationConfig.with_max_tokens(10 ** 6))   # prompt + max_new_tokens > max_seq_len
+    out = m.generate([1, 2], GenerationConfig.with_max_tokens(4))       # default config samples (temperature 0.67)
+    assert len(out) == 6 and out[:2] == [1, 2]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -296,3 +298,47 @@ def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
     finally:
         if nseq > 3:
             m.close()
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3-untied", "tiny-qwen3.5"])
+@pytest.mark.parametrize("heads_max,ns", [(0, 2), (4096, 1), (4096, 2), (4096, 4), (150, 2)])
+def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
+    """The two decode-attention formulations (split-KV + combine launch; per-head blocks with the merge fused into
+    o_proj's prologue) and the switch between them at a context threshold must all reproduce the oracle -- single
+    sequence (graph per variant) and batched, over a context that spans several pages."""
+    monkeypatch.setenv("CM_ATTN_HEADS_MAX", str(heads_max))
+    monkeypatch.setenv("CM_ATTN_NS", str(ns))
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    if name == "tiny-qwen3.5":
+        from oracle import qwen3_5_oracle as O5
+        o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), w)
+        o2 = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), w)
+    else:
+        o = Qwen3Oracle(Qwen3Config.from_json(cfg), w)
+        o2 = Qwen3Oracle(Qwen3Config.from_json(cfg), w)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype="f32")
+    try:
+        V = cfg["vocab_size"]
+        ids = configs.synthetic_prompt(140, V)
+        ref = o.forward(ids, 0)
+        assert rel(m.forward_step(ids, 0).reshape(-1), ref) < 1e-4
+        tok = int(ref.argmax())
+        for step in range(14):                                   # crosses 150 tokens of context
+            ref = o.forward([tok], 140 + step)
+            got = m.forward_step([tok], 140 + step).reshape(-1)
+            assert rel(got, ref) < 1e-4, step
+            tok = int(ref.argmax())
+        # batched: the same context in two extra sequences, one of them shorter
+        s1, s2 = m.seq_alloc(), m.seq_alloc()
+        m.seq_forward(s1, ids, 0, want_logits=False)
+        m.seq_forward(s2, ids[:33], 0, want_logits=False)
+        o.forward(ids, 0); o2.forward(ids[:33], 0)
+        t1, t2 = 5, 9
+        for step in range(12):
+            lg, _ = m.step_batch_decode([s1, s2], [t1, t2])
+            r1, r2 = o.forward([t1], 140 + step), o2.forward([t2], 33 + step)
+            assert rel(lg[0].reshape(-1), r1) < 1e-4 and rel(lg[1].reshape(-1), r2) < 1e-4, step
+            t1, t2 = int(r1.argmax()), int(r2.argmax())
+    finally:
+        m.close()
