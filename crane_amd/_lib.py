@@ -34,7 +34,7 @@ class CmOpts(C.Structure):
         ("tp_size", C.c_int32), ("tp_unique_id", C.c_void_p), ("max_seq_len", C.c_uint32),
         ("max_seqs", C.c_uint32), ("kv_block_size", C.c_uint32), ("kv_pool_tokens", C.c_uint64),
         ("kv_dtype", C.c_int32), ("use_graph", C.c_int32), ("prefill_chunk", C.c_uint32),
-        ("prefill_split", C.c_int32), ("reserved", C.c_uint32 * 8),
+        ("prefill_split", C.c_int32), ("isq", C.c_uint32), ("reserved", C.c_uint32 * 7),
     ]
 
 

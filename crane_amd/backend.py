@@ -94,7 +94,7 @@ class Model:
     @staticmethod
     def _opts(device=0, max_seq_len=0, max_seqs=0, kv_block_size=0, kv_pool_tokens=0, use_graph=0,
               tp_rank=0, tp_size=1, tp_unique_id: Optional[bytes] = None, prefill_chunk=0, prefill_split=0,
-              kv_dtype="bf16"):
+              kv_dtype="bf16", isq: Optional[str] = None):
         o = _lib.CmOpts()
         o.abi_version = _lib.CM_ABI_VERSION
         o.device, o.tp_rank, o.tp_size = device, tp_rank, tp_size
@@ -102,6 +102,7 @@ class Model:
         o.kv_pool_tokens, o.use_graph = kv_pool_tokens, use_graph
         o.prefill_chunk, o.prefill_split = prefill_chunk, prefill_split
         o.kv_dtype = {"bf16": 0, "f32": 1}[kv_dtype]
+        o.isq = {None: 0, "none": 0, "q8_0": 8}[isq.lower() if isinstance(isq, str) else isq]     # --quant / CRANE_ISQ
         keep = None
         if tp_unique_id is not None:
             keep = C.create_string_buffer(bytes(tp_unique_id), 128)

@@ -34,6 +34,23 @@ static int guard(cm_model* h, F&& f) {
     }
 }
 
+// cm_opts.isq, else CRANE_ISQ (qwen3_5/model.rs:615-626 isq_from_env): only q8_0 is offered -- the K-quant
+// quantisers of ggml (make_qkx2_quants search) are not restated, see oracle/gguf_oracle.py
+static void apply_isq(cm::Model& m) {
+    uint32_t isq = m.opts.isq;
+    if (isq == 0) {
+        if (const char* e = getenv("CRANE_ISQ")) {
+            std::string v(e);
+            for (char& c : v) c = (char)tolower((unsigned char)c);
+            if (v == "q8_0") isq = CM_ISQ_Q8_0;
+            else if (!v.empty()) throw CmError(CM_ERR_UNSUPPORTED, "CRANE_ISQ='" + v + "': only q8_0 is implemented");
+        }
+    }
+    if (isq == 0) return;
+    if (isq != CM_ISQ_Q8_0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.isq: only CM_ISQ_Q8_0 is implemented");
+    m.isq_q8_0();
+}
+
 extern "C" {
 
 int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out) {
@@ -41,12 +58,16 @@ int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out) {
     *out = nullptr;
     cm_model* h = nullptr;
     int rc = guard(nullptr, [&] {
+        const std::string path(model_dir);
+        const bool gguf = path.size() > 5 && path.compare(path.size() - 5, 5, ".gguf") == 0;   // ModelFormat::Auto (qwen3/model.rs:55-71)
         std::string cfg;
-        try { cfg = cmst::read_text(std::string(model_dir) + "/config.json"); }
+        try { cfg = gguf ? cm::gguf_config_json(path) : cmst::read_text(path + "/config.json"); }
+        catch (const CmError&) { throw; }
         catch (const std::exception& e) { throw CmError(CM_ERR_IO, e.what()); }
         h = new cm_model();
         h->m.init_common(cfg, opts);
-        cm::load_from_dir(h->m, model_dir);
+        if (gguf) cm::load_from_gguf(h->m, path);
+        else { cm::load_from_dir(h->m, path); apply_isq(h->m); }
         h->m.alloc_runtime();
     });
     if (rc != CM_OK) { delete h; return rc; }
@@ -62,6 +83,7 @@ int cm_create_synthetic(const char* config_json, uint64_t seed, const cm_opts* o
         h = new cm_model();
         h->m.init_common(config_json, opts);
         cm::load_synthetic(h->m, seed);
+        apply_isq(h->m);
         h->m.alloc_runtime();
     });
     if (rc != CM_OK) { delete h; return rc; }

@@ -168,6 +168,36 @@ void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncol
 void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s);
 
+// ---- quantised weights (kernels_quant.hip) ----
+enum { QFMT_NONE = 0, QFMT_Q8_0 = 8, QFMT_Q4_K = 12, QFMT_Q6_K = 14 };    // ggml type ids
+struct QWeight {
+    int fmt = QFMT_NONE;
+    int N = 0, K = 0;
+    const uint8_t* p0 = nullptr;   // Q8_0 codes | Q4_K qs | Q6_K ql
+    const uint8_t* p1 = nullptr;   // Q8_0 d     | Q4_K hdr | Q6_K qh
+    const uint8_t* p2 = nullptr;   //                        Q6_K scales
+    const uint8_t* p3 = nullptr;   //                        Q6_K d
+    QWeight rows(int row0, int n) const;      // a view of rows [row0, row0 + n)
+    uint64_t bytes() const;
+};
+struct GemvQArgs {
+    QWeight w;
+    const float* x;        // [K] f32
+    const float* nw;       // RMSNorm weight (PRO_RMSNORM)
+    float* y;
+    const float* res;
+    float* pmax;
+    int* pidx;
+    int idx_base;
+    float eps;
+};
+int gemvq_grid(int N, int num_cu);
+bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s);
+void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s);
+void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s);
+void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s);
+void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s);
+
 // sampler (kernels_sample.hip)
 int topk_pad(int k);
 int topk_blocks(int n);

@@ -1,0 +1,393 @@
+// Quantised-weight decode kernels: GEMV over ggml Q8_0 / Q4_K / Q6_K weights, the quantised
+// embedding-row gather, and the in-situ Q8_0 quantiser.
+//
+// Replaces LinearLayer::Quantized(QMatMul) (crane-core/src/ops/linear.rs:18-51: "dequantizes weights to F32 and
+// requires F32 input") and EmbeddingLayer::Quantized (modules/embedding.rs:31-98): y[n] = sum_k dequant(W)[n,k] * x[k]
+// with f32 activations and f32 accumulation -- the weights are decoded in registers on the way from HBM and never
+// materialised.  Block arithmetic follows ggml's dequantize_row_{q8_0,q4_K,q6_K} (restated in oracle/gguf_oracle.py).
+//
+// HBM layouts (repacked once at load from the GGUF byte stream; pure permutations, no re-quantisation):
+//   Q8_0 : codes i8 [N][K]                       | d f16 [N][K/32]
+//   Q4_K : qs u8 [N][K/2] (128 B per 256-block, native nibble order) | hdr [N][K/256][16 B] = {f16 d, f16 dmin, u8 scales[12]}
+//   Q6_K : ql u8 [N][K/2] | qh u8 [N][K/4] | sc i8 [N][K/16] | d f16 [N][K/256]
+// so every stream a wave reads is contiguous and 16-byte aligned (the GGUF blocks are 34 / 144 / 210 bytes).
+//
+// Work split: a wave owns R = 2 rows and sweeps K in chunks of CK elements (1024 for Q8_0: 16 codes = 16 B per
+// lane; 2048 for the K-quants: 8 lanes per 256-block, 32 weights per lane).  x lives in LDS as f32, permuted per
+// format so that the NJ float4 a lane needs per chunk are at [chunk][j][lane] (conflict-free ds_read_b128).
+// Same fused prologue (RMSNorm) and epilogues (store / residual add / SiLU*mul / arg-max) as the bf16 GEMV.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {
+    _Float16 v;
+    const uint16_t b = (uint16_t)h;
+    __builtin_memcpy(&v, &b, 2);
+    return (float)v;
+}
+__device__ __forceinline__ float sb(uint32_t w, int n) { return (float)(int)(signed char)((w >> (8 * n)) & 0xFFu); }
+__device__ __forceinline__ float ub(uint32_t w, int n) { return (float)((w >> (8 * n)) & 0xFFu); }
+
+template <int FMT> struct QF;
+template <> struct QF<QFMT_Q8_0> { static constexpr int CK = 1024, NJ = 4, SH = 8; };
+template <> struct QF<QFMT_Q4_K> { static constexpr int CK = 2048, NJ = 8, SH = 9; };
+template <> struct QF<QFMT_Q6_K> { static constexpr int CK = 2048, NJ = 8, SH = 9; };
+
+// LDS float4 slot of x[4*k4 .. 4*k4+3]
+template <int FMT>
+__device__ __forceinline__ int x_slot(int k4) {
+    if (FMT == QFMT_Q8_0) {
+        const int c = k4 >> 8, r = k4 & 255;
+        return c * 256 + (r & 3) * 64 + (r >> 2);
+    } else if (FMT == QFMT_Q4_K) {
+        const int c = k4 >> 9, r = k4 & 511, b = r >> 6, e4 = r & 63, p = e4 >> 4, f4 = e4 & 15;
+        const int hi = f4 >> 3, g4 = f4 & 7, half = g4 >> 2, q = g4 & 3;
+        return c * 512 + (hi * 4 + q) * 64 + (b * 8 + p * 2 + half);
+    } else {
+        const int c = k4 >> 9, r = k4 & 511, b = r >> 6, e4 = r & 63, n = e4 >> 5, f4 = e4 & 31;
+        const int t = f4 >> 3, g4 = f4 & 7, j = g4 >> 1, q = g4 & 1;
+        return c * 512 + (t * 2 + q) * 64 + (b * 8 + n * 4 + j);
+    }
+}
+
+struct QRow {                 // the bytes one lane needs for one (row, chunk)
+    u32x4 a;                  // Q8_0: 16 codes | Q4_K: 16 B of qs | Q6_K: {ql[l], ql[l+32]} 8 B each
+    u32x4 b;                  // Q4_K: block header | Q6_K: {qh 8 B, scales 4 B, d 2 B}
+    float d;                  // Q8_0: block scale
+};
+
+template <int FMT>
+__device__ __forceinline__ QRow q_load(const QWeight& w, int row, int c, int lane) {
+    QRow r;
+    r.d = 0.f;
+    const size_t K = (size_t)w.K;
+    if (FMT == QFMT_Q8_0) {
+        const size_t k = (size_t)c * 1024 + (size_t)lane * 16;
+        r.a = ld_nt16(w.p0 + (size_t)row * K + k);
+        r.b = (u32x4){0, 0, 0, 0};
+        r.d = f16_bits_to_f32(*(const uint16_t*)(w.p1 + ((size_t)row * (K >> 5) + (k >> 5)) * 2));
+    } else if (FMT == QFMT_Q4_K) {
+        const size_t blk = (size_t)row * (K >> 8) + (size_t)c * 8 + (lane >> 3);
+        const int h = lane & 7;
+        r.a = ld_nt16(w.p0 + blk * 128 + (h >> 1) * 32 + (h & 1) * 16);
+        r.b = ld16(w.p1 + blk * 16);
+    } else {
+        const size_t blk = (size_t)row * (K >> 8) + (size_t)c * 8 + (lane >> 3);
+        const int n = (lane >> 2) & 1, j = lane & 3;
+        const u32x2 q0 = *(const u32x2*)(w.p0 + blk * 128 + n * 64 + j * 8);
+        const u32x2 q1 = *(const u32x2*)(w.p0 + blk * 128 + n * 64 + 32 + j * 8);
+        const u32x2 qh = *(const u32x2*)(w.p1 + blk * 64 + n * 32 + j * 8);
+        r.a = (u32x4){q0[0], q0[1], q1[0], q1[1]};
+        const uint8_t* sc = w.p2 + blk * 16 + n * 8 + (j >> 1);
+        const uint32_t s4 = (uint32_t)sc[0] | ((uint32_t)sc[2] << 8) | ((uint32_t)sc[4] << 16) | ((uint32_t)sc[6] << 24);
+        r.b = (u32x4){qh[0], qh[1], s4, (uint32_t)*(const uint16_t*)(w.p3 + blk * 2)};
+    }
+    return r;
+}
+
+// sum over this lane's weights of dequant(w) * x ; xs = the lane's NJ float4, sx = per-run sums of x
+template <int FMT>
+__device__ __forceinline__ float q_dot(const QRow& r, const f32x4* xv, const float* sx, int lane) {
+    if (FMT == QFMT_Q8_0) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            s += sb(r.a[j], 0) * xv[j][0] + sb(r.a[j], 1) * xv[j][1] + sb(r.a[j], 2) * xv[j][2] + sb(r.a[j], 3) * xv[j][3];
+        return r.d * s;
+    } else if (FMT == QFMT_Q4_K) {
+        const float d = f16_bits_to_f32(r.b[0] & 0xFFFFu), dmin = f16_bits_to_f32(r.b[0] >> 16);
+        // scales[12] = bytes 4..15 of the header; get_scale_min_k4 for sub-blocks 2p (low nibbles), 2p+1 (high)
+        const int p = (lane & 7) >> 1;
+        auto sbyte = [&](int i) -> uint32_t { const int bi = 4 + i; return (r.b[bi >> 2] >> (8 * (bi & 3))) & 0xFFu; };
+        auto scale_min = [&](int j, float& sc, float& mn) {
+            if (j < 4) { sc = (float)(sbyte(j) & 63u); mn = (float)(sbyte(j + 4) & 63u); }
+            else {
+                sc = (float)((sbyte(j + 4) & 0xFu) | ((sbyte(j - 4) >> 6) << 4));
+                mn = (float)((sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4));
+            }
+        };
+        float sc0, m0, sc1, m1;
+        scale_min(2 * p, sc0, m0);
+        scale_min(2 * p + 1, sc1, m1);
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t wl = r.a[j] & 0x0F0F0F0Fu, wh = (r.a[j] >> 4) & 0x0F0F0F0Fu;
+            lo += ub(wl, 0) * xv[j][0] + ub(wl, 1) * xv[j][1] + ub(wl, 2) * xv[j][2] + ub(wl, 3) * xv[j][3];
+            hi += ub(wh, 0) * xv[4 + j][0] + ub(wh, 1) * xv[4 + j][1] + ub(wh, 2) * xv[4 + j][2] + ub(wh, 3) * xv[4 + j][3];
+        }
+        return (d * sc0) * lo - (dmin * m0) * sx[0] + (d * sc1) * hi - (dmin * m1) * sx[1];
+    } else {
+        const float d = f16_bits_to_f32(r.b[3]);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // run t: weights 128n + 32t + 8j + i ; low 4 bits from ql (t<2: low nibble, t>=2: high nibble of ql[l] / ql[l+32])
+            const int qsel = (t & 1) * 2;                  // t odd -> ql[l + 32] words (a[2], a[3])
+            const int hshift = 2 * t;
+            float s = 0.f;
+#pragma unroll
+            for (int wi = 0; wi < 2; ++wi) {
+                const uint32_t qlw = r.a[qsel + wi], qhw = r.b[wi];
+                const uint32_t lo4 = (t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu;
+                const uint32_t hi2 = ((qhw >> hshift) & 0x03030303u) << 4;
+                const uint32_t q = lo4 | hi2;
+                const f32x4 x = xv[t * 2 + wi];
+                s += ub(q, 0) * x[0] + ub(q, 1) * x[1] + ub(q, 2) * x[2] + ub(q, 3) * x[3];
+            }
+            const float sc = sb(r.b[2], t);
+            acc += (d * sc) * (s - 32.0f * sx[t]);
+        }
+        return acc;
+    }
+}
+
+template <int FMT, int PRO, int EPI>
+__global__ __launch_bounds__(256, 4) void gemvq_kernel(GemvQArgs a) {
+    using F = QF<FMT>;
+    constexpr int R = 2, NJ = F::NJ, CK = F::CK;
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.w.K, N = a.w.N;
+    const int nch = (K + CK - 1) / CK;
+    float* red = xs + (size_t)nch * CK;
+
+    // ---- stage x into LDS (format permutation), fused RMSNorm statistics ----
+    float ss = 0.f;
+    const int n4 = K >> 2;
+    for (int k4 = tid; k4 < n4; k4 += 256) {
+        f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
+        if (PRO == PRO_RMSNORM) {
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            const f32x4 w = *(const f32x4*)(a.nw + (k4 << 2));
+            v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
+        }
+        ((f32x4*)xs)[x_slot<FMT>(k4)] = v;
+    }
+    float scale = 1.f;
+    if (PRO == PRO_RMSNORM) {
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+    }
+    __syncthreads();
+    if (PRO == PRO_RMSNORM) scale = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + a.eps);
+
+    // lanes past the end of K in the last chunk stay idle (K % 32 == 0 for Q8_0, K % 256 == 0 for the K-quants)
+    const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    const int G = (N + R - 1) / R;
+    for (int g = blockIdx.x * 4 + wave; g < G; g += gridDim.x * 4) {
+        const int r0 = g * R;
+        float acc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            if (c * CK + lane_k >= K) continue;
+            QRow q[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) q[i] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c, lane);
+            f32x4 xv[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xv[j] = ((const f32x4*)xs)[c * (CK / 4) + j * 64 + lane];
+            float sx[4] = {0.f, 0.f, 0.f, 0.f};
+            if (FMT == QFMT_Q4_K) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sx[0] += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+                    sx[1] += (xv[4 + j][0] + xv[4 + j][1]) + (xv[4 + j][2] + xv[4 + j][3]);
+                }
+            } else if (FMT == QFMT_Q6_K) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    sx[t] = ((xv[2 * t][0] + xv[2 * t][1]) + (xv[2 * t][2] + xv[2 * t][3])) +
+                            ((xv[2 * t + 1][0] + xv[2 * t + 1][1]) + (xv[2 * t + 1][2] + xv[2 * t + 1][3]));
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i] += q_dot<FMT>(q[i], xv, sx, lane);
+        }
+        float mine = 0.f, mine_up = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            acc[i] = wave_sum(acc[i]) * scale;
+            if (EPI != EPI_SILUMUL && lane == i) mine = acc[i];
+            if (EPI == EPI_SILUMUL && (i & 1) && lane == (i >> 1)) { mine = acc[i - 1]; mine_up = acc[i]; }
+        }
+        if (EPI == EPI_STORE) {
+            if (lane < R && r0 + lane < N) a.y[r0 + lane] = mine;
+        } else if (EPI == EPI_RESADD) {
+            if (lane < R && r0 + lane < N) a.y[r0 + lane] = a.res[r0 + lane] + mine;
+        } else if (EPI == EPI_SILUMUL) {
+            if (lane < R / 2 && r0 + 2 * lane + 1 < N) a.y[(r0 >> 1) + lane] = (mine / (1.0f + expf(-mine))) * mine_up;
+        } else if (EPI == EPI_ARGMAX) {
+            if (lane < R && r0 + lane < N) a.y[r0 + lane] = mine;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int ix = r0 + i + a.idx_base;
+                if (r0 + i < N && (acc[i] > best || (acc[i] == best && ix < besti))) { best = acc[i]; besti = ix; }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        __syncthreads();
+        int* redi = (int*)(red + 4);
+        if (lane == 0) { red[wave] = best; redi[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            float bb = red[0]; int bbi = redi[0];
+            for (int w = 1; w < 4; ++w)
+                if (red[w] > bb || (red[w] == bb && redi[w] < bbi)) { bb = red[w]; bbi = redi[w]; }
+            a.pmax[blockIdx.x] = bb; a.pidx[blockIdx.x] = bbi;
+        }
+    }
+}
+
+QWeight QWeight::rows(int row0, int n) const {
+    QWeight v = *this;
+    v.N = n;
+    const size_t r = (size_t)row0, k = (size_t)K;
+    if (fmt == QFMT_Q8_0) { v.p0 = p0 + r * k; v.p1 = p1 + r * (k >> 5) * 2; }
+    else if (fmt == QFMT_Q4_K) { v.p0 = p0 + r * (k >> 1); v.p1 = p1 + r * (k >> 8) * 16; }
+    else if (fmt == QFMT_Q6_K) { v.p0 = p0 + r * (k >> 1); v.p1 = p1 + r * (k >> 2); v.p2 = p2 + r * (k >> 4); v.p3 = p3 + r * (k >> 8) * 2; }
+    return v;
+}
+uint64_t QWeight::bytes() const {
+    const uint64_t n = (uint64_t)N * (uint64_t)K;
+    if (fmt == QFMT_Q8_0) return n + n / 32 * 2;
+    if (fmt == QFMT_Q4_K) return n / 2 + n / 256 * 16;
+    if (fmt == QFMT_Q6_K) return n / 2 + n / 4 + n / 16 + n / 256 * 2;
+    return 0;
+}
+
+__global__ void silu_mul_kernel(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ o, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = g[i]; o[i] = (v / (1.0f + expf(-v))) * u[i]; }
+}
+void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gate, up, out, n);
+}
+
+int gemvq_grid(int N, int num_cu) {
+    const int groups = (N + 1) / 2;
+    return std::max(1, std::min((groups + 3) / 4, num_cu * 4));
+}
+
+template <int FMT>
+static void launch_gemvq_f(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s) {
+    constexpr int CK = QF<FMT>::CK;
+    const size_t lds = (size_t)((a.w.K + CK - 1) / CK) * CK * 4 + 64;
+#define CM_Q(P, E) { static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemvq_kernel<FMT, P, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((gemvq_kernel<FMT, P, E>), dim3(grid), dim3(256), lds, s, a); return; }
+    if (pro == PRO_RMSNORM) {
+        if (epi == EPI_STORE) CM_Q(PRO_RMSNORM, EPI_STORE)
+        if (epi == EPI_SILUMUL) CM_Q(PRO_RMSNORM, EPI_SILUMUL)
+        if (epi == EPI_ARGMAX) CM_Q(PRO_RMSNORM, EPI_ARGMAX)
+        CM_Q(PRO_RMSNORM, EPI_RESADD)
+    } else {
+        if (epi == EPI_STORE) CM_Q(PRO_PLAIN, EPI_STORE)
+        if (epi == EPI_SILUMUL) CM_Q(PRO_PLAIN, EPI_SILUMUL)
+        if (epi == EPI_ARGMAX) CM_Q(PRO_PLAIN, EPI_ARGMAX)
+        CM_Q(PRO_PLAIN, EPI_RESADD)
+    }
+#undef CM_Q
+}
+
+bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s) {
+    switch (a.w.fmt) {
+        case QFMT_Q8_0: launch_gemvq_f<QFMT_Q8_0>(pro, epi, a, grid, s); return true;
+        case QFMT_Q4_K: launch_gemvq_f<QFMT_Q4_K>(pro, epi, a, grid, s); return true;
+        case QFMT_Q6_K: launch_gemvq_f<QFMT_Q6_K>(pro, epi, a, grid, s); return true;
+        default: return false;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// element-wise dequantisation (embedding-row gather; also the reference for the GEMV in tests)
+// ---------------------------------------------------------------------------------------------------------
+__device__ float q_elem(const QWeight& w, size_t row, int k) {
+    const size_t K = (size_t)w.K;
+    if (w.fmt == QFMT_Q8_0) {
+        const float d = f16_bits_to_f32(*(const uint16_t*)(w.p1 + (row * (K >> 5) + (size_t)(k >> 5)) * 2));
+        return d * (float)(int)((const signed char*)w.p0)[row * K + (size_t)k];
+    }
+    const size_t blk = row * (K >> 8) + (size_t)(k >> 8);
+    const int e = k & 255;
+    if (w.fmt == QFMT_Q4_K) {
+        const uint8_t* h = w.p1 + blk * 16;
+        const float d = f16_bits_to_f32((uint32_t)h[0] | ((uint32_t)h[1] << 8)), dmin = f16_bits_to_f32((uint32_t)h[2] | ((uint32_t)h[3] << 8));
+        const uint8_t* sc = h + 4;
+        const int j = e >> 5;
+        uint32_t s, m;
+        if (j < 4) { s = sc[j] & 63u; m = sc[j + 4] & 63u; }
+        else { s = (sc[j + 4] & 0xFu) | ((uint32_t)(sc[j - 4] >> 6) << 4); m = (uint32_t)(sc[j + 4] >> 4) | ((uint32_t)(sc[j] >> 6) << 4); }
+        const uint8_t byte = w.p0[blk * 128 + (size_t)(e >> 6) * 32 + (e & 31)];
+        const uint32_t q = ((e >> 5) & 1) ? (byte >> 4) : (byte & 0xFu);
+        return (d * (float)s) * (float)q - (dmin * (float)m);
+    }
+    // Q6_K
+    const int n = e >> 7, f = e & 127, t = f >> 5, l = f & 31;
+    const uint8_t qlb = w.p0[blk * 128 + (size_t)n * 64 + (t & 1) * 32 + l];
+    const uint8_t qhb = w.p1[blk * 64 + (size_t)n * 32 + l];
+    const uint32_t q = ((t < 2) ? (qlb & 0xFu) : (uint32_t)(qlb >> 4)) | (((uint32_t)(qhb >> (2 * t)) & 3u) << 4);
+    const float sc = (float)(int)((const signed char*)w.p2)[blk * 16 + (size_t)n * 8 + (l >> 4) + 2 * t];
+    const float d = f16_bits_to_f32(*(const uint16_t*)(w.p3 + blk * 2));
+    return (d * sc) * (float)((int)q - 32);
+}
+
+__global__ void embed_row_q_kernel(QWeight w, const StepState* __restrict__ st, float* __restrict__ x, int H, int V) {
+    uint32_t tok = st->token;
+    if (tok >= (uint32_t)V) tok = 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H) x[i] = q_elem(w, (size_t)tok, i);
+}
+
+__global__ void dequant_rows_kernel(QWeight w, float* __restrict__ out, int row0, int nrows) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nrows * w.K) return;
+    const size_t r = i / (size_t)w.K;
+    out[i] = q_elem(w, (size_t)row0 + r, (int)(i % (size_t)w.K));
+}
+
+void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s) {
+    hipLaunchKernelGGL(embed_row_q_kernel, dim3((H + 255) / 256), dim3(256), 0, s, w, st, x, H, V);
+}
+void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s) {
+    const size_t n = (size_t)nrows * w.K;
+    hipLaunchKernelGGL(dequant_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, out, row0, nrows);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// in-situ quantisation bf16 -> Q8_0 (ops/linear.rs:83-100 quantize_linear; ggml quantize_row_q8_0_ref:
+// d = amax / 127, id = d ? 1/d : 0, q = roundf(x * id), d stored as f16)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void isq_q8_0_kernel(const uint16_t* __restrict__ src, size_t src_stride, int N, int K, signed char* __restrict__ codes,
+                                uint16_t* __restrict__ dd) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 32-weight block per thread
+    const size_t nb_row = (size_t)K >> 5;
+    if (b >= (size_t)N * nb_row) return;
+    const size_t row = b / nb_row, kb = b % nb_row;
+    const uint16_t* p = src + row * src_stride + kb * 32;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { v[i] = bf16_to_f32(p[i]); amax = fmaxf(amax, fabsf(v[i])); }
+    const float d = amax / 127.0f;
+    const float id = d != 0.f ? 1.0f / d : 0.f;
+    signed char* q = codes + row * (size_t)K + kb * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) q[i] = (signed char)(int)roundf(v[i] * id);
+    const _Float16 h = (_Float16)d;
+    uint16_t hb;
+    __builtin_memcpy(&hb, &h, 2);
+    dd[b] = hb;
+}
+
+void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s) {
+    const size_t nb = (size_t)N * (K >> 5);
+    hipLaunchKernelGGL(isq_q8_0_kernel, dim3((unsigned)((nb + 127) / 128)), dim3(128), 0, s, src, src_stride, N, K, (signed char*)codes,
+                       (uint16_t*)d);
+}
+
+}  // namespace cm

@@ -1,0 +1,263 @@
+// GGUF checkpoint loader (dense Qwen3) + in-situ Q8_0 quantisation.
+//   names / metadata : qwen3/modeling.rs:242-282 (attn_q/k/v/output, attn_q_norm/k_norm), :593-606 (ffn_gate/up/down),
+//                      :678-696 (attn_norm / ffn_norm), :821-960 (general.architecture, {arch}.block_count,
+//                      embedding_length, feed_forward_length, attention.head_count(_kv), attention.key_length (128),
+//                      context_length (32768), attention.layer_norm_rms_epsilon (1e-6), rope.freq_base (1e6);
+//                      use_qk_norm = has blk.0.attn_q_norm.weight; tied = no output.weight; vocab = token_embd rows)
+//   quantised tensors stay quantised: linears (QMatMul, ops/linear.rs:18-51), the embedding table
+//   (quantized_embedding, hunyuan_dense/modeling.rs:52-64) and its tied use as lm_head; norms are dequantised to f32.
+// The GGUF byte stream is permuted into the kernel layouts of kernels_quant.hip on the host (no re-quantisation).
+#include <cmath>
+#include <cstring>
+
+#include "gguf.h"
+#include "model.h"
+
+namespace cm {
+
+namespace {
+
+using cmgguf::File;
+using cmgguf::TensorInfo;
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sgn = (h >> 15) & 1, ex = (h >> 10) & 0x1F, mant = h & 0x3FF;
+    float f;
+    if (ex == 0) f = std::ldexp((float)mant, -24);
+    else if (ex == 31) f = mant ? NAN : INFINITY;
+    else f = std::ldexp((float)(mant | 0x400), (int)ex - 25);
+    return sgn ? -f : f;
+}
+
+std::string arch_of(const File& g) {
+    const cmgguf::Value* a = g.meta("general.architecture");
+    return (a && a->type == 8) ? a->s : "qwen3";
+}
+
+// host staging of one repacked matrix
+struct Packed {
+    int fmt = QFMT_NONE;
+    std::vector<uint8_t> p0, p1, p2, p3;
+};
+
+void pack_rows(const TensorInfo& t, int row0, int nrows, int K, Packed& out) {
+    const size_t nb32 = (size_t)K / 32, nb256 = (size_t)K / 256;
+    if (t.type == cmgguf::Q8_0) {
+        if (K % 32) throw CmError(CM_ERR_UNSUPPORTED, "Q8_0 needs K % 32 == 0 (" + t.name + ")");
+        out.fmt = QFMT_Q8_0;
+        const size_t o0 = out.p0.size(), o1 = out.p1.size();
+        out.p0.resize(o0 + (size_t)nrows * K);
+        out.p1.resize(o1 + (size_t)nrows * nb32 * 2);
+        for (int r = 0; r < nrows; ++r) {
+            const uint8_t* src = t.data + (size_t)(row0 + r) * nb32 * 34;
+            for (size_t b = 0; b < nb32; ++b) {
+                memcpy(&out.p1[o1 + ((size_t)r * nb32 + b) * 2], src + b * 34, 2);
+                memcpy(&out.p0[o0 + (size_t)r * K + b * 32], src + b * 34 + 2, 32);
+            }
+        }
+    } else if (t.type == cmgguf::Q4_K) {
+        if (K % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q4_K needs K % 256 == 0 (" + t.name + ")");
+        out.fmt = QFMT_Q4_K;
+        const size_t o0 = out.p0.size(), o1 = out.p1.size();
+        out.p0.resize(o0 + (size_t)nrows * K / 2);
+        out.p1.resize(o1 + (size_t)nrows * nb256 * 16);
+        for (int r = 0; r < nrows; ++r) {
+            const uint8_t* src = t.data + (size_t)(row0 + r) * nb256 * 144;
+            for (size_t b = 0; b < nb256; ++b) {
+                memcpy(&out.p1[o1 + ((size_t)r * nb256 + b) * 16], src + b * 144, 16);
+                memcpy(&out.p0[o0 + ((size_t)r * nb256 + b) * 128], src + b * 144 + 16, 128);
+            }
+        }
+    } else if (t.type == cmgguf::Q6_K) {
+        if (K % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q6_K needs K % 256 == 0 (" + t.name + ")");
+        out.fmt = QFMT_Q6_K;
+        const size_t o0 = out.p0.size(), o1 = out.p1.size(), o2 = out.p2.size(), o3 = out.p3.size();
+        out.p0.resize(o0 + (size_t)nrows * K / 2);
+        out.p1.resize(o1 + (size_t)nrows * K / 4);
+        out.p2.resize(o2 + (size_t)nrows * K / 16);
+        out.p3.resize(o3 + (size_t)nrows * nb256 * 2);
+        for (int r = 0; r < nrows; ++r) {
+            const uint8_t* src = t.data + (size_t)(row0 + r) * nb256 * 210;
+            for (size_t b = 0; b < nb256; ++b) {
+                const size_t bi = (size_t)r * nb256 + b;
+                memcpy(&out.p0[o0 + bi * 128], src + b * 210, 128);
+                memcpy(&out.p1[o1 + bi * 64], src + b * 210 + 128, 64);
+                memcpy(&out.p2[o2 + bi * 16], src + b * 210 + 192, 16);
+                memcpy(&out.p3[o3 + bi * 2], src + b * 210 + 208, 2);
+            }
+        }
+    } else {
+        throw CmError(CM_ERR_UNSUPPORTED, "GGUF tensor " + t.name + ": ggml type " + std::to_string(t.type) +
+                                              " is not supported for matrices (Q8_0, Q4_K, Q6_K)");
+    }
+}
+
+const uint8_t* upload(Model& m, const std::vector<uint8_t>& v) {
+    if (v.empty()) return nullptr;
+    uint8_t* d = (uint8_t*)m.dalloc<uint16_t>((v.size() + 1) / 2, true);
+    CM_HIP(hipMemcpy(d, v.data(), v.size(), hipMemcpyHostToDevice));
+    return d;
+}
+
+QWeight to_device(Model& m, const Packed& p, int N, int K) {
+    QWeight w;
+    w.fmt = p.fmt; w.N = N; w.K = K;
+    w.p0 = upload(m, p.p0); w.p1 = upload(m, p.p1); w.p2 = upload(m, p.p2); w.p3 = upload(m, p.p3);
+    m.quant_weight_bytes += w.bytes();
+    return w;
+}
+
+void check_shape(const TensorInfo& t, uint64_t rows, uint64_t cols) {
+    if (t.shape.size() != 2 || t.shape[0] != rows || t.shape[1] != cols)
+        throw CmError(CM_ERR_IO, "GGUF tensor " + t.name + " has unexpected shape");
+}
+
+QWeight load_matrix(Model& m, const File& g, const std::string& name, int N, int K) {
+    const TensorInfo& t = g.tensor(name);
+    check_shape(t, (uint64_t)N, (uint64_t)K);
+    Packed p;
+    pack_rows(t, 0, N, K, p);
+    return to_device(m, p, N, K);
+}
+
+float* load_vec_f32(Model& m, const File& g, const std::string& name, int n) {
+    const TensorInfo& t = g.tensor(name);
+    if (t.numel() != (uint64_t)n) throw CmError(CM_ERR_IO, "GGUF tensor " + name + " has unexpected length");
+    std::vector<float> h((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (t.type == cmgguf::F32) memcpy(&h[(size_t)i], t.data + (size_t)i * 4, 4);
+        else if (t.type == cmgguf::F16) { uint16_t v; memcpy(&v, t.data + (size_t)i * 2, 2); h[(size_t)i] = f16_to_f32(v); }
+        else if (t.type == cmgguf::BF16) { uint16_t v; memcpy(&v, t.data + (size_t)i * 2, 2); const uint32_t u = (uint32_t)v << 16; memcpy(&h[(size_t)i], &u, 4); }
+        else throw CmError(CM_ERR_UNSUPPORTED, "GGUF tensor " + name + ": vectors must be F32 / F16 / BF16");
+    }
+    float* d = m.dalloc<float>((size_t)n, true);
+    CM_HIP(hipMemcpy(d, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+}  // namespace
+
+std::string gguf_config_json(const std::string& path) {
+    File g(path);
+    const std::string a = arch_of(g);
+    if (a != "qwen3") throw CmError(CM_ERR_UNSUPPORTED, "GGUF architecture '" + a + "' not implemented (qwen3)");
+    auto need_u = [&](const std::string& k) -> uint64_t {
+        const cmgguf::Value* v = g.meta(a + "." + k);
+        if (!v) throw CmError(CM_ERR_IO, "cannot find " + a + "." + k + " in GGUF metadata");
+        return v->as_u64();
+    };
+    auto opt_u = [&](const std::string& k, uint64_t def) { const cmgguf::Value* v = g.meta(a + "." + k); return v ? v->as_u64() : def; };
+    auto opt_f = [&](const std::string& k, double def) { const cmgguf::Value* v = g.meta(a + "." + k); return v ? v->as_f64() : def; };
+    const TensorInfo& emb = g.tensor("token_embd.weight");
+    if (emb.shape.size() != 2) throw CmError(CM_ERR_IO, "token_embd.weight must be a matrix");
+    char buf[1024];
+    snprintf(buf, sizeof buf,
+             "{\"model_type\":\"qwen3\",\"hidden_size\":%llu,\"num_hidden_layers\":%llu,\"num_attention_heads\":%llu,"
+             "\"num_key_value_heads\":%llu,\"head_dim\":%llu,\"intermediate_size\":%llu,\"vocab_size\":%llu,"
+             "\"max_position_embeddings\":%llu,\"rms_norm_eps\":%.9g,\"rope_theta\":%.9g,\"tie_word_embeddings\":%s,\"use_qk_norm\":%s}",
+             (unsigned long long)need_u("embedding_length"), (unsigned long long)need_u("block_count"),
+             (unsigned long long)need_u("attention.head_count"), (unsigned long long)need_u("attention.head_count_kv"),
+             (unsigned long long)opt_u("attention.key_length", 128), (unsigned long long)need_u("feed_forward_length"),
+             (unsigned long long)emb.shape[0], (unsigned long long)opt_u("context_length", 32768),
+             opt_f("attention.layer_norm_rms_epsilon", 1e-6), opt_f("rope.freq_base", 1e6),
+             g.has("output.weight") ? "false" : "true", g.has("blk.0.attn_q_norm.weight") ? "true" : "false");
+    return buf;
+}
+
+void load_from_gguf(Model& m, const std::string& path) {
+    if (m.tp != 1) throw CmError(CM_ERR_UNSUPPORTED, "quantised (GGUF) weights under tensor parallelism are not implemented");
+    try {
+        File g(path);
+        const Config& c = m.cfg;
+        const int H = c.H, D = c.D, I = c.I;
+        m.quantized = true;
+        m.q_embed = load_matrix(m, g, "token_embd.weight", c.V, H);
+        m.quant_weight_bytes -= m.q_embed.bytes();                 // only one row is read per token
+        m.norm = load_vec_f32(m, g, "output_norm.weight", H);
+        if (!c.tie) m.q_lm_head = load_matrix(m, g, "output.weight", c.V, H);
+        else { m.q_lm_head = m.q_embed; m.quant_weight_bytes += m.q_embed.bytes(); }
+        m.layers.resize((size_t)c.L);
+        const int qd = c.Hq * D, kd = c.Hkv * D;
+        for (int li = 0; li < c.L; ++li) {
+            LayerW& w = m.layers[(size_t)li];
+            w.full = true;
+            const std::string p = "blk." + std::to_string(li) + ".";
+            const TensorInfo &tq = g.tensor(p + "attn_q.weight"), &tk = g.tensor(p + "attn_k.weight"), &tv = g.tensor(p + "attn_v.weight");
+            check_shape(tq, (uint64_t)qd, (uint64_t)H); check_shape(tk, (uint64_t)kd, (uint64_t)H); check_shape(tv, (uint64_t)kd, (uint64_t)H);
+            if (tq.type == tk.type && tk.type == tv.type) {
+                Packed pk;
+                pack_rows(tq, 0, qd, H, pk); pack_rows(tk, 0, kd, H, pk); pack_rows(tv, 0, kd, H, pk);
+                w.q_qkv[0] = to_device(m, pk, qd + 2 * kd, H);
+                w.n_qkv = 1; w.qkv_row0[0] = 0;
+            } else {
+                w.q_qkv[0] = load_matrix(m, g, p + "attn_q.weight", qd, H);
+                w.q_qkv[1] = load_matrix(m, g, p + "attn_k.weight", kd, H);
+                w.q_qkv[2] = load_matrix(m, g, p + "attn_v.weight", kd, H);
+                w.n_qkv = 3; w.qkv_row0[0] = 0; w.qkv_row0[1] = qd; w.qkv_row0[2] = qd + kd;
+            }
+            w.q_o = load_matrix(m, g, p + "attn_output.weight", H, qd);
+            if (c.qk_norm) {
+                w.qn = load_vec_f32(m, g, p + "attn_q_norm.weight", D);
+                w.kn = load_vec_f32(m, g, p + "attn_k_norm.weight", D);
+            }
+            const TensorInfo &tg = g.tensor(p + "ffn_gate.weight"), &tu = g.tensor(p + "ffn_up.weight");
+            check_shape(tg, (uint64_t)I, (uint64_t)H); check_shape(tu, (uint64_t)I, (uint64_t)H);
+            if (tg.type == tu.type) {
+                Packed pk;                                              // row 2j = gate_j, row 2j+1 = up_j
+                for (int j = 0; j < I; ++j) { pack_rows(tg, j, 1, H, pk); pack_rows(tu, j, 1, H, pk); }
+                w.q_gate_up = to_device(m, pk, 2 * I, H);
+            } else {
+                w.split_gate_up = true;
+                w.q_gate = load_matrix(m, g, p + "ffn_gate.weight", I, H);
+                w.q_up = load_matrix(m, g, p + "ffn_up.weight", I, H);
+                if (!m.gu_tmp) m.gu_tmp = m.dalloc<float>((size_t)2 * I);
+            }
+            w.q_down = load_matrix(m, g, p + "ffn_down.weight", H, I);
+            w.ln1 = load_vec_f32(m, g, p + "attn_norm.weight", H);
+            w.ln2 = load_vec_f32(m, g, p + "ffn_norm.weight", H);
+        }
+        CM_HIP(hipStreamSynchronize(m.stream));
+    } catch (const CmError&) {
+        throw;
+    } catch (const std::exception& e) {
+        throw CmError(CM_ERR_IO, e.what());
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// ISQ: quantise the bf16 linears already in HBM to Q8_0 and drop the bf16 copies.  The reference quantises every
+// linear of the decoder plus (GGUF path only) keeps the embedding quantised; here: qkv, o, gate_up, down, lm_head
+// (when untied); the embedding table stays bf16 (one row per token) and so does a tied lm_head.
+// ------------------------------------------------------------------------------------
+void Model::isq_q8_0() {
+    if (tp != 1) throw CmError(CM_ERR_UNSUPPORTED, "ISQ under tensor parallelism is not implemented");
+    if (cfg.hybrid) throw CmError(CM_ERR_UNSUPPORTED, "ISQ is implemented for the dense Qwen3 family only");
+    auto quant = [&](uint16_t* src, int N, int K) -> QWeight {
+        if (K % 32) throw CmError(CM_ERR_UNSUPPORTED, "ISQ Q8_0 needs the input dimension to be a multiple of 32");
+        QWeight w;
+        w.fmt = QFMT_Q8_0; w.N = N; w.K = K;
+        uint8_t* codes = (uint8_t*)dalloc<uint16_t>(((size_t)N * K + 1) / 2, true);
+        uint8_t* d = (uint8_t*)dalloc<uint16_t>((size_t)N * (K / 32), true);
+        launch_isq_q8_0(src, (size_t)K, N, K, codes, d, stream);
+        w.p0 = codes; w.p1 = d;
+        quant_weight_bytes += w.bytes();
+        return w;
+    };
+    const int H = cfg.H, D = cfg.D;
+    for (LayerW& w : layers) {
+        w.q_qkv[0] = quant(w.qkv, (Hq_l + 2 * Hkv_l) * D, H); w.n_qkv = 1; w.qkv_row0[0] = 0;
+        w.q_o = quant(w.o, H, Hq_l * D);
+        w.q_gate_up = quant(w.gate_up, 2 * I_l, H);
+        w.q_down = quant(w.down, H, I_l);
+    }
+    if (!cfg.tie) q_lm_head = quant(lm_head, cfg.V, H);
+    CM_HIP(hipStreamSynchronize(stream));
+    for (LayerW& w : layers) {
+        dfree(w.qkv); dfree(w.o); dfree(w.gate_up); dfree(w.down);
+        w.qkv = w.o = w.gate_up = w.down = nullptr;
+    }
+    if (!cfg.tie) { dfree(lm_head); lm_head = nullptr; }
+    quantized = true;
+}
+
+}  // namespace cm

@@ -19,6 +19,7 @@ T* Model::dalloc(size_t n, bool count_weight) {
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
     CM_HIP(hipMalloc(&p, bytes));
     allocs.push_back(p);
+    alloc_sizes.push_back(count_weight ? bytes : 0);
     if (count_weight) weight_bytes += bytes;
     return (T*)p;
 }
@@ -26,6 +27,18 @@ template uint16_t* Model::dalloc<uint16_t>(size_t, bool);
 template float* Model::dalloc<float>(size_t, bool);
 template int* Model::dalloc<int>(size_t, bool);
 template uint32_t* Model::dalloc<uint32_t>(size_t, bool);
+
+void Model::dfree(void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < allocs.size(); ++i)
+        if (allocs[i] == p) {
+            weight_bytes -= alloc_sizes[i];
+            (void)hipFree(p);
+            allocs.erase(allocs.begin() + (long)i);
+            alloc_sizes.erase(alloc_sizes.begin() + (long)i);
+            return;
+        }
+}
 
 Model::~Model() {
     if (stream) (void)hipStreamSynchronize(stream);
@@ -230,7 +243,7 @@ void Model::alloc_runtime() {
     part_o = dalloc<float>((size_t)Hq_l * nsplit * D);
     part_ml = dalloc<float>((size_t)Hq_l * nsplit * 2);
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
-    lm_grid = gemv_grid(v_eff, H, num_cu);
+    lm_grid = (quantized && q_lm_head.fmt != QFMT_NONE) ? gemvq_grid(v_eff, num_cu) : gemv_grid(v_eff, H, num_cu);
     pmax = dalloc<float>((size_t)lm_grid * tp);
     pidx = dalloc<int>((size_t)lm_grid * tp);
     st = (StepState*)dalloc<int>(sizeof(StepState) / sizeof(int));
@@ -417,6 +430,13 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
     }
     const uint64_t v_eff = (uint64_t)std::max(0, std::min(V_l, cfg.V - v0));
     w_elems += v_eff * H + H /*final norm*/ + H /*embedding row*/;
+    if (quantized) {
+        // every quantised matrix once (codes + scales) + f32 norm vectors + one embedding row + KV
+        uint64_t b = quant_weight_bytes + (uint64_t)cfg.L * (2 * H + (cfg.qk_norm ? 2 * D : 0)) * 4 + H * 4;
+        if (q_lm_head.fmt == QFMT_NONE) b += v_eff * H * 2;           // tied bf16 table used as lm_head (ISQ)
+        b += q_embed.fmt != QFMT_NONE ? q_embed.bytes() / (uint64_t)cfg.V : H * 2;
+        return b + extra;
+    }
     return w_elems * 2 + extra;
 }
 
@@ -426,10 +446,12 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
 void Model::enqueue_decode_step(bool advance) {
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
-    launch_embed_row(embed, st, x, H, cfg.V, 1, s);
+    if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_row_q(q_embed, st, x, H, cfg.V, s);
+    else launch_embed_row(embed, st, x, H, cfg.V, 1, s);
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
+        if (quantized) { enqueue_quant_layer(li); continue; }
         GemvArgs g{};
         if (!w.full) {
             // ---- Gated Delta Net layer (ops/gdn/layer.rs:122-182): in_proj GEMV, fused GDN kernel, out_proj GEMV ----
@@ -495,12 +517,47 @@ void Model::enqueue_decode_step(bool advance) {
     enqueue_lm_head(advance);
 }
 
+// one dense decoder layer over quantised weights (LinearLayer::Quantized, ops/linear.rs:18-51)
+void Model::enqueue_quant_layer(int li) {
+    const LayerW& w = layers[(size_t)li];
+    const int D = cfg.D;
+    hipStream_t s = stream;
+    auto qg = [&](int pro, int epi, const QWeight& qw, const float* xin, const float* nw, float* yout, const float* res) {
+        GemvQArgs q{};
+        q.w = qw; q.x = xin; q.nw = nw; q.y = yout; q.res = res; q.eps = cfg.eps;
+        if (!launch_gemvq(pro, epi, q, gemvq_grid(qw.N, num_cu), s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
+    };
+    for (int i = 0; i < w.n_qkv; ++i) qg(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], x, w.ln1, qkv + w.qkv_row0[i], nullptr);
+    AttnDecArgs a{};
+    a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
+    a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
+    a.q_off = 0; a.k_off = Hq_l * D; a.v_off = a.k_off + Hkv_l * D; a.gate = nullptr; a.rot_dim = cfg.rot_dim;
+    a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+    if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+    qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
+    if (!w.split_gate_up) {
+        qg(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, x, w.ln2, hbuf, nullptr);
+    } else {
+        qg(PRO_RMSNORM, EPI_STORE, w.q_gate, x, w.ln2, gu_tmp, nullptr);
+        qg(PRO_RMSNORM, EPI_STORE, w.q_up, x, w.ln2, gu_tmp + cfg.I, nullptr);
+        launch_silu_mul(gu_tmp, gu_tmp + cfg.I, hbuf, cfg.I, s);
+    }
+    qg(PRO_PLAIN, EPI_RESADD, w.q_down, hbuf, nullptr, x, x);
+}
+
 void Model::enqueue_lm_head(bool advance) {
     // final norm + lm_head (last position only, modeling.rs:1024-1035) + arg-max
     const int H = cfg.H;
     hipStream_t s = stream;
     logits_gathered = false;
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+    if (quantized && q_lm_head.fmt != QFMT_NONE) {
+        GemvQArgs q{};
+        q.w = q_lm_head; q.x = x; q.nw = norm; q.y = logits; q.pmax = pmax; q.pidx = pidx; q.idx_base = 0; q.eps = cfg.eps;
+        if (!launch_gemvq(PRO_RMSNORM, EPI_ARGMAX, q, lm_grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
+        launch_argmax_final(pmax, pidx, lm_grid, st, ring, RING - 1, advance ? 1 : 0, 1, s);
+        return;
+    }
     GemvArgs g{};
     g.W = lm_head; g.x = x; g.nw = norm; g.y = logits + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H;
     g.eps = cfg.eps; g.pmax = pmax + (size_t)rank * lm_grid; g.pidx = pidx + (size_t)rank * lm_grid; g.idx_base = v0;
@@ -705,6 +762,7 @@ void Model::ensure_batch_buffers() {
 void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out,
                          const std::function<void(size_t, int)>* after_group) {
     if (rccl) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
+    if (quantized) throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights is not implemented");
     ensure_batch_buffers();
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
@@ -806,7 +864,7 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     ensure_pages(s, (int64_t)(start_pos + n));
     activate(s);
     bool use_prefill = false;
-    if (n >= 2 && getenv("CM_NO_PREFILL") == nullptr) {
+    if (n >= 2 && !quantized && getenv("CM_NO_PREFILL") == nullptr) {      // quantised weights: token-serial (no dequant-GEMM yet)
         ensure_prefill_buffers();
         use_prefill = prefill_ok;
     }
@@ -943,6 +1001,21 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
         size_t li = i % (size_t)cfg.L;
         if ((which == "qkv" || which == "o") && !layers[li].full) li = (size_t)(cfg.interval - 1);
         const LayerW& w = layers[li];
+        if (quantized) {
+            GemvQArgs q{};
+            q.eps = cfg.eps;
+            int pro = PRO_PLAIN, epi = EPI_RESADD;
+            if (which == "qkv") { q.w = w.q_qkv[0]; q.x = x; q.nw = w.ln1; q.y = qkv; pro = PRO_RMSNORM; epi = EPI_STORE; }
+            else if (which == "o") { q.w = w.q_o; q.x = attn; q.y = y; q.res = x; }
+            else if (which == "gate_up" && !w.split_gate_up) { q.w = w.q_gate_up; q.x = x; q.nw = w.ln2; q.y = hbuf; pro = PRO_RMSNORM; epi = EPI_SILUMUL; }
+            else if (which == "down") { q.w = w.q_down; q.x = hbuf; q.y = y; q.res = x; }
+            else if (which == "lm_head" && q_lm_head.fmt != QFMT_NONE) { q.w = q_lm_head; q.x = x; q.nw = norm; q.y = logits; q.pmax = pmax; q.pidx = pidx; pro = PRO_RMSNORM; epi = EPI_ARGMAX; }
+            else throw CmError(CM_ERR_INVALID, "unknown / unavailable kernel name for quantised weights");
+            const int grid = which == "lm_head" ? lm_grid : gemvq_grid(q.w.N, num_cu);
+            if (!launch_gemvq(pro, epi, q, grid, stream)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
+            b = q.w.bytes() + (uint64_t)q.w.K * 4 + (q.nw ? (uint64_t)q.w.K * 4 : 0);
+            return;
+        }
         GemvArgs g{};
         g.eps = cfg.eps;
         if (which == "qkv") {

@@ -70,6 +70,14 @@ struct LayerW {
     float* A_log = nullptr;       // [NV]
     float* dt_bias = nullptr;     // [NV]
     float* gnorm = nullptr;       // [Vd] plain RMSNormGated weight
+    // quantised linears (GGUF / ISQ; loader_gguf.cpp).  q|k|v are merged into ONE segment when their ggml types
+    // agree, otherwise kept as separate GEMV launches into the same qkv buffer; gate/up are row-interleaved
+    // like the bf16 layout when their types agree, else two GEMVs + a SiLU*mul launch.
+    QWeight q_qkv[3];
+    int n_qkv = 0;
+    int qkv_row0[3] = {0, 0, 0};
+    QWeight q_o, q_gate_up, q_gate, q_up, q_down;
+    bool split_gate_up = false;
 };
 
 struct Seq {
@@ -122,6 +130,7 @@ struct Model {
     float* sin = nullptr;
     uint64_t weight_bytes = 0;
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_sizes;   // weight bytes of each allocation (0 for scratch)
 
     // paged KV pool: [L][2][n_pages][Hkv_l][page][D] bf16 (or f32: cm_opts.kv_dtype)
     uint8_t* kv_pool = nullptr;
@@ -224,6 +233,14 @@ struct Model {
     uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false, float* dev_logits = nullptr);
     bool logits_gathered = false;
 
+    // quantised weights (dense Qwen3, TP = 1): embedding / lm_head tables + per-layer QWeights in LayerW
+    bool quantized = false;
+    QWeight q_embed, q_lm_head;
+    float* gu_tmp = nullptr;           // [2 I] scratch when gate / up have different ggml types
+    uint64_t quant_weight_bytes = 0;   // bytes of every quantised matrix read once per decoded token
+    void isq_q8_0();                   // in-situ quantisation of the loaded bf16 linears (ops/linear.rs:83-116)
+    void dfree(void* p);
+
     hipGraph_t graph[2] = {nullptr, nullptr};          // one captured decode step per attention variant
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     bool graph_ok[2] = {false, false};
@@ -260,6 +277,7 @@ struct Model {
     // ---- forward ----
     void enqueue_decode_step(bool advance);     // one token from st->token at st->pos
     void enqueue_lm_head(bool advance);         // final norm + lm_head + arg-max on x
+    void enqueue_quant_layer(int li);           // dense layer over GGUF / ISQ weights
     void ensure_prefill_buffers();
     void prefill(const uint32_t* ids, size_t n, size_t start_pos);   // active sequence, pages ensured
     void run_decode_step(bool advance, int64_t ctx_len);   // graph replay or eager; ctx_len = tokens attended (pos + 1)
@@ -276,5 +294,7 @@ struct Model {
 // loaders (loader.cpp)
 void load_from_dir(Model& m, const std::string& dir);
 void load_synthetic(Model& m, uint64_t seed);
+std::string gguf_config_json(const std::string& path);     // loader_gguf.cpp
+void load_from_gguf(Model& m, const std::string& path);
 
 }  // namespace cm

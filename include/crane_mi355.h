@@ -69,8 +69,12 @@ typedef struct cm_opts {
     uint32_t prefill_chunk;    /* tokens per prefill chunk (default 2048,            */
                                /*   PREFILL_CHUNK_SIZE engine/mod.rs:65)             */
     int32_t  prefill_split;    /* activation split terms for MFMA GEMMs: 0/2 = bf16x2 (parity), 1 = bf16 */
-    uint32_t reserved[8];
+    uint32_t isq;              /* in-situ quantisation of the linears at load: 0 none, CM_ISQ_Q8_0       */
+                               /*   (--quant / CRANE_ISQ, ops/linear.rs:53-116; also read from CRANE_ISQ) */
+    uint32_t reserved[7];
 } cm_opts;
+
+enum { CM_ISQ_NONE = 0, CM_ISQ_Q8_0 = 8 };
 
 typedef struct cm_model cm_model;
 
@@ -79,7 +83,10 @@ typedef struct cm_model cm_model;
 /* Model::new / from_pretrained (qwen3/model.rs:45-106): reads config.json and
  * every *.safetensors (sharded index honoured, utils/utils.rs:16-57) from
  * `model_dir`, merges QKV and gate||up at load (modeling.rs:187-204,582-588),
- * ties lm_head to the embedding when the config says so (modeling.rs:786-794). */
+ * ties lm_head to the embedding when the config says so (modeling.rs:786-794).
+ * A path ending in ".gguf" is loaded as a GGUF checkpoint instead (ModelFormat::Auto,
+ * qwen3/model.rs:55-71,108-152): Q8_0 / Q4_K / Q6_K matrices stay quantised in HBM
+ * (LinearLayer::Quantized, ops/linear.rs:18-51) and are decoded inside the GEMV. */
 int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out);
 
 /* Same model object from a config.json *string* with deterministic synthetic

@@ -1,0 +1,342 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the GGUF container and the ggml block formats the reference
+loads through candle (`candle_core::quantized::{gguf_file, k_quants}` 0.11, a port of ggml's ggml-quants.c; the
+crate is NOT under /root/reference, so the published ggml definitions are restated here).
+
+Reference call sites: qwen3/model.rs:108-152 + qwen3/modeling.rs:242-282,593-606,678-696,821-960 (GGUF names,
+metadata keys), hunyuan_dense/modeling.rs:14-95 (Gguf helper), ops/linear.rs:18-116 (QMatMul semantics: "dequantizes
+weights to F32 and requires F32 input"; ISQ falls back to Q8_0 when K % 256 != 0).
+
+Block formats (little endian):
+  Q8_0  32 weights : f16 d; i8 qs[32]                                   y = d * q
+  Q4_K  256 weights: f16 d; f16 dmin; u8 scales[12]; u8 qs[128]         y = d*sc_j*q - dmin*m_j   (8 sub-blocks of 32)
+  Q6_K  256 weights: u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d        y = d*sc_j*(q - 32)        (16 sub-blocks of 16)
+Dequantisers are exact restatements (dequantize_row_q8_0 / _q4_K / _q6_K).  quantize_q8_0 restates
+quantize_row_q8_0_ref exactly; the Q4_K / Q6_K *quantisers* here are simple valid encoders for writing test files
+(ggml's make_qkx2_quants search is not reproduced -- PARITY UNPINNED for K-quant ISQ, which crane_amd does not offer).
+"""
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+GGML_F32, GGML_F16, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_BF16 = 0, 1, 8, 12, 14, 30
+BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_BF16: (1, 2), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q6_K: (256, 210)}
+TYPE_NAMES = {"f32": GGML_F32, "f16": GGML_F16, "bf16": GGML_BF16, "q8_0": GGML_Q8_0, "q4_k": GGML_Q4_K, "q6_k": GGML_Q6_K}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Q8_0
+# ---------------------------------------------------------------------------------------------------------
+def quantize_q8_0(x: np.ndarray) -> np.ndarray:
+    """quantize_row_q8_0_ref: d = amax / 127 (stored f16), q = round(x * (1/d)) with id = 0 when d == 0."""
+    x = np.asarray(x, np.float32).reshape(-1, 32)
+    amax = np.abs(x).max(axis=1)
+    d = (amax / np.float32(127.0)).astype(np.float32)
+    idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0)).astype(np.float32)
+    t = x * idv[:, None]                                     # roundf: ties away from zero
+    q = np.where(np.abs(t - np.trunc(t)) == 0.5, np.trunc(t) + np.sign(t), np.rint(t)).astype(np.int8)
+    out = np.zeros((x.shape[0], 34), np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q.view(np.uint8)
+    return out.reshape(-1)
+
+
+def dequantize_q8_0(raw: np.ndarray, n: int) -> np.ndarray:
+    b = np.asarray(raw, np.uint8).reshape(-1, 34)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)              # [nb, 1]
+    q = b[:, 2:].copy().view(np.int8).astype(np.float32)
+    return (q * d).astype(np.float32).reshape(-1)[:n]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Q4_K
+# ---------------------------------------------------------------------------------------------------------
+def _get_scale_min_k4(j: int, s: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """get_scale_min_k4: 6-bit scales/mins packed in 12 bytes.  s: [nb, 12] uint8 -> (sc, m) [nb] each."""
+    s = s.astype(np.uint16)
+    if j < 4:
+        return s[:, j] & 63, s[:, j + 4] & 63
+    sc = (s[:, j + 4] & 0xF) | ((s[:, j - 4] >> 6) << 4)
+    m = (s[:, j + 4] >> 4) | ((s[:, j] >> 6) << 4)
+    return sc, m
+
+
+def dequantize_q4_k(raw: np.ndarray, n: int) -> np.ndarray:
+    b = np.asarray(raw, np.uint8).reshape(-1, 144)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)[:, 0]
+    dmin = b[:, 2:4].copy().view(np.float16).astype(np.float32)[:, 0]
+    sc12 = b[:, 4:16]
+    qs = b[:, 16:]
+    y = np.zeros((b.shape[0], 256), np.float32)
+    for p in range(4):                                       # 64 weights: low nibbles then high nibbles of 32 bytes
+        q = qs[:, 32 * p:32 * p + 32]
+        sc1, m1 = _get_scale_min_k4(2 * p, sc12)
+        sc2, m2 = _get_scale_min_k4(2 * p + 1, sc12)
+        d1 = (d * sc1.astype(np.float32)).astype(np.float32); mm1 = (dmin * m1.astype(np.float32)).astype(np.float32)
+        d2 = (d * sc2.astype(np.float32)).astype(np.float32); mm2 = (dmin * m2.astype(np.float32)).astype(np.float32)
+        y[:, 64 * p:64 * p + 32] = d1[:, None] * (q & 0xF).astype(np.float32) - mm1[:, None]
+        y[:, 64 * p + 32:64 * p + 64] = d2[:, None] * (q >> 4).astype(np.float32) - mm2[:, None]
+    return y.reshape(-1)[:n]
+
+
+def quantize_q4_k(x: np.ndarray) -> np.ndarray:
+    """A simple valid Q4_K encoder (min/max affine per sub-block, 6-bit scale/min against the super-block max)."""
+    x = np.asarray(x, np.float32).reshape(-1, 8, 32)
+    nb = x.shape[0]
+    mn = np.minimum(x.min(axis=2), 0.0)                       # y = d*sc*q - dmin*m  with m >= 0
+    mx = x.max(axis=2)
+    scale = np.maximum(mx - mn, 1e-30) / 15.0                 # per sub-block
+    mins = -mn
+    d = (scale.max(axis=1) / 63.0).astype(np.float16).astype(np.float32)
+    dmin = (mins.max(axis=1) / 63.0).astype(np.float16).astype(np.float32)
+    sc = np.clip(np.rint(scale / np.where(d > 0, d, 1)[:, None]), 0, 63).astype(np.uint8)
+    m = np.clip(np.rint(mins / np.where(dmin > 0, dmin, 1)[:, None]), 0, 63).astype(np.uint8)
+    d1 = d[:, None] * sc
+    m1 = dmin[:, None] * m
+    q = np.clip(np.rint((x + m1[:, :, None]) / np.where(d1 > 0, d1, 1)[:, :, None]), 0, 15).astype(np.uint8)
+    out = np.zeros((nb, 144), np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:4] = dmin.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    s = np.zeros((nb, 12), np.uint8)
+    for j in range(8):
+        if j < 4:
+            s[:, j] |= sc[:, j] & 63
+            s[:, j + 4] |= m[:, j] & 63
+        else:
+            s[:, j + 4] |= (sc[:, j] & 0xF) | ((m[:, j] & 0xF) << 4)
+            s[:, j - 4] |= (sc[:, j] >> 4) << 6
+            s[:, j] |= (m[:, j] >> 4) << 6
+    out[:, 4:16] = s
+    for p in range(4):
+        out[:, 16 + 32 * p:16 + 32 * p + 32] = q[:, 2 * p] | (q[:, 2 * p + 1] << 4)
+    return out.reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Q6_K
+# ---------------------------------------------------------------------------------------------------------
+def dequantize_q6_k(raw: np.ndarray, n: int) -> np.ndarray:
+    b = np.asarray(raw, np.uint8).reshape(-1, 210)
+    ql, qh = b[:, 0:128], b[:, 128:192]
+    sc = b[:, 192:208].copy().view(np.int8).astype(np.float32)
+    d = b[:, 208:210].copy().view(np.float16).astype(np.float32)[:, 0]
+    y = np.zeros((b.shape[0], 256), np.float32)
+    for h in range(2):                                       # two halves of 128 weights
+        L, H, S = ql[:, 64 * h:64 * h + 64], qh[:, 32 * h:32 * h + 32], sc[:, 8 * h:8 * h + 8]
+        l = np.arange(32)
+        isx = l // 16
+        q1 = ((L[:, l] & 0xF) | (((H[:, l] >> 0) & 3) << 4)).astype(np.int32) - 32
+        q2 = ((L[:, l + 32] & 0xF) | (((H[:, l] >> 2) & 3) << 4)).astype(np.int32) - 32
+        q3 = ((L[:, l] >> 4) | (((H[:, l] >> 4) & 3) << 4)).astype(np.int32) - 32
+        q4 = ((L[:, l + 32] >> 4) | (((H[:, l] >> 6) & 3) << 4)).astype(np.int32) - 32
+        base = 128 * h
+        y[:, base + l] = (d[:, None] * S[:, isx + 0]) * q1
+        y[:, base + 32 + l] = (d[:, None] * S[:, isx + 2]) * q2
+        y[:, base + 64 + l] = (d[:, None] * S[:, isx + 4]) * q3
+        y[:, base + 96 + l] = (d[:, None] * S[:, isx + 6]) * q4
+    return y.astype(np.float32).reshape(-1)[:n]
+
+
+def quantize_q6_k(x: np.ndarray) -> np.ndarray:
+    """A simple valid Q6_K encoder (symmetric per 16-weight sub-block, int8 scale against the super-block)."""
+    x = np.asarray(x, np.float32).reshape(-1, 16, 16)
+    nb = x.shape[0]
+    amax = np.abs(x).max(axis=2)                              # [nb, 16]
+    sub = amax / 31.0
+    d = (sub.max(axis=1) / 127.0).astype(np.float16).astype(np.float32)
+    sc = np.clip(np.rint(sub / np.where(d > 0, d, 1)[:, None]), 0, 127).astype(np.int8)
+    eff = d[:, None] * sc.astype(np.float32)
+    q = np.clip(np.rint(x / np.where(eff > 0, eff, 1)[:, :, None]), -32, 31).astype(np.int32) + 32     # 0..63
+    q = q.reshape(nb, 256).astype(np.uint8)
+    out = np.zeros((nb, 210), np.uint8)
+    for h in range(2):
+        base = 128 * h
+        l = np.arange(32)
+        a1, a2, a3, a4 = q[:, base + l], q[:, base + 32 + l], q[:, base + 64 + l], q[:, base + 96 + l]
+        out[:, 64 * h + l] = (a1 & 0xF) | ((a3 & 0xF) << 4)
+        out[:, 64 * h + 32 + l] = (a2 & 0xF) | ((a4 & 0xF) << 4)
+        out[:, 128 + 32 * h + l] = (a1 >> 4) | ((a2 >> 4) << 2) | ((a3 >> 4) << 4) | ((a4 >> 4) << 6)
+    out[:, 192:208] = sc.view(np.uint8)
+    out[:, 208:210] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    return out.reshape(-1)
+
+
+def _bf16_bytes(x: np.ndarray) -> np.ndarray:
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    return r.view(np.uint8)
+
+
+def quantize(x: np.ndarray, ggml_type: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    if ggml_type == GGML_F32:
+        return x.view(np.uint8)
+    if ggml_type == GGML_F16:
+        return x.astype(np.float16).view(np.uint8)
+    if ggml_type == GGML_BF16:
+        return _bf16_bytes(x)
+    return {GGML_Q8_0: quantize_q8_0, GGML_Q4_K: quantize_q4_k, GGML_Q6_K: quantize_q6_k}[ggml_type](x)
+
+
+def dequantize(raw: np.ndarray, ggml_type: int, n: int) -> np.ndarray:
+    raw = np.asarray(raw, np.uint8)
+    if ggml_type == GGML_F32:
+        return raw.view(np.float32)[:n].copy()
+    if ggml_type == GGML_F16:
+        return raw.view(np.float16)[:n].astype(np.float32)
+    if ggml_type == GGML_BF16:
+        return (raw.view(np.uint16)[:n].astype(np.uint32) << 16).view(np.float32)
+    return {GGML_Q8_0: dequantize_q8_0, GGML_Q4_K: dequantize_q4_k, GGML_Q6_K: dequantize_q6_k}[ggml_type](raw, n)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GGUF v3 container
+# ---------------------------------------------------------------------------------------------------------
+GGUF_MAGIC = 0x46554747
+(T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I64, T_F64) = range(13)
+_SCALAR = {T_U8: "<B", T_I8: "<b", T_U16: "<H", T_I16: "<h", T_U32: "<I", T_I32: "<i", T_F32: "<f", T_BOOL: "<B",
+           T_U64: "<Q", T_I64: "<q", T_F64: "<d"}
+
+
+def _wstr(s: str) -> bytes:
+    b = s.encode()
+    return struct.pack("<Q", len(b)) + b
+
+
+def _wval(v) -> bytes:
+    """v = (type, value) or (T_ARR, (elem_type, [values]))."""
+    t, x = v
+    if t == T_STR:
+        return struct.pack("<I", t) + _wstr(x)
+    if t == T_ARR:
+        et, items = x
+        body = b"".join(_wstr(i) if et == T_STR else struct.pack(_SCALAR[et], i) for i in items)
+        return struct.pack("<I", t) + struct.pack("<IQ", et, len(items)) + body
+    return struct.pack("<I", t) + struct.pack(_SCALAR[t], x)
+
+
+def write_gguf(path: str, metadata: Dict[str, tuple], tensors: List[Tuple[str, np.ndarray, int]], alignment: int = 32):
+    """tensors: (name, f32 array [rows, cols] or [n], ggml_type).  GGUF dims are stored innermost-first."""
+    infos, blobs, off = [], [], 0
+    for name, arr, gt in tensors:
+        arr = np.asarray(arr, np.float32)
+        raw = quantize(arr, gt)
+        dims = list(arr.shape)[::-1]
+        infos.append((name, dims, gt, off))
+        blobs.append(raw)
+        off += (raw.size + alignment - 1) // alignment * alignment
+    md = dict(metadata)
+    md.setdefault("general.alignment", (T_U32, alignment))
+    head = struct.pack("<IIQQ", GGUF_MAGIC, 3, len(infos), len(md))
+    for k, v in md.items():
+        head += _wstr(k) + _wval(v)
+    for name, dims, gt, o in infos:
+        head += _wstr(name) + struct.pack("<I", len(dims)) + b"".join(struct.pack("<Q", d) for d in dims) + struct.pack("<IQ", gt, o)
+    pad = (-len(head)) % alignment
+    with open(path, "wb") as f:
+        f.write(head + b"\0" * pad)
+        for raw in blobs:
+            f.write(raw.tobytes())
+            f.write(b"\0" * ((-raw.size) % alignment))
+
+
+def read_gguf(path: str):
+    """-> (metadata {key: python value}, tensors {name: (shape outermost-first, ggml_type, raw uint8)})."""
+    data = np.fromfile(path, dtype=np.uint8)
+    buf = data.tobytes()
+    pos = 0
+
+    def rd(fmt):
+        nonlocal pos
+        v = struct.unpack_from(fmt, buf, pos)
+        pos += struct.calcsize(fmt)
+        return v if len(v) > 1 else v[0]
+
+    def rstr():
+        nonlocal pos
+        n = rd("<Q")
+        s = buf[pos:pos + n].decode()
+        pos += n
+        return s
+
+    def rval(t):
+        if t == T_STR:
+            return rstr()
+        if t == T_ARR:
+            et, n = rd("<IQ")
+            return [rval(et) for _ in range(n)]
+        return rd(_SCALAR[t])
+
+    magic, version, n_t, n_kv = rd("<IIQQ")
+    assert magic == GGUF_MAGIC and version in (2, 3), (hex(magic), version)
+    md = {}
+    for _ in range(n_kv):
+        k = rstr()
+        md[k] = rval(rd("<I"))
+    infos = []
+    for _ in range(n_t):
+        name = rstr()
+        nd = rd("<I")
+        dims = [rd("<Q") for _ in range(nd)]
+        gt, off = rd("<IQ")
+        infos.append((name, dims[::-1], gt, off))
+    align = md.get("general.alignment", 32)
+    base = (pos + align - 1) // align * align
+    out = {}
+    for name, shape, gt, off in infos:
+        n = int(np.prod(shape))
+        be, bb = BLOCK[gt]
+        nbytes = n // be * bb
+        out[name] = (tuple(shape), gt, data[base + off:base + off + nbytes])
+    return md, out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Qwen3 <-> GGUF naming (qwen3/modeling.rs:242-282, 593-606, 678-696, 821-960)
+# ---------------------------------------------------------------------------------------------------------
+def qwen3_gguf_names(cfg: dict) -> Dict[str, str]:
+    """HF safetensors name -> GGUF tensor name."""
+    m = {"model.embed_tokens.weight": "token_embd.weight", "model.norm.weight": "output_norm.weight"}
+    if not cfg.get("tie_word_embeddings", True):
+        m["lm_head.weight"] = "output.weight"
+    for i in range(cfg["num_hidden_layers"]):
+        p, g = f"model.layers.{i}.", f"blk.{i}."
+        m.update({p + "self_attn.q_proj.weight": g + "attn_q.weight", p + "self_attn.k_proj.weight": g + "attn_k.weight",
+                  p + "self_attn.v_proj.weight": g + "attn_v.weight", p + "self_attn.o_proj.weight": g + "attn_output.weight",
+                  p + "self_attn.q_norm.weight": g + "attn_q_norm.weight", p + "self_attn.k_norm.weight": g + "attn_k_norm.weight",
+                  p + "input_layernorm.weight": g + "attn_norm.weight", p + "post_attention_layernorm.weight": g + "ffn_norm.weight",
+                  p + "mlp.gate_proj.weight": g + "ffn_gate.weight", p + "mlp.up_proj.weight": g + "ffn_up.weight",
+                  p + "mlp.down_proj.weight": g + "ffn_down.weight"})
+    return m
+
+
+def qwen3_metadata(cfg: dict) -> Dict[str, tuple]:
+    a = "qwen3"
+    return {
+        "general.architecture": (T_STR, a),
+        f"{a}.block_count": (T_U32, cfg["num_hidden_layers"]),
+        f"{a}.embedding_length": (T_U32, cfg["hidden_size"]),
+        f"{a}.feed_forward_length": (T_U32, cfg["intermediate_size"]),
+        f"{a}.attention.head_count": (T_U32, cfg["num_attention_heads"]),
+        f"{a}.attention.head_count_kv": (T_U32, cfg["num_key_value_heads"]),
+        f"{a}.attention.key_length": (T_U32, cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]),
+        f"{a}.context_length": (T_U32, cfg.get("max_position_embeddings", 32768)),
+        f"{a}.attention.layer_norm_rms_epsilon": (T_F32, cfg.get("rms_norm_eps", 1e-6)),
+        f"{a}.rope.freq_base": (T_F32, cfg.get("rope_theta", 1e6)),
+    }
+
+
+def write_qwen3_gguf(path: str, cfg: dict, weights_f32: Dict[str, np.ndarray], type_of) -> Dict[str, np.ndarray]:
+    """type_of(gguf_name, shape) -> ggml type.  Returns the DEQUANTISED weights under their HF names: exactly what a
+    loader of this file must compute with (the oracle forward runs on these)."""
+    names = qwen3_gguf_names(cfg)
+    tensors, deq = [], {}
+    for hf, gg in names.items():
+        w = np.asarray(weights_f32[hf], np.float32)
+        gt = type_of(gg, w.shape)
+        if w.ndim == 1:
+            gt = GGML_F32
+        tensors.append((gg, w, gt))
+        deq[hf] = dequantize(quantize(w, gt), gt, w.size).reshape(w.shape)
+    write_gguf(path, qwen3_metadata(cfg), tensors)
+    return deq

@@ -1,0 +1,84 @@
+"""CPU: oracle/gguf_oracle.py -- ggml block formats (hand-built known answers + quantise/dequantise bounds) and the
+GGUF v3 container round trip."""
+import numpy as np
+import pytest
+
+from oracle import gguf_oracle as G
+
+
+def test_q8_0_known_block():
+    x = np.zeros(32, np.float32); x[0] = 127.0; x[1] = -63.5; x[2] = 0.49; x[3] = 2.5
+    raw = G.quantize_q8_0(x)
+    assert raw.size == 34 and raw[:2].view(np.float16)[0] == np.float16(1.0)
+    q = raw[2:].view(np.int8)
+    assert q[0] == 127 and q[1] == -64 and q[2] == 0 and q[3] == 3          # roundf: halves away from zero
+    np.testing.assert_array_equal(G.dequantize_q8_0(raw, 32)[:4], [127, -64, 0, 3])
+    assert G.dequantize_q8_0(G.quantize_q8_0(np.zeros(32)), 32).tolist() == [0.0] * 32
+
+
+def test_q4_k_known_block():
+    b = np.zeros(144, np.uint8)
+    b[0:2] = np.array([2.0], np.float16).view(np.uint8)       # d
+    b[2:4] = np.array([0.5], np.float16).view(np.uint8)       # dmin
+    s = b[4:16]
+    s[0] = 3; s[4] = 2                                        # sub-block 0: sc 3, m 2
+    s[1] = 1 | (1 << 6); s[5] = 4 | (2 << 6)                  # sub-block 1: sc 1, m 4; high bits feed sub-blocks 4/5
+    s[8] = (5 & 0xF) | ((7 & 0xF) << 4)                       # sub-block 4: sc = 5 | (s[0]>>6)<<4 = 5, m = 7 | (s[4]>>6)<<4 = 7
+    s[9] = (6 & 0xF) | ((1 & 0xF) << 4)                       # sub-block 5: sc = 6 | (1<<4) = 22, m = 1 | (2<<4) = 33
+    qs = b[16:]
+    qs[0] = 0x21                                              # weight 0: q 1 (sub-block 0); weight 32: q 2 (sub-block 1)
+    qs[64 + 3] = 0xF4                                         # weight 128+3: q 4 (sub-block 4); weight 160+3: q 15 (sub-block 5)
+    y = G.dequantize_q4_k(b, 256)
+    assert y[0] == 2.0 * 3 * 1 - 0.5 * 2 and y[1] == -1.0
+    assert y[32] == 2.0 * 1 * 2 - 0.5 * 4 and y[33] == -2.0
+    assert y[128 + 3] == 2.0 * 5 * 4 - 0.5 * 7 and y[128 + 4] == -3.5
+    assert y[160 + 3] == 2.0 * 22 * 15 - 0.5 * 33
+
+
+def test_q6_k_known_block():
+    b = np.zeros(210, np.uint8)
+    b[208:210] = np.array([0.5], np.float16).view(np.uint8)
+    sc = b[192:208].view(np.int8)
+    sc[:] = np.arange(1, 17)
+    sc[9] = -3
+    ql, qh = b[0:128], b[128:192]
+    ql[5] = 0x9C; qh[5] = 0b10_01_11_00                       # l=5: q1 = 0xC|0<<4, q3 = 0x9|(1<<4); q2/q4 take ql[37]
+    ql[37] = 0x07                                             # q2 = 7 | (3<<4) = 55, q4 = 0 | (2<<4) = 32
+    ql[64 + 20] = 0x01; qh[32 + 20] = 0b00_00_00_10           # second half, l=20 (is=1): q1 = 1 | (2<<4) = 33
+    y = G.dequantize_q6_k(b, 256)
+    assert y[5] == 0.5 * 1 * (12 - 32)                        # scale index 0
+    assert y[32 + 5] == 0.5 * 3 * (55 - 32)                   # scale index 2
+    assert y[64 + 5] == 0.5 * 5 * (25 - 32)                   # scale index 4
+    assert y[96 + 5] == 0.5 * 7 * (32 - 32)
+    assert y[128 + 20] == 0.5 * (-3) * (33 - 32)              # second half: scales 8.., is = 1 -> sc[9]
+    assert y[0] == 0.5 * 1 * (0 - 32)
+
+
+@pytest.mark.parametrize("name,tol", [("q8_0", 0.005), ("q6_k", 0.03), ("q4_k", 0.09), ("f16", 1e-3), ("bf16", 4e-3), ("f32", 0.0)])
+def test_quantise_dequantise_bound(name, tol):
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(4096) * 0.05).astype(np.float32)
+    gt = G.TYPE_NAMES[name]
+    raw = G.quantize(x, gt)
+    assert raw.size == x.size // G.BLOCK[gt][0] * G.BLOCK[gt][1]
+    y = G.dequantize(raw, gt, x.size)
+    assert np.abs(y - x).max() <= tol * np.abs(x).max() + 1e-12
+    np.testing.assert_array_equal(G.dequantize(G.quantize(y, gt), gt, x.size), y) if name in ("q8_0", "f16", "bf16", "f32") else None
+
+
+def test_gguf_container_round_trip(tmp_path):
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((8, 256)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    md = {"general.architecture": (G.T_STR, "qwen3"), "qwen3.block_count": (G.T_U32, 7), "qwen3.rope.freq_base": (G.T_F32, 1e6),
+          "tokenizer.ggml.tokens": (G.T_ARR, (G.T_STR, ["a", "bc"])), "x.arr": (G.T_ARR, (G.T_I32, [1, -2, 3]))}
+    p = str(tmp_path / "t.gguf")
+    G.write_gguf(p, md, [("blk.0.attn_q.weight", a, G.GGML_Q4_K), ("output_norm.weight", b, G.GGML_F32), ("w8", a, G.GGML_Q8_0)])
+    m2, t2 = G.read_gguf(p)
+    assert m2["general.architecture"] == "qwen3" and m2["qwen3.block_count"] == 7 and m2["tokenizer.ggml.tokens"] == ["a", "bc"]
+    assert m2["x.arr"] == [1, -2, 3] and abs(m2["qwen3.rope.freq_base"] - 1e6) < 1
+    shape, gt, raw = t2["blk.0.attn_q.weight"]
+    assert shape == (8, 256) and gt == G.GGML_Q4_K
+    np.testing.assert_array_equal(raw, G.quantize(a, G.GGML_Q4_K))
+    np.testing.assert_array_equal(G.dequantize(t2["output_norm.weight"][2], G.GGML_F32, 64), b)
+    assert t2["w8"][0] == (8, 256) and t2["w8"][2].size == 8 * 8 * 34

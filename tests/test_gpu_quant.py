@@ -1,0 +1,117 @@
+"""GPU: quantised weights -- GGUF checkpoints (Q8_0 / Q4_K / Q6_K, merged and mixed-type projections, quantised
+embedding, tied and untied heads) and in-situ Q8_0 -- against the f32 oracle run on the DEQUANTISED weights
+(LinearLayer::Quantized = dequantise-to-f32 matmul, ops/linear.rs:18-51)."""
+import numpy as np
+import pytest
+
+from crane_amd import configs, synth
+from oracle import gguf_oracle as G
+from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+
+pytestmark = pytest.mark.gpu
+
+LINEARS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+def rel(a, ref):
+    return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+
+def _types(kind):
+    if kind in ("q8_0", "q4_k", "q6_k"):
+        t = G.TYPE_NAMES[kind]
+        return lambda name, shape: t
+    # llama.cpp-style mixture: different types inside qkv and inside gate/up, quantised embedding, q8_0 head
+    def mixed(name, shape):
+        if "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
+            return G.GGML_Q6_K
+        if "attn_output" in name or name == "output.weight":
+            return G.GGML_Q8_0
+        return G.GGML_Q4_K
+    return mixed
+
+
+def _check(m, oracle, V, n_prompt=19, n_decode=6):
+    ids = configs.synthetic_prompt(n_prompt, V)
+    ref = oracle.forward(ids, 0)
+    got = m.forward_step(ids, 0).reshape(-1)
+    assert rel(got, ref) < 2e-4, rel(got, ref)
+    tok = int(ref.argmax())
+    for step in range(n_decode):
+        ref = oracle.forward([tok], n_prompt + step)
+        got, greedy = m.forward_step_greedy([tok], n_prompt + step), None
+        lg = m.read_logits()
+        assert rel(lg, ref) < 2e-4, (step, rel(lg, ref))
+        assert int(got) == int(lg.argmax()) == int(ref.argmax())
+        tok = int(ref.argmax())
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed"])
+def test_gguf_checkpoint_matches_oracle_on_dequantised_weights(tmp_path, name, kind):
+    from crane_amd.backend import Model
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / f"{name}-{kind}.gguf")
+    deq = G.write_qwen3_gguf(path, cfg, w, _types(kind))
+    if cfg.get("tie_word_embeddings", True):
+        deq["lm_head.weight"] = deq["model.embed_tokens.weight"]
+    oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    try:
+        assert m.vocab_size == cfg["vocab_size"] and m.num_layers() == cfg["num_hidden_layers"]
+        _check(m, oracle, cfg["vocab_size"])
+        # generate() and the engine's sequential path run on the quantised decode step too
+        from crane_amd.backend import GenerationConfig
+        ids = configs.synthetic_prompt(7, cfg["vocab_size"])
+        out = m.generate(ids, GenerationConfig.greedy(5))
+        assert out[len(ids):] == oracle.generate(ids, 5)[len(ids):]
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
+def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name):
+    """ISQ (ops/linear.rs:83-116, CRANE_ISQ): the device quantiser must reproduce ggml's quantize_row_q8_0_ref."""
+    from crane_amd.backend import Model
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    deq = dict(w)
+    for k, v in w.items():
+        if any(k.endswith(f"{l}.weight") for l in LINEARS) or (k == "lm_head.weight" and not cfg.get("tie_word_embeddings", True)):
+            deq[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
+    oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
+    for how in ("opt", "env"):
+        if how == "env":
+            monkeypatch.setenv("CRANE_ISQ", "q8_0")
+            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32")
+            monkeypatch.delenv("CRANE_ISQ")
+        else:
+            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
+        try:
+            _check(m, oracle, cfg["vocab_size"])
+        finally:
+            m.close()
+
+
+def test_quant_errors():
+    from crane_amd._lib import CraneError
+    from crane_amd.backend import Model
+    import os
+    cfg = configs.get_config("tiny-qwen3")
+    os.environ["CRANE_ISQ"] = "q4k"
+    try:
+        with pytest.raises(CraneError, match="only q8_0"):
+            Model.synthetic(cfg, seed=0)
+    finally:
+        del os.environ["CRANE_ISQ"]
+    with pytest.raises(CraneError):
+        Model.from_pretrained("/nonexistent/model.gguf")
+    m = Model.synthetic(cfg, seed=0, isq="q8_0", max_seqs=4)
+    try:
+        s = m.seq_alloc()
+        m.seq_forward(s, [1, 2, 3], 0, want_logits=False)
+        with pytest.raises(CraneError, match="quantised"):
+            m.step_batch_decode([0, s], [1, 2])
+    finally:
+        m.close()
