@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--isq", default=None, help="in-situ weight quantisation (q8_0): a DIFFERENT workload than the bf16 headline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,7 +84,7 @@ def main():
     m = Model.synthetic(cfg, seed=0, device=(local_rank % ndev) if world > 1 else 0,
                         max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1,
                         use_graph=-1 if args.no_graph else 0,
-                        tp_rank=rank if world > 1 else 0, tp_size=world, tp_unique_id=uid)
+                        tp_rank=rank if world > 1 else 0, tp_size=world, tp_unique_id=uid, isq=args.isq)
     m.debug_fill_kv(ctx, seed=1)            # synthetic KV for positions [0, ctx): inputs resident in HBM
     first = 3
     if W > 0:
@@ -123,7 +124,7 @@ def main():
         # PMC traffic cannot be collected inside this process: it comes from the committed rocprofv3 --pmc passes
         # (profiles/r01_pmc_traffic_decode.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch
         try:
-            if args.model == "qwen3-8b":
+            if args.model == "qwen3-8b" and not args.isq:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_decode.json")))
                 for r in pm["kernels"]:
                     if "gemv_bf16_kernel<1, 2," in r["kernel"]:
@@ -142,6 +143,8 @@ def main():
     prefill = None
     try:
         import numpy as np
+        if args.isq:
+            raise RuntimeError("quantised weights prefill token-serially; not measured here")
         ids = configs.synthetic_prompt(1024, cfg["vocab_size"])
         m.clear_kv_cache(); m.forward_step_greedy(ids, 0)            # warm-up (allocates chunk buffers)
         m.clear_kv_cache()
@@ -155,16 +158,17 @@ def main():
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.model, ctx)
 
+    wdt = args.isq or "bf16"
     if rank == 0:
         line = {
-            "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if args.model == "qwen3-8b"
-                      else f"decode tokens/s {args.model} bf16 greedy, ctx {ctx}",
+            "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if (args.model == "qwen3-8b" and not args.isq)
+                      else f"decode tokens/s {args.model} {wdt} greedy, ctx {ctx}",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": n, "steps": K, "warmup": W,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if n > 1 else "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if not args.isq else f"{args.isq} weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
-                                   f"bf16 weights + bf16 paged KV, f32 activations",
+                                   f"{wdt} weights + bf16 paged KV, f32 activations",
                        "parallelism": f"tp{n}", "graph": not args.no_graph},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "cpu_baseline": cpu,
         }
