@@ -28,16 +28,17 @@ TYPE_NAMES = {"f32": GGML_F32, "f16": GGML_F16, "bf16": GGML_BF16, "q8_0": GGML_
 # Q8_0
 # ---------------------------------------------------------------------------------------------------------
 def quantize_q8_0(x: np.ndarray) -> np.ndarray:
-    """quantize_row_q8_0_ref: d = amax / 127 (stored f16), q = round(x * (1/d)) with id = 0 when d == 0."""
+    """quantize_row_q8_0_ref: d = amax / 127 (stored f16), q = roundf(x * id) with id = d ? 1/d : 0."""
     x = np.asarray(x, np.float32).reshape(-1, 32)
     amax = np.abs(x).max(axis=1)
     d = (amax / np.float32(127.0)).astype(np.float32)
     idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0)).astype(np.float32)
-    t = x * idv[:, None]                                     # roundf: ties away from zero
-    q = np.where(np.abs(t - np.trunc(t)) == 0.5, np.trunc(t) + np.sign(t), np.rint(t)).astype(np.int8)
+    t = (x.reshape(-1) * np.repeat(idv, 32)).astype(np.float32)        # f32 product like the C code
+    t64 = t.astype(np.float64)
+    q = np.copysign(np.floor(np.abs(t64) + 0.5), t64).astype(np.int8)  # roundf: ties away from zero (exact in f64)
     out = np.zeros((x.shape[0], 34), np.uint8)
     out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
-    out[:, 2:] = q.view(np.uint8)
+    out[:, 2:] = q.view(np.uint8).reshape(-1, 32)
     return out.reshape(-1)
 
 

@@ -1,0 +1,39 @@
+"""Dequant-GEMV bandwidth per ggml type on Qwen3-8B layer shapes: writes a 4-layer GGUF (random weights, quantised by
+oracle/gguf_oracle.py), loads it through cm_create and times each projection with cm_bench_kernel.
+usage: python tools/bench_gguf.py q4_k [layers]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from oracle import gguf_oracle as G
+from crane_amd.backend import Model
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "q4_k"
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cfg = dict(model_type="qwen3", hidden_size=4096, intermediate_size=12288, num_attention_heads=32, num_key_value_heads=8,
+           head_dim=128, num_hidden_layers=L, vocab_size=8192, tie_word_embeddings=True, rms_norm_eps=1e-6, rope_theta=1e6,
+           max_position_embeddings=4096)
+gt = G.TYPE_NAMES[kind]
+rng = np.random.default_rng(0)
+t0 = time.time()
+tensors = []
+for hf, gg in G.qwen3_gguf_names(cfg).items():
+    if "norm" in gg:
+        n = cfg["head_dim"] if ("q_norm" in gg or "k_norm" in gg) else cfg["hidden_size"]
+        tensors.append((gg, np.ones(n, np.float32), G.GGML_F32)); continue
+    H, I, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"]
+    shape = {"token_embd": (cfg["vocab_size"], H), "attn_q": (32 * D, H), "attn_k": (8 * D, H), "attn_v": (8 * D, H), "attn_output": (H, 32 * D),
+             "ffn_gate": (I, H), "ffn_up": (I, H), "ffn_down": (H, I)}[gg.split(".")[-2]]
+    tensors.append((gg, (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(shape[1])).astype(np.float32), gt))
+path = f"/tmp/bench_{kind}.gguf"
+G.write_gguf(path, G.qwen3_metadata(cfg), tensors)
+del tensors
+print(f"wrote {path} ({os.path.getsize(path) / 1e6:.0f} MB) in {time.time() - t0:.1f}s", flush=True)
+m = Model.from_pretrained(path, max_seq_len=2048)
+for which in ["qkv", "o", "gate_up", "down"]:
+    r = m.bench_kernel(which, 360)
+    print(f"{kind} {which:8s} {r['ms'] * 1e3:8.2f} us  {r['bytes'] / r['ms'] / 1e9:6.2f} TB/s  ({r['bytes'] / 1e6:.1f} MB)")
+m.debug_fill_kv(1024, seed=1)
+toks, ms = m.bench_decode(3, 64)
+print(f"{kind} {L}-layer decode step {ms / 64 * 1e3:.1f} us")
+m.close()
+os.remove(path)
