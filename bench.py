@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kv", default="bf16", choices=["bf16", "f32", "int8", "int4"], help="KV cache element type (bf16 = headline)")
     ap.add_argument("--isq", default=None, help="in-situ weight quantisation (q8_0): a DIFFERENT workload than the bf16 headline")
     args = ap.parse_args()
 
@@ -84,7 +85,7 @@ def main():
     m = Model.synthetic(cfg, seed=0, device=(local_rank % ndev) if world > 1 else 0,
                         max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1,
                         use_graph=-1 if args.no_graph else 0,
-                        tp_rank=rank if world > 1 else 0, tp_size=world, tp_unique_id=uid, isq=args.isq)
+                        tp_rank=rank if world > 1 else 0, tp_size=world, tp_unique_id=uid, isq=args.isq, kv_dtype=args.kv)
     m.debug_fill_kv(ctx, seed=1)            # synthetic KV for positions [0, ctx): inputs resident in HBM
     first = 3
     if W > 0:
@@ -161,14 +162,14 @@ def main():
     wdt = args.isq or "bf16"
     if rank == 0:
         line = {
-            "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if (args.model == "qwen3-8b" and not args.isq)
-                      else f"decode tokens/s {args.model} {wdt} greedy, ctx {ctx}",
+            "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if (args.model == "qwen3-8b" and not args.isq and args.kv == "bf16" and ctx == 1024)
+                      else f"decode tokens/s {args.model} {wdt} weights / {args.kv} KV greedy, ctx {ctx}",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": n, "steps": K, "warmup": W,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if n > 1 else "weak", "vs_baseline": None,
             "dtype": "bf16" if not args.isq else f"{args.isq} weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
-                                   f"{wdt} weights + bf16 paged KV, f32 activations",
+                                   f"{wdt} weights + {args.kv} paged KV, f32 activations",
                        "parallelism": f"tp{n}", "graph": not args.no_graph},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "cpu_baseline": cpu,
         }

@@ -101,7 +101,7 @@ class Model:
         o.max_seq_len, o.max_seqs, o.kv_block_size = max_seq_len, max_seqs, kv_block_size
         o.kv_pool_tokens, o.use_graph = kv_pool_tokens, use_graph
         o.prefill_chunk, o.prefill_split = prefill_chunk, prefill_split
-        o.kv_dtype = {"bf16": 0, "f32": 1}[kv_dtype]
+        o.kv_dtype = {"bf16": 0, "f32": 1, "int8": 2, "int4": 3}[kv_dtype]
         o.isq = {None: 0, "none": 0, "q8_0": 8}[isq.lower() if isinstance(isq, str) else isq]     # --quant / CRANE_ISQ
         keep = None
         if tp_unique_id is not None:

@@ -43,6 +43,7 @@ struct AttnDecArgs {
     int q_off, k_off, v_off;     // element offsets of q / k / v inside qkv
     int qkv_stride, bt_stride;   // batched step: per-sequence strides of qkv rows and block tables
     int Hkv, page, max_pages, rot_dim;
+    size_t page_bytes = 0;       // int8 / int4 KV: bytes of one page (codes [Hkv][PAGE][row] + f32 scales [Hkv][PAGE])
     float eps, scale;
 };
 
@@ -156,7 +157,7 @@ void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, 
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, int n_seq, hipStream_t s);
 bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, bool kv_f32, int n_seq, hipStream_t s);
-bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, int out_stride, int n_seq,
+bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq,
                         hipStream_t s);
 void launch_gdn(const GdnArgs& a, hipStream_t s);
 void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hipStream_t s);
@@ -165,6 +166,7 @@ void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hi
 // dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))
 void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncols, int row0, int col0,
                        int full_cols, uint32_t tseed, float mul, float off, hipStream_t s);
+void launch_kv_fill_quant(void* pool, const int32_t* pages, int npages, size_t page_bytes, size_t code_bytes, uint32_t tseed, hipStream_t s);
 void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s);
 

@@ -16,7 +16,7 @@
 
 namespace cm {
 
-template <int D, int NREP, bool KVF32>
+template <int D, int NREP, int KVT>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     constexpr int LPR = D / 8;            // lanes per token row
     constexpr int RPW = 64 / LPR;         // rows per wave
@@ -43,17 +43,36 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     // `pos`: their block-table entries and K/V rows are requested first (pos, q, RoPE rows load
     // meanwhile); validity (t <= pos) is a mask.  Perfectly balanced for any context length.
     const int tok_in_chunk = wave * RPW + r;
+    // KVT: 0 bf16, 1 f32 (element offsets into [pages][Hkv][PAGE][D]); 2 int8, 3 int4 (per-token symmetric codes +
+    // f32 scale, qwen3_5/kv_cache.rs:253-301; byte offsets, each page = codes [Hkv][PAGE][row] then scales [Hkv][PAGE])
+    constexpr bool KVQ = KVT >= 2;
+    constexpr bool KVF32 = KVT == 1;
+    constexpr int ROWB = KVT == 2 ? D : D / 2;            // code bytes per token row (quantised modes)
     auto kv_off = [&](int t) -> size_t {
         int pi = t / a.page;
         pi = pi < a.max_pages ? pi : a.max_pages - 1;     // speculative loads stay inside the table
         const int page = block_table[pi];
+        if (KVQ) return (size_t)page * a.page_bytes + (size_t)(kvh * a.page + (t % a.page)) * ROWB;
         return ((size_t)(page * a.Hkv + kvh) * a.page + (t % a.page)) * D + dimbase;
     };
-    struct KV8 { u32x4 a, b; };
-    auto ld_kv = [&](const void* pool, size_t off) -> KV8 {
+    auto sc_off = [&](int t) -> size_t {                  // byte offset of the row's f32 scale
+        int pi = t / a.page;
+        pi = pi < a.max_pages ? pi : a.max_pages - 1;
+        return (size_t)block_table[pi] * a.page_bytes + (size_t)a.Hkv * a.page * ROWB + (size_t)(kvh * a.page + (t % a.page)) * 4;
+    };
+    struct KV8 { u32x4 a, b; float s; };
+    auto ld_kv = [&](const void* pool, size_t off, int t) -> KV8 {
         KV8 v;
-        if (KVF32) { v.a = ld16((const float*)pool + off); v.b = ld16((const float*)pool + off + 4); }
-        else { v.a = ld16((const uint16_t*)pool + off); v.b = v.a; }
+        v.s = 1.f;
+        if (KVT == 1) { v.a = ld16((const float*)pool + off); v.b = ld16((const float*)pool + off + 4); }
+        else if (KVT == 0) { v.a = ld16((const uint16_t*)pool + off); v.b = v.a; }
+        else {
+            const uint8_t* p = (const uint8_t*)pool;
+            if (KVT == 2) { const u32x2 c = *(const u32x2*)(p + off + dimbase); v.a = (u32x4){c[0], c[1], 0, 0}; }
+            else v.a = (u32x4){*(const uint32_t*)(p + off + (dimbase >> 1)), 0, 0, 0};
+            v.b = v.a;
+            v.s = *(const float*)(p + sc_off(t));
+        }
         return v;
     };
     KV8 kq[2], vq[2];
@@ -62,8 +81,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     for (int u = 0; u < 2; ++u) {
         tt[u] = CT * (split + nsplit * u) + tok_in_chunk;
         const size_t off = kv_off(tt[u]);
-        kq[u] = ld_kv(a.kpool, off);
-        vq[u] = ld_kv(a.vpool, off);
+        kq[u] = ld_kv(a.kpool, off, tt[u]);
+        vq[u] = ld_kv(a.vpool, off, tt[u]);
     }
     const int pos = st->pos;
     const int rpos = pos + st->rsv[0];          // rotary position = cache position + MRoPE delta (vlm.rs:294-301)
@@ -111,6 +130,31 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
         } else {
             float* dst = (item == NREP) ? knew : vnew;
             void* pool = (item == NREP) ? a.kpool : a.vpool;
+            if (KVQ) {
+                // quantize_per_token (kv_cache.rs:253-268): scale = amax * (1/qmax) + 1e-8, code = round(x / scale) + offset;
+                // attention reads the DEQUANTISED value of the new token too (append() returns dequantize(full cache), :318-322)
+                constexpr float QMAX = KVT == 2 ? 127.f : 7.f, OFFS = KVT == 2 ? 128.f : 8.f;
+                float amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) amax = fmaxf(amax, fabsf(xv[j]));
+                amax = wave_max(amax);
+                const float scale = __fadd_rn(__fmul_rn(amax, (float)(1.0 / (double)QMAX)), 1e-8f);
+                uint8_t* pb = (uint8_t*)pool;
+                const size_t roff = owner ? kv_off(pos) : 0;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int d = lane + 64 * j;
+                    const float code = roundf(__fdiv_rn(xv[j], scale)) + OFFS;
+                    dst[d] = __fmul_rn(code - OFFS, scale);
+                    const uint32_t ci = (uint32_t)(int)code;
+                    if (KVT == 2) { if (owner) pb[roff + d] = (uint8_t)ci; }
+                    else {
+                        const uint32_t hi = (uint32_t)__shfl_down((int)ci, 1);      // byte = lo + hi*16 for (even, odd) pairs
+                        if (owner && !(lane & 1)) pb[roff + (d >> 1)] = (uint8_t)(ci | (hi << 4));
+                    }
+                }
+                if (owner && lane == 0) *(float*)(pb + sc_off(pos)) = scale;
+            } else {
             const size_t eoff = owner ? ((size_t)(block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
@@ -123,6 +167,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
                     dst[d] = bf16_to_f32(b);
                     if (owner) ((uint16_t*)pool)[eoff + d] = b;
                 }
+            }
             }
         }
     }
@@ -149,7 +194,17 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
         float kf[8], vf[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (KVF32) {
+            if (KVT == 2) {           // dequantize_per_token: (code - 128) * scale
+                kf[e] = __fmul_rn((float)((kqv.a[0] >> (8 * e)) & 0xFFu) - 128.f, kqv.s);
+                kf[4 + e] = __fmul_rn((float)((kqv.a[1] >> (8 * e)) & 0xFFu) - 128.f, kqv.s);
+                vf[e] = __fmul_rn((float)((vqv.a[0] >> (8 * e)) & 0xFFu) - 128.f, vqv.s);
+                vf[4 + e] = __fmul_rn((float)((vqv.a[1] >> (8 * e)) & 0xFFu) - 128.f, vqv.s);
+            } else if (KVT == 3) {    // nibbles: element 2i = low, 2i+1 = high of byte i
+                kf[2 * e] = __fmul_rn((float)((kqv.a[0] >> (8 * e)) & 0xFu) - 8.f, kqv.s);
+                kf[2 * e + 1] = __fmul_rn((float)((kqv.a[0] >> (8 * e + 4)) & 0xFu) - 8.f, kqv.s);
+                vf[2 * e] = __fmul_rn((float)((vqv.a[0] >> (8 * e)) & 0xFu) - 8.f, vqv.s);
+                vf[2 * e + 1] = __fmul_rn((float)((vqv.a[0] >> (8 * e + 4)) & 0xFu) - 8.f, vqv.s);
+            } else if (KVF32) {
                 kf[e] = __uint_as_float(kqv.a[e]); kf[4 + e] = __uint_as_float(kqv.b[e]);
                 vf[e] = __uint_as_float(vqv.a[e]); vf[4 + e] = __uint_as_float(vqv.b[e]);
             } else {
@@ -189,8 +244,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
             tt[u] = CT * (split + nsplit * (j + u)) + tok_in_chunk;
             if (u == 0 || second) {
                 const size_t off = kv_off(tt[u]);
-                kq[u] = ld_kv(a.kpool, off);
-                vq[u] = ld_kv(a.vpool, off);
+                kq[u] = ld_kv(a.kpool, off, tt[u]);
+                vq[u] = ld_kv(a.vpool, off, tt[u]);
             }
         }
         consume(kq[0], vq[0], tt[0]);
@@ -497,11 +552,13 @@ bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, boo
 }
 
 template <int D>
-static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32, int n_seq, hipStream_t s) {
+static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode, int n_seq, hipStream_t s) {
     dim3 grid(nsplit, a.Hkv, n_seq), block(256);
 #define CM_ATTN_CASE(N) \
-    case N: if (kv_f32) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, true>), grid, block, 0, s, a); \
-            else hipLaunchKernelGGL((attn_decode_split_kernel<D, N, false>), grid, block, 0, s, a); return true;
+    case N: if (kv_mode == 1) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 1>), grid, block, 0, s, a); \
+            else if (kv_mode == 2) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 2>), grid, block, 0, s, a); \
+            else if (kv_mode == 3) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 3>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 0>), grid, block, 0, s, a); return true;
     switch (nrep) {
         CM_ATTN_CASE(1) CM_ATTN_CASE(2) CM_ATTN_CASE(3) CM_ATTN_CASE(4) CM_ATTN_CASE(6) CM_ATTN_CASE(8)
         default: return false;
@@ -509,14 +566,14 @@ static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, bool kv_f32
 #undef CM_ATTN_CASE
 }
 
-bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, bool kv_f32, float* out, int out_stride, int n_seq,
+bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq,
                         hipStream_t s) {
     if (D == 128) {
-        if (!launch_split<128>(a, nrep, nsplit, kv_f32, n_seq, s)) return false;
+        if (!launch_split<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else if (D == 256) {
-        if (!launch_split<256>(a, nrep, nsplit, kv_f32, n_seq, s)) return false;
+        if (!launch_split<256>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else {

@@ -40,6 +40,25 @@ __global__ void kv_fill_kernel(T* __restrict__ pool, const int32_t* __restrict__
     }
 }
 
+// quantised KV pages (bench set-up): random codes, a fixed plausible per-token scale
+__global__ void kv_fill_quant_kernel(uint8_t* __restrict__ pool, const int32_t* __restrict__ pages, int npages, size_t page_bytes,
+                                     size_t code_bytes, uint32_t tseed) {
+    const size_t words = page_bytes / 4, total = (size_t)npages * words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / words);
+        const size_t w = i % words;
+        uint32_t v = fmix32((uint32_t)i * 0x9E3779B1u + tseed);
+        if (w * 4 >= code_bytes) v = __float_as_uint(0.02f);
+        ((uint32_t*)(pool + (size_t)pages[p] * page_bytes))[w] = v;
+    }
+}
+void launch_kv_fill_quant(void* pool, const int32_t* pages, int npages, size_t page_bytes, size_t code_bytes, uint32_t tseed, hipStream_t s) {
+    const size_t total = (size_t)npages * (page_bytes / 4);
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kv_fill_quant_kernel, dim3(blocks), dim3(256), 0, s, (uint8_t*)pool, pages, npages, page_bytes, code_bytes, tseed);
+}
+
 void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s) {
     const size_t total = (size_t)npages * page_elems;

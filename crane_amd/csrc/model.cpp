@@ -212,9 +212,10 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     use_graph = opts.use_graph >= 0;
-    if (opts.kv_dtype != CM_KV_BF16 && opts.kv_dtype != CM_KV_F32) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
-    kv_f32 = opts.kv_dtype == CM_KV_F32;
-    kv_esize = kv_f32 ? 4 : 2;
+    if (opts.kv_dtype > CM_KV_INT4) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
+    kv_mode = (int)opts.kv_dtype;
+    kv_f32 = kv_mode == CM_KV_F32;
+    kv_esize = kv_f32 ? 4 : (kv_mode >= CM_KV_INT8 ? 1 : 2);
     seqs.resize((size_t)max_seqs + 1);
     seqs[0].used = true;
 }
@@ -261,8 +262,9 @@ void Model::alloc_runtime() {
     kv_index.assign((size_t)cfg.L, -1);
     n_kv_layers = 0;
     for (int i = 0; i < cfg.L; ++i) if (cfg.layer_full(i)) kv_index[(size_t)i] = n_kv_layers++;
-    const size_t pool_elems = (size_t)n_kv_layers * 2 * n_pages * page_elems;
-    kv_pool = (uint8_t*)dalloc<uint16_t>(pool_elems * (kv_esize / 2));
+    kv_row_bytes = kv_mode == CM_KV_F32 ? (size_t)D * 4 : (kv_mode == CM_KV_INT8 ? (size_t)D : (kv_mode == CM_KV_INT4 ? (size_t)D / 2 : (size_t)D * 2));
+    page_bytes = (size_t)Hkv_l * page * (kv_row_bytes + (kv_mode >= CM_KV_INT8 ? 4 : 0));
+    kv_pool = (uint8_t*)dalloc<uint16_t>(((size_t)n_kv_layers * 2 * n_pages * page_bytes + 1) / 2);
     free_pages.resize((size_t)n_pages);
     for (int64_t i = 0; i < n_pages; ++i) free_pages[(size_t)i] = (int32_t)(n_pages - 1 - i);
     page_ref.assign((size_t)n_pages, 0);
@@ -370,9 +372,9 @@ int Model::seq_fork(int src) {
         page_ref[(size_t)newp] = 1;
         page_ref[(size_t)oldp]--;
         b.pages.back() = newp;
-        const size_t pitch = (size_t)n_pages * page_elems * kv_esize;
-        CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_elems * kv_esize, pitch, kv_pool + (size_t)oldp * page_elems * kv_esize, pitch,
-                                page_elems * kv_esize, (size_t)n_kv_layers * 2, hipMemcpyDeviceToDevice, stream));
+        const size_t pitch = (size_t)n_pages * page_bytes;
+        CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_bytes, pitch, kv_pool + (size_t)oldp * page_bytes, pitch,
+                                page_bytes, (size_t)n_kv_layers * 2, hipMemcpyDeviceToDevice, stream));
     }
     return d;
 }
@@ -409,7 +411,7 @@ void Model::activate(int s) {
 uint64_t Model::kv_bytes() const {
     uint64_t pages_used = 0;
     for (auto r : page_ref) if (r > 0) ++pages_used;
-    return pages_used * page_elems * kv_esize * 2ull * (uint64_t)n_kv_layers;
+    return pages_used * page_bytes * 2ull * (uint64_t)n_kv_layers;
 }
 
 uint64_t Model::decode_bytes_per_token(size_t ctx) const {
@@ -421,7 +423,7 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
         if (cfg.layer_full(i)) {
             const uint64_t qrows = (uint64_t)(cfg.hybrid ? 2 * Hq_l : Hq_l) * D;
             w_elems += (qrows + 2ull * Hkv_l * D) * H + H * (uint64_t)Hq_l * D + (cfg.qk_norm ? 2 * D : 0) + mlp;
-            extra += 2ull * Hkv_l * D * ctx * kv_esize;
+            extra += 2ull * Hkv_l * ctx * (kv_row_bytes + (kv_mode >= CM_KV_INT8 ? 4 : 0));
         } else {
             w_elems += (uint64_t)in_proj_rows * H + H * (uint64_t)cfg.value_dim() + mlp;
             extra += 2ull * cfg.NV * cfg.Kd * cfg.Vd * 4 + 2ull * cfg.conv_dim() * (cfg.conv_k - 1) * 4 +
@@ -483,11 +485,11 @@ void Model::enqueue_decode_step(bool advance) {
         a.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; a.v_off = a.k_off + Hkv_l * D;
         a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr;
         a.rot_dim = cfg.rot_dim;
-        a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-        const bool heads = attn_variant == 1;      // short context: per-head blocks, merge fused into o_proj's prologue
+        a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+        const bool heads = attn_variant == 1 && kv_mode < CM_KV_INT8;      // short context: per-head blocks, merge fused into o_proj's prologue
         if (heads) {
             if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
-        } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
@@ -532,8 +534,8 @@ void Model::enqueue_quant_layer(int li) {
     a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
     a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
     a.q_off = 0; a.k_off = Hq_l * D; a.v_off = a.k_off + Hkv_l * D; a.gate = nullptr; a.rot_dim = cfg.rot_dim;
-    a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-    if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+    a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+    if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
     qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
     if (!w.split_gate_up) {
         qg(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, x, w.ln2, hbuf, nullptr);
@@ -773,7 +775,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
         int64_t longest = 0;
         for (int b = 0; b < nb; ++b) longest = std::max(longest, seq(sq[g0 + b]).len + 1);
-        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max;
+        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && kv_mode < CM_KV_INT8;
         for (int b = 0; b < nb; ++b) {
             const int sidx = sq[g0 + b];
             Seq& q = seq(sidx);
@@ -815,7 +817,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 a.q_off = 0; a.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; a.v_off = a.k_off + Hkv_l * D;
                 a.gate = cfg.hybrid ? qkvb + (size_t)Hq_l * D : nullptr;
                 a.qkv_stride = ldq; a.bt_stride = max_pages_per_seq; a.rot_dim = cfg.rot_dim;
-                a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
+                a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
                 if (heads_b) {
                     if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
                     GemvBArgs g{};
@@ -824,7 +826,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.dshift = D == 128 ? 7 : 8;
                     launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else {
-                if (!launch_attn_decode(a, D, nrep, nsplit, kv_f32, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
                 }
             }
@@ -864,7 +866,8 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     ensure_pages(s, (int64_t)(start_pos + n));
     activate(s);
     bool use_prefill = false;
-    if (n >= 2 && !quantized && getenv("CM_NO_PREFILL") == nullptr) {      // quantised weights: token-serial (no dequant-GEMM yet)
+    // quantised weights / quantised KV: token-serial through the decode step (no dequant-GEMM / quantising prefill yet)
+    if (n >= 2 && !quantized && kv_mode < CM_KV_INT8 && getenv("CM_NO_PREFILL") == nullptr) {
         ensure_prefill_buffers();
         use_prefill = prefill_ok;
     }
@@ -1060,6 +1063,12 @@ void Model::debug_fill_kv(size_t ctx, uint64_t seed) {
     Seq& q = seq(0);
     for (int li = 0; li < cfg.L; ++li) {
         if (!cfg.layer_full(li)) continue;
+        if (kv_mode >= CM_KV_INT8) {
+            const size_t code_bytes = (size_t)Hkv_l * page * kv_row_bytes;
+            launch_kv_fill_quant(kpool(li), d_bt, (int)q.pages.size(), page_bytes, code_bytes, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
+            launch_kv_fill_quant(vpool(li), d_bt, (int)q.pages.size(), page_bytes, code_bytes, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
+            continue;
+        }
         launch_kv_fill(kpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
         launch_kv_fill(vpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
     }

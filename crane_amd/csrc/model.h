@@ -135,8 +135,11 @@ struct Model {
     // paged KV pool: [L][2][n_pages][Hkv_l][page][D] bf16 (or f32: cm_opts.kv_dtype)
     uint8_t* kv_pool = nullptr;
     size_t page_elems = 0;
-    size_t kv_esize = 2;
+    size_t kv_esize = 2;               // bytes per cached element for the roofline accounting (int4: counted as 1/2 below)
     bool kv_f32 = false;
+    int kv_mode = 0;                   // cm_kv_dtype: 0 bf16, 1 f32, 2 int8, 3 int4 (per-token symmetric, qwen3_5/kv_cache.rs:209-342)
+    size_t kv_row_bytes = 0;           // bytes of one token row of one KV head
+    size_t page_bytes = 0;             // bytes of one page of one (layer, K|V): rows + (quantised) f32 scales
     std::vector<int32_t> free_pages;
     std::vector<int32_t> page_ref;
     std::vector<Seq> seqs;
@@ -263,8 +266,8 @@ struct Model {
     // ---- kv / sequences ----
     std::vector<int> kv_index;     // layer -> index among the softmax-attention layers (-1: GDN layer)
     int n_kv_layers = 0;
-    void* kpool(int layer) const { return kv_pool + ((size_t)kv_index[(size_t)layer] * 2 + 0) * n_pages * page_elems * kv_esize; }
-    void* vpool(int layer) const { return kv_pool + ((size_t)kv_index[(size_t)layer] * 2 + 1) * n_pages * page_elems * kv_esize; }
+    void* kpool(int layer) const { return kv_pool + ((size_t)kv_index[(size_t)layer] * 2 + 0) * n_pages * page_bytes; }
+    void* vpool(int layer) const { return kv_pool + ((size_t)kv_index[(size_t)layer] * 2 + 1) * n_pages * page_bytes; }
     int seq_alloc();
     void seq_free(int s);
     int seq_fork(int src);

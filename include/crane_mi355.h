@@ -48,7 +48,10 @@ typedef enum cm_status {
     CM_ERR_RANGE = -6         /* position / token id out of range             */
 } cm_status;
 
-typedef enum cm_kv_dtype { CM_KV_BF16 = 0, CM_KV_F32 = 1 } cm_kv_dtype;
+/* KV cache element type.  INT8 / INT4 = KvCache::Quant (qwen3_5/kv_cache.rs:209-342): per-token symmetric codes
+ * (scale = amax/qmax + 1e-8, code = round(x/scale) + 128|8, int4 nibble-packed lo + 16*hi) + one f32 scale per
+ * (token, kv head); dequantisation is fused into the attention kernel instead of re-materialising the cache. */
+typedef enum cm_kv_dtype { CM_KV_BF16 = 0, CM_KV_F32 = 1, CM_KV_INT8 = 2, CM_KV_INT4 = 3 } cm_kv_dtype;
 
 /* Options of Model::new / select_device / create_backend
  * (qwen3/model.rs:45-106, crane-serve/src/lib.rs:432-499,

@@ -189,6 +189,10 @@ class Qwen35Oracle:
         k, v = k.transpose(1, 0, 2), v.transpose(1, 0, 2)
         if self.kv_dtype == "bf16":
             k, v = bf16_round(k), bf16_round(v)
+        elif self.kv_dtype in ("int8", "int4"):       # KvCache::Quant (qwen3_5/kv_cache.rs:209-342)
+            from oracle.kv_quant_oracle import roundtrip
+            bits = 8 if self.kv_dtype == "int8" else 4
+            k, v = roundtrip(k, bits), roundtrip(v, bits)
         if self.kc[li] is None or start == 0:
             self.kc[li], self.vc[li] = k, v
         else:

@@ -190,6 +190,10 @@ class Qwen3Oracle:
         # k, v: [Hkv, S, D]
         if self.kv_dtype == "bf16":
             k, v = bf16_round(k), bf16_round(v)
+        elif self.kv_dtype in ("int8", "int4"):       # KvCache::Quant (qwen3_5/kv_cache.rs:209-342)
+            from oracle.kv_quant_oracle import roundtrip
+            bits = 8 if self.kv_dtype == "int8" else 4
+            k, v = roundtrip(k, bits), roundtrip(v, bits)
         if self.k_cache[li] is None or start_pos == 0:
             self.k_cache[li], self.v_cache[li] = k, v
         else:

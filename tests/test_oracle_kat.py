@@ -168,3 +168,21 @@ def test_silu_and_repeat_penalty_arithmetic():
     l = np.array([2.0, -2.0, 1.0, 0.5], dtype=F32)
     out = apply_repeat_penalty(l, 2.0, [0, 1, 0])
     assert np.allclose(out, [1.0, -4.0, 1.0, 0.5])          # positive /p, negative *p, once per distinct token
+
+
+def test_kv_quant_per_token_rules():
+    """qwen3_5/kv_cache.rs:253-301: codes in [1, 2*qmax+1], scale = amax/qmax + 1e-8, nibble packing lo + 16*hi."""
+    from oracle import kv_quant_oracle as Q
+    x = np.array([[1.0, -2.0, 0.5, 4.0, -4.0, 0.0, 3.99, -0.01]], np.float32)
+    c8, s8 = Q.quantize_per_token(x, 8)
+    assert s8.shape == (1, 1) and s8[0, 0] == np.float32(4.0) * np.float32(1.0 / 127.0) + np.float32(1e-8)
+    assert c8.dtype == np.uint8 and c8.min() >= 1 and c8[0, 3] == 255 and c8[0, 4] == 1 and c8[0, 5] == 128
+    c4, s4 = Q.quantize_per_token(x, 4)
+    assert c4.shape == (1, 4) and s4[0, 0] == np.float32(4.0) * np.float32(1.0 / 7.0) + np.float32(1e-8)
+    codes = np.round(x / s4) + 8
+    assert c4[0, 0] == int(codes[0, 0]) + 16 * int(codes[0, 1]) and c4[0, 1] == int(codes[0, 2]) + 16 * 15
+    for bits, tol in ((8, 0.5 / 127 + 1e-6), (4, 0.5 / 7 + 1e-6)):
+        y = Q.roundtrip(x, bits)
+        assert np.abs(y - x).max() <= tol * 4.0
+    z = np.zeros((2, 8), np.float32)
+    assert np.all(Q.roundtrip(z, 8) == 0) and np.all(Q.roundtrip(z, 4) == 0)       # scale = 1e-8, codes = offset
