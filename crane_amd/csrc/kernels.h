@@ -203,7 +203,8 @@ void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipS
 // sampler (kernels_sample.hip)
 int topk_pad(int k);
 int topk_blocks(int n);
-void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* idx_out, float* val_out, hipStream_t s);
+void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* hist, uint32_t* sel, uint32_t* idx_out,
+                 float* val_out, hipStream_t s);
 void launch_penalties(float* logits, const uint32_t* ids, const uint32_t* counts, int n, float rp, bool true_div, float fp, float pp,
                       int V, hipStream_t s);
 void launch_sample_topk(const uint32_t* idx, const float* val, int k, float temperature, float top_p, uint64_t seed, uint32_t draw,

@@ -42,8 +42,9 @@ constexpr int TK_SLICE = 4096;
 
 // stage 1: block b sorts logits[b*4096 .. +4096) and emits its kp best keys
 __global__ __launch_bounds__(1024) void topk_stage1_kernel(const float* __restrict__ logits, int n, int kp,
-                                                           unsigned long long* __restrict__ cand) {
+                                                           unsigned long long* __restrict__ cand, const uint32_t* __restrict__ sel) {
     __shared__ unsigned long long s[TK_SLICE];
+    if (sel[2] != 0) return;                                   // the radix-select path already produced the answer
     const int base = blockIdx.x * TK_SLICE;
     for (int i = threadIdx.x; i < TK_SLICE; i += blockDim.x) {
         const int g = base + i;
@@ -57,8 +58,9 @@ __global__ __launch_bounds__(1024) void topk_stage1_kernel(const float* __restri
 // stage 2: one block folds all candidates, keeping the running best kp at the front
 __global__ __launch_bounds__(1024) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int kp, int k,
                                                            uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
-                                                           const float* __restrict__ logits) {
+                                                           const float* __restrict__ logits, const uint32_t* __restrict__ sel) {
     __shared__ unsigned long long s[TK_SLICE];
+    if (sel[2] != 0) return;
     int consumed = 0;
     for (int i = threadIdx.x; i < TK_SLICE; i += blockDim.x) s[i] = 0ull;
     __syncthreads();
@@ -72,6 +74,102 @@ __global__ __launch_bounds__(1024) void topk_stage2_kernel(const unsigned long l
         __syncthreads();
         bitonic_desc(s, TK_SLICE);
     }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint32_t id = ~(uint32_t)(s[i] & 0xFFFFFFFFull);
+        idx_out[i] = id;
+        val_out[i] = logits[id];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: radix select on the top 12 key bits, then sort only the survivors.
+//   hist    : 4096-bin histogram of (ordered value bits >> 20), LDS atomics per 4096-logit slice, non-empty bins
+//             flushed to HBM
+//   select  : one block; suffix counts from the top bin; T = the bin holding the k-th largest value; every logit
+//             in a bin >= T is a candidate (k <= n_cand); fast iff n_cand <= 4096 -- heavy exact ties (e.g. a
+//             constant vector) fall back to the two-stage bitonic kernels above, which early-exit otherwise
+//   collect : candidates appended in any order (the sort restores the total order)
+//   final   : one block sorts pow2(n_cand) keys (typically 64..256) and emits the first k
+// sel = {T, n_cand, fast, counter}
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TK_BINS = 4096, TK_CAP = 4096;
+
+__device__ __forceinline__ uint32_t topk_ord(float v) {
+    if (v == 0.0f) v = 0.0f;
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict__ logits, int n, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[TK_BINS];
+    for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * TK_SLICE;
+    for (int i = threadIdx.x; i < TK_SLICE; i += blockDim.x) {
+        const int g = base + i;
+        if (g < n) atomicAdd(&h[topk_ord(logits[g]) >> 20], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(uint32_t* __restrict__ hist, int k, uint32_t* __restrict__ sel) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = hist[4 * t + j]; hist[4 * t + j] = 0; sum += c[j]; }      // zeroed for the next call
+    part[t] = sum;
+    __syncthreads();
+    // suffix sums over the 1024 partials (Hillis-Steele, 10 steps)
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (t + d < 1024) ? part[t + d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t above = (t + 1 < 1024) ? part[t + 1] : 0u;          // count in bins > 4t+3
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+        const uint32_t incl = above + c[j];
+        if (above < (uint32_t)k && incl >= (uint32_t)k) {
+            sel[0] = (uint32_t)(4 * t + j);
+            sel[1] = incl;
+            sel[2] = incl <= (uint32_t)TK_CAP ? 1u : 0u;
+            sel[3] = 0u;
+        }
+        above = incl;
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_collect_kernel(const float* __restrict__ logits, int n, uint32_t* __restrict__ sel,
+                                                            unsigned long long* __restrict__ cand) {
+    if (sel[2] == 0) return;
+    const uint32_t T = sel[0];
+    const int base = blockIdx.x * TK_SLICE;
+    for (int i = threadIdx.x; i < TK_SLICE; i += blockDim.x) {
+        const int g = base + i;
+        if (g >= n) break;
+        const float v = logits[g];
+        if ((topk_ord(v) >> 20) >= T) {
+            const uint32_t p = atomicAdd(&sel[3], 1u);
+            if (p < (uint32_t)TK_CAP) cand[p] = topk_key(v, (uint32_t)g);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ cand, const uint32_t* __restrict__ sel,
+                                                          int k, uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                          const float* __restrict__ logits) {
+    __shared__ unsigned long long s[TK_CAP];
+    if (sel[2] == 0) return;
+    const int n = (int)sel[1];
+    int P = 64;
+    while (P < n) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) s[i] = i < n ? cand[i] : 0ull;
+    __syncthreads();
+    bitonic_desc(s, P);
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const uint32_t id = ~(uint32_t)(s[i] & 0xFFFFFFFFull);
         idx_out[i] = id;
@@ -183,10 +281,17 @@ __global__ __launch_bounds__(256) void gumbel_final_kernel(const float* __restri
 int topk_pad(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 int topk_blocks(int n) { return (n + TK_SLICE - 1) / TK_SLICE; }
 
-void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* idx_out, float* val_out, hipStream_t s) {
+// cand: >= max(topk_blocks(n) * topk_pad(k), 4096) keys; hist: 4096 zeroed u32 (left zeroed); sel: 4 u32
+void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* hist, uint32_t* sel, uint32_t* idx_out,
+                 float* val_out, hipStream_t s) {
     const int kp = topk_pad(k), nb = topk_blocks(n);
-    hipLaunchKernelGGL(topk_stage1_kernel, dim3(nb), dim3(1024), 0, s, logits, n, kp, cand);
-    hipLaunchKernelGGL(topk_stage2_kernel, dim3(1), dim3(1024), 0, s, cand, nb * kp, kp, k, idx_out, val_out, logits);
+    hipLaunchKernelGGL(topk_hist_kernel, dim3(nb), dim3(1024), 0, s, logits, n, hist);
+    hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, s, hist, k, sel);
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(nb), dim3(1024), 0, s, logits, n, sel, cand);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), 0, s, cand, sel, k, idx_out, val_out, logits);
+    // exact-tie fallback (early-exits when the fast path ran)
+    hipLaunchKernelGGL(topk_stage1_kernel, dim3(nb), dim3(1024), 0, s, logits, n, kp, cand, sel);
+    hipLaunchKernelGGL(topk_stage2_kernel, dim3(1), dim3(1024), 0, s, cand, nb * kp, kp, k, idx_out, val_out, logits, sel);
 }
 void launch_penalties(float* logits, const uint32_t* ids, const uint32_t* counts, int n, float rp, bool true_div, float fp, float pp,
                       int V, hipStream_t s) {

@@ -222,6 +222,7 @@ struct Model {
     // device sampler scratch (model_sample.cpp; allocated on first use)
     unsigned long long* tk_cand = nullptr; size_t tk_cand_cap = 0;
     float* tk_in = nullptr; size_t tk_in_cap = 0;
+    uint32_t* tk_hist = nullptr;       // [4096] radix-select histogram (kept zeroed between calls) + [4] select record
     uint32_t* tk_idx = nullptr;        // [512]
     float* tk_val = nullptr;           // [512]
     uint32_t* d_pen = nullptr;         // [2][PEN_CAP] distinct ids, counts

@@ -15,6 +15,8 @@ static constexpr int SM_BLOCKS = 256;
 
 void Model::ensure_sampler() {
     if (tk_idx) return;
+    tk_hist = dalloc<uint32_t>(4096 + 4);
+    CM_HIP(hipMemsetAsync(tk_hist, 0, (4096 + 4) * sizeof(uint32_t), stream));
     tk_idx = dalloc<uint32_t>(512);
     tk_val = dalloc<float>(512);
     d_pen = dalloc<uint32_t>(2 * (size_t)PEN_CAP);
@@ -51,14 +53,14 @@ void Model::topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_o
         n = (size_t)cfg.V;
     }
     if (k == 0 || k > 512 || (size_t)k > n) throw CmError(CM_ERR_RANGE, "k must be in 1..min(512, n)");
-    const size_t need = (size_t)topk_blocks((int)n) * (size_t)topk_pad((int)k);
+    const size_t need = std::max<size_t>((size_t)topk_blocks((int)n) * (size_t)topk_pad((int)k), 4096);
     if (need > tk_cand_cap) {
         if (tk_cand) (void)hipFree(tk_cand);
         tk_cand = nullptr; tk_cand_cap = 0;
         CM_HIP(hipMalloc((void**)&tk_cand, need * sizeof(unsigned long long)));
         tk_cand_cap = need;
     }
-    launch_topk(src, (int)n, (int)k, tk_cand, tk_idx, tk_val, stream);
+    launch_topk(src, (int)n, (int)k, tk_cand, tk_hist, tk_hist + 4096, tk_idx, tk_val, stream);
     CM_HIP(hipMemcpyAsync(h_tk + 1, tk_idx, k * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipMemcpyAsync(h_tk + 1 + 512, tk_val, k * sizeof(float), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
@@ -88,14 +90,14 @@ uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_
             h_pen[nd] = t; h_pen[PEN_CAP + nd] = 1; ++nd;
         }
         if (nd) {
-            CM_HIP(hipMemcpyAsync(d_pen, h_pen, (size_t)nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            CM_HIP(hipMemcpyAsync(d_pen + PEN_CAP, h_pen + PEN_CAP, (size_t)nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            launch_penalties(logits, d_pen, d_pen + PEN_CAP, nd, rep ? p.repetition_penalty : 1.0f, true_div, p.frequency_penalty,
+            for (int i = 0; i < nd; ++i) h_pen[nd + i] = h_pen[PEN_CAP + i];          // [ids | counts] in one H2D copy
+            CM_HIP(hipMemcpyAsync(d_pen, h_pen, (size_t)2 * nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            launch_penalties(logits, d_pen, d_pen + nd, nd, rep ? p.repetition_penalty : 1.0f, true_div, p.frequency_penalty,
                              p.presence_penalty, V, stream);
         }
     }
     auto need_cand = [&](int k) {
-        const size_t need = (size_t)topk_blocks(V) * (size_t)topk_pad(k);
+        const size_t need = std::max<size_t>((size_t)topk_blocks(V) * (size_t)topk_pad(k), 4096);
         if (need > tk_cand_cap) {
             if (tk_cand) (void)hipFree(tk_cand);
             tk_cand = nullptr; tk_cand_cap = 0;
@@ -105,7 +107,7 @@ uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_
     };
     if (!(p.temperature > 0.f)) {                                  // greedy: arg-max, first index on ties
         need_cand(1);
-        launch_topk(logits, V, 1, tk_cand, d_tok, tk_val, stream);
+        launch_topk(logits, V, 1, tk_cand, tk_hist, tk_hist + 4096, d_tok, tk_val, stream);
     } else {
         const bool top_p_active = p.top_p > 0.f && p.top_p < 1.f;
         int k = (int)p.top_k;
@@ -113,7 +115,7 @@ uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_
         k = std::min(std::min(k, 64), V);                          // sampling.rs:268
         if (k > 0 && k < V) {
             need_cand(k);
-            launch_topk(logits, V, k, tk_cand, tk_idx, tk_val, stream);
+            launch_topk(logits, V, k, tk_cand, tk_hist, tk_hist + 4096, tk_idx, tk_val, stream);
             launch_sample_topk(tk_idx, tk_val, k, p.temperature, top_p_active ? p.top_p : 0.f, p.seed, p.draw, d_tok, stream);
         } else {
             launch_gumbel_full(logits, V, p.temperature, p.seed, p.draw, sm_pmax, sm_pidx, SM_BLOCKS, d_tok, stream);
