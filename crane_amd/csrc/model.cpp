@@ -209,6 +209,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
                                   : (int64_t)max_seqs * max_pages_per_seq;
     if (n_pages < max_pages_per_seq) n_pages = max_pages_per_seq;
     nsplit = std::max(1, std::min(64, num_cu / std::max(1, Hkv_l)));
+    if (const char* e = getenv("CM_TP_GRAPH")) tp_graph = atoi(e) != 0;
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     use_graph = opts.use_graph >= 0;
@@ -709,7 +710,12 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     // attention variant by context length (host-known): one captured graph per variant
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
     const int v = attn_variant;
-    if (use_graph && !rccl) {
+    logits_gathered = false;
+    // Tensor parallelism: the RCCL all-reduces / all-gathers are captured INTO the decode-step graph (one launch per
+    // token instead of ~290 kernel + 74 collective launches, which is what bounds an eager TP step).  The first step
+    // runs eagerly so that RCCL's lazy connection set-up happens outside a capture.  CM_TP_GRAPH=0 keeps TP eager.
+    if (rccl && !rccl_warm) { rccl_warm = true; enqueue_decode_step(true); return; }
+    if (use_graph && (!rccl || tp_graph)) {
         if (!graph_ok[v] && graph[v] == nullptr) {
             hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {

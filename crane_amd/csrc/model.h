@@ -248,6 +248,7 @@ struct Model {
     hipGraph_t graph[2] = {nullptr, nullptr};          // one captured decode step per attention variant
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     bool graph_ok[2] = {false, false};
+    bool tp_graph = true, rccl_warm = false;   // capture RCCL collectives into the decode graph (CM_TP_GRAPH=0: eager)
     int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj
     int attn_ns = 2;               // token splits per head of variant 1
     int64_t attn_heads_max = 0;    // contexts up to this many tokens use variant 1 (CM_ATTN_HEADS_MAX; 0 = never: measured

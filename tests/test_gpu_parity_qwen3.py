@@ -237,10 +237,13 @@ def test_prefill_f32_kv_and_plain_bf16_modes():
         m.close()
 
 
-def test_rccl_code_path_single_rank():
+@pytest.mark.parametrize("tp_graph", ["1", "0"])
+def test_rccl_code_path_single_rank(tp_graph, monkeypatch):
     """CM_FORCE_RCCL=1: the tp=1 reductions go through a 1-rank RCCL communicator (dlopen, unique-id ABI,
-    all-reduce + all-gather on the model's stream).  Results must equal the collective-free path."""
+    all-reduce + all-gather on the model's stream), captured into the decode hipGraph (CM_TP_GRAPH=1, the default) or
+    launched eagerly (0).  Results must equal the collective-free path."""
     import os
+    monkeypatch.setenv("CM_TP_GRAPH", tp_graph)
     cfg = configs.get_config("tiny-qwen3-untied")
     ids = configs.synthetic_prompt(40, cfg["vocab_size"])
     m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2)
