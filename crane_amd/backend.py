@@ -361,6 +361,13 @@ class Model:
         self._check(self._lib.cm_debug_read(self._h, what.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out
 
+    def debug_qgemv(self, layer: int, which: str, x: np.ndarray, n: int) -> np.ndarray:
+        xv = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty(n, dtype=np.float32)
+        self._check(self._lib.cm_debug_qgemv(self._h, layer, which.encode(), xv.ctypes.data_as(C.POINTER(C.c_float)), xv.size,
+                                             out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out
+
     def decode_bytes_per_token(self, ctx: int) -> int:
         return int(self._lib.cm_decode_bytes_per_token(self._h, ctx))
 

@@ -242,6 +242,11 @@ int cm_read_logits(cm_model* h, float* logits_out) {
     });
 }
 
+int cm_debug_qgemv(cm_model* h, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n) {
+    if (!h || !which || !x || !y) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.debug_qgemv(layer, which, x, k, y, n); });
+}
+
 int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
     if (!h) return CM_ERR_INVALID;
     return guard(h, [&] { h->m.bench_decode(first_token, k, tokens_out, ms_out); });

@@ -192,6 +192,7 @@ struct GemvQArgs {
     int* pidx;
     int idx_base;
     float eps;
+    int act_int = 0;       // 1: activations quantised to Q8_0 / Q8_K + integer dot products (ggml vec_dot semantics)
 };
 int gemvq_grid(int N, int num_cu);
 bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s);

@@ -268,6 +268,248 @@ void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipS
     hipLaunchKernelGGL(silu_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gate, up, out, n);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Integer-dot GEMV: the activation row is quantised to the weight type's VecDotType in the prologue (Q8_0 blocks
+// of 32 for Q8_0 weights, Q8_K blocks of 256 for the K-quants -- ggml quantize_row_q8_0 / quantize_row_q8_K as
+// candle's k_quants `matmul` does before `vec_dot`), products are summed as INTEGERS inside a block with
+// v_dot4_i32_i8 (4 MACs per lane-op instead of cvt + fma per weight) and scaled once per block:
+//   Q8_0 . Q8_0 : sumf += (d_w * d_x) * sum(q_w * q_x)                                   (ggml_vec_dot_q8_0_q8_0)
+//   Q4_K . Q8_K : sumf += (d_x * d) * sum_j sc_j * sum(q4 * q8) - (d_x * dmin) * sum_j m_j * bsum_j   (_q4_K_q8_K)
+//   Q6_K . Q8_K : sumf += (d_x * d) * sum_j sc_j * sum((q6 - 32) * q8)                    (_q6_K_q8_K)
+// x codes live in LDS in natural order (1 byte per element + per-block scales + per-8 code sums).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float f16_round(float v) {
+    const _Float16 h = (_Float16)v;
+    return (float)h;
+}
+
+template <int FMT, int PRO, int EPI>
+__global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
+    using F = QF<FMT>;
+    constexpr int R = 2, CK = F::CK;
+    constexpr bool KQ = FMT != QFMT_Q8_0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.w.K, N = a.w.N;
+    const int nch = (K + CK - 1) / CK;
+    const int Kpad = nch * CK;
+    signed char* xq = (signed char*)lds_raw;                       // [Kpad] int8 codes
+    float* xd = (float*)(lds_raw + Kpad);                          // block scales: [Kpad/32] (Q8_0) | [Kpad/256] (Q8_K)
+    int* xs8 = (int*)(xd + (KQ ? Kpad / 256 : Kpad / 32));         // K-quants: sums of 8 consecutive codes [Kpad/8]
+    float* red = (float*)(xs8 + (KQ ? Kpad / 8 : 0));
+
+    const int n4 = K >> 2;
+    float rr = 1.f;
+    if (PRO == PRO_RMSNORM) {                                      // 1/rms first: the reference quantises the NORMALISED row
+        float ss = 0.f;
+        for (int k4 = tid; k4 < n4; k4 += 256) {
+            const f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        rr = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + a.eps);
+    }
+    auto xval = [&](int k4) -> f32x4 {
+        f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
+        if (PRO == PRO_RMSNORM) {
+            const f32x4 w = *(const f32x4*)(a.nw + (k4 << 2));
+            v[0] = __fmul_rn(__fmul_rn(v[0], rr), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], rr), w[1]);
+            v[2] = __fmul_rn(__fmul_rn(v[2], rr), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], rr), w[3]);
+        }
+        return v;
+    };
+    if (!KQ) {
+        // quantize_row_q8_0: 32-element blocks = 8 consecutive lanes
+        for (int k4 = tid; k4 < n4; k4 += 256) {
+            const f32x4 v = xval(k4);
+            float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+            const float d = am / 127.0f;
+            const float id = d != 0.f ? 1.0f / d : 0.f;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(v[e] * id) & 0xFFu) << (8 * e);
+            ((uint32_t*)xq)[k4] = pk;
+            if ((tid & 7) == 0) xd[k4 >> 3] = f16_round(d);
+        }
+    } else {
+        // quantize_row_q8_K: one wave per 256-element block
+        const int nblk = K >> 8;
+        for (int blk = wave; blk < nblk; blk += 4) {
+            const int k4 = blk * 64 + lane;
+            const f32x4 v = xval(k4);
+            // signed value of the FIRST element with the largest |x|
+            unsigned long long key = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long ke = ((unsigned long long)__float_as_uint(fabsf(v[e])) << 32) | (unsigned)(255 - (lane * 4 + e));
+                key = ke > key ? ke : key;
+            }
+            unsigned long long best = key;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, o), hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o);
+                const unsigned long long ot = ((unsigned long long)hi << 32) | lo;
+                best = ot > best ? ot : best;
+            }
+            const int widx = 255 - (int)(unsigned)(best & 0xFFFFFFFFull);
+            float cand = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (lane * 4 + e == widx) cand = v[e];
+            const float mx = wave_sum(cand);
+            const float iscale = mx != 0.f ? -128.0f / mx : 0.f;
+            int q[4]; int s4 = 0; uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                q[e] = mx != 0.f ? min(127, __float2int_rn(v[e] * iscale)) : 0;
+                s4 += q[e];
+                pk |= ((uint32_t)q[e] & 0xFFu) << (8 * e);
+            }
+            ((uint32_t*)xq)[k4] = pk;
+            const int s8 = s4 + __shfl_xor(s4, 1);
+            if (!(lane & 1)) xs8[k4 >> 1] = s8;
+            if (lane == 0) xd[blk] = mx != 0.f ? 1.0f / iscale : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
+    float best = -INFINITY; int besti = 0x7FFFFFFF;
+    const int G = (N + R - 1) / R;
+    for (int g = blockIdx.x * 4 + wave; g < G; g += gridDim.x * 4) {
+        const int r0 = g * R;
+        float acc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            if (c * CK + lane_k >= K) continue;
+            QRow q[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) q[i] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c, lane);
+            if constexpr (FMT == QFMT_Q8_0) {
+                const int e0 = c * 1024 + lane * 16;
+                const u32x4 xv = *(const u32x4*)(xq + e0);
+                const float dx = xd[e0 >> 5];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    int isum = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i].a[j], (int)xv[j], isum, false);
+                    acc[i] += (q[i].d * dx) * (float)isum;
+                }
+            } else if constexpr (FMT == QFMT_Q4_K) {
+                const int kb = c * 8 + (lane >> 3), h = lane & 7, p = h >> 1;
+                const int e0 = kb * 256 + 64 * p + 16 * (h & 1);
+                const u32x4 x0 = *(const u32x4*)(xq + e0), x1 = *(const u32x4*)(xq + e0 + 32);
+                const int bs0 = xs8[e0 >> 3] + xs8[(e0 >> 3) + 1], bs1 = xs8[(e0 + 32) >> 3] + xs8[((e0 + 32) >> 3) + 1];
+                const float dx = xd[kb];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const u32x4 hb = q[i].b;
+                    const float d = f16_bits_to_f32(hb[0] & 0xFFFFu), dmin = f16_bits_to_f32(hb[0] >> 16);
+                    auto sbyte = [&](int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
+                    auto scale_min = [&](int j, int& sc, int& mn) {
+                        if (j < 4) { sc = sbyte(j) & 63; mn = sbyte(j + 4) & 63; }
+                        else { sc = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
+                    };
+                    int sc0, m0, sc1, m1;
+                    scale_min(2 * p, sc0, m0);
+                    scale_min(2 * p + 1, sc1, m1);
+                    int il = 0, ih = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        il = __builtin_amdgcn_sdot4((int)(q[i].a[j] & 0x0F0F0F0Fu), (int)x0[j], il, false);
+                        ih = __builtin_amdgcn_sdot4((int)((q[i].a[j] >> 4) & 0x0F0F0F0Fu), (int)x1[j], ih, false);
+                    }
+                    acc[i] += (dx * d) * (float)(sc0 * il + sc1 * ih) - (dx * dmin) * (float)(m0 * bs0 + m1 * bs1);
+                }
+            } else {
+                const int kb = c * 8 + (lane >> 3), n = (lane >> 2) & 1, j = lane & 3;
+                const int e0 = kb * 256 + 128 * n + 8 * j;
+                u32x2 xr[4]; int bs[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { xr[t] = *(const u32x2*)(xq + e0 + 32 * t); bs[t] = xs8[(e0 + 32 * t) >> 3]; }
+                const float dx = xd[kb];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const float d = f16_bits_to_f32(q[i].b[3]);
+                    int sumi = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int qsel = (t & 1) * 2, hshift = 2 * t;
+                        int is = 0;
+#pragma unroll
+                        for (int wi = 0; wi < 2; ++wi) {
+                            const uint32_t qlw = q[i].a[qsel + wi], qhw = q[i].b[wi];
+                            const uint32_t code = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
+                            is = __builtin_amdgcn_sdot4((int)code, (int)xr[t][wi], is, false);
+                        }
+                        const int sc = (int)(signed char)((q[i].b[2] >> (8 * t)) & 0xFFu);
+                        sumi += sc * (is - 32 * bs[t]);
+                    }
+                    acc[i] += (dx * d) * (float)sumi;
+                }
+            }
+        }
+        float mine = 0.f, mine_up = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            acc[i] = wave_sum(acc[i]);
+            if (EPI != EPI_SILUMUL && lane == i) mine = acc[i];
+            if (EPI == EPI_SILUMUL && (i & 1) && lane == (i >> 1)) { mine = acc[i - 1]; mine_up = acc[i]; }
+        }
+        if (EPI == EPI_STORE) {
+            if (lane < R && r0 + lane < N) a.y[r0 + lane] = mine;
+        } else if (EPI == EPI_RESADD) {
+            if (lane < R && r0 + lane < N) a.y[r0 + lane] = a.res[r0 + lane] + mine;
+        } else if (EPI == EPI_SILUMUL) {
+            if (lane < R / 2 && r0 + 2 * lane + 1 < N) a.y[(r0 >> 1) + lane] = (mine / (1.0f + expf(-mine))) * mine_up;
+        } else if (EPI == EPI_ARGMAX) {
+            if (lane < R && r0 + lane < N) a.y[r0 + lane] = mine;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int ix = r0 + i + a.idx_base;
+                if (r0 + i < N && (acc[i] > best || (acc[i] == best && ix < besti))) { best = acc[i]; besti = ix; }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        __syncthreads();
+        int* redi = (int*)(red + 4);
+        if (lane == 0) { red[wave] = best; redi[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            float bb = red[0]; int bbi = redi[0];
+            for (int w = 1; w < 4; ++w)
+                if (red[w] > bb || (red[w] == bb && redi[w] < bbi)) { bb = red[w]; bbi = redi[w]; }
+            a.pmax[blockIdx.x] = bb; a.pidx[blockIdx.x] = bbi;
+        }
+    }
+}
+
+template <int FMT>
+static void launch_gemvq_i8_f(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s) {
+    constexpr int CK = QF<FMT>::CK;
+    const size_t kpad = (size_t)((a.w.K + CK - 1) / CK) * CK;
+    const size_t lds = kpad + (FMT == QFMT_Q8_0 ? kpad / 32 * 4 : kpad / 256 * 4 + kpad / 8 * 4) + 64;
+#define CM_QI(P, E) { hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E>), dim3(grid), dim3(256), lds, s, a); return; }
+    if (pro == PRO_RMSNORM) {
+        if (epi == EPI_STORE) CM_QI(PRO_RMSNORM, EPI_STORE)
+        if (epi == EPI_SILUMUL) CM_QI(PRO_RMSNORM, EPI_SILUMUL)
+        if (epi == EPI_ARGMAX) CM_QI(PRO_RMSNORM, EPI_ARGMAX)
+        CM_QI(PRO_RMSNORM, EPI_RESADD)
+    } else {
+        if (epi == EPI_STORE) CM_QI(PRO_PLAIN, EPI_STORE)
+        if (epi == EPI_SILUMUL) CM_QI(PRO_PLAIN, EPI_SILUMUL)
+        if (epi == EPI_ARGMAX) CM_QI(PRO_PLAIN, EPI_ARGMAX)
+        CM_QI(PRO_PLAIN, EPI_RESADD)
+    }
+#undef CM_QI
+}
+
 int gemvq_grid(int N, int num_cu) {
     const int groups = (N + 1) / 2;
     return std::max(1, std::min((groups + 3) / 4, num_cu * 4));
@@ -295,6 +537,14 @@ static void launch_gemvq_f(int pro, int epi, const GemvQArgs& a, int grid, hipSt
 }
 
 bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s) {
+    if (a.act_int) {
+        switch (a.w.fmt) {
+            case QFMT_Q8_0: launch_gemvq_i8_f<QFMT_Q8_0>(pro, epi, a, grid, s); return true;
+            case QFMT_Q4_K: launch_gemvq_i8_f<QFMT_Q4_K>(pro, epi, a, grid, s); return true;
+            case QFMT_Q6_K: launch_gemvq_i8_f<QFMT_Q6_K>(pro, epi, a, grid, s); return true;
+            default: return false;
+        }
+    }
     switch (a.w.fmt) {
         case QFMT_Q8_0: launch_gemvq_f<QFMT_Q8_0>(pro, epi, a, grid, s); return true;
         case QFMT_Q4_K: launch_gemvq_f<QFMT_Q4_K>(pro, epi, a, grid, s); return true;

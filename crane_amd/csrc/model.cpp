@@ -210,6 +210,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (n_pages < max_pages_per_seq) n_pages = max_pages_per_seq;
     nsplit = std::max(1, std::min(64, num_cu / std::max(1, Hkv_l)));
     if (const char* e = getenv("CM_TP_GRAPH")) tp_graph = atoi(e) != 0;
+    if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     use_graph = opts.use_graph >= 0;
@@ -527,7 +528,7 @@ void Model::enqueue_quant_layer(int li) {
     hipStream_t s = stream;
     auto qg = [&](int pro, int epi, const QWeight& qw, const float* xin, const float* nw, float* yout, const float* res) {
         GemvQArgs q{};
-        q.w = qw; q.x = xin; q.nw = nw; q.y = yout; q.res = res; q.eps = cfg.eps;
+        q.w = qw; q.x = xin; q.nw = nw; q.y = yout; q.res = res; q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
         if (!launch_gemvq(pro, epi, q, gemvq_grid(qw.N, num_cu), s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
     };
     for (int i = 0; i < w.n_qkv; ++i) qg(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], x, w.ln1, qkv + w.qkv_row0[i], nullptr);
@@ -557,6 +558,7 @@ void Model::enqueue_lm_head(bool advance) {
     if (quantized && q_lm_head.fmt != QFMT_NONE) {
         GemvQArgs q{};
         q.w = q_lm_head; q.x = x; q.nw = norm; q.y = logits; q.pmax = pmax; q.pidx = pidx; q.idx_base = 0; q.eps = cfg.eps;
+        q.act_int = quant_act_int ? 1 : 0;
         if (!launch_gemvq(PRO_RMSNORM, EPI_ARGMAX, q, lm_grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
         launch_argmax_final(pmax, pidx, lm_grid, st, ring, RING - 1, advance ? 1 : 0, 1, s);
         return;
@@ -1012,7 +1014,7 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
         const LayerW& w = layers[li];
         if (quantized) {
             GemvQArgs q{};
-            q.eps = cfg.eps;
+            q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
             int pro = PRO_PLAIN, epi = EPI_RESADD;
             if (which == "qkv") { q.w = w.q_qkv[0]; q.x = x; q.nw = w.ln1; q.y = qkv; pro = PRO_RMSNORM; epi = EPI_STORE; }
             else if (which == "o") { q.w = w.q_o; q.x = attn; q.y = y; q.res = x; }
@@ -1060,6 +1062,37 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
     (void)hipEventDestroy(e1);
     if (ms) *ms = t / (float)iters;
     if (bytes) *bytes = b;
+}
+
+void Model::debug_qgemv(int layer, const std::string& which, const float* xh, size_t k, float* yh, size_t n) {
+    if (!quantized) throw CmError(CM_ERR_INVALID, "model has no quantised weights");
+    QWeight w;
+    if (which == "lm_head") w = q_lm_head;
+    else {
+        if (layer < 0 || layer >= cfg.L) throw CmError(CM_ERR_RANGE, "layer out of range");
+        const LayerW& lw = layers[(size_t)layer];
+        if (which == "qkv0") w = lw.q_qkv[0];
+        else if (which == "qkv1" && lw.n_qkv > 1) w = lw.q_qkv[1];
+        else if (which == "qkv2" && lw.n_qkv > 2) w = lw.q_qkv[2];
+        else if (which == "o") w = lw.q_o;
+        else if (which == "gate_up") w = lw.q_gate_up;
+        else if (which == "gate") w = lw.q_gate;
+        else if (which == "up") w = lw.q_up;
+        else if (which == "down") w = lw.q_down;
+    }
+    if (w.fmt == QFMT_NONE) throw CmError(CM_ERR_INVALID, "no such quantised projection: " + which);
+    if ((size_t)w.K != k || (size_t)w.N != n) throw CmError(CM_ERR_RANGE, "debug_qgemv: expected k=" + std::to_string(w.K) + " n=" + std::to_string(w.N));
+    float *dx = nullptr, *dy = nullptr;
+    CM_HIP(hipMalloc((void**)&dx, k * sizeof(float)));
+    CM_HIP(hipMalloc((void**)&dy, n * sizeof(float)));
+    CM_HIP(hipMemcpyAsync(dx, xh, k * sizeof(float), hipMemcpyHostToDevice, stream));
+    GemvQArgs q{};
+    q.w = w; q.x = dx; q.y = dy; q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
+    const bool ok = launch_gemvq(PRO_PLAIN, EPI_STORE, q, gemvq_grid(w.N, num_cu), stream);
+    if (ok) CM_HIP(hipMemcpyAsync(yh, dy, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(dx); (void)hipFree(dy);
+    if (!ok) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
 }
 
 void Model::debug_fill_kv(size_t ctx, uint64_t seed) {

@@ -239,9 +239,11 @@ struct Model {
 
     // quantised weights (dense Qwen3, TP = 1): embedding / lm_head tables + per-layer QWeights in LayerW
     bool quantized = false;
+    bool quant_act_int = true;         // ggml vec_dot semantics: activations -> Q8_0 / Q8_K + integer dots (CM_QUANT_ACT=f32: exact dequant x f32)
     QWeight q_embed, q_lm_head;
     float* gu_tmp = nullptr;           // [2 I] scratch when gate / up have different ggml types
     uint64_t quant_weight_bytes = 0;   // bytes of every quantised matrix read once per decoded token
+    void debug_qgemv(int layer, const std::string& which, const float* x, size_t k, float* y, size_t n);
     void isq_q8_0();                   // in-situ quantisation of the loaded bf16 linears (ops/linear.rs:83-116)
     void dfree(void* p);
 

@@ -327,6 +327,11 @@ int cm_debug_fill_kv(cm_model* m, size_t ctx, uint64_t seed);
  * what: "hidden" (f32 [H] residual after the last forward), "logits". */
 int cm_debug_read(cm_model* m, const char* what, float* out, size_t n);
 
+/* Run ONE quantised projection of `layer` on a host vector: y = W_q . x (plain prologue, store epilogue), in the
+ * model's activation mode (integer dot or f32).  which: "qkv0".."qkv2" (segments), "o", "gate_up" (interleaved rows
+ * 2j = gate_j, 2j+1 = up_j) | "gate" | "up", "down", "lm_head".  Kernel-level parity hook for tests. */
+int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,17 +327,157 @@ def qwen3_metadata(cfg: dict) -> Dict[str, tuple]:
     }
 
 
-def write_qwen3_gguf(path: str, cfg: dict, weights_f32: Dict[str, np.ndarray], type_of) -> Dict[str, np.ndarray]:
+def write_qwen3_gguf(path: str, cfg: dict, weights_f32: Dict[str, np.ndarray], type_of, want_qmats: bool = False):
     """type_of(gguf_name, shape) -> ggml type.  Returns the DEQUANTISED weights under their HF names: exactly what a
-    loader of this file must compute with (the oracle forward runs on these)."""
+    loader of this file must compute with (the oracle forward runs on these).  With want_qmats also returns
+    {hf name: QuantMatrix} for every quantised matrix (the vec_dot semantics)."""
     names = qwen3_gguf_names(cfg)
-    tensors, deq = [], {}
+    tensors, deq, qm = [], {}, {}
     for hf, gg in names.items():
         w = np.asarray(weights_f32[hf], np.float32)
         gt = type_of(gg, w.shape)
         if w.ndim == 1:
             gt = GGML_F32
         tensors.append((gg, w, gt))
-        deq[hf] = dequantize(quantize(w, gt), gt, w.size).reshape(w.shape)
+        raw = quantize(w, gt)
+        deq[hf] = dequantize(raw, gt, w.size).reshape(w.shape)
+        if want_qmats and w.ndim == 2 and gt in (GGML_Q8_0, GGML_Q4_K, GGML_Q6_K):
+            qm[hf] = QuantMatrix(raw, gt, w.shape)
     write_gguf(path, qwen3_metadata(cfg), tensors)
-    return deq
+    return (deq, qm) if want_qmats else deq
+
+
+def qwen3_oracle_qmats(cfg: dict, qm: Dict[str, "QuantMatrix"]) -> dict:
+    """{hf name: QuantMatrix} -> the (layer, name) -> [QuantMatrix...] map Qwen3Oracle.qmats expects."""
+    out = {}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        out[(i, "qkv")] = [qm[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")]
+        out[(i, "o")] = [qm[p + "self_attn.o_proj.weight"]]
+        out[(i, "gate_up")] = [qm[p + "mlp.gate_proj.weight"], qm[p + "mlp.up_proj.weight"]]
+        out[(i, "down")] = [qm[p + "mlp.down_proj.weight"]]
+    head = "model.embed_tokens.weight" if cfg.get("tie_word_embeddings", True) else "lm_head.weight"
+    if head in qm:
+        out[(-1, "lm_head")] = [qm[head]]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Quantised mat-vec with QUANTISED ACTIVATIONS -- what candle's CPU QMatMul / ggml's vec_dot actually compute
+# (k_quants.rs `vec_dot`; ggml-quants.c quantize_row_q8_0 / quantize_row_q8_K + ggml_vec_dot_q8_0_q8_0 /
+# _q4_K_q8_K / _q6_K_q8_K): the activation row is quantised to the weight type's VecDotType (Q8_0 for Q8_0 weights,
+# Q8_K for the K-quants), the products are summed as integers inside a block and scaled once per block.
+# PARITY UNPINNED: the crate is not in /root/reference; q8_K's `iscale = -128 / max` follows candle 0.x k_quants.rs.
+# ---------------------------------------------------------------------------------------------------------
+def _roundf(t):
+    t64 = np.asarray(t, np.float64)
+    return np.copysign(np.floor(np.abs(t64) + 0.5), t64)
+
+
+def quantize_act_q8_0(x: np.ndarray):
+    """x [S, K] f32 -> (q int32 [S, K], d f32 [S, K/32] after the f16 round trip)."""
+    x = np.asarray(x, np.float32)
+    S, K = x.shape
+    xb = x.reshape(S, K // 32, 32)
+    amax = np.abs(xb).max(axis=2)
+    d = (amax / np.float32(127.0)).astype(np.float32)
+    idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0)).astype(np.float32)
+    q = _roundf((xb * idv[:, :, None]).astype(np.float32)).astype(np.int32).reshape(S, K)
+    return q, d.astype(np.float16).astype(np.float32)
+
+
+def quantize_act_q8_k(x: np.ndarray):
+    """x [S, K] -> (q int32 [S, K], d f32 [S, K/256]); max = the signed value of the FIRST element with the largest |x|,
+    iscale = -128 / max, q = min(127, nearest_int(iscale * x)) (round half to even), d = 1 / iscale."""
+    x = np.asarray(x, np.float32)
+    S, K = x.shape
+    xb = x.reshape(S, K // 256, 256)
+    ax = np.abs(xb)
+    first = ax.argmax(axis=2)                                   # first occurrence of the maximum
+    mx = np.take_along_axis(xb, first[:, :, None], axis=2)[:, :, 0]
+    nz = mx != 0
+    iscale = np.where(nz, np.float32(-128.0) / np.where(nz, mx, 1), np.float32(0)).astype(np.float32)
+    t = (xb * iscale[:, :, None]).astype(np.float32)
+    q = np.minimum(127, np.rint(t)).astype(np.int32)           # np.rint = half to even, like the magic-number nearest_int
+    q = np.where(nz[:, :, None], q, 0).reshape(S, K)
+    d = np.where(nz, np.float32(1.0) / np.where(nz, iscale, 1), np.float32(0)).astype(np.float32)
+    return q, d
+
+
+class QuantMatrix:
+    """A [N, K] ggml-quantised matrix; `vecdot(x [S, K]) -> [S, N]` with ggml's quantised-activation semantics."""
+
+    def __init__(self, raw: np.ndarray, ggml_type: int, shape):
+        self.gt, self.shape = ggml_type, tuple(shape)
+        N, K = self.shape
+        if ggml_type == GGML_Q8_0:
+            b = np.asarray(raw, np.uint8).reshape(N, K // 32, 34)
+            self.d = b[:, :, 0:2].copy().view(np.float16).astype(np.float32)[:, :, 0]
+            self.q = b[:, :, 2:].copy().view(np.int8).astype(np.int32)                       # [N, nb, 32]
+        elif ggml_type == GGML_Q4_K:
+            b = np.asarray(raw, np.uint8).reshape(N * (K // 256), 144)
+            self.d = b[:, 0:2].copy().view(np.float16).astype(np.float32)[:, 0].reshape(N, -1)
+            self.dmin = b[:, 2:4].copy().view(np.float16).astype(np.float32)[:, 0].reshape(N, -1)
+            sm = [_get_scale_min_k4(j, b[:, 4:16]) for j in range(8)]
+            self.sc = np.stack([s for s, _ in sm], axis=1).astype(np.int32).reshape(N, -1, 8)
+            self.mn = np.stack([m for _, m in sm], axis=1).astype(np.int32).reshape(N, -1, 8)
+            qs = b[:, 16:].reshape(-1, 4, 32)
+            q = np.stack([qs & 0xF, qs >> 4], axis=2)                                           # [nbt, 4, 2, 32]
+            self.q = q.reshape(N, K // 256, 8, 32).astype(np.int32)
+        elif ggml_type == GGML_Q6_K:
+            deq_codes = _q6k_codes(np.asarray(raw, np.uint8).reshape(-1, 210))                  # [nbt, 256] in 0..63
+            b = np.asarray(raw, np.uint8).reshape(-1, 210)
+            self.q = (deq_codes.astype(np.int32) - 32).reshape(N, K // 256, 16, 16)
+            self.sc = b[:, 192:208].copy().view(np.int8).astype(np.int32).reshape(N, -1, 16)
+            self.d = b[:, 208:210].copy().view(np.float16).astype(np.float32)[:, 0].reshape(N, -1)
+        else:
+            raise ValueError("QuantMatrix: unsupported ggml type")
+
+    def dequantize(self) -> np.ndarray:
+        raise NotImplementedError
+
+    def vecdot(self, x: np.ndarray) -> np.ndarray:
+        x = np.asarray(x, np.float32)
+        if x.ndim == 1:
+            return self.vecdot(x[None])[0]
+        N, K = self.shape
+        S = x.shape[0]
+        out = np.zeros((S, N), np.float32)
+        if self.gt == GGML_Q8_0:
+            xq, xd = quantize_act_q8_0(x)
+            for s in range(S):
+                isum = (self.q * xq[s].reshape(1, K // 32, 32)).sum(axis=2)                      # int, [N, nb]
+                out[s] = (isum.astype(np.float32) * (self.d * xd[s][None, :]).astype(np.float32)).sum(axis=1, dtype=np.float32)
+            return out
+        xq, xd = quantize_act_q8_k(x)
+        for s in range(S):
+            q8 = xq[s].reshape(K // 256, 256)
+            if self.gt == GGML_Q4_K:
+                isum = (self.q * q8.reshape(1, -1, 8, 32)).sum(axis=3)                           # [N, nb, 8]
+                sumi = (isum * self.sc).sum(axis=2)
+                bs = q8.reshape(-1, 8, 32).sum(axis=2)                                           # bsums[2j] + bsums[2j+1]
+                summs = (self.mn * bs[None]).sum(axis=2)
+                dd = (xd[s][None, :] * self.d).astype(np.float32)
+                dm = (xd[s][None, :] * self.dmin).astype(np.float32)
+                out[s] = (dd * sumi.astype(np.float32) - dm * summs.astype(np.float32)).astype(np.float32).sum(axis=1, dtype=np.float32)
+            else:
+                isum = (self.q * q8.reshape(1, -1, 16, 16)).sum(axis=3)                          # [N, nb, 16]
+                sumi = (isum * self.sc).sum(axis=2)
+                dd = (xd[s][None, :] * self.d).astype(np.float32)
+                out[s] = (dd * sumi.astype(np.float32)).astype(np.float32).sum(axis=1, dtype=np.float32)
+        return out
+
+
+def _q6k_codes(b: np.ndarray) -> np.ndarray:
+    """[nb, 210] raw Q6_K blocks -> [nb, 256] unsigned 6-bit codes in weight order."""
+    ql, qh = b[:, 0:128], b[:, 128:192]
+    y = np.zeros((b.shape[0], 256), np.uint8)
+    l = np.arange(32)
+    for h in range(2):
+        L, H = ql[:, 64 * h:64 * h + 64], qh[:, 32 * h:32 * h + 32]
+        base = 128 * h
+        y[:, base + l] = (L[:, l] & 0xF) | (((H[:, l] >> 0) & 3) << 4)
+        y[:, base + 32 + l] = (L[:, l + 32] & 0xF) | (((H[:, l] >> 2) & 3) << 4)
+        y[:, base + 64 + l] = (L[:, l] >> 4) | (((H[:, l] >> 4) & 3) << 4)
+        y[:, base + 96 + l] = (L[:, l + 32] >> 4) | (((H[:, l] >> 6) & 3) << 4)
+    return y

@@ -180,6 +180,16 @@ class Qwen3Oracle:
         self.cos, self.sin = rotary_tables(cfg.hd, mp, cfg.rope_theta)
         self.clear_kv_cache()
 
+    # -- linear: x @ W^T, or a quantised mat-vec with ggml's quantised-activation semantics when `qmats` maps
+    #    (layer, name) -> [QuantMatrix, ...] whose outputs are concatenated (q|k|v, gate|up) -----------------
+    qmats = None
+
+    def _mm(self, x, li, name):
+        if self.qmats is not None and (li, name) in self.qmats:
+            return np.concatenate([qm.vecdot(x) for qm in self.qmats[(li, name)]], axis=-1).astype(F32)
+        W = self.lm_head if name == "lm_head" else self.layers[li][name]
+        return x @ W.T
+
     # -- KV cache (kv_cache.rs:38-101: contiguous BHSD, append) ------------
     def clear_kv_cache(self):
         self.k_cache: List[Optional[np.ndarray]] = [None] * self.cfg.num_hidden_layers
@@ -206,7 +216,7 @@ class Qwen3Oracle:
         cfg, lw = self.cfg, self.layers[li]
         S = x.shape[0]
         Hq, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hd
-        qkv = _act(x, self.act_dtype) @ lw["qkv"].T                    # modeling.rs:318-323
+        qkv = self._mm(_act(x, self.act_dtype), li, "qkv")                # modeling.rs:318-323
         q = qkv[:, :Hq * D].reshape(S, Hq, D)                           # BSHD (modeling.rs:335-339)
         k = qkv[:, Hq * D:(Hq + Hkv) * D].reshape(S, Hkv, D)
         v = qkv[:, (Hq + Hkv) * D:].reshape(S, Hkv, D)
@@ -230,14 +240,14 @@ class Qwen3Oracle:
         p = softmax_last(scores)
         out = np.einsum("grsl,gld->grsd", p, V, optimize=True).astype(F32)
         out = out.reshape(Hq, S, D).transpose(1, 0, 2).reshape(S, Hq * D)
-        return (_act(out, self.act_dtype) @ lw["o"].T).astype(F32)      # o_proj
+        return self._mm(_act(out, self.act_dtype), li, "o").astype(F32)   # o_proj
 
     # -- Mlp::forward (modeling.rs:608-642) ---------------------------------
     def _mlp(self, li: int, x: np.ndarray) -> np.ndarray:
         lw, I = self.layers[li], self.cfg.intermediate_size
-        gu = _act(x, self.act_dtype) @ lw["gate_up"].T
+        gu = self._mm(_act(x, self.act_dtype), li, "gate_up")
         h = silu(gu[:, :I]) * gu[:, I:]
-        return (_act(h, self.act_dtype) @ lw["down"].T).astype(F32)
+        return self._mm(_act(h, self.act_dtype), li, "down").astype(F32)
 
     # -- Qwen3Model::forward/decode (modeling.rs:942-953, 984-1036) ----------
     def forward_hidden(self, input_ids: Sequence[int], start_pos: int) -> np.ndarray:
@@ -254,7 +264,7 @@ class Qwen3Oracle:
         """Logits of the LAST position only, shape [vocab] (modeling.rs:1024-1035)."""
         h = self.forward_hidden(input_ids, start_pos)
         last = rms_norm(h[-1:], self.norm, self.cfg.rms_norm_eps)
-        return (last @ self.lm_head.T).astype(F32)[0]
+        return self._mm(last, -1, "lm_head").astype(F32)[0]
 
     forward_step = forward      # ModelBackend::forward_step (backend.rs:41)
 

@@ -31,41 +31,78 @@ def _types(kind):
     return mixed
 
 
-def _check(m, oracle, V, n_prompt=19, n_decode=6):
+def _check(m, oracle, V, n_prompt=19, n_decode=6, tol=2e-4, exact_tokens=True):
     ids = configs.synthetic_prompt(n_prompt, V)
     ref = oracle.forward(ids, 0)
     got = m.forward_step(ids, 0).reshape(-1)
-    assert rel(got, ref) < 2e-4, rel(got, ref)
+    assert rel(got, ref) < tol, rel(got, ref)
     tok = int(ref.argmax())
     for step in range(n_decode):
         ref = oracle.forward([tok], n_prompt + step)
         got, greedy = m.forward_step_greedy([tok], n_prompt + step), None
         lg = m.read_logits()
-        assert rel(lg, ref) < 2e-4, (step, rel(lg, ref))
-        assert int(got) == int(lg.argmax()) == int(ref.argmax())
+        assert rel(lg, ref) < tol, (step, rel(lg, ref))
+        assert int(got) == int(lg.argmax())
+        if exact_tokens:
+            assert int(got) == int(ref.argmax())
         tok = int(ref.argmax())
 
 
 @pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
 @pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed"])
-def test_gguf_checkpoint_matches_oracle_on_dequantised_weights(tmp_path, name, kind):
+@pytest.mark.parametrize("act", ["int", "f32"])
+def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
+    """act=int (default): ggml / candle vec_dot semantics -- the activation row is quantised to Q8_0 / Q8_K and block
+    products are integer sums -- against the oracle that restates them; act=f32 (CM_QUANT_ACT=f32): exact dequantised
+    weights times f32 activations against the f32 oracle on the dequantised weights."""
     from crane_amd.backend import Model
     cfg = configs.get_config(name)
     w = synth.synth_weights_f32(cfg, seed=0)
     path = str(tmp_path / f"{name}-{kind}.gguf")
-    deq = G.write_qwen3_gguf(path, cfg, w, _types(kind))
+    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types(kind), want_qmats=True)
     if cfg.get("tie_word_embeddings", True):
         deq["lm_head.weight"] = deq["model.embed_tokens.weight"]
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
+    if act == "int":
+        oracle.qmats = G.qwen3_oracle_qmats(cfg, qm)
+    else:
+        monkeypatch.setenv("CM_QUANT_ACT", "f32")
     m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
     try:
         assert m.vocab_size == cfg["vocab_size"] and m.num_layers() == cfg["num_hidden_layers"]
-        _check(m, oracle, cfg["vocab_size"])
-        # generate() and the engine's sequential path run on the quantised decode step too
-        from crane_amd.backend import GenerationConfig
-        ids = configs.synthetic_prompt(7, cfg["vocab_size"])
-        out = m.generate(ids, GenerationConfig.greedy(5))
-        assert out[len(ids):] == oracle.generate(ids, 5)[len(ids):]
+        # kernel level: ONE projection on identical inputs -- integer block sums are exact, only the f32 accumulation
+        # order across blocks differs from the oracle
+        rng = np.random.default_rng(3)
+        H, I = cfg["hidden_size"], cfg["intermediate_size"]
+        P = "model.layers.1."
+        xh = rng.standard_normal(H).astype(np.float32)
+        xi = (rng.standard_normal(I) * np.abs(rng.standard_normal(I))).astype(np.float32)
+        mats = {"o": (P + "self_attn.o_proj.weight", None), "down": (P + "mlp.down_proj.weight", xi)}
+        if kind != "mixed":
+            mats["qkv0"] = ([P + f"self_attn.{n}_proj.weight" for n in "qkv"], xh)
+        else:
+            mats.update({"qkv0": ([P + "self_attn.q_proj.weight"], xh), "qkv2": ([P + "self_attn.v_proj.weight"], xh),
+                         "gate": ([P + "mlp.gate_proj.weight"], xh), "up": ([P + "mlp.up_proj.weight"], xh)})
+        for which, (names, xv) in mats.items():
+            names = [names] if isinstance(names, str) else names
+            if xv is None:
+                xv = rng.standard_normal(deq[names[0]].shape[1]).astype(np.float32)
+            if act == "int":
+                want = np.concatenate([qm[n].vecdot(xv) for n in names])
+            else:
+                want = np.concatenate([deq[n] @ xv for n in names])
+            got = m.debug_qgemv(1, which, xv, want.size)
+            assert rel(got, want) < 2e-5, (which, rel(got, want))
+        if act == "f32":
+            _check(m, oracle, cfg["vocab_size"])
+            from crane_amd.backend import GenerationConfig
+            ids = configs.synthetic_prompt(7, cfg["vocab_size"])
+            out = m.generate(ids, GenerationConfig.greedy(5))      # generate() runs on the quantised decode step too
+            assert out[len(ids):] == oracle.generate(ids, 5)[len(ids):]
+        else:
+            # end to end, an activation code that sits on a rounding boundary can flip with a 1e-6 input difference and
+            # moves a K=256..512 dot product by ~1e-3: inherent to 8-bit activations, so the model-level bound is loose
+            _check(m, oracle, cfg["vocab_size"], tol=3e-2, exact_tokens=False)
     finally:
         m.close()
 
@@ -81,6 +118,7 @@ def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name):
         if any(k.endswith(f"{l}.weight") for l in LINEARS) or (k == "lm_head.weight" and not cfg.get("tie_word_embeddings", True)):
             deq[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
+    monkeypatch.setenv("CM_QUANT_ACT", "f32")          # isolates the weight quantiser; the int path is covered by the GGUF test
     for how in ("opt", "env"):
         if how == "env":
             monkeypatch.setenv("CRANE_ISQ", "q8_0")
