@@ -284,7 +284,7 @@ __device__ __forceinline__ float f16_round(float v) {
     return (float)h;
 }
 
-template <int FMT, int PRO, int EPI>
+template <int FMT, int PRO, int EPI, int U>
 __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     using F = QF<FMT>;
     constexpr int R = 2, CK = F::CK;
@@ -298,6 +298,21 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     float* xd = (float*)(lds_raw + Kpad);                          // block scales: [Kpad/32] (Q8_0) | [Kpad/256] (Q8_K)
     int* xs8 = (int*)(xd + (KQ ? Kpad / 256 : Kpad / 32));         // K-quants: sums of 8 consecutive codes [Kpad/8]
     float* red = (float*)(xs8 + (KQ ? Kpad / 8 : 0));
+
+    // the first batch of weight bytes is requested before the activation row is quantised (independent of x)
+    const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
+    const int G = (N + R - 1) / R;
+    QRow q[R][U];
+    auto load_batch = [&](int g, int c0) {
+        const int r0 = g * R;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if ((c0 + u) * CK + lane_k < K) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) q[i][u] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c0 + u, lane);
+            }
+    };
+    if ((int)(blockIdx.x * 4 + wave) < G) load_batch(blockIdx.x * 4 + wave, 0);
 
     const int n4 = K >> 2;
     float rr = 1.f;
@@ -376,19 +391,17 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     }
     __syncthreads();
 
-    const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
     float best = -INFINITY; int besti = 0x7FFFFFFF;
-    const int G = (N + R - 1) / R;
     for (int g = blockIdx.x * 4 + wave; g < G; g += gridDim.x * 4) {
         const int r0 = g * R;
         float acc[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) acc[i] = 0.f;
-        for (int c = 0; c < nch; ++c) {
-            if (c * CK + lane_k >= K) continue;
-            QRow q[R];
+        for (int c0 = 0; c0 < nch; c0 += U) {
 #pragma unroll
-            for (int i = 0; i < R; ++i) q[i] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c, lane);
+          for (int u = 0; u < U; ++u) {
+            const int c = c0 + u;
+            if (c * CK + lane_k >= K) continue;
             if constexpr (FMT == QFMT_Q8_0) {
                 const int e0 = c * 1024 + lane * 16;
                 const u32x4 xv = *(const u32x4*)(xq + e0);
@@ -397,8 +410,8 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                 for (int i = 0; i < R; ++i) {
                     int isum = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i].a[j], (int)xv[j], isum, false);
-                    acc[i] += (q[i].d * dx) * (float)isum;
+                    for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i][u].a[j], (int)xv[j], isum, false);
+                    acc[i] += (q[i][u].d * dx) * (float)isum;
                 }
             } else if constexpr (FMT == QFMT_Q4_K) {
                 const int kb = c * 8 + (lane >> 3), h = lane & 7, p = h >> 1;
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                 const float dx = xd[kb];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const u32x4 hb = q[i].b;
+                    const u32x4 hb = q[i][u].b;
                     const float d = f16_bits_to_f32(hb[0] & 0xFFFFu), dmin = f16_bits_to_f32(hb[0] >> 16);
                     auto sbyte = [&](int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
                     auto scale_min = [&](int j, int& sc, int& mn) {
@@ -421,8 +434,8 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                     int il = 0, ih = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        il = __builtin_amdgcn_sdot4((int)(q[i].a[j] & 0x0F0F0F0Fu), (int)x0[j], il, false);
-                        ih = __builtin_amdgcn_sdot4((int)((q[i].a[j] >> 4) & 0x0F0F0F0Fu), (int)x1[j], ih, false);
+                        il = __builtin_amdgcn_sdot4((int)(q[i][u].a[j] & 0x0F0F0F0Fu), (int)x0[j], il, false);
+                        ih = __builtin_amdgcn_sdot4((int)((q[i][u].a[j] >> 4) & 0x0F0F0F0Fu), (int)x1[j], ih, false);
                     }
                     acc[i] += (dx * d) * (float)(sc0 * il + sc1 * ih) - (dx * dmin) * (float)(m0 * bs0 + m1 * bs1);
                 }
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                 const float dx = xd[kb];
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const float d = f16_bits_to_f32(q[i].b[3]);
+                    const float d = f16_bits_to_f32(q[i][u].b[3]);
                     int sumi = 0;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -443,16 +456,19 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                         int is = 0;
 #pragma unroll
                         for (int wi = 0; wi < 2; ++wi) {
-                            const uint32_t qlw = q[i].a[qsel + wi], qhw = q[i].b[wi];
+                            const uint32_t qlw = q[i][u].a[qsel + wi], qhw = q[i][u].b[wi];
                             const uint32_t code = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
                             is = __builtin_amdgcn_sdot4((int)code, (int)xr[t][wi], is, false);
                         }
-                        const int sc = (int)(signed char)((q[i].b[2] >> (8 * t)) & 0xFFu);
+                        const int sc = (int)(signed char)((q[i][u].b[2] >> (8 * t)) & 0xFFu);
                         sumi += sc * (is - 32 * bs[t]);
                     }
                     acc[i] += (dx * d) * (float)sumi;
                 }
             }
+          }
+          if (c0 + U < nch) load_batch(g, c0 + U);
+          else if (g + (int)gridDim.x * 4 < G) load_batch(g + gridDim.x * 4, 0);
         }
         float mine = 0.f, mine_up = 0.f;
 #pragma unroll
@@ -495,7 +511,13 @@ static void launch_gemvq_i8_f(int pro, int epi, const GemvQArgs& a, int grid, hi
     constexpr int CK = QF<FMT>::CK;
     const size_t kpad = (size_t)((a.w.K + CK - 1) / CK) * CK;
     const size_t lds = kpad + (FMT == QFMT_Q8_0 ? kpad / 32 * 4 : kpad / 256 * 4 + kpad / 8 * 4) + 64;
-#define CM_QI(P, E) { hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E>), dim3(grid), dim3(256), lds, s, a); return; }
+    const int nch = (a.w.K + CK - 1) / CK;
+    static int env_u = -1;
+    if (env_u < 0) { env_u = 0; if (const char* e = getenv("CM_GEMVQ_U")) env_u = atoi(e); }
+    const int want = env_u > 0 ? env_u : 1;          // batching 2 chunks measured no faster (VALU-issue-bound)
+    const int u = (want >= 2 && nch % 2 == 0) ? 2 : 1;
+#define CM_QI(P, E) { if (u == 2) hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E, 2>), dim3(grid), dim3(256), lds, s, a); \
+                      else hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E, 1>), dim3(grid), dim3(256), lds, s, a); return; }
     if (pro == PRO_RMSNORM) {
         if (epi == EPI_STORE) CM_QI(PRO_RMSNORM, EPI_STORE)
         if (epi == EPI_SILUMUL) CM_QI(PRO_RMSNORM, EPI_SILUMUL)
