@@ -198,6 +198,8 @@ int gemvq_grid(int N, int num_cu);
 bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s);
 void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s);
 void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s);
+void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s);
+void launch_embed_rows_q(const QWeight& w, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
 void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s);
 void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s);
 

@@ -622,6 +622,34 @@ __global__ void dequant_rows_kernel(QWeight w, float* __restrict__ out, int row0
     out[i] = q_elem(w, (size_t)row0 + r, (int)(i % (size_t)w.K));
 }
 
+// prefill over quantised weights: rows of W are dequantised to a bf16 scratch matrix for the MFMA GEMM (bf16 rounding
+// of the dequantised value, 2^-9, is below every format's own quantisation step); dst row = row * row_mul + row_off
+// so gate / up matrices of different ggml types can still be interleaved
+__global__ void dequant_bf16_kernel(QWeight w, uint16_t* __restrict__ out, int row_mul, int row_off) {
+    const size_t i8 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i8 >= (size_t)w.N * w.K) return;
+    const size_t r = i8 / (size_t)w.K;
+    const int k = (int)(i8 % (size_t)w.K);
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o[e] = (uint32_t)f32_to_bf16(q_elem(w, r, k + 2 * e)) | ((uint32_t)f32_to_bf16(q_elem(w, r, k + 2 * e + 1)) << 16);
+    *(u32x4*)(out + (r * row_mul + row_off) * (size_t)w.K + k) = (u32x4){o[0], o[1], o[2], o[3]};
+}
+void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s) {
+    const size_t n8 = (size_t)w.N * w.K / 8;
+    hipLaunchKernelGGL(dequant_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, out, row_mul, row_off);
+}
+
+__global__ void embed_rows_q_kernel(QWeight w, const uint32_t* __restrict__ ids, float* __restrict__ x, int H, int V) {
+    uint32_t tok = ids[blockIdx.x];
+    if (tok >= (uint32_t)V) tok = 0;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) x[(size_t)blockIdx.x * H + i] = q_elem(w, (size_t)tok, i);
+}
+void launch_embed_rows_q(const QWeight& w, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s) {
+    hipLaunchKernelGGL(embed_rows_q_kernel, dim3(S), dim3(256), 0, s, w, ids, x, H, V);
+}
+
 void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s) {
     hipLaunchKernelGGL(embed_row_q_kernel, dim3((H + 255) / 256), dim3(256), 0, s, w, st, x, H, V);
 }

@@ -604,6 +604,7 @@ void Model::ensure_prefill_buffers() {
     const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
     pAT_hi = z((size_t)chunk_pad * at_cols); pAT_lo = z((size_t)chunk_pad * at_cols);
     pHH_hi = z((size_t)chunk_pad * I_l); pHH_lo = z((size_t)chunk_pad * I_l);
+    if (quantized) wq_scratch = dalloc<uint16_t>(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H));
     d_ids = (uint32_t*)dalloc<int>(chunk);
     CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
 }
@@ -619,7 +620,8 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         CM_HIP(hipStreamSynchronize(s));                       // h_ids reuse
         memcpy(h_ids, ids + off, (size_t)S * sizeof(uint32_t));
         CM_HIP(hipMemcpyAsync(d_ids, h_ids, (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, s);
+        if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_rows_q(q_embed, d_ids, pX, S, H, cfg.V, s);
+        else launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, s);
         if (splice_map_dev) launch_splice_rows(pX, vFeat, splice_map_dev + off, S, H, s);   // image rows over <|image_pad|>
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
@@ -657,6 +659,10 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 }
             } else {
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
+            if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
+                for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], wq_scratch + (size_t)w.qkv_row0[i] * H, 1, 0, s);
+                g.W = wq_scratch;
+            }
             g.M = S; g.N = qkv_rows; g.K = H;
             if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
             QkRopeArgs q{};
@@ -676,6 +682,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             launch_attn_prefill(at, D, kv_f32, s);
             g = GemmArgs{};
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
+            if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
@@ -686,10 +693,16 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
             g = GemmArgs{};
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
+            if (quantized) {
+                if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
+                else { launch_dequant_bf16(w.q_gate, wq_scratch, 2, 0, s); launch_dequant_bf16(w.q_up, wq_scratch, 2, 1, s); }
+                g.W = wq_scratch;
+            }
             g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
             launch_gemm(g, GEPI_SILUMUL, s);
             g = GemmArgs{};
             g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
+            if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
@@ -874,8 +887,12 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     ensure_pages(s, (int64_t)(start_pos + n));
     activate(s);
     bool use_prefill = false;
-    // quantised weights / quantised KV: token-serial through the decode step (no dequant-GEMM / quantising prefill yet)
-    if (n >= 2 && !quantized && kv_mode < CM_KV_INT8 && getenv("CM_NO_PREFILL") == nullptr) {
+    // quantised KV: token-serial through the decode step (the prefill KV-append kernel does not quantise yet).
+    // quantised weights: each matrix is dequantised to a bf16 scratch in front of its MFMA GEMM (CM_QUANT_PREFILL=0:
+    // token-serial, i.e. the decode kernels' integer-dot arithmetic for the prompt too)
+    const char* qpe = getenv("CM_QUANT_PREFILL");
+    const bool qprefill = qpe == nullptr || atoi(qpe) != 0;
+    if (n >= 2 && (!quantized || qprefill) && kv_mode < CM_KV_INT8 && getenv("CM_NO_PREFILL") == nullptr) {
         ensure_prefill_buffers();
         use_prefill = prefill_ok;
     }

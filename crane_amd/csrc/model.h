@@ -241,6 +241,7 @@ struct Model {
     bool quantized = false;
     bool quant_act_int = true;         // ggml vec_dot semantics: activations -> Q8_0 / Q8_K + integer dots (CM_QUANT_ACT=f32: exact dequant x f32)
     QWeight q_embed, q_lm_head;
+    uint16_t* wq_scratch = nullptr;    // [max N*K] bf16: one dequantised matrix at a time for the prefill GEMMs
     float* gu_tmp = nullptr;           // [2 I] scratch when gate / up have different ggml types
     uint64_t quant_weight_bytes = 0;   // bytes of every quantised matrix read once per decoded token
     void debug_qgemv(int layer, const std::string& which, const float* x, size_t k, float* y, size_t n);

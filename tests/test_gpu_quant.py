@@ -67,6 +67,7 @@ def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
         oracle.qmats = G.qwen3_oracle_qmats(cfg, qm)
     else:
         monkeypatch.setenv("CM_QUANT_ACT", "f32")
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")        # prompts through the decode kernels: one arithmetic end to end
     m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
     try:
         assert m.vocab_size == cfg["vocab_size"] and m.num_layers() == cfg["num_hidden_layers"]
@@ -119,6 +120,7 @@ def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name):
             deq[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
     monkeypatch.setenv("CM_QUANT_ACT", "f32")          # isolates the weight quantiser; the int path is covered by the GGUF test
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
     for how in ("opt", "env"):
         if how == "env":
             monkeypatch.setenv("CRANE_ISQ", "q8_0")
@@ -130,6 +132,38 @@ def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name):
             _check(m, oracle, cfg["vocab_size"])
         finally:
             m.close()
+
+
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "mixed"])
+def test_quantised_prefill_through_dequantised_gemm(tmp_path, monkeypatch, kind):
+    """Prompts over quantised weights run the MFMA GEMMs on a bf16 scratch copy of each dequantised matrix (default);
+    the result must agree with the token-serial decode kernels and with the f32 oracle on the dequantised weights to
+    within the bf16 rounding of the weights (2^-9 per weight -- below every format's own quantisation step)."""
+    from crane_amd.backend import Model
+    cfg = configs.get_config("tiny-qwen3-untied")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / f"p-{kind}.gguf")
+    deq = G.write_qwen3_gguf(path, cfg, w, _types(kind))
+    oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
+    monkeypatch.setenv("CM_QUANT_ACT", "f32")
+    ids = configs.synthetic_prompt(70, cfg["vocab_size"])
+    ref = oracle.forward(ids, 0)
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    try:
+        got = m.forward_step(ids, 0).reshape(-1)                      # MFMA prefill (dequant -> bf16 scratch)
+        monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+        serial = m.forward_step(ids, 0).reshape(-1)                   # token-serial decode kernels
+        assert rel(serial, ref) < 2e-4
+        assert rel(got, ref) < 1e-2 and rel(got, serial) < 1e-2, (rel(got, ref), rel(got, serial))
+        assert int(got.argmax()) == int(ref.argmax())
+        monkeypatch.delenv("CM_QUANT_PREFILL")
+        # decode continues on the KV written by the prefill path
+        tok = int(ref.argmax())
+        r2 = oracle.forward([tok], 70)
+        g2 = m.forward_step(ids, 0); g2 = m.forward_step([tok], 70).reshape(-1)
+        assert rel(g2, r2) < 1e-2
+    finally:
+        m.close()
 
 
 def test_quant_errors():
