@@ -231,7 +231,7 @@ void load_from_gguf(Model& m, const std::string& path) {
 // ------------------------------------------------------------------------------------
 void Model::isq_q8_0() {
     if (tp != 1) throw CmError(CM_ERR_UNSUPPORTED, "ISQ under tensor parallelism is not implemented");
-    if (cfg.hybrid) throw CmError(CM_ERR_UNSUPPORTED, "ISQ is implemented for the dense Qwen3 family only");
+    if (vcfg.present) throw CmError(CM_ERR_UNSUPPORTED, "ISQ of the vision-language checkpoints is not implemented");
     auto quant = [&](uint16_t* src, int N, int K) -> QWeight {
         if (K % 32) throw CmError(CM_ERR_UNSUPPORTED, "ISQ Q8_0 needs the input dimension to be a multiple of 32");
         QWeight w;
@@ -245,16 +245,28 @@ void Model::isq_q8_0() {
     };
     const int H = cfg.H, D = cfg.D;
     for (LayerW& w : layers) {
-        w.q_qkv[0] = quant(w.qkv, (Hq_l + 2 * Hkv_l) * D, H); w.n_qkv = 1; w.qkv_row0[0] = 0;
-        w.q_o = quant(w.o, H, Hq_l * D);
+        if (w.full) {
+            const int rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;     // hybrid: [q | gate | k | v]
+            w.q_qkv[0] = quant(w.qkv, rows, H); w.n_qkv = 1; w.qkv_row0[0] = 0;
+            w.q_o = quant(w.o, H, Hq_l * D);
+        } else {
+            // Gated Delta Net: in_proj_qkv / in_proj_z / out_proj are quantised, the a / b gate projections never are
+            // (ops/gdn/projection.rs:78-83)
+            const int qz = cfg.conv_dim() + cfg.value_dim(), nba = 2 * cfg.NV;
+            w.q_in_proj = quant(w.in_proj, qz, H);
+            w.in_proj_ba = dalloc<uint16_t>((size_t)nba * H, true);
+            CM_HIP(hipMemcpyAsync(w.in_proj_ba, w.in_proj + (size_t)qz * H, (size_t)nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
+            quant_weight_bytes += (uint64_t)nba * H * 2;
+            w.q_out_proj = quant(w.out_proj, H, cfg.value_dim());
+        }
         w.q_gate_up = quant(w.gate_up, 2 * I_l, H);
         w.q_down = quant(w.down, H, I_l);
     }
     if (!cfg.tie) q_lm_head = quant(lm_head, cfg.V, H);
     CM_HIP(hipStreamSynchronize(stream));
     for (LayerW& w : layers) {
-        dfree(w.qkv); dfree(w.o); dfree(w.gate_up); dfree(w.down);
-        w.qkv = w.o = w.gate_up = w.down = nullptr;
+        dfree(w.qkv); dfree(w.o); dfree(w.gate_up); dfree(w.down); dfree(w.in_proj); dfree(w.out_proj);
+        w.qkv = w.o = w.gate_up = w.down = w.in_proj = w.out_proj = nullptr;
     }
     if (!cfg.tie) { dfree(lm_head); lm_head = nullptr; }
     quantized = true;

@@ -521,24 +521,42 @@ void Model::enqueue_decode_step(bool advance) {
     enqueue_lm_head(advance);
 }
 
-// one dense decoder layer over quantised weights (LinearLayer::Quantized, ops/linear.rs:18-51)
+// one decoder layer over quantised weights (LinearLayer::Quantized, ops/linear.rs:18-51): dense Qwen3, or the hybrid
+// family's gated full-attention / Gated-Delta-Net layers
 void Model::enqueue_quant_layer(int li) {
     const LayerW& w = layers[(size_t)li];
-    const int D = cfg.D;
+    const int D = cfg.D, H = cfg.H;
     hipStream_t s = stream;
     auto qg = [&](int pro, int epi, const QWeight& qw, const float* xin, const float* nw, float* yout, const float* res) {
         GemvQArgs q{};
         q.w = qw; q.x = xin; q.nw = nw; q.y = yout; q.res = res; q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
         if (!launch_gemvq(pro, epi, q, gemvq_grid(qw.N, num_cu), s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
     };
-    for (int i = 0; i < w.n_qkv; ++i) qg(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], x, w.ln1, qkv + w.qkv_row0[i], nullptr);
-    AttnDecArgs a{};
-    a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
-    a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
-    a.q_off = 0; a.k_off = Hq_l * D; a.v_off = a.k_off + Hkv_l * D; a.gate = nullptr; a.rot_dim = cfg.rot_dim;
-    a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-    if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-    qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
+    if (!w.full) {
+        const int qz = cfg.conv_dim() + cfg.value_dim();
+        qg(PRO_RMSNORM, EPI_STORE, w.q_in_proj, x, w.ln1, qkv, nullptr);
+        GemvArgs g{};                                    // the a / b gate rows stay bf16
+        g.W = w.in_proj_ba; g.x = x; g.nw = w.ln1; g.y = qkv + qz; g.N = 2 * cfg.NV; g.K = H; g.ldw = H; g.eps = cfg.eps;
+        launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+        GdnArgs ga{};
+        ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
+        ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
+        ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+        ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
+        launch_gdn(ga, s);
+        qg(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attn, nullptr, x, x);
+    } else {
+        for (int i = 0; i < w.n_qkv; ++i) qg(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], x, w.ln1, qkv + w.qkv_row0[i], nullptr);
+        AttnDecArgs a{};
+        a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
+        a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
+        a.q_off = 0; a.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; a.v_off = a.k_off + Hkv_l * D;
+        a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr; a.rot_dim = cfg.rot_dim;
+        a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps;
+        a.scale = (float)(1.0 / std::sqrt((double)D));
+        if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
+    }
     if (!w.split_gate_up) {
         qg(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, x, w.ln2, hbuf, nullptr);
     } else {
@@ -604,7 +622,7 @@ void Model::ensure_prefill_buffers() {
     const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
     pAT_hi = z((size_t)chunk_pad * at_cols); pAT_lo = z((size_t)chunk_pad * at_cols);
     pHH_hi = z((size_t)chunk_pad * I_l); pHH_lo = z((size_t)chunk_pad * I_l);
-    if (quantized) wq_scratch = dalloc<uint16_t>(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H));
+    if (quantized) wq_scratch = dalloc<uint16_t>(std::max(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H), (size_t)in_proj_pad * H));
     d_ids = (uint32_t*)dalloc<int>(chunk);
     CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
 }
@@ -630,6 +648,13 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             if (!w.full) {
                 // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
                 g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
+                if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
+                    const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
+                    launch_dequant_bf16(w.q_in_proj, wq_scratch, 1, 0, s);
+                    CM_HIP(hipMemcpyAsync(wq_scratch + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+                    CM_HIP(hipMemsetAsync(wq_scratch + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
+                    g.W = wq_scratch;
+                }
                 g.M = S; g.N = in_proj_pad; g.K = H;
                 if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
                 GdnArgs ga{};
@@ -651,6 +676,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
                 g = GemmArgs{};
                 g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
+                if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
                 if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
                 else {
                     g.C = pY; launch_gemm(g, GEPI_STORE, s);

@@ -77,6 +77,8 @@ struct LayerW {
     int n_qkv = 0;
     int qkv_row0[3] = {0, 0, 0};
     QWeight q_o, q_gate_up, q_gate, q_up, q_down;
+    QWeight q_in_proj, q_out_proj;   // GDN: in_proj rows [qkv | z] quantised; the a / b gate rows stay bf16 (projection.rs:78-83)
+    uint16_t* in_proj_ba = nullptr;  // [2 NV, H] bf16: b rows then a rows
     bool split_gate_up = false;
 };
 

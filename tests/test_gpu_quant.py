@@ -187,3 +187,53 @@ def test_quant_errors():
             m.step_batch_decode([0, s], [1, 2])
     finally:
         m.close()
+
+
+def test_isq_q8_0_hybrid_family(monkeypatch):
+    """ISQ on Qwen 3.5: every linear is quantised except the GDN a / b gate projections (ops/gdn/projection.rs:78-83);
+    decode (quantised GEMVs + the small bf16 GEMV for a|b) and prefill (dequantised-to-bf16 GEMMs) against the f32
+    oracle on the dequantised weights."""
+    from crane_amd.backend import Model
+    from oracle import qwen3_5_oracle as O5
+    cfg = configs.get_config("tiny-qwen3.5")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    deq = dict(w)
+    quantised = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj", "in_proj_qkv", "in_proj_z", "out_proj")
+    nq = 0
+    for k, v in w.items():
+        if any(k.endswith(f"{l}.weight") for l in quantised) or (k == "lm_head.weight" and not cfg.get("tie_word_embeddings", True)):
+            deq[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
+            nq += 1
+    assert nq > 0 and any(k.endswith("in_proj_a.weight") for k in w)
+    o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), deq)
+    monkeypatch.setenv("CM_QUANT_ACT", "f32")
+    V = cfg["vocab_size"]
+    ids = configs.synthetic_prompt(33, V)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
+    try:
+        monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+        ref = o.forward(ids, 0)
+        got = m.forward_step(ids, 0).reshape(-1)
+        assert rel(got, ref) < 2e-4, rel(got, ref)
+        tok = int(ref.argmax())
+        for step in range(5):
+            ref = o.forward([tok], 33 + step)
+            got = m.forward_step([tok], 33 + step).reshape(-1)
+            assert rel(got, ref) < 2e-4, (step, rel(got, ref))
+            tok = int(ref.argmax())
+        monkeypatch.delenv("CM_QUANT_PREFILL")
+        ref = o.forward(ids, 0)
+        got = m.forward_step(ids, 0).reshape(-1)                 # MFMA prefill on the bf16 scratch
+        assert rel(got, ref) < 1e-2 and int(got.argmax()) == int(ref.argmax()), rel(got, ref)
+    finally:
+        m.close()
+    # integer-dot default: same model, loose agreement with the float-activation result
+    monkeypatch.delenv("CM_QUANT_ACT")
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
+    try:
+        monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+        got = m.forward_step(ids, 0).reshape(-1)
+        ref = o.forward(ids, 0)
+        assert rel(got, ref) < 5e-2, rel(got, ref)
+    finally:
+        m.close()
