@@ -32,11 +32,12 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
     __shared__ float red[8];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bq = blockIdx.y;                                 // sequence of a batched decode step (0 otherwise)
-    const int kh = h / a.vpg;                                  // Interleaved: value head h uses key head h / vpg
+    const int nk = a.NV / a.vpg;
+    const int kh = a.chunked ? h % nk : h / a.vpg;             // Interleaved (HF): h / vpg; Chunked (GGUF): h % NK
     const int cq = kh * K + tid, ck = a.key_dim + kh * K + tid, cv = 2 * a.key_dim + h * V + tid;
     const int conv_dim = 2 * a.key_dim + a.NV * V;
     const int proj_stride = a.proj_stride;
-    const bool writer = (h % a.vpg) == 0;                      // one block per key-head group rolls the q/k windows
+    const bool writer = a.chunked ? (h < nk) : (h % a.vpg) == 0;   // one block per key head rolls the q/k windows
 
     // conv weights of my three channels, state column in registers
     float wq[KER], wk[KER], wv[KER];

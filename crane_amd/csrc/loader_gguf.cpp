@@ -140,7 +140,8 @@ float* load_vec_f32(Model& m, const File& g, const std::string& name, int n) {
 std::string gguf_config_json(const std::string& path) {
     File g(path);
     const std::string a = arch_of(g);
-    if (a != "qwen3") throw CmError(CM_ERR_UNSUPPORTED, "GGUF architecture '" + a + "' not implemented (qwen3)");
+    const bool hybrid = a == "qwen35" || a == "qwen3_5" || a == "qwen35moe";
+    if (a != "qwen3" && !hybrid) throw CmError(CM_ERR_UNSUPPORTED, "GGUF architecture '" + a + "' not implemented (qwen3, qwen35)");
     auto need_u = [&](const std::string& k) -> uint64_t {
         const cmgguf::Value* v = g.meta(a + "." + k);
         if (!v) throw CmError(CM_ERR_IO, "cannot find " + a + "." + k + " in GGUF metadata");
@@ -150,17 +151,59 @@ std::string gguf_config_json(const std::string& path) {
     auto opt_f = [&](const std::string& k, double def) { const cmgguf::Value* v = g.meta(a + "." + k); return v ? v->as_f64() : def; };
     const TensorInfo& emb = g.tensor("token_embd.weight");
     if (emb.shape.size() != 2) throw CmError(CM_ERR_IO, "token_embd.weight must be a matrix");
-    char buf[1024];
+    char buf[2048];
+    if (!hybrid) {
+        snprintf(buf, sizeof buf,
+                 "{\"model_type\":\"qwen3\",\"hidden_size\":%llu,\"num_hidden_layers\":%llu,\"num_attention_heads\":%llu,"
+                 "\"num_key_value_heads\":%llu,\"head_dim\":%llu,\"intermediate_size\":%llu,\"vocab_size\":%llu,"
+                 "\"max_position_embeddings\":%llu,\"rms_norm_eps\":%.9g,\"rope_theta\":%.9g,\"tie_word_embeddings\":%s,\"use_qk_norm\":%s}",
+                 (unsigned long long)need_u("embedding_length"), (unsigned long long)need_u("block_count"),
+                 (unsigned long long)need_u("attention.head_count"), (unsigned long long)need_u("attention.head_count_kv"),
+                 (unsigned long long)opt_u("attention.key_length", 128), (unsigned long long)need_u("feed_forward_length"),
+                 (unsigned long long)emb.shape[0], (unsigned long long)opt_u("context_length", 32768),
+                 opt_f("attention.layer_norm_rms_epsilon", 1e-6), opt_f("rope.freq_base", 1e6),
+                 g.has("output.weight") ? "false" : "true", g.has("blk.0.attn_q_norm.weight") ? "true" : "false");
+        return buf;
+    }
+    // Qwen 3.5 family (qwen3_5/model.rs:155-287)
+    const uint64_t head_dim = need_u("attention.key_length"), L = need_u("block_count"), Hq = need_u("attention.head_count");
+    const uint64_t nv = need_u("ssm.time_step_rank"), inner = need_u("ssm.inner_size");
+    const uint64_t rot = opt_u("rope.dimension_count", head_dim / 4);
+    uint64_t interval = opt_u("full_attention_interval", 4);
+    // layer kinds come from tensor presence (model.rs:223-232); they must follow the interval rule this runtime uses
+    int first_full = -1;
+    for (uint64_t i = 0; i < L; ++i)
+        if (!g.has("blk." + std::to_string(i) + ".ssm_a")) { first_full = (int)i; break; }
+    if (first_full >= 0 && !g.meta(a + ".full_attention_interval")) interval = (uint64_t)first_full + 1;
+    for (uint64_t i = 0; i < L; ++i) {
+        const bool full = !g.has("blk." + std::to_string(i) + ".ssm_a");
+        if (full != (((i + 1) % interval) == 0)) throw CmError(CM_ERR_UNSUPPORTED, "GGUF layer kinds do not follow full_attention_interval");
+    }
+    bool gate = true;
+    if (first_full >= 0) {
+        const TensorInfo& q = g.tensor("blk." + std::to_string(first_full) + ".attn_q.weight");
+        gate = q.shape.size() == 2 && q.shape[0] == 2 * Hq * head_dim;            // model.rs:235-248
+    }
+    std::string sec = "[";
+    if (const cmgguf::Value* v = g.meta(a + ".rope.dimension_sections"))
+        for (size_t i = 0; i < v->arr.size() && i < 3; ++i) sec += (i ? "," : "") + std::to_string((long long)std::max<int64_t>(0, (int64_t)v->arr[i].as_f64()));
+    sec += "]";
     snprintf(buf, sizeof buf,
-             "{\"model_type\":\"qwen3\",\"hidden_size\":%llu,\"num_hidden_layers\":%llu,\"num_attention_heads\":%llu,"
+             "{\"model_type\":\"qwen3_5_text\",\"hidden_size\":%llu,\"num_hidden_layers\":%llu,\"num_attention_heads\":%llu,"
              "\"num_key_value_heads\":%llu,\"head_dim\":%llu,\"intermediate_size\":%llu,\"vocab_size\":%llu,"
-             "\"max_position_embeddings\":%llu,\"rms_norm_eps\":%.9g,\"rope_theta\":%.9g,\"tie_word_embeddings\":%s,\"use_qk_norm\":%s}",
-             (unsigned long long)need_u("embedding_length"), (unsigned long long)need_u("block_count"),
-             (unsigned long long)need_u("attention.head_count"), (unsigned long long)need_u("attention.head_count_kv"),
-             (unsigned long long)opt_u("attention.key_length", 128), (unsigned long long)need_u("feed_forward_length"),
-             (unsigned long long)emb.shape[0], (unsigned long long)opt_u("context_length", 32768),
-             opt_f("attention.layer_norm_rms_epsilon", 1e-6), opt_f("rope.freq_base", 1e6),
-             g.has("output.weight") ? "false" : "true", g.has("blk.0.attn_q_norm.weight") ? "true" : "false");
+             "\"max_position_embeddings\":%llu,\"rms_norm_eps\":%.9g,\"tie_word_embeddings\":%s,\"full_attention_interval\":%llu,"
+             "\"linear_conv_kernel_dim\":%llu,\"linear_key_head_dim\":%llu,\"linear_value_head_dim\":%llu,\"linear_num_key_heads\":%llu,"
+             "\"linear_num_value_heads\":%llu,\"attn_output_gate\":%s,"
+             "\"rope_parameters\":{\"rope_theta\":%.9g,\"partial_rotary_factor\":%.9g,\"mrope_section\":%s}}",
+             (unsigned long long)need_u("embedding_length"), (unsigned long long)L, (unsigned long long)Hq,
+             (unsigned long long)need_u("attention.head_count_kv"), (unsigned long long)head_dim,
+             (unsigned long long)need_u("feed_forward_length"), (unsigned long long)emb.shape[0],
+             (unsigned long long)opt_u("context_length", 262144), opt_f("attention.layer_norm_rms_epsilon", 1e-6),
+             g.has("output.weight") ? "false" : "true", (unsigned long long)interval,
+             (unsigned long long)need_u("ssm.conv_kernel"), (unsigned long long)need_u("ssm.state_size"),
+             (unsigned long long)(inner / std::max<uint64_t>(1, nv)), (unsigned long long)need_u("ssm.group_count"),
+             (unsigned long long)nv, gate ? "true" : "false", opt_f("rope.freq_base", 1e7),
+             (double)rot / (double)head_dim, sec.c_str());
     return buf;
 }
 
@@ -178,27 +221,85 @@ void load_from_gguf(Model& m, const std::string& path) {
         else { m.q_lm_head = m.q_embed; m.quant_weight_bytes += m.q_embed.bytes(); }
         m.layers.resize((size_t)c.L);
         const int qd = c.Hq * D, kd = c.Hkv * D;
+        m.gdn_chunked = c.hybrid;                  // llama.cpp orders the GDN value heads Chunked (ops/gdn/config.rs:13-22)
+        int gdn_idx = 0;
         for (int li = 0; li < c.L; ++li) {
             LayerW& w = m.layers[(size_t)li];
-            w.full = true;
+            w.full = c.layer_full(li);
             const std::string p = "blk." + std::to_string(li) + ".";
+            if (!w.full) {
+                // Gated Delta Net block (qwen3_5/modeling.rs:725-765): attn_qkv = in_proj_qkv, attn_gate = z, ssm_beta / ssm_alpha =
+                // b / a (dequantised, never quantised), ssm_conv1d [conv_dim, k], ssm_a = -exp(A_log), ssm_dt.bias, ssm_norm, ssm_out
+                w.gdn_idx = gdn_idx++;
+                const int cd = c.conv_dim(), vd = c.value_dim(), nv = c.NV;
+                const TensorInfo &tqkv = g.tensor(p + "attn_qkv.weight"), &tz = g.tensor(p + "attn_gate.weight");
+                check_shape(tqkv, (uint64_t)cd, (uint64_t)H); check_shape(tz, (uint64_t)vd, (uint64_t)H);
+                if (tqkv.type == tz.type) {
+                    Packed pk;
+                    pack_rows(tqkv, 0, cd, H, pk); pack_rows(tz, 0, vd, H, pk);
+                    w.q_in_proj = to_device(m, pk, cd + vd, H);
+                } else {
+                    w.q_in_proj = load_matrix(m, g, p + "attn_qkv.weight", cd, H);
+                    w.q_in_proj_z = load_matrix(m, g, p + "attn_gate.weight", vd, H);
+                }
+                // b rows then a rows, kept in the model dtype (bf16)
+                std::vector<uint16_t> ba((size_t)2 * nv * H);
+                for (int which = 0; which < 2; ++which) {
+                    const TensorInfo& t = g.tensor(p + (which == 0 ? "ssm_beta.weight" : "ssm_alpha.weight"));
+                    check_shape(t, (uint64_t)nv, (uint64_t)H);
+                    for (size_t i = 0; i < (size_t)nv * H; ++i) {
+                        float f;
+                        if (t.type == cmgguf::F32) memcpy(&f, t.data + i * 4, 4);
+                        else if (t.type == cmgguf::F16) { uint16_t v; memcpy(&v, t.data + i * 2, 2); f = f16_to_f32(v); }
+                        else if (t.type == cmgguf::BF16) { uint16_t v; memcpy(&v, t.data + i * 2, 2); const uint32_t u = (uint32_t)v << 16; memcpy(&f, &u, 4); }
+                        else throw CmError(CM_ERR_UNSUPPORTED, "ssm_alpha / ssm_beta must be F32 / F16 / BF16");
+                        uint32_t u; memcpy(&u, &f, 4);
+                        ba[(size_t)which * nv * H + i] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                    }
+                }
+                w.in_proj_ba = m.dalloc<uint16_t>(ba.size(), true);
+                CM_HIP(hipMemcpy(w.in_proj_ba, ba.data(), ba.size() * 2, hipMemcpyHostToDevice));
+                m.quant_weight_bytes += ba.size() * 2;
+                w.q_out_proj = load_matrix(m, g, p + "ssm_out.weight", H, vd);
+                w.conv_w = load_vec_f32(m, g, p + "ssm_conv1d.weight", cd * c.conv_k);
+                {   // A_log = log(-ssm_a)
+                    const TensorInfo& t = g.tensor(p + "ssm_a");
+                    if (t.numel() != (uint64_t)nv || t.type != cmgguf::F32) throw CmError(CM_ERR_IO, "ssm_a must be F32 [num_v_heads]");
+                    std::vector<float> al((size_t)nv);
+                    for (int i = 0; i < nv; ++i) { float v; memcpy(&v, t.data + (size_t)i * 4, 4); al[(size_t)i] = logf(-v); }
+                    w.A_log = m.dalloc<float>((size_t)nv, true);
+                    CM_HIP(hipMemcpy(w.A_log, al.data(), (size_t)nv * 4, hipMemcpyHostToDevice));
+                }
+                w.dt_bias = load_vec_f32(m, g, p + "ssm_dt.bias", nv);
+                w.gnorm = load_vec_f32(m, g, p + "ssm_norm.weight", c.Vd);
+            } else {
             const TensorInfo &tq = g.tensor(p + "attn_q.weight"), &tk = g.tensor(p + "attn_k.weight"), &tv = g.tensor(p + "attn_v.weight");
-            check_shape(tq, (uint64_t)qd, (uint64_t)H); check_shape(tk, (uint64_t)kd, (uint64_t)H); check_shape(tv, (uint64_t)kd, (uint64_t)H);
+            const int qrows = c.hybrid ? 2 * qd : qd;
+            check_shape(tq, (uint64_t)qrows, (uint64_t)H); check_shape(tk, (uint64_t)kd, (uint64_t)H); check_shape(tv, (uint64_t)kd, (uint64_t)H);
+            // hybrid: attn_q keeps HF's per-head [query | gate] rows (modeling.rs:376-378); HBM layout is [all q | all gate | k | v]
+            auto pack_q = [&](Packed& pk) {
+                if (!c.hybrid) { pack_rows(tq, 0, qd, H, pk); return; }
+                for (int h = 0; h < c.Hq; ++h) pack_rows(tq, h * 2 * D, D, H, pk);
+                for (int h = 0; h < c.Hq; ++h) pack_rows(tq, h * 2 * D + D, D, H, pk);
+            };
             if (tq.type == tk.type && tk.type == tv.type) {
                 Packed pk;
-                pack_rows(tq, 0, qd, H, pk); pack_rows(tk, 0, kd, H, pk); pack_rows(tv, 0, kd, H, pk);
-                w.q_qkv[0] = to_device(m, pk, qd + 2 * kd, H);
+                pack_q(pk); pack_rows(tk, 0, kd, H, pk); pack_rows(tv, 0, kd, H, pk);
+                w.q_qkv[0] = to_device(m, pk, qrows + 2 * kd, H);
                 w.n_qkv = 1; w.qkv_row0[0] = 0;
             } else {
-                w.q_qkv[0] = load_matrix(m, g, p + "attn_q.weight", qd, H);
+                Packed pq;
+                pack_q(pq);
+                w.q_qkv[0] = to_device(m, pq, qrows, H);
                 w.q_qkv[1] = load_matrix(m, g, p + "attn_k.weight", kd, H);
                 w.q_qkv[2] = load_matrix(m, g, p + "attn_v.weight", kd, H);
-                w.n_qkv = 3; w.qkv_row0[0] = 0; w.qkv_row0[1] = qd; w.qkv_row0[2] = qd + kd;
+                w.n_qkv = 3; w.qkv_row0[0] = 0; w.qkv_row0[1] = qrows; w.qkv_row0[2] = qrows + kd;
             }
             w.q_o = load_matrix(m, g, p + "attn_output.weight", H, qd);
             if (c.qk_norm) {
-                w.qn = load_vec_f32(m, g, p + "attn_q_norm.weight", D);
+                w.qn = load_vec_f32(m, g, p + "attn_q_norm.weight", D);         // hybrid: stored with the +1 already folded
                 w.kn = load_vec_f32(m, g, p + "attn_k_norm.weight", D);
+            }
             }
             const TensorInfo &tg = g.tensor(p + "ffn_gate.weight"), &tu = g.tensor(p + "ffn_up.weight");
             check_shape(tg, (uint64_t)I, (uint64_t)H); check_shape(tu, (uint64_t)I, (uint64_t)H);
@@ -213,8 +314,8 @@ void load_from_gguf(Model& m, const std::string& path) {
                 if (!m.gu_tmp) m.gu_tmp = m.dalloc<float>((size_t)2 * I);
             }
             w.q_down = load_matrix(m, g, p + "ffn_down.weight", H, I);
-            w.ln1 = load_vec_f32(m, g, p + "attn_norm.weight", H);
-            w.ln2 = load_vec_f32(m, g, p + "ffn_norm.weight", H);
+            w.ln1 = load_vec_f32(m, g, p + "attn_norm.weight", H);             // hybrid: +1 pre-folded (modeling.rs:693-695)
+            w.ln2 = load_vec_f32(m, g, p + (c.hybrid ? "post_attention_norm.weight" : "ffn_norm.weight"), H);
         }
         CM_HIP(hipStreamSynchronize(m.stream));
     } catch (const CmError&) {

@@ -464,7 +464,7 @@ void Model::enqueue_decode_step(bool advance) {
             GdnArgs ga{};
             ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
             ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
-            ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+            ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
             ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
             launch_gdn(ga, s);
             g = GemvArgs{};
@@ -535,13 +535,14 @@ void Model::enqueue_quant_layer(int li) {
     if (!w.full) {
         const int qz = cfg.conv_dim() + cfg.value_dim();
         qg(PRO_RMSNORM, EPI_STORE, w.q_in_proj, x, w.ln1, qkv, nullptr);
+        if (w.q_in_proj_z.fmt != QFMT_NONE) qg(PRO_RMSNORM, EPI_STORE, w.q_in_proj_z, x, w.ln1, qkv + w.q_in_proj.N, nullptr);
         GemvArgs g{};                                    // the a / b gate rows stay bf16
         g.W = w.in_proj_ba; g.x = x; g.nw = w.ln1; g.y = qkv + qz; g.N = 2 * cfg.NV; g.K = H; g.ldw = H; g.eps = cfg.eps;
         launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
         GdnArgs ga{};
         ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
         ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
-        ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+        ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
         ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
         launch_gdn(ga, s);
         qg(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attn, nullptr, x, x);
@@ -651,6 +652,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
                     const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
                     launch_dequant_bf16(w.q_in_proj, wq_scratch, 1, 0, s);
+                    if (w.q_in_proj_z.fmt != QFMT_NONE) launch_dequant_bf16(w.q_in_proj_z, wq_scratch + (size_t)w.q_in_proj.N * H, 1, 0, s);
                     CM_HIP(hipMemcpyAsync(wq_scratch + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
                     CM_HIP(hipMemsetAsync(wq_scratch + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
                     g.W = wq_scratch;
@@ -660,7 +662,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 GdnArgs ga{};
                 ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
                 ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.st = nullptr;
-                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.slot = active_seq; ga.n_seq = 1;
                 // the conv windows are double-buffered by position parity: every launch must advance an ODD
@@ -851,7 +853,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 GdnArgs ga{};
                 ga.proj = qkvb; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
                 ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attnb; ga.st = stb;
-                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK;
+                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
                 launch_gdn(ga, s);

@@ -77,7 +77,7 @@ struct LayerW {
     int n_qkv = 0;
     int qkv_row0[3] = {0, 0, 0};
     QWeight q_o, q_gate_up, q_gate, q_up, q_down;
-    QWeight q_in_proj, q_out_proj;   // GDN: in_proj rows [qkv | z] quantised; the a / b gate rows stay bf16 (projection.rs:78-83)
+    QWeight q_in_proj, q_in_proj_z, q_out_proj;   // GDN: in_proj rows [qkv | z] quantised; the a / b gate rows stay bf16 (projection.rs:78-83)
     uint16_t* in_proj_ba = nullptr;  // [2 NV, H] bf16: b rows then a rows
     bool split_gate_up = false;
 };
@@ -241,6 +241,7 @@ struct Model {
 
     // quantised weights (dense Qwen3, TP = 1): embedding / lm_head tables + per-layer QWeights in LayerW
     bool quantized = false;
+    bool gdn_chunked = false;          // GGUF value-head order (VHeadOrder::Chunked)
     bool quant_act_int = true;         // ggml vec_dot semantics: activations -> Q8_0 / Q8_K + integer dots (CM_QUANT_ACT=f32: exact dequant x f32)
     QWeight q_embed, q_lm_head;
     uint16_t* wq_scratch = nullptr;    // [max N*K] bf16: one dequantised matrix at a time for the prefill GEMMs

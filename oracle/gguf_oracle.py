@@ -481,3 +481,98 @@ def _q6k_codes(b: np.ndarray) -> np.ndarray:
         y[:, base + 64 + l] = (L[:, l] >> 4) | (((H[:, l] >> 4) & 3) << 4)
         y[:, base + 96 + l] = (L[:, l + 32] >> 4) | (((H[:, l] >> 6) & 3) << 4)
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Qwen 3.5 family <-> llama.cpp `qwen35` GGUF layout (qwen3_5/model.rs:155-325, modeling.rs:375-411,684-775):
+#   block / final / per-head q,k norms stored with the +1 already folded; ssm_norm plain
+#   linear-attention blocks: attn_qkv (in_proj_qkv), attn_gate (z), ssm_beta (b), ssm_alpha (a), ssm_conv1d [conv_dim, k],
+#   ssm_a = -exp(A_log), ssm_dt.bias, ssm_norm, ssm_out; full-attention: attn_q ([q | gate] per head), attn_k/v/output
+#   value-head axis is CHUNKED (index = replica * num_k_heads + key_head), HF is Interleaved (key_head * vpg + replica)
+# ---------------------------------------------------------------------------------------------------------
+def _chunk_perm(NK: int, NV: int) -> np.ndarray:
+    """perm[c] = HF (interleaved) value-head index stored at chunked position c."""
+    vpg = NV // NK
+    return np.array([(c % NK) * vpg + (c // NK) for c in range(NV)], dtype=np.int64)
+
+
+def qwen35_metadata(cfg: dict) -> Dict[str, tuple]:
+    a, t = "qwen35", cfg.get("text_config", cfg)
+    rp = t.get("rope_parameters", {})
+    D = t["head_dim"]
+    md = {
+        "general.architecture": (T_STR, a),
+        f"{a}.block_count": (T_U32, t["num_hidden_layers"]), f"{a}.embedding_length": (T_U32, t["hidden_size"]),
+        f"{a}.feed_forward_length": (T_U32, t["intermediate_size"]), f"{a}.attention.head_count": (T_U32, t["num_attention_heads"]),
+        f"{a}.attention.head_count_kv": (T_U32, t["num_key_value_heads"]), f"{a}.attention.key_length": (T_U32, D),
+        f"{a}.context_length": (T_U32, t.get("max_position_embeddings", 262144)),
+        f"{a}.attention.layer_norm_rms_epsilon": (T_F32, t.get("rms_norm_eps", 1e-6)),
+        f"{a}.rope.freq_base": (T_F32, rp.get("rope_theta", 1e7)),
+        f"{a}.rope.dimension_count": (T_U32, int(D * rp.get("partial_rotary_factor", 0.25))),
+        f"{a}.rope.dimension_sections": (T_ARR, (T_I32, list(rp.get("mrope_section", [11, 11, 10])) + [0])),
+        f"{a}.full_attention_interval": (T_U32, t.get("full_attention_interval", 4)),
+        f"{a}.ssm.conv_kernel": (T_U32, t.get("linear_conv_kernel_dim", 4)), f"{a}.ssm.state_size": (T_U32, t["linear_key_head_dim"]),
+        f"{a}.ssm.group_count": (T_U32, t["linear_num_key_heads"]), f"{a}.ssm.time_step_rank": (T_U32, t["linear_num_value_heads"]),
+        f"{a}.ssm.inner_size": (T_U32, t["linear_num_value_heads"] * t["linear_value_head_dim"]),
+    }
+    return md
+
+
+def write_qwen35_gguf(path: str, cfg: dict, w: Dict[str, np.ndarray], type_of) -> Dict[str, np.ndarray]:
+    """HF-named f32 weights -> qwen35 GGUF.  Returns the HF-named, HF-ordered weights a loader of the file computes with
+    (matrices dequantised from the file and un-permuted; A_log = log(-ssm_a))."""
+    t = cfg.get("text_config", cfg)
+    L, NK, NV = t["num_hidden_layers"], t["linear_num_key_heads"], t["linear_num_value_heads"]
+    K, V, interval = t["linear_key_head_dim"], t["linear_value_head_dim"], t.get("full_attention_interval", 4)
+    KD = NK * K
+    perm = _chunk_perm(NK, NV)
+    inv = np.argsort(perm)
+    vrow = (perm[:, None] * V + np.arange(V)[None, :]).reshape(-1)          # chunked position -> HF row of the value axis
+    vinv = (inv[:, None] * V + np.arange(V)[None, :]).reshape(-1)
+    tensors, out = [], dict(w)
+
+    def put(gg, arr, hf=None, undo=None, force=None):
+        arr = np.asarray(arr, np.float32)
+        gt = force if force is not None else (GGML_F32 if arr.ndim == 1 else type_of(gg, arr.shape))
+        tensors.append((gg, arr, gt))
+        if hf is not None:
+            d = dequantize(quantize(arr, gt), gt, arr.size).reshape(arr.shape)
+            out[hf] = undo(d) if undo else d
+
+    put("token_embd.weight", w["model.embed_tokens.weight"], "model.embed_tokens.weight")
+    put("output_norm.weight", w["model.norm.weight"] + 1.0)
+    if "lm_head.weight" in w and not t.get("tie_word_embeddings", cfg.get("tie_word_embeddings", False)):
+        put("output.weight", w["lm_head.weight"], "lm_head.weight")
+    for i in range(L):
+        p, g = f"model.layers.{i}.", f"blk.{i}."
+        put(g + "attn_norm.weight", w[p + "input_layernorm.weight"] + 1.0)
+        put(g + "post_attention_norm.weight", w[p + "post_attention_layernorm.weight"] + 1.0)
+        for n in ("gate", "up", "down"):
+            put(g + f"ffn_{n}.weight", w[p + f"mlp.{n}_proj.weight"], p + f"mlp.{n}_proj.weight")
+        if (i + 1) % interval == 0:
+            a = p + "self_attn."
+            put(g + "attn_q.weight", w[a + "q_proj.weight"], a + "q_proj.weight")
+            put(g + "attn_k.weight", w[a + "k_proj.weight"], a + "k_proj.weight")
+            put(g + "attn_v.weight", w[a + "v_proj.weight"], a + "v_proj.weight")
+            put(g + "attn_output.weight", w[a + "o_proj.weight"], a + "o_proj.weight")
+            put(g + "attn_q_norm.weight", w[a + "q_norm.weight"] + 1.0)
+            put(g + "attn_k_norm.weight", w[a + "k_norm.weight"] + 1.0)
+        else:
+            a = p + "linear_attn."
+            qkv = w[a + "in_proj_qkv.weight"]
+            rows = np.concatenate([np.arange(2 * KD), 2 * KD + vrow])
+            rinv = np.concatenate([np.arange(2 * KD), 2 * KD + vinv])
+            put(g + "attn_qkv.weight", qkv[rows], a + "in_proj_qkv.weight", undo=lambda d, r=rinv: d[r])
+            put(g + "attn_gate.weight", w[a + "in_proj_z.weight"][vrow], a + "in_proj_z.weight", undo=lambda d: d[vinv])
+            put(g + "ssm_beta.weight", w[a + "in_proj_b.weight"][perm], force=GGML_F32)
+            put(g + "ssm_alpha.weight", w[a + "in_proj_a.weight"][perm], force=GGML_F32)
+            conv = w[a + "conv1d.weight"].reshape(2 * KD + NV * V, -1)
+            put(g + "ssm_conv1d.weight", conv[rows], force=GGML_F32)
+            ssm_a = (-np.exp(w[a + "A_log"].astype(np.float32))).astype(np.float32)
+            put(g + "ssm_a", ssm_a[perm], force=GGML_F32)
+            out[a + "A_log"] = np.log(-ssm_a).astype(np.float32)
+            put(g + "ssm_dt.bias", w[a + "dt_bias"][perm], force=GGML_F32)
+            put(g + "ssm_norm.weight", w[a + "norm.weight"], force=GGML_F32)
+            put(g + "ssm_out.weight", w[a + "out_proj.weight"][:, vrow], a + "out_proj.weight", undo=lambda d: d[:, vinv])
+    write_gguf(path, qwen35_metadata(cfg), tensors)
+    return out

@@ -237,3 +237,49 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
         assert rel(got, ref) < 5e-2, rel(got, ref)
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("kind", ["q8_0", "mixed35"])
+def test_qwen35_gguf_checkpoint(tmp_path, monkeypatch, kind):
+    """llama.cpp `qwen35` GGUF layout (qwen3_5/model.rs:155-325, modeling.rs:375-411,684-775): pre-folded +1 norms, ssm_a =
+    -exp(A_log), [conv_dim, k] conv taps, per-head [q | gate] attn_q rows, a / b never quantised and -- the silent one --
+    the CHUNKED value-head order (ops/gdn/config.rs:13-22).  The file is written from HF-ordered weights with the
+    converter's transforms; the HF-order oracle on the dequantised weights must be reproduced."""
+    from crane_amd.backend import Model
+    from oracle import qwen3_5_oracle as O5
+    cfg = configs.get_config("tiny-qwen3.5")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    if kind == "q8_0":
+        type_of = lambda name, shape: G.GGML_Q8_0
+    else:      # different types inside in_proj (qkv vs z), inside q|k|v and inside gate/up
+        def type_of(name, shape):
+            if "attn_gate" in name or "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
+                return G.GGML_Q6_K
+            if "ssm_out" in name or "attn_output" in name or name == "output.weight":
+                return G.GGML_Q8_0
+            return G.GGML_Q4_K
+    path = str(tmp_path / f"q35-{kind}.gguf")
+    deq = G.write_qwen35_gguf(path, cfg, w, type_of)
+    o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), deq)
+    monkeypatch.setenv("CM_QUANT_ACT", "f32")
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+    V = cfg["vocab_size"]
+    ids = configs.synthetic_prompt(21, V)
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    try:
+        assert m.num_layers() == cfg["num_hidden_layers"] and m.vocab_size == V
+        ref = o.forward(ids, 0)
+        got = m.forward_step(ids, 0).reshape(-1)
+        assert rel(got, ref) < 3e-4, rel(got, ref)
+        tok = int(ref.argmax())
+        for step in range(4):
+            ref = o.forward([tok], 21 + step)
+            got = m.forward_step([tok], 21 + step).reshape(-1)
+            assert rel(got, ref) < 3e-4, (step, rel(got, ref))
+            tok = int(ref.argmax())
+        monkeypatch.delenv("CM_QUANT_PREFILL")
+        ref = o.forward(ids, 0)
+        got = m.forward_step(ids, 0).reshape(-1)                 # MFMA prefill on the dequantised bf16 scratch
+        assert rel(got, ref) < 2e-2, rel(got, ref)
+    finally:
+        m.close()
