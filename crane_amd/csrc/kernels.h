@@ -97,6 +97,11 @@ struct QkRopeArgs {
     const int32_t* pos3;         // MRoPE positions (T, H, W): pos3[axis * pos3_stride + s], or null (position = start_pos + s)
     int pos3_stride, sec_h, sec_w;   // mrope_section[1], [2]
     float eps, scale;
+    // int8 / int4 KV: codes + scales go to kpool / vpool (page_bytes layout), the DEQUANTISED row goes to the f32 shadow
+    // (identity page table) that the prefill attention reads
+    size_t page_bytes = 0;
+    float* kshadow = nullptr;
+    float* vshadow = nullptr;
 };
 
 struct AttnPreArgs {
@@ -116,7 +121,9 @@ struct AttnPreArgs {
 void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
 void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t* lo, int S, int H, float eps,
                          hipStream_t s);
-void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, bool kv_f32, hipStream_t s);
+void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, int kv_mode, hipStream_t s);
+void launch_kvq_dequant_prefix(const void* kpool, const void* vpool, const int32_t* block_table, float* kshadow, float* vshadow,
+                               int tokens, int Hkv, int page, int D, int kv_mode, size_t page_bytes, hipStream_t s);
 void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);

@@ -68,9 +68,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
 // grid (S, Hq + 2 Hkv), block 64: per-head RMSNorm(q,k) BEFORE RoPE (qwen3/modeling.rs:341-359,
 // qwen3_5/modeling.rs:464-468), rotate-half over the first rot_dim dims, q scaled by 1/sqrt(D)
 // -> bf16 hi/lo [S, Hq, D]; k, v -> paged cache at position start+s.
-template <int D, bool KVF32>
+template <int D, int KVT>
 __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
     constexpr int EPL = D / 64;
+    constexpr bool KVF32 = KVT == 1;
     __shared__ float tmp[D];
     const int s = blockIdx.x, item = blockIdx.y, lane = threadIdx.x;
     const int Hq = a.Hq, Hkv = a.Hkv;
@@ -120,6 +121,34 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
             a.q_hi[off + lane + 64 * j] = h;
             a.q_lo[off + lane + 64 * j] = f32_to_bf16(x - bf16_to_f32(h));
         }
+    } else if (KVT >= 2) {
+        // quantize_per_token (qwen3_5/kv_cache.rs:253-268), same arithmetic as the decode kernel's append
+        constexpr float QMAX = KVT == 2 ? 127.f : 7.f, OFFS = KVT == 2 ? 128.f : 8.f;
+        constexpr int ROWB = KVT == 2 ? D : D / 2;
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) amax = fmaxf(amax, fabsf(xv[j]));
+        amax = wave_max(amax);
+        const float scale = __fadd_rn(__fmul_rn(amax, (float)(1.0 / (double)QMAX)), 1e-8f);
+        uint8_t* pb = (uint8_t*)(is_k ? a.kpool : a.vpool);
+        float* sh = is_k ? a.kshadow : a.vshadow;
+        const int page = a.block_table[pos / a.page];
+        const size_t roff = (size_t)page * a.page_bytes + (size_t)(kvh * a.page + (pos % a.page)) * ROWB;
+        const size_t soff = (size_t)page * a.page_bytes + (size_t)Hkv * a.page * ROWB + (size_t)(kvh * a.page + (pos % a.page)) * 4;
+        const size_t hoff = ((size_t)((pos / a.page) * Hkv + kvh) * a.page + (pos % a.page)) * D;       // shadow: identity pages
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int d = lane + 64 * j;
+            const float code = roundf(__fdiv_rn(xv[j], scale)) + OFFS;
+            sh[hoff + d] = __fmul_rn(code - OFFS, scale);
+            const uint32_t ci = (uint32_t)(int)code;
+            if (KVT == 2) pb[roff + d] = (uint8_t)ci;
+            else {
+                const uint32_t hi = (uint32_t)__shfl_down((int)ci, 1);
+                if (!(lane & 1)) pb[roff + (d >> 1)] = (uint8_t)(ci | (hi << 4));
+            }
+        }
+        if (lane == 0) *(float*)(pb + soff) = scale;
     } else {
         void* pool = is_k ? a.kpool : a.vpool;
         const int page = a.block_table[pos / a.page];
@@ -129,6 +158,30 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
             if (KVF32) ((float*)pool)[off + lane + 64 * j] = xv[j];
             else ((uint16_t*)pool)[off + lane + 64 * j] = f32_to_bf16(xv[j]);
         }
+    }
+}
+
+// chunked prefill over a quantised cache: the tokens already cached are dequantised into the f32 shadow first
+// grid (tokens, 2 * Hkv), one wave per (token, K|V, kv head)
+template <int D, int KVT>
+__global__ __launch_bounds__(64) void kvq_dequant_prefix_kernel(const uint8_t* __restrict__ kpool, const uint8_t* __restrict__ vpool,
+                                                                const int32_t* __restrict__ block_table, float* __restrict__ kshadow,
+                                                                float* __restrict__ vshadow, int Hkv, int page, size_t page_bytes) {
+    constexpr int ROWB = KVT == 2 ? D : D / 2;
+    constexpr float OFFS = KVT == 2 ? 128.f : 8.f;
+    const int t = blockIdx.x, kvh = blockIdx.y % Hkv, lane = threadIdx.x;
+    const bool is_k = (int)blockIdx.y < Hkv;
+    const uint8_t* pb = is_k ? kpool : vpool;
+    float* sh = is_k ? kshadow : vshadow;
+    const int pg = block_table[t / page];
+    const size_t roff = (size_t)pg * page_bytes + (size_t)(kvh * page + (t % page)) * ROWB;
+    const float scale = *(const float*)(pb + (size_t)pg * page_bytes + (size_t)Hkv * page * ROWB + (size_t)(kvh * page + (t % page)) * 4);
+    const size_t hoff = ((size_t)((t / page) * Hkv + kvh) * page + (t % page)) * D;
+    for (int d = lane; d < D; d += 64) {
+        float code;
+        if (KVT == 2) code = (float)pb[roff + d];
+        else { const uint8_t b = pb[roff + (d >> 1)]; code = (float)((d & 1) ? (b >> 4) : (b & 0xF)); }
+        sh[hoff + d] = __fmul_rn(code - OFFS, scale);
     }
 }
 
@@ -431,14 +484,27 @@ void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t*
                          hipStream_t s) {
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, s, x, w, hi, lo, H, eps);
 }
-void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, bool kv_f32, hipStream_t s) {
+void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, int kv_mode, hipStream_t s) {
     dim3 grid(S, a.Hq + 2 * a.Hkv);
+#define CM_QK(DD) \
+    if (kv_mode == 1) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 1>), grid, dim3(64), 0, s, a); \
+    else if (kv_mode == 2) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 2>), grid, dim3(64), 0, s, a); \
+    else if (kv_mode == 3) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 3>), grid, dim3(64), 0, s, a); \
+    else hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 0>), grid, dim3(64), 0, s, a);
+    if (D == 128) { CM_QK(128) } else { CM_QK(256) }
+#undef CM_QK
+}
+void launch_kvq_dequant_prefix(const void* kpool, const void* vpool, const int32_t* block_table, float* kshadow, float* vshadow,
+                               int tokens, int Hkv, int page, int D, int kv_mode, size_t page_bytes, hipStream_t s) {
+    if (tokens <= 0) return;
+    dim3 grid(tokens, 2 * Hkv);
+    const uint8_t *kp = (const uint8_t*)kpool, *vp = (const uint8_t*)vpool;
     if (D == 128) {
-        if (kv_f32) hipLaunchKernelGGL((qknorm_rope_kv_kernel<128, true>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((qknorm_rope_kv_kernel<128, false>), grid, dim3(64), 0, s, a);
+        if (kv_mode == 2) hipLaunchKernelGGL((kvq_dequant_prefix_kernel<128, 2>), grid, dim3(64), 0, s, kp, vp, block_table, kshadow, vshadow, Hkv, page, page_bytes);
+        else hipLaunchKernelGGL((kvq_dequant_prefix_kernel<128, 3>), grid, dim3(64), 0, s, kp, vp, block_table, kshadow, vshadow, Hkv, page, page_bytes);
     } else {
-        if (kv_f32) hipLaunchKernelGGL((qknorm_rope_kv_kernel<256, true>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((qknorm_rope_kv_kernel<256, false>), grid, dim3(64), 0, s, a);
+        if (kv_mode == 2) hipLaunchKernelGGL((kvq_dequant_prefix_kernel<256, 2>), grid, dim3(64), 0, s, kp, vp, block_table, kshadow, vshadow, Hkv, page, page_bytes);
+        else hipLaunchKernelGGL((kvq_dequant_prefix_kernel<256, 3>), grid, dim3(64), 0, s, kp, vp, block_table, kshadow, vshadow, Hkv, page, page_bytes);
     }
 }
 void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s) {

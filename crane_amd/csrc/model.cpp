@@ -623,6 +623,15 @@ void Model::ensure_prefill_buffers() {
     const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
     pAT_hi = z((size_t)chunk_pad * at_cols); pAT_lo = z((size_t)chunk_pad * at_cols);
     pHH_hi = z((size_t)chunk_pad * I_l); pHH_lo = z((size_t)chunk_pad * I_l);
+    if (kv_mode >= CM_KV_INT8) {
+        const size_t shadow = (size_t)max_pages_per_seq * Hkv_l * page * D;
+        kshadow = dalloc<float>(shadow);
+        vshadow = dalloc<float>(shadow);
+        std::vector<int32_t> ident((size_t)max_pages_per_seq);
+        for (int i = 0; i < max_pages_per_seq; ++i) ident[(size_t)i] = i;
+        d_ident_bt = dalloc<int>((size_t)max_pages_per_seq);
+        CM_HIP(hipMemcpy(d_ident_bt, ident.data(), ident.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     if (quantized) wq_scratch = dalloc<uint16_t>(std::max(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H), (size_t)in_proj_pad * H));
     d_ids = (uint32_t*)dalloc<int>(chunk);
     CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
@@ -701,13 +710,22 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             q.rot_dim = cfg.rot_dim; q.pos3 = pos3_dev ? pos3_dev + off : nullptr; q.pos3_stride = pos3_stride;
             q.sec_h = cfg.mrope_sec[1]; q.sec_w = cfg.mrope_sec[2];
             q.scale = (float)(1.0 / std::sqrt((double)D));
-            launch_qknorm_rope_kv(q, D, S, kv_f32, s);
+            const bool kvq = kv_mode >= CM_KV_INT8;
+            if (kvq) {
+                // KvCache::Quant (qwen3_5/kv_cache.rs:303-325): append() returns dequantize(full cache); the attention of this
+                // chunk therefore reads an f32 shadow of the layer: old tokens dequantised from the pages, new tokens written
+                // next to their codes by the append kernel
+                q.page_bytes = page_bytes; q.kshadow = kshadow; q.vshadow = vshadow;
+                launch_kvq_dequant_prefix(kpool(li), vpool(li), d_bt, kshadow, vshadow, sp, Hkv_l, page, D, kv_mode, page_bytes, s);
+            }
+            launch_qknorm_rope_kv(q, D, S, kv_mode, s);
             AttnPreArgs at{};
-            at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = d_bt; at.kpool = kpool(li); at.vpool = vpool(li);
+            at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = kvq ? d_ident_bt : d_bt;
+            at.kpool = kvq ? (void*)kshadow : kpool(li); at.vpool = kvq ? (void*)vshadow : vpool(li);
             at.out_hi = pAT_hi; at.out_lo = pAT_lo; at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
             at.page = page; at.start_pos = sp; at.causal = 1;
             at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
-            launch_attn_prefill(at, D, kv_f32, s);
+            launch_attn_prefill(at, D, kv_f32 || kvq, s);
             g = GemmArgs{};
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
@@ -915,12 +933,11 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     ensure_pages(s, (int64_t)(start_pos + n));
     activate(s);
     bool use_prefill = false;
-    // quantised KV: token-serial through the decode step (the prefill KV-append kernel does not quantise yet).
     // quantised weights: each matrix is dequantised to a bf16 scratch in front of its MFMA GEMM (CM_QUANT_PREFILL=0:
     // token-serial, i.e. the decode kernels' integer-dot arithmetic for the prompt too)
     const char* qpe = getenv("CM_QUANT_PREFILL");
     const bool qprefill = qpe == nullptr || atoi(qpe) != 0;
-    if (n >= 2 && (!quantized || qprefill) && kv_mode < CM_KV_INT8 && getenv("CM_NO_PREFILL") == nullptr) {
+    if (n >= 2 && (!quantized || qprefill) && getenv("CM_NO_PREFILL") == nullptr) {
         ensure_prefill_buffers();
         use_prefill = prefill_ok;
     }

@@ -244,6 +244,8 @@ struct Model {
     bool gdn_chunked = false;          // GGUF value-head order (VHeadOrder::Chunked)
     bool quant_act_int = true;         // ggml vec_dot semantics: activations -> Q8_0 / Q8_K + integer dots (CM_QUANT_ACT=f32: exact dequant x f32)
     QWeight q_embed, q_lm_head;
+    float *kshadow = nullptr, *vshadow = nullptr;   // int8/int4 KV prefill: dequantised f32 K/V of ONE layer, identity pages
+    int32_t* d_ident_bt = nullptr;                  // [max_pages_per_seq] 0, 1, 2, ...
     uint16_t* wq_scratch = nullptr;    // [max N*K] bf16: one dequantised matrix at a time for the prefill GEMMs
     float* gu_tmp = nullptr;           // [2 I] scratch when gate / up have different ggml types
     uint64_t quant_weight_bytes = 0;   // bytes of every quantised matrix read once per decoded token

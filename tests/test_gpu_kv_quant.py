@@ -62,6 +62,39 @@ def test_quantised_kv_matches_oracle(name, kv):
         m.close()
 
 
+@pytest.mark.parametrize("name", ["tiny-qwen3-untied", "tiny-qwen3.5"])
+@pytest.mark.parametrize("kv", ["int8", "int4"])
+def test_quantised_kv_chunked_prefill_and_serial_agree(monkeypatch, name, kv):
+    """Prompts over a quantised cache: the append kernel quantises K/V and the chunk's attention reads the dequantised
+    f32 shadow (old tokens re-dequantised from the pages); chunked (3 chunks), single-chunk and token-serial prefill must
+    agree with each other and with the oracle."""
+    from crane_amd.backend import Model
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    o = _oracle(name, cfg, w, kv)
+    ids = configs.synthetic_prompt(150, cfg["vocab_size"])
+    ref = o.forward(ids, 0)
+    tol = 2e-3 if kv == "int8" else 1e-3
+    outs = []
+    for chunk in (0, 64):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, kv_dtype=kv, prefill_chunk=chunk)
+        try:
+            outs.append(m.forward_step(ids, 0).reshape(-1).copy())
+            nxt = m.forward_step([int(ref.argmax())], 150).reshape(-1).copy()       # decode on the pages the prefill wrote
+            outs.append(nxt)
+        finally:
+            m.close()
+    monkeypatch.setenv("CM_NO_PREFILL", "1")
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, kv_dtype=kv)
+    try:
+        serial = m.forward_step(ids, 0).reshape(-1).copy()
+    finally:
+        m.close()
+    ref2 = o.forward([int(ref.argmax())], 150)
+    assert rel(outs[0], ref) < tol and rel(outs[2], ref) < tol and rel(serial, ref) < tol, (rel(outs[0], ref), rel(outs[2], ref), rel(serial, ref))
+    assert rel(outs[1], ref2) < tol and rel(outs[3], ref2) < tol
+
+
 def test_quantised_kv_is_close_to_full_precision():
     """int8 KV must stay within ~1e-2 of the f32-KV logits on the same weights (sanity of the scales)."""
     from crane_amd.backend import Model
