@@ -551,6 +551,273 @@ bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, boo
     return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Long-context variant on the matrix cores (bf16 KV).  The split kernel above spends ~35 VALU ops per (token, lane):
+// a 16-lane dot-product reduction per head and an exp replicated over the 16 lanes of a row -- at 32 K tokens it is
+// VALU-bound at 1.8 TB/s.  Here the NREP query heads that share a KV head are the 16 "query columns" of an MFMA tile
+// (the prefill kernel's transposed formulation):
+//   S^T[16 tokens x 16 heads] = K_tile . Q^T     mfma_f32_16x16x32_bf16, A = K rows straight from the pages (16 B per
+//                                                lane), B = q as bf16 hi + lo (two MFMAs: no q rounding loss)
+//   online softmax per head column (statistics replicated over the 4 row groups of a lane's column)
+//   O^T[D x 16 heads] += V^T . P^T               mfma_f32_16x16x16bf16_1k, A = V^T through ds_read_tr16_b64 from the wave's
+//                                                private LDS tile, B = P^T as bf16 hi + lo straight from the S^T registers
+// One wave owns 16 tokens per step (a block covers 64), the next step's K and V rows are prefetched into a second
+// register set; grid (nsplit, Hkv); partials go to the same combine kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int D, int NREP>
+__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
+    constexpr int NKS = D / 32, NNT = D / 16, VLD = D + 16, EPL = D / 64, TB = 64;
+    constexpr int VCH = (16 * D / 8) / 64;                       // 16-byte V chunks per lane per tile
+    __shared__ __attribute__((aligned(16))) uint16_t q_hi[16 * D];
+    __shared__ __attribute__((aligned(16))) uint16_t q_lo[16 * D];
+    __shared__ __attribute__((aligned(16))) uint16_t knew[D];
+    __shared__ __attribute__((aligned(16))) uint16_t vnew[D];
+    __shared__ __attribute__((aligned(16))) float tmp[4][D];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[4][16 * VLD];      // one tile per wave; reused as red_o at the end
+    __shared__ float red_m[4][16];
+    __shared__ float red_l[4][16];
+
+    const int split = blockIdx.x, kvh = blockIdx.y, nsplit = gridDim.x, bq = blockIdx.z;
+    const StepState* st = a.st + bq;
+    const int32_t* block_table = a.block_table + (size_t)bq * a.bt_stride;
+    const float* qkv = a.qkv + (size_t)bq * a.qkv_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, g = lane >> 4;
+    const uint16_t* kpool = (const uint16_t*)a.kpool;
+    const uint16_t* vpool = (const uint16_t*)a.vpool;
+
+    for (int i = tid; i < 16 * D; i += 256) { q_hi[i] = 0; q_lo[i] = 0; }
+    const int pos = st->pos;
+    const int rpos = pos + st->rsv[0];
+    const bool owner = ((pos / TB) % nsplit) == split;
+    const int rot = a.rot_dim, hrot = rot >> 1;
+    __syncthreads();
+
+    // ---- prologue: the group's q heads (norm, rope, 1/sqrt(D), bf16 hi + lo), new k / v (bf16; owner appends) ----
+    for (int item = wave; item < NREP + 2; item += 4) {
+        const float* src;
+        const float* nw = nullptr;
+        if (item < NREP) { src = qkv + a.q_off + (size_t)(kvh * NREP + item) * D; nw = a.qnw; }
+        else if (item == NREP) { src = qkv + a.k_off + (size_t)kvh * D; nw = a.knw; }
+        else { src = qkv + a.v_off + (size_t)kvh * D; }
+        float xv[EPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { xv[j] = src[lane + 64 * j]; ss += xv[j] * xv[j]; }
+        if (item <= NREP) {
+            if (nw != nullptr) {
+                ss = wave_sum(ss);
+                const float rr = 1.0f / sqrtf(ss / (float)D + a.eps);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) xv[j] = xv[j] * rr * nw[lane + 64 * j];
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) tmp[wave][lane + 64 * j] = xv[j];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int d = lane + 64 * j;
+                if (d < rot) {
+                    const int i = d < hrot ? d : d - hrot;
+                    const float c = a.cos[(size_t)rpos * hrot + i], sn = a.sin[(size_t)rpos * hrot + i];
+                    const float lo = tmp[wave][i], hi = tmp[wave][i + hrot];
+                    xv[j] = d < hrot ? lo * c - hi * sn : lo * sn + hi * c;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (item < NREP) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const float x = xv[j] * a.scale;
+                const uint16_t h = f32_to_bf16(x);
+                q_hi[item * D + lane + 64 * j] = h;
+                q_lo[item * D + lane + 64 * j] = f32_to_bf16(x - bf16_to_f32(h));
+            }
+        } else {
+            uint16_t* dst = (item == NREP) ? knew : vnew;
+            uint16_t* pool = (uint16_t*)((item == NREP) ? a.kpool : a.vpool);
+            const size_t eoff = owner ? ((size_t)(block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int d = lane + 64 * j;
+                const uint16_t b = f32_to_bf16(xv[j]);
+                dst[d] = b;
+                if (owner) pool[eoff + d] = b;
+            }
+        }
+    }
+    __syncthreads();
+
+    // Q^T fragments (B operand): lane holds q[head = sub][dims g*8 + 32*ks .. +8]
+    bf16x8 qh[NKS], ql[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        qh[ks] = *(const bf16x8*)&q_hi[sub * D + ks * 32 + g * 8];
+        ql[ks] = *(const bf16x8*)&q_lo[sub * D + ks * 32 + g * 8];
+    }
+    f32x4 o[NNT];
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // this wave's tiles: CACHED tokens [TB * (split + nsplit * j) + 16 * wave, +16), j = 0, 1, ... (t < pos: written by
+    // earlier steps, visible); the token appended by this very step is one extra pseudo-tile of the owner block
+    const int psh = __builtin_ctz(a.page);                      // page size is a power of two (launcher checks)
+    auto row_off = [&](int t) -> size_t {
+        const int page = block_table[t >> psh];
+        return ((size_t)(page * a.Hkv + kvh) * a.page + (t & (a.page - 1))) * D;
+    };
+    auto load_tile = [&](bf16x8 (&kf)[NKS], u32x4 (&vf)[VCH], int tb) {
+        const size_t ko = row_off(min(tb + sub, pos - 1)) + g * 8;       // clamped rows are masked later
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kpool + ko + ks * 32);
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
+            vf[i] = ld16(vpool + row_off(min(tb + tok, pos - 1)) + d8);
+        }
+    };
+    uint16_t* Vw = Vs[wave];
+    auto step = [&](const bf16x8 (&kf)[NKS], const u32x4 (&vf)[VCH], int tb, int limit) {
+        // stage this tile's V rows in the wave's LDS region
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
+            *(u32x4*)&Vw[tok * VLD + d8] = vf[i];
+        }
+        f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qh[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], ql[ks], sc, 0, 0, 0);
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (tb + g * 4 + r >= limit) sc[r] = -INFINITY;
+            mt = fmaxf(mt, sc[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);                    // finite: token tb < limit is in this tile
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+        bf16x4 ph, pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = expf(sc[r] - m_new);
+            psum += p;
+            const uint16_t hh = f32_to_bf16(p);
+            ph[r] = (short)hh;
+            pl[r] = (short)f32_to_bf16(p - bf16_to_f32(hh));
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) { o[nt][0] *= alpha; o[nt][1] *= alpha; o[nt][2] *= alpha; o[nt][3] *= alpha; }
+        __builtin_amdgcn_wave_barrier();                         // LDS tile written by this wave only
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+            const uint16_t* vp = &Vw[(g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
+            const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, ph, o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, pl, o[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();                         // tile consumed before the next step overwrites it
+    };
+    {
+        bf16x8 kA[NKS], kB[NKS];
+        u32x4 vA[VCH], vB[VCH];
+        const int stride = TB * nsplit;
+        int tb = TB * split + 16 * wave;
+        if (tb < pos) load_tile(kA, vA, tb);
+        while (tb < pos) {
+            if (tb + stride < pos) load_tile(kB, vB, tb + stride);
+            step(kA, vA, tb, pos);
+            tb += stride;
+            if (tb >= pos) break;
+            if (tb + stride < pos) load_tile(kA, vA, tb + stride);
+            step(kB, vB, tb, pos);
+            tb += stride;
+        }
+        if (owner && wave == 0) {                                // the token appended by this step: row 0 of a pseudo-tile
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const u32x4 kn = *(const u32x4*)&knew[ks * 32 + g * 8];
+                const u32x4 kz = sub == 0 ? kn : (u32x4){0, 0, 0, 0};
+                kA[ks] = __builtin_bit_cast(bf16x8, kz);
+            }
+#pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
+                vA[i] = tok == 0 ? *(const u32x4*)&vnew[d8] : (u32x4){0, 0, 0, 0};
+            }
+            step(kA, vA, pos, pos + 1);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+
+    // ---- merge the 4 waves: O^T rows = dims nt*16 + g*4 + r, column = head `sub` ----
+    __syncthreads();
+    float* red_o = (float*)&Vs[0][0];                            // [4][NREP][D] f32 (fits: NREP * D * 4 * 4 <= sizeof(Vs))
+    if (sub < NREP) {
+        if (g == 0) { red_m[wave][sub] = m_run; red_l[wave][sub] = l_run; }
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt)
+            *(f32x4*)&red_o[((size_t)wave * NREP + sub) * D + nt * 16 + g * 4] = o[nt];
+    }
+    __syncthreads();
+    for (int it = tid; it < NREP * D; it += 256) {
+        const int h = it / D, d = it % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, red_m[w][h]);
+        float O = 0.f, Ls = 0.f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float wt = red_m[w][h] > -INFINITY ? expf(red_m[w][h] - M) : 0.f;
+                O += wt * red_o[((size_t)w * NREP + h) * D + d];
+                Ls += wt * red_l[w][h];
+            }
+        }
+        const size_t ph = ((size_t)bq * a.Hkv * NREP + (size_t)(kvh * NREP + h)) * nsplit + split;
+        a.part_o[ph * D + d] = O;
+        if (d == 0) { a.part_ml[ph * 2] = M; a.part_ml[ph * 2 + 1] = Ls; }
+    }
+}
+
+template <int D>
+static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int n_seq, hipStream_t s) {
+    dim3 grid(nsplit, a.Hkv, n_seq), block(256);
+#define CM_MF(N) case N: hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N>), grid, block, 0, s, a); return true;
+    switch (nrep) {
+        CM_MF(1) CM_MF(2) CM_MF(3) CM_MF(4) CM_MF(6) CM_MF(8)
+        default: return false;
+    }
+#undef CM_MF
+}
+
+// bf16 KV only; same partial format and combine kernel as launch_attn_decode
+bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, float* out, int out_stride, int n_seq, hipStream_t s) {
+    if (a.page <= 0 || (a.page & (a.page - 1)) != 0) return false;
+    if (D == 128) {
+        if (!launch_mfma<128>(a, nrep, nsplit, n_seq, s)) return false;
+        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+                           a.gate, out, nsplit, a.qkv_stride, out_stride);
+    } else if (D == 256) {
+        if (!launch_mfma<256>(a, nrep, nsplit, n_seq, s)) return false;
+        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+                           a.gate, out, nsplit, a.qkv_stride, out_stride);
+    } else {
+        return false;
+    }
+    return true;
+}
+
 template <int D>
 static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode, int n_seq, hipStream_t s) {
     dim3 grid(nsplit, a.Hkv, n_seq), block(256);

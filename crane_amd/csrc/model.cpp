@@ -42,7 +42,7 @@ void Model::dfree(void* p) {
 
 Model::~Model() {
     if (stream) (void)hipStreamSynchronize(stream);
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 3; ++v) {
         if (graph_exec[v]) (void)hipGraphExecDestroy(graph_exec[v]);
         if (graph[v]) (void)hipGraphDestroy(graph[v]);
     }
@@ -213,6 +213,8 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
+    if (const char* e = getenv("CM_ATTN_MFMA_MIN")) attn_mfma_min = atoll(e);
+    nsplit_mfma = std::max(nsplit, std::min(64, 2 * num_cu / std::max(1, Hkv_l)));
     use_graph = opts.use_graph >= 0;
     if (opts.kv_dtype > CM_KV_INT4) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
     kv_mode = (int)opts.kv_dtype;
@@ -243,8 +245,8 @@ void Model::alloc_runtime() {
     }
     hbuf = dalloc<float>(I_l);
     logits = dalloc<float>((size_t)V_l * tp);
-    part_o = dalloc<float>((size_t)Hq_l * nsplit * D);
-    part_ml = dalloc<float>((size_t)Hq_l * nsplit * 2);
+    part_o = dalloc<float>((size_t)Hq_l * std::max(nsplit, nsplit_mfma) * D);
+    part_ml = dalloc<float>((size_t)Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     lm_grid = (quantized && q_lm_head.fmt != QFMT_NONE) ? gemvq_grid(v_eff, num_cu) : gemv_grid(v_eff, H, num_cu);
     pmax = dalloc<float>((size_t)lm_grid * tp);
@@ -491,6 +493,8 @@ void Model::enqueue_decode_step(bool advance) {
         const bool heads = attn_variant == 1 && kv_mode < CM_KV_INT8;      // short context: per-head blocks, merge fused into o_proj's prologue
         if (heads) {
             if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
+        } else if (attn_variant == 2) {      // long context, bf16 KV: matrix-core flash-decode
+            if (!launch_attn_decode_mfma(a, D, nrep, nsplit_mfma, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
@@ -555,7 +559,9 @@ void Model::enqueue_quant_layer(int li) {
         a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr; a.rot_dim = cfg.rot_dim;
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps;
         a.scale = (float)(1.0 / std::sqrt((double)D));
-        if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        if (attn_variant == 2) {
+            if (!launch_attn_decode_mfma(a, D, nrep, nsplit_mfma, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
     }
     if (!w.split_gate_up) {
@@ -770,6 +776,7 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     ++ring_count;    // host mirror of st->pad (ring write index)
     // attention variant by context length (host-known): one captured graph per variant
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
+    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode == CM_KV_BF16 && cfg.D == 128 && (page & (page - 1)) == 0) attn_variant = 2;
     const int v = attn_variant;
     logits_gathered = false;
     // Tensor parallelism: the RCCL all-reduces / all-gathers are captured INTO the decode-step graph (one launch per
@@ -817,8 +824,8 @@ void Model::ensure_batch_buffers() {
     attnb = dalloc<float>((size_t)MAXB * at_cols);
     hbb = dalloc<float>((size_t)MAXB * I_l);
     logitsb = dalloc<float>((size_t)MAXB * cfg.V);
-    part_ob = dalloc<float>((size_t)MAXB * Hq_l * nsplit * D);
-    part_mlb = dalloc<float>((size_t)MAXB * Hq_l * nsplit * 2);
+    part_ob = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * D);
+    part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     const int g = gemvb_grid(cfg.V, H, num_cu);
     pmaxb = dalloc<float>((size_t)MAXB * g);
     pidxb = dalloc<int>((size_t)MAXB * g);
@@ -893,7 +900,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.dshift = D == 128 ? 7 : 8;
                     launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else {
-                if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode == CM_KV_BF16 && D == 128 && (page & (page - 1)) == 0;
+                if (mf) {
+                    if (!launch_attn_decode_mfma(a, D, nrep, nsplit_mfma, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
                 }
             }

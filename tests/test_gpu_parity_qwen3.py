@@ -345,3 +345,41 @@ def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
             t1, t2 = int(r1.argmax()), int(r2.argmax())
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("mfma_min", [1, 200])
+def test_decode_attention_mfma_variant(monkeypatch, mfma_min):
+    """Long-context decode attention on the matrix cores (bf16 KV, head_dim 128): S^T = K.Q^T over the GQA group and
+    O^T += V^T.P^T through ds_read_tr, same partial format / combine kernel.  Forced on from the first token (1) and
+    switched on mid-generation (200): must match the oracle with the same KV rounding, single sequence and batched."""
+    monkeypatch.setenv("CM_ATTN_MFMA_MIN", str(mfma_min))
+    for name in ("tiny-qwen3-untied", "tiny-qwen3"):
+        cfg = configs.get_config(name)
+        w = synth.synth_weights_f32(cfg, seed=0)
+        o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+        o2 = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+        m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3)
+        try:
+            V = cfg["vocab_size"]
+            ids = configs.synthetic_prompt(190, V)
+            ref = o.forward(ids, 0)
+            assert rel(m.forward_step(ids, 0).reshape(-1), ref) < REL_SAME
+            tok = int(ref.argmax())
+            for step in range(24):                                   # crosses 200 tokens and several 16/64-token tiles
+                ref = o.forward([tok], 190 + step)
+                got = m.forward_step([tok], 190 + step).reshape(-1)
+                assert rel(got, ref) < REL_SAME, (name, step, rel(got, ref))
+                assert int(got.argmax()) == int(ref.argmax())
+                tok = int(ref.argmax())
+            s1, s2 = m.seq_alloc(), m.seq_alloc()
+            m.seq_forward(s1, ids, 0, want_logits=False)
+            m.seq_forward(s2, ids[:77], 0, want_logits=False)
+            o.forward(ids, 0); o2.forward(ids[:77], 0)
+            t1, t2 = 5, 9
+            for step in range(12):
+                lg, _ = m.step_batch_decode([s1, s2], [t1, t2])
+                r1, r2 = o.forward([t1], 190 + step), o2.forward([t2], 77 + step)
+                assert rel(lg[0].reshape(-1), r1) < REL_SAME and rel(lg[1].reshape(-1), r2) < REL_SAME, (name, step)
+                t1, t2 = int(r1.argmax()), int(r2.argmax())
+        finally:
+            m.close()
