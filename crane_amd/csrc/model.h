@@ -259,7 +259,8 @@ struct Model {
     bool tp_graph = true, rccl_warm = false;   // capture RCCL collectives into the decode graph (CM_TP_GRAPH=0: eager)
     int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj
     int nsplit_mfma = 64;          // token splits of variant 2 (MFMA flash-decode, bf16 KV, head_dim 128)
-    int64_t attn_mfma_min = 4096;  // contexts of at least this many tokens use variant 2 (CM_ATTN_MFMA_MIN; 0 = never)
+    int64_t attn_mfma_min = 1536;  // contexts of at least this many tokens use variant 2 (CM_ATTN_MFMA_MIN; 0 = never);
+                                   // measured crossover on Qwen3-8B: 3.16 vs 3.12 ms at 1 K, 3.16 vs 3.23 at 2 K
     int attn_ns = 2;               // token splits per head of variant 1
     int64_t attn_heads_max = 0;    // contexts up to this many tokens use variant 1 (CM_ATTN_HEADS_MAX; 0 = never: measured
                                    // slower on MI355X at every context tried)
