@@ -42,7 +42,7 @@ void Model::dfree(void* p) {
 
 Model::~Model() {
     if (stream) (void)hipStreamSynchronize(stream);
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 4; ++v) {
         if (graph_exec[v]) (void)hipGraphExecDestroy(graph_exec[v]);
         if (graph[v]) (void)hipGraphDestroy(graph[v]);
     }
@@ -214,7 +214,9 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN")) attn_mfma_min = atoll(e);
+    if (const char* e = getenv("CM_ATTN_MFMA_WIDE_MIN")) attn_mfma_wide_min = atoll(e);
     nsplit_mfma = std::max(nsplit, std::min(64, 2 * num_cu / std::max(1, Hkv_l)));
+    if (const char* e = getenv("CM_ATTN_MFMA_NSPLIT")) nsplit_mfma = std::max(1, std::min(64, atoi(e)));
     use_graph = opts.use_graph >= 0;
     if (opts.kv_dtype > CM_KV_INT4) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
     kv_mode = (int)opts.kv_dtype;
@@ -493,8 +495,8 @@ void Model::enqueue_decode_step(bool advance) {
         const bool heads = attn_variant == 1 && kv_mode < CM_KV_INT8;      // short context: per-head blocks, merge fused into o_proj's prologue
         if (heads) {
             if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
-        } else if (attn_variant == 2) {      // long context, bf16 KV: matrix-core flash-decode
-            if (!launch_attn_decode_mfma(a, D, nrep, nsplit_mfma, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        } else if (attn_variant >= 2) {      // bf16 KV: matrix-core flash-decode (32 token splits, 64 for long contexts)
+            if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
@@ -559,8 +561,8 @@ void Model::enqueue_quant_layer(int li) {
         a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr; a.rot_dim = cfg.rot_dim;
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps;
         a.scale = (float)(1.0 / std::sqrt((double)D));
-        if (attn_variant == 2) {
-            if (!launch_attn_decode_mfma(a, D, nrep, nsplit_mfma, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        if (attn_variant >= 2) {
+            if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
     }
@@ -776,7 +778,8 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     ++ring_count;    // host mirror of st->pad (ring write index)
     // attention variant by context length (host-known): one captured graph per variant
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
-    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode == CM_KV_BF16 && cfg.D == 128 && (page & (page - 1)) == 0) attn_variant = 2;
+    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode == CM_KV_BF16 && cfg.D == 128 && (page & (page - 1)) == 0)
+        attn_variant = ctx_len >= attn_mfma_wide_min ? 3 : 2;
     const int v = attn_variant;
     logits_gathered = false;
     // Tensor parallelism: the RCCL all-reduces / all-gathers are captured INTO the decode-step graph (one launch per
@@ -902,7 +905,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 } else {
                 const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode == CM_KV_BF16 && D == 128 && (page & (page - 1)) == 0;
                 if (mf) {
-                    if (!launch_attn_decode_mfma(a, D, nrep, nsplit_mfma, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                    if (!launch_attn_decode_mfma(a, D, nrep, longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
                 }

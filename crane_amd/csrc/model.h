@@ -253,14 +253,16 @@ struct Model {
     void isq_q8_0();                   // in-situ quantisation of the loaded bf16 linears (ops/linear.rs:83-116)
     void dfree(void* p);
 
-    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};          // one captured decode step per attention variant
-    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
-    bool graph_ok[3] = {false, false, false};
+    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
+    hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool graph_ok[4] = {false, false, false, false};
     bool tp_graph = true, rccl_warm = false;   // capture RCCL collectives into the decode graph (CM_TP_GRAPH=0: eager)
     int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj
-    int nsplit_mfma = 64;          // token splits of variant 2 (MFMA flash-decode, bf16 KV, head_dim 128)
-    int64_t attn_mfma_min = 1536;  // contexts of at least this many tokens use variant 2 (CM_ATTN_MFMA_MIN; 0 = never);
-                                   // measured crossover on Qwen3-8B: 3.16 vs 3.12 ms at 1 K, 3.16 vs 3.23 at 2 K
+    int nsplit_mfma = 64;          // token splits of variant 3 (MFMA flash-decode, bf16 KV, head_dim 128, long contexts);
+                                   // variant 2 = the same kernel with `nsplit` (32) splits for mid-size contexts
+    int64_t attn_mfma_wide_min = 8192;   // measured: 32 splits win up to 4 K (3.26 vs 3.30 ms), 64 at 32 K (3.96 vs 4.08)
+    int64_t attn_mfma_min = 768;   // contexts of at least this many tokens use the MFMA kernel (CM_ATTN_MFMA_MIN; 0 = never);
+                                   // Qwen3-8B ms/token split vs MFMA(32 splits): 256: 3.056 / 3.068, 1 K: 3.11 / 3.085, 4 K: 3.44 / 3.26
     int attn_ns = 2;               // token splits per head of variant 1
     int64_t attn_heads_max = 0;    // contexts up to this many tokens use variant 1 (CM_ATTN_HEADS_MAX; 0 = never: measured
                                    // slower on MI355X at every context tried)

@@ -347,12 +347,13 @@ def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
         m.close()
 
 
-@pytest.mark.parametrize("mfma_min", [1, 200])
-def test_decode_attention_mfma_variant(monkeypatch, mfma_min):
+@pytest.mark.parametrize("mfma_min,wide_min", [(1, 8192), (200, 206), (1, 1)])
+def test_decode_attention_mfma_variant(monkeypatch, mfma_min, wide_min):
     """Long-context decode attention on the matrix cores (bf16 KV, head_dim 128): S^T = K.Q^T over the GQA group and
     O^T += V^T.P^T through ds_read_tr, same partial format / combine kernel.  Forced on from the first token (1) and
     switched on mid-generation (200): must match the oracle with the same KV rounding, single sequence and batched."""
     monkeypatch.setenv("CM_ATTN_MFMA_MIN", str(mfma_min))
+    monkeypatch.setenv("CM_ATTN_MFMA_WIDE_MIN", str(wide_min))      # 32 -> 64 token splits (a third captured graph)
     for name in ("tiny-qwen3-untied", "tiny-qwen3"):
         cfg = configs.get_config(name)
         w = synth.synth_weights_f32(cfg, seed=0)
