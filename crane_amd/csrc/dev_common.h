@@ -17,14 +17,18 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xFFFF0000u); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round to nearest even): one instruction per PAIR instead of five
+// integer ops per value
+typedef __attribute__((ext_vector_type(2))) float cm_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 cm_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const cm_bf16x2 v = __builtin_convertvector((cm_f32x2){lo, hi}, cm_bf16x2);
+    uint32_t r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
 // ---- streaming (non-temporal) 16-byte load: weights are read once ----------
 __device__ __forceinline__ u32x4 ld_nt16(const void* p) {

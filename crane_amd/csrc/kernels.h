@@ -154,6 +154,11 @@ struct GemvBArgs {
     int ns = 0, dshift = 0, gate_stride = 0;
 };
 int gemvb_grid(int N, int K, int num_cu);
+// matrix-core variant (kernels_decode_mfma.hip): <= 8 sequences
+bool gemvm_ok(int epi, int n_seq, int K);
+int gemvm_nkt(int K);
+int gemvm_grid(int N, int K, int num_cu);
+void launch_gemvm(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
 void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
 
 // ---- decode ----

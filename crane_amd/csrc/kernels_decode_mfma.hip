@@ -1,0 +1,234 @@
+// Batched decode on the matrix cores: y[m, n] = epilogue( W[n, :] . prologue(x[m, :]) ) for up to 8 sequences with the
+// weight stream read ONCE.  The VALU formulation (kernels_decode_batch.hip) spends 8 FMAs per weight at batch 8 and is
+// VALU/LDS-bound at ~2x the single-sequence time; here the sequences are the M rows of an MFMA tile, so the arithmetic
+// is free and the kernel is a pure weight streamer again:
+//   16 independent 4x4x4 products per instruction (mfma_f32_4x4x4bf16_1k): lane l = 4 * b + i feeds block b with
+//   4 k-values of weight row i (A) and of sequence j = l % 4 (B); block b is a DIFFERENT K chunk, so one 16-byte load
+//   per lane reads 4 weight rows x 256 contiguous bytes per wave instruction (the 16x16x32 tile needs 16 rows x 64 B
+//   per instruction, 8 KiB apart: measured 2.5x slower, it serialises on HBM channels) and the 16 partial sums per
+//   (row, sequence) are folded with four shuffles at the end of the row group
+//   A = 4 weight rows straight from HBM (non-temporal), 8 x 16 B per lane in flight, 8 waves per block
+//   B = the activations as bf16 hi + lo (so x keeps ~2^-17 relative precision) staged once per block in LDS
+//       ([8 sequences][K slice]; the 16 lanes of one sequence read 256 contiguous bytes: conflict-free)
+// A block owns ONE 4096-wide K slice of x and grid-strides over 16-row groups; K > 4096 (down_proj) splits K across
+// blocks and accumulates with f32 atomics onto the residual / a zeroed buffer (store).  Same fused RMSNorm prologue
+// and store / residual / SiLU*mul / arg-max epilogues as the other decode GEMVs.
+// Replaces step_batch_decode's batched matmuls (reference qwen3/modeling.rs:1202-1234) for 2..8 sequences.
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace cm {
+
+constexpr int GM_KT = 4096;          // K slice per block (elements)
+constexpr int GM_MB = 8;             // sequence rows kept in LDS
+constexpr int GM_LD = GM_KT;         // LDS row stride (elements)
+constexpr int GM_W = 16;             // waves per block (1 block per CU: 16 x 8 KiB of weight loads in flight)
+constexpr int GM_U = 8;              // k-steps (16-byte weight loads) in flight per lane
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(1024, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* xh = lds;                                  // [GM_MB][GM_LD] (rows >= n_seq are zero)
+    uint16_t* xl = lds + GM_MB * GM_LD;
+    float* fsc = (float*)(xl + GM_MB * GM_LD);     // [GM_MB] 1/rms per sequence, then arg-max scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, N = a.N;
+    const int slice = blockIdx.x % nkt, bgrp = blockIdx.x / nkt, nbg = gridDim.x / nkt;
+    const int k0 = slice * GM_KT;
+    const int kt = min(GM_KT, K - k0);                   // multiple of 32
+
+    // ---- stage this block's K slice of x as bf16 hi + lo; RMSNorm statistics over the WHOLE row ----
+    float ss[GM_MB];
+#pragma unroll
+    for (int m = 0; m < GM_MB; ++m) ss[m] = 0.f;
+    for (int e = tid; e < GM_MB * (GM_KT / 4); e += 64 * GM_W) {
+        const int m = e / (GM_KT / 4), k = (e % (GM_KT / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < a.n_seq && k < kt) {
+            v = *(const f32x4*)(a.x + (size_t)m * a.ldx + k0 + k);
+            if (PRO == PRO_RMSNORM) {
+                if (nkt == 1) {          // the slice IS the row: statistics from the same pass
+                    const float s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+                    for (int mm = 0; mm < GM_MB; ++mm) if (mm == m) ss[mm] += s2;
+                }
+                const f32x4 w = *(const f32x4*)(a.nw + k0 + k);
+                v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
+            }
+        }
+        const uint32_t h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
+        const uint32_t l01 = pack_bf16x2(v[0] - bf16_lo(h01), v[1] - bf16_hi(h01));
+        const uint32_t l23 = pack_bf16x2(v[2] - bf16_lo(h23), v[3] - bf16_hi(h23));
+        *(u32x2*)&xh[m * GM_LD + k] = (u32x2){h01, h23};
+        *(u32x2*)&xl[m * GM_LD + k] = (u32x2){l01, l23};
+    }
+    if (PRO == PRO_RMSNORM) {
+        if (nkt > 1)
+        for (int e = tid; e < a.n_seq * (K / 4); e += 64 * GM_W) {
+            const int m = e / (K / 4), k = (e % (K / 4)) * 4;
+            const f32x4 v = *(const f32x4*)(a.x + (size_t)m * a.ldx + k);
+            const float s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+            for (int mm = 0; mm < GM_MB; ++mm) if (mm == m) ss[mm] += s2;
+        }
+        float* red = fsc + GM_MB;                        // [GM_W][GM_MB]
+#pragma unroll
+        for (int m = 0; m < GM_MB; ++m) {
+            const float s2 = wave_sum(ss[m]);
+            if (lane == 0) red[wave * GM_MB + m] = s2;
+        }
+        __syncthreads();
+        if (tid < GM_MB) {
+            float tot = 0.f;
+            for (int w = 0; w < GM_W; ++w) tot += red[w * GM_MB + tid];
+            fsc[tid] = 1.0f / sqrtf(tot / (float)K + a.eps);
+        }
+    } else if (tid < GM_MB) {
+        fsc[tid] = 1.0f;
+    }
+    __syncthreads();
+
+    // lane = 4 * blk + i: weight row i of the 4-row group (A) / sequence j = i (+4 for the second half) (B); block blk
+    // owns the 8 k-values [128 * ks + 8 * blk, +8) of every 128-wide k-step
+    const int i4 = lane & 3, blk = lane >> 2;
+    const uint16_t* xh0 = xh + i4 * GM_LD + blk * 8;         // sequences 0..3
+    const uint16_t* xh1 = xh + (4 + i4) * GM_LD + blk * 8;   // sequences 4..7
+    const uint16_t* xl0 = xl + i4 * GM_LD + blk * 8;
+    const uint16_t* xl1 = xl + (4 + i4) * GM_LD + blk * 8;
+    const float sc0 = fsc[i4], sc1 = fsc[4 + i4];
+    float best0 = -INFINITY, best1 = -INFINITY; int besti0 = 0x7FFFFFFF, besti1 = 0x7FFFFFFF;
+    const bool two = a.n_seq > 4;
+
+    const int G = (N + 3) / 4;
+    const int nks = (kt + 127) / 128;                        // 128-wide k-steps in this slice
+    for (int rg = bgrp * GM_W + wave; rg < G; rg += nbg * GM_W) {
+        const int row = rg * 4 + i4;                         // weight row whose bytes this lane loads
+        const uint16_t* wp = a.W + (size_t)(row < N ? row : N - 1) * a.ldw + k0 + blk * 8;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nks; ks += GM_U) {
+            u32x4 wq[GM_U];
+#pragma unroll
+            for (int u = 0; u < GM_U; ++u)
+                wq[u] = ((ks + u) * 128 + blk * 8 < kt) ? ld_nt16(wp + (ks + u) * 128) : (u32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < GM_U; ++u) {
+                if ((ks + u) * 128 + blk * 8 < kt) {
+                    const bf16x4 w_a = __builtin_bit_cast(bf16x4, (u32x2){wq[u][0], wq[u][1]});     // k 0..3 of the chunk
+                    const bf16x4 w_b = __builtin_bit_cast(bf16x4, (u32x2){wq[u][2], wq[u][3]});     // k 4..7
+                    const int ko = (ks + u) * 128;
+                    const u32x4 h0 = *(const u32x4*)(xh0 + ko), l0 = *(const u32x4*)(xl0 + ko);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h0[0], h0[1]}), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h0[2], h0[3]}), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l0[0], l0[1]}), acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l0[2], l0[3]}), acc0, 0, 0, 0);
+                    if (two) {
+                        const u32x4 h1 = *(const u32x4*)(xh1 + ko), l1 = *(const u32x4*)(xl1 + ko);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h1[0], h1[1]}), acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h1[2], h1[3]}), acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l1[0], l1[1]}), acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l1[2], l1[3]}), acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // D layout: lane 4 * blk + j holds D[i = 0..3][j] of block blk; fold the 16 blocks (K chunks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {
+                acc0[r] += __shfl_xor(acc0[r], o);
+                acc1[r] += __shfl_xor(acc1[r], o);
+            }
+        }
+        // lanes 0..3 (blk 0): sequence j = i4 (acc0) and 4 + i4 (acc1), weight rows rg * 4 + r
+        if (blk == 0) {
+            const int r0 = rg * 4;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int m = half * 4 + i4;
+                if (m >= a.n_seq) continue;
+                const f32x4 acc = half ? acc1 : acc0;
+                const float scl = half ? sc1 : sc0;
+                if (EPI == EPI_SILUMUL) {                    // rows 2q = gate_q, 2q + 1 = up_q
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (r0 + 2 * q + 1 < N) {
+                            const float gte = acc[2 * q] * scl, up = acc[2 * q + 1] * scl;
+                            a.y[(size_t)m * a.ldy + (r0 >> 1) + q] = (gte / (1.0f + expf(-gte))) * up;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r0 + r >= N) continue;
+                        const float v = acc[r] * scl;
+                        const size_t o = (size_t)m * a.ldy + r0 + r;
+                        if (nkt > 1) atomicAdd(&a.y[o], v);  // split K: partial sums onto the residual / the zeroed output
+                        else if (EPI == EPI_RESADD) a.y[o] = a.res[o] + v;
+                        else a.y[o] = v;
+                        if (EPI == EPI_ARGMAX) {
+                            const int ix = r0 + r + a.idx_base;
+                            float& bb = half ? best1 : best0; int& bi = half ? besti1 : besti0;
+                            if (v > bb || (v == bb && ix < bi)) { bb = v; bi = ix; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        __syncthreads();
+        float* rb = fsc + GM_MB; int* ri = (int*)(rb + GM_W * GM_MB);
+        if (blk == 0) {
+            rb[wave * GM_MB + i4] = best0; ri[wave * GM_MB + i4] = besti0;
+            rb[wave * GM_MB + 4 + i4] = best1; ri[wave * GM_MB + 4 + i4] = besti1;
+        }
+        __syncthreads();
+        if (tid < GM_MB && tid < a.n_seq) {
+            float b = rb[tid]; int bi = ri[tid];
+            for (int w = 1; w < GM_W; ++w)
+                if (rb[w * GM_MB + tid] > b || (rb[w * GM_MB + tid] == b && ri[w * GM_MB + tid] < bi)) { b = rb[w * GM_MB + tid]; bi = ri[w * GM_MB + tid]; }
+            a.pmax[(size_t)tid * gridDim.x + blockIdx.x] = b;
+            a.pidx[(size_t)tid * gridDim.x + blockIdx.x] = bi;
+        }
+    }
+}
+
+// usable: 5..8 sequences (measured on Qwen3-8B, ms/step VALU gemvb vs this kernel: 2 seq 4.21 / 4.74, 4 seq 5.25 / 5.15,
+// 8 seq 7.85 / 6.21), K % 8 == 0, and no K split for the epilogues that need complete sums
+bool gemvm_ok(int epi, int n_seq, int K) {
+    if (n_seq <= 4 || n_seq > GM_MB || K % 8 != 0) return false;
+    const int nkt = (K + GM_KT - 1) / GM_KT;
+    return nkt == 1 || epi == EPI_STORE || epi == EPI_RESADD;
+}
+int gemvm_nkt(int K) { return (K + GM_KT - 1) / GM_KT; }
+int gemvm_grid(int N, int K, int num_cu) {
+    const int nkt = gemvm_nkt(K), G = (N + 3) / 4;
+    const int per = std::max(1, std::min((G + GM_W - 1) / GM_W, std::max(1, num_cu / nkt)));
+    return per * nkt;
+}
+
+template <int PRO, int EPI>
+static void launch_gemvm_t(const GemvBArgs& a, int grid, hipStream_t s) {
+    const size_t ldsb = (size_t)2 * GM_MB * GM_LD * 2 + (GM_MB + 2 * GM_W * GM_MB) * 4 + 64;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemvm_kernel<PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((gemvm_kernel<PRO, EPI>), dim3(grid), dim3(64 * GM_W), ldsb, s, a, gemvm_nkt(a.K));
+}
+
+// nkt > 1 with EPI_STORE: the caller zeroes y first
+void launch_gemvm(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s) {
+    if (pro == PRO_PLAIN) {
+        if (epi == EPI_STORE) launch_gemvm_t<PRO_PLAIN, EPI_STORE>(a, grid, s);
+        else if (epi == EPI_RESADD) launch_gemvm_t<PRO_PLAIN, EPI_RESADD>(a, grid, s);
+        else if (epi == EPI_SILUMUL) launch_gemvm_t<PRO_PLAIN, EPI_SILUMUL>(a, grid, s);
+        else launch_gemvm_t<PRO_PLAIN, EPI_ARGMAX>(a, grid, s);
+    } else {
+        if (epi == EPI_STORE) launch_gemvm_t<PRO_RMSNORM, EPI_STORE>(a, grid, s);
+        else if (epi == EPI_RESADD) launch_gemvm_t<PRO_RMSNORM, EPI_RESADD>(a, grid, s);
+        else if (epi == EPI_SILUMUL) launch_gemvm_t<PRO_RMSNORM, EPI_SILUMUL>(a, grid, s);
+        else launch_gemvm_t<PRO_RMSNORM, EPI_ARGMAX>(a, grid, s);
+    }
+}
+
+}  // namespace cm

@@ -829,7 +829,7 @@ void Model::ensure_batch_buffers() {
     logitsb = dalloc<float>((size_t)MAXB * cfg.V);
     part_ob = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
-    const int g = gemvb_grid(cfg.V, H, num_cu);
+    const int g = std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu));
     pmaxb = dalloc<float>((size_t)MAXB * g);
     pidxb = dalloc<int>((size_t)MAXB * g);
     CM_HIP(hipHostMalloc((void**)&h_stb, MAXB * sizeof(StepState)));
@@ -868,10 +868,16 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         CM_HIP(hipMemcpyAsync(stb, h_stb, (size_t)nb * sizeof(StepState), hipMemcpyHostToDevice, s));
         CM_HIP(hipMemcpyAsync(d_btb, h_btb, (size_t)nb * max_pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
         launch_embed_row(embed, stb, xb, H, cfg.V, nb, s);
+        static const bool use_mfma_gemv = getenv("CM_GEMVM") == nullptr || atoi(getenv("CM_GEMVM")) != 0;
         auto gb = [&](int pro, int epi, const uint16_t* W, const float* xin, int ldx, const float* nw, float* y, int ldy, int N, int K) {
             GemvBArgs g{};
             g.W = W; g.x = xin; g.nw = nw; g.y = y; g.res = y; g.N = N; g.K = K; g.ldw = K; g.ldx = ldx; g.ldy = ldy; g.n_seq = nb;
             g.eps = cfg.eps;
+            if (use_mfma_gemv && gemvm_ok(epi, nb, K)) {       // sequences as MFMA rows: the weight stream is the only cost
+                if (gemvm_nkt(K) > 1 && epi == EPI_STORE) CM_HIP(hipMemsetAsync(y, 0, (size_t)nb * ldy * sizeof(float), s));
+                launch_gemvm(pro, epi, g, gemvm_grid(N, K, num_cu), s);
+                return;
+            }
             launch_gemvb(pro, epi, g, gemvb_grid(N, K, num_cu), s);
         };
         for (int li = 0; li < cfg.L; ++li) {
@@ -916,8 +922,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         GemvBArgs g{};
         g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb; g.N = cfg.V; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
         g.eps = cfg.eps; g.pmax = pmaxb; g.pidx = pidxb;
-        const int lmg = gemvb_grid(cfg.V, H, num_cu);
-        launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+        const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nb, H);
+        const int lmg = lm_mfma ? gemvm_grid(cfg.V, H, num_cu) : gemvb_grid(cfg.V, H, num_cu);
+        if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+        else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
         launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s);
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
         if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -55,7 +55,7 @@ def test_quantised_kv_matches_oracle(name, kv):
         # fork shares pages (codes + scales travel together); batched decode over two sequences
         s1 = m.seq_fork(0)
         lg, _ = m.step_batch_decode([0, s1], [5, 5])
-        assert rel(lg[0].reshape(-1), lg[1].reshape(-1)) < 1e-6
+        assert rel(lg[0].reshape(-1), lg[1].reshape(-1)) < 2e-5        # same inputs, different MFMA columns / reduction slots
         ref = o.forward([5], 80)
         assert rel(lg[0].reshape(-1), ref) < tol
     finally:
