@@ -21,12 +21,12 @@ namespace cm {
 
 constexpr int GM_KT = 4096;          // K slice per block (elements)
 constexpr int GM_MB = 8;             // sequence rows kept in LDS
-constexpr int GM_LD = GM_KT;         // LDS row stride (elements)
-constexpr int GM_W = 16;             // waves per block (1 block per CU: 16 x 8 KiB of weight loads in flight)
+constexpr int GM_LD = GM_KT + 32;    // LDS row stride (elements): +64 B, so the 4 sequences x 4 K-chunks a quarter-wave reads hit 16 distinct 16-byte bank slots
+constexpr int GM_W = 8;              // waves per block (1 block per CU; 2 x 8 weight loads in flight per lane)
 constexpr int GM_U = 8;              // k-steps (16-byte weight loads) in flight per lane
 
 template <int PRO, int EPI>
-__global__ __launch_bounds__(1024, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
+__global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* xh = lds;                                  // [GM_MB][GM_LD] (rows >= n_seq are zero)
     uint16_t* xl = lds + GM_MB * GM_LD;
@@ -104,12 +104,17 @@ __global__ __launch_bounds__(1024, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     for (int rg = bgrp * GM_W + wave; rg < G; rg += nbg * GM_W) {
         const int row = rg * 4 + i4;                         // weight row whose bytes this lane loads
         const uint16_t* wp = a.W + (size_t)(row < N ? row : N - 1) * a.ldw + k0 + blk * 8;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nks; ks += GM_U) {
-            u32x4 wq[GM_U];
+        // 4 independent accumulators per sequence half (k-half x hi/lo): no MFMA waits on the previous one
+        f32x4 c0[4], c1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; c1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        u32x4 wa[GM_U], wb[GM_U];
+        auto load_w = [&](u32x4 (&wq)[GM_U], int ks) {
 #pragma unroll
             for (int u = 0; u < GM_U; ++u)
                 wq[u] = ((ks + u) * 128 + blk * 8 < kt) ? ld_nt16(wp + (ks + u) * 128) : (u32x4){0, 0, 0, 0};
+        };
+        auto consume = [&](const u32x4 (&wq)[GM_U], int ks) {
 #pragma unroll
             for (int u = 0; u < GM_U; ++u) {
                 if ((ks + u) * 128 + blk * 8 < kt) {
@@ -117,19 +122,35 @@ __global__ __launch_bounds__(1024, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
                     const bf16x4 w_b = __builtin_bit_cast(bf16x4, (u32x2){wq[u][2], wq[u][3]});     // k 4..7
                     const int ko = (ks + u) * 128;
                     const u32x4 h0 = *(const u32x4*)(xh0 + ko), l0 = *(const u32x4*)(xl0 + ko);
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h0[0], h0[1]}), acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h0[2], h0[3]}), acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l0[0], l0[1]}), acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l0[2], l0[3]}), acc0, 0, 0, 0);
+                    c0[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h0[0], h0[1]}), c0[0], 0, 0, 0);
+                    c0[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h0[2], h0[3]}), c0[1], 0, 0, 0);
+                    c0[2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l0[0], l0[1]}), c0[2], 0, 0, 0);
+                    c0[3] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l0[2], l0[3]}), c0[3], 0, 0, 0);
                     if (two) {
                         const u32x4 h1 = *(const u32x4*)(xh1 + ko), l1 = *(const u32x4*)(xl1 + ko);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h1[0], h1[1]}), acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h1[2], h1[3]}), acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l1[0], l1[1]}), acc1, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l1[2], l1[3]}), acc1, 0, 0, 0);
+                        c1[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h1[0], h1[1]}), c1[0], 0, 0, 0);
+                        c1[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h1[2], h1[3]}), c1[1], 0, 0, 0);
+                        c1[2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l1[0], l1[1]}), c1[2], 0, 0, 0);
+                        c1[3] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l1[2], l1[3]}), c1[3], 0, 0, 0);
                     }
                 }
             }
+        };
+        // weight registers are double-buffered: the next 8 loads are in flight while the current 8 feed the MFMAs
+        load_w(wa, 0);
+        for (int ks = 0; ks < nks; ks += 2 * GM_U) {
+            if (ks + GM_U < nks) load_w(wb, ks + GM_U);
+            consume(wa, ks);
+            if (ks + GM_U < nks) {
+                if (ks + 2 * GM_U < nks) load_w(wa, ks + 2 * GM_U);
+                consume(wb, ks + GM_U);
+            }
+        }
+        f32x4 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0[r] = (c0[0][r] + c0[1][r]) + (c0[2][r] + c0[3][r]);
+            acc1[r] = (c1[0][r] + c1[1][r]) + (c1[2][r] + c1[3][r]);
         }
         // D layout: lane 4 * blk + j holds D[i = 0..3][j] of block blk; fold the 16 blocks (K chunks)
 #pragma unroll

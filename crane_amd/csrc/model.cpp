@@ -911,8 +911,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 } else {
                 const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode == CM_KV_BF16 && D == 128 && (page & (page - 1)) == 0;
                 if (mf) {
-                    if (!launch_attn_decode_mfma(a, D, nrep, longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                    // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
+                    const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
+                    if (!launch_attn_decode_mfma(a, D, nrep, ns_b, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                } else if (!launch_attn_decode(a, D, nrep, std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
                 }
             }
