@@ -40,45 +40,61 @@ __global__ __launch_bounds__(512, 2) void gemvb_kernel(GemvBArgs a) {
     auto stage = [&](int kt, bool count) {
         const int k0 = kt * BKT;
         const int tile = min(BKT, K - k0);
-        for (int e = tid; e < MB * (tk / 4); e += 64 * BW) {
-            const int m = e / (tk / 4), k4 = e % (tk / 4), k = k4 << 2;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < tile) {
+        // 4 independent 16-byte loads per thread per batch (one L2 round trip per batch, not per element)
+        const int total = MB * (tk / 4);
+        for (int e0 = tid; e0 < total; e0 += 64 * BW * 4) {
+            f32x4 vv[4], ww[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * 64 * BW;
+                const int m = e / (tk / 4), k = (e % (tk / 4)) << 2;
+                const bool live = e < total && k < tile;
                 if (PRO == PRO_ATTNCOMB) {            // merge the per-head partials of attn_decode_head_kernel
-                    const int kk = k0 + k, h = kk >> a.dshift, d = kk & ((1 << a.dshift) - 1);
-                    const float* ml = a.part_ml + ((size_t)m * (a.K >> a.dshift) + h) * a.ns * 2;
-                    const float* po = a.x + (size_t)m * a.ldx + ((size_t)h * a.ns << a.dshift) + d;
-                    float M = -INFINITY;
-                    for (int s2 = 0; s2 < a.ns; ++s2) M = fmaxf(M, ml[2 * s2]);
-                    float Ls = 0.f;
-                    for (int s2 = 0; s2 < a.ns; ++s2) {
-                        const float mm = ml[2 * s2];
-                        const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
-                        Ls += w * ml[2 * s2 + 1];
-                        const f32x4 p = *(const f32x4*)(po + ((size_t)s2 << a.dshift));
-                        v[0] += w * p[0]; v[1] += w * p[1]; v[2] += w * p[2]; v[3] += w * p[3];
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (live) {
+                        const int kk = k0 + k, h = kk >> a.dshift, d = kk & ((1 << a.dshift) - 1);
+                        const float* ml = a.part_ml + ((size_t)m * (a.K >> a.dshift) + h) * a.ns * 2;
+                        const float* po = a.x + (size_t)m * a.ldx + ((size_t)h * a.ns << a.dshift) + d;
+                        float M = -INFINITY;
+                        for (int s2 = 0; s2 < a.ns; ++s2) M = fmaxf(M, ml[2 * s2]);
+                        float Ls = 0.f;
+                        for (int s2 = 0; s2 < a.ns; ++s2) {
+                            const float mm = ml[2 * s2];
+                            const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
+                            Ls += w * ml[2 * s2 + 1];
+                            const f32x4 p = *(const f32x4*)(po + ((size_t)s2 << a.dshift));
+                            v[0] += w * p[0]; v[1] += w * p[1]; v[2] += w * p[2]; v[3] += w * p[3];
+                        }
+                        const float inv = 1.0f / Ls;
+                        v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
+                        if (a.gate != nullptr) {
+                            const f32x4 g = *(const f32x4*)(a.gate + (size_t)m * a.gate_stride + kk);
+                            v[0] *= 1.0f / (1.0f + expf(-g[0])); v[1] *= 1.0f / (1.0f + expf(-g[1]));
+                            v[2] *= 1.0f / (1.0f + expf(-g[2])); v[3] *= 1.0f / (1.0f + expf(-g[3]));
+                        }
                     }
-                    const float inv = 1.0f / Ls;
-                    v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv;
-                    if (a.gate != nullptr) {
-                        const f32x4 g = *(const f32x4*)(a.gate + (size_t)m * a.gate_stride + kk);
-                        v[0] *= 1.0f / (1.0f + expf(-g[0])); v[1] *= 1.0f / (1.0f + expf(-g[1]));
-                        v[2] *= 1.0f / (1.0f + expf(-g[2])); v[3] *= 1.0f / (1.0f + expf(-g[3]));
-                    }
+                    vv[i] = v;
                 } else
-                v = *(const f32x4*)(a.x + (size_t)m * a.ldx + k0 + k);
+                vv[i] = live ? *(const f32x4*)(a.x + (size_t)m * a.ldx + k0 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (PRO == PRO_RMSNORM) ww[i] = live ? *(const f32x4*)(a.nw + k0 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * 64 * BW;
+                if (e >= total) continue;
+                const int m = e / (tk / 4), k = (e % (tk / 4)) << 2;
+                f32x4 v = vv[i];
                 if (PRO == PRO_RMSNORM) {
                     if (count) {
                         const float s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
 #pragma unroll
                         for (int mm = 0; mm < MB; ++mm) if (mm == m) ss[mm] += s2;
                     }
-                    const f32x4 w = *(const f32x4*)(a.nw + k0 + k);
-                    v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
+                    v[0] *= ww[i][0]; v[1] *= ww[i][1]; v[2] *= ww[i][2]; v[3] *= ww[i][3];
                 }
+                const int c = k >> 9, j = k & 511;
+                ((f32x4*)(xs + m * tk))[c * 128 + ((j >> 2) & 1) * 64 + (j >> 3)] = v;
             }
-            const int c = k >> 9, j = k & 511;
-            ((f32x4*)(xs + m * tk))[c * 128 + ((j >> 2) & 1) * 64 + (j >> 3)] = v;
         }
     };
     auto finish_scale = [&]() {       // block-wide sum of squares -> 1/rms per sequence

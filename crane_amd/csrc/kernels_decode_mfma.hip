@@ -14,6 +14,8 @@
 // blocks and accumulates with f32 atomics onto the residual / a zeroed buffer (store).  Same fused RMSNorm prologue
 // and store / residual / SiLU*mul / arg-max epilogues as the other decode GEMVs.
 // Replaces step_batch_decode's batched matmuls (reference qwen3/modeling.rs:1202-1234) for 2..8 sequences.
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -41,26 +43,39 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     float ss[GM_MB];
 #pragma unroll
     for (int m = 0; m < GM_MB; ++m) ss[m] = 0.f;
-    for (int e = tid; e < GM_MB * (GM_KT / 4); e += 64 * GM_W) {
-        const int m = e / (GM_KT / 4), k = (e % (GM_KT / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < a.n_seq && k < kt) {
-            v = *(const f32x4*)(a.x + (size_t)m * a.ldx + k0 + k);
+    // 8 independent 16-byte loads per thread are issued before the first conversion (one L2 round trip per batch instead
+    // of one per element: the un-batched loop cost ~15 us per launch)
+    constexpr int SB = 8;
+    static_assert((GM_MB * (GM_KT / 4)) % (64 * GM_W * SB) == 0, "staging batches");
+    for (int e0 = tid; e0 < GM_MB * (GM_KT / 4); e0 += 64 * GM_W * SB) {
+        f32x4 v[SB], w[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int e = e0 + i * 64 * GM_W;
+            const int m = e / (GM_KT / 4), k = (e % (GM_KT / 4)) * 4;
+            const bool live = m < a.n_seq && k < kt;
+            v[i] = live ? *(const f32x4*)(a.x + (size_t)m * a.ldx + k0 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (PRO == PRO_RMSNORM) w[i] = live ? *(const f32x4*)(a.nw + k0 + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int e = e0 + i * 64 * GM_W;
+            const int m = e / (GM_KT / 4), k = (e % (GM_KT / 4)) * 4;
+            f32x4 x4 = v[i];
             if (PRO == PRO_RMSNORM) {
                 if (nkt == 1) {          // the slice IS the row: statistics from the same pass
-                    const float s2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    const float s2 = x4[0] * x4[0] + x4[1] * x4[1] + x4[2] * x4[2] + x4[3] * x4[3];
 #pragma unroll
                     for (int mm = 0; mm < GM_MB; ++mm) if (mm == m) ss[mm] += s2;
                 }
-                const f32x4 w = *(const f32x4*)(a.nw + k0 + k);
-                v[0] *= w[0]; v[1] *= w[1]; v[2] *= w[2]; v[3] *= w[3];
+                x4[0] *= w[i][0]; x4[1] *= w[i][1]; x4[2] *= w[i][2]; x4[3] *= w[i][3];
             }
+            const uint32_t h01 = pack_bf16x2(x4[0], x4[1]), h23 = pack_bf16x2(x4[2], x4[3]);
+            const uint32_t l01 = pack_bf16x2(x4[0] - bf16_lo(h01), x4[1] - bf16_hi(h01));
+            const uint32_t l23 = pack_bf16x2(x4[2] - bf16_lo(h23), x4[3] - bf16_hi(h23));
+            *(u32x2*)&xh[m * GM_LD + k] = (u32x2){h01, h23};
+            *(u32x2*)&xl[m * GM_LD + k] = (u32x2){l01, l23};
         }
-        const uint32_t h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
-        const uint32_t l01 = pack_bf16x2(v[0] - bf16_lo(h01), v[1] - bf16_hi(h01));
-        const uint32_t l23 = pack_bf16x2(v[2] - bf16_lo(h23), v[3] - bf16_hi(h23));
-        *(u32x2*)&xh[m * GM_LD + k] = (u32x2){h01, h23};
-        *(u32x2*)&xl[m * GM_LD + k] = (u32x2){l01, l23};
     }
     if (PRO == PRO_RMSNORM) {
         if (nkt > 1)
@@ -215,10 +230,12 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     }
 }
 
-// usable: 5..8 sequences (measured on Qwen3-8B, ms/step VALU gemvb vs this kernel: 2 seq 4.21 / 4.74, 4 seq 5.25 / 5.15,
-// 8 seq 7.85 / 6.21), K % 8 == 0, and no K split for the epilogues that need complete sums
+// usable: 3..8 sequences (measured on Qwen3-8B, ms/step VALU gemvb vs this kernel: 2 seq 4.12 / 4.51, 4 seq 4.88 / 4.73,
+// 8 seq 7.85 / 5.27), K % 8 == 0, and no K split for the epilogues that need complete sums
 bool gemvm_ok(int epi, int n_seq, int K) {
-    if (n_seq <= 4 || n_seq > GM_MB || K % 8 != 0) return false;
+    static int min_seq = -1;
+    if (min_seq < 0) { min_seq = 3; if (const char* e = getenv("CM_GEMVM_MIN")) min_seq = atoi(e); }
+    if (n_seq < min_seq || n_seq > GM_MB || K % 8 != 0) return false;
     const int nkt = (K + GM_KT - 1) / GM_KT;
     return nkt == 1 || epi == EPI_STORE || epi == EPI_RESADD;
 }
