@@ -565,8 +565,14 @@ bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, boo
 // One wave owns 16 tokens per step (a block covers 64), the next step's K and V rows are prefetched into a second
 // register set; grid (nsplit, Hkv); partials go to the same combine kernel.
 // ---------------------------------------------------------------------------------------------------------
-template <int D, int NREP>
+// KVT = 2 / 3 (int8 / int4 pages): the codes minus their offset are small integers -- exact in bf16 -- so they feed the
+// MFMAs directly; the per-token scales are applied outside the products: S^T rows are multiplied by the K scale of
+// their token and p by the V scale before it becomes the P^T operand (l uses the unscaled p).
+template <int D, int NREP, int KVT>
 __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
+    constexpr bool KVQ = KVT >= 2;
+    constexpr int ROWB = KVT == 2 ? D : D / 2;                   // code bytes per token row
+    constexpr float OFFS = KVT == 2 ? 128.f : 8.f, QMAX = KVT == 2 ? 127.f : 7.f;
     constexpr int NKS = D / 32, NNT = D / 16, VLD = D + 16, EPL = D / 64, TB = 64;
     constexpr int VCH = (16 * D / 8) / 64;                       // 16-byte V chunks per lane per tile
     __shared__ __attribute__((aligned(16))) uint16_t q_hi[16 * D];
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t Vs[4][16 * VLD];      // one tile per wave; reused as red_o at the end
     __shared__ float red_m[4][16];
     __shared__ float red_l[4][16];
+    __shared__ float new_scale[2];                               // quantised KV: scales of the appended k / v rows
 
     const int split = blockIdx.x, kvh = blockIdx.y, nsplit = gridDim.x, bq = blockIdx.z;
     const StepState* st = a.st + bq;
@@ -637,6 +644,33 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
             }
         } else {
             uint16_t* dst = (item == NREP) ? knew : vnew;
+            if (KVQ) {
+                // quantize_per_token (qwen3_5/kv_cache.rs:253-268); LDS keeps code - offset as a bf16 integer
+                float amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) amax = fmaxf(amax, fabsf(xv[j]));
+                amax = wave_max(amax);
+                const float scale = __fadd_rn(__fmul_rn(amax, (float)(1.0 / (double)QMAX)), 1e-8f);
+                uint8_t* pb = (uint8_t*)((item == NREP) ? a.kpool : a.vpool);
+                const size_t pbase = owner ? (size_t)block_table[pos / a.page] * a.page_bytes : 0;
+                const size_t roff = pbase + (size_t)(kvh * a.page + (pos % a.page)) * ROWB;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int d = lane + 64 * j;
+                    const float code = roundf(__fdiv_rn(xv[j], scale)) + OFFS;
+                    dst[d] = f32_to_bf16(code - OFFS);
+                    const uint32_t ci = (uint32_t)(int)code;
+                    if (KVT == 2) { if (owner) pb[roff + d] = (uint8_t)ci; }
+                    else {
+                        const uint32_t hi = (uint32_t)__shfl_down((int)ci, 1);
+                        if (owner && !(lane & 1)) pb[roff + (d >> 1)] = (uint8_t)(ci | (hi << 4));
+                    }
+                }
+                if (lane == 0) {
+                    new_scale[item - NREP] = scale;
+                    if (owner) *(float*)(pb + pbase + (size_t)a.Hkv * a.page * ROWB + (size_t)(kvh * a.page + (pos % a.page)) * 4) = scale;
+                }
+            } else {
             uint16_t* pool = (uint16_t*)((item == NREP) ? a.kpool : a.vpool);
             const size_t eoff = owner ? ((size_t)(block_table[pos / a.page] * a.Hkv + kvh) * a.page + (pos % a.page)) * D : 0;
 #pragma unroll
@@ -645,6 +679,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
                 const uint16_t b = f32_to_bf16(xv[j]);
                 dst[d] = b;
                 if (owner) pool[eoff + d] = b;
+            }
             }
         }
     }
@@ -667,12 +702,61 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
     const int psh = __builtin_ctz(a.page);                      // page size is a power of two (launcher checks)
     auto row_off = [&](int t) -> size_t {
         const int page = block_table[t >> psh];
+        if (KVQ) return (size_t)page * a.page_bytes + (size_t)(kvh * a.page + (t & (a.page - 1))) * ROWB;     // bytes
         return ((size_t)(page * a.Hkv + kvh) * a.page + (t & (a.page - 1))) * D;
     };
-    auto load_tile = [&](bf16x8 (&kf)[NKS], u32x4 (&vf)[VCH], int tb) {
-        const size_t ko = row_off(min(tb + sub, pos - 1)) + g * 8;       // clamped rows are masked later
+    auto scale_off = [&](int t) -> size_t {                      // byte offset of token t's f32 scale
+        return (size_t)block_table[t >> psh] * a.page_bytes + (size_t)a.Hkv * a.page * ROWB + (size_t)(kvh * a.page + (t & (a.page - 1))) * 4;
+    };
+    // 8 codes -> 8 bf16 integers (code - offset)
+    auto codes8 = [&](uint32_t lo, uint32_t hi) -> u32x4 {       // int8: lo / hi = bytes 0..3 / 4..7; int4: lo = 8 nibbles
+        float f[8];
+        if (KVT == 2) {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kpool + ko + ks * 32);
+            for (int e = 0; e < 4; ++e) { f[e] = (float)((lo >> (8 * e)) & 0xFFu) - OFFS; f[4 + e] = (float)((hi >> (8 * e)) & 0xFFu) - OFFS; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)((lo >> (4 * e)) & 0xFu) - OFFS;
+        }
+        return (u32x4){pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+    };
+    f32x4 ksA, ksB, vsA, vsB;                                    // per-token scales of the tile rows g*4 .. g*4+3
+    auto load_tile = [&](bf16x8 (&kf)[NKS], u32x4 (&vf)[VCH], f32x4& kscl, f32x4& vscl, int tb) {
+        const size_t ko = row_off(min(tb + sub, pos - 1));               // clamped rows are masked later
+        if (KVQ) {
+            const uint8_t* kb = (const uint8_t*)a.kpool + ko;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 32 + g * 8;
+                u32x4 c;
+                if (KVT == 2) { const u32x2 w = *(const u32x2*)(kb + d0); c = codes8(w[0], w[1]); }
+                else c = codes8(*(const uint32_t*)(kb + (d0 >> 1)), 0);
+                kf[ks] = __builtin_bit_cast(bf16x8, c);
+            }
+#pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                const int cch = lane + 64 * i, tok = cch / (D / 8), d8 = (cch % (D / 8)) * 8;
+                const uint8_t* vb = (const uint8_t*)a.vpool + row_off(min(tb + tok, pos - 1));
+                if (KVT == 2) { const u32x2 w = *(const u32x2*)(vb + d8); vf[i] = codes8(w[0], w[1]); }
+                else vf[i] = codes8(*(const uint32_t*)(vb + (d8 >> 1)), 0);
+            }
+            // rows g*4 .. g*4+3 of a 16-aligned tile sit in one page: 4 contiguous scales (clamped tokens are masked)
+            const int t0 = min(tb + g * 4, pos - 1), t3 = min(tb + g * 4 + 3, pos - 1);
+            if (t3 - t0 == 3) {
+                kscl = *(const f32x4*)((const uint8_t*)a.kpool + scale_off(t0));
+                vscl = *(const f32x4*)((const uint8_t*)a.vpool + scale_off(t0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = min(tb + g * 4 + r, pos - 1);
+                    kscl[r] = *(const float*)((const uint8_t*)a.kpool + scale_off(t));
+                    vscl[r] = *(const float*)((const uint8_t*)a.vpool + scale_off(t));
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kpool + ko + g * 8 + ks * 32);
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
             const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
@@ -680,7 +764,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         }
     };
     uint16_t* Vw = Vs[wave];
-    auto step = [&](const bf16x8 (&kf)[NKS], const u32x4 (&vf)[VCH], int tb, int limit) {
+    auto step = [&](const bf16x8 (&kf)[NKS], const u32x4 (&vf)[VCH], const f32x4& kscl, const f32x4& vscl, int tb, int limit) {
         // stage this tile's V rows in the wave's LDS region
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
@@ -696,6 +780,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         float mt = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (KVQ) sc[r] *= kscl[r];
             if (tb + g * 4 + r >= limit) sc[r] = -INFINITY;
             mt = fmaxf(mt, sc[r]);
         }
@@ -709,9 +794,10 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         for (int r = 0; r < 4; ++r) {
             const float p = expf(sc[r] - m_new);
             psum += p;
-            const uint16_t hh = f32_to_bf16(p);
+            const float pv = KVQ ? p * vscl[r] : p;              // V scale of the token folded into the P^T operand
+            const uint16_t hh = f32_to_bf16(pv);
             ph[r] = (short)hh;
-            pl[r] = (short)f32_to_bf16(p - bf16_to_f32(hh));
+            pl[r] = (short)f32_to_bf16(pv - bf16_to_f32(hh));
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -732,14 +818,14 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         u32x4 vA[VCH], vB[VCH];
         const int stride = TB * nsplit;
         int tb = TB * split + 16 * wave;
-        if (tb < pos) load_tile(kA, vA, tb);
+        if (tb < pos) load_tile(kA, vA, ksA, vsA, tb);
         while (tb < pos) {
-            if (tb + stride < pos) load_tile(kB, vB, tb + stride);
-            step(kA, vA, tb, pos);
+            if (tb + stride < pos) load_tile(kB, vB, ksB, vsB, tb + stride);
+            step(kA, vA, ksA, vsA, tb, pos);
             tb += stride;
             if (tb >= pos) break;
-            if (tb + stride < pos) load_tile(kA, vA, tb + stride);
-            step(kB, vB, tb, pos);
+            if (tb + stride < pos) load_tile(kA, vA, ksA, vsA, tb + stride);
+            step(kB, vB, ksB, vsB, tb, pos);
             tb += stride;
         }
         if (owner && wave == 0) {                                // the token appended by this step: row 0 of a pseudo-tile
@@ -754,7 +840,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
                 const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
                 vA[i] = tok == 0 ? *(const u32x4*)&vnew[d8] : (u32x4){0, 0, 0, 0};
             }
-            step(kA, vA, pos, pos + 1);
+            ksA = (f32x4){new_scale[0], 1.f, 1.f, 1.f}; vsA = (f32x4){new_scale[1], 1.f, 1.f, 1.f};
+            step(kA, vA, ksA, vsA, pos, pos + 1);
         }
     }
     l_run += __shfl_xor(l_run, 16);
@@ -791,9 +878,11 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
 }
 
 template <int D>
-static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int n_seq, hipStream_t s) {
+static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode, int n_seq, hipStream_t s) {
     dim3 grid(nsplit, a.Hkv, n_seq), block(256);
-#define CM_MF(N) case N: hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N>), grid, block, 0, s, a); return true;
+#define CM_MF(N) case N: if (kv_mode == 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, 2>), grid, block, 0, s, a); \
+                         else if (kv_mode == 3) hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, 3>), grid, block, 0, s, a); \
+                         else hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, 0>), grid, block, 0, s, a); return true;
     switch (nrep) {
         CM_MF(1) CM_MF(2) CM_MF(3) CM_MF(4) CM_MF(6) CM_MF(8)
         default: return false;
@@ -801,15 +890,15 @@ static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int n_seq, h
 #undef CM_MF
 }
 
-// bf16 KV only; same partial format and combine kernel as launch_attn_decode
-bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, float* out, int out_stride, int n_seq, hipStream_t s) {
-    if (a.page <= 0 || (a.page & (a.page - 1)) != 0) return false;
+// bf16 / int8 / int4 KV (not f32); same partial format and combine kernel as launch_attn_decode
+bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq, hipStream_t s) {
+    if (a.page <= 0 || (a.page & (a.page - 1)) != 0 || kv_mode == 1) return false;
     if (D == 128) {
-        if (!launch_mfma<128>(a, nrep, nsplit, n_seq, s)) return false;
+        if (!launch_mfma<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else if (D == 256) {
-        if (!launch_mfma<256>(a, nrep, nsplit, n_seq, s)) return false;
+        if (!launch_mfma<256>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else {

@@ -496,7 +496,7 @@ void Model::enqueue_decode_step(bool advance) {
         if (heads) {
             if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
         } else if (attn_variant >= 2) {      // bf16 KV: matrix-core flash-decode (32 token splits, 64 for long contexts)
-            if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+            if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
@@ -562,7 +562,7 @@ void Model::enqueue_quant_layer(int li) {
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps;
         a.scale = (float)(1.0 / std::sqrt((double)D));
         if (attn_variant >= 2) {
-            if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+            if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
     }
@@ -778,7 +778,7 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     ++ring_count;    // host mirror of st->pad (ring write index)
     // attention variant by context length (host-known): one captured graph per variant
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
-    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode == CM_KV_BF16 && cfg.D == 128 && (page & (page - 1)) == 0)
+    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode != CM_KV_F32 && cfg.D == 128 && (page & (page - 1)) == 0)
         attn_variant = ctx_len >= attn_mfma_wide_min ? 3 : 2;
     const int v = attn_variant;
     logits_gathered = false;
@@ -909,11 +909,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.dshift = D == 128 ? 7 : 8;
                     launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else {
-                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode == CM_KV_BF16 && D == 128 && (page & (page - 1)) == 0;
+                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode != CM_KV_F32 && D == 128 && (page & (page - 1)) == 0;
                 if (mf) {
                     // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
                     const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
-                    if (!launch_attn_decode_mfma(a, D, nrep, ns_b, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                    if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
                 }

@@ -109,3 +109,43 @@ def test_quantised_kv_is_close_to_full_precision():
             m.close()
     assert rel(outs["int8"], outs["f32"]) < 2e-2
     assert rel(outs["int4"], outs["f32"]) < 0.3
+
+
+@pytest.mark.parametrize("kv", ["int8", "int4"])
+@pytest.mark.parametrize("mfma_min,wide_min", [(1, 8192), (160, 166)])
+def test_quantised_kv_on_the_mfma_decode_kernel(monkeypatch, kv, mfma_min, wide_min):
+    """Long-context decode attention on the matrix cores over int8 / int4 pages: (code - offset) are exact bf16 integers
+    fed straight to the MFMAs, the per-token scales multiply S^T rows (K) and p (V).  Forced from the first token and
+    switched in mid-generation; single sequence and batched."""
+    from crane_amd.backend import Model
+    monkeypatch.setenv("CM_ATTN_MFMA_MIN", str(mfma_min))
+    monkeypatch.setenv("CM_ATTN_MFMA_WIDE_MIN", str(wide_min))
+    name = "tiny-qwen3-untied"
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    o, o2 = _oracle(name, cfg, w, kv), _oracle(name, cfg, w, kv)
+    tol = 2e-3 if kv == "int8" else 1e-3
+    m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype=kv)
+    try:
+        V = cfg["vocab_size"]
+        ids = configs.synthetic_prompt(150, V)
+        ref = o.forward(ids, 0)
+        assert rel(m.forward_step(ids, 0).reshape(-1), ref) < tol
+        tok = int(ref.argmax())
+        for step in range(24):
+            ref = o.forward([tok], 150 + step)
+            got = m.forward_step([tok], 150 + step).reshape(-1)
+            assert rel(got, ref) < tol, (step, rel(got, ref))
+            tok = int(ref.argmax())
+        s1, s2 = m.seq_alloc(), m.seq_alloc()
+        m.seq_forward(s1, ids, 0, want_logits=False)
+        m.seq_forward(s2, ids[:77], 0, want_logits=False)
+        o.forward(ids, 0); o2.forward(ids[:77], 0)
+        t1, t2 = 5, 9
+        for step in range(8):
+            lg, _ = m.step_batch_decode([s1, s2], [t1, t2])
+            r1, r2 = o.forward([t1], 150 + step), o2.forward([t2], 77 + step)
+            assert rel(lg[0].reshape(-1), r1) < tol and rel(lg[1].reshape(-1), r2) < tol, step
+            t1, t2 = int(r1.argmax()), int(r2.argmax())
+    finally:
+        m.close()
