@@ -818,15 +818,22 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         u32x4 vA[VCH], vB[VCH];
         const int stride = TB * nsplit;
         int tb = TB * split + 16 * wave;
-        if (tb < pos) load_tile(kA, vA, ksA, vsA, tb);
-        while (tb < pos) {
-            if (tb + stride < pos) load_tile(kB, vB, ksB, vsB, tb + stride);
-            step(kA, vA, ksA, vsA, tb, pos);
-            tb += stride;
-            if (tb >= pos) break;
-            if (tb + stride < pos) load_tile(kA, vA, ksA, vsA, tb + stride);
-            step(kB, vB, ksB, vsB, tb, pos);
-            tb += stride;
+        if constexpr (D <= 128) {                                // two statically named register sets: next tile in flight
+            if (tb < pos) load_tile(kA, vA, ksA, vsA, tb);
+            while (tb < pos) {
+                if (tb + stride < pos) load_tile(kB, vB, ksB, vsB, tb + stride);
+                step(kA, vA, ksA, vsA, tb, pos);
+                tb += stride;
+                if (tb >= pos) break;
+                if (tb + stride < pos) load_tile(kA, vA, ksA, vsA, tb + stride);
+                step(kB, vB, ksB, vsB, tb, pos);
+                tb += stride;
+            }
+        } else {                                                 // head_dim 256: one register set (the second one spills)
+            for (; tb < pos; tb += stride) {
+                load_tile(kA, vA, ksA, vsA, tb);
+                step(kA, vA, ksA, vsA, tb, pos);
+            }
         }
         if (owner && wave == 0) {                                // the token appended by this step: row 0 of a pseudo-tile
 #pragma unroll

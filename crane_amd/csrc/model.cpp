@@ -778,7 +778,7 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     ++ring_count;    // host mirror of st->pad (ring write index)
     // attention variant by context length (host-known): one captured graph per variant
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
-    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode != CM_KV_F32 && cfg.D == 128 && (page & (page - 1)) == 0)
+    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode != CM_KV_F32 && (cfg.D == 128 || cfg.D == 256) && (page & (page - 1)) == 0)
         attn_variant = ctx_len >= attn_mfma_wide_min ? 3 : 2;
     const int v = attn_variant;
     logits_gathered = false;
@@ -909,7 +909,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.dshift = D == 128 ? 7 : 8;
                     launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else {
-                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode != CM_KV_F32 && D == 128 && (page & (page - 1)) == 0;
+                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode != CM_KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
                 if (mf) {
                     // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
                     const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));

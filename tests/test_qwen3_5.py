@@ -212,3 +212,32 @@ def test_hip_qwen38_27b_geometry():
         o2.forward(ids[:20], 0); assert rel(lg[1, 0], o2.forward([8], 20)) < 1e-4
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["bf16", "int8"])
+def test_hybrid_decode_attention_on_the_mfma_kernel(monkeypatch, kv):
+    """head_dim 256 gated attention of the hybrid family through the matrix-core flash-decode kernel (single register
+    set; the sigmoid gate stays in the combine kernel), forced from the first token and with the 32 -> 64 split switch."""
+    from crane_amd import configs, synth
+    from crane_amd.backend import Model
+    from oracle import qwen3_5_oracle as O5
+    monkeypatch.setenv("CM_ATTN_MFMA_MIN", "1")
+    monkeypatch.setenv("CM_ATTN_MFMA_WIDE_MIN", "150")
+    cfg = configs.get_config("tiny-qwen3.5")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), w, kv_dtype=kv)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype=kv)
+    tol = 5e-4 if kv == "bf16" else 2e-3
+    try:
+        ids = configs.synthetic_prompt(140, cfg["vocab_size"])
+        ref = o.forward(ids, 0)
+        assert np.abs(m.forward_step(ids, 0).reshape(-1) - ref).max() / np.abs(ref).max() < tol
+        tok = int(ref.argmax())
+        for step in range(16):
+            ref = o.forward([tok], 140 + step)
+            got = m.forward_step([tok], 140 + step).reshape(-1)
+            assert np.abs(got - ref).max() / np.abs(ref).max() < tol, step
+            tok = int(ref.argmax())
+    finally:
+        m.close()
