@@ -173,10 +173,23 @@ struct Engine {
                 std::vector<uint32_t> toks(batch.size()), greedy(batch.size()), out(batch.size());
                 for (size_t i = 0; i < batch.size(); ++i) { sq[i] = req(batch[i]).seq; toks[i] = req(batch[i]).tokens.back(); }
                 const std::function<void(size_t, int)> after = [&](size_t g0, int nb) {
+                    // every sampled row of the group is enqueued on its own sampler slot; ONE host sync for the group
+                    uint32_t picked[Model::SAMPLE_SLOTS];
+                    bool any = false;
                     for (int b = 0; b < nb; ++b) {
                         Request& r = req(batch[g0 + (size_t)b]);
-                        out[g0 + (size_t)b] = r.greedy_plain ? m->h_stb[b].next
-                                                             : pick(r, m->logitsb + (size_t)b * m->cfg.V, 0);
+                        if (r.greedy_plain) continue;
+                        const size_t w = std::min(r.tokens.size(), (size_t)opts.repeat_last_n);
+                        cm_sample_params sp = r.sp;
+                        sp.repeat_last_n = 0;
+                        sp.draw = (uint32_t)r.num_generated();
+                        m->sample_enqueue(b, sp, r.tokens.data() + (r.tokens.size() - w), w, false, m->logitsb + (size_t)b * m->cfg.V);
+                        any = true;
+                    }
+                    if (any) m->sample_collect(nb, picked);
+                    for (int b = 0; b < nb; ++b) {
+                        Request& r = req(batch[g0 + (size_t)b]);
+                        out[g0 + (size_t)b] = r.greedy_plain ? m->h_stb[b].next : picked[b];
                     }
                 };
                 m->decode_batch(sq.data(), toks.data(), batch.size(), nullptr, greedy.data(), &after);

@@ -237,6 +237,11 @@ struct Model {
     void gather_logits();              // TP: all-gather the vocab shards into `logits`
     void topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out);
     uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false, float* dev_logits = nullptr);
+    // pipelined form for the engine's decode rounds: enqueue one row per slot (own scratch, no host sync), then ONE sync
+    static constexpr int SAMPLE_SLOTS = 8;
+    void sample_enqueue(int slot, const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div, float* dev_logits);
+    void sample_collect(int n_slots, uint32_t* tokens_out);
+    unsigned long long* tk_cand_rows = nullptr; size_t tk_cand_row_cap = 0;
     bool logits_gathered = false;
 
     // quantised weights (dense Qwen3, TP = 1): embedding / lm_head tables + per-layer QWeights in LayerW

@@ -15,15 +15,18 @@ static constexpr int SM_BLOCKS = 256;
 
 void Model::ensure_sampler() {
     if (tk_idx) return;
-    tk_hist = dalloc<uint32_t>(4096 + 4);
-    CM_HIP(hipMemsetAsync(tk_hist, 0, (4096 + 4) * sizeof(uint32_t), stream));
-    tk_idx = dalloc<uint32_t>(512);
-    tk_val = dalloc<float>(512);
-    d_pen = dalloc<uint32_t>(2 * (size_t)PEN_CAP);
-    d_tok = dalloc<uint32_t>(1);
+    // one scratch set per sampler slot (slot 0 doubles as the single-row path)
+    tk_hist = dalloc<uint32_t>((size_t)SAMPLE_SLOTS * (4096 + 4));
+    CM_HIP(hipMemsetAsync(tk_hist, 0, (size_t)SAMPLE_SLOTS * (4096 + 4) * sizeof(uint32_t), stream));
+    tk_idx = dalloc<uint32_t>((size_t)SAMPLE_SLOTS * 512);
+    tk_val = dalloc<float>((size_t)SAMPLE_SLOTS * 512);
+    d_pen = dalloc<uint32_t>((size_t)SAMPLE_SLOTS * 2 * PEN_CAP);
+    d_tok = dalloc<uint32_t>(SAMPLE_SLOTS);
+    tk_cand_row_cap = std::max<size_t>((size_t)topk_blocks(cfg.V) * 64, 4096);
+    tk_cand_rows = (unsigned long long*)dalloc<uint32_t>((size_t)SAMPLE_SLOTS * tk_cand_row_cap * 2);
     sm_pmax = dalloc<float>(SM_BLOCKS);
     sm_pidx = dalloc<int>(SM_BLOCKS);
-    CM_HIP(hipHostMalloc((void**)&h_pen, 2 * (size_t)PEN_CAP * sizeof(uint32_t)));
+    CM_HIP(hipHostMalloc((void**)&h_pen, (size_t)SAMPLE_SLOTS * 2 * PEN_CAP * sizeof(uint32_t)));
     CM_HIP(hipHostMalloc((void**)&h_tk, (1 + 512 + 512) * sizeof(uint32_t)));
 }
 
@@ -69,10 +72,31 @@ void Model::topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_o
 }
 
 uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div, float* dev_logits) {
+    sample_enqueue(0, p, ctx, n_ctx, true_div, dev_logits);
+    uint32_t t = 0;
+    sample_collect(1, &t);
+    return t;
+}
+
+void Model::sample_collect(int n_slots, uint32_t* tokens_out) {
+    CM_HIP(hipMemcpyAsync(h_tk, d_tok, (size_t)n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    memcpy(tokens_out, h_tk, (size_t)n_slots * sizeof(uint32_t));
+}
+
+void Model::sample_enqueue(int slot, const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div, float* dev_logits) {
+    if (slot < 0 || slot >= SAMPLE_SLOTS) throw CmError(CM_ERR_INVALID, "sampler slot out of range");
     ensure_sampler();
     float* logits = dev_logits ? dev_logits : this->logits;      // a row of the batched step, or the last forward's logits
     if (!dev_logits) gather_logits();
     const int V = cfg.V;
+    uint32_t* hp = h_pen + (size_t)slot * 2 * PEN_CAP;           // pinned staging of this slot (reused only after a sync)
+    uint32_t* dp = d_pen + (size_t)slot * 2 * PEN_CAP;
+    uint32_t* hist = tk_hist + (size_t)slot * (4096 + 4);
+    uint32_t* idx = tk_idx + (size_t)slot * 512;
+    float* val = tk_val + (size_t)slot * 512;
+    unsigned long long* cand = tk_cand_rows + (size_t)slot * tk_cand_row_cap;
+    uint32_t* tok = d_tok + slot;
     // ---- penalties over the window (sampling.rs:422-478): distinct ids + counts, applied on the device ----
     const bool rep = p.repetition_penalty != 1.0f && p.repetition_penalty > 0.f;      // strict sentinel (sampling.rs:431)
     const bool fp = p.frequency_penalty != 0.f || p.presence_penalty != 0.f;
@@ -84,46 +108,33 @@ uint32_t Model::sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_
             const uint32_t t = ctx[i];
             if (t >= (uint32_t)V) continue;
             auto it = pos.find(t);
-            if (it != pos.end()) { h_pen[PEN_CAP + it->second]++; continue; }
+            if (it != pos.end()) { hp[PEN_CAP + it->second]++; continue; }
             if (nd == PEN_CAP) throw CmError(CM_ERR_RANGE, "more than 8192 distinct tokens in the penalty window");
             pos.emplace(t, (uint32_t)nd);
-            h_pen[nd] = t; h_pen[PEN_CAP + nd] = 1; ++nd;
+            hp[nd] = t; hp[PEN_CAP + nd] = 1; ++nd;
         }
         if (nd) {
-            for (int i = 0; i < nd; ++i) h_pen[nd + i] = h_pen[PEN_CAP + i];          // [ids | counts] in one H2D copy
-            CM_HIP(hipMemcpyAsync(d_pen, h_pen, (size_t)2 * nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-            launch_penalties(logits, d_pen, d_pen + nd, nd, rep ? p.repetition_penalty : 1.0f, true_div, p.frequency_penalty,
+            for (int i = 0; i < nd; ++i) hp[nd + i] = hp[PEN_CAP + i];                // [ids | counts] in one H2D copy
+            CM_HIP(hipMemcpyAsync(dp, hp, (size_t)2 * nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            launch_penalties(logits, dp, dp + nd, nd, rep ? p.repetition_penalty : 1.0f, true_div, p.frequency_penalty,
                              p.presence_penalty, V, stream);
         }
     }
-    auto need_cand = [&](int k) {
-        const size_t need = std::max<size_t>((size_t)topk_blocks(V) * (size_t)topk_pad(k), 4096);
-        if (need > tk_cand_cap) {
-            if (tk_cand) (void)hipFree(tk_cand);
-            tk_cand = nullptr; tk_cand_cap = 0;
-            CM_HIP(hipMalloc((void**)&tk_cand, need * sizeof(unsigned long long)));
-            tk_cand_cap = need;
-        }
-    };
     if (!(p.temperature > 0.f)) {                                  // greedy: arg-max, first index on ties
-        need_cand(1);
-        launch_topk(logits, V, 1, tk_cand, tk_hist, tk_hist + 4096, d_tok, tk_val, stream);
+        launch_topk(logits, V, 1, cand, hist, hist + 4096, tok, val, stream);
     } else {
         const bool top_p_active = p.top_p > 0.f && p.top_p < 1.f;
         int k = (int)p.top_k;
         if (k == 0 && top_p_active) k = 64;                        // CRANE_TOPP_FALLBACK_TOPK default (sampling.rs:263-267)
         k = std::min(std::min(k, 64), V);                          // sampling.rs:268
         if (k > 0 && k < V) {
-            need_cand(k);
-            launch_topk(logits, V, k, tk_cand, tk_hist, tk_hist + 4096, tk_idx, tk_val, stream);
-            launch_sample_topk(tk_idx, tk_val, k, p.temperature, top_p_active ? p.top_p : 0.f, p.seed, p.draw, d_tok, stream);
+            launch_topk(logits, V, k, cand, hist, hist + 4096, idx, val, stream);
+            launch_sample_topk(idx, val, k, p.temperature, top_p_active ? p.top_p : 0.f, p.seed, p.draw, tok, stream);
         } else {
-            launch_gumbel_full(logits, V, p.temperature, p.seed, p.draw, sm_pmax, sm_pidx, SM_BLOCKS, d_tok, stream);
+            // full-vocabulary Gumbel-max shares one partial buffer: stream order serialises the slots
+            launch_gumbel_full(logits, V, p.temperature, p.seed, p.draw, sm_pmax, sm_pidx, SM_BLOCKS, tok, stream);
         }
     }
-    CM_HIP(hipMemcpyAsync(h_tk, d_tok, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CM_HIP(hipStreamSynchronize(stream));
-    return h_tk[0];
 }
 
 }  // namespace cm
