@@ -209,13 +209,28 @@ struct GemvQArgs {
     int act_int = 0;       // 1: activations quantised to Q8_0 / Q8_K + integer dot products (ggml vec_dot semantics)
 };
 int gemvq_grid(int N, int num_cu);
+// batched integer-dot GEMV: <= 8 sequences per pass over the quantised weights (activations always quantised)
+struct GemvQBArgs {
+    QWeight w;
+    const float* x;        // [n_seq, ldx] f32
+    const float* nw;
+    float* y;              // [n_seq, ldy]
+    const float* res;      // [n_seq, ldy] (EPI_RESADD)
+    float* pmax;           // [n_seq, grid] (EPI_ARGMAX)
+    int* pidx;
+    int n_seq, ldx, ldy, idx_base;
+    float eps;
+};
+int gemvqb_max_seqs(int fmt, int K);
+int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu);
+bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s);
 bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s);
-void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s);
+void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s, int n_seq = 1);
 void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s);
 void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s);
 void launch_embed_rows_q(const QWeight& w, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
 void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s);
-void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s);
+void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s, int n_seq = 1, int in_stride = 0, int out_stride = 0);
 
 // sampler (kernels_sample.hip)
 int topk_pad(int k);

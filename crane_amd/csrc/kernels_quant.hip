@@ -16,6 +16,8 @@
 // lane; 2048 for the K-quants: 8 lanes per 256-block, 32 weights per lane).  x lives in LDS as f32, permuted per
 // format so that the NJ float4 a lane needs per chunk are at [chunk][j][lane] (conflict-free ds_read_b128).
 // Same fused prologue (RMSNorm) and epilogues (store / residual add / SiLU*mul / arg-max) as the bf16 GEMV.
+#include <stdexcept>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -260,12 +262,14 @@ uint64_t QWeight::bytes() const {
     return 0;
 }
 
-__global__ void silu_mul_kernel(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ o, int n) {
+__global__ void silu_mul_kernel(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ o, int n,
+                                int in_stride, int out_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    g += (size_t)blockIdx.y * in_stride; u += (size_t)blockIdx.y * in_stride; o += (size_t)blockIdx.y * out_stride;
     if (i < n) { const float v = g[i]; o[i] = (v / (1.0f + expf(-v))) * u[i]; }
 }
-void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s) {
-    hipLaunchKernelGGL(silu_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gate, up, out, n);
+void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s, int n_seq, int in_stride, int out_stride) {
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((n + 255) / 256, n_seq), dim3(256), 0, s, gate, up, out, n, in_stride, out_stride);
 }
 
 
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
         float ss = 0.f;
         for (int k4 = tid; k4 < n4; k4 += 256) {
             const f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss))));   // explicit: gemvqb must match bit for bit
         }
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                     int isum = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i][u].a[j], (int)xv[j], isum, false);
-                    acc[i] += (q[i][u].d * dx) * (float)isum;
+                    acc[i] = fmaf(q[i][u].d * dx, (float)isum, acc[i]);
                 }
             } else if constexpr (FMT == QFMT_Q4_K) {
                 const int kb = c * 8 + (lane >> 3), h = lane & 7, p = h >> 1;
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                         il = __builtin_amdgcn_sdot4((int)(q[i][u].a[j] & 0x0F0F0F0Fu), (int)x0[j], il, false);
                         ih = __builtin_amdgcn_sdot4((int)((q[i][u].a[j] >> 4) & 0x0F0F0F0Fu), (int)x1[j], ih, false);
                     }
-                    acc[i] += (dx * d) * (float)(sc0 * il + sc1 * ih) - (dx * dmin) * (float)(m0 * bs0 + m1 * bs1);
+                    acc[i] = fmaf(-(dx * dmin), (float)(m0 * bs0 + m1 * bs1), fmaf(dx * d, (float)(sc0 * il + sc1 * ih), acc[i]));
                 }
             } else {
                 const int kb = c * 8 + (lane >> 3), n = (lane >> 2) & 1, j = lane & 3;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                         const int sc = (int)(signed char)((q[i][u].b[2] >> (8 * t)) & 0xFFu);
                         sumi += sc * (is - 32 * bs[t]);
                     }
-                    acc[i] += (dx * d) * (float)sumi;
+                    acc[i] = fmaf(dx * d, (float)sumi, acc[i]);
                 }
             }
           }
@@ -576,6 +580,338 @@ bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Batched integer-dot GEMV (continuous batching over quantised weights, qwen3/modeling.rs:1202-1234 with
+// LinearLayer::Quantized): up to MB sequences share ONE pass over the weight stream.  The weight bytes of a
+// (row, chunk) are decoded once and dotted with every sequence's activation codes, so the per-weight decode
+// cost that bounds gemvq_i8_kernel is amortised over the batch.  Each sequence's row is quantised exactly as
+// gemvq_i8_kernel does it (two 256-thread halves of the block take alternate sequences and walk K with the same
+// thread -> element mapping), and a wave sums a row in the same order, so y[m] is bit-identical to the
+// single-sequence kernel on x[m].
+//   block = 512 threads (8 waves); LDS per sequence = Kpad codes + block scales (+ Kpad/8 code sums for K-quants)
+// ---------------------------------------------------------------------------------------------------------
+template <int FMT, int PRO, int EPI, int MB>
+__global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
+    using F = QF<FMT>;
+    constexpr int R = 2, CK = F::CK, NW = 8;
+    constexpr bool KQ = FMT != QFMT_Q8_0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.w.K, N = a.w.N, ns = a.n_seq;
+    const int nch = (K + CK - 1) / CK;
+    const int Kpad = nch * CK;
+    const int nscale = KQ ? Kpad / 256 : Kpad / 32;
+    const int seq_bytes = Kpad + nscale * 4 + (KQ ? Kpad / 8 * 4 : 0);
+    float* red = (float*)(lds_raw + (size_t)MB * seq_bytes);       // [MB][4] sums of squares, later [NW][MB] arg-max pairs
+
+    const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
+    const int G = (N + R - 1) / R;
+    const int gstride = gridDim.x * NW;
+    const int gfirst = blockIdx.x * NW + wave;
+    QRow q[R], qn[R];
+    auto load_rows = [&](QRow (&dst)[R], int g, int c) {
+        if (c * CK + lane_k < K) {
+            const int r0 = g * R;
+#pragma unroll
+            for (int i = 0; i < R; ++i) dst[i] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c, lane);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < R; ++i) { q[i].a = (u32x4){0, 0, 0, 0}; q[i].b = (u32x4){0, 0, 0, 0}; q[i].d = 0.f; qn[i] = q[i]; }
+    if (gfirst < G) load_rows(q, gfirst, 0);       // weight bytes are requested before the activation rows are quantised
+
+    // ---- quantise the activation rows: half `grp` of the block takes sequences grp, grp + 2, ... ----
+    const int grp = tid >> 8, t2 = tid & 255, w2 = wave & 3;
+    const int n4 = K >> 2;
+    if (PRO == PRO_RMSNORM) {
+        for (int m = grp; m < ns; m += 2) {
+            const float* xr = a.x + (size_t)m * a.ldx;
+            float ss = 0.f;
+            for (int k4 = t2; k4 < n4; k4 += 256) {
+                const f32x4 v = *(const f32x4*)(xr + (k4 << 2));
+                ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss))));
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[m * 4 + w2] = ss;
+        }
+        __syncthreads();
+    }
+    for (int m = grp; m < ns; m += 2) {
+        const float* xr = a.x + (size_t)m * a.ldx;
+        signed char* xq = (signed char*)(lds_raw + (size_t)m * seq_bytes);
+        float* xd = (float*)(xq + Kpad);
+        int* xs8 = (int*)(xd + nscale);
+        float rr = 1.f;
+        if (PRO == PRO_RMSNORM)
+            rr = 1.0f / sqrtf(((red[m * 4] + red[m * 4 + 1]) + (red[m * 4 + 2] + red[m * 4 + 3])) / (float)K + a.eps);
+        auto xval = [&](int k4) -> f32x4 {
+            f32x4 v = *(const f32x4*)(xr + (k4 << 2));
+            if (PRO == PRO_RMSNORM) {
+                const f32x4 w = *(const f32x4*)(a.nw + (k4 << 2));
+                v[0] = __fmul_rn(__fmul_rn(v[0], rr), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], rr), w[1]);
+                v[2] = __fmul_rn(__fmul_rn(v[2], rr), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], rr), w[3]);
+            }
+            return v;
+        };
+        if (!KQ) {
+            for (int k4 = t2; k4 < n4; k4 += 256) {                // quantize_row_q8_0: 32 elements = 8 consecutive lanes
+                const f32x4 v = xval(k4);
+                float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+                const float d = am / 127.0f;
+                const float id = d != 0.f ? 1.0f / d : 0.f;
+                uint32_t pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(v[e] * id) & 0xFFu) << (8 * e);
+                ((uint32_t*)xq)[k4] = pk;
+                if ((t2 & 7) == 0) xd[k4 >> 3] = f16_round(d);
+            }
+        } else {
+            const int nblk = K >> 8;                               // quantize_row_q8_K: one wave per 256-element block
+            for (int blk = w2; blk < nblk; blk += 4) {
+                const int k4 = blk * 64 + lane;
+                const f32x4 v = xval(k4);
+                unsigned long long key = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned long long ke = ((unsigned long long)__float_as_uint(fabsf(v[e])) << 32) | (unsigned)(255 - (lane * 4 + e));
+                    key = ke > key ? ke : key;
+                }
+                unsigned long long bestk = key;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)bestk, o), hi = (unsigned)__shfl_xor((int)(unsigned)(bestk >> 32), o);
+                    const unsigned long long ot = ((unsigned long long)hi << 32) | lo;
+                    bestk = ot > bestk ? ot : bestk;
+                }
+                const int widx = 255 - (int)(unsigned)(bestk & 0xFFFFFFFFull);
+                float cand = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (lane * 4 + e == widx) cand = v[e];
+                const float mx = wave_sum(cand);
+                const float iscale = mx != 0.f ? -128.0f / mx : 0.f;
+                int qq[4]; int s4 = 0; uint32_t pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qq[e] = mx != 0.f ? min(127, __float2int_rn(v[e] * iscale)) : 0;
+                    s4 += qq[e];
+                    pk |= ((uint32_t)qq[e] & 0xFFu) << (8 * e);
+                }
+                ((uint32_t*)xq)[k4] = pk;
+                const int s8 = s4 + __shfl_xor(s4, 1);
+                if (!(lane & 1)) xs8[k4 >> 1] = s8;
+                if (lane == 0) xd[blk] = mx != 0.f ? 1.0f / iscale : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    float best[MB]; int besti[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) { best[m] = -INFINITY; besti[m] = 0x7FFFFFFF; }
+    for (int g = gfirst; g < G; g += gstride) {
+        const int r0 = g * R;
+        float acc[R][MB];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[i][m] = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            // the next (row group, chunk) is in flight while this one is dotted with every sequence
+            if (c + 1 < nch) load_rows(qn, g, c + 1);
+            else if (g + gstride < G) load_rows(qn, g + gstride, 0);
+            if (c * CK + lane_k < K) {
+                if constexpr (FMT == QFMT_Q8_0) {
+                    const int e0 = c * 1024 + lane * 16;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        if (m >= ns) break;
+                        const unsigned char* sp = lds_raw + (size_t)m * seq_bytes;
+                        const u32x4 xv = *(const u32x4*)(sp + e0);
+                        const float dx = ((const float*)(sp + Kpad))[e0 >> 5];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            int isum = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i].a[j], (int)xv[j], isum, false);
+                            acc[i][m] = fmaf(q[i].d * dx, (float)isum, acc[i][m]);
+                        }
+                    }
+                } else if constexpr (FMT == QFMT_Q4_K) {
+                    const int kb = c * 8 + (lane >> 3), h = lane & 7, p = h >> 1;
+                    const int e0 = kb * 256 + 64 * p + 16 * (h & 1);
+                    float d[R], dmin[R]; int sc0[R], m0[R], sc1[R], m1[R]; u32x4 wl[R], wh[R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const u32x4 hb = q[i].b;
+                        d[i] = f16_bits_to_f32(hb[0] & 0xFFFFu); dmin[i] = f16_bits_to_f32(hb[0] >> 16);
+                        auto sbyte = [&](int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
+                        auto scale_min = [&](int j, int& sc, int& mn) {
+                            if (j < 4) { sc = sbyte(j) & 63; mn = sbyte(j + 4) & 63; }
+                            else { sc = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
+                        };
+                        scale_min(2 * p, sc0[i], m0[i]);
+                        scale_min(2 * p + 1, sc1[i], m1[i]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { wl[i][j] = q[i].a[j] & 0x0F0F0F0Fu; wh[i][j] = (q[i].a[j] >> 4) & 0x0F0F0F0Fu; }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        if (m >= ns) break;
+                        const unsigned char* sp = lds_raw + (size_t)m * seq_bytes;
+                        const float* xd = (const float*)(sp + Kpad);
+                        const int* xs8 = (const int*)(xd + nscale);
+                        const u32x4 x0 = *(const u32x4*)(sp + e0), x1 = *(const u32x4*)(sp + e0 + 32);
+                        const int bs0 = xs8[e0 >> 3] + xs8[(e0 >> 3) + 1], bs1 = xs8[(e0 + 32) >> 3] + xs8[((e0 + 32) >> 3) + 1];
+                        const float dx = xd[kb];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            int il = 0, ih = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                il = __builtin_amdgcn_sdot4((int)wl[i][j], (int)x0[j], il, false);
+                                ih = __builtin_amdgcn_sdot4((int)wh[i][j], (int)x1[j], ih, false);
+                            }
+                            acc[i][m] = fmaf(-(dx * dmin[i]), (float)(m0[i] * bs0 + m1[i] * bs1), fmaf(dx * d[i], (float)(sc0[i] * il + sc1[i] * ih), acc[i][m]));
+                        }
+                    }
+                } else {
+                    const int kb = c * 8 + (lane >> 3), n = (lane >> 2) & 1, j = lane & 3;
+                    const int e0 = kb * 256 + 128 * n + 8 * j;
+                    float d[R]; uint32_t code[R][4][2]; int sc[R][4];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        d[i] = f16_bits_to_f32(q[i].b[3]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int qsel = (t & 1) * 2, hshift = 2 * t;
+#pragma unroll
+                            for (int wi = 0; wi < 2; ++wi) {
+                                const uint32_t qlw = q[i].a[qsel + wi], qhw = q[i].b[wi];
+                                code[i][t][wi] = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
+                            }
+                            sc[i][t] = (int)(signed char)((q[i].b[2] >> (8 * t)) & 0xFFu);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        if (m >= ns) break;
+                        const unsigned char* sp = lds_raw + (size_t)m * seq_bytes;
+                        const float* xd = (const float*)(sp + Kpad);
+                        const int* xs8 = (const int*)(xd + nscale);
+                        u32x2 xr[4]; int bs[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { xr[t] = *(const u32x2*)(sp + e0 + 32 * t); bs[t] = xs8[(e0 + 32 * t) >> 3]; }
+                        const float dx = xd[kb];
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            int sumi = 0;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                int is = 0;
+#pragma unroll
+                                for (int wi = 0; wi < 2; ++wi) is = __builtin_amdgcn_sdot4((int)code[i][t][wi], (int)xr[t][wi], is, false);
+                                sumi += sc[i][t] * (is - 32 * bs[t]);
+                            }
+                            acc[i][m] = fmaf(dx * d[i], (float)sumi, acc[i][m]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < R; ++i) q[i] = qn[i];
+        }
+        // lane m*R + i ends up holding (row r0 + i, sequence m)
+        float mine = 0.f, gate_v = 0.f, up_v = 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m >= ns) break;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                acc[i][m] = wave_sum(acc[i][m]);
+                if (lane == m * R + i) mine = acc[i][m];
+            }
+            if (EPI == EPI_SILUMUL && lane == m) { gate_v = acc[0][m]; up_v = acc[1][m]; }
+            if (EPI == EPI_ARGMAX) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ix = r0 + i + a.idx_base;
+                    if (r0 + i < N && (acc[i][m] > best[m] || (acc[i][m] == best[m] && ix < besti[m]))) { best[m] = acc[i][m]; besti[m] = ix; }
+                }
+            }
+        }
+        const int mi = lane / R, ri = lane % R;
+        if (EPI == EPI_STORE || EPI == EPI_ARGMAX) {
+            if (mi < ns && r0 + ri < N) a.y[(size_t)mi * a.ldy + r0 + ri] = mine;
+        } else if (EPI == EPI_RESADD) {
+            if (mi < ns && r0 + ri < N) a.y[(size_t)mi * a.ldy + r0 + ri] = a.res[(size_t)mi * a.ldy + r0 + ri] + mine;
+        } else if (EPI == EPI_SILUMUL) {
+            if (lane < ns && r0 + 1 < N) a.y[(size_t)lane * a.ldy + (r0 >> 1)] = (gate_v / (1.0f + expf(-gate_v))) * up_v;
+        }
+    }
+    if (EPI == EPI_ARGMAX) {
+        __syncthreads();
+        int* redi = (int*)(red + NW * MB);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { red[wave * MB + m] = best[m]; redi[wave * MB + m] = besti[m]; }
+        }
+        __syncthreads();
+        if (tid < ns) {
+            float bb = red[tid]; int bbi = redi[tid];
+            for (int w = 1; w < NW; ++w)
+                if (red[w * MB + tid] > bb || (red[w * MB + tid] == bb && redi[w * MB + tid] < bbi)) { bb = red[w * MB + tid]; bbi = redi[w * MB + tid]; }
+            a.pmax[(size_t)tid * gridDim.x + blockIdx.x] = bb; a.pidx[(size_t)tid * gridDim.x + blockIdx.x] = bbi;
+        }
+    }
+}
+
+static size_t gemvqb_seq_bytes(int fmt, int K) {
+    const int CK = fmt == QFMT_Q8_0 ? 1024 : 2048;
+    const size_t kpad = (size_t)((K + CK - 1) / CK) * CK;
+    return kpad + (fmt == QFMT_Q8_0 ? kpad / 32 * 4 : kpad / 256 * 4 + kpad / 8 * 4);
+}
+constexpr size_t QB_LDS_MAX = 160 * 1024 - 1024;
+
+// sequences one launch can take (0: the activation codes of even one sequence pair do not fit in LDS)
+int gemvqb_max_seqs(int fmt, int K) {
+    const size_t fit = (QB_LDS_MAX - 8 * 8 * 8) / gemvqb_seq_bytes(fmt, K);
+    return fit >= 8 ? 8 : fit >= 4 ? 4 : 0;
+}
+int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu) {
+    (void)fmt; (void)K; (void)n_seq;
+    // every block re-quantises the activation rows and the K-quant kernels hold > 128 VGPRs: one fat block per CU
+    const int groups = (N + 1) / 2;
+    return std::max(1, std::min((groups + 7) / 8, num_cu));
+}
+
+template <int FMT, int MB>
+static void launch_gemvqb_t(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)MB * gemvqb_seq_bytes(FMT, a.w.K) + 8 * 8 * 8;
+#define CM_QB(P, E) { static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemvqb_i8_kernel<FMT, P, E, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((gemvqb_i8_kernel<FMT, P, E, MB>), dim3(grid), dim3(512), lds, s, a); return; }
+    if (pro == PRO_RMSNORM && epi == EPI_STORE) CM_QB(PRO_RMSNORM, EPI_STORE)
+    if (pro == PRO_RMSNORM && epi == EPI_SILUMUL) CM_QB(PRO_RMSNORM, EPI_SILUMUL)
+    if (pro == PRO_RMSNORM && epi == EPI_ARGMAX) CM_QB(PRO_RMSNORM, EPI_ARGMAX)
+    if (pro == PRO_PLAIN && epi == EPI_RESADD) CM_QB(PRO_PLAIN, EPI_RESADD)
+#undef CM_QB
+    throw std::runtime_error("gemvqb: prologue/epilogue combination not built");
+}
+
+// n_seq <= gemvqb_max_seqs(fmt, K); the (prologue, epilogue) pairs the decoder uses
+bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s) {
+    if (a.n_seq < 1 || a.n_seq > 8) return false;
+#define CM_QBF(F) { if (a.n_seq <= 4) launch_gemvqb_t<F, 4>(pro, epi, a, grid, s); else launch_gemvqb_t<F, 8>(pro, epi, a, grid, s); return true; }
+    switch (a.w.fmt) {
+        case QFMT_Q8_0: CM_QBF(QFMT_Q8_0)
+        case QFMT_Q4_K: CM_QBF(QFMT_Q4_K)
+        case QFMT_Q6_K: CM_QBF(QFMT_Q6_K)
+        default: return false;
+    }
+#undef CM_QBF
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // element-wise dequantisation (embedding-row gather; also the reference for the GEMV in tests)
 // ---------------------------------------------------------------------------------------------------------
 __device__ float q_elem(const QWeight& w, size_t row, int k) {
@@ -609,6 +945,8 @@ __device__ float q_elem(const QWeight& w, size_t row, int k) {
 }
 
 __global__ void embed_row_q_kernel(QWeight w, const StepState* __restrict__ st, float* __restrict__ x, int H, int V) {
+    st += blockIdx.y;                              // batched step: one state / output row per sequence
+    x += (size_t)blockIdx.y * H;
     uint32_t tok = st->token;
     if (tok >= (uint32_t)V) tok = 0;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -650,8 +988,8 @@ void launch_embed_rows_q(const QWeight& w, const uint32_t* ids, float* x, int S,
     hipLaunchKernelGGL(embed_rows_q_kernel, dim3(S), dim3(256), 0, s, w, ids, x, H, V);
 }
 
-void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s) {
-    hipLaunchKernelGGL(embed_row_q_kernel, dim3((H + 255) / 256), dim3(256), 0, s, w, st, x, H, V);
+void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s, int n_seq) {
+    hipLaunchKernelGGL(embed_row_q_kernel, dim3((H + 255) / 256, n_seq), dim3(256), 0, s, w, st, x, H, V);
 }
 void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s) {
     const size_t n = (size_t)nrows * w.K;

@@ -829,7 +829,9 @@ void Model::ensure_batch_buffers() {
     logitsb = dalloc<float>((size_t)MAXB * cfg.V);
     part_ob = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
-    const int g = std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu));
+    int g = std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu));
+    if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu));
+    if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * cfg.I);
     pmaxb = dalloc<float>((size_t)MAXB * g);
     pidxb = dalloc<int>((size_t)MAXB * g);
     CM_HIP(hipHostMalloc((void**)&h_stb, MAXB * sizeof(StepState)));
@@ -841,7 +843,8 @@ void Model::ensure_batch_buffers() {
 void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out,
                          const std::function<void(size_t, int)>* after_group) {
     if (rccl) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
-    if (quantized) throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights is not implemented");
+    if (quantized && !quant_act_int)
+        throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights needs the integer-dot activation mode (CM_QUANT_ACT unset)");
     ensure_batch_buffers();
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
@@ -867,7 +870,8 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         }
         CM_HIP(hipMemcpyAsync(stb, h_stb, (size_t)nb * sizeof(StepState), hipMemcpyHostToDevice, s));
         CM_HIP(hipMemcpyAsync(d_btb, h_btb, (size_t)nb * max_pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        launch_embed_row(embed, stb, xb, H, cfg.V, nb, s);
+        if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_row_q(q_embed, stb, xb, H, cfg.V, s, nb);
+        else launch_embed_row(embed, stb, xb, H, cfg.V, nb, s);
         static const bool use_mfma_gemv = getenv("CM_GEMVM") == nullptr || atoi(getenv("CM_GEMVM")) != 0;
         auto gb = [&](int pro, int epi, const uint16_t* W, const float* xin, int ldx, const float* nw, float* y, int ldy, int N, int K) {
             GemvBArgs g{};
@@ -880,9 +884,31 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             }
             launch_gemvb(pro, epi, g, gemvb_grid(N, K, num_cu), s);
         };
+        // quantised weights: one pass over the codes for all nb sequences (gemvqb: activations quantised per sequence,
+        // integer dots -- row for row the arithmetic of the single-sequence step)
+        auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy) {
+            const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
+            if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
+            for (int m0 = 0; m0 < nb; m0 += cap) {
+                GemvQBArgs q{};
+                q.w = qw; q.x = xin + (size_t)m0 * ldx; q.nw = nw; q.y = y + (size_t)m0 * ldy; q.res = q.y;
+                q.n_seq = std::min(cap, nb - m0); q.ldx = ldx; q.ldy = ldy; q.eps = cfg.eps;
+                const int grid = gemvqb_grid(qw.fmt, qw.N, qw.K, q.n_seq, num_cu);
+                if (!launch_gemvqb(pro, epi, q, grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
+            }
+        };
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
             if (!w.full) {
+                if (quantized) {
+                    const int qz = cfg.conv_dim() + cfg.value_dim();
+                    qb(PRO_RMSNORM, EPI_STORE, w.q_in_proj, xb, H, w.ln1, qkvb, ldq);
+                    if (w.q_in_proj_z.fmt != QFMT_NONE) qb(PRO_RMSNORM, EPI_STORE, w.q_in_proj_z, xb, H, w.ln1, qkvb + w.q_in_proj.N, ldq);
+                    GemvBArgs g{};                                   // the a / b gate rows stay bf16
+                    g.W = w.in_proj_ba; g.x = xb; g.nw = w.ln1; g.y = qkvb + qz; g.res = g.y; g.N = 2 * cfg.NV; g.K = H; g.ldw = H;
+                    g.ldx = H; g.ldy = ldq; g.n_seq = nb; g.eps = cfg.eps;
+                    launch_gemvb(PRO_RMSNORM, EPI_STORE, g, gemvb_grid(g.N, g.K, num_cu), s);
+                } else
                 gb(PRO_RMSNORM, EPI_STORE, w.in_proj, xb, H, w.ln1, qkvb, ldq, in_proj_rows, H);
                 GdnArgs ga{};
                 ga.proj = qkvb; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
@@ -891,9 +917,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
                 launch_gdn(ga, s);
-                gb(PRO_PLAIN, EPI_RESADD, w.out_proj, attnb, (int)at_cols, nullptr, xb, H, H, cfg.value_dim());
+                if (quantized) qb(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attnb, (int)at_cols, nullptr, xb, H);
+                else gb(PRO_PLAIN, EPI_RESADD, w.out_proj, attnb, (int)at_cols, nullptr, xb, H, H, cfg.value_dim());
             } else {
-                gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
+                if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
+                else gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
                 AttnDecArgs a{};
                 a.qkv = qkvb; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = stb; a.block_table = d_btb;
                 a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_ob; a.part_ml = part_mlb;
@@ -901,7 +929,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 a.gate = cfg.hybrid ? qkvb + (size_t)Hq_l * D : nullptr;
                 a.qkv_stride = ldq; a.bt_stride = max_pages_per_seq; a.rot_dim = cfg.rot_dim;
                 a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-                if (heads_b) {
+                if (heads_b && !quantized) {
                     if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
                     GemvBArgs g{};
                     g.W = w.o; g.x = part_ob; g.y = xb; g.res = xb; g.N = H; g.K = Hq_l * D; g.ldw = g.K; g.ldx = Hq_l * attn_ns * D; g.ldy = H;
@@ -915,12 +943,37 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
+                if (quantized) qb(PRO_PLAIN, EPI_RESADD, w.q_o, attnb, (int)at_cols, nullptr, xb, H);
+                else gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
                 }
+            }
+            if (quantized) {
+                if (!w.split_gate_up) {
+                    qb(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, xb, H, w.ln2, hbb, I_l);
+                } else {
+                    qb(PRO_RMSNORM, EPI_STORE, w.q_gate, xb, H, w.ln2, gu_tmpb, 2 * cfg.I);
+                    qb(PRO_RMSNORM, EPI_STORE, w.q_up, xb, H, w.ln2, gu_tmpb + cfg.I, 2 * cfg.I);
+                    launch_silu_mul(gu_tmpb, gu_tmpb + cfg.I, hbb, cfg.I, s, nb, 2 * cfg.I, I_l);
+                }
+                qb(PRO_PLAIN, EPI_RESADD, w.q_down, hbb, I_l, nullptr, xb, H);
+                continue;
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
             gb(PRO_PLAIN, EPI_RESADD, w.down, hbb, I_l, nullptr, xb, H, H, I_l);
         }
+        if (quantized && q_lm_head.fmt != QFMT_NONE) {
+            const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
+            if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
+            const int lmq = gemvqb_grid(q_lm_head.fmt, cfg.V, H, std::min(cap, nb), num_cu);
+            for (int m0 = 0; m0 < nb; m0 += cap) {
+                GemvQBArgs q{};
+                q.w = q_lm_head; q.x = xb + (size_t)m0 * H; q.nw = norm; q.y = logitsb + (size_t)m0 * cfg.V; q.res = q.y;
+                q.pmax = pmaxb + (size_t)m0 * lmq; q.pidx = pidxb + (size_t)m0 * lmq;
+                q.n_seq = std::min(cap, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
+                if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmq, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
+            }
+            launch_argmax_final(pmaxb, pidxb, lmq, stb, ring, RING - 1, 0, nb, s);
+        } else {
         GemvBArgs g{};
         g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb; g.N = cfg.V; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
         g.eps = cfg.eps; g.pmax = pmaxb; g.pidx = pidxb;
@@ -929,6 +982,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
         else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
         launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s);
+        }
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
         if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));
         CM_HIP(hipStreamSynchronize(s));

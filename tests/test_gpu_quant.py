@@ -179,14 +179,18 @@ def test_quant_errors():
         del os.environ["CRANE_ISQ"]
     with pytest.raises(CraneError):
         Model.from_pretrained("/nonexistent/model.gguf")
-    m = Model.synthetic(cfg, seed=0, isq="q8_0", max_seqs=4)
+    os.environ["CM_QUANT_ACT"] = "f32"          # the batched step exists for the integer-dot activation mode only
     try:
-        s = m.seq_alloc()
-        m.seq_forward(s, [1, 2, 3], 0, want_logits=False)
-        with pytest.raises(CraneError, match="quantised"):
-            m.step_batch_decode([0, s], [1, 2])
+        m = Model.synthetic(cfg, seed=0, isq="q8_0", max_seqs=4)
+        try:
+            s = m.seq_alloc()
+            m.seq_forward(s, [1, 2, 3], 0, want_logits=False)
+            with pytest.raises(CraneError, match="quantised"):
+                m.step_batch_decode([0, s], [1, 2])
+        finally:
+            m.close()
     finally:
-        m.close()
+        del os.environ["CM_QUANT_ACT"]
 
 
 def test_isq_q8_0_hybrid_family(monkeypatch):
@@ -283,3 +287,77 @@ def test_qwen35_gguf_checkpoint(tmp_path, monkeypatch, kind):
         assert rel(got, ref) < 2e-2, rel(got, ref)
     finally:
         m.close()
+
+
+def _batched_vs_sequential(m, V, nb, rounds=3):
+    """Every sequence of a batched step must get, bit for bit, the logits the single-sequence step gives it."""
+    seqs, toks = [], []
+    for b in range(nb):
+        s = 0 if b == 0 else m.seq_alloc()
+        ids = [(7 * i + 3 + 11 * b) % V for i in range(5 + 3 * b)]
+        _, g = m.seq_forward(s, ids, 0, want_logits=False)
+        seqs.append(s); toks.append(int(g))
+    for r in range(rounds):
+        want = []
+        for s, t in zip(seqs, toks):
+            f = m.seq_fork(s)
+            lg, g = m.seq_forward(f, [t], m.seq_len(f))
+            want.append((lg.reshape(-1).copy(), int(g)))
+            m.seq_free(f)
+        lg, greedy = m.step_batch_decode(seqs, toks)
+        for b in range(nb):
+            assert np.array_equal(lg[b, 0], want[b][0]), (r, b, rel(lg[b, 0], want[b][0]))
+            assert int(greedy[b]) == want[b][1]
+        toks = [int(g) for g in greedy]
+
+
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed"])
+@pytest.mark.parametrize("nb", [2, 5, 8])
+def test_batched_decode_over_gguf_weights(tmp_path, monkeypatch, kind, nb):
+    """cm_decode_batch on quantised weights (gemvqb): one pass over the codes for all sequences, each row quantised and
+    dotted exactly as the single-sequence integer-dot GEMV does it."""
+    from crane_amd.backend import Model
+    name = "tiny-qwen3-untied" if kind != "q8_0" else "tiny-qwen3"
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / f"{name}-{kind}.gguf")
+    G.write_qwen3_gguf(path, cfg, w, _types(kind))
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", max_seqs=10)
+    try:
+        _batched_vs_sequential(m, cfg["vocab_size"], nb)
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("nb", [3, 8])
+def test_batched_decode_isq_hybrid(monkeypatch, nb):
+    from crane_amd.backend import Model
+    cfg = configs.get_config("tiny-qwen3.5")
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", max_seqs=10)
+    try:
+        _batched_vs_sequential(m, cfg["vocab_size"], nb, rounds=2)
+    finally:
+        m.close()
+
+
+def test_engine_batches_quantised_model():
+    """The continuous-batching engine over an ISQ model: max_running 4 must emit the tokens max_running 1 emits."""
+    from crane_amd.backend import Model
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    cfg = configs.get_config("tiny-qwen3")
+    outs = []
+    for mr in (1, 4):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=128, isq="q8_0", max_seqs=8)
+        try:
+            eng = InferenceEngine(m, max_running=mr)
+            V = cfg["vocab_size"]
+            ids = [eng.submit([(7 * k + 3 + 13 * i) % V for k in range(6 + i)], GenerationParams.greedy(8) if i % 2 else GenerationParams(max_tokens=8, temperature=0.0))
+                   for i in range(5)]
+            toks, _ = eng.run_until_idle()
+            outs.append([toks[i] for i in ids])
+            eng.close()
+        finally:
+            m.close()
+    assert outs[0] == outs[1]

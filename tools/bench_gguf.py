@@ -28,12 +28,27 @@ path = f"/tmp/bench_{kind}.gguf"
 G.write_gguf(path, G.qwen3_metadata(cfg), tensors)
 del tensors
 print(f"wrote {path} ({os.path.getsize(path) / 1e6:.0f} MB) in {time.time() - t0:.1f}s", flush=True)
-m = Model.from_pretrained(path, max_seq_len=2048)
+m = Model.from_pretrained(path, max_seq_len=2048, max_seqs=9)
 for which in ["qkv", "o", "gate_up", "down"]:
     r = m.bench_kernel(which, 360)
     print(f"{kind} {which:8s} {r['ms'] * 1e3:8.2f} us  {r['bytes'] / r['ms'] / 1e9:6.2f} TB/s  ({r['bytes'] / 1e6:.1f} MB)")
 m.debug_fill_kv(1024, seed=1)
 toks, ms = m.bench_decode(3, 64)
 print(f"{kind} {L}-layer decode step {ms / 64 * 1e3:.1f} us")
+# batched decode (gemvqb): 8 sequences per pass over the codes
+ids = [(7 * i + 3) % cfg["vocab_size"] for i in range(1024)]
+for nseq in (2, 4, 8):
+    seqs = []
+    for i in range(nseq):
+        s = m.seq_alloc(); m.seq_forward(s, ids, 0, want_logits=False); seqs.append(s)
+    toks = [5 + i for i in range(nseq)]
+    for _ in range(3):
+        _, g = m.step_batch_decode(seqs, toks, want_logits=False); toks = [int(t) for t in g]
+    t0 = time.perf_counter(); K = 32
+    for _ in range(K):
+        _, g = m.step_batch_decode(seqs, toks, want_logits=False); toks = [int(t) for t in g]
+    dt = time.perf_counter() - t0
+    print(f"{kind} {L}-layer batch {nseq}: {dt / K * 1e6:8.1f} us/step", flush=True)
+    for s in seqs: m.seq_free(s)
 m.close()
 os.remove(path)
