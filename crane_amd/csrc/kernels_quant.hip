@@ -592,8 +592,12 @@ bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s)
 template <int FMT, int PRO, int EPI, int MB>
 __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
     using F = QF<FMT>;
-    constexpr int R = 2, CK = F::CK, NW = 8;
     constexpr bool KQ = FMT != QFMT_Q8_0;
+    // rows per wave: 4 for Q8_0 up to 4 sequences (halves the LDS reads per weight), 2 otherwise (measured: Q8_0 at 8
+    // sequences 5.95 ms/step with 2 rows vs 6.67 with 4; the K-quants sit at the 256-VGPR budget with 2).  U chunks per
+    // load batch stays 1: two chunks in flight spill (R = 4) or gain nothing (the kernel is issue-bound, not
+    // bytes-in-flight-bound).
+    constexpr int R = (!KQ && MB <= 4) ? 4 : 2, U = 1, CK = F::CK, NW = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.w.K, N = a.w.N, ns = a.n_seq;
@@ -607,99 +611,160 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
     const int G = (N + R - 1) / R;
     const int gstride = gridDim.x * NW;
     const int gfirst = blockIdx.x * NW + wave;
-    QRow q[R], qn[R];
-    auto load_rows = [&](QRow (&dst)[R], int g, int c) {
-        if (c * CK + lane_k < K) {
-            const int r0 = g * R;
+    QRow q[R][U], qn[R][U];
+    auto load_rows = [&](QRow (&dst)[R][U], int g, int c0) {
+        const int r0 = g * R;
 #pragma unroll
-            for (int i = 0; i < R; ++i) dst[i] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c, lane);
-        }
+        for (int u = 0; u < U; ++u)
+            if (c0 + u < nch && (c0 + u) * CK + lane_k < K) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) dst[i][u] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c0 + u, lane);
+            }
     };
 #pragma unroll
-    for (int i = 0; i < R; ++i) { q[i].a = (u32x4){0, 0, 0, 0}; q[i].b = (u32x4){0, 0, 0, 0}; q[i].d = 0.f; qn[i] = q[i]; }
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u) { q[i][u].a = (u32x4){0, 0, 0, 0}; q[i][u].b = (u32x4){0, 0, 0, 0}; q[i][u].d = 0.f; qn[i][u] = q[i][u]; }
     if (gfirst < G) load_rows(q, gfirst, 0);       // weight bytes are requested before the activation rows are quantised
 
     // ---- quantise the activation rows: half `grp` of the block takes sequences grp, grp + 2, ... ----
+    // Loads are issued SG sequences x 4 strides at a time: one L2 round trip per 1024 elements of K for all of a
+    // half-block's sequences (a load-per-iteration loop costs a round trip each: ~16 us per launch at 8 x 4096).
+    constexpr int SG = MB / 2;
     const int grp = tid >> 8, t2 = tid & 255, w2 = wave & 3;
     const int n4 = K >> 2;
+    auto xrow = [&](int mi) { return a.x + (size_t)min(grp + 2 * mi, ns - 1) * a.ldx; };   // clamped: loads stay in-bounds
     if (PRO == PRO_RMSNORM) {
-        for (int m = grp; m < ns; m += 2) {
-            const float* xr = a.x + (size_t)m * a.ldx;
-            float ss = 0.f;
-            for (int k4 = t2; k4 < n4; k4 += 256) {
-                const f32x4 v = *(const f32x4*)(xr + (k4 << 2));
-                ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss))));
-            }
-            ss = wave_sum(ss);
-            if (lane == 0) red[m * 4 + w2] = ss;
+        float ss[SG];
+#pragma unroll
+        for (int mi = 0; mi < SG; ++mi) ss[mi] = 0.f;
+        for (int kb = t2; kb < n4; kb += 1024) {
+            f32x4 v[SG][4];
+#pragma unroll
+            for (int mi = 0; mi < SG; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[mi][j] = (kb + 256 * j < n4) ? *(const f32x4*)(xrow(mi) + ((kb + 256 * j) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < SG; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (kb + 256 * j < n4)
+                        ss[mi] = fmaf(v[mi][j][3], v[mi][j][3], fmaf(v[mi][j][2], v[mi][j][2], fmaf(v[mi][j][1], v[mi][j][1], fmaf(v[mi][j][0], v[mi][j][0], ss[mi]))));
+        }
+#pragma unroll
+        for (int mi = 0; mi < SG; ++mi) {
+            const float t = wave_sum(ss[mi]);
+            if (lane == 0 && grp + 2 * mi < ns) red[(grp + 2 * mi) * 4 + w2] = t;
         }
         __syncthreads();
     }
-    for (int m = grp; m < ns; m += 2) {
-        const float* xr = a.x + (size_t)m * a.ldx;
-        signed char* xq = (signed char*)(lds_raw + (size_t)m * seq_bytes);
-        float* xd = (float*)(xq + Kpad);
-        int* xs8 = (int*)(xd + nscale);
-        float rr = 1.f;
+    float rr[SG];
+#pragma unroll
+    for (int mi = 0; mi < SG; ++mi) {
+        rr[mi] = 1.f;
+        const int m = min(grp + 2 * mi, ns - 1);
         if (PRO == PRO_RMSNORM)
-            rr = 1.0f / sqrtf(((red[m * 4] + red[m * 4 + 1]) + (red[m * 4 + 2] + red[m * 4 + 3])) / (float)K + a.eps);
-        auto xval = [&](int k4) -> f32x4 {
-            f32x4 v = *(const f32x4*)(xr + (k4 << 2));
-            if (PRO == PRO_RMSNORM) {
-                const f32x4 w = *(const f32x4*)(a.nw + (k4 << 2));
-                v[0] = __fmul_rn(__fmul_rn(v[0], rr), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], rr), w[1]);
-                v[2] = __fmul_rn(__fmul_rn(v[2], rr), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], rr), w[3]);
+            rr[mi] = 1.0f / sqrtf(((red[m * 4] + red[m * 4 + 1]) + (red[m * 4 + 2] + red[m * 4 + 3])) / (float)K + a.eps);
+    }
+    auto normed = [&](f32x4 v, const f32x4& w, float r) -> f32x4 {
+        if (PRO == PRO_RMSNORM) {
+            v[0] = __fmul_rn(__fmul_rn(v[0], r), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], r), w[1]);
+            v[2] = __fmul_rn(__fmul_rn(v[2], r), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], r), w[3]);
+        }
+        return v;
+    };
+    if (!KQ) {
+        for (int kb = t2; kb < n4; kb += 1024) {                   // quantize_row_q8_0: 32 elements = 8 consecutive lanes
+            f32x4 v[SG][4], nwv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool live = kb + 256 * j < n4;
+                nwv[j] = (PRO == PRO_RMSNORM && live) ? *(const f32x4*)(a.nw + ((kb + 256 * j) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < SG; ++mi)
+                    v[mi][j] = live ? *(const f32x4*)(xrow(mi) + ((kb + 256 * j) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            return v;
-        };
-        if (!KQ) {
-            for (int k4 = t2; k4 < n4; k4 += 256) {                // quantize_row_q8_0: 32 elements = 8 consecutive lanes
-                const f32x4 v = xval(k4);
-                float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
-                const float d = am / 127.0f;
-                const float id = d != 0.f ? 1.0f / d : 0.f;
-                uint32_t pk = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(v[e] * id) & 0xFFu) << (8 * e);
-                ((uint32_t*)xq)[k4] = pk;
-                if ((t2 & 7) == 0) xd[k4 >> 3] = f16_round(d);
+            for (int mi = 0; mi < SG; ++mi) {
+                const int m = grp + 2 * mi;
+                if (m >= ns) break;
+                signed char* xq = (signed char*)(lds_raw + (size_t)m * seq_bytes);
+                float* xd = (float*)(xq + Kpad);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k4 = kb + 256 * j;
+                    if (k4 >= n4) break;
+                    const f32x4 x = normed(v[mi][j], nwv[j], rr[mi]);
+                    float am = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+                    am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+                    const float d = am / 127.0f;
+                    const float id = d != 0.f ? 1.0f / d : 0.f;
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(x[e] * id) & 0xFFu) << (8 * e);
+                    ((uint32_t*)xq)[k4] = pk;
+                    if ((t2 & 7) == 0) xd[k4 >> 3] = f16_round(d);
+                }
             }
-        } else {
-            const int nblk = K >> 8;                               // quantize_row_q8_K: one wave per 256-element block
-            for (int blk = w2; blk < nblk; blk += 4) {
-                const int k4 = blk * 64 + lane;
-                const f32x4 v = xval(k4);
-                unsigned long long key = 0;
+        }
+    } else {
+        const int nblk = K >> 8;                                   // quantize_row_q8_K: one wave per 256-element block
+        for (int b0 = w2; b0 < nblk; b0 += 16) {
+            f32x4 v[SG][4], nwv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned long long ke = ((unsigned long long)__float_as_uint(fabsf(v[e])) << 32) | (unsigned)(255 - (lane * 4 + e));
-                    key = ke > key ? ke : key;
+            for (int j = 0; j < 4; ++j) {
+                const bool live = b0 + 4 * j < nblk;
+                const int k4 = (b0 + 4 * j) * 64 + lane;
+                nwv[j] = (PRO == PRO_RMSNORM && live) ? *(const f32x4*)(a.nw + (k4 << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < SG; ++mi)
+                    v[mi][j] = live ? *(const f32x4*)(xrow(mi) + (k4 << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int mi = 0; mi < SG; ++mi) {
+                const int m = grp + 2 * mi;
+                if (m >= ns) break;
+                signed char* xq = (signed char*)(lds_raw + (size_t)m * seq_bytes);
+                float* xd = (float*)(xq + Kpad);
+                int* xs8 = (int*)(xd + nscale);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int blk = b0 + 4 * j;
+                    if (blk >= nblk) break;
+                    const int k4 = blk * 64 + lane;
+                    const f32x4 x = normed(v[mi][j], nwv[j], rr[mi]);
+                    unsigned long long key = 0;                    // signed value of the FIRST element with the largest |x|
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned long long ke = ((unsigned long long)__float_as_uint(fabsf(x[e])) << 32) | (unsigned)(255 - (lane * 4 + e));
+                        key = ke > key ? ke : key;
+                    }
+                    unsigned long long bestk = key;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)bestk, o), hi = (unsigned)__shfl_xor((int)(unsigned)(bestk >> 32), o);
+                        const unsigned long long ot = ((unsigned long long)hi << 32) | lo;
+                        bestk = ot > bestk ? ot : bestk;
+                    }
+                    const int widx = 255 - (int)(unsigned)(bestk & 0xFFFFFFFFull);
+                    float cand = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (lane * 4 + e == widx) cand = x[e];
+                    const float mx = wave_sum(cand);
+                    const float iscale = mx != 0.f ? -128.0f / mx : 0.f;
+                    int qq[4]; int s4 = 0; uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        qq[e] = mx != 0.f ? min(127, __float2int_rn(x[e] * iscale)) : 0;
+                        s4 += qq[e];
+                        pk |= ((uint32_t)qq[e] & 0xFFu) << (8 * e);
+                    }
+                    ((uint32_t*)xq)[k4] = pk;
+                    const int s8 = s4 + __shfl_xor(s4, 1);
+                    if (!(lane & 1)) xs8[k4 >> 1] = s8;
+                    if (lane == 0) xd[blk] = mx != 0.f ? 1.0f / iscale : 0.f;
                 }
-                unsigned long long bestk = key;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)bestk, o), hi = (unsigned)__shfl_xor((int)(unsigned)(bestk >> 32), o);
-                    const unsigned long long ot = ((unsigned long long)hi << 32) | lo;
-                    bestk = ot > bestk ? ot : bestk;
-                }
-                const int widx = 255 - (int)(unsigned)(bestk & 0xFFFFFFFFull);
-                float cand = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (lane * 4 + e == widx) cand = v[e];
-                const float mx = wave_sum(cand);
-                const float iscale = mx != 0.f ? -128.0f / mx : 0.f;
-                int qq[4]; int s4 = 0; uint32_t pk = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    qq[e] = mx != 0.f ? min(127, __float2int_rn(v[e] * iscale)) : 0;
-                    s4 += qq[e];
-                    pk |= ((uint32_t)qq[e] & 0xFFu) << (8 * e);
-                }
-                ((uint32_t*)xq)[k4] = pk;
-                const int s8 = s4 + __shfl_xor(s4, 1);
-                if (!(lane & 1)) xs8[k4 >> 1] = s8;
-                if (lane == 0) xd[blk] = mx != 0.f ? 1.0f / iscale : 0.f;
             }
         }
     }
@@ -715,11 +780,14 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int m = 0; m < MB; ++m) acc[i][m] = 0.f;
-        for (int c = 0; c < nch; ++c) {
-            // the next (row group, chunk) is in flight while this one is dotted with every sequence
-            if (c + 1 < nch) load_rows(qn, g, c + 1);
+        for (int c0 = 0; c0 < nch; c0 += U) {
+            // the next batch of (row group, chunks) is in flight while this one is dotted with every sequence
+            if (c0 + U < nch) load_rows(qn, g, c0 + U);
             else if (g + gstride < G) load_rows(qn, g + gstride, 0);
-            if (c * CK + lane_k < K) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+            const int c = c0 + u;
+            if (c < nch && c * CK + lane_k < K) {
                 if constexpr (FMT == QFMT_Q8_0) {
                     const int e0 = c * 1024 + lane * 16;
 #pragma unroll
@@ -732,8 +800,8 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                         for (int i = 0; i < R; ++i) {
                             int isum = 0;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i].a[j], (int)xv[j], isum, false);
-                            acc[i][m] = fmaf(q[i].d * dx, (float)isum, acc[i][m]);
+                            for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i][u].a[j], (int)xv[j], isum, false);
+                            acc[i][m] = fmaf(q[i][u].d * dx, (float)isum, acc[i][m]);
                         }
                     }
                 } else if constexpr (FMT == QFMT_Q4_K) {
@@ -742,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                     float d[R], dmin[R]; int sc0[R], m0[R], sc1[R], m1[R]; u32x4 wl[R], wh[R];
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        const u32x4 hb = q[i].b;
+                        const u32x4 hb = q[i][u].b;
                         d[i] = f16_bits_to_f32(hb[0] & 0xFFFFu); dmin[i] = f16_bits_to_f32(hb[0] >> 16);
                         auto sbyte = [&](int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
                         auto scale_min = [&](int j, int& sc, int& mn) {
@@ -752,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                         scale_min(2 * p, sc0[i], m0[i]);
                         scale_min(2 * p + 1, sc1[i], m1[i]);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { wl[i][j] = q[i].a[j] & 0x0F0F0F0Fu; wh[i][j] = (q[i].a[j] >> 4) & 0x0F0F0F0Fu; }
+                        for (int j = 0; j < 4; ++j) { wl[i][j] = q[i][u].a[j] & 0x0F0F0F0Fu; wh[i][j] = (q[i][u].a[j] >> 4) & 0x0F0F0F0Fu; }
                     }
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
@@ -780,16 +848,16 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                     float d[R]; uint32_t code[R][4][2]; int sc[R][4];
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        d[i] = f16_bits_to_f32(q[i].b[3]);
+                        d[i] = f16_bits_to_f32(q[i][u].b[3]);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int qsel = (t & 1) * 2, hshift = 2 * t;
 #pragma unroll
                             for (int wi = 0; wi < 2; ++wi) {
-                                const uint32_t qlw = q[i].a[qsel + wi], qhw = q[i].b[wi];
+                                const uint32_t qlw = q[i][u].a[qsel + wi], qhw = q[i][u].b[wi];
                                 code[i][t][wi] = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
                             }
-                            sc[i][t] = (int)(signed char)((q[i].b[2] >> (8 * t)) & 0xFFu);
+                            sc[i][t] = (int)(signed char)((q[i][u].b[2] >> (8 * t)) & 0xFFu);
                         }
                     }
 #pragma unroll
@@ -817,10 +885,14 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                     }
                 }
             }
+            if (U > 1) __builtin_amdgcn_sched_barrier(0);          // keep one chunk's activation codes live at a time (VGPR budget)
+            }
 #pragma unroll
-            for (int i = 0; i < R; ++i) q[i] = qn[i];
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int u = 0; u < U; ++u) q[i][u] = qn[i][u];
         }
-        // lane m*R + i ends up holding (row r0 + i, sequence m)
+        // lane m*R + i ends up holding (row r0 + i, sequence m); SiLU*mul: lane m*(R/2) + p holds the (gate, up) pair p
         float mine = 0.f, gate_v = 0.f, up_v = 0.f;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -830,7 +902,11 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                 acc[i][m] = wave_sum(acc[i][m]);
                 if (lane == m * R + i) mine = acc[i][m];
             }
-            if (EPI == EPI_SILUMUL && lane == m) { gate_v = acc[0][m]; up_v = acc[1][m]; }
+            if (EPI == EPI_SILUMUL) {
+#pragma unroll
+                for (int pp = 0; pp < R / 2; ++pp)
+                    if (lane == m * (R / 2) + pp) { gate_v = acc[2 * pp][m]; up_v = acc[2 * pp + 1][m]; }
+            }
             if (EPI == EPI_ARGMAX) {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
@@ -845,7 +921,8 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
         } else if (EPI == EPI_RESADD) {
             if (mi < ns && r0 + ri < N) a.y[(size_t)mi * a.ldy + r0 + ri] = a.res[(size_t)mi * a.ldy + r0 + ri] + mine;
         } else if (EPI == EPI_SILUMUL) {
-            if (lane < ns && r0 + 1 < N) a.y[(size_t)lane * a.ldy + (r0 >> 1)] = (gate_v / (1.0f + expf(-gate_v))) * up_v;
+            const int ms = lane / (R / 2), ps = lane % (R / 2);
+            if (ms < ns && r0 + 2 * ps + 1 < N) a.y[(size_t)ms * a.ldy + (r0 >> 1) + ps] = (gate_v / (1.0f + expf(-gate_v))) * up_v;
         }
     }
     if (EPI == EPI_ARGMAX) {
@@ -878,9 +955,10 @@ int gemvqb_max_seqs(int fmt, int K) {
     return fit >= 8 ? 8 : fit >= 4 ? 4 : 0;
 }
 int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu) {
-    (void)fmt; (void)K; (void)n_seq;
+    (void)K;
     // every block re-quantises the activation rows and the K-quant kernels hold > 128 VGPRs: one fat block per CU
-    const int groups = (N + 1) / 2;
+    const int rows = (fmt == QFMT_Q8_0 && n_seq <= 4) ? 4 : 2;
+    const int groups = (N + rows - 1) / rows;
     return std::max(1, std::min((groups + 7) / 8, num_cu));
 }
 
