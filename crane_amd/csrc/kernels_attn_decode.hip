@@ -281,23 +281,35 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     }
 }
 
-// grid = Hq, block = 256: out[h, d] = sum_s e^{m_s-M} o_s[d] / sum_s e^{m_s-M} l_s  (* sigmoid(gate))
+// grid = Hq, block = 1024: out[h, d] = sum_s e^{m_s-M} o_s[d] / sum_s e^{m_s-M} l_s  (* sigmoid(gate)).
+// The kernel is pure latency (a few KB per head): 1024 / D thread groups split the `s` range so that every partial a
+// thread needs is requested in ONE batch, before the (m, l) weights it will be scaled by have even arrived.
 template <int D>
-__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ part_o,
-                                                                  const float* __restrict__ part_ml,
-                                                                  const float* __restrict__ gate,
-                                                                  float* __restrict__ out, int nsplit, int gate_stride,
-                                                                  int out_stride) {
-    constexpr int NH = 256 / D;                  // thread groups that split the `s` range
+__global__ __launch_bounds__(1024) void attn_decode_combine_kernel(const float* __restrict__ part_o,
+                                                                   const float* __restrict__ part_ml,
+                                                                   const float* __restrict__ gate,
+                                                                   float* __restrict__ out, int nsplit, int gate_stride,
+                                                                   int out_stride) {
+    constexpr int NH = 1024 / D;                 // thread groups that split the `s` range
+    constexpr int PER = 64 / NH;                 // nsplit <= 64
     __shared__ float w_s[64];
     __shared__ float inv_l;
-    __shared__ float half_o[D];
+    __shared__ float grp_o[NH][D];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int bq = blockIdx.y, nh = gridDim.x;
     part_o += (size_t)bq * nh * nsplit * D;
     part_ml += (size_t)bq * nh * nsplit * 2;
     out += (size_t)bq * out_stride;
     if (gate != nullptr) gate += (size_t)bq * gate_stride;
+    const int d = tid % D, grp = tid / D;
+    const int per = (nsplit + NH - 1) / NH;
+    const int s0 = grp * per, s1 = min(nsplit, s0 + per);
+    const float* po = part_o + (size_t)h * nsplit * D + d;
+    float pv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) pv[j] = (s0 + j < s1) ? po[(size_t)(s0 + j) * D] : 0.f;
+    float gv = 0.f;
+    if (gate != nullptr && grp == 0) gv = gate[(size_t)h * D + d];
     if (tid < 64) {
         float mm = -INFINITY, ll = 0.f;
         if (lane < nsplit) {
@@ -311,21 +323,17 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
         if (lane == 0) inv_l = 1.0f / Ls;
     }
     __syncthreads();
-    const int d = tid % D, grp = tid / D;
-    const int per = (nsplit + NH - 1) / NH;
-    const int s0 = grp * per, s1 = min(nsplit, s0 + per);
     float O = 0.f;
-    const float* po = part_o + (size_t)h * nsplit * D + d;
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) O += w_s[s] * po[(size_t)s * D];
-    if (NH == 2) {
-        if (grp) half_o[d] = O;
-        __syncthreads();
-        if (grp) return;
-        O += half_o[d];
-    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (s0 + j < s1) O += w_s[s0 + j] * pv[j];
+    grp_o[grp][d] = O;
+    __syncthreads();
+    if (grp) return;
+#pragma unroll
+    for (int g = 1; g < NH; ++g) O += grp_o[g][d];
     float v = O * inv_l;
-    if (gate != nullptr) v *= 1.0f / (1.0f + expf(-gate[(size_t)h * D + d]));
+    if (gate != nullptr) v *= 1.0f / (1.0f + expf(-gv));
     out[(size_t)h * D + d] = v;
 }
 
@@ -601,6 +609,81 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
     const int rot = a.rot_dim, hrot = rot >> 1;
     __syncthreads();
 
+    // this wave's tiles: CACHED tokens [TB * (split + nsplit * j) + 16 * wave, +16), j = 0, 1, ... (t < pos: written by
+    // earlier steps, visible); the token appended by this very step is one extra pseudo-tile of the owner block
+    const int psh = __builtin_ctz(a.page);                      // page size is a power of two (launcher checks)
+    auto row_off = [&](int t) -> size_t {
+        const int page = block_table[t >> psh];
+        if (KVQ) return (size_t)page * a.page_bytes + (size_t)(kvh * a.page + (t & (a.page - 1))) * ROWB;     // bytes
+        return ((size_t)(page * a.Hkv + kvh) * a.page + (t & (a.page - 1))) * D;
+    };
+    auto scale_off = [&](int t) -> size_t {                      // byte offset of token t's f32 scale
+        return (size_t)block_table[t >> psh] * a.page_bytes + (size_t)a.Hkv * a.page * ROWB + (size_t)(kvh * a.page + (t & (a.page - 1))) * 4;
+    };
+    // 8 codes -> 8 bf16 integers (code - offset)
+    auto codes8 = [&](uint32_t lo, uint32_t hi) -> u32x4 {       // int8: lo / hi = bytes 0..3 / 4..7; int4: lo = 8 nibbles
+        float f[8];
+        if (KVT == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = (float)((lo >> (8 * e)) & 0xFFu) - OFFS; f[4 + e] = (float)((hi >> (8 * e)) & 0xFFu) - OFFS; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)((lo >> (4 * e)) & 0xFu) - OFFS;
+        }
+        return (u32x4){pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+    };
+    f32x4 ksA, ksB, vsA, vsB;                                    // per-token scales of the tile rows g*4 .. g*4+3
+    auto load_tile = [&](bf16x8 (&kf)[NKS], u32x4 (&vf)[VCH], f32x4& kscl, f32x4& vscl, int tb) {
+        const size_t ko = row_off(min(tb + sub, pos - 1));               // clamped rows are masked later
+        if (KVQ) {
+            const uint8_t* kb = (const uint8_t*)a.kpool + ko;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int d0 = ks * 32 + g * 8;
+                u32x4 c;
+                if (KVT == 2) { const u32x2 w = *(const u32x2*)(kb + d0); c = codes8(w[0], w[1]); }
+                else c = codes8(*(const uint32_t*)(kb + (d0 >> 1)), 0);
+                kf[ks] = __builtin_bit_cast(bf16x8, c);
+            }
+#pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                const int cch = lane + 64 * i, tok = cch / (D / 8), d8 = (cch % (D / 8)) * 8;
+                const uint8_t* vb = (const uint8_t*)a.vpool + row_off(min(tb + tok, pos - 1));
+                if (KVT == 2) { const u32x2 w = *(const u32x2*)(vb + d8); vf[i] = codes8(w[0], w[1]); }
+                else vf[i] = codes8(*(const uint32_t*)(vb + (d8 >> 1)), 0);
+            }
+            // rows g*4 .. g*4+3 of a 16-aligned tile sit in one page: 4 contiguous scales (clamped tokens are masked)
+            const int t0 = min(tb + g * 4, pos - 1), t3 = min(tb + g * 4 + 3, pos - 1);
+            if (t3 - t0 == 3) {
+                kscl = *(const f32x4*)((const uint8_t*)a.kpool + scale_off(t0));
+                vscl = *(const f32x4*)((const uint8_t*)a.vpool + scale_off(t0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = min(tb + g * 4 + r, pos - 1);
+                    kscl[r] = *(const float*)((const uint8_t*)a.kpool + scale_off(t));
+                    vscl[r] = *(const float*)((const uint8_t*)a.vpool + scale_off(t));
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kpool + ko + g * 8 + ks * 32);
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
+            vf[i] = ld16(vpool + row_off(min(tb + tok, pos - 1)) + d8);
+        }
+    };
+    // the first tile's K / V rows are requested BEFORE the q prologue: at short contexts a wave has a single tile, and
+    // its HBM latency then overlaps the q loads, norms and rotations instead of following them
+    bf16x8 kA[NKS], kB[NKS];
+    u32x4 vA[VCH], vB[VCH];
+    const int tb_first = TB * split + 16 * wave;
+    if constexpr (D <= 128 && !KVQ) {
+        if (tb_first < pos) load_tile(kA, vA, ksA, vsA, tb_first);
+    }
+
     // ---- prologue: the group's q heads (norm, rope, 1/sqrt(D), bf16 hi + lo), new k / v (bf16; owner appends) ----
     for (int item = wave; item < NREP + 2; item += 4) {
         const float* src;
@@ -697,72 +780,6 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
     for (int nt = 0; nt < NNT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    // this wave's tiles: CACHED tokens [TB * (split + nsplit * j) + 16 * wave, +16), j = 0, 1, ... (t < pos: written by
-    // earlier steps, visible); the token appended by this very step is one extra pseudo-tile of the owner block
-    const int psh = __builtin_ctz(a.page);                      // page size is a power of two (launcher checks)
-    auto row_off = [&](int t) -> size_t {
-        const int page = block_table[t >> psh];
-        if (KVQ) return (size_t)page * a.page_bytes + (size_t)(kvh * a.page + (t & (a.page - 1))) * ROWB;     // bytes
-        return ((size_t)(page * a.Hkv + kvh) * a.page + (t & (a.page - 1))) * D;
-    };
-    auto scale_off = [&](int t) -> size_t {                      // byte offset of token t's f32 scale
-        return (size_t)block_table[t >> psh] * a.page_bytes + (size_t)a.Hkv * a.page * ROWB + (size_t)(kvh * a.page + (t & (a.page - 1))) * 4;
-    };
-    // 8 codes -> 8 bf16 integers (code - offset)
-    auto codes8 = [&](uint32_t lo, uint32_t hi) -> u32x4 {       // int8: lo / hi = bytes 0..3 / 4..7; int4: lo = 8 nibbles
-        float f[8];
-        if (KVT == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { f[e] = (float)((lo >> (8 * e)) & 0xFFu) - OFFS; f[4 + e] = (float)((hi >> (8 * e)) & 0xFFu) - OFFS; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = (float)((lo >> (4 * e)) & 0xFu) - OFFS;
-        }
-        return (u32x4){pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
-    };
-    f32x4 ksA, ksB, vsA, vsB;                                    // per-token scales of the tile rows g*4 .. g*4+3
-    auto load_tile = [&](bf16x8 (&kf)[NKS], u32x4 (&vf)[VCH], f32x4& kscl, f32x4& vscl, int tb) {
-        const size_t ko = row_off(min(tb + sub, pos - 1));               // clamped rows are masked later
-        if (KVQ) {
-            const uint8_t* kb = (const uint8_t*)a.kpool + ko;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const int d0 = ks * 32 + g * 8;
-                u32x4 c;
-                if (KVT == 2) { const u32x2 w = *(const u32x2*)(kb + d0); c = codes8(w[0], w[1]); }
-                else c = codes8(*(const uint32_t*)(kb + (d0 >> 1)), 0);
-                kf[ks] = __builtin_bit_cast(bf16x8, c);
-            }
-#pragma unroll
-            for (int i = 0; i < VCH; ++i) {
-                const int cch = lane + 64 * i, tok = cch / (D / 8), d8 = (cch % (D / 8)) * 8;
-                const uint8_t* vb = (const uint8_t*)a.vpool + row_off(min(tb + tok, pos - 1));
-                if (KVT == 2) { const u32x2 w = *(const u32x2*)(vb + d8); vf[i] = codes8(w[0], w[1]); }
-                else vf[i] = codes8(*(const uint32_t*)(vb + (d8 >> 1)), 0);
-            }
-            // rows g*4 .. g*4+3 of a 16-aligned tile sit in one page: 4 contiguous scales (clamped tokens are masked)
-            const int t0 = min(tb + g * 4, pos - 1), t3 = min(tb + g * 4 + 3, pos - 1);
-            if (t3 - t0 == 3) {
-                kscl = *(const f32x4*)((const uint8_t*)a.kpool + scale_off(t0));
-                vscl = *(const f32x4*)((const uint8_t*)a.vpool + scale_off(t0));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = min(tb + g * 4 + r, pos - 1);
-                    kscl[r] = *(const float*)((const uint8_t*)a.kpool + scale_off(t));
-                    vscl[r] = *(const float*)((const uint8_t*)a.vpool + scale_off(t));
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(kpool + ko + g * 8 + ks * 32);
-#pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int c = lane + 64 * i, tok = c / (D / 8), d8 = (c % (D / 8)) * 8;
-            vf[i] = ld16(vpool + row_off(min(tb + tok, pos - 1)) + d8);
-        }
-    };
     uint16_t* Vw = Vs[wave];
     auto step = [&](const bf16x8 (&kf)[NKS], const u32x4 (&vf)[VCH], const f32x4& kscl, const f32x4& vscl, int tb, int limit) {
         // stage this tile's V rows in the wave's LDS region
@@ -814,12 +831,10 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         __builtin_amdgcn_wave_barrier();                         // tile consumed before the next step overwrites it
     };
     {
-        bf16x8 kA[NKS], kB[NKS];
-        u32x4 vA[VCH], vB[VCH];
         const int stride = TB * nsplit;
-        int tb = TB * split + 16 * wave;
+        int tb = tb_first;
         if constexpr (D <= 128) {                                // two statically named register sets: next tile in flight
-            if (tb < pos) load_tile(kA, vA, ksA, vsA, tb);
+            if (KVQ && tb < pos) load_tile(kA, vA, ksA, vsA, tb);
             while (tb < pos) {
                 if (tb + stride < pos) load_tile(kB, vB, ksB, vsB, tb + stride);
                 step(kA, vA, ksA, vsA, tb, pos);
@@ -902,11 +917,11 @@ bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, 
     if (a.page <= 0 || (a.page & (a.page - 1)) != 0 || kv_mode == 1) return false;
     if (D == 128) {
         if (!launch_mfma<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
-        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else if (D == 256) {
         if (!launch_mfma<256>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
-        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else {
         return false;
@@ -933,11 +948,11 @@ bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int k
                         hipStream_t s) {
     if (D == 128) {
         if (!launch_split<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
-        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else if (D == 256) {
         if (!launch_split<256>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
-        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(256), 0, s, a.part_o, a.part_ml,
+        hipLaunchKernelGGL(attn_decode_combine_kernel<256>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,
                            a.gate, out, nsplit, a.qkv_stride, out_stride);
     } else {
         return false;
