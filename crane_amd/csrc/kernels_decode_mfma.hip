@@ -43,9 +43,9 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     float ss[GM_MB];
 #pragma unroll
     for (int m = 0; m < GM_MB; ++m) ss[m] = 0.f;
-    // 8 independent 16-byte loads per thread are issued before the first conversion (one L2 round trip per batch instead
+    // 16 independent 16-byte loads per thread (the whole [8][4096] slice) are issued before the first conversion (one L2 round trip instead
     // of one per element: the un-batched loop cost ~15 us per launch)
-    constexpr int SB = 8;
+    constexpr int SB = 16;
     static_assert((GM_MB * (GM_KT / 4)) % (64 * GM_W * SB) == 0, "staging batches");
     for (int e0 = tid; e0 < GM_MB * (GM_KT / 4); e0 += 64 * GM_W * SB) {
         f32x4 v[SB], w[SB];
