@@ -27,7 +27,7 @@ constexpr int GM_LD = GM_KT + 32;    // LDS row stride (elements): +64 B, so the
 constexpr int GM_W = 8;              // waves per block (1 block per CU; 2 x 8 weight loads in flight per lane)
 constexpr int GM_U = 8;              // k-steps (16-byte weight loads) in flight per lane
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool TWO>
 __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* xh = lds;                                  // [GM_MB][GM_LD] (rows >= n_seq are zero)
@@ -112,75 +112,73 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     const uint16_t* xl1 = xl + (4 + i4) * GM_LD + blk * 8;
     const float sc0 = fsc[i4], sc1 = fsc[4 + i4];
     float best0 = -INFINITY, best1 = -INFINITY; int besti0 = 0x7FFFFFFF, besti1 = 0x7FFFFFFF;
-    const bool two = a.n_seq > 4;
+    constexpr bool two = TWO;                                // sequences 4..7 present (compile-time: no branch splits the MFMA stream)
 
     const int G = (N + 3) / 4;
     const int nks = (kt + 127) / 128;                        // 128-wide k-steps in this slice
-    for (int rg = bgrp * GM_W + wave; rg < G; rg += nbg * GM_W) {
-        const int row = rg * 4 + i4;                         // weight row whose bytes this lane loads
-        const uint16_t* wp = a.W + (size_t)(row < N ? row : N - 1) * a.ldw + k0 + blk * 8;
-        // 4 independent accumulators per sequence half (k-half x hi/lo): no MFMA waits on the previous one
-        f32x4 c0[4], c1[4];
+    const int rg_stride = nbg * GM_W;
+    // 4 independent accumulators per sequence half (k-half x hi/lo): no MFMA waits on the previous one
+    f32x4 c0[4], c1[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { c0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; c1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        u32x4 wa[GM_U], wb[GM_U];
-        auto load_w = [&](u32x4 (&wq)[GM_U], int ks) {
+    for (int q = 0; q < 4; ++q) { c0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; c1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    u32x4 wa[GM_U], wb[GM_U];
+    // Loads are UNCONDITIONAL: a k-step past the slice re-reads the row's first bytes (x is zero there) and a row group
+    // past the end re-reads the last row (never consumed).  A load under a branch -- lane-variant or uniform -- makes
+    // the compiler wait with vmcnt(0) before the first use, which also waits for the NEXT batch just requested and
+    // serialises the double buffer (measured: 5.27 -> 4.87 ms per 8-sequence step for the lane-variant guards alone).
+    auto load_w = [&](u32x4 (&wq)[GM_U], int rgq, int ksq) {
+        const int row = min(rgq * 4 + i4, N - 1);            // weight row whose bytes this lane loads
+        const uint16_t* wp = a.W + (size_t)row * a.ldw + k0 + blk * 8;
 #pragma unroll
-            for (int u = 0; u < GM_U; ++u)
-                wq[u] = ((ks + u) * 128 + blk * 8 < kt) ? ld_nt16(wp + (ks + u) * 128) : (u32x4){0, 0, 0, 0};
-        };
-        auto consume = [&](const u32x4 (&wq)[GM_U], int ks) {
+        for (int u = 0; u < GM_U; ++u) {
+            const int ko = ((ksq + u) * 128 + blk * 8 < kt) ? (ksq + u) * 128 : -blk * 8;
+            wq[u] = ld_nt16(wp + ko);
+        }
+    };
+    auto consume = [&](const u32x4 (&wq)[GM_U], int ks) {
 #pragma unroll
-            for (int u = 0; u < GM_U; ++u) {
-                if ((ks + u) * 128 + blk * 8 < kt) {
-                    const bf16x4 w_a = __builtin_bit_cast(bf16x4, (u32x2){wq[u][0], wq[u][1]});     // k 0..3 of the chunk
-                    const bf16x4 w_b = __builtin_bit_cast(bf16x4, (u32x2){wq[u][2], wq[u][3]});     // k 4..7
-                    const int ko = (ks + u) * 128;
-                    const u32x4 h0 = *(const u32x4*)(xh0 + ko), l0 = *(const u32x4*)(xl0 + ko);
-                    c0[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h0[0], h0[1]}), c0[0], 0, 0, 0);
-                    c0[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h0[2], h0[3]}), c0[1], 0, 0, 0);
-                    c0[2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l0[0], l0[1]}), c0[2], 0, 0, 0);
-                    c0[3] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l0[2], l0[3]}), c0[3], 0, 0, 0);
-                    if (two) {
-                        const u32x4 h1 = *(const u32x4*)(xh1 + ko), l1 = *(const u32x4*)(xl1 + ko);
-                        c1[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h1[0], h1[1]}), c1[0], 0, 0, 0);
-                        c1[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h1[2], h1[3]}), c1[1], 0, 0, 0);
-                        c1[2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l1[0], l1[1]}), c1[2], 0, 0, 0);
-                        c1[3] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l1[2], l1[3]}), c1[3], 0, 0, 0);
-                    }
-                }
-            }
-        };
-        // weight registers are double-buffered: the next 8 loads are in flight while the current 8 feed the MFMAs
-        load_w(wa, 0);
-        for (int ks = 0; ks < nks; ks += 2 * GM_U) {
-            if (ks + GM_U < nks) load_w(wb, ks + GM_U);
-            consume(wa, ks);
-            if (ks + GM_U < nks) {
-                if (ks + 2 * GM_U < nks) load_w(wa, ks + 2 * GM_U);
-                consume(wb, ks + GM_U);
+        for (int u = 0; u < GM_U; ++u) {                     // steps past the slice multiply zeros (x is zero-padded to GM_KT)
+            const bf16x4 w_a = __builtin_bit_cast(bf16x4, (u32x2){wq[u][0], wq[u][1]});     // k 0..3 of the chunk
+            const bf16x4 w_b = __builtin_bit_cast(bf16x4, (u32x2){wq[u][2], wq[u][3]});     // k 4..7
+            const int ko = (ks + u) * 128;
+            const u32x4 h0 = *(const u32x4*)(xh0 + ko), l0 = *(const u32x4*)(xl0 + ko);
+            c0[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h0[0], h0[1]}), c0[0], 0, 0, 0);
+            c0[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h0[2], h0[3]}), c0[1], 0, 0, 0);
+            c0[2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l0[0], l0[1]}), c0[2], 0, 0, 0);
+            c0[3] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l0[2], l0[3]}), c0[3], 0, 0, 0);
+            if (two) {
+                const u32x4 h1 = *(const u32x4*)(xh1 + ko), l1 = *(const u32x4*)(xl1 + ko);
+                c1[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){h1[0], h1[1]}), c1[0], 0, 0, 0);
+                c1[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){h1[2], h1[3]}), c1[1], 0, 0, 0);
+                c1[2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_a, __builtin_bit_cast(bf16x4, (u32x2){l1[0], l1[1]}), c1[2], 0, 0, 0);
+                c1[3] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w_b, __builtin_bit_cast(bf16x4, (u32x2){l1[2], l1[3]}), c1[3], 0, 0, 0);
             }
         }
+    };
+    // fold the 16 K-chunk blocks of a finished row group, apply the epilogue, clear the accumulators
+    auto finish = [&](int rg) {
         f32x4 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             acc0[r] = (c0[0][r] + c0[1][r]) + (c0[2][r] + c0[3][r]);
             acc1[r] = (c1[0][r] + c1[1][r]) + (c1[2][r] + c1[3][r]);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; c1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         // D layout: lane 4 * blk + j holds D[i = 0..3][j] of block blk; fold the 16 blocks (K chunks)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int o = 4; o < 64; o <<= 1) {
                 acc0[r] += __shfl_xor(acc0[r], o);
-                acc1[r] += __shfl_xor(acc1[r], o);
+                if (two) acc1[r] += __shfl_xor(acc1[r], o);
             }
         }
         // lanes 0..3 (blk 0): sequence j = i4 (acc0) and 4 + i4 (acc1), weight rows rg * 4 + r
         if (blk == 0) {
             const int r0 = rg * 4;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < (two ? 2 : 1); ++half) {
                 const int m = half * 4 + i4;
                 if (m >= a.n_seq) continue;
                 const f32x4 acc = half ? acc1 : acc0;
@@ -200,7 +198,12 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
                         const float v = acc[r] * scl;
                         const size_t o = (size_t)m * a.ldy + r0 + r;
                         if (nkt > 1) atomicAdd(&a.y[o], v);  // split K: partial sums onto the residual / the zeroed output
-                        else if (EPI == EPI_RESADD) a.y[o] = a.res[o] + v;
+                        else if (EPI == EPI_RESADD) {
+                            // in-place residual (the decoder's only use): a fire-and-forget f32 atomic is the same single
+                            // add and, unlike load + store, does not make the wave drain its weight loads (vmcnt(0))
+                            if (a.res == a.y) atomicAdd(&a.y[o], v);
+                            else a.y[o] = a.res[o] + v;
+                        }
                         else a.y[o] = v;
                         if (EPI == EPI_ARGMAX) {
                             const int ix = r0 + r + a.idx_base;
@@ -211,6 +214,25 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
                 }
             }
         }
+    };
+    // The weight stream is ONE continuous pipeline over (row group, k-batch): two statically named register sets; the
+    // next batch -- of this row group or the first of the next one -- is requested before the current one is consumed.
+    int rg = bgrp * GM_W + wave, ks = 0;
+    if (rg < G) load_w(wa, rg, 0);
+    while (rg < G) {
+        int nrg = rg, nk = ks + GM_U;
+        if (nk >= nks) { nrg = rg + rg_stride; nk = 0; }
+        load_w(wb, nrg, nk);
+        consume(wa, ks);
+        if (nk == 0) finish(rg);
+        rg = nrg; ks = nk;
+        if (rg >= G) break;
+        nrg = rg; nk = ks + GM_U;
+        if (nk >= nks) { nrg = rg + rg_stride; nk = 0; }
+        load_w(wa, nrg, nk);
+        consume(wb, ks);
+        if (nk == 0) finish(rg);
+        rg = nrg; ks = nk;
     }
     if (EPI == EPI_ARGMAX) {
         __syncthreads();
@@ -250,8 +272,13 @@ template <int PRO, int EPI>
 static void launch_gemvm_t(const GemvBArgs& a, int grid, hipStream_t s) {
     const size_t ldsb = (size_t)2 * GM_MB * GM_LD * 2 + (GM_MB + 2 * GM_W * GM_MB) * 4 + 64;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemvm_kernel<PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((gemvm_kernel<PRO, EPI>), dim3(grid), dim3(64 * GM_W), ldsb, s, a, gemvm_nkt(a.K));
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemvm_kernel<PRO, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemvm_kernel<PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (a.n_seq > 4) hipLaunchKernelGGL((gemvm_kernel<PRO, EPI, true>), dim3(grid), dim3(64 * GM_W), ldsb, s, a, gemvm_nkt(a.K));
+    else hipLaunchKernelGGL((gemvm_kernel<PRO, EPI, false>), dim3(grid), dim3(64 * GM_W), ldsb, s, a, gemvm_nkt(a.K));
 }
 
 // nkt > 1 with EPI_STORE: the caller zeroes y first
