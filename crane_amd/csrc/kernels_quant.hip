@@ -54,22 +54,30 @@ __device__ __forceinline__ int x_slot(int k4) {
     }
 }
 
-struct QRow {                 // the bytes one lane needs for one (row, chunk)
+// The bytes one lane needs for one (row, chunk), exactly as loaded: nothing is converted or re-packed at load time, so
+// the loads carry no ALU dependency and can stay in flight while the previous (row, chunk) is consumed.
+struct QRow {
     u32x4 a;                  // Q8_0: 16 codes | Q4_K: 16 B of qs | Q6_K: {ql[l], ql[l+32]} 8 B each
-    u32x4 b;                  // Q4_K: block header | Q6_K: {qh 8 B, scales 4 B, d 2 B}
-    float d;                  // Q8_0: block scale
+    u32x4 b;                  // Q4_K: block header | Q6_K: {qh 8 B, the 8 scale bytes of this half-block}
+    uint32_t dh;              // Q8_0 / Q6_K: block scale d, raw f16 bits
 };
+__device__ __forceinline__ float q_d(const QRow& r) { return f16_bits_to_f32(r.dh); }
+// Q6_K: scale of run t (weights 128n + 32t + 8j ..): byte (j >> 1) + 2t of the half-block's 8 scale bytes
+__device__ __forceinline__ int q6_sc(const QRow& r, int t, int lane) {
+    const int bi = ((lane >> 1) & 1) + 2 * (t & 1);
+    return (int)(signed char)((r.b[2 + (t >> 1)] >> (8 * bi)) & 0xFFu);
+}
 
 template <int FMT>
 __device__ __forceinline__ QRow q_load(const QWeight& w, int row, int c, int lane) {
     QRow r;
-    r.d = 0.f;
+    r.dh = 0;
     const size_t K = (size_t)w.K;
     if (FMT == QFMT_Q8_0) {
         const size_t k = (size_t)c * 1024 + (size_t)lane * 16;
         r.a = ld_nt16(w.p0 + (size_t)row * K + k);
         r.b = (u32x4){0, 0, 0, 0};
-        r.d = f16_bits_to_f32(*(const uint16_t*)(w.p1 + ((size_t)row * (K >> 5) + (k >> 5)) * 2));
+        r.dh = *(const uint16_t*)(w.p1 + ((size_t)row * (K >> 5) + (k >> 5)) * 2);
     } else if (FMT == QFMT_Q4_K) {
         const size_t blk = (size_t)row * (K >> 8) + (size_t)c * 8 + (lane >> 3);
         const int h = lane & 7;
@@ -82,9 +90,9 @@ __device__ __forceinline__ QRow q_load(const QWeight& w, int row, int c, int lan
         const u32x2 q1 = *(const u32x2*)(w.p0 + blk * 128 + n * 64 + 32 + j * 8);
         const u32x2 qh = *(const u32x2*)(w.p1 + blk * 64 + n * 32 + j * 8);
         r.a = (u32x4){q0[0], q0[1], q1[0], q1[1]};
-        const uint8_t* sc = w.p2 + blk * 16 + n * 8 + (j >> 1);
-        const uint32_t s4 = (uint32_t)sc[0] | ((uint32_t)sc[2] << 8) | ((uint32_t)sc[4] << 16) | ((uint32_t)sc[6] << 24);
-        r.b = (u32x4){qh[0], qh[1], s4, (uint32_t)*(const uint16_t*)(w.p3 + blk * 2)};
+        const u32x2 sc = *(const u32x2*)(w.p2 + blk * 16 + n * 8);
+        r.b = (u32x4){qh[0], qh[1], sc[0], sc[1]};
+        r.dh = *(const uint16_t*)(w.p3 + blk * 2);
     }
     return r;
 }
@@ -97,7 +105,7 @@ __device__ __forceinline__ float q_dot(const QRow& r, const f32x4* xv, const flo
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             s += sb(r.a[j], 0) * xv[j][0] + sb(r.a[j], 1) * xv[j][1] + sb(r.a[j], 2) * xv[j][2] + sb(r.a[j], 3) * xv[j][3];
-        return r.d * s;
+        return q_d(r) * s;
     } else if (FMT == QFMT_Q4_K) {
         const float d = f16_bits_to_f32(r.b[0] & 0xFFFFu), dmin = f16_bits_to_f32(r.b[0] >> 16);
         // scales[12] = bytes 4..15 of the header; get_scale_min_k4 for sub-blocks 2p (low nibbles), 2p+1 (high)
@@ -122,7 +130,7 @@ __device__ __forceinline__ float q_dot(const QRow& r, const f32x4* xv, const flo
         }
         return (d * sc0) * lo - (dmin * m0) * sx[0] + (d * sc1) * hi - (dmin * m1) * sx[1];
     } else {
-        const float d = f16_bits_to_f32(r.b[3]);
+        const float d = q_d(r);
         float acc = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -139,7 +147,7 @@ __device__ __forceinline__ float q_dot(const QRow& r, const f32x4* xv, const flo
                 const f32x4 x = xv[t * 2 + wi];
                 s += ub(q, 0) * x[0] + ub(q, 1) * x[1] + ub(q, 2) * x[2] + ub(q, 3) * x[3];
             }
-            const float sc = sb(r.b[2], t);
+            const float sc = (float)q6_sc(r, t, lane);
             acc += (d * sc) * (s - 32.0f * sx[t]);
         }
         return acc;
@@ -288,7 +296,7 @@ __device__ __forceinline__ float f16_round(float v) {
     return (float)h;
 }
 
-template <int FMT, int PRO, int EPI, int U>
+template <int FMT, int PRO, int EPI>
 __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     using F = QF<FMT>;
     constexpr int R = 2, CK = F::CK;
@@ -303,20 +311,23 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     int* xs8 = (int*)(xd + (KQ ? Kpad / 256 : Kpad / 32));         // K-quants: sums of 8 consecutive codes [Kpad/8]
     float* red = (float*)(xs8 + (KQ ? Kpad / 8 : 0));
 
-    // the first batch of weight bytes is requested before the activation row is quantised (independent of x)
+    // Weight loads are UNCONDITIONAL and carry no ALU on the loaded bytes: a lane (or a whole step) past the end of K
+    // or N re-reads an in-bounds (row, chunk) whose product is zero (x codes, scales and code sums are zero past K) or
+    // never consumed.  A load under a branch makes the compiler wait with vmcnt(0) at the first use -- which also waits
+    // for the NEXT (row group, chunk) just requested and serialises the double buffer.
     const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
     const int G = (N + R - 1) / R;
-    QRow q[R][U];
-    auto load_batch = [&](int g, int c0) {
-        const int r0 = g * R;
+    const int gstride = gridDim.x * 4;
+    auto load_rows = [&](QRow (&dst)[R], int g, int c) {
+        const bool inr = c * CK + lane_k < K;
+        const int ce = inr ? c : 0, le = inr ? lane : (KQ ? (lane & 7) : 0);
+        const int r0 = min(g, G - 1) * R;
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if ((c0 + u) * CK + lane_k < K) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) q[i][u] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c0 + u, lane);
-            }
+        for (int i = 0; i < R; ++i) dst[i] = q_load<FMT>(a.w, min(r0 + i, N - 1), ce, le);
     };
-    if ((int)(blockIdx.x * 4 + wave) < G) load_batch(blockIdx.x * 4 + wave, 0);
+    QRow qa[R], qb[R];
+    const int gfirst = blockIdx.x * 4 + wave;
+    load_rows(qa, gfirst, 0);              // requested before the activation row is quantised (independent of x)
 
     const int n4 = K >> 2;
     float rr = 1.f;
@@ -340,6 +351,12 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
         }
         return v;
     };
+    if (K < Kpad) {                                                // lanes past K multiply zeros (see load_rows)
+        for (int e = (K >> 2) + tid; e < (Kpad >> 2); e += 256) ((uint32_t*)xq)[e] = 0;
+        const int sb0 = KQ ? K >> 8 : K >> 5, sb1 = KQ ? Kpad >> 8 : Kpad >> 5;
+        for (int e = sb0 + tid; e < sb1; e += 256) xd[e] = 0.f;
+        if (KQ) for (int e = (K >> 3) + tid; e < (Kpad >> 3); e += 256) xs8[e] = 0;
+    }
     if (!KQ) {
         // quantize_row_q8_0: 32-element blocks = 8 consecutive lanes
         for (int k4 = tid; k4 < n4; k4 += 256) {
@@ -396,84 +413,77 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     __syncthreads();
 
     float best = -INFINITY; int besti = 0x7FFFFFFF;
-    for (int g = blockIdx.x * 4 + wave; g < G; g += gridDim.x * 4) {
-        const int r0 = g * R;
-        float acc[R];
+    float acc[R];
 #pragma unroll
-        for (int i = 0; i < R; ++i) acc[i] = 0.f;
-        for (int c0 = 0; c0 < nch; c0 += U) {
+    for (int i = 0; i < R; ++i) acc[i] = 0.f;
+    auto dot = [&](const QRow (&q)[R], int c) {
+        if constexpr (FMT == QFMT_Q8_0) {
+            const int e0 = c * 1024 + lane * 16;
+            const u32x4 xv = *(const u32x4*)(xq + e0);
+            const float dx = xd[e0 >> 5];
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int c = c0 + u;
-            if (c * CK + lane_k >= K) continue;
-            if constexpr (FMT == QFMT_Q8_0) {
-                const int e0 = c * 1024 + lane * 16;
-                const u32x4 xv = *(const u32x4*)(xq + e0);
-                const float dx = xd[e0 >> 5];
+            for (int i = 0; i < R; ++i) {
+                int isum = 0;
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    int isum = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i][u].a[j], (int)xv[j], isum, false);
-                    acc[i] = fmaf(q[i][u].d * dx, (float)isum, acc[i]);
-                }
-            } else if constexpr (FMT == QFMT_Q4_K) {
-                const int kb = c * 8 + (lane >> 3), h = lane & 7, p = h >> 1;
-                const int e0 = kb * 256 + 64 * p + 16 * (h & 1);
-                const u32x4 x0 = *(const u32x4*)(xq + e0), x1 = *(const u32x4*)(xq + e0 + 32);
-                const int bs0 = xs8[e0 >> 3] + xs8[(e0 >> 3) + 1], bs1 = xs8[(e0 + 32) >> 3] + xs8[((e0 + 32) >> 3) + 1];
-                const float dx = xd[kb];
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const u32x4 hb = q[i][u].b;
-                    const float d = f16_bits_to_f32(hb[0] & 0xFFFFu), dmin = f16_bits_to_f32(hb[0] >> 16);
-                    auto sbyte = [&](int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
-                    auto scale_min = [&](int j, int& sc, int& mn) {
-                        if (j < 4) { sc = sbyte(j) & 63; mn = sbyte(j + 4) & 63; }
-                        else { sc = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
-                    };
-                    int sc0, m0, sc1, m1;
-                    scale_min(2 * p, sc0, m0);
-                    scale_min(2 * p + 1, sc1, m1);
-                    int il = 0, ih = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        il = __builtin_amdgcn_sdot4((int)(q[i][u].a[j] & 0x0F0F0F0Fu), (int)x0[j], il, false);
-                        ih = __builtin_amdgcn_sdot4((int)((q[i][u].a[j] >> 4) & 0x0F0F0F0Fu), (int)x1[j], ih, false);
-                    }
-                    acc[i] = fmaf(-(dx * dmin), (float)(m0 * bs0 + m1 * bs1), fmaf(dx * d, (float)(sc0 * il + sc1 * ih), acc[i]));
-                }
-            } else {
-                const int kb = c * 8 + (lane >> 3), n = (lane >> 2) & 1, j = lane & 3;
-                const int e0 = kb * 256 + 128 * n + 8 * j;
-                u32x2 xr[4]; int bs[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { xr[t] = *(const u32x2*)(xq + e0 + 32 * t); bs[t] = xs8[(e0 + 32 * t) >> 3]; }
-                const float dx = xd[kb];
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const float d = f16_bits_to_f32(q[i][u].b[3]);
-                    int sumi = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int qsel = (t & 1) * 2, hshift = 2 * t;
-                        int is = 0;
-#pragma unroll
-                        for (int wi = 0; wi < 2; ++wi) {
-                            const uint32_t qlw = q[i][u].a[qsel + wi], qhw = q[i][u].b[wi];
-                            const uint32_t code = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
-                            is = __builtin_amdgcn_sdot4((int)code, (int)xr[t][wi], is, false);
-                        }
-                        const int sc = (int)(signed char)((q[i][u].b[2] >> (8 * t)) & 0xFFu);
-                        sumi += sc * (is - 32 * bs[t]);
-                    }
-                    acc[i] = fmaf(dx * d, (float)sumi, acc[i]);
-                }
+                for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i].a[j], (int)xv[j], isum, false);
+                acc[i] = fmaf(q_d(q[i]) * dx, (float)isum, acc[i]);
             }
-          }
-          if (c0 + U < nch) load_batch(g, c0 + U);
-          else if (g + (int)gridDim.x * 4 < G) load_batch(g + gridDim.x * 4, 0);
+        } else if constexpr (FMT == QFMT_Q4_K) {
+            const int kb = c * 8 + (lane >> 3), h = lane & 7, p = h >> 1;
+            const int e0 = kb * 256 + 64 * p + 16 * (h & 1);
+            const u32x4 x0 = *(const u32x4*)(xq + e0), x1 = *(const u32x4*)(xq + e0 + 32);
+            const int bs0 = xs8[e0 >> 3] + xs8[(e0 >> 3) + 1], bs1 = xs8[(e0 + 32) >> 3] + xs8[((e0 + 32) >> 3) + 1];
+            const float dx = xd[kb];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const u32x4 hb = q[i].b;
+                const float d = f16_bits_to_f32(hb[0] & 0xFFFFu), dmin = f16_bits_to_f32(hb[0] >> 16);
+                auto sbyte = [&](int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
+                auto scale_min = [&](int j, int& sc, int& mn) {
+                    if (j < 4) { sc = sbyte(j) & 63; mn = sbyte(j + 4) & 63; }
+                    else { sc = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
+                };
+                int sc0, m0, sc1, m1;
+                scale_min(2 * p, sc0, m0);
+                scale_min(2 * p + 1, sc1, m1);
+                int il = 0, ih = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    il = __builtin_amdgcn_sdot4((int)(q[i].a[j] & 0x0F0F0F0Fu), (int)x0[j], il, false);
+                    ih = __builtin_amdgcn_sdot4((int)((q[i].a[j] >> 4) & 0x0F0F0F0Fu), (int)x1[j], ih, false);
+                }
+                acc[i] = fmaf(-(dx * dmin), (float)(m0 * bs0 + m1 * bs1), fmaf(dx * d, (float)(sc0 * il + sc1 * ih), acc[i]));
+            }
+        } else {
+            const int kb = c * 8 + (lane >> 3), n = (lane >> 2) & 1, j = lane & 3;
+            const int e0 = kb * 256 + 128 * n + 8 * j;
+            u32x2 xr[4]; int bs[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { xr[t] = *(const u32x2*)(xq + e0 + 32 * t); bs[t] = xs8[(e0 + 32 * t) >> 3]; }
+            const float dx = xd[kb];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float d = q_d(q[i]);
+                int sumi = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int qsel = (t & 1) * 2, hshift = 2 * t;
+                    int is = 0;
+#pragma unroll
+                    for (int wi = 0; wi < 2; ++wi) {
+                        const uint32_t qlw = q[i].a[qsel + wi], qhw = q[i].b[wi];
+                        const uint32_t code = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
+                        is = __builtin_amdgcn_sdot4((int)code, (int)xr[t][wi], is, false);
+                    }
+                    const int sc = q6_sc(q[i], t, lane);
+                    sumi += sc * (is - 32 * bs[t]);
+                }
+                acc[i] = fmaf(dx * d, (float)sumi, acc[i]);
+            }
         }
+    };
+    auto finish = [&](int g) {
+        const int r0 = g * R;
         float mine = 0.f, mine_up = 0.f;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -484,7 +494,10 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
         if (EPI == EPI_STORE) {
             if (lane < R && r0 + lane < N) a.y[r0 + lane] = mine;
         } else if (EPI == EPI_RESADD) {
-            if (lane < R && r0 + lane < N) a.y[r0 + lane] = a.res[r0 + lane] + mine;
+            if (lane < R && r0 + lane < N) {
+                if (a.res == a.y) atomicAdd(&a.y[r0 + lane], mine);          // in-place residual: no load to wait for
+                else a.y[r0 + lane] = a.res[r0 + lane] + mine;
+            }
         } else if (EPI == EPI_SILUMUL) {
             if (lane < R / 2 && r0 + 2 * lane + 1 < N) a.y[(r0 >> 1) + lane] = (mine / (1.0f + expf(-mine))) * mine_up;
         } else if (EPI == EPI_ARGMAX) {
@@ -495,6 +508,25 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
                 if (r0 + i < N && (acc[i] > best || (acc[i] == best && ix < besti))) { best = acc[i]; besti = ix; }
             }
         }
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = 0.f;
+    };
+    // one continuous pipeline over (row group, chunk): the next one is requested before the current one is dotted
+    int g = gfirst, c = 0;
+    while (g < G) {
+        int ng = g, nc = c + 1;
+        if (nc >= nch) { ng = g + gstride; nc = 0; }
+        load_rows(qb, ng, nc);
+        dot(qa, c);
+        if (nc == 0) finish(g);
+        g = ng; c = nc;
+        if (g >= G) break;
+        ng = g; nc = c + 1;
+        if (nc >= nch) { ng = g + gstride; nc = 0; }
+        load_rows(qa, ng, nc);
+        dot(qb, c);
+        if (nc == 0) finish(g);
+        g = ng; c = nc;
     }
     if (EPI == EPI_ARGMAX) {
         __syncthreads();
@@ -515,13 +547,7 @@ static void launch_gemvq_i8_f(int pro, int epi, const GemvQArgs& a, int grid, hi
     constexpr int CK = QF<FMT>::CK;
     const size_t kpad = (size_t)((a.w.K + CK - 1) / CK) * CK;
     const size_t lds = kpad + (FMT == QFMT_Q8_0 ? kpad / 32 * 4 : kpad / 256 * 4 + kpad / 8 * 4) + 64;
-    const int nch = (a.w.K + CK - 1) / CK;
-    static int env_u = -1;
-    if (env_u < 0) { env_u = 0; if (const char* e = getenv("CM_GEMVQ_U")) env_u = atoi(e); }
-    const int want = env_u > 0 ? env_u : 1;          // batching 2 chunks measured no faster (VALU-issue-bound)
-    const int u = (want >= 2 && nch % 2 == 0) ? 2 : 1;
-#define CM_QI(P, E) { if (u == 2) hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E, 2>), dim3(grid), dim3(256), lds, s, a); \
-                      else hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E, 1>), dim3(grid), dim3(256), lds, s, a); return; }
+#define CM_QI(P, E) { hipLaunchKernelGGL((gemvq_i8_kernel<FMT, P, E>), dim3(grid), dim3(256), lds, s, a); return; }
     if (pro == PRO_RMSNORM) {
         if (epi == EPI_STORE) CM_QI(PRO_RMSNORM, EPI_STORE)
         if (epi == EPI_SILUMUL) CM_QI(PRO_RMSNORM, EPI_SILUMUL)
@@ -612,20 +638,19 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
     const int gstride = gridDim.x * NW;
     const int gfirst = blockIdx.x * NW + wave;
     QRow q[R][U], qn[R][U];
+    // unconditional, clamped loads (see gemvq_i8_kernel): lanes / steps past K or N re-read in-bounds bytes whose
+    // product is zero (codes, scales and code sums are zero past K) or that are never consumed
     auto load_rows = [&](QRow (&dst)[R][U], int g, int c0) {
-        const int r0 = g * R;
+        const int r0 = min(g, G - 1) * R;
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (c0 + u < nch && (c0 + u) * CK + lane_k < K) {
+        for (int u = 0; u < U; ++u) {
+            const bool inr = c0 + u < nch && (c0 + u) * CK + lane_k < K;
+            const int ce = inr ? c0 + u : 0, le = inr ? lane : (KQ ? (lane & 7) : 0);
 #pragma unroll
-                for (int i = 0; i < R; ++i) dst[i][u] = q_load<FMT>(a.w, (r0 + i < N) ? r0 + i : N - 1, c0 + u, lane);
-            }
+            for (int i = 0; i < R; ++i) dst[i][u] = q_load<FMT>(a.w, min(r0 + i, N - 1), ce, le);
+        }
     };
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-#pragma unroll
-        for (int u = 0; u < U; ++u) { q[i][u].a = (u32x4){0, 0, 0, 0}; q[i][u].b = (u32x4){0, 0, 0, 0}; q[i][u].d = 0.f; qn[i][u] = q[i][u]; }
-    if (gfirst < G) load_rows(q, gfirst, 0);       // weight bytes are requested before the activation rows are quantised
+    load_rows(q, gfirst, 0);                       // weight bytes are requested before the activation rows are quantised
 
     // ---- quantise the activation rows: half `grp` of the block takes sequences grp, grp + 2, ... ----
     // Loads are issued SG sequences x 4 strides at a time: one L2 round trip per 1024 elements of K for all of a
@@ -674,6 +699,16 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
         }
         return v;
     };
+    if (K < Kpad) {                                                // lanes past K multiply zeros (see load_rows)
+        for (int m = 0; m < ns; ++m) {
+            unsigned char* sp = lds_raw + (size_t)m * seq_bytes;
+            float* zd = (float*)(sp + Kpad);
+            int* zs = (int*)(zd + nscale);
+            for (int e = (K >> 2) + tid; e < (Kpad >> 2); e += 512) ((uint32_t*)sp)[e] = 0;
+            for (int e = (KQ ? K >> 8 : K >> 5) + tid; e < nscale; e += 512) zd[e] = 0.f;
+            if (KQ) for (int e = (K >> 3) + tid; e < (Kpad >> 3); e += 512) zs[e] = 0;
+        }
+    }
     if (!KQ) {
         for (int kb = t2; kb < n4; kb += 1024) {                   // quantize_row_q8_0: 32 elements = 8 consecutive lanes
             f32x4 v[SG][4], nwv[4];
@@ -783,13 +818,16 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
         for (int c0 = 0; c0 < nch; c0 += U) {
             // the next batch of (row group, chunks) is in flight while this one is dotted with every sequence
             if (c0 + U < nch) load_rows(qn, g, c0 + U);
-            else if (g + gstride < G) load_rows(qn, g + gstride, 0);
+            else load_rows(qn, g + gstride, 0);                    // past the last row group: a clamped, unused re-read
 #pragma unroll
             for (int u = 0; u < U; ++u) {
             const int c = c0 + u;
-            if (c < nch && c * CK + lane_k < K) {
+            {
                 if constexpr (FMT == QFMT_Q8_0) {
                     const int e0 = c * 1024 + lane * 16;
+                    float dw[R];
+#pragma unroll
+                    for (int i = 0; i < R; ++i) dw[i] = q_d(q[i][u]);
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
                         if (m >= ns) break;
@@ -801,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                             int isum = 0;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) isum = __builtin_amdgcn_sdot4((int)q[i][u].a[j], (int)xv[j], isum, false);
-                            acc[i][m] = fmaf(q[i][u].d * dx, (float)isum, acc[i][m]);
+                            acc[i][m] = fmaf(dw[i] * dx, (float)isum, acc[i][m]);
                         }
                     }
                 } else if constexpr (FMT == QFMT_Q4_K) {
@@ -848,7 +886,7 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                     float d[R]; uint32_t code[R][4][2]; int sc[R][4];
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
-                        d[i] = f16_bits_to_f32(q[i][u].b[3]);
+                        d[i] = q_d(q[i][u]);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int qsel = (t & 1) * 2, hshift = 2 * t;
@@ -857,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
                                 const uint32_t qlw = q[i][u].a[qsel + wi], qhw = q[i][u].b[wi];
                                 code[i][t][wi] = ((t < 2 ? qlw : (qlw >> 4)) & 0x0F0F0F0Fu) | (((qhw >> hshift) & 0x03030303u) << 4);
                             }
-                            sc[i][t] = (int)(signed char)((q[i][u].b[2] >> (8 * t)) & 0xFFu);
+                            sc[i][t] = q6_sc(q[i][u], t, lane);
                         }
                     }
 #pragma unroll
@@ -919,7 +957,10 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
         if (EPI == EPI_STORE || EPI == EPI_ARGMAX) {
             if (mi < ns && r0 + ri < N) a.y[(size_t)mi * a.ldy + r0 + ri] = mine;
         } else if (EPI == EPI_RESADD) {
-            if (mi < ns && r0 + ri < N) a.y[(size_t)mi * a.ldy + r0 + ri] = a.res[(size_t)mi * a.ldy + r0 + ri] + mine;
+            if (mi < ns && r0 + ri < N) {
+                if (a.res == a.y) atomicAdd(&a.y[(size_t)mi * a.ldy + r0 + ri], mine);      // in-place residual: no load to wait for
+                else a.y[(size_t)mi * a.ldy + r0 + ri] = a.res[(size_t)mi * a.ldy + r0 + ri] + mine;
+            }
         } else if (EPI == EPI_SILUMUL) {
             const int ms = lane / (R / 2), ps = lane % (R / 2);
             if (ms < ns && r0 + 2 * ps + 1 < N) a.y[(size_t)ms * a.ldy + (r0 >> 1) + ps] = (gate_v / (1.0f + expf(-gate_v))) * up_v;
