@@ -282,8 +282,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     }
 
     // epilogue: C layout of mfma 16x16: col = lane & 15 (n), row = (lane >> 4) * 4 + reg (m)
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};                      // a lane's 4 columns: the bias is loaded once, not per element
+    if (a.bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = a.bias[n0 + wc * 64 + j * 16 + (lane & 15)];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        // residual add: the 16 old values of this row band are requested in ONE batch from clamped (always valid)
+        // addresses -- a load under the `m < M` guard is followed by vmcnt(0), i.e. 64 serial round trips per lane
+        float cold[4][4];
+        if (EPI == GEPI_RESADD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = min(m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r, a.M - 1);
+                    cold[j][r] = a.C[(size_t)m * a.ldc + n0 + wc * 64 + j * 16 + (lane & 15)];
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + (lane & 15);
@@ -291,11 +308,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
                 float v = acc[i][j][r];
-                if (a.bias != nullptr) v += a.bias[n];
+                if (a.bias != nullptr) v += bv[j];
                 if (EPI == GEPI_STORE) {
                     if (m < a.M) a.C[(size_t)m * a.ldc + n] = v;
                 } else if (EPI == GEPI_RESADD) {
-                    if (m < a.M) a.C[(size_t)m * a.ldc + n] += v;
+                    if (m < a.M) a.C[(size_t)m * a.ldc + n] = cold[j][r] + v;
                 } else if (EPI == GEPI_ACT_SPLIT) {   // H[m, n] = act(v) as bf16 hi (+lo): A operand of the next GEMM
                     if (m < a.M) {
                         float h = v;
