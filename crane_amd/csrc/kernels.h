@@ -208,7 +208,7 @@ struct GemvQArgs {
     float eps;
     int act_int = 0;       // 1: activations quantised to Q8_0 / Q8_K + integer dot products (ggml vec_dot semantics)
 };
-int gemvq_grid(int N, int num_cu);
+int gemvq_grid(int N, int num_cu, int fmt = QFMT_NONE);
 // batched integer-dot GEMV: <= 8 sequences per pass over the quantised weights (activations always quantised)
 struct GemvQBArgs {
     QWeight w;

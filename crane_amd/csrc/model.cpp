@@ -250,7 +250,7 @@ void Model::alloc_runtime() {
     part_o = dalloc<float>((size_t)Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_ml = dalloc<float>((size_t)Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
-    lm_grid = (quantized && q_lm_head.fmt != QFMT_NONE) ? gemvq_grid(v_eff, num_cu) : gemv_grid(v_eff, H, num_cu);
+    lm_grid = (quantized && q_lm_head.fmt != QFMT_NONE) ? gemvq_grid(v_eff, num_cu, q_lm_head.fmt) : gemv_grid(v_eff, H, num_cu);
     pmax = dalloc<float>((size_t)lm_grid * tp);
     pidx = dalloc<int>((size_t)lm_grid * tp);
     st = (StepState*)dalloc<int>(sizeof(StepState) / sizeof(int));
@@ -536,7 +536,7 @@ void Model::enqueue_quant_layer(int li) {
     auto qg = [&](int pro, int epi, const QWeight& qw, const float* xin, const float* nw, float* yout, const float* res) {
         GemvQArgs q{};
         q.w = qw; q.x = xin; q.nw = nw; q.y = yout; q.res = res; q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
-        if (!launch_gemvq(pro, epi, q, gemvq_grid(qw.N, num_cu), s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
+        if (!launch_gemvq(pro, epi, q, gemvq_grid(qw.N, num_cu, qw.fmt), s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
     };
     if (!w.full) {
         const int qz = cfg.conv_dim() + cfg.value_dim();
@@ -1161,7 +1161,7 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
             else if (which == "down") { q.w = w.q_down; q.x = hbuf; q.y = y; q.res = x; }
             else if (which == "lm_head" && q_lm_head.fmt != QFMT_NONE) { q.w = q_lm_head; q.x = x; q.nw = norm; q.y = logits; q.pmax = pmax; q.pidx = pidx; pro = PRO_RMSNORM; epi = EPI_ARGMAX; }
             else throw CmError(CM_ERR_INVALID, "unknown / unavailable kernel name for quantised weights");
-            const int grid = which == "lm_head" ? lm_grid : gemvq_grid(q.w.N, num_cu);
+            const int grid = which == "lm_head" ? lm_grid : gemvq_grid(q.w.N, num_cu, q.w.fmt);
             if (!launch_gemvq(pro, epi, q, grid, stream)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
             b = q.w.bytes() + (uint64_t)q.w.K * 4 + (q.nw ? (uint64_t)q.w.K * 4 : 0);
             return;
@@ -1227,7 +1227,7 @@ void Model::debug_qgemv(int layer, const std::string& which, const float* xh, si
     CM_HIP(hipMemcpyAsync(dx, xh, k * sizeof(float), hipMemcpyHostToDevice, stream));
     GemvQArgs q{};
     q.w = w; q.x = dx; q.y = dy; q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
-    const bool ok = launch_gemvq(PRO_PLAIN, EPI_STORE, q, gemvq_grid(w.N, num_cu), stream);
+    const bool ok = launch_gemvq(PRO_PLAIN, EPI_STORE, q, gemvq_grid(w.N, num_cu, w.fmt), stream);
     if (ok) CM_HIP(hipMemcpyAsync(yh, dy, n * sizeof(float), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
     (void)hipFree(dx); (void)hipFree(dy);
