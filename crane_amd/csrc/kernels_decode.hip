@@ -193,7 +193,12 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
         if (EPI == EPI_STORE) {
             if (lane < R && r0 + lane < N) a.y[r0 + lane] = mine;
         } else if (EPI == EPI_RESADD) {
-            if (lane < R && r0 + lane < N) a.y[r0 + lane] = a.res[r0 + lane] + mine;
+            if (lane < R && r0 + lane < N) {
+                // in-place residual (the decoder's use): a fire-and-forget f32 atomic is the same single add and, unlike
+                // load + store, does not make the wave drain the weight loads it has in flight
+                if (PIPE && a.res == a.y) atomicAdd(&a.y[r0 + lane], mine);
+                else a.y[r0 + lane] = a.res[r0 + lane] + mine;
+            }
         } else if (EPI == EPI_SILUMUL) {
             if (lane < R / 2 && r0 + 2 * lane + 1 < N)
                 a.y[(r0 >> 1) + lane] = (mine / (1.0f + expf(-mine))) * mine_up;
@@ -215,13 +220,23 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
     auto batch_cb = [&](int b) { return (b % nbpg) * U; };
 
     if constexpr (PIPE) {
-        for (int b = 0; b < NB; b += 2) {
-            if (b + 1 < NB) load_batch(qb, batch_g(b + 1), batch_cb(b + 1));
+        // Two statically named register sets, and NO load under a branch inside the steady state: a guarded prefetch
+        // makes the compiler wait with vmcnt(0) at the next use, which also waits for the batch just requested
+        // (DESIGN 3.13).  The last one or two batches are peeled into straight-line code.
+        int b = 0;
+        while (b + 2 < NB) {
+            load_batch(qb, batch_g(b + 1), batch_cb(b + 1));
             compute(qa);
-            if (b + 1 < NB) {
-                if (b + 2 < NB) load_batch(qa, batch_g(b + 2), batch_cb(b + 2));
-                compute(qb);
-            }
+            load_batch(qa, batch_g(b + 2), batch_cb(b + 2));
+            compute(qb);
+            b += 2;
+        }
+        if (b + 1 < NB) {
+            load_batch(qb, batch_g(b + 1), batch_cb(b + 1));
+            compute(qa);
+            compute(qb);
+        } else if (b < NB) {
+            compute(qa);
         }
     } else {
         for (int b = 0; b < NB; ++b) {
