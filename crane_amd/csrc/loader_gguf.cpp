@@ -331,7 +331,10 @@ void load_from_gguf(Model& m, const std::string& path) {
 // (when untied); the embedding table stays bf16 (one row per token) and so does a tied lm_head.
 // ------------------------------------------------------------------------------------
 void Model::isq_q8_0() {
-    if (tp != 1) throw CmError(CM_ERR_UNSUPPORTED, "ISQ under tensor parallelism is not implemented");
+    // Tensor parallelism: every rank quantises ITS shard (dense family).  Q8_0 blocks run along K, and the row-parallel
+    // shards (o_proj, down_proj) cut K on multiples of head_dim / of the intermediate slice, so a rank's blocks are the
+    // blocks the unsharded matrix would have -- the codes are the same as quantise-then-shard.
+    if (tp != 1 && cfg.hybrid) throw CmError(CM_ERR_UNSUPPORTED, "ISQ of the hybrid family under tensor parallelism is not implemented");
     if (vcfg.present) throw CmError(CM_ERR_UNSUPPORTED, "ISQ of the vision-language checkpoints is not implemented");
     auto quant = [&](uint16_t* src, int N, int K) -> QWeight {
         if (K % 32) throw CmError(CM_ERR_UNSUPPORTED, "ISQ Q8_0 needs the input dimension to be a multiple of 32");
@@ -363,7 +366,7 @@ void Model::isq_q8_0() {
         w.q_gate_up = quant(w.gate_up, 2 * I_l, H);
         w.q_down = quant(w.down, H, I_l);
     }
-    if (!cfg.tie) q_lm_head = quant(lm_head, cfg.V, H);
+    if (!cfg.tie) q_lm_head = quant(lm_head, tp == 1 ? cfg.V : V_l, H);     // vocabulary shard [v0, v0 + V_l) under TP
     CM_HIP(hipStreamSynchronize(stream));
     for (LayerW& w : layers) {
         dfree(w.qkv); dfree(w.o); dfree(w.gate_up); dfree(w.down); dfree(w.in_proj); dfree(w.out_proj);

@@ -564,7 +564,11 @@ void Model::enqueue_quant_layer(int li) {
         if (attn_variant >= 2) {
             if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-        qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
+        if (!rccl) qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
+        else {       // row-parallel: partial sums over this rank's heads, rank 0 carries the residual
+            qg(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, w.q_o, attn, nullptr, y, x);
+            rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
+        }
     }
     if (!w.split_gate_up) {
         qg(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, x, w.ln2, hbuf, nullptr);
@@ -573,7 +577,11 @@ void Model::enqueue_quant_layer(int li) {
         qg(PRO_RMSNORM, EPI_STORE, w.q_up, x, w.ln2, gu_tmp + cfg.I, nullptr);
         launch_silu_mul(gu_tmp, gu_tmp + cfg.I, hbuf, cfg.I, s);
     }
-    qg(PRO_PLAIN, EPI_RESADD, w.q_down, hbuf, nullptr, x, x);
+    if (!rccl) qg(PRO_PLAIN, EPI_RESADD, w.q_down, hbuf, nullptr, x, x);
+    else {
+        qg(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, w.q_down, hbuf, nullptr, y, x);
+        rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
+    }
 }
 
 void Model::enqueue_lm_head(bool advance) {
@@ -584,10 +592,16 @@ void Model::enqueue_lm_head(bool advance) {
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     if (quantized && q_lm_head.fmt != QFMT_NONE) {
         GemvQArgs q{};
-        q.w = q_lm_head; q.x = x; q.nw = norm; q.y = logits; q.pmax = pmax; q.pidx = pidx; q.idx_base = 0; q.eps = cfg.eps;
+        q.w = q_lm_head.rows(0, v_eff); q.x = x; q.nw = norm; q.y = logits + (size_t)rank * V_l;
+        q.pmax = pmax + (size_t)rank * lm_grid; q.pidx = pidx + (size_t)rank * lm_grid; q.idx_base = v0; q.eps = cfg.eps;
         q.act_int = quant_act_int ? 1 : 0;
         if (!launch_gemvq(PRO_RMSNORM, EPI_ARGMAX, q, lm_grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
-        launch_argmax_final(pmax, pidx, lm_grid, st, ring, RING - 1, advance ? 1 : 0, 1, s);
+        if (rccl) {
+            rccl->all_gather(pmax + (size_t)rank * lm_grid, pmax, (size_t)lm_grid * sizeof(float), s);
+            rccl->all_gather(pidx + (size_t)rank * lm_grid, pidx, (size_t)lm_grid * sizeof(int), s);
+        }
+        if (rccl && rccl->fake) launch_argmax_final(pmax + (size_t)rank * lm_grid, pidx + (size_t)rank * lm_grid, lm_grid, st, ring, RING - 1, advance ? 1 : 0, 1, s);
+        else launch_argmax_final(pmax, pidx, lm_grid * tp, st, ring, RING - 1, advance ? 1 : 0, 1, s);
         return;
     }
     GemvArgs g{};

@@ -244,7 +244,7 @@ struct Model {
     unsigned long long* tk_cand_rows = nullptr; size_t tk_cand_row_cap = 0;
     bool logits_gathered = false;
 
-    // quantised weights (dense Qwen3, TP = 1): embedding / lm_head tables + per-layer QWeights in LayerW
+    // quantised weights (GGUF: TP = 1; ISQ: also under TP for the dense family): embedding / lm_head tables + per-layer QWeights in LayerW
     bool quantized = false;
     bool gdn_chunked = false;          // GGUF value-head order (VHeadOrder::Chunked)
     bool quant_act_int = true;         // ggml vec_dot semantics: activations -> Q8_0 / Q8_K + integer dots (CM_QUANT_ACT=f32: exact dequant x f32)

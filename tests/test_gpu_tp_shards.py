@@ -16,12 +16,12 @@ def rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
-def _run_rank(cfg, rank, world, ids):
+def _run_rank(cfg, rank, world, ids, isq=None):
     from crane_amd.backend import Model
     os.environ["CM_TP_FAKE"] = "1"
     try:
         m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
-                            tp_unique_id=b"\0" * 128)
+                            tp_unique_id=b"\0" * 128, isq=isq)
     finally:
         del os.environ["CM_TP_FAKE"]
     try:
@@ -66,3 +66,29 @@ def test_hybrid_rank_shards():
         got_a, got_b = _run_rank(cfg, rank, 2, ids)
         v = slice(plan.vocab.start, plan.vocab.stop)
         assert rel(got_a[v], o.forward(ids, 0)) < 1e-4 and rel(got_b[v], o.forward([5], len(ids))) < 1e-4
+
+
+def test_dense_rank_shards_isq_q8_0(monkeypatch):
+    """ISQ under TP: every rank quantises its own shard (Q8_0 blocks never straddle a shard boundary), the row-parallel
+    projections feed the all-reduce, the vocabulary-sharded quantised lm_head feeds the arg-max gather."""
+    from oracle import gguf_oracle as G
+    from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+    monkeypatch.setenv("CM_QUANT_ACT", "f32")
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+    cfg = configs.get_config("tiny-qwen3-untied")
+    w = synth.synth_weights_f32(cfg, 0)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    world = 2
+    linears = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+    for rank in range(world):
+        plan = tp.shard_plan(cfg, world, rank)
+        sw = tp.shard_weights(cfg, w, plan)
+        for k, v in list(sw.items()):
+            if any(k.endswith(f"{l}.weight") for l in linears) or k == "lm_head.weight":
+                sw[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
+        local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads),
+                     intermediate_size=len(plan.inter))
+        o = Qwen3Oracle(Qwen3Config.from_json(local), sw)
+        got_a, got_b = _run_rank(cfg, rank, world, ids, isq="q8_0")
+        v = slice(plan.vocab.start, plan.vocab.stop)
+        assert rel(got_a[v], o.forward(ids, 0)) < 2e-4 and rel(got_b[v], o.forward([5], len(ids))) < 2e-4
