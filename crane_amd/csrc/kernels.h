@@ -168,7 +168,7 @@ void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s);
 void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, int n_seq, hipStream_t s);
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
-                         int ring_mask, int advance, int n_seq, hipStream_t s);
+                         int ring_mask, int advance, int n_seq, hipStream_t s, int slabs = 1, size_t slab_stride = 0);
 bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq, hipStream_t s);
 bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, bool kv_f32, int n_seq, hipStream_t s);
 bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq,

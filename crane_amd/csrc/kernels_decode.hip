@@ -263,15 +263,16 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
 __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restrict__ pmax,
                                                            const int* __restrict__ pidx, int n,
                                                            StepState* st, uint32_t* ring, int ring_mask,
-                                                           int advance) {
+                                                           int advance, int slabs, size_t slab_stride) {
     __shared__ float sm[256];
     __shared__ int si[256];
     pmax += (size_t)blockIdx.x * n; pidx += (size_t)blockIdx.x * n; st += blockIdx.x;   // batched step: one block per sequence
     float b = -INFINITY; int bi = 0x7FFFFFFF;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        float v = pmax[i]; int ix = pidx[i];
-        if (v > b || (v == b && ix < bi)) { b = v; bi = ix; }
-    }
+    for (int sl = 0; sl < slabs; ++sl)            // batched step under TP: one [n_seq][n] slab per rank (vocabulary shard)
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float v = pmax[sl * slab_stride + i]; int ix = pidx[sl * slab_stride + i];
+            if (v > b || (v == b && ix < bi)) { b = v; bi = ix; }
+        }
     sm[threadIdx.x] = b; si[threadIdx.x] = bi;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -373,8 +374,8 @@ void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, 
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s, st, token, pos, slot, rope_delta);
 }
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
-                         int ring_mask, int advance, int n_seq, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(n_seq), dim3(256), 0, s, pmax, pidx, n, st, ring, ring_mask, advance);
+                         int ring_mask, int advance, int n_seq, hipStream_t s, int slabs, size_t slab_stride) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(n_seq), dim3(256), 0, s, pmax, pidx, n, st, ring, ring_mask, advance, slabs, slab_stride);
 }
 
 }  // namespace cm

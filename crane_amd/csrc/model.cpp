@@ -843,11 +843,13 @@ void Model::ensure_batch_buffers() {
     logitsb = dalloc<float>((size_t)MAXB * cfg.V);
     part_ob = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
+    if (rccl) yb = dalloc<float>((size_t)MAXB * H);
     int g = std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu));
     if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu));
     if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * cfg.I);
-    pmaxb = dalloc<float>((size_t)MAXB * g);
-    pidxb = dalloc<int>((size_t)MAXB * g);
+    pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
+    pidxb = dalloc<int>((size_t)MAXB * g * tp);
+    lm_gridb = g;
     CM_HIP(hipHostMalloc((void**)&h_stb, MAXB * sizeof(StepState)));
     CM_HIP(hipHostMalloc((void**)&h_btb, (size_t)MAXB * max_pages_per_seq * sizeof(int32_t)));
     CM_HIP(hipHostMalloc((void**)&h_logitsb, (size_t)MAXB * cfg.V * sizeof(float)));
@@ -856,7 +858,8 @@ void Model::ensure_batch_buffers() {
 
 void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out,
                          const std::function<void(size_t, int)>* after_group) {
-    if (rccl) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism is not implemented");
+    if (rccl && quantized) throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights under tensor parallelism is not implemented");
+    if (rccl && cfg.V % tp != 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism needs vocab_size divisible by tp_size");
     if (quantized && !quant_act_int)
         throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights needs the integer-dot activation mode (CM_QUANT_ACT unset)");
     ensure_batch_buffers();
@@ -898,6 +901,26 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             }
             launch_gemvb(pro, epi, g, gemvb_grid(N, K, num_cu), s);
         };
+        // row-parallel projection + residual into xb (o_proj / out_proj / down_proj).  TP: every rank holds partial sums
+        // over its K slice in yb (rank 0 carries the residual), one all-reduce for all nb rows puts the sum back into xb
+        auto rp = [&](const uint16_t* W, const float* xin, int ldx, int K) {
+            if (!rccl) { gb(PRO_PLAIN, EPI_RESADD, W, xin, ldx, nullptr, xb, H, H, K); return; }
+            const bool carry = rank == 0 || rccl->fake;
+            GemvBArgs g{};
+            g.W = W; g.x = xin; g.y = yb; g.res = xb; g.N = H; g.K = K; g.ldw = K; g.ldx = ldx; g.ldy = H; g.n_seq = nb; g.eps = cfg.eps;
+            if (use_mfma_gemv && gemvm_ok(EPI_STORE, nb, K)) {
+                int epi = carry ? EPI_RESADD : EPI_STORE;
+                if (gemvm_nkt(K) > 1) {        // split K accumulates with atomics onto yb: seed it with the residual / zero
+                    if (carry) CM_HIP(hipMemcpyAsync(yb, xb, (size_t)nb * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    else CM_HIP(hipMemsetAsync(yb, 0, (size_t)nb * H * sizeof(float), s));
+                    epi = EPI_STORE;
+                }
+                launch_gemvm(PRO_PLAIN, epi, g, gemvm_grid(H, K, num_cu), s);
+            } else {
+                launch_gemvb(PRO_PLAIN, carry ? EPI_RESADD : EPI_STORE, g, gemvb_grid(H, K, num_cu), s);
+            }
+            rccl->all_reduce_sum_f32(yb, xb, (size_t)nb * H, s);
+        };
         // quantised weights: one pass over the codes for all nb sequences (gemvqb: activations quantised per sequence,
         // integer dots -- row for row the arithmetic of the single-sequence step)
         auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy) {
@@ -932,7 +955,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
                 launch_gdn(ga, s);
                 if (quantized) qb(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attnb, (int)at_cols, nullptr, xb, H);
-                else gb(PRO_PLAIN, EPI_RESADD, w.out_proj, attnb, (int)at_cols, nullptr, xb, H, H, cfg.value_dim());
+                else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
                 if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
                 else gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
@@ -943,7 +966,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 a.gate = cfg.hybrid ? qkvb + (size_t)Hq_l * D : nullptr;
                 a.qkv_stride = ldq; a.bt_stride = max_pages_per_seq; a.rot_dim = cfg.rot_dim;
                 a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-                if (heads_b && !quantized) {
+                if (heads_b && !quantized && !rccl) {
                     if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
                     GemvBArgs g{};
                     g.W = w.o; g.x = part_ob; g.y = xb; g.res = xb; g.N = H; g.K = Hq_l * D; g.ldw = g.K; g.ldx = Hq_l * attn_ns * D; g.ldy = H;
@@ -958,7 +981,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 if (quantized) qb(PRO_PLAIN, EPI_RESADD, w.q_o, attnb, (int)at_cols, nullptr, xb, H);
-                else gb(PRO_PLAIN, EPI_RESADD, w.o, attnb, (int)at_cols, nullptr, xb, H, H, Hq_l * D);
+                else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }
             }
             if (quantized) {
@@ -973,7 +996,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 continue;
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
-            gb(PRO_PLAIN, EPI_RESADD, w.down, hbb, I_l, nullptr, xb, H, H, I_l);
+            rp(w.down, hbb, I_l, I_l);
         }
         if (quantized && q_lm_head.fmt != QFMT_NONE) {
             const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
@@ -988,14 +1011,27 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             }
             launch_argmax_final(pmaxb, pidxb, lmq, stb, ring, RING - 1, 0, nb, s);
         } else {
+        // vocabulary shard [v0, v0 + V_l) of this rank (TP = 1: the whole table): logits land in their columns of the
+        // [nb][V] rows, the per-block maxima in this rank's [MAXB][lmg] slab
+        const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+        const size_t slab = (size_t)MAXB * lm_gridb;
         GemvBArgs g{};
-        g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb; g.N = cfg.V; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
-        g.eps = cfg.eps; g.pmax = pmaxb; g.pidx = pidxb;
+        g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
+        g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab; g.pidx = pidxb + (size_t)rank * slab; g.idx_base = v0;
         const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nb, H);
-        const int lmg = lm_mfma ? gemvm_grid(cfg.V, H, num_cu) : gemvb_grid(cfg.V, H, num_cu);
+        const int lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu) : gemvb_grid(v_eff, H, num_cu);
         if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
         else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
-        launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s);
+        if (rccl && !rccl->fake) {
+            rccl->all_gather(pmaxb + (size_t)rank * slab, pmaxb, slab * sizeof(float), s);
+            rccl->all_gather(pidxb + (size_t)rank * slab, pidxb, slab * sizeof(int), s);
+            launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s, tp, slab);
+            if (logits_out || after_group)         // full rows only when somebody reads them (host copy / device sampler)
+                for (int b = 0; b < nb; ++b)
+                    rccl->all_gather(logitsb + (size_t)b * cfg.V + (size_t)rank * V_l, logitsb + (size_t)b * cfg.V, (size_t)V_l * sizeof(float), s);
+        } else {
+            launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
+        }
         }
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
         if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -246,24 +246,32 @@ def test_rccl_code_path_single_rank(tp_graph, monkeypatch):
     monkeypatch.setenv("CM_TP_GRAPH", tp_graph)
     cfg = configs.get_config("tiny-qwen3-untied")
     ids = configs.synthetic_prompt(40, cfg["vocab_size"])
-    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2)
+    def batched(m):        # cm_decode_batch: 3 sequences (matrix-core GEMVs), all-reduce of [3, H] + in-place gathers
+        seqs = [0, m.seq_alloc(), m.seq_alloc()]
+        for i, s in enumerate(seqs):
+            m.seq_forward(s, ids[: 9 + 4 * i], 0, want_logits=False)
+        return m.step_batch_decode(seqs, [7, 8, 9])
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4)
     try:
         a = m.forward_step(ids, 0)[0, 0]
         a2 = m.forward_step([7], 40)[0, 0]
+        a3, g3 = batched(m)
     finally:
         m.close()
     os.environ["CM_FORCE_RCCL"] = "1"
     try:
-        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2)
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4)
         try:
             b = m.forward_step(ids, 0)[0, 0]
             b2 = m.forward_step([7], 40)[0, 0]
+            b3, h3 = batched(m)
             toks = m.generate(ids[:5], GenerationConfig.greedy(6), sync_every=3)
         finally:
             m.close()
     finally:
         del os.environ["CM_FORCE_RCCL"]
     assert rel(b, a) < 1e-6 and rel(b2, a2) < 1e-6 and len(toks) == 11
+    assert rel(b3, a3) < 1e-6 and list(h3) == list(g3)
 
 
 @pytest.mark.parametrize("nseq", [2, 3, 8, 11])

@@ -92,3 +92,43 @@ def test_dense_rank_shards_isq_q8_0(monkeypatch):
         got_a, got_b = _run_rank(cfg, rank, world, ids, isq="q8_0")
         v = slice(plan.vocab.start, plan.vocab.stop)
         assert rel(got_a[v], o.forward(ids, 0)) < 2e-4 and rel(got_b[v], o.forward([5], len(ids))) < 2e-4
+
+
+@pytest.mark.parametrize("name,nb", [("tiny-qwen3-untied", 2), ("tiny-qwen3-untied", 5), ("tiny-qwen3.5", 3)])
+def test_batched_decode_on_a_rank(name, nb):
+    """cm_decode_batch under TP: the row-parallel projections of all sequences go through ONE all-reduce per layer and the
+    vocabulary-sharded lm_head through one gather.  With CM_TP_FAKE a rank's batched step must agree with its own
+    single-sequence steps on its vocabulary slice (logits and rank-local arg-max)."""
+    from crane_amd.backend import Model
+    cfg = configs.get_config(name)
+    V = cfg["vocab_size"]
+    world = 2
+    for rank in range(world):
+        plan = tp.shard_plan(cfg, world, rank)
+        v = slice(plan.vocab.start, plan.vocab.stop)
+        os.environ["CM_TP_FAKE"] = "1"
+        try:
+            m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=12, kv_dtype="f32", tp_rank=rank, tp_size=world,
+                                tp_unique_id=b"\0" * 128)
+        finally:
+            del os.environ["CM_TP_FAKE"]
+        try:
+            seqs, toks = [], []
+            for b in range(nb):
+                s = 0 if b == 0 else m.seq_alloc()
+                _, g = m.seq_forward(s, [(7 * i + 3 + 11 * b) % V for i in range(5 + 3 * b)], 0, want_logits=False)
+                seqs.append(s); toks.append(int(g))
+            for r in range(2):
+                want = []
+                for s, t in zip(seqs, toks):
+                    f = m.seq_fork(s)
+                    lg, g = m.seq_forward(f, [t], m.seq_len(f))
+                    want.append((lg.reshape(-1)[v].copy(), int(g)))
+                    m.seq_free(f)
+                lg, greedy = m.step_batch_decode(seqs, toks)
+                for b in range(nb):
+                    assert rel(lg[b, 0][v], want[b][0]) < 3e-5, (rank, r, b)
+                    assert int(greedy[b]) == want[b][1]
+                toks = [int(g) for g in greedy]
+        finally:
+            m.close()
