@@ -188,11 +188,11 @@ int cm_decode_batch(cm_model* h, const int32_t* seqs, const uint32_t* last_token
     return guard(h, [&] {
         if (!seqs || !last_tokens || n == 0) throw CmError(CM_ERR_INVALID, "empty batch");
         // One pass over the weights for up to 8 sequences at a time (kernels_decode_batch.hip); a single sequence, and
-        // the combinations the batched step does not cover (TP over quantised weights, TP with a vocabulary that does
-        // not divide), take the ordinary decode path one sequence at a time.
+        // the combinations the batched step does not cover (quantised weights with f32 activations, TP with a vocabulary
+        // that does not divide), take the ordinary decode path one sequence at a time.
         const size_t V = (size_t)h->m.cfg.V;
-        const bool tp_batched = !h->m.rccl || (!h->m.quantized && h->m.cfg.V % h->m.tp == 0);
-        if (n >= 2 && tp_batched) { h->m.decode_batch(seqs, last_tokens, n, logits_out, greedy_out); return; }
+        const bool batched = (!h->m.rccl || h->m.cfg.V % h->m.tp == 0) && (!h->m.quantized || h->m.quant_act_int);
+        if (n >= 2 && batched) { h->m.decode_batch(seqs, last_tokens, n, logits_out, greedy_out); return; }
         for (size_t i = 0; i < n; ++i) {
             const int64_t len = cm_seq_len(h, seqs[i]);
             if (len < 0) throw CmError(CM_ERR_INVALID, "invalid sequence handle in batch");

@@ -158,7 +158,7 @@ struct Engine {
         if (batch.empty()) return;
         stats.decode_rounds++;
         try {
-            if (batch.size() == 1 || (m->rccl && (m->quantized || m->cfg.V % m->tp != 0)) || (m->quantized && !m->quant_act_int)) {
+            if (batch.size() == 1 || (m->rccl && m->cfg.V % m->tp != 0) || (m->quantized && !m->quant_act_int)) {
                 // step_decode_sequential (engine/mod.rs:1064-1170): graph-replayed single-sequence step
                 for (uint64_t id : batch) {
                     Request& r = req(id);

@@ -858,7 +858,6 @@ void Model::ensure_batch_buffers() {
 
 void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, float* logits_out, uint32_t* greedy_out,
                          const std::function<void(size_t, int)>* after_group) {
-    if (rccl && quantized) throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights under tensor parallelism is not implemented");
     if (rccl && cfg.V % tp != 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode under tensor parallelism needs vocab_size divisible by tp_size");
     if (quantized && !quant_act_int)
         throw CmError(CM_ERR_UNSUPPORTED, "batched decode over quantised weights needs the integer-dot activation mode (CM_QUANT_ACT unset)");
@@ -934,6 +933,20 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (!launch_gemvqb(pro, epi, q, grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
             }
         };
+        auto qrp = [&](const QWeight& qw, const float* xin, int ldx) {        // quantised row-parallel projection + residual
+            if (!rccl) { qb(PRO_PLAIN, EPI_RESADD, qw, xin, ldx, nullptr, xb, H); return; }
+            const bool carry = rank == 0 || rccl->fake;
+            const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
+            if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
+            for (int m0 = 0; m0 < nb; m0 += cap) {
+                GemvQBArgs q{};
+                q.w = qw; q.x = xin + (size_t)m0 * ldx; q.y = yb + (size_t)m0 * H; q.res = xb + (size_t)m0 * H;
+                q.n_seq = std::min(cap, nb - m0); q.ldx = ldx; q.ldy = H; q.eps = cfg.eps;
+                const int grid = gemvqb_grid(qw.fmt, qw.N, qw.K, q.n_seq, num_cu);
+                if (!launch_gemvqb(PRO_PLAIN, carry ? EPI_RESADD : EPI_STORE, q, grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
+            }
+            rccl->all_reduce_sum_f32(yb, xb, (size_t)nb * H, s);
+        };
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
             if (!w.full) {
@@ -954,7 +967,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
                 launch_gdn(ga, s);
-                if (quantized) qb(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attnb, (int)at_cols, nullptr, xb, H);
+                if (quantized) qrp(w.q_out_proj, attnb, (int)at_cols);
                 else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
                 if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
@@ -980,7 +993,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                if (quantized) qb(PRO_PLAIN, EPI_RESADD, w.q_o, attnb, (int)at_cols, nullptr, xb, H);
+                if (quantized) qrp(w.q_o, attnb, (int)at_cols);
                 else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }
             }
@@ -992,36 +1005,38 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     qb(PRO_RMSNORM, EPI_STORE, w.q_up, xb, H, w.ln2, gu_tmpb + cfg.I, 2 * cfg.I);
                     launch_silu_mul(gu_tmpb, gu_tmpb + cfg.I, hbb, cfg.I, s, nb, 2 * cfg.I, I_l);
                 }
-                qb(PRO_PLAIN, EPI_RESADD, w.q_down, hbb, I_l, nullptr, xb, H);
+                qrp(w.q_down, hbb, I_l);
                 continue;
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
             rp(w.down, hbb, I_l, I_l);
         }
+        // lm_head over the vocabulary shard [v0, v0 + V_l) of this rank (TP = 1: the whole table): logits land in their
+        // columns of the [nb][V] rows, the per-block maxima in this rank's [MAXB][lm_gridb] slab of pmaxb / pidxb
+        const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+        const size_t slab = (size_t)MAXB * lm_gridb;
+        int lmg = 0;
         if (quantized && q_lm_head.fmt != QFMT_NONE) {
             const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
-            const int lmq = gemvqb_grid(q_lm_head.fmt, cfg.V, H, std::min(cap, nb), num_cu);
+            lmg = gemvqb_grid(q_lm_head.fmt, v_eff, H, std::min(cap, nb), num_cu);
             for (int m0 = 0; m0 < nb; m0 += cap) {
                 GemvQBArgs q{};
-                q.w = q_lm_head; q.x = xb + (size_t)m0 * H; q.nw = norm; q.y = logitsb + (size_t)m0 * cfg.V; q.res = q.y;
-                q.pmax = pmaxb + (size_t)m0 * lmq; q.pidx = pidxb + (size_t)m0 * lmq;
-                q.n_seq = std::min(cap, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
-                if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmq, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
+                q.w = q_lm_head.rows(0, v_eff); q.x = xb + (size_t)m0 * H; q.nw = norm;
+                q.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l; q.res = q.y;
+                q.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lmg; q.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lmg;
+                q.idx_base = v0; q.n_seq = std::min(cap, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
+                if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
             }
-            launch_argmax_final(pmaxb, pidxb, lmq, stb, ring, RING - 1, 0, nb, s);
         } else {
-        // vocabulary shard [v0, v0 + V_l) of this rank (TP = 1: the whole table): logits land in their columns of the
-        // [nb][V] rows, the per-block maxima in this rank's [MAXB][lmg] slab
-        const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
-        const size_t slab = (size_t)MAXB * lm_gridb;
-        GemvBArgs g{};
-        g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
-        g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab; g.pidx = pidxb + (size_t)rank * slab; g.idx_base = v0;
-        const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nb, H);
-        const int lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu) : gemvb_grid(v_eff, H, num_cu);
-        if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
-        else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+            GemvBArgs g{};
+            g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
+            g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab; g.pidx = pidxb + (size_t)rank * slab; g.idx_base = v0;
+            const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nb, H);
+            lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu) : gemvb_grid(v_eff, H, num_cu);
+            if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+            else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+        }
         if (rccl && !rccl->fake) {
             rccl->all_gather(pmaxb + (size_t)rank * slab, pmaxb, slab * sizeof(float), s);
             rccl->all_gather(pidxb + (size_t)rank * slab, pidxb, slab * sizeof(int), s);
@@ -1031,7 +1046,6 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     rccl->all_gather(logitsb + (size_t)b * cfg.V + (size_t)rank * V_l, logitsb + (size_t)b * cfg.V, (size_t)V_l * sizeof(float), s);
         } else {
             launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
-        }
         }
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
         if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -179,14 +179,18 @@ def test_quant_errors():
         del os.environ["CRANE_ISQ"]
     with pytest.raises(CraneError):
         Model.from_pretrained("/nonexistent/model.gguf")
-    os.environ["CM_QUANT_ACT"] = "f32"          # the batched step exists for the integer-dot activation mode only
+    os.environ["CM_QUANT_ACT"] = "f32"          # no batched kernel for f32 activations: cm_decode_batch steps one sequence at a time
     try:
         m = Model.synthetic(cfg, seed=0, isq="q8_0", max_seqs=4)
         try:
+            m.seq_forward(0, [4, 5], 0, want_logits=False)
             s = m.seq_alloc()
             m.seq_forward(s, [1, 2, 3], 0, want_logits=False)
-            with pytest.raises(CraneError, match="quantised"):
-                m.step_batch_decode([0, s], [1, 2])
+            f0, f1 = m.seq_fork(0), m.seq_fork(s)
+            w0, _ = m.seq_forward(f0, [1], 2)
+            w1, _ = m.seq_forward(f1, [2], 3)
+            lg, _ = m.step_batch_decode([0, s], [1, 2])
+            assert np.array_equal(lg[0, 0], w0.reshape(-1)) and np.array_equal(lg[1, 0], w1.reshape(-1))
         finally:
             m.close()
     finally:

@@ -94,8 +94,9 @@ def test_dense_rank_shards_isq_q8_0(monkeypatch):
         assert rel(got_a[v], o.forward(ids, 0)) < 2e-4 and rel(got_b[v], o.forward([5], len(ids))) < 2e-4
 
 
-@pytest.mark.parametrize("name,nb", [("tiny-qwen3-untied", 2), ("tiny-qwen3-untied", 5), ("tiny-qwen3.5", 3)])
-def test_batched_decode_on_a_rank(name, nb):
+@pytest.mark.parametrize("name,nb,isq", [("tiny-qwen3-untied", 2, None), ("tiny-qwen3-untied", 5, None), ("tiny-qwen3.5", 3, None),
+                                         ("tiny-qwen3-untied", 5, "q8_0")])
+def test_batched_decode_on_a_rank(name, nb, isq):
     """cm_decode_batch under TP: the row-parallel projections of all sequences go through ONE all-reduce per layer and the
     vocabulary-sharded lm_head through one gather.  With CM_TP_FAKE a rank's batched step must agree with its own
     single-sequence steps on its vocabulary slice (logits and rank-local arg-max)."""
@@ -109,7 +110,7 @@ def test_batched_decode_on_a_rank(name, nb):
         os.environ["CM_TP_FAKE"] = "1"
         try:
             m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=12, kv_dtype="f32", tp_rank=rank, tp_size=world,
-                                tp_unique_id=b"\0" * 128)
+                                tp_unique_id=b"\0" * 128, isq=isq)
         finally:
             del os.environ["CM_TP_FAKE"]
         try:
