@@ -312,7 +312,7 @@ static GemvCfg gemv_cfg(int K) {
     }
     if (eR > 0 && nch % eU == 0) return {eR, eU, eP};
     if (nch % 4 == 0) return {2, 4, 0};      // measured best on MI355X (profiles/r01_gemv_variant_sweep.log)
-    if (nch % 2 == 0) return {8, 2, 0};
+    if (nch % 2 == 0) return {2, 2, 1};      // K = 5120 / 17408 (Qwen3.8-27B): 106.2 tok/s vs 102.0 with {8, 2, 0}
     return {8, 1, 0};
 }
 
