@@ -61,6 +61,10 @@ struct GdnArgs {
     int proj_stride, out_stride;
     int start_pos, slot;         // used when st == nullptr (prefill)
     int S, NV, vpg, key_dim, layer_idx, gdn_layers;
+    float* pre_q = nullptr;      // prefill scratch (three-pass path): q^ [S][key_dim], k^ [S][key_dim], v [S][NV][V],
+    float* pre_k = nullptr;      //   {beta, decay} [S][NV][2]; null: always the fused kernel
+    float* pre_v = nullptr;
+    float* pre_bd = nullptr;
     int chunked = 0;            // value-head order: 0 Interleaved (HF: key head = v / vpg), 1 Chunked (llama.cpp GGUF: v % NK; ops/gdn/config.rs:13-22)
     int n_seq, batch_proj_stride, batch_out_stride;   // batched decode step (grid.y)
     float eps;

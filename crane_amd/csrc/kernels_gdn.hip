@@ -114,7 +114,157 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Prefill in three passes.  The fused kernel above walks a prompt with 4 barriers, two block reductions and a handful
+// of transcendental functions per token on ONE block per value head (~5 us per token and layer).  Everything except
+// the state recurrence is independent across tokens, so:
+//   gdn_pre_kernel  (grid S x (NK + NV)): conv + SiLU, L2 norms, q scale, beta, exp(g)  -> q^ k^ v beta decay per token
+//   gdn_scan_kernel (grid NV): the recurrence only; 4 threads share a state column (32 of the 128 k each, partial
+//                   sums folded with two quad shuffles), q^ / k^ of 8 tokens staged per barrier
+//   gdn_post_kernel (grid S x NV): gated RMSNorm of the raw y rows in place
+// Same per-token arithmetic as the fused kernel except that the two 128-term sums over k are folded 4 x 32.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void gdn_pre_kernel(GdnArgs a) {
+    constexpr int K = 128, V = 128, KER = 4;
+    __shared__ float red[4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = a.NV / a.vpg;
+    const int conv_dim = 2 * a.key_dim + a.NV * V;
+    const float* conv_state = a.conv_pool + ((size_t)a.slot * a.gdn_layers + a.layer_idx) * 2 * conv_dim * (KER - 1);
+    const float* cs_in = conv_state + (size_t)(a.start_pos & 1) * conv_dim * (KER - 1);
+    float* cs_out = a.conv_pool + ((size_t)a.slot * a.gdn_layers + a.layer_idx) * 2 * conv_dim * (KER - 1) +
+                    (size_t)((a.start_pos + a.S) & 1) * conv_dim * (KER - 1);
+    // input of channel c at token tt (tt < 0: the rolling window left by the previous call, oldest first)
+    auto xin = [&](int c, int tt) -> float {
+        return tt >= 0 ? a.proj[(size_t)tt * a.proj_stride + c] : cs_in[c * (KER - 1) + (KER - 1) + tt];
+    };
+    auto conv = [&](int c) -> float {
+        const float x0 = xin(c, t - 3), x1 = xin(c, t - 2), x2 = xin(c, t - 1), x3 = xin(c, t);
+        const float* w = a.conv_w + c * KER;
+        return silu_f(x0 * w[0] + x1 * w[1] + x2 * w[2] + x3 * w[3]);
+    };
+    auto roll = [&](int c) {                         // the last token's block leaves the window for the next call
+        if (t == a.S - 1) {
+#pragma unroll
+            for (int j = 0; j < KER - 1; ++j) cs_out[c * (KER - 1) + j] = xin(c, a.S - (KER - 1) + j);
+        }
+    };
+    const float* pr = a.proj + (size_t)t * a.proj_stride;
+    if ((int)blockIdx.y < nk) {                      // q and k of key head kh
+        const int kh = blockIdx.y, cq = kh * K + tid, ck = a.key_dim + kh * K + tid;
+        float q = conv(cq), k = conv(ck);
+        const float sq = wave_sum(q * q), sk = wave_sum(k * k);
+        if (lane == 0) { red[wave] = sq; red[2 + wave] = sk; }
+        __syncthreads();
+        q = q / sqrtf(red[0] + red[1] + 1e-6f) * 0.08838834764831845f;      // 1/sqrt(128)
+        k = k / sqrtf(red[2] + red[3] + 1e-6f);
+        a.pre_q[(size_t)t * a.key_dim + cq] = q;
+        a.pre_k[(size_t)t * a.key_dim + kh * K + tid] = k;
+        roll(cq); roll(ck);
+    } else {                                         // v, beta, decay of value head h
+        const int h = blockIdx.y - nk, cv = 2 * a.key_dim + h * V + tid;
+        a.pre_v[((size_t)t * a.NV + h) * V + tid] = conv(cv);
+        if (tid == 0) {
+            const float beta = 1.0f / (1.0f + expf(-pr[conv_dim + a.NV * V + h]));
+            const float av = pr[conv_dim + a.NV * V + a.NV + h] + a.dt_bias[h];
+            const float g = -expf(a.A_log[h]) * logf(1.0f + expf(av));
+            a.pre_bd[((size_t)t * a.NV + h) * 2] = beta;
+            a.pre_bd[((size_t)t * a.NV + h) * 2 + 1] = expf(g);
+        }
+        roll(cv);
+    }
+}
+
+// grid = NV, block = 512: thread = (column v = tid / 4, k-slice ks = tid % 4)
+__global__ __launch_bounds__(512) void gdn_scan_kernel(GdnArgs a) {
+    constexpr int K = 128, V = 128, KS = 4, KP = K / KS, TB = 8;
+    __shared__ __attribute__((aligned(16))) float qk[2][TB][2][K];      // double-buffered q^ / k^ of TB tokens
+    __shared__ float bd[2][TB][2];
+    const int h = blockIdx.x, tid = threadIdx.x, v = tid >> 2, ks = tid & 3;
+    const int nk = a.NV / a.vpg;
+    const int kh = a.chunked ? h % nk : h / a.vpg;
+    float* Sg = a.state_pool + (((size_t)a.slot * a.gdn_layers + a.layer_idx) * a.NV + h) * K * V;
+    float S[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) S[k] = Sg[(ks * KP + k) * V + v];
+    auto stage = [&](int buf, int t0) {              // 2048 floats of q^ / k^ by 512 threads, + beta / decay
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 512 * i, tt = e >> 8, which = (e >> 7) & 1, kk = e & 127;
+            const int t = min(t0 + tt, a.S - 1);
+            qk[buf][tt][which][kk] = (which ? a.pre_k : a.pre_q)[(size_t)t * a.key_dim + kh * K + kk];
+        }
+        if (tid < 2 * TB) {
+            const int t = min(t0 + (tid >> 1), a.S - 1);
+            bd[buf][tid >> 1][tid & 1] = a.pre_bd[((size_t)t * a.NV + h) * 2 + (tid & 1)];
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int t0 = 0; t0 < a.S; t0 += TB) {
+        const int buf = (t0 / TB) & 1;
+        if (t0 + TB < a.S) stage(buf ^ 1, t0 + TB);
+        const int nt = min(TB, a.S - t0);
+        float vv[TB];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) vv[i] = a.pre_v[((size_t)min(t0 + i, a.S - 1) * a.NV + h) * V + v];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            if (i >= nt) break;
+            const float beta = bd[buf][i][0], decay = bd[buf][i][1];
+            const f32x4* kp = (const f32x4*)&qk[buf][i][1][ks * KP];
+            const f32x4* qp = (const f32x4*)&qk[buf][i][0][ks * KP];
+            float kv = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < KP / 4; ++k4) {
+                const f32x4 kk = kp[k4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { S[k4 * 4 + e] *= decay; kv += S[k4 * 4 + e] * kk[e]; }
+            }
+            kv += dpp_mov<0xB1>(kv);                 // fold the 4 k-slices of this column (lanes 4v .. 4v+3)
+            kv += dpp_mov<0x4E>(kv);
+            const float delta = (vv[i] - kv) * beta;
+            float y = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < KP / 4; ++k4) {
+                const f32x4 kk = kp[k4], qq = qp[k4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { S[k4 * 4 + e] += kk[e] * delta; y += S[k4 * 4 + e] * qq[e]; }
+            }
+            y += dpp_mov<0xB1>(y);
+            y += dpp_mov<0x4E>(y);
+            if (ks == 0) a.out[(size_t)(t0 + i) * a.out_stride + h * V + v] = y;      // raw; gdn_post_kernel normalises
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) Sg[(ks * KP + k) * V + v] = S[k];
+}
+
+__global__ __launch_bounds__(128) void gdn_post_kernel(GdnArgs a) {
+    constexpr int V = 128;
+    __shared__ float red[2];
+    const int t = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int conv_dim = 2 * a.key_dim + a.NV * V;
+    float* o = a.out + (size_t)t * a.out_stride + h * V + tid;
+    const float y = *o;
+    const float sy = wave_sum(y * y);
+    if (lane == 0) red[wave] = sy;
+    __syncthreads();
+    const float rms = 1.0f / sqrtf((red[0] + red[1]) / (float)V + a.eps);
+    const float z = a.proj[(size_t)t * a.proj_stride + conv_dim + h * V + tid];
+    *o = y * rms * a.gnorm_w[tid] * silu_f(z);
+}
+
 void launch_gdn(const GdnArgs& a, hipStream_t s) {
+    // prompts: three passes (needs the scratch rows of ensure_prefill_buffers); decode steps and short tails: fused
+    if (a.st == nullptr && a.pre_q != nullptr && a.S >= 16 && a.n_seq <= 1) {
+        const int nk = a.NV / a.vpg;
+        hipLaunchKernelGGL(gdn_pre_kernel, dim3(a.S, nk + a.NV), dim3(128), 0, s, a);
+        hipLaunchKernelGGL(gdn_scan_kernel, dim3(a.NV), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(gdn_post_kernel, dim3(a.S, a.NV), dim3(128), 0, s, a);
+        return;
+    }
     hipLaunchKernelGGL(gdn_kernel, dim3(a.NV, a.n_seq > 0 ? a.n_seq : 1), dim3(128), 0, s, a);
 }
 

@@ -634,7 +634,13 @@ void Model::ensure_prefill_buffers() {
     pX = dalloc<float>((size_t)chunk * H);
     if (rccl) pY = dalloc<float>((size_t)chunk * H);
     pQKV = dalloc<float>((size_t)chunk * std::max(qkv_rows, in_proj_pad));
-    if (cfg.hybrid) pGY = dalloc<float>((size_t)chunk * cfg.value_dim());
+    if (cfg.hybrid) {
+        pGY = dalloc<float>((size_t)chunk * cfg.value_dim());
+        gdn_pre_q = dalloc<float>((size_t)chunk * cfg.key_dim());      // three-pass Gated-Delta-Net prefill (kernels_gdn.hip)
+        gdn_pre_k = dalloc<float>((size_t)chunk * cfg.key_dim());
+        gdn_pre_v = dalloc<float>((size_t)chunk * cfg.value_dim());
+        gdn_pre_bd = dalloc<float>((size_t)chunk * cfg.NV * 2);
+    }
     auto z = [&](size_t n) {
         uint16_t* p = dalloc<uint16_t>(n);
         CM_HIP(hipMemsetAsync(p, 0, n * sizeof(uint16_t), stream));
@@ -696,6 +702,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.slot = active_seq; ga.n_seq = 1;
+                ga.pre_q = gdn_pre_q; ga.pre_k = gdn_pre_k; ga.pre_v = gdn_pre_v; ga.pre_bd = gdn_pre_bd;
                 // the conv windows are double-buffered by position parity: every launch must advance an ODD
                 // number of positions, so an even chunk is scanned as (S-1) + 1
                 int done = 0;
