@@ -313,7 +313,10 @@ static GemvCfg gemv_cfg(int K) {
     if (eR > 0 && nch % eU == 0) return {eR, eU, eP};
     if (nch % 4 == 0) return {2, 4, 0};      // measured best on MI355X (profiles/r01_gemv_variant_sweep.log)
     if (nch % 2 == 0) return {2, 2, 1};      // K = 5120 / 17408 (Qwen3.8-27B): 106.2 tok/s vs 102.0 with {8, 2, 0}
-    return {8, 1, 0};
+    // odd chunk counts (K = 3584: Qwen3.5-0.8B down_proj): the whole row pair in one batch keeps 2 x nch loads in flight per
+    // wave AND two-row groups keep the wave count up for small N ({8, 1, 0} left 32 blocks for N = 1024: 0.8 TB/s)
+    if (nch == 1 || nch == 3 || nch == 5 || nch == 7) return {2, nch, 0};
+    return {2, 1, 1};
 }
 
 template <int PRO, int EPI>
@@ -329,6 +332,7 @@ static void launch_gemv_t(const GemvArgs& a, int grid, hipStream_t s) {
     CM_GEMV_CASE(4, 4, 0) CM_GEMV_CASE(4, 4, 1) CM_GEMV_CASE(4, 2, 0) CM_GEMV_CASE(4, 2, 1)
     CM_GEMV_CASE(8, 2, 0) CM_GEMV_CASE(8, 2, 1) CM_GEMV_CASE(8, 1, 0) CM_GEMV_CASE(8, 1, 1)
     CM_GEMV_CASE(2, 2, 1)
+    CM_GEMV_CASE(2, 1, 0) CM_GEMV_CASE(2, 3, 0) CM_GEMV_CASE(2, 5, 0) CM_GEMV_CASE(2, 7, 0) CM_GEMV_CASE(2, 1, 1)
 #undef CM_GEMV_CASE
     hipLaunchKernelGGL((gemv_bf16_kernel<PRO, EPI, 8, 1, false, false>), g, b, lds, s, a);
 }

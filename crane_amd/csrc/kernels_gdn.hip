@@ -88,13 +88,15 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
         const float decay = expf(g);
         __syncthreads();
         // ---- recurrence on my column ----
-        float kv = 0.f;
+        float kv4[4] = {0.f, 0.f, 0.f, 0.f};                     // 4 independent chains instead of one 128-deep dependent one
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) { S[kk] *= decay; kv += S[kk] * ks[kk]; }
+        for (int kk = 0; kk < K; ++kk) { S[kk] *= decay; kv4[kk & 3] += S[kk] * ks[kk]; }
+        const float kv = (kv4[0] + kv4[1]) + (kv4[2] + kv4[3]);
         const float delta = (v - kv) * beta;
-        float y = 0.f;
+        float y4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) { S[kk] += ks[kk] * delta; y += S[kk] * qs[kk]; }
+        for (int kk = 0; kk < K; ++kk) { S[kk] += ks[kk] * delta; y4[kk & 3] += S[kk] * qs[kk]; }
+        const float y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
         // ---- gated RMSNorm over the value head ----
         const float sy = wave_sum(y * y);
         if (lane == 0) red[4 + wave] = sy;
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
 // of transcendental functions per token on ONE block per value head (~5 us per token and layer).  Everything except
 // the state recurrence is independent across tokens, so:
 //   gdn_pre_kernel  (grid S x (NK + NV)): conv + SiLU, L2 norms, q scale, beta, exp(g)  -> q^ k^ v beta decay per token
-//   gdn_scan_kernel (grid NV): the recurrence only; 4 threads share a state column (32 of the 128 k each, partial
-//                   sums folded with two quad shuffles), q^ / k^ of 8 tokens staged per barrier
+//   gdn_scan_kernel (grid NV x 4): the recurrence only; 16 lanes share a state column (8 of the 128 k each, partial
+//                   sums folded with one DPP row reduction), q^ / k^ of 8 tokens staged per barrier
 //   gdn_post_kernel (grid S x NV): gated RMSNorm of the raw y rows in place
-// Same per-token arithmetic as the fused kernel except that the two 128-term sums over k are folded 4 x 32.
+// Same per-token arithmetic as the fused kernel except for the association of the two 128-term sums over k.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void gdn_pre_kernel(GdnArgs a) {
     constexpr int K = 128, V = 128, KER = 4;
@@ -175,66 +177,73 @@ __global__ __launch_bounds__(128) void gdn_pre_kernel(GdnArgs a) {
     }
 }
 
-// grid = NV, block = 512: thread = (column v = tid / 4, k-slice ks = tid % 4)
+// grid = (NV, V / 32), block = 512: thread = (column v = 32 * blockIdx.y + tid / 16, k-slice ks = tid % 16: 8 of the 128 k).
+// The recurrence is VALU-issue-bound (4 lane-ops per state element and token), so a value head is spread over 4 CUs and
+// 16 lanes share a column: ~50 instructions per token and wave instead of 160 (4 lanes per column, one CU per head:
+// 0.59 us per token).  The 16 partial sums of a column are one DPP row reduction.
 __global__ __launch_bounds__(512) void gdn_scan_kernel(GdnArgs a) {
-    constexpr int K = 128, V = 128, KS = 4, KP = K / KS, TB = 8;
+    constexpr int K = 128, V = 128, KS = 16, KP = K / KS, CB = 32, TB = 8;
     __shared__ __attribute__((aligned(16))) float qk[2][TB][2][K];      // double-buffered q^ / k^ of TB tokens
     __shared__ float bd[2][TB][2];
-    const int h = blockIdx.x, tid = threadIdx.x, v = tid >> 2, ks = tid & 3;
+    const int h = blockIdx.x, tid = threadIdx.x, v = blockIdx.y * CB + (tid >> 4), ks = tid & 15;
     const int nk = a.NV / a.vpg;
     const int kh = a.chunked ? h % nk : h / a.vpg;
     float* Sg = a.state_pool + (((size_t)a.slot * a.gdn_layers + a.layer_idx) * a.NV + h) * K * V;
     float S[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) S[k] = Sg[(ks * KP + k) * V + v];
-    auto stage = [&](int buf, int t0) {              // 2048 floats of q^ / k^ by 512 threads, + beta / decay
+    // The next batch of TB tokens (q^ / k^ rows, beta / decay, this column's v values) is requested into REGISTERS before
+    // the current batch is consumed and parked in LDS after it: the loads have a whole batch of compute to arrive.
+    float rq[4], rbd = 0.f, vvn[TB], vv[TB];
+    auto fetch = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 512 * i, tt = e >> 8, which = (e >> 7) & 1, kk = e & 127;
             const int t = min(t0 + tt, a.S - 1);
-            qk[buf][tt][which][kk] = (which ? a.pre_k : a.pre_q)[(size_t)t * a.key_dim + kh * K + kk];
+            rq[i] = (which ? a.pre_k : a.pre_q)[(size_t)t * a.key_dim + kh * K + kk];
         }
-        if (tid < 2 * TB) {
-            const int t = min(t0 + (tid >> 1), a.S - 1);
-            bd[buf][tid >> 1][tid & 1] = a.pre_bd[((size_t)t * a.NV + h) * 2 + (tid & 1)];
-        }
+        if (tid < 2 * TB) rbd = a.pre_bd[((size_t)min(t0 + (tid >> 1), a.S - 1) * a.NV + h) * 2 + (tid & 1)];
+#pragma unroll
+        for (int i = 0; i < TB; ++i) vvn[i] = a.pre_v[((size_t)min(t0 + i, a.S - 1) * a.NV + h) * V + v];
     };
-    stage(0, 0);
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 512 * i, tt = e >> 8, which = (e >> 7) & 1, kk = e & 127;
+            qk[buf][tt][which][kk] = rq[i];
+        }
+        if (tid < 2 * TB) bd[buf][tid >> 1][tid & 1] = rbd;
+#pragma unroll
+        for (int i = 0; i < TB; ++i) vv[i] = vvn[i];
+    };
+    fetch(0);
+    park(0);
     __syncthreads();
     for (int t0 = 0; t0 < a.S; t0 += TB) {
         const int buf = (t0 / TB) & 1;
-        if (t0 + TB < a.S) stage(buf ^ 1, t0 + TB);
+        fetch(min(t0 + TB, a.S - 1));                // unconditional (clamped): no load under a branch
         const int nt = min(TB, a.S - t0);
-        float vv[TB];
-#pragma unroll
-        for (int i = 0; i < TB; ++i) vv[i] = a.pre_v[((size_t)min(t0 + i, a.S - 1) * a.NV + h) * V + v];
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
             if (i >= nt) break;
             const float beta = bd[buf][i][0], decay = bd[buf][i][1];
             const f32x4* kp = (const f32x4*)&qk[buf][i][1][ks * KP];
             const f32x4* qp = (const f32x4*)&qk[buf][i][0][ks * KP];
-            float kv = 0.f;
+            const f32x4 ka = kp[0], kb = kp[1], qa = qp[0], qb = qp[1];
+            const float kf[KP] = {ka[0], ka[1], ka[2], ka[3], kb[0], kb[1], kb[2], kb[3]};
+            const float qf[KP] = {qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
+            float kv2[2] = {0.f, 0.f};
 #pragma unroll
-            for (int k4 = 0; k4 < KP / 4; ++k4) {
-                const f32x4 kk = kp[k4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { S[k4 * 4 + e] *= decay; kv += S[k4 * 4 + e] * kk[e]; }
-            }
-            kv += dpp_mov<0xB1>(kv);                 // fold the 4 k-slices of this column (lanes 4v .. 4v+3)
-            kv += dpp_mov<0x4E>(kv);
+            for (int k = 0; k < KP; ++k) { S[k] *= decay; kv2[k & 1] += S[k] * kf[k]; }
+            const float kv = row16_sum(kv2[0] + kv2[1]);          // the 16 k-slices of this column are one DPP row
             const float delta = (vv[i] - kv) * beta;
-            float y = 0.f;
+            float y2[2] = {0.f, 0.f};
 #pragma unroll
-            for (int k4 = 0; k4 < KP / 4; ++k4) {
-                const f32x4 kk = kp[k4], qq = qp[k4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { S[k4 * 4 + e] += kk[e] * delta; y += S[k4 * 4 + e] * qq[e]; }
-            }
-            y += dpp_mov<0xB1>(y);
-            y += dpp_mov<0x4E>(y);
+            for (int k = 0; k < KP; ++k) { S[k] += kf[k] * delta; y2[k & 1] += S[k] * qf[k]; }
+            const float y = row16_sum(y2[0] + y2[1]);
             if (ks == 0) a.out[(size_t)(t0 + i) * a.out_stride + h * V + v] = y;      // raw; gdn_post_kernel normalises
         }
+        park(buf ^ 1);                               // the other buffer was consumed one iteration ago (barrier below)
         __syncthreads();
     }
 #pragma unroll
@@ -261,7 +270,7 @@ void launch_gdn(const GdnArgs& a, hipStream_t s) {
     if (a.st == nullptr && a.pre_q != nullptr && a.S >= 16 && a.n_seq <= 1) {
         const int nk = a.NV / a.vpg;
         hipLaunchKernelGGL(gdn_pre_kernel, dim3(a.S, nk + a.NV), dim3(128), 0, s, a);
-        hipLaunchKernelGGL(gdn_scan_kernel, dim3(a.NV), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(gdn_scan_kernel, dim3(a.NV, 4), dim3(512), 0, s, a);
         hipLaunchKernelGGL(gdn_post_kernel, dim3(a.S, a.NV), dim3(128), 0, s, a);
         return;
     }
