@@ -314,6 +314,26 @@ int cm_engine_step(cm_engine* h, cm_engine_event* ev, size_t cap, size_t* n) {
     return rc;
 }
 
+int cm_engine_step_many(cm_engine* h, size_t max_steps, cm_engine_event* ev, size_t cap, size_t* n) {
+    if (!h || !n || !ev || cap == 0) return CM_ERR_INVALID;
+    cm::Engine& e = h->e;
+    int rc = CM_OK;
+    // a step emits at most 2 events per running sequence (token + finished); stop while that still fits in `cap`
+    const size_t per_step = 2 * (size_t)std::max<long>(1, e.opts.max_running > 0 ? (long)e.opts.max_running : (long)e.m->seqs.size());
+    try {
+        (void)hipSetDevice(e.m->dev);
+        for (size_t i = 0; i < max_steps && e.events.size() + per_step <= cap; ++i) {
+            if (e.waiting.empty() && e.running.empty()) break;
+            e.step();
+        }
+    } catch (const CmError& x) { e.err = x.what(); rc = x.code; }
+    catch (const std::exception& x) { e.err = x.what(); rc = CM_ERR_INVALID; }
+    size_t k = 0;
+    while (k < cap && !e.events.empty()) { ev[k++] = e.events.front(); e.events.pop_front(); }
+    *n = k;
+    return rc;
+}
+
 int cm_engine_has_work(const cm_engine* h) {
     if (!h) return 0;
     return (!h->e.waiting.empty() || !h->e.running.empty() || !h->e.events.empty()) ? 1 : 0;

@@ -101,9 +101,13 @@ class InferenceEngine:
     def has_work(self) -> bool:
         return bool(self._lib.cm_engine_has_work(self._h))
 
-    def step(self) -> List[Event]:
+    def step(self, max_steps: int = 1) -> List[Event]:
+        """One scheduling decision (max_steps = 1, cm_engine_step) or up to max_steps of them in one native call."""
         n = C.c_size_t(0)
-        rc = self._lib.cm_engine_step(self._h, self._ev, len(self._ev), C.byref(n))
+        if max_steps <= 1:
+            rc = self._lib.cm_engine_step(self._h, self._ev, len(self._ev), C.byref(n))
+        else:
+            rc = self._lib.cm_engine_step_many(self._h, max_steps, self._ev, len(self._ev), C.byref(n))
         if rc != 0:
             self._err(rc)
         out = []
@@ -119,14 +123,14 @@ class InferenceEngine:
         self._lib.cm_engine_get_stats(self._h, C.byref(s))
         return {n: int(getattr(s, n)) for n, _ in s._fields_ if n != "reserved"}
 
-    def run_until_idle(self, max_steps: int = 1 << 20):
+    def run_until_idle(self, max_steps: int = 1 << 20, steps_per_call: int = 1):
         """Drive the loop; returns ({req_id: generated tokens}, {req_id: finished Event})."""
         toks: Dict[int, List[int]] = {}
         done: Dict[int, Event] = {}
         for _ in range(max_steps):
             if not self.has_work():
                 break
-            for e in self.step():
+            for e in self.step(steps_per_call):
                 if e.kind == "token":
                     toks.setdefault(e.req_id, []).append(e.token)
                 else:

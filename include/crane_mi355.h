@@ -305,6 +305,9 @@ int  cm_engine_cancel(cm_engine* e, uint64_t req_id);
 /* One scheduling decision + its execution (Scheduler::schedule + execute_step).  Writes up to `cap` events and
  * keeps the rest queued for the next call; *n_events = 0 with no work left means idle. */
 int  cm_engine_step(cm_engine* e, cm_engine_event* events, size_t cap, size_t* n_events);
+/* Up to `max_steps` scheduling decisions in one call (stops early when the engine is idle or the next step's events
+ * might not fit in `cap`): amortises the caller's per-step overhead; same event stream as repeated cm_engine_step. */
+int  cm_engine_step_many(cm_engine* e, size_t max_steps, cm_engine_event* events, size_t cap, size_t* n_events);
 int  cm_engine_has_work(const cm_engine* e);
 int  cm_engine_get_stats(const cm_engine* e, cm_engine_stats* out);
 const char* cm_engine_last_error(const cm_engine* e);

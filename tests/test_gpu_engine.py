@@ -166,3 +166,25 @@ def test_sampled_requests_are_seeded_and_bounded():
         assert toks[rid] == _reference_greedy(m, prompts[0], 10)
     finally:
         m.close()
+
+
+def test_step_many_matches_single_steps():
+    """cm_engine_step_many: several scheduling decisions per native call, same event stream."""
+    from crane_amd import configs
+    from crane_amd.backend import Model
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    cfg = configs.get_config("tiny-qwen3")
+    V = cfg["vocab_size"]
+    outs = []
+    for spc in (1, 5):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=8)
+        try:
+            eng = InferenceEngine(m, max_running=3)
+            ids = [eng.submit([(7 * k + 3 + 13 * i) % V for k in range(6 + i)],
+                              GenerationParams.greedy(9) if i % 2 else GenerationParams(max_tokens=9, seed=5)) for i in range(6)]
+            toks, done = eng.run_until_idle(steps_per_call=spc)
+            outs.append(([toks[i] for i in ids], [done[i].finish_reason for i in ids]))
+            eng.close()
+        finally:
+            m.close()
+    assert outs[0] == outs[1]

@@ -8,6 +8,7 @@ from crane_amd.engine import GenerationParams, InferenceEngine
 
 model = sys.argv[1] if len(sys.argv) > 1 else "qwen3-8b"
 N, P, G = (int(x) for x in (sys.argv[2:5] + ["32", "128", "128"][len(sys.argv[2:5]):]))
+SPC = int(sys.argv[5]) if len(sys.argv) > 5 else 1          # scheduler steps per native call (cm_engine_step_many)
 cfg = configs.get_config(model)
 m = Model.synthetic(cfg, seed=0, max_seq_len=P + G + 64, max_seqs=9)
 V = cfg["vocab_size"]
@@ -18,11 +19,11 @@ for label, params in [("greedy", GenerationParams.greedy(G)),
         for j in range(N):
             eng.submit([(7 * i + 3 + 11 * j) % V for i in range(P)], params)
         t0 = time.perf_counter()
-        toks, done = eng.run_until_idle()
+        toks, done = eng.run_until_idle(steps_per_call=SPC)
         dt = time.perf_counter() - t0
         st = eng.stats()
         n = sum(len(v) for v in toks.values())
-        print(f"{model} {label:55s} max_running={max_running}: {n} tokens in {dt:.2f}s = {n / dt:7.1f} tok/s "
+        print(f"{model} {label:55s} max_running={max_running} steps/call={SPC}: {n} tokens in {dt:.2f}s = {n / dt:7.1f} tok/s "
               f"(prefill steps {st['prefill_steps']}, decode rounds {st['decode_rounds']}, preemptions {st['preemptions']})", flush=True)
         eng.close()
 m.close()
