@@ -207,8 +207,8 @@ __global__ void add_rows_kernel(float* __restrict__ x, const float* __restrict__
 // bf16 MFMA GEMM, 128x128x32 tiles, 4 waves (2x2), each wave 64x64 = 4x4 mfma_f32_16x16x32_bf16.
 //   A: activation hi (+lo) [Mpad, K] row-major; W: [N, K] row-major (both K-contiguous, so both
 //   MFMA operands are plain 16-byte row segments); f32 accumulate.
-//   Register-staged double-buffered LDS (row stride 40 elements = 80 B: the 16 rows of a fragment
-//   read fall on 16 distinct 16-B bank slots).
+//   Double-buffered LDS (row stride 40 elements = 80 B: the 16 rows of a fragment read fall on 16 distinct
+//   16-B bank slots) fed from PD = 4 register stages of k-tile loads.
 // ---------------------------------------------------------------------------------------------
 constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 40;
 
