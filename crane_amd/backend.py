@@ -80,6 +80,21 @@ def _u32(ids: Sequence[int]):
     return arr, arr.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
+def gguf_config(path: str) -> dict:
+    """config.json as the loader derives it from a GGUF file (cm_gguf_config; host only, no GPU needed)."""
+    import json
+    lib = _lib.load()
+    need = C.c_size_t(0)
+    rc = lib.cm_gguf_config(path.encode(), None, 0, C.byref(need))
+    if rc != 0:
+        raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
+    buf = C.create_string_buffer(need.value)
+    rc = lib.cm_gguf_config(path.encode(), buf, need.value, C.byref(need))
+    if rc != 0:
+        raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
+    return json.loads(buf.value.decode())
+
+
 class Model:
     """One replica / TP rank of the MI355X inference path (qwen3::Model + ModelBackend)."""
 

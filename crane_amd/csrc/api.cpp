@@ -100,6 +100,16 @@ void cm_destroy(cm_model* h) {
 const char* cm_last_error(const cm_model* h) { return h ? h->m.err.c_str() : g_err.c_str(); }
 const char* cm_last_global_error(void) { return g_err.c_str(); }
 
+int cm_gguf_config(const char* path, char* json_out, size_t cap, size_t* needed) {
+    if (!path || !needed || (cap && !json_out)) { g_err = "null argument"; return CM_ERR_INVALID; }
+    return guard(nullptr, [&] {
+        const std::string cfg = cm::gguf_config_json(path);          // host only: mmap + metadata / tensor directory
+        *needed = cfg.size() + 1;
+        if (cap >= cfg.size() + 1) memcpy(json_out, cfg.c_str(), cfg.size() + 1);
+        else if (cap) throw CmError(CM_ERR_RANGE, "buffer too small for the config JSON");
+    });
+}
+
 int cm_tp_unique_id(void* out128) {
     if (!out128) { g_err = "null argument"; return CM_ERR_INVALID; }
     return guard(nullptr, [&] { cm::Rccl::unique_id(out128); });

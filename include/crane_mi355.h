@@ -106,6 +106,11 @@ const char* cm_last_global_error(void);
  * broadcasts it, e.g. over torch.distributed / the engine's own channel). */
 int cm_tp_unique_id(void* out128);
 
+/* The config.json the loader derives from a GGUF file's metadata and tensor directory (qwen3/model.rs:138-147,
+ * qwen3_5/model.rs:196-287: layer kinds from blk.i.ssm_a, tied head from a missing output.weight, ...).  Host only, no
+ * device needed.  *needed = bytes including the terminator; cap = 0 only queries the size.  Errors: cm_last_global_error. */
+int cm_gguf_config(const char* path, char* json_out, size_t cap, size_t* needed);
+
 /* ---- introspection (ModelBackend::num_layers/dtype/..., backend.rs:47-60) --- */
 size_t cm_num_layers(const cm_model* m);
 size_t cm_vocab_size(const cm_model* m);

@@ -1,0 +1,89 @@
+"""Host logic of the GGUF loader, no GPU: the config the C++ side derives from a file's metadata and tensor directory
+(cm_gguf_config; qwen3/model.rs:138-147, qwen3_5/model.rs:196-287) and the reader's error behaviour.  Files are written by
+oracle/gguf_oracle.py from the synthetic configs."""
+import struct
+
+import numpy as np
+import pytest
+
+from crane_amd import _lib, configs, synth
+from crane_amd.backend import gguf_config
+from oracle import gguf_oracle as G
+
+DENSE_KEYS = ("hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "head_dim",
+              "intermediate_size", "vocab_size", "max_position_embeddings", "tie_word_embeddings")
+HYBRID_KEYS = DENSE_KEYS + ("full_attention_interval", "linear_conv_kernel_dim", "linear_key_head_dim", "linear_value_head_dim",
+                            "linear_num_key_heads", "linear_num_value_heads", "attn_output_gate")
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k"])
+def test_dense_config_round_trip(tmp_path, name, kind):
+    cfg = configs.get_config(name)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / "m.gguf")
+    G.write_qwen3_gguf(path, cfg, w, lambda n, s: G.TYPE_NAMES[kind])
+    got = gguf_config(path)
+    assert got["model_type"] == "qwen3"
+    for k in DENSE_KEYS:
+        assert got[k] == cfg[k], (k, got[k], cfg[k])       # tied head: detected from the missing output.weight
+    assert abs(got["rope_theta"] - cfg["rope_theta"]) < 1 and abs(got["rms_norm_eps"] - cfg["rms_norm_eps"]) < 1e-9
+
+
+def test_hybrid_config_round_trip(tmp_path):
+    cfg = configs.get_config("tiny-qwen3.5")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / "h.gguf")
+    G.write_qwen35_gguf(path, cfg, w, lambda n, s: G.GGML_Q8_0)
+    got = gguf_config(path)
+    assert got["model_type"] == "qwen3_5_text"
+    for k in HYBRID_KEYS:
+        assert got[k] == cfg[k], (k, got[k], cfg[k])       # layer kinds from blk.i.ssm_a, output gate from attn_q's rows
+    rp, want = got["rope_parameters"], cfg["rope_parameters"]
+    assert rp["mrope_section"] == want["mrope_section"] and rp["partial_rotary_factor"] == want["partial_rotary_factor"]
+    assert abs(rp["rope_theta"] - want["rope_theta"]) < 1
+
+
+def _minimal(path, arch="qwen3", version=3, magic=0x46554747, drop=None, extra_tensor=None):
+    """A header-only GGUF (metadata + one tiny tensor) for the error paths."""
+    md = G.qwen3_metadata(configs.get_config("tiny-qwen3"))
+    md["general.architecture"] = (G.T_STR, arch)
+    if drop:
+        md.pop(drop)
+    tensors = [("token_embd.weight", np.zeros((512, 256), np.float32), G.GGML_F32)]
+    if extra_tensor:
+        tensors.append(extra_tensor)
+    G.write_gguf(path, md, tensors)
+    if magic != 0x46554747 or version != 3:
+        with open(path, "r+b") as f:
+            f.write(struct.pack("<II", magic, version))
+
+
+def test_reader_errors(tmp_path):
+    p = str(tmp_path / "x.gguf")
+    with pytest.raises(_lib.CraneError):
+        gguf_config(str(tmp_path / "missing.gguf"))
+    _minimal(p, magic=0x12345678)
+    with pytest.raises(_lib.CraneError, match="not a GGUF"):
+        gguf_config(p)
+    _minimal(p, version=1)
+    with pytest.raises(_lib.CraneError, match="version"):
+        gguf_config(p)
+    _minimal(p, arch="llama")
+    with pytest.raises(_lib.CraneError, match="llama"):
+        gguf_config(p)
+    _minimal(p, drop="qwen3.block_count")
+    with pytest.raises(_lib.CraneError, match="block_count"):
+        gguf_config(p)
+    _minimal(p)
+    with open(p, "r+b") as f:                                  # cut the file inside the tensor data
+        f.truncate(200)
+    with pytest.raises(_lib.CraneError):
+        gguf_config(p)
+
+
+def test_buffer_protocol():
+    import ctypes as C
+    lib = _lib.load()
+    need = C.c_size_t(0)
+    assert lib.cm_gguf_config(None, None, 0, C.byref(need)) != 0          # null path
