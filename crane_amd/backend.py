@@ -80,19 +80,29 @@ def _u32(ids: Sequence[int]):
     return arr, arr.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
-def gguf_config(path: str) -> dict:
-    """config.json as the loader derives it from a GGUF file (cm_gguf_config; host only, no GPU needed)."""
+def _host_json(fn_name: str, path: str) -> dict:
     import json
     lib = _lib.load()
+    fn = getattr(lib, fn_name)
     need = C.c_size_t(0)
-    rc = lib.cm_gguf_config(path.encode(), None, 0, C.byref(need))
+    rc = fn(path.encode(), None, 0, C.byref(need))
     if rc != 0:
         raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
     buf = C.create_string_buffer(need.value)
-    rc = lib.cm_gguf_config(path.encode(), buf, need.value, C.byref(need))
+    rc = fn(path.encode(), buf, need.value, C.byref(need))
     if rc != 0:
         raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
     return json.loads(buf.value.decode())
+
+
+def gguf_config(path: str) -> dict:
+    """config.json as the loader derives it from a GGUF file (cm_gguf_config; host only, no GPU needed)."""
+    return _host_json("cm_gguf_config", path)
+
+
+def checkpoint_inspect(model_dir: str) -> dict:
+    """Tensor directory of a (sharded) safetensors checkpoint as the C++ loader sees it (cm_checkpoint_inspect; host only)."""
+    return _host_json("cm_checkpoint_inspect", model_dir)
 
 
 class Model:

@@ -100,6 +100,33 @@ void cm_destroy(cm_model* h) {
 const char* cm_last_error(const cm_model* h) { return h ? h->m.err.c_str() : g_err.c_str(); }
 const char* cm_last_global_error(void) { return g_err.c_str(); }
 
+static void emit(const std::string& txt, char* out, size_t cap, size_t* needed) {
+    *needed = txt.size() + 1;
+    if (cap >= txt.size() + 1) memcpy(out, txt.c_str(), txt.size() + 1);
+    else if (cap) throw CmError(CM_ERR_RANGE, "buffer too small");
+}
+
+int cm_checkpoint_inspect(const char* model_dir, char* json_out, size_t cap, size_t* needed) {
+    if (!model_dir || !needed || (cap && !json_out)) { g_err = "null argument"; return CM_ERR_INVALID; }
+    return guard(nullptr, [&] {
+        // host only: the shard discovery + header parsing the loader runs before anything touches the device
+        cmst::Checkpoint ck(model_dir);
+        std::string js = "{";
+        bool first = true;
+        for (const std::string& n : ck.names()) {
+            const cmst::TensorView& t = ck.get(n);
+            uint64_t h = 1469598103934665603ull;                       // FNV-1a over the tensor bytes
+            for (size_t i = 0; i < t.nbytes; ++i) { h ^= t.data[i]; h *= 1099511628211ull; }
+            js += (first ? "\"" : ", \"") + n + "\": {\"dtype\": \"" + t.dtype + "\", \"shape\": [";
+            for (size_t i = 0; i < t.shape.size(); ++i) js += (i ? ", " : "") + std::to_string(t.shape[i]);
+            js += "], \"nbytes\": " + std::to_string(t.nbytes) + ", \"fnv1a\": \"" + std::to_string(h) + "\"}";
+            first = false;
+        }
+        js += "}";
+        emit(js, json_out, cap, needed);
+    });
+}
+
 int cm_gguf_config(const char* path, char* json_out, size_t cap, size_t* needed) {
     if (!path || !needed || (cap && !json_out)) { g_err = "null argument"; return CM_ERR_INVALID; }
     return guard(nullptr, [&] {

@@ -111,6 +111,11 @@ int cm_tp_unique_id(void* out128);
  * device needed.  *needed = bytes including the terminator; cap = 0 only queries the size.  Errors: cm_last_global_error. */
 int cm_gguf_config(const char* path, char* json_out, size_t cap, size_t* needed);
 
+/* Shard discovery + safetensors header parsing of a checkpoint directory (utils/utils.rs:16-57: model.safetensors.index.json,
+ * else model.safetensors, else every *.safetensors), host only: {"name": {"dtype", "shape", "nbytes", "fnv1a"}, ...} with
+ * an FNV-1a hash of each tensor's bytes.  Same buffer protocol as cm_gguf_config. */
+int cm_checkpoint_inspect(const char* model_dir, char* json_out, size_t cap, size_t* needed);
+
 /* ---- introspection (ModelBackend::num_layers/dtype/..., backend.rs:47-60) --- */
 size_t cm_num_layers(const cm_model* m);
 size_t cm_vocab_size(const cm_model* m);

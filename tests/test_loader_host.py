@@ -1,4 +1,4 @@
-"""Host logic of the GGUF loader, no GPU: the config the C++ side derives from a file's metadata and tensor directory
+"""Host logic of the loaders, no GPU: shard discovery + header parsing of safetensors checkpoints (cm_checkpoint_inspect) and the config the C++ side derives from a file's metadata and tensor directory
 (cm_gguf_config; qwen3/model.rs:138-147, qwen3_5/model.rs:196-287) and the reader's error behaviour.  Files are written by
 oracle/gguf_oracle.py from the synthetic configs."""
 import struct
@@ -87,3 +87,61 @@ def test_buffer_protocol():
     lib = _lib.load()
     need = C.c_size_t(0)
     assert lib.cm_gguf_config(None, None, 0, C.byref(need)) != 0          # null path
+
+
+def _fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_safetensors_shard_discovery(tmp_path, shards):
+    """cm_checkpoint_inspect: index.json weight_map / single file / header parsing (utils/utils.rs:16-57) in the C++ loader,
+    checked tensor by tensor (dtype, shape, byte hash) against the files read back in Python."""
+    import json, os
+    from crane_amd.backend import checkpoint_inspect
+    cfg = configs.get_config("tiny-qwen3-untied")
+    d = synth.write_model_dir(str(tmp_path / "m"), cfg, seed=0, shards=shards)
+    got = checkpoint_inspect(d)
+    want = {}
+    for fn in sorted(os.listdir(d)):
+        if not fn.endswith(".safetensors"):
+            continue
+        raw = open(os.path.join(d, fn), "rb").read()
+        (hl,) = struct.unpack("<Q", raw[:8])
+        hdr = json.loads(raw[8:8 + hl])
+        for name, t in hdr.items():
+            if name == "__metadata__":
+                continue
+            b, e = t["data_offsets"]
+            want[name] = (t["dtype"], t["shape"], _fnv1a(raw[8 + hl + b: 8 + hl + e]) if e - b <= 1 << 16 else None, e - b)
+    assert set(got) == set(want) == {n for n, *_ in synth.specs_for(cfg)}
+    for name, (dt, shape, h, nb) in want.items():
+        g = got[name]
+        assert g["dtype"] == dt and g["shape"] == shape and g["nbytes"] == nb
+        if h is not None:
+            assert int(g["fnv1a"]) == h, name
+
+
+def test_safetensors_errors(tmp_path):
+    from crane_amd.backend import checkpoint_inspect
+    with pytest.raises(_lib.CraneError):
+        checkpoint_inspect(str(tmp_path / "nope"))
+    d = tmp_path / "empty"
+    d.mkdir()
+    with pytest.raises(_lib.CraneError, match="no safetensors"):
+        checkpoint_inspect(str(d))
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    (bad / "model.safetensors").write_bytes(struct.pack("<Q", 1 << 40) + b"{}")
+    with pytest.raises(_lib.CraneError, match="header length"):
+        checkpoint_inspect(str(bad))
+    (bad / "model.safetensors").write_bytes(b"\x01")
+    with pytest.raises(_lib.CraneError, match="truncated"):
+        checkpoint_inspect(str(bad))
+    hdr = b'{"w": {"dtype": "F32", "shape": [4], "data_offsets": [0, 64]}}'
+    (bad / "model.safetensors").write_bytes(struct.pack("<Q", len(hdr)) + hdr + b"\0" * 16)
+    with pytest.raises(_lib.CraneError, match="out of file bounds"):
+        checkpoint_inspect(str(bad))
