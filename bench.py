@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: greedy decode tokens/s, Qwen3-8B bf16, context 1024 (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--model qwen3-8b|qwen3-0.6b|qwen3.5-0.8b|qwen3.8-27b]
 
-One "step" = one decode token through the whole model (36 layers + lm_head + arg-max) with
-weights and KV cache resident in HBM.  N = 1: TP=1 on one MI355X.  N > 1 (launched by
-`python -m torch.distributed.run --nproc-per-node N ...`): tensor parallel TP=N over RCCL/xGMI
-(attention heads + MLP columns sharded, 2 all-reduces per layer) -- total work is fixed, so
-`scaling` is "strong".  torch is used only for the rendezvous (gloo) around the timed region.
+One "step" = one decode token through the whole model (all layers + lm_head + arg-max) with weights and KV cache
+resident in HBM.  N = 1: TP=1 on one MI355X.  N > 1: tensor parallel TP=N over RCCL/xGMI (attention heads + MLP columns
+sharded, 2 all-reduces per layer); total work is fixed, so `scaling` is "strong".  The N ranks are one process per GPU:
+when this script is started WITHOUT a torch.distributed environment (`python bench.py --gpus N`) it re-launches itself
+under `python -m torch.distributed.run --nproc-per-node N`; started by torchrun it uses the ranks it was given.  Every
+rank creates its shard with tp_size = N, rank 0 creates the RCCL id, and the run aborts unless the library reports an
+N-rank communicator -- a TP=1 number can never be labelled as N GPUs.  torch is used only for the rendezvous (gloo).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel,
-HIP-event timed on the model's own stream) and `cpu_baseline` (oracle/c port on host cores).
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel, HIP-event timed on the model's
+own stream), `roofline_step` (whole step), `parity` (first tokens / logits of this very configuration against the CPU
+oracle) and `cpu_baseline` (oracle/c port on the host cores; rank 0, N = 1).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,16 +30,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def cpu_baseline(model_name: str, ctx: int, budget_s: float = 20.0):
-    """Time the C port of the reference's CPU decode path (oracle/c) on the host cores."""
+def cpu_leg(model_name: str, ctx: int, budget_s: float):
+    """oracle/c on the host cores: greedy decode of the same workload (KV filled with the device's synthetic values).
+    Returns (cpu_baseline dict, reference tokens, logits of the first step) -- the checker side of `parity`."""
     so = os.path.join(ROOT, "oracle", "c", "libqwen3_cpu.so")
     if not os.path.exists(so):
-        return None
-    try:
-        from oracle.c_oracle import time_decode
-        return time_decode(model_name, ctx, budget_s)
-    except Exception as e:  # baseline must never break the headline number
-        return {"error": str(e)}
+        return None, None, None
+    from oracle.c_oracle import time_decode
+    return time_decode(model_name, ctx, budget_s)
+
+
+def relaunch_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` (no torchrun): start the N ranks ourselves, one process per GPU."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s); refusing to report a {n}-GPU number",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -45,26 +66,35 @@ def main():
     ap.add_argument("--model", default="qwen3-8b")
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU decode steps for cpu_baseline / parity")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--engine", type=int, default=0, choices=[-1, 0, 1], help="persistent chain kernel: 1 require, -1 off, 0 library default")
     ap.add_argument("--kv", default="bf16", choices=["bf16", "f32", "int8", "int4"], help="KV cache element type (bf16 = headline)")
     ap.add_argument("--isq", default=None, help="in-situ weight quantisation (q8_0): a DIFFERENT workload than the bf16 headline")
     args = ap.parse_args()
 
+    n = args.gpus
+    if n < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if n > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(n))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = args.gpus
-    if world != n and world != 1:
-        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
+    if world != n:
+        raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}: one rank per GPU is required")
 
+    import numpy as np
+    import torch
     from crane_amd import configs
     from crane_amd.backend import Model
 
     dist = None
     uid = None
     if world > 1:
-        import torch
         import torch.distributed as dist
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} visible device(s)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from crane_amd import _lib
@@ -80,12 +110,13 @@ def main():
 
     cfg = configs.get_config(args.model)
     K, W, ctx = args.steps, args.warmup, args.ctx
-    import torch
-    ndev = max(1, torch.cuda.device_count())
-    m = Model.synthetic(cfg, seed=0, device=(local_rank % ndev) if world > 1 else 0,
+    m = Model.synthetic(cfg, seed=0, device=local_rank if world > 1 else 0,
                         max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1,
-                        use_graph=-1 if args.no_graph else 0,
-                        tp_rank=rank if world > 1 else 0, tp_size=world, tp_unique_id=uid, isq=args.isq, kv_dtype=args.kv)
+                        use_graph=-1 if args.no_graph else 0, engine=args.engine,
+                        tp_rank=rank, tp_size=world, tp_unique_id=uid, isq=args.isq, kv_dtype=args.kv)
+    ranks = m.tp_ranks()
+    if ranks != n:
+        raise SystemExit(f"library reports an RCCL communicator of {ranks} rank(s), expected {n}")
     m.debug_fill_kv(ctx, seed=1)            # synthetic KV for positions [0, ctx): inputs resident in HBM
     first = 3
     if W > 0:
@@ -96,12 +127,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    import torch
+    def dev_sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
     barrier()
-    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    dev_sync()
     t0 = time.perf_counter()
     toks, ev_ms = m.bench_decode(first, K)   # enqueues K steps, synchronises on the model's stream
-    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    dev_sync()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -114,23 +148,33 @@ def main():
     avg_ctx = ctx + W + K / 2.0
     bytes_tok_rank = m.decode_bytes_per_token(int(avg_ctx))
 
-    # dominant kernel: RMSNorm + gate||up GEMV + SiLU*mul (2/3 of the weight bytes), HIP-event timed
+    # dominant kernel, HIP-event timed on the model's stream over launches that cycle through the layers' weights:
+    # per-projection launches -> RMSNorm + gate||up GEMV + SiLU*mul (2/3 of the weight bytes); persistent path -> the
+    # chain launch itself (o_proj + gate||up + down_proj + next QKV: every weight byte of a layer)
     roof = None
+    dom = "chain" if m.engine_active() else "gate_up"
+    pmc_key = "engine_chain_kernel" if m.engine_active() else "gemv_bf16_kernel<1, 2,"
     try:
-        kb = m.bench_kernel("gate_up", 360)
+        kb = m.bench_kernel(dom, 360)
         roof = {"bound": "hbm", "kernel": kb["kernel"], "achieved": round(kb["bytes"] / (kb["ms"] * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "bytes_per_launch": kb["bytes"], "us_per_launch": round(kb["ms"] * 1e3, 3)}
         roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
         # PMC traffic cannot be collected inside this process: it comes from the committed rocprofv3 --pmc passes
-        # (profiles/r01_pmc_traffic_decode.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch
+        # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch
         try:
-            if args.model == "qwen3-8b" and not args.isq:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_decode.json")))
-                for r in pm["kernels"]:
-                    if "gemv_bf16_kernel<1, 2," in r["kernel"]:
-                        roof["traffic"] = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
-                        roof["traffic_source"] = "profiles/r01_pmc_traffic_decode.json"
+            if args.model == "qwen3-8b" and not args.isq and n == 1:
+                for src in ("r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json"):
+                    path = os.path.join(ROOT, "profiles", src)
+                    if not os.path.exists(path):
+                        continue
+                    pm = json.load(open(path))
+                    for r in pm["kernels"]:
+                        if pmc_key in r["kernel"]:
+                            roof["traffic"] = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
+                            roof["traffic_source"] = "profiles/" + src
+                    if roof["traffic"] is not None:
+                        break
         except Exception:
             pass
     except Exception as e:
@@ -139,30 +183,57 @@ def main():
     roof_step = {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(step_gbs / HBM_PEAK_GBS, 4), "bytes_per_token_per_gpu": bytes_tok_rank,
                  "event_ms_per_step": round(ev_ms / K, 4)}
+    if dist is not None:                       # every rank's own step figure (the shards differ by the vocabulary tail)
+        per = [None] * world
+        dist.all_gather_object(per, roof_step)
+        roof_step = {"rank0": roof_step, "per_rank": per}
 
     # prefill throughput (second half of BASELINE.json's metric): one 1024-token prompt, MFMA path
     prefill = None
     try:
-        import numpy as np
         if args.isq:
-            raise RuntimeError("quantised weights prefill token-serially; not measured here")
+            raise RuntimeError("quantised weights: not part of the bf16 headline")
         ids = configs.synthetic_prompt(1024, cfg["vocab_size"])
         m.clear_kv_cache(); m.forward_step_greedy(ids, 0)            # warm-up (allocates chunk buffers)
         m.clear_kv_cache()
+        barrier()
         tp0 = time.perf_counter(); m.forward_step_greedy(ids, 0); tp1 = time.perf_counter()
         prefill = {"tokens": 1024, "ms": round((tp1 - tp0) * 1e3, 3), "tokens_per_s": round(1024 / (tp1 - tp0), 1),
                    "activations": "bf16x2 split (parity mode)"}
     except Exception as e:
         prefill = {"error": str(e)}
 
-    cpu = None
+    # CPU leg (rank 0, one GPU): baseline + parity of THIS configuration (same synthetic weights, same synthetic KV)
+    cpu, parity = None, None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.model, ctx)
+        dense = cfg.get("model_type", "qwen3") == "qwen3"
+        if not dense:
+            cpu = {"skipped": "oracle/c restates the dense Qwen3 CPU path only; the hybrid family's checker is the numpy "
+                              "oracle (tests/), too slow to time at this size"}
+        else:
+            try:
+                cpu, ref_toks, ref_logits = cpu_leg(args.model, ctx, args.cpu_budget)
+                if ref_toks:
+                    m.debug_fill_kv(ctx, seed=1)
+                    got0 = m.forward_step([3], ctx)[0, 0]
+                    lrel = float(np.abs(got0 - ref_logits).max() / np.abs(ref_logits).max())
+                    m.debug_fill_kv(ctx, seed=1)
+                    gt, _ = m.bench_decode(3, len(ref_toks))
+                    gt = [int(t) for t in gt]
+                    eq = 0
+                    while eq < len(ref_toks) and gt[eq] == ref_toks[eq]:
+                        eq += 1
+                    parity = {"tokens_checked": len(ref_toks), "tokens_equal": eq, "logit_rel": float(f"{lrel:.3e}"),
+                              "reference": "oracle/c f32 forward, bf16-rounded KV appends, identical synthetic weights + KV",
+                              "ok": bool(eq == len(ref_toks) and lrel < 1e-3)}
+            except Exception as e:  # the baseline must never break the headline number
+                cpu = {"error": str(e)}
 
     wdt = args.isq or "bf16"
     if rank == 0:
+        headline = args.model == "qwen3-8b" and not args.isq and args.kv == "bf16" and ctx == 1024
         line = {
-            "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if (args.model == "qwen3-8b" and not args.isq and args.kv == "bf16" and ctx == 1024)
+            "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if headline
                       else f"decode tokens/s {args.model} {wdt} weights / {args.kv} KV greedy, ctx {ctx}",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": n, "steps": K, "warmup": W,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -170,8 +241,9 @@ def main():
             "dtype": "bf16" if not args.isq else f"{args.isq} weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
                                    f"{wdt} weights + {args.kv} paged KV, f32 activations",
-                       "parallelism": f"tp{n}", "graph": not args.no_graph},
-            "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "cpu_baseline": cpu,
+                       "parallelism": f"tp{n}", "rccl_ranks": ranks, "graph": not args.no_graph,
+                       "decode_path": "persistent chain kernel" if m.engine_active() else "per-projection launches"},
+            "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "parity": parity, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     m.close()

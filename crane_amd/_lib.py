@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "CM_OK", -1: "CM_ERR_INVALID", -2: "CM_ERR_IO", -3: "CM_ERR_U
 EXPORTS = [
     "cm_create", "cm_create_synthetic", "cm_destroy", "cm_last_error", "cm_last_global_error",
     "cm_tp_unique_id", "cm_num_layers", "cm_vocab_size", "cm_hidden_size", "cm_max_seq_len",
-    "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_forward_step",
+    "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_tp_ranks", "cm_engine_active", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
     "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
@@ -34,7 +34,8 @@ class CmOpts(C.Structure):
         ("tp_size", C.c_int32), ("tp_unique_id", C.c_void_p), ("max_seq_len", C.c_uint32),
         ("max_seqs", C.c_uint32), ("kv_block_size", C.c_uint32), ("kv_pool_tokens", C.c_uint64),
         ("kv_dtype", C.c_int32), ("use_graph", C.c_int32), ("prefill_chunk", C.c_uint32),
-        ("prefill_split", C.c_int32), ("isq", C.c_uint32), ("reserved", C.c_uint32 * 7),
+        ("prefill_split", C.c_int32), ("isq", C.c_uint32), ("engine", C.c_int32), ("debug_flags", C.c_uint32),
+        ("reserved", C.c_uint32 * 5),
     ]
 
 
@@ -119,6 +120,8 @@ def load():
     for n in ("cm_kv_bytes", "cm_weight_bytes"):
         getattr(lib, n).argtypes = [vp]
         getattr(lib, n).restype = C.c_uint64
+    lib.cm_tp_ranks.argtypes = [vp]
+    lib.cm_engine_active.argtypes = [vp]
     lib.cm_decode_bytes_per_token.argtypes = [vp, C.c_size_t]
     lib.cm_decode_bytes_per_token.restype = C.c_uint64
     lib.cm_forward_step.argtypes = [vp, u32p, C.c_size_t, C.c_size_t, f32p]

@@ -119,7 +119,7 @@ class Model:
     @staticmethod
     def _opts(device=0, max_seq_len=0, max_seqs=0, kv_block_size=0, kv_pool_tokens=0, use_graph=0,
               tp_rank=0, tp_size=1, tp_unique_id: Optional[bytes] = None, prefill_chunk=0, prefill_split=0,
-              kv_dtype="bf16", isq: Optional[str] = None):
+              kv_dtype="bf16", isq: Optional[str] = None, engine=0, debug_tp_local=False, debug_force_rccl=False):
         o = _lib.CmOpts()
         o.abi_version = _lib.CM_ABI_VERSION
         o.device, o.tp_rank, o.tp_size = device, tp_rank, tp_size
@@ -128,6 +128,8 @@ class Model:
         o.prefill_chunk, o.prefill_split = prefill_chunk, prefill_split
         o.kv_dtype = {"bf16": 0, "f32": 1, "int8": 2, "int4": 3}[kv_dtype]
         o.isq = {None: 0, "none": 0, "q8_0": 8}[isq.lower() if isinstance(isq, str) else isq]     # --quant / CRANE_ISQ
+        o.engine = int(engine)                                    # persistent chain kernel: 0 default, 1 require, -1 off
+        o.debug_flags = (1 if debug_tp_local else 0) | (2 if debug_force_rccl else 0)
         keep = None
         if tp_unique_id is not None:
             keep = C.create_string_buffer(bytes(tp_unique_id), 128)
@@ -370,7 +372,8 @@ class Model:
         return toks, float(ms.value)
 
     _KERNEL_NAMES = {"qkv": "gemv<rmsnorm,store>", "o": "gemv<plain,resadd>", "gate_up": "gemv<rmsnorm,silu_mul>",
-                     "down": "gemv<plain,resadd>", "lm_head": "gemv<rmsnorm,argmax>"}
+                     "down": "gemv<plain,resadd>", "lm_head": "gemv<rmsnorm,argmax>",
+                     "chain": "engine_chain<o_proj,gate_up,down_proj,next_qkv>"}
 
     def bench_kernel(self, which: str, iters: int = 360) -> dict:
         ms = C.c_float()
@@ -398,6 +401,13 @@ class Model:
 
     def weight_bytes(self) -> int:
         return int(self._lib.cm_weight_bytes(self._h))
+
+    def tp_ranks(self) -> int:
+        """ranks of the RCCL communicator (1: no tensor parallelism, 0: collectives are debug no-ops)"""
+        return int(self._lib.cm_tp_ranks(self._h))
+
+    def engine_active(self) -> bool:
+        return bool(self._lib.cm_engine_active(self._h))
 
 
 # the reference's adapter name for this family (backend.rs:609-748)

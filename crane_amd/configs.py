@@ -22,6 +22,18 @@ CONFIGS = {
     "qwen3-8b": dict(_QWEN3_COMMON, vocab_size=151936, hidden_size=4096, intermediate_size=12288,
                      num_hidden_layers=36, num_attention_heads=32, num_key_value_heads=8,
                      head_dim=128, tie_word_embeddings=False),
+    # the headline geometry (every projection shape, GQA group and the 151 936-row lm_head of Qwen3-8B) at a depth the
+    # CPU oracle finishes in seconds: the parity tests of the benchmarked kernel instantiations
+    "qwen3-8b-2l": dict(_QWEN3_COMMON, vocab_size=151936, hidden_size=4096, intermediate_size=12288,
+                        num_hidden_layers=2, num_attention_heads=32, num_key_value_heads=8,
+                        head_dim=128, tie_word_embeddings=False),
+    "qwen3-0.6b-2l": dict(_QWEN3_COMMON, vocab_size=151936, hidden_size=1024, intermediate_size=3072,
+                          num_hidden_layers=2, num_attention_heads=16, num_key_value_heads=8,
+                          head_dim=128, tie_word_embeddings=True),
+    # widths that are multiples of 2048 (what the persistent chain kernel needs), small enough for the numpy oracle
+    "eng-qwen3": dict(_QWEN3_COMMON, vocab_size=2048, hidden_size=2048, intermediate_size=4096,
+                      num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=8,
+                      head_dim=128, tie_word_embeddings=False, max_position_embeddings=8192),
     # small shapes for CPU-oracle parity
     "tiny-qwen3": dict(_QWEN3_COMMON, vocab_size=512, hidden_size=256, intermediate_size=512,
                        num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,

@@ -149,6 +149,12 @@ size_t cm_max_seq_len(const cm_model* h) { return h ? (size_t)h->m.max_seq : 0; 
 uint64_t cm_kv_bytes(const cm_model* h) { return h ? h->m.kv_bytes() : 0; }
 uint64_t cm_weight_bytes(const cm_model* h) { return h ? h->m.weight_bytes : 0; }
 uint64_t cm_decode_bytes_per_token(const cm_model* h, size_t ctx) { return h ? h->m.decode_bytes_per_token(ctx) : 0; }
+int cm_tp_ranks(const cm_model* h) {
+    if (!h) return 0;
+    if (!h->m.rccl) return 1;
+    return h->m.rccl->fake ? 0 : h->m.rccl->nranks;
+}
+int cm_engine_active(const cm_model* h) { return h && h->m.engine_on ? 1 : 0; }
 
 int cm_forward_step(cm_model* h, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out) {
     if (!h) return CM_ERR_INVALID;

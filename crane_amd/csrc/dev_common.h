@@ -97,7 +97,8 @@ struct StepState {
     uint32_t next;      // arg-max result of this step
     int32_t pad;        // token-ring write index
     int32_t slot;       // active sequence slot (indexes the per-sequence GDN state pools)
-    int32_t rsv[3];     // rsv[0] = rotary position delta (MRoPE counter - cache position)
+    int32_t rsv[3];     // rsv[0] = rotary position delta (MRoPE counter - cache position); rsv[1] = epoch base and
+                        // rsv[2] = error code of the persistent chain kernel (kernels_engine.hip)
 };
 
 }  // namespace cm

@@ -180,6 +180,36 @@ bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int k
 void launch_gdn(const GdnArgs& a, hipStream_t s);
 void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hipStream_t s);
 
+// ---- persistent chain kernel (kernels_engine.hip): o_proj -> gate||up -> down_proj -> next layer's QKV in one launch ----
+enum { ENG_STORE = 0, ENG_RESADD = 1, ENG_SILUMUL = 2 };
+constexpr int ENG_NSW = 4, ENG_NCW = 4, ENG_PF = 4;   // stream waves, comm waves per workgroup; register sets in flight per stream wave
+struct EngPhase {                 // one row-streaming projection
+    const uint16_t* W;            // [N, K] bf16, K contiguous
+    const float* nw;              // RMSNorm weight applied to the INPUT vector, or null (plain input)
+    const float* vin;             // input vector [K] f32 when in_edge < 0 (written by an earlier kernel)
+    float* vout;                  // output vector when out_edge < 0 (read by a later kernel)
+    int N, K;
+    int kind;                     // ENG_STORE | ENG_RESADD | ENG_SILUMUL (rows interleaved gate_j, up_j)
+    int gpw;                      // row groups (of 2 rows) per stream wave, rounded up
+    int nbpg;                     // batches per row group = K / 2048
+    int xoff;                     // float offset of the input buffer inside LDS
+    int in_edge, out_edge;        // granule buffers (0..2) carrying the input / output between workgroups, or -1
+};
+constexpr int ENG_MAXPH = 4;
+struct EngArgs {
+    const EngPhase* prog;         // phase table in HBM (one per layer); read through the constant address space (scalar loads)
+    unsigned long long* gran0;    // 8-byte {f32 value, u32 tag} granules, one buffer per dependency edge of the chain
+    unsigned long long* gran1;
+    unsigned long long* gran2;
+    float* xres;                  // [H] residual stream (read at entry, written back at exit)
+    uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)
+    int nph, H, gpw_res, xf_total;   // phases; hidden size; row groups per wave of the residual phases; LDS floats of all input buffers
+    float eps;
+};
+size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw);
+bool engine_prepare(size_t lds_bytes);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
+bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s);
+
 // ---- synthetic weights / utility ----
 // dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))
 void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncols, int row0, int col0,

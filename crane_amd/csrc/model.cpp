@@ -295,17 +295,104 @@ void Model::alloc_runtime() {
     CM_HIP(hipMemcpy(cos, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
     CM_HIP(hipMemcpy(sin, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
 
-    // CM_FORCE_RCCL=1 (debug): route the tp=1 reductions through a 1-rank RCCL communicator so the
-    // collective code path can be exercised on a single GPU.
-    const bool force_cc = tp == 1 && getenv("CM_FORCE_RCCL") != nullptr;
+    // CM_DEBUG_FORCE_RCCL: route the tp=1 reductions through a 1-rank RCCL communicator so the collective code path
+    // can be exercised on a single GPU.
+    const bool force_cc = tp == 1 && (opts.debug_flags & CM_DEBUG_FORCE_RCCL) != 0;
     if (tp > 1 || force_cc) {
         rccl.reset(new Rccl());
         UniqueId self_id;
         const void* id = opts.tp_unique_id;
         if (force_cc && !id) { Rccl::unique_id(&self_id); id = &self_id; }
-        rccl->init(tp, rank, id, stream);
+        rccl->init(tp, rank, id, stream, (opts.debug_flags & CM_DEBUG_TP_LOCAL) != 0);
     }
+    build_engine();
     CM_HIP(hipStreamSynchronize(stream));
+}
+
+// ------------------------------------------------------------------------------------
+// persistent chain kernel (kernels_engine.hip): phase tables + granule buffers
+// ------------------------------------------------------------------------------------
+bool Model::engine_eligible(std::string* why) const {
+    auto no = [&](const char* m) { if (why) *why = m; return false; };
+    if (cfg.hybrid) return no("hybrid (Gated-Delta-Net) layers");
+    if (quantized) return no("quantised weights");
+    if (tp != 1 || rccl) return no("tensor parallelism");
+    const int Ko = Hq_l * cfg.D;
+    if (Ko % 2048 || cfg.H % 2048 || I_l % 2048) return no("projection widths must be multiples of 2048");
+    const int TW = num_cu * ENG_NSW;
+    if ((cfg.H / 2 + TW - 1) / TW > 4) return no("hidden size too large for the residual slots");
+    return true;
+}
+
+void Model::build_engine() {
+    engine_on = false;
+    if (opts.engine < 0) return;
+    std::string why;
+    bool ok = engine_eligible(&why);
+    // default (0): opt-in through CM_ENGINE=1 until the launch path is retired; 1: required
+    if (opts.engine == 0) { const char* e = getenv("CM_ENGINE"); if (!(e && atoi(e) > 0)) return; }
+    if (!ok) {
+        if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: " + why);
+        return;
+    }
+    const int H = cfg.H, D = cfg.D, Ko = Hq_l * D, TW = num_cu * ENG_NSW;
+    const int x0 = std::max(Ko, H), x1 = H, xh = I_l;
+    eng_xf_total = x0 + x1 + xh;
+    auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
+    eng_gpw_res = gpw(H);
+    EngArgs probe{};
+    probe.xf_total = eng_xf_total; probe.gpw_res = eng_gpw_res;
+    if (engine_lds_bytes(probe, ENG_NSW, ENG_NCW) > 160 * 1024 - 256) {
+        if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: input vectors do not fit LDS");
+        return;
+    }
+    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    std::vector<EngPhase> prog((size_t)cfg.L * ENG_MAXPH);
+    for (int li = 0; li < cfg.L; ++li) {
+        const LayerW& w = layers[(size_t)li];
+        EngPhase* p = &prog[(size_t)li * ENG_MAXPH];
+        p[0] = EngPhase{w.o, nullptr, attn, nullptr, H, Ko, ENG_RESADD, gpw(H), Ko / 2048, 0, -1, 0};
+        p[1] = EngPhase{w.gate_up, w.ln2, nullptr, nullptr, 2 * I_l, H, ENG_SILUMUL, gpw(2 * I_l), H / 2048, x0, 0, 1};
+        p[2] = EngPhase{w.down, nullptr, nullptr, nullptr, H, I_l, ENG_RESADD, gpw(H), I_l / 2048, x0 + x1, 1, li + 1 < cfg.L ? 2 : -1};
+        if (li + 1 < cfg.L) {
+            const LayerW& n = layers[(size_t)li + 1];
+            p[3] = EngPhase{n.qkv, n.ln1, nullptr, qkv, qkv_rows, H, ENG_STORE, gpw(qkv_rows), H / 2048, 0, 2, -1};
+        } else {
+            p[3] = EngPhase{};
+        }
+    }
+    eng_prog = (EngPhase*)dalloc<int>(prog.size() * sizeof(EngPhase) / sizeof(int));
+    CM_HIP(hipMemcpy(eng_prog, prog.data(), prog.size() * sizeof(EngPhase), hipMemcpyHostToDevice));
+    const size_t gsz[3] = {(size_t)H, (size_t)I_l, (size_t)H};
+    for (int e = 0; e < 3; ++e) {
+        eng_gran[e] = (unsigned long long*)dalloc<int>(gsz[e] * 2);
+        CM_HIP(hipMemset(eng_gran[e], 0, gsz[e] * 8));       // tag 0 is never a valid epoch
+    }
+    if (!engine_prepare(engine_lds_bytes(probe, ENG_NSW, ENG_NCW))) {
+        if (opts.engine > 0) throw CmError(CM_ERR_DEVICE, "cm_opts.engine = 1: kernel attribute");
+        return;
+    }
+    engine_on = true;
+}
+
+EngArgs Model::engine_args(int li) const {
+    EngArgs e{};
+    e.prog = eng_prog + (size_t)li * ENG_MAXPH;
+    e.gran0 = eng_gran[0]; e.gran1 = eng_gran[1]; e.gran2 = eng_gran[2];
+    e.xres = x; e.ctl = (uint32_t*)&st->rsv[1];
+    e.nph = li + 1 < cfg.L ? 4 : 3; e.H = cfg.H; e.gpw_res = eng_gpw_res; e.xf_total = eng_xf_total; e.eps = cfg.eps;
+    return e;
+}
+
+void Model::engine_check() {
+    if (!engine_on) return;
+    CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    if (h_st->rsv[2] != 0) {
+        char b[96];
+        snprintf(b, sizeof b, "persistent chain kernel timed out (code 0x%x): workgroups not co-resident?", (unsigned)h_st->rsv[2]);
+        throw CmError(CM_ERR_DEVICE, b);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -457,6 +544,28 @@ void Model::enqueue_decode_step(bool advance) {
     if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_row_q(q_embed, st, x, H, cfg.V, s);
     else launch_embed_row(embed, st, x, H, cfg.V, 1, s);
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
+    if (engine_on) {
+        // persistent chain path: QKV of layer 0 as a plain launch, then per layer the attention kernels + ONE chain launch
+        // (o_proj -> gate||up -> down_proj -> QKV of the next layer)
+        GemvArgs g{};
+        g.W = layers[0].qkv; g.x = x; g.nw = layers[0].ln1; g.y = qkv; g.N = qkv_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
+        launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+        for (int li = 0; li < cfg.L; ++li) {
+            const LayerW& w = layers[(size_t)li];
+            AttnDecArgs a{};
+            a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
+            a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
+            a.q_off = 0; a.k_off = Hq_l * D; a.v_off = a.k_off + Hkv_l * D; a.gate = nullptr; a.rot_dim = cfg.rot_dim;
+            a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps;
+            a.scale = (float)(1.0 / std::sqrt((double)D));
+            if (attn_variant >= 2) {
+                if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+            } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+            if (!launch_engine_chain(engine_args(li), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent chain kernel launch");
+        }
+        enqueue_lm_head(advance);
+        return;
+    }
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
         if (quantized) { enqueue_quant_layer(li); continue; }
@@ -1105,6 +1214,10 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     }
     if (logits_out) fetch_logits(logits_out);
     if (!greedy_out && !logits_out) CM_HIP(hipStreamSynchronize(stream));
+    if (engine_on && !use_prefill) {
+        if (greedy_out) { if (h_st->rsv[2] != 0) engine_check(); }      // h_st was just copied
+        else engine_check();
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1179,6 +1292,7 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
             for (size_t i = 0; i < want; ++i) run_decode_step(true, q.len + (int64_t)i + 1);
             CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CM_HIP(hipStreamSynchronize(stream));
+            engine_check();
             size_t used = 0;
             for (size_t i = 0; i < want && !stop; ++i) { emit(h_ring[(ring0 + i) & (RING - 1)]); ++used; }
             q.len += (int64_t)used;     // tokens decoded past an EOS/stop stay beyond len and are overwritten later
@@ -1207,6 +1321,7 @@ void Model::bench_decode(uint32_t first, size_t k, uint32_t* toks, float* ms) {
     (void)hipEventDestroy(e1);
     if (ms) *ms = t;
     q.len += (int64_t)k;
+    engine_check();
     if (toks) {
         CM_HIP(hipMemcpy(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; ++i) toks[i] = h_ring[(ring0 + i) & (RING - 1)];
@@ -1235,6 +1350,15 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
             const int grid = which == "lm_head" ? lm_grid : gemvq_grid(q.w.N, num_cu, q.w.fmt);
             if (!launch_gemvq(pro, epi, q, grid, stream)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
             b = q.w.bytes() + (uint64_t)q.w.K * 4 + (q.nw ? (uint64_t)q.w.K * 4 : 0);
+            return;
+        }
+        if (which == "chain") {      // the persistent chain launch of a layer that has a successor (4 phases)
+            if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent chain kernel is not active on this model");
+            const int lc = cfg.L > 1 ? (int)(i % (size_t)(cfg.L - 1)) : 0;
+            if (!launch_engine_chain(engine_args(lc), num_cu, stream)) throw CmError(CM_ERR_DEVICE, "persistent chain kernel launch");
+            const uint64_t Ko = (uint64_t)Hq_l * D, qrows = (uint64_t)(Hq_l + 2 * Hkv_l) * D;
+            b = ((uint64_t)H * Ko + 2ull * I_l * H + (uint64_t)H * I_l + (cfg.L > 1 ? qrows * H : 0)) * 2    // weights, bf16
+                + Ko * 4 + (uint64_t)H * 4 + 2ull * H * 4;                                                  // attn in, x in/out, 2 norm vectors
             return;
         }
         GemvArgs g{};
@@ -1272,6 +1396,7 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
     (void)hipEventDestroy(e1);
     if (ms) *ms = t / (float)iters;
     if (bytes) *bytes = b;
+    engine_check();
 }
 
 void Model::debug_qgemv(int layer, const std::string& which, const float* xh, size_t k, float* yh, size_t n) {

@@ -262,6 +262,16 @@ struct Model {
     void isq_q8_0();                   // in-situ quantisation of the loaded bf16 linears (ops/linear.rs:83-116)
     void dfree(void* p);
 
+    // persistent chain kernel (kernels_engine.hip): per layer ONE launch for o_proj -> gate||up -> down_proj -> next QKV
+    bool engine_on = false;
+    EngPhase* eng_prog = nullptr;              // device [L][ENG_MAXPH]
+    unsigned long long* eng_gran[3] = {nullptr, nullptr, nullptr};   // granule buffers of the three edges inside a chain
+    int eng_gpw_res = 0, eng_xf_total = 0;
+    bool engine_eligible(std::string* why = nullptr) const;
+    void build_engine();
+    EngArgs engine_args(int li) const;
+    void engine_check();                       // after a host sync: throws if a chain launch timed out (StepState.rsv[2])
+
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
     hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
     bool graph_ok[4] = {false, false, false, false};

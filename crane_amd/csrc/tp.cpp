@@ -60,8 +60,8 @@ void Rccl::unique_id(void* out128) {
     memcpy(out128, &id, sizeof id);
 }
 
-void Rccl::init(int n, int r, const void* unique_id128, hipStream_t) {
-    if (getenv("CM_TP_FAKE") != nullptr) { fake = true; nranks = n; rank = r; return; }
+void Rccl::init(int n, int r, const void* unique_id128, hipStream_t, bool local_only) {
+    if (local_only) { fake = true; nranks = n; rank = r; return; }
     if (!unique_id128) throw CmError(CM_ERR_INVALID, "tp_size > 1 needs cm_opts.tp_unique_id");
     load();
     nranks = n; rank = r;

@@ -19,7 +19,7 @@ struct Rccl {
     void* lib = nullptr;
     void* comm = nullptr;
     int nranks = 1, rank = 0;
-    bool fake = false;     // CM_TP_FAKE=1 (debug): no communicator; all-reduce = local copy, all-gather = no-op, so one
+    bool fake = false;     // cm_opts.debug_flags & CM_DEBUG_TP_LOCAL: no communicator; all-reduce = local copy, all-gather = no-op, so one
                            // process can run ONE rank's shard and be compared with the oracle on the same shard
     // resolved entry points
     int (*p_get_unique_id)(void*) = nullptr;
@@ -31,7 +31,7 @@ struct Rccl {
 
     ~Rccl();
     void load();
-    void init(int nranks, int rank, const void* unique_id128, hipStream_t s);
+    void init(int nranks, int rank, const void* unique_id128, hipStream_t s, bool local_only);
     void all_reduce_sum_f32(const float* send, float* recv, size_t count, hipStream_t s);
     // gathers `bytes_per_rank` from every rank into recv (rank-major); send may alias its slot
     void all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s);

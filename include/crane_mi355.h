@@ -74,8 +74,17 @@ typedef struct cm_opts {
     int32_t  prefill_split;    /* activation split terms for MFMA GEMMs: 0/2 = bf16x2 (parity), 1 = bf16 */
     uint32_t isq;              /* in-situ quantisation of the linears at load: 0 none, CM_ISQ_Q8_0       */
                                /*   (--quant / CRANE_ISQ, ops/linear.rs:53-116; also read from CRANE_ISQ) */
-    uint32_t reserved[7];
+    int32_t  engine;           /* persistent per-layer chain kernel for the decode step: 0 default (on when the  */
+                               /*   shapes allow it), 1 require (cm_create fails otherwise), -1 off              */
+    uint32_t debug_flags;      /* CM_DEBUG_* bits; test hooks only, never set in production                      */
+    uint32_t reserved[5];
 } cm_opts;
+
+/* cm_opts.debug_flags.  TP_LOCAL: no communicator is created and every collective is a local no-op, so ONE rank of a
+ * tensor-parallel model can run alone and be compared with the oracle on its shard (the logits are partial sums!).
+ * FORCE_RCCL: a tp_size = 1 model routes its reductions through a 1-rank RCCL communicator (exercises the RCCL calls
+ * on a single GPU). */
+enum { CM_DEBUG_TP_LOCAL = 1u, CM_DEBUG_FORCE_RCCL = 2u };
 
 enum { CM_ISQ_NONE = 0, CM_ISQ_Q8_0 = 8 };
 
@@ -128,6 +137,12 @@ uint64_t cm_weight_bytes(const cm_model* m);
 /* algorithmic HBM bytes one decode step reads at context `ctx` on this rank
  * (SURVEY.md section 8(d) formula; used by bench.py's roofline object) */
 uint64_t cm_decode_bytes_per_token(const cm_model* m, size_t ctx);
+
+/* ranks of the RCCL communicator this handle reduces over: 1 without tensor parallelism, tp_size once the communicator
+ * is up, 0 when the collectives are local no-ops (CM_DEBUG_TP_LOCAL) -- bench.py asserts it equals --gpus */
+int cm_tp_ranks(const cm_model* m);
+/* 1 when the decode step runs on the persistent per-layer chain kernel (cm_opts.engine), else 0 */
+int cm_engine_active(const cm_model* m);
 
 /* ---- single-sequence path (the implicit sequence of B1/B2) ----------------- */
 

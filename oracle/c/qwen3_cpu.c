@@ -273,6 +273,28 @@ void qc_fill_kv(qc_model* m, int ctx, uint64_t seed) {
     m->len = ctx;
 }
 
+/* the same fill in the element order of the device's paged pool ([page][kv head][token in page][D], `page` tokens per
+ * page, whole pages): bit-identical to cm_debug_fill_kv (crane_amd/csrc/kernels_misc.hip kv_fill_kernel), so a decode
+ * step at the benchmark's context can be compared logit by logit */
+void qc_fill_kv_paged(qc_model* m, int ctx, uint64_t seed, int page) {
+    const qc_cfg* c = &m->c;
+    for (int li = 0; li < c->L; ++li)
+        for (int kv = 0; kv < 2; ++kv) {
+            float* dst = kv ? m->layers[li].v : m->layers[li].k;
+            const uint32_t ts = fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1 + kv);
+#pragma omp parallel for schedule(static)
+            for (int g = 0; g < c->Hkv; ++g)
+                for (int p = 0; p < ctx; ++p)
+                    for (int i = 0; i < c->D; ++i) {
+                        const size_t idx = (((size_t)(p / page) * c->Hkv + g) * page + (size_t)(p % page)) * c->D + i;
+                        const uint32_t h = fmix32((uint32_t)idx * 0x9E3779B1u + ts);
+                        const int k = (int)((h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + (h >> 24)) - 510;
+                        dst[((size_t)g * c->max_seq + p) * c->D + i] = bf2f(f2bf((float)k * (1.0f / 147.80054f)));
+                    }
+        }
+    m->len = ctx;
+}
+
 int qc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

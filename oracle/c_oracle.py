@@ -29,6 +29,7 @@ def _lib():
     lib.qc_destroy.argtypes = [C.c_void_p]
     lib.qc_forward.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.qc_fill_kv.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    lib.qc_fill_kv_paged.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     lib.qc_num_threads.restype = C.c_int
     return lib
 
@@ -56,6 +57,10 @@ class CQwen3:
     def fill_kv(self, ctx: int, seed: int = 1):
         self.lib.qc_fill_kv(self.h, ctx, seed)
 
+    def fill_kv_paged(self, ctx: int, seed: int = 1, page: int = 64):
+        """Same values as cm_debug_fill_kv (the device fills its pool page by page)."""
+        self.lib.qc_fill_kv_paged(self.h, ctx, seed, page)
+
     def threads(self) -> int:
         return int(self.lib.qc_num_threads())
 
@@ -71,23 +76,32 @@ class CQwen3:
             pass
 
 
-def time_decode(model_name: str, ctx: int, budget_s: float = 20.0) -> dict:
+def time_decode(model_name: str, ctx: int, budget_s: float = 20.0):
+    """bench.py's CPU leg: (cpu_baseline dict, greedy tokens, logits of the first step).
+
+    The KV cache of positions [0, ctx) holds the values cm_debug_fill_kv writes on the device and the first token is
+    bench.py's (3), so the tokens / first logits double as the parity reference of the benchmarked configuration.
+    The forward is the f32 CPU forward (K/V appends unrounded)."""
     from crane_amd import configs
     cfg = configs.get_config(model_name)
     t0 = time.perf_counter()
-    m = CQwen3(cfg, seed=0, max_seq=ctx + 64, kv_bf16=True)
+    m = CQwen3(cfg, seed=0, max_seq=ctx + 64, kv_bf16=False)
     t_build = time.perf_counter() - t0
-    m.fill_kv(ctx, 1)
-    tok, n, dt = 3, 0, 0.0
-    m.forward([tok], ctx)                      # untimed warm-up step (page-in)
+    m.fill_kv_paged(ctx, 1, 64)
+    first = m.forward([3], ctx)                # untimed first step (page-in); its logits are the parity reference
+    tok = int(first.argmax())
+    toks = [tok]
+    n, dt = 0, 0.0
     while n < 32 and dt < budget_s:
         t1 = time.perf_counter()
         lg = m.forward([tok], ctx + 1 + n)
         dt += time.perf_counter() - t1
         tok = int(lg.argmax())
+        toks.append(tok)
         n += 1
     thr = m.threads()
     m.close()
-    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": thr, "kind": "port",
+    base = {"value": round(n / dt, 3), "unit": "tokens/s", "cores": thr, "kind": "port",
             "sample": f"{n} greedy decode steps of {model_name} at context {ctx} (bf16-stored weights, f32 compute, "
                       f"OpenMP over {thr} host threads; weight synthesis {t_build:.1f}s excluded)"}
+    return base, toks, first

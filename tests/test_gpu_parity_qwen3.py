@@ -239,7 +239,7 @@ def test_prefill_f32_kv_and_plain_bf16_modes():
 
 @pytest.mark.parametrize("tp_graph", ["1", "0"])
 def test_rccl_code_path_single_rank(tp_graph, monkeypatch):
-    """CM_FORCE_RCCL=1: the tp=1 reductions go through a 1-rank RCCL communicator (dlopen, unique-id ABI,
+    """cm_opts.debug_flags = CM_DEBUG_FORCE_RCCL: the tp=1 reductions go through a 1-rank RCCL communicator (dlopen, unique-id ABI,
     all-reduce + all-gather on the model's stream), captured into the decode hipGraph (CM_TP_GRAPH=1, the default) or
     launched eagerly (0).  Results must equal the collective-free path."""
     import os
@@ -258,18 +258,14 @@ def test_rccl_code_path_single_rank(tp_graph, monkeypatch):
         a3, g3 = batched(m)
     finally:
         m.close()
-    os.environ["CM_FORCE_RCCL"] = "1"
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4, debug_force_rccl=True)
     try:
-        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4)
-        try:
-            b = m.forward_step(ids, 0)[0, 0]
-            b2 = m.forward_step([7], 40)[0, 0]
-            b3, h3 = batched(m)
-            toks = m.generate(ids[:5], GenerationConfig.greedy(6), sync_every=3)
-        finally:
-            m.close()
+        b = m.forward_step(ids, 0)[0, 0]
+        b2 = m.forward_step([7], 40)[0, 0]
+        b3, h3 = batched(m)
+        toks = m.generate(ids[:5], GenerationConfig.greedy(6), sync_every=3)
     finally:
-        del os.environ["CM_FORCE_RCCL"]
+        m.close()
     assert rel(b, a) < 1e-6 and rel(b2, a2) < 1e-6 and len(toks) == 11
     assert rel(b3, a3) < 1e-6 and list(h3) == list(g3)
 

@@ -1,4 +1,4 @@
-"""One TP rank at a time on ONE GPU (CM_TP_FAKE=1: collectives are local no-ops): the C++ loader's shard of every
+"""One TP rank at a time on ONE GPU (cm_opts.debug_flags = CM_DEBUG_TP_LOCAL: collectives are local no-ops): the C++ loader's shard of every
 weight + the kernels running on local head counts must reproduce the oracle evaluated on the SAME shard with an
 identity all-reduce.  Together with the gloo tests (real all-reduce on the same plan) this covers the TP path that
 cannot be run on a single-GPU box."""
@@ -18,12 +18,8 @@ def rel(a, ref):
 
 def _run_rank(cfg, rank, world, ids, isq=None):
     from crane_amd.backend import Model
-    os.environ["CM_TP_FAKE"] = "1"
-    try:
-        m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
-                            tp_unique_id=b"\0" * 128, isq=isq)
-    finally:
-        del os.environ["CM_TP_FAKE"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
+                        tp_unique_id=b"\0" * 128, isq=isq, debug_tp_local=True)
     try:
         a = m.forward_step(ids, 0)[0, 0]
         b = m.forward_step([5], len(ids))[0, 0]
@@ -98,7 +94,7 @@ def test_dense_rank_shards_isq_q8_0(monkeypatch):
                                          ("tiny-qwen3-untied", 5, "q8_0")])
 def test_batched_decode_on_a_rank(name, nb, isq):
     """cm_decode_batch under TP: the row-parallel projections of all sequences go through ONE all-reduce per layer and the
-    vocabulary-sharded lm_head through one gather.  With CM_TP_FAKE a rank's batched step must agree with its own
+    vocabulary-sharded lm_head through one gather.  With CM_DEBUG_TP_LOCAL a rank's batched step must agree with its own
     single-sequence steps on its vocabulary slice (logits and rank-local arg-max)."""
     from crane_amd.backend import Model
     cfg = configs.get_config(name)
@@ -107,12 +103,8 @@ def test_batched_decode_on_a_rank(name, nb, isq):
     for rank in range(world):
         plan = tp.shard_plan(cfg, world, rank)
         v = slice(plan.vocab.start, plan.vocab.stop)
-        os.environ["CM_TP_FAKE"] = "1"
-        try:
-            m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=12, kv_dtype="f32", tp_rank=rank, tp_size=world,
-                                tp_unique_id=b"\0" * 128, isq=isq)
-        finally:
-            del os.environ["CM_TP_FAKE"]
+        m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=12, kv_dtype="f32", tp_rank=rank, tp_size=world,
+                            tp_unique_id=b"\0" * 128, isq=isq, debug_tp_local=True)
         try:
             seqs, toks = [], []
             for b in range(nb):
