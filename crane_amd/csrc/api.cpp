@@ -313,6 +313,7 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
         const float* src = nullptr;
         size_t avail = 0;
         const std::string w = what;
+        if (w == "engine_trace") { h->m.engine_trace(out, n); return; }
         if (w == "hidden") { src = h->m.x; avail = (size_t)h->m.cfg.H; }
         else if (w == "logits") { src = h->m.logits; avail = (size_t)h->m.V_l * h->m.tp; }
         else if (w == "attn") { src = h->m.attn; avail = (size_t)h->m.Hq_l * h->m.cfg.D; }

@@ -203,12 +203,13 @@ struct EngArgs {
     unsigned long long* gran2;
     float* xres;                  // [H] residual stream (read at entry, written back at exit)
     uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)
+    unsigned long long* trace;    // debug build of the kernel only: [grid][waves][ENG_MAXPH][4] 100 MHz timestamps
     int nph, H, gpw_res, xf_total;   // phases; hidden size; row groups per wave of the residual phases; LDS floats of all input buffers
     float eps;
 };
 size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw);
 bool engine_prepare(size_t lds_bytes);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
-bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s);
+bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s, bool trace = false);
 
 // ---- synthetic weights / utility ----
 // dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))

@@ -22,6 +22,8 @@
 //   * the residual stream row r is owned by the same lane of the same wave in o_proj and down_proj and lives in LDS
 //     between phases.
 // Every spin is bounded; a timeout raises ctl[1], later launches return at once, and the host reports the code.
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -60,7 +62,7 @@ __device__ __forceinline__ int xperm(int k) {
 
 }  // namespace
 
-template <int NSW, int NCW, int PF>
+template <int NSW, int NCW, int PF, bool TRACE>
 __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_chain_kernel(EngArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -69,6 +71,12 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     float* xres_l = ssq + 2 * NCW;                       // [NSW][gpw_res][R] residual rows of this block's stream waves
     uint32_t* ctrl = (uint32_t*)(xres_l + NSW * a.gpw_res * R);   // [0] inputs staged (x NCW), [1] stream waves done (x NSW), [2] abort
 
+    // TRACE (debug instantiation, cm_debug_read "engine_trace"): 100 MHz timestamps per (wave, phase, event)
+    auto stamp = [&](int ph, int k, u64 val = ~0ull) __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            if (lane == 0) a.trace[(((size_t)blockIdx.x * (NSW + NCW) + wave) * ENG_MAXPH + ph) * 4 + k] = val == ~0ull ? __builtin_amdgcn_s_memrealtime() : val;
+        }
+    };
     if (__builtin_nontemporal_load(&a.ctl[1]) != 0u) return;       // an earlier launch timed out: do nothing
     const uint32_t base = __builtin_nontemporal_load(&a.ctl[0]);   // epoch base of this launch (tags base+1 ... base+nph)
     if (threadIdx.x < 4) ctrl[threadIdx.x] = 0u;
@@ -85,6 +93,8 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             gf_cptr nw = (gf_cptr)P->nw;
             gf_cptr vin = (gf_cptr)P->vin;
             float* xs = lds + P->xoff;
+            stamp(p, 0);
+            uint32_t total_spins = 0;
             if (p > 0) {                                  // do not poll HBM while this CU's own waves are mid-phase
                 uint32_t spins = 0;
                 while (lds_ld(&ctrl[1]) < (uint32_t)(NSW * p) && lds_ld(&ctrl[2]) == 0u) {
@@ -92,6 +102,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     if (++spins > SPIN_LDS) { if (lane == 0) { atomicExch(&a.ctl[1], 0x100u + (uint32_t)p); ctrl[2] = 1u; } break; }
                 }
             }
+            stamp(p, 1);
             const u64* G = in_edge == 0 ? a.gran0 : (in_edge == 1 ? a.gran1 : a.gran2);
             const uint32_t tag = base + (uint32_t)p;      // written by phase p - 1
             float ss = 0.f;
@@ -120,6 +131,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (++spins > SPIN_GLOBAL) { if (lane == 0) { atomicExch(&a.ctl[1], 0x200u + (uint32_t)p); ctrl[2] = 1u; } break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
+                    total_spins += spins;
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -134,12 +146,15 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) lds_add(&ctrl[0], 1u);
+            stamp(p, 2);
+            stamp(p, 3, (u64)total_spins);
         }
         return;
     }
 
     // =============================== STREAM waves: rows x weights, never waiting on HBM ===============================
     const int gwid = blockIdx.x * NSW + wave, TW = gridDim.x * NSW;
+    stamp(0, 3);
 
     // residual rows owned by this wave (same mapping in o_proj and down_proj): lane i < R of group gi.  Requested first
     // and written to LDS only after the weight prefetch has been issued, so the wait is a counted one.
@@ -203,12 +218,14 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             cN = CP->N; cK = CP->K; cgpw = CP->gpw; cnb = CP->nbpg; ckind = CP->kind; cout = CP->out_edge; cvout = (gf_ptr)CP->vout;
             xs4 = (const f32x4*)(lds + CP->xoff);
             const uint32_t want = (uint32_t)(NCW * (cph + 1));
+            stamp(cph, 0);
             uint32_t spins = 0;
             while (lds_ld(&ctrl[0]) < want && lds_ld(&ctrl[2]) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > SPIN_LDS) { if (lane == 0) { atomicExch(&a.ctl[1], 0x300u + (uint32_t)cph); ctrl[2] = 1u; } break; }
             }
             asm volatile("" ::: "memory");
+            stamp(cph, 1);
             scale = 1.f;
             if (CP->nw != nullptr) {
                 const float* sp = ssq + (cph & 1) * NCW;
@@ -267,6 +284,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             cgi = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) lds_add(&ctrl[1], 1u);               // this wave is done with phase cph
+            stamp(cph, 2);
             ++cph; ++CP;
         }
     };
@@ -298,19 +316,51 @@ size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw) {
     return ((size_t)a.xf_total + 2 * (size_t)ncw + (size_t)nsw * a.gpw_res * R) * 4 + 64;
 }
 
-bool engine_prepare(size_t lds_bytes) {
-    auto k = engine_chain_kernel<ENG_NSW, ENG_NCW, ENG_PF>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+// register sets in flight per stream wave: ENG_PF by default; CM_ENG_PF=3|5 selects the other instantiations (tuning only)
+static int eng_pf() {
+    static int pf = 0;
+    if (pf == 0) {
+        pf = ENG_PF;
+        if (const char* e = getenv("CM_ENG_PF")) { const int v = atoi(e); if (v == 3 || v == 4 || v == 5) pf = v; }
+    }
+    return pf;
+}
+
+template <int PF>
+static bool prepare_pf(size_t lds_bytes) {
+    auto k = engine_chain_kernel<ENG_NSW, ENG_NCW, PF, false>;
+    auto kt = engine_chain_kernel<ENG_NSW, ENG_NCW, PF, true>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     return true;
 }
 
-bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s) {
+bool engine_prepare(size_t lds_bytes) {
+    switch (eng_pf()) {
+        case 3: return prepare_pf<3>(lds_bytes);
+        case 5: return prepare_pf<5>(lds_bytes);
+        default: return prepare_pf<4>(lds_bytes);
+    }
+}
+
+template <int PF>
+static void launch_pf(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
+    if (trace) hipLaunchKernelGGL((engine_chain_kernel<ENG_NSW, ENG_NCW, PF, true>), dim3(grid), dim3((ENG_NSW + ENG_NCW) * 64), lds, s, a);
+    else hipLaunchKernelGGL((engine_chain_kernel<ENG_NSW, ENG_NCW, PF, false>), dim3(grid), dim3((ENG_NSW + ENG_NCW) * 64), lds, s, a);
+}
+
+bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const size_t lds = engine_lds_bytes(a, ENG_NSW, ENG_NCW);
     if (lds > 160 * 1024 - 256 || a.gpw_res > 4) return false;
-    hipLaunchKernelGGL((engine_chain_kernel<ENG_NSW, ENG_NCW, ENG_PF>), dim3(grid), dim3((ENG_NSW + ENG_NCW) * 64), lds, s, a);
+    const bool tr = trace && a.trace != nullptr;
+    switch (eng_pf()) {
+        case 3: launch_pf<3>(a, grid, lds, s, tr); break;
+        case 5: launch_pf<5>(a, grid, lds, s, tr); break;
+        default: launch_pf<4>(a, grid, lds, s, tr); break;
+    }
     return true;
 }
 

@@ -384,6 +384,37 @@ EngArgs Model::engine_args(int li) const {
     return e;
 }
 
+// cm_debug_read("engine_trace"): a few warm chain launches, then ONE launch of the instrumented instantiation;
+// out[((block * waves + wave) * ENG_MAXPH + phase) * 4 + event] = microseconds since the earliest stamp (0 = not recorded;
+// event 3 of a comm wave = number of granule sweeps that found stale tags)
+void Model::engine_trace(float* out, size_t n) {
+    if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent chain kernel is not active on this model");
+    const size_t waves = ENG_NSW + ENG_NCW, total = (size_t)num_cu * waves * ENG_MAXPH * 4;
+    if (n != total) throw CmError(CM_ERR_RANGE, "engine_trace: expected " + std::to_string(total) + " values");
+    unsigned long long* d = nullptr;
+    CM_HIP(hipMalloc((void**)&d, total * 8));
+    CM_HIP(hipMemsetAsync(d, 0, total * 8, stream));
+    const int layers_w = std::max(1, cfg.L - 1);
+    for (int i = 0; i < 6; ++i) launch_engine_chain(engine_args(i % layers_w), num_cu, stream);
+    EngArgs e = engine_args(6 % layers_w);
+    e.trace = d;
+    launch_engine_chain(e, num_cu, stream, true);
+    std::vector<unsigned long long> h(total);
+    CM_HIP(hipStreamSynchronize(stream));
+    CM_HIP(hipMemcpy(h.data(), d, total * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < total; ++i)
+        if ((i & 3) != 3 || ((i / 4) % ENG_MAXPH == 0 && ((i / (4 * ENG_MAXPH)) % waves) < (size_t)ENG_NSW))   // stamps, not spin counts
+            if (h[i] != 0 && h[i] < t0) t0 = h[i];
+    for (size_t i = 0; i < total; ++i) {
+        const bool is_count = (i & 3) == 3 && ((i / (4 * ENG_MAXPH)) % waves) >= (size_t)ENG_NSW;
+        if (is_count) out[i] = (float)h[i];
+        else out[i] = h[i] == 0 ? 0.f : (float)((double)(h[i] - t0) * 0.01) + 0.01f;    // 100 MHz -> us
+    }
+    engine_check();
+}
+
 void Model::engine_check() {
     if (!engine_on) return;
     CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));

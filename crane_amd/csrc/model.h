@@ -270,6 +270,7 @@ struct Model {
     bool engine_eligible(std::string* why = nullptr) const;
     void build_engine();
     EngArgs engine_args(int li) const;
+    void engine_trace(float* out, size_t n);   // debug: microsecond timestamps of one traced chain launch
     void engine_check();                       // after a host sync: throws if a chain launch timed out (StepState.rsv[2])
 
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant

@@ -1,0 +1,36 @@
+"""Timeline of ONE persistent chain launch (cm_debug_read "engine_trace"): where the ~70 us of a Qwen3-8B layer go.
+Prints, per phase, when the stream waves arrive at / pass the input wait and finish their rows, and when the comm waves
+start polling and finish staging (microseconds since the earliest stamp of the launch; min / median / max over the chip)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from crane_amd import configs
+from crane_amd.backend import Model
+
+name = sys.argv[1] if len(sys.argv) > 1 else "qwen3-8b"
+cfg = configs.get_config(name)
+if len(sys.argv) > 2:
+    cfg["num_hidden_layers"] = int(sys.argv[2])
+m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, engine=1)
+m.debug_fill_kv(1024, seed=1)
+m.bench_decode(3, 8)
+NB, NW, NSW, MAXPH = 256, 8, 4, 4
+for rep in range(2):
+    t = m.debug_read("engine_trace", NB * NW * MAXPH * 4).reshape(NB, NW, MAXPH, 4)
+    print(f"--- traced launch {rep} (PF={os.environ.get('CM_ENG_PF', '4')}) ---")
+    ent = t[:, :NSW, 0, 3]
+    print(f"kernel entry (stream waves): min {ent.min():.2f} med {np.median(ent):.2f} max {ent.max():.2f}")
+    names = ["o_proj", "gate_up", "down", "qkv_next"]
+    def st(a):
+        a = a[a > 0]
+        return f"{a.min():7.2f} {np.median(a):7.2f} {a.max():7.2f}" if a.size else "   -"
+    for p in range(MAXPH):
+        s, c = t[:, :NSW, p, :], t[:, NSW:, p, :]
+        print(f"phase {p} {names[p]:9s} stream: arrive[{st(s[..., 0])}] go[{st(s[..., 1])}] done[{st(s[..., 2])}]")
+        print(f"                  comm  : begin [{st(c[..., 0])}] poll[{st(c[..., 1])}] staged[{st(c[..., 2])}] stale sweeps avg {c[..., 3].mean():.1f} max {c[..., 3].max():.0f}")
+    print(f"end of launch: {t[..., :3].max():.2f} us")
+m.close()
