@@ -207,6 +207,8 @@ struct EngArgs {
     int nph, H, gpw_res, xf_total;   // phases; hidden size; row groups per wave of the residual phases; LDS floats of all input buffers
     float eps;
 };
+struct EngCfg { int nsw, ncw, pf; };
+EngCfg engine_config();           // the instantiation the launcher uses (default, or CM_ENG_CFG while tuning)
 size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw);
 bool engine_prepare(size_t lds_bytes);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
 bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s, bool trace = false);

@@ -22,6 +22,7 @@
 //   * the residual stream row r is owned by the same lane of the same wave in o_proj and down_proj and lives in LDS
 //     between phases.
 // Every spin is bounded; a timeout raises ctl[1], later launches return at once, and the host reports the code.
+#include <cstdio>
 #include <cstdlib>
 
 #include "dev_common.h"
@@ -87,7 +88,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     if (wave >= NSW) {
         // =========================== COMM waves: stage every phase's input vector into LDS ===========================
         const int cw = wave - NSW;
-        for (int p = 0; p < nph; ++p) {
+        for (int p = 1; p < nph; ++p) {                  // phase 0's input is staged by the stream waves (below)
             ph_ptr P = (ph_ptr)a.prog + p;
             const int K = P->K, in_edge = P->in_edge;
             gf_cptr nw = (gf_cptr)P->nw;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             float* xs = lds + P->xoff;
             stamp(p, 0);
             uint32_t total_spins = 0;
-            if (p > 0) {                                  // do not poll HBM while this CU's own waves are mid-phase
+            {                                             // do not poll HBM while this CU's own waves are mid-phase
                 uint32_t spins = 0;
                 while (lds_ld(&ctrl[1]) < (uint32_t)(NSW * p) && lds_ld(&ctrl[2]) == 0u) {
                     __builtin_amdgcn_s_sleep(8);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 if (lane == 0) ssq[(p & 1) * NCW + cw] = ss;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_add(&ctrl[0], 1u);
+            if (lane == 0) lds_add(&ctrl[0], (uint32_t)NSW);      // NSW * NCW units per staged phase
             stamp(p, 2);
             stamp(p, 3, (u64)total_spins);
         }
@@ -166,6 +167,22 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         row = row < a.H ? row : a.H - 1;
         xv0[gi] = a.xres[row];
     }
+    // Phase 0's input vector was written by an earlier kernel: the stream waves request their 1/NSW of it BEFORE the weight
+    // prefetch (a load issued behind this CU's 128 KiB prefetch burst returns ~5 us later: measured 7.7 us until the
+    // o_proj rows could start when the comm waves did this), and stage it once the prefetch is on its way.
+    constexpr int MAXV = 8;
+    ph_ptr P0 = (ph_ptr)a.prog;
+    const int k4n = P0->K >> 2, per = k4n / NSW;                   // f32x4 groups of the vector, per stream wave
+    f32x4 xin[MAXV];
+    {
+        const CM_GLOBAL f32x4* v4 = (const CM_GLOBAL f32x4*)P0->vin;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int idx = wave * per + i * 64 + lane;
+            idx = idx < k4n ? idx : k4n - 1;
+            xin[i] = v4[idx];
+        }
+    }
 
     // ---- load-side cursor (runs PF batches ahead of the compute-side cursor) ----
     ph_ptr LP = (ph_ptr)a.prog;
@@ -175,13 +192,14 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     bool lvalid = true;
     auto load_batch = [&](u32x4 (&q)[R][U]) __attribute__((always_inline)) {
         const int G = lN / R;
-        int g = gwid + lgi * TW;
-        g = g < G ? g : G - 1;                                   // a wave past the last group re-reads a valid one (discarded)
-        // past the end of the program every lane reads the same 16 bytes: the loads stay unconditional
-        const size_t roff = lvalid ? (size_t)g * R * (size_t)lK + (size_t)lkb * (U * 512) : 0;
-        const int loff = lvalid ? lane * 8 : 0;
-        const size_t sK = lvalid ? (size_t)lK : 0;
-        const int sU = lvalid ? 512 : 0;
+        const int g = gwid + lgi * TW;
+        // a row group past the last one, or a batch past the end of the program: every lane reads the same 16 bytes of the
+        // matrix (no HBM traffic, result never used) -- the loads stay unconditional
+        const bool real = lvalid && g < G;
+        const size_t roff = real ? (size_t)g * R * (size_t)lK + (size_t)lkb * (U * 512) : 0;
+        const int loff = real ? lane * 8 : 0;
+        const size_t sK = real ? (size_t)lK : 0;
+        const int sU = real ? 512 : 0;
         const CM_GLOBAL uint16_t* wp = lW + roff + loff;
 #pragma unroll
         for (int i = 0; i < R; ++i)
@@ -217,7 +235,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             // ---- phase start: parameters, then wait until the comm waves have staged this phase's input ----
             cN = CP->N; cK = CP->K; cgpw = CP->gpw; cnb = CP->nbpg; ckind = CP->kind; cout = CP->out_edge; cvout = (gf_ptr)CP->vout;
             xs4 = (const f32x4*)(lds + CP->xoff);
-            const uint32_t want = (uint32_t)(NCW * (cph + 1));
+            const uint32_t want = (uint32_t)(NSW * NCW * (cph + 1));
             stamp(cph, 0);
             uint32_t spins = 0;
             while (lds_ld(&ctrl[0]) < want && lds_ld(&ctrl[2]) == 0u) {
@@ -296,6 +314,14 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
 #pragma unroll
     for (int gi = 0; gi < MAXRES; ++gi)
         if (gi < a.gpw_res && lane < R) xres_l[(wave * a.gpw_res + gi) * R + lane] = xv0[gi];
+    {
+        float* xs0 = lds + P0->xoff;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (i * 64 < per) *(f32x4*)(xs0 + xperm((wave * per + i * 64 + lane) << 2)) = xin[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) lds_add(&ctrl[0], (uint32_t)NCW);
+    }
     while (cph < nph) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
@@ -316,20 +342,23 @@ size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw) {
     return ((size_t)a.xf_total + 2 * (size_t)ncw + (size_t)nsw * a.gpw_res * R) * 4 + 64;
 }
 
-// register sets in flight per stream wave: ENG_PF by default; CM_ENG_PF=3|5 selects the other instantiations (tuning only)
-static int eng_pf() {
-    static int pf = 0;
-    if (pf == 0) {
-        pf = ENG_PF;
-        if (const char* e = getenv("CM_ENG_PF")) { const int v = atoi(e); if (v == 3 || v == 4 || v == 5) pf = v; }
+// (stream waves per workgroup, register sets in flight per stream wave): the default, or CM_ENG_CFG="nsw,pf" (tuning only)
+EngCfg engine_config() {
+    static EngCfg c{0, 0, 0};
+    if (c.nsw == 0) {
+        c = EngCfg{ENG_NSW, ENG_NCW, ENG_PF};
+        if (const char* e = getenv("CM_ENG_CFG")) {
+            int n = 0, p = 0;
+            if (sscanf(e, "%d,%d", &n, &p) == 2 && ((n == 4 && (p == 3 || p == 4)) || (n == 8 && (p == 2 || p == 3)))) { c.nsw = n; c.pf = p; }
+        }
     }
-    return pf;
+    return c;
 }
 
-template <int PF>
-static bool prepare_pf(size_t lds_bytes) {
-    auto k = engine_chain_kernel<ENG_NSW, ENG_NCW, PF, false>;
-    auto kt = engine_chain_kernel<ENG_NSW, ENG_NCW, PF, true>;
+template <int NSW, int PF>
+static bool prepare_v(size_t lds_bytes) {
+    auto k = engine_chain_kernel<NSW, ENG_NCW, PF, false>;
+    auto kt = engine_chain_kernel<NSW, ENG_NCW, PF, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -339,28 +368,24 @@ static bool prepare_pf(size_t lds_bytes) {
 }
 
 bool engine_prepare(size_t lds_bytes) {
-    switch (eng_pf()) {
-        case 3: return prepare_pf<3>(lds_bytes);
-        case 5: return prepare_pf<5>(lds_bytes);
-        default: return prepare_pf<4>(lds_bytes);
-    }
+    const EngCfg c = engine_config();
+    if (c.nsw == 8) return c.pf == 2 ? prepare_v<8, 2>(lds_bytes) : prepare_v<8, 3>(lds_bytes);
+    return c.pf == 3 ? prepare_v<4, 3>(lds_bytes) : prepare_v<4, 4>(lds_bytes);
 }
 
-template <int PF>
-static void launch_pf(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
-    if (trace) hipLaunchKernelGGL((engine_chain_kernel<ENG_NSW, ENG_NCW, PF, true>), dim3(grid), dim3((ENG_NSW + ENG_NCW) * 64), lds, s, a);
-    else hipLaunchKernelGGL((engine_chain_kernel<ENG_NSW, ENG_NCW, PF, false>), dim3(grid), dim3((ENG_NSW + ENG_NCW) * 64), lds, s, a);
+template <int NSW, int PF>
+static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
+    if (trace) hipLaunchKernelGGL((engine_chain_kernel<NSW, ENG_NCW, PF, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    else hipLaunchKernelGGL((engine_chain_kernel<NSW, ENG_NCW, PF, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
 }
 
 bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s, bool trace) {
-    const size_t lds = engine_lds_bytes(a, ENG_NSW, ENG_NCW);
+    const EngCfg c = engine_config();
+    const size_t lds = engine_lds_bytes(a, c.nsw, c.ncw);
     if (lds > 160 * 1024 - 256 || a.gpw_res > 4) return false;
     const bool tr = trace && a.trace != nullptr;
-    switch (eng_pf()) {
-        case 3: launch_pf<3>(a, grid, lds, s, tr); break;
-        case 5: launch_pf<5>(a, grid, lds, s, tr); break;
-        default: launch_pf<4>(a, grid, lds, s, tr); break;
-    }
+    if (c.nsw == 8) { if (c.pf == 2) launch_v<8, 2>(a, grid, lds, s, tr); else launch_v<8, 3>(a, grid, lds, s, tr); }
+    else { if (c.pf == 3) launch_v<4, 3>(a, grid, lds, s, tr); else launch_v<4, 4>(a, grid, lds, s, tr); }
     return true;
 }
 

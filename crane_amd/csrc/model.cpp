@@ -319,7 +319,7 @@ bool Model::engine_eligible(std::string* why) const {
     if (tp != 1 || rccl) return no("tensor parallelism");
     const int Ko = Hq_l * cfg.D;
     if (Ko % 2048 || cfg.H % 2048 || I_l % 2048) return no("projection widths must be multiples of 2048");
-    const int TW = num_cu * ENG_NSW;
+    const int TW = num_cu * engine_config().nsw;
     if ((cfg.H / 2 + TW - 1) / TW > 4) return no("hidden size too large for the residual slots");
     return true;
 }
@@ -335,14 +335,15 @@ void Model::build_engine() {
         if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: " + why);
         return;
     }
-    const int H = cfg.H, D = cfg.D, Ko = Hq_l * D, TW = num_cu * ENG_NSW;
+    const EngCfg ec = engine_config();
+    const int H = cfg.H, D = cfg.D, Ko = Hq_l * D, TW = num_cu * ec.nsw;
     const int x0 = std::max(Ko, H), x1 = H, xh = I_l;
     eng_xf_total = x0 + x1 + xh;
     auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
     eng_gpw_res = gpw(H);
     EngArgs probe{};
     probe.xf_total = eng_xf_total; probe.gpw_res = eng_gpw_res;
-    if (engine_lds_bytes(probe, ENG_NSW, ENG_NCW) > 160 * 1024 - 256) {
+    if (engine_lds_bytes(probe, ec.nsw, ec.ncw) > 160 * 1024 - 256) {
         if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: input vectors do not fit LDS");
         return;
     }
@@ -368,7 +369,7 @@ void Model::build_engine() {
         eng_gran[e] = (unsigned long long*)dalloc<int>(gsz[e] * 2);
         CM_HIP(hipMemset(eng_gran[e], 0, gsz[e] * 8));       // tag 0 is never a valid epoch
     }
-    if (!engine_prepare(engine_lds_bytes(probe, ENG_NSW, ENG_NCW))) {
+    if (!engine_prepare(engine_lds_bytes(probe, ec.nsw, ec.ncw))) {
         if (opts.engine > 0) throw CmError(CM_ERR_DEVICE, "cm_opts.engine = 1: kernel attribute");
         return;
     }
@@ -389,7 +390,8 @@ EngArgs Model::engine_args(int li) const {
 // event 3 of a comm wave = number of granule sweeps that found stale tags)
 void Model::engine_trace(float* out, size_t n) {
     if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent chain kernel is not active on this model");
-    const size_t waves = ENG_NSW + ENG_NCW, total = (size_t)num_cu * waves * ENG_MAXPH * 4;
+    const EngCfg ec = engine_config();
+    const size_t waves = (size_t)(ec.nsw + ec.ncw), total = (size_t)num_cu * waves * ENG_MAXPH * 4;
     if (n != total) throw CmError(CM_ERR_RANGE, "engine_trace: expected " + std::to_string(total) + " values");
     unsigned long long* d = nullptr;
     CM_HIP(hipMalloc((void**)&d, total * 8));
@@ -405,10 +407,10 @@ void Model::engine_trace(float* out, size_t n) {
     (void)hipFree(d);
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < total; ++i)
-        if ((i & 3) != 3 || ((i / 4) % ENG_MAXPH == 0 && ((i / (4 * ENG_MAXPH)) % waves) < (size_t)ENG_NSW))   // stamps, not spin counts
+        if ((i & 3) != 3 || ((i / 4) % ENG_MAXPH == 0 && ((i / (4 * ENG_MAXPH)) % waves) < (size_t)ec.nsw))   // stamps, not spin counts
             if (h[i] != 0 && h[i] < t0) t0 = h[i];
     for (size_t i = 0; i < total; ++i) {
-        const bool is_count = (i & 3) == 3 && ((i / (4 * ENG_MAXPH)) % waves) >= (size_t)ENG_NSW;
+        const bool is_count = (i & 3) == 3 && ((i / (4 * ENG_MAXPH)) % waves) >= (size_t)ec.nsw;
         if (is_count) out[i] = (float)h[i];
         else out[i] = h[i] == 0 ? 0.f : (float)((double)(h[i] - t0) * 0.01) + 0.01f;    // 100 MHz -> us
     }

@@ -142,26 +142,33 @@ void qc_destroy(qc_model* m) {
 }
 
 /* y[n] = W[n,:] . x  (bf16 weights, f32 accumulate), rows split over the host cores.
- * 16 independent lane accumulators (fixed order) so the compiler can use SIMD without
- * re-associating a single float chain. */
+ * 16 independent lane accumulators (lane j sums the products of k = j mod 16 in ascending k, then a fixed tree): written
+ * with GCC vector extensions so the bf16 -> f32 widening and the multiply/add are SIMD (AVX2 / AVX-512 with -march=native)
+ * without re-associating anything -- bit-identical to the scalar loop it replaces (-ffp-contract=off: no FMA). */
+typedef float v16f __attribute__((vector_size(64)));
+typedef uint16_t v16h __attribute__((vector_size(32)));
+typedef uint32_t v16u __attribute__((vector_size(64)));
+
 static void gemv(const uint16_t* W, const float* x, float* y, int N, int K) {
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
         const uint16_t* w = W + (size_t)n * K;
-        float acc[16];
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        v16f acc = {0};
         int k = 0;
         for (; k + 16 <= K; k += 16) {
-            for (int j = 0; j < 16; ++j) {
-                uint32_t u = ((uint32_t)w[k + j]) << 16;
-                float f;
-                memcpy(&f, &u, 4);
-                acc[j] += f * x[k + j];
-            }
+            v16h h;
+            v16f xv, f;
+            memcpy(&h, w + k, sizeof h);
+            memcpy(&xv, x + k, sizeof xv);
+            const v16u u = __builtin_convertvector(h, v16u) << 16;
+            memcpy(&f, &u, sizeof f);
+            acc += f * xv;
         }
-        for (; k < K; ++k) acc[k & 15] += bf2f(w[k]) * x[k];
+        float a[16];
+        memcpy(a, &acc, sizeof a);
+        for (; k < K; ++k) a[k & 15] += bf2f(w[k]) * x[k];
         float s8[8];
-        for (int j = 0; j < 8; ++j) s8[j] = acc[j] + acc[j + 8];
+        for (int j = 0; j < 8; ++j) s8[j] = a[j] + a[j + 8];
         y[n] = ((s8[0] + s8[4]) + (s8[1] + s8[5])) + ((s8[2] + s8[6]) + (s8[3] + s8[7]));
     }
 }
@@ -293,6 +300,16 @@ void qc_fill_kv_paged(qc_model* m, int ctx, uint64_t seed, int page) {
                     }
         }
     m->len = ctx;
+}
+
+/* OpenMP team size of the forward (default: OMP_NUM_THREADS / all visible CPUs).  More threads than physical cores of
+ * one socket made the GPU hosts SLOWER (barrier cost, remote NUMA reads), so the caller sizes it. */
+void qc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int qc_num_threads(void) {

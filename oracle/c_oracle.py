@@ -31,6 +31,7 @@ def _lib():
     lib.qc_fill_kv.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
     lib.qc_fill_kv_paged.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     lib.qc_num_threads.restype = C.c_int
+    lib.qc_set_threads.argtypes = [C.c_int]
     return lib
 
 

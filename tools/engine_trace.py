@@ -18,10 +18,11 @@ if len(sys.argv) > 2:
 m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, engine=1)
 m.debug_fill_kv(1024, seed=1)
 m.bench_decode(3, 8)
-NB, NW, NSW, MAXPH = 256, 8, 4, 4
+NSW = int(os.environ.get('CM_ENG_CFG', '4,4').split(',')[0])
+NB, NW, MAXPH = 256, NSW + 4, 4
 for rep in range(2):
     t = m.debug_read("engine_trace", NB * NW * MAXPH * 4).reshape(NB, NW, MAXPH, 4)
-    print(f"--- traced launch {rep} (PF={os.environ.get('CM_ENG_PF', '4')}) ---")
+    print(f"--- traced launch {rep} (CM_ENG_CFG={os.environ.get('CM_ENG_CFG', 'default')}) ---")
     ent = t[:, :NSW, 0, 3]
     print(f"kernel entry (stream waves): min {ent.min():.2f} med {np.median(ent):.2f} max {ent.max():.2f}")
     names = ["o_proj", "gate_up", "down", "qkv_next"]
