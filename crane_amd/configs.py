@@ -32,7 +32,7 @@ CONFIGS = {
                           head_dim=128, tie_word_embeddings=True),
     # widths that are multiples of 2048 (what the persistent chain kernel needs), small enough for the numpy oracle
     "eng-qwen3": dict(_QWEN3_COMMON, vocab_size=2048, hidden_size=2048, intermediate_size=4096,
-                      num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=8,
+                      num_hidden_layers=3, num_attention_heads=32, num_key_value_heads=8,
                       head_dim=128, tie_word_embeddings=False, max_position_embeddings=8192),
     # small shapes for CPU-oracle parity
     "tiny-qwen3": dict(_QWEN3_COMMON, vocab_size=512, hidden_size=256, intermediate_size=512,

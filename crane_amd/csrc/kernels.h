@@ -180,38 +180,63 @@ bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int k
 void launch_gdn(const GdnArgs& a, hipStream_t s);
 void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hipStream_t s);
 
-// ---- persistent chain kernel (kernels_engine.hip): o_proj -> gate||up -> down_proj -> next layer's QKV in one launch ----
+// ---- persistent decode kernel (kernels_engine.hip): the row-streaming projections of MANY layers in one launch ----
 enum { ENG_STORE = 0, ENG_RESADD = 1, ENG_SILUMUL = 2 };
-constexpr int ENG_NSW = 4, ENG_NCW = 4, ENG_PF = 4;   // stream waves, comm waves per workgroup; register sets in flight per stream wave
-struct EngPhase {                 // one row-streaming projection
+constexpr int ENG_NCW = 4;                 // comm waves per workgroup
+constexpr int ENG_TRACE_PH = 8;            // phases the debug instantiation records
+// granule buffers: one per kind of vector handed between workgroups inside a launch
+enum { ENG_E_X0 = 0,      // [H]   residual after down_proj  -> input of the next layer's QKV
+       ENG_E_QKV = 1,     // [qkv rows] merged q | k | v of the token -> attention
+       ENG_E_PART = 2,    // [Hkv][nsplit][nrep][D + 2] split-KV partials (o, m, l)
+       ENG_E_ATTN = 3,    // [Hq * D] attention output -> input of o_proj
+       ENG_E_X1 = 4,      // [H]   residual after o_proj -> input of gate||up
+       ENG_E_H = 5,       // [I]   silu(gate) * up -> input of down_proj
+       ENG_NEDGE = 6 };
+struct EngPhase {                 // one row-streaming projection of the program (table in HBM, read as constant memory)
     const uint16_t* W;            // [N, K] bf16, K contiguous
     const float* nw;              // RMSNorm weight applied to the INPUT vector, or null (plain input)
-    const float* vin;             // input vector [K] f32 when in_edge < 0 (written by an earlier kernel)
-    float* vout;                  // output vector when out_edge < 0 (read by a later kernel)
     int N, K;
     int kind;                     // ENG_STORE | ENG_RESADD | ENG_SILUMUL (rows interleaved gate_j, up_j)
     int gpw;                      // row groups (of 2 rows) per stream wave, rounded up
-    int nbpg;                     // batches per row group = K / 2048
-    int xoff;                     // float offset of the input buffer inside LDS
-    int in_edge, out_edge;        // granule buffers (0..2) carrying the input / output between workgroups, or -1
+    int nb;                       // 2048-element chunks of K (= batches per row group)
+    int gblk;                     // row groups a wave keeps open at once (chunk-major order inside such a block)
+    int xoff, xbuf;               // LDS input buffer: float offset; readiness-counter row (0..3; bit 0 = sum-of-squares row)
+    int in_edge, out_edge;        // granule buffers (ENG_E_*), -1: none
+    int in_tag, out_tag;          // tags of those edges relative to the launch's epoch base
+    int layer;                    // decoder layer (attention operands)
+    int useq;                     // how many earlier phases of the table share this counter row
+    int pre_attn;                 // the comm waves run this layer's attention before staging this phase's input
 };
-constexpr int ENG_MAXPH = 4;
+struct EngAttnL {                 // attention operands of one layer
+    void* kpool;                  // [pages][Hkv][PAGE][D] bf16
+    void* vpool;
+    const float* qnw;             // [D] f32 or null
+    const float* knw;
+};
 struct EngArgs {
-    const EngPhase* prog;         // phase table in HBM (one per layer); read through the constant address space (scalar loads)
-    unsigned long long* gran0;    // 8-byte {f32 value, u32 tag} granules, one buffer per dependency edge of the chain
-    unsigned long long* gran1;
-    unsigned long long* gran2;
+    const EngPhase* prog;         // phase table; this launch runs phases [p0, p1)
+    const EngAttnL* attn;         // per layer, or null when no phase of the launch has pre_attn
+    unsigned long long* gran[ENG_NEDGE];   // 8-byte {f32 value, u32 tag} granules
+    const float* vin;             // input vector of phase p0 (written by an earlier kernel)
+    float* vout;                  // plain_last: output vector of phase p1 - 1 (read by a later kernel)
     float* xres;                  // [H] residual stream (read at entry, written back at exit)
     uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)
-    unsigned long long* trace;    // debug build of the kernel only: [grid][waves][ENG_MAXPH][4] 100 MHz timestamps
-    int nph, H, gpw_res, xf_total;   // phases; hidden size; row groups per wave of the residual phases; LDS floats of all input buffers
-    float eps;
+    unsigned long long* trace;    // debug instantiation only: [grid][waves][ENG_TRACE_PH][4] 100 MHz timestamps
+    const StepState* st;          // attention: position of the token
+    const int32_t* block_table;
+    const float* cos;             // [max_pos, D/2]
+    const float* sin;
+    int p0, p1, plain_last, epoch_step;
+    int ub0, ub1, ub2, ub3;       // useq of the first phase of THIS launch on each counter row
+    int H, gpw_res, xf_total;     // hidden size; row groups per wave of the residual phases; LDS floats of the input buffers
+    int Hkv, page, max_pages, q_off, k_off, v_off;
+    float eps, scale;
 };
 struct EngCfg { int nsw, ncw, pf; };
 EngCfg engine_config();           // the instantiation the launcher uses (default, or CM_ENG_CFG while tuning)
 size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw);
 bool engine_prepare(size_t lds_bytes);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
-bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s, bool trace = false);
+bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace = false);
 
 // ---- synthetic weights / utility ----
 // dst[(r * dst_row_stride) + c] = bf16(synth(idx = (row0 + r) * full_cols + col0 + c))

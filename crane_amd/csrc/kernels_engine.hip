@@ -1,26 +1,29 @@
-// Persistent "chain" kernel for the decode step: the row-streaming projections of one decoder layer that follow the
-// attention -- o_proj (+residual) -> RMSNorm -> gate||up (+SiLU*mul) -> down_proj (+residual) -> RMSNorm -> the NEXT
-// layer's merged QKV projection -- run as ONE launch on one workgroup per CU instead of four dependent launches
-// (reference: DecoderLayer::forward / Mlp::forward / Attention::forward, crane-core/src/models/qwen3/modeling.rs:
-// 307-363, 608-642, 698-716).  The arithmetic is the fused GEMV's of kernels_decode.hip, operation for operation.
+// Persistent decode kernel: ONE launch on one workgroup per CU runs the row-streaming projections of a whole token --
+// per layer RMSNorm + merged QKV, o_proj (+residual), RMSNorm + gate||up (+SiLU*mul), down_proj (+residual) -- and, between
+// QKV and o_proj, the attention of that layer (per-head RMSNorm, RoPE, KV append, split-KV online softmax, merge).
+// Reference: Qwen3Model::decode / DecoderLayer::forward / Attention::forward / Mlp::forward,
+// crane-core/src/models/qwen3/modeling.rs:307-533, 608-642, 698-716, 984-1036.  The arithmetic per row is the fused
+// GEMV's of kernels_decode.hip and the attention's is attn_decode_split_kernel's (kernels_attn_decode.hip).
 //
-// Why: at batch 1 every projection is a pure weight stream, and a dependent launch costs its boundary plus the ramp
-// and drain of the HBM pipe (~20 us of the 81 us a Qwen3-8B layer takes as six launches).  Here the weight stream never
-// stops at a dependency edge:
-//   * STREAM waves (4 per CU) own fixed row groups of every phase and keep PF register sets of 16-byte non-temporal
-//     weight loads in flight (PF x 8 KiB per wave).  Weight addresses do not depend on activations, so while a wave
-//     waits for the next phase's input vector the loads of that phase are already landing (the register file is the
-//     prefetch ring: 128 KiB per CU).  Loads are unconditional and the register sets statically named, so every wait is
-//     a counted vmcnt.
-//   * COMM waves (4 per CU) have nothing in their own memory queue, so their polls are not stuck behind a prefetch
-//     burst (s_waitcnt vmcnt counts in issue order per wave).  They move each phase's output vector from the 1024
-//     producing waves to every CU: a producer writes each f32 as ONE 8-byte {value, tag} granule with a write-through
-//     (sc1) agent-scope store; a comm wave sweeps the granules with sc1 loads until every tag equals the epoch of the
-//     edge, stages the values into LDS in the GEMV's conflict-free permutation (folding the RMSNorm weight and the
-//     sum of squares), and bumps an LDS counter the stream waves poll (LDS traffic uses lgkmcnt, never vmcnt).
-//     The data is its own flag: no fences, no release/acquire, placement-independent (MI355X_MICROARCH.md, Guideline 16 R2).
-//   * the residual stream row r is owned by the same lane of the same wave in o_proj and down_proj and lives in LDS
-//     between phases.
+// Why: at batch 1 every projection is a pure weight stream; as separate launches a Qwen3-8B layer costs 81 us for
+// 62 us of streaming (six boundaries, each with the ramp and drain of the HBM pipe, and two latency-bound attention
+// launches).  Here the weight stream does not stop at a dependency:
+//   * STREAM waves own fixed row groups of every phase and keep PF register sets of 16-byte non-temporal weight loads
+//     in flight (PF x 8 KiB per wave).  Weight addresses do not depend on activations, so while a wave waits for an
+//     input vector the next phases' weights are already landing: the register file is the prefetch ring.  Loads are
+//     unconditional and the register sets statically named, so every wait is a counted vmcnt.
+//   * Dependencies are per 2048-element CHUNK of the input vector, not per vector: a wave keeps `gblk` row groups
+//     open and walks them chunk-major, so the last chunk of an input (the one that needs the slowest producer) is
+//     needed only after (nb - 1) / nb of the wave's work on that block.
+//   * COMM waves have nothing in their own memory queue, so their polls are not stuck behind a prefetch burst
+//     (s_waitcnt vmcnt counts in issue order per wave).  A producer writes each f32 of an output vector as ONE 8-byte
+//     {value, tag} granule with a write-through (sc1) agent-scope store; a comm wave sweeps 1024 granules per pass with
+//     sc1 loads until every tag equals the epoch of the edge, stages the values into LDS in the GEMV's conflict-free
+//     permutation (folding the RMSNorm weight and the sum of squares) and bumps the chunk's LDS counter.  The data is
+//     its own flag: no fences, placement-independent (MI355X_MICROARCH.md, Guideline 16 R2).
+//   * The comm waves of workgroup (kv head, split) also run that split of the layer's attention -- the block of
+//     attn_decode_split_kernel on 4 waves -- exchange partials as granules, merge a 16-value slice each and publish it.
+//   * The residual stream row r is owned by the same lane of the same wave in o_proj and down_proj and lives in LDS.
 // Every spin is bounded; a timeout raises ctl[1], later launches return at once, and the host reports the code.
 #include <cstdio>
 #include <cstdlib>
@@ -34,11 +37,17 @@ namespace {
 
 constexpr int R = 2;            // rows per group (one wave reduces R rows at a time)
 constexpr int U = 4;            // 512-element chunks per batch: a batch = R x U 16-byte loads per lane = 8 KiB per wave
+constexpr int CHUNK = U * 512;  // input elements one batch consumes
+constexpr int MAXCH = 8;        // chunks per input vector (K <= 16384)
+constexpr int MAXGB = 6;        // row groups a wave keeps open
+constexpr int MAXRES = 4;       // residual row groups per wave
+constexpr int AD = 128;         // attention head_dim
+constexpr int ACT = 16;         // attention: tokens per workgroup step (4 waves x 4 rows of 16 lanes)
 constexpr uint32_t SPIN_LDS = 400000u;     // x ~0.1 us
 constexpr uint32_t SPIN_GLOBAL = 60000u;   // x ~0.5 us
 
 typedef unsigned long long u64;
-// every pointer taken from the phase table is a global-memory pointer: say so, or the loads become flat_* (which count on
+// every pointer taken from the tables is a global-memory pointer: say so, or the accesses become flat_* (which count on
 // lgkmcnt as well and force full waits)
 #define CM_GLOBAL __attribute__((address_space(1)))
 #define CM_CONST __attribute__((address_space(4)))
@@ -46,12 +55,24 @@ typedef const CM_CONST EngPhase* ph_ptr;
 typedef const CM_GLOBAL u32x4* gw_ptr;
 typedef const CM_GLOBAL float* gf_cptr;
 typedef CM_GLOBAL float* gf_ptr;
+typedef CM_GLOBAL u64* gu_ptr;
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void lds_add(uint32_t* p, uint32_t v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ u64 gran_ld(const u64* p) {
+    return __hip_atomic_load((gu_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_st(u64* p, uint32_t tag, float v) {
+    __hip_atomic_store((gu_ptr)p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a.gran[e] with a run-time e: a chain of selects (indexing the by-value argument struct dynamically would copy it to scratch)
+__device__ __forceinline__ u64* gran_sel(const EngArgs& a, int e) {
+    return e == 0 ? a.gran[0] : e == 1 ? a.gran[1] : e == 2 ? a.gran[2] : e == 3 ? a.gran[3] : e == 4 ? a.gran[4] : a.gran[5];
 }
 
 // float index inside an LDS input buffer: the permutation gemv_bf16_kernel stages x with (two conflict-free
@@ -61,105 +82,360 @@ __device__ __forceinline__ int xperm(int k) {
     return ((c * 128 + ((j >> 2) & 1) * 64 + (j >> 3)) << 2) + (j & 3);
 }
 
+// LDS control words (uint32 index)
+enum { C_PROG = 0,      // row groups finished by this workgroup's stream waves (monotonic over the launch)
+       C_ABORT = 1,
+       C_CBAR = 2,      // barrier counter of the comm waves
+       C_CNT = 4,       // [4 counter rows][MAXCH]: passes staged (monotonic; 2 passes per chunk)
+       C_WORDS = 64 };
+
 }  // namespace
 
-template <int NSW, int NCW, int PF, bool TRACE>
-__global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_chain_kernel(EngArgs a) {
+template <int NSW, int NCW, int PF, int NREP, bool TRACE>
+__global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_kernel(EngArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float* ssq = lds + a.xf_total;                       // [2][NCW] partial sums of squares
-    float* xres_l = ssq + 2 * NCW;                       // [NSW][gpw_res][R] residual rows of this block's stream waves
-    uint32_t* ctrl = (uint32_t*)(xres_l + NSW * a.gpw_res * R);   // [0] inputs staged (x NCW), [1] stream waves done (x NSW), [2] abort
+    // ---- LDS carve (floats) ----
+    float* ssq = lds + a.xf_total;                       // [2][16] sum of squares per 1024-element pass of a normed input
+    float* accp = ssq + 32;                              // [NSW][MAXGB][R] running row sums of the open row groups
+    float* xres_l = accp + NSW * MAXGB * R;              // [NSW][MAXRES][R] residual rows owned by the stream waves
+    uint32_t* ctrl = (uint32_t*)(xres_l + NSW * MAXRES * R);
+    float* asc = (float*)(ctrl + C_WORDS);               // attention scratch of the comm waves
 
-    // TRACE (debug instantiation, cm_debug_read "engine_trace"): 100 MHz timestamps per (wave, phase, event)
     auto stamp = [&](int ph, int k, u64 val = ~0ull) __attribute__((always_inline)) {
         if constexpr (TRACE) {
-            if (lane == 0) a.trace[(((size_t)blockIdx.x * (NSW + NCW) + wave) * ENG_MAXPH + ph) * 4 + k] = val == ~0ull ? __builtin_amdgcn_s_memrealtime() : val;
+            if (lane == 0 && ph < ENG_TRACE_PH)
+                a.trace[(((size_t)blockIdx.x * (NSW + NCW) + wave) * ENG_TRACE_PH + ph) * 4 + k] = val == ~0ull ? __builtin_amdgcn_s_memrealtime() : val;
         }
     };
     if (__builtin_nontemporal_load(&a.ctl[1]) != 0u) return;       // an earlier launch timed out: do nothing
-    const uint32_t base = __builtin_nontemporal_load(&a.ctl[0]);   // epoch base of this launch (tags base+1 ... base+nph)
-    if (threadIdx.x < 4) ctrl[threadIdx.x] = 0u;
+    const uint32_t base = __builtin_nontemporal_load(&a.ctl[0]);   // epoch base of this launch
+    if (threadIdx.x < C_WORDS) ctrl[threadIdx.x] = 0u;
     __syncthreads();
 
-    const int nph = a.nph;
+    const int p0 = a.p0, p1 = a.p1;
+    auto fail = [&](uint32_t code) __attribute__((always_inline)) {
+        if (lane == 0) { atomicExch(&a.ctl[1], code); ctrl[C_ABORT] = 1u; }
+    };
 
     if (wave >= NSW) {
-        // =========================== COMM waves: stage every phase's input vector into LDS ===========================
+        // =====================================================================================================
+        // COMM waves: stage the input vector of every phase into LDS (chunk by chunk); run the attention
+        // =====================================================================================================
         const int cw = wave - NSW;
-        for (int p = 1; p < nph; ++p) {                  // phase 0's input is staged by the stream waves (below)
-            ph_ptr P = (ph_ptr)a.prog + p;
-            const int K = P->K, in_edge = P->in_edge;
-            gf_cptr nw = (gf_cptr)P->nw;
-            gf_cptr vin = (gf_cptr)P->vin;
-            float* xs = lds + P->xoff;
-            stamp(p, 0);
-            uint32_t total_spins = 0;
-            {                                             // do not poll HBM while this CU's own waves are mid-phase
-                uint32_t spins = 0;
-                while (lds_ld(&ctrl[1]) < (uint32_t)(NSW * p) && lds_ld(&ctrl[2]) == 0u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SPIN_LDS) { if (lane == 0) { atomicExch(&a.ctl[1], 0x100u + (uint32_t)p); ctrl[2] = 1u; } break; }
-                }
+        const int tid = cw * 64 + lane;
+        uint32_t prog_before = 0;                         // row groups all phases before the previous one added to C_PROG
+        uint32_t nbar = 0;                                // comm-wave barriers passed
+        int prev_gpw = 0;
+        auto own_progress = [&](uint32_t want, uint32_t code) __attribute__((always_inline)) {
+            uint32_t spins = 0;
+            while (lds_ld(&ctrl[C_PROG]) < want && lds_ld(&ctrl[C_ABORT]) == 0u) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SPIN_LDS) { fail(code); break; }
             }
-            stamp(p, 1);
-            const u64* G = in_edge == 0 ? a.gran0 : (in_edge == 1 ? a.gran1 : a.gran2);
-            const uint32_t tag = base + (uint32_t)p;      // written by phase p - 1
-            float ss = 0.f;
-            for (int pass = cw; pass * 1024 < K; pass += NCW) {
-                const int kb = pass * 1024 + lane;
-                float v[16], wv[16];
-                if (nw != nullptr) {
+        };
+        auto cbar = [&]() __attribute__((always_inline)) {
+            ++nbar;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_add(&ctrl[C_CBAR], 1u);
+            uint32_t spins = 0;
+            while (lds_ld(&ctrl[C_CBAR]) < nbar * NCW && lds_ld(&ctrl[C_ABORT]) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LDS) { fail(0x500u); break; }
+            }
+            asm volatile("" ::: "memory");
+        };
+
+        for (int p = p0; p < p1; ++p) {
+            ph_ptr P = (ph_ptr)a.prog + p;
+            const int K = P->K, xbuf = P->xbuf, gpw_p = P->gpw;
+            if (p == p0) {                                // staged by the stream waves from a.vin
+                prev_gpw = gpw_p;
+                continue;
+            }
+            stamp(p - p0, 0);
+            if (P->pre_attn) {
+                // ================= attention of this layer (split `blockIdx / Hkv` of kv head `blockIdx % Hkv`) =================
+                const CM_CONST EngAttnL* AL = (const CM_CONST EngAttnL*)a.attn + P->layer;
+                const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = gridDim.x / Hkv;
+                const int r = lane >> 4, sub = lane & 15, dimbase = sub * 8, tok_in_chunk = cw * 4 + r;
+                const uint32_t tag = base + (uint32_t)P->in_tag;     // QKV, partials and merged output of this layer share it
+                float* qs = asc;                          // [NREP][AD]
+                float* knew = qs + NREP * AD;             // [AD]
+                float* vnew = knew + AD;                  // [AD]
+                float* red_m = vnew + AD;                 // [ACT][NREP]
+                float* red_l = red_m + ACT * NREP;        // [ACT][NREP]
+                float* red_o = red_l + ACT * NREP;        // [ACT][NREP][AD]
+                float* mo = red_o + ACT * NREP * AD;      // [nsplit <= 32][18] gathered partial slices
+                const CM_GLOBAL uint16_t* kp = (const CM_GLOBAL uint16_t*)AL->kpool;
+                const CM_GLOBAL uint16_t* vp = (const CM_GLOBAL uint16_t*)AL->vpool;
+                const CM_GLOBAL int32_t* bt = (const CM_GLOBAL int32_t*)a.block_table;
+                auto kv_off = [&](int t) -> size_t {
+                    int pi = t / a.page;
+                    pi = pi < a.max_pages ? pi : a.max_pages - 1;     // speculative loads stay inside the table
+                    return ((size_t)(bt[pi] * Hkv + kvh) * a.page + (t % a.page)) * AD + dimbase;
+                };
+                // K/V rows of this block's first two chunks: requested before anything else (independent of this layer's QKV)
+                u32x4 kq[2], vq[2];
+                int tt[2];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) wv[i] = nw[kb + i * 64];
+                for (int u = 0; u < 2; ++u) {
+                    tt[u] = ACT * (split + nsplit * u) + tok_in_chunk;
+                    const size_t off = kv_off(tt[u]);
+                    kq[u] = *(gw_ptr)(kp + off);
+                    vq[u] = *(gw_ptr)(vp + off);
                 }
-                if (in_edge < 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = vin[kb + i * 64];
-                } else {
+                const int pos = ((const CM_GLOBAL StepState*)a.st)->pos;
+                const int rpos = pos + ((const CM_GLOBAL StepState*)a.st)->rsv[0];
+                const int L = pos + 1;
+                const bool owner = ((pos / ACT) % nsplit) == split;
+                const int hrot = AD >> 1;
+                // this workgroup's own stream waves must be through the QKV phase before its comm waves poll the result
+                own_progress(prog_before + (uint32_t)(NSW * prev_gpw), 0x600u + (uint32_t)(p - p0));
+                stamp(p - p0, 1);
+                const u64* GQ = a.gran[ENG_E_QKV];
+                for (int item = cw; item < NREP + 2; item += NCW) {      // q heads of the group, new k, new v
+                    int g0;
+                    gf_cptr nw = nullptr;
+                    if (item < NREP) { g0 = a.q_off + (kvh * NREP + item) * AD; nw = (gf_cptr)AL->qnw; }
+                    else if (item == NREP) { g0 = a.k_off + kvh * AD; nw = (gf_cptr)AL->knw; }
+                    else { g0 = a.v_off + kvh * AD; }
+                    float xv[2];
                     uint32_t spins = 0;
+                    for (;;) {
+                        const u64 x0 = gran_ld(GQ + g0 + lane), x1 = gran_ld(GQ + g0 + lane + 64);
+                        xv[0] = __uint_as_float((uint32_t)x0); xv[1] = __uint_as_float((uint32_t)x1);
+                        if (__all((uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag)) break;
+                        if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
+                        if (++spins > SPIN_GLOBAL) { fail(0x700u + (uint32_t)(p - p0)); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (item <= NREP) {
+                        if (nw != nullptr) {
+                            const float ss = wave_sum(xv[0] * xv[0] + xv[1] * xv[1]);
+                            const float rr = 1.0f / sqrtf(ss / (float)AD + a.eps);
+                            xv[0] = xv[0] * rr * nw[lane]; xv[1] = xv[1] * rr * nw[lane + 64];
+                        }
+                        // rotate-half RoPE over the whole head: the partner of d is d +/- D/2 = the other element of this lane
+                        const float c = ((gf_cptr)a.cos)[(size_t)rpos * hrot + lane], s = ((gf_cptr)a.sin)[(size_t)rpos * hrot + lane];
+                        const float lo = xv[0], hi = xv[1];
+                        xv[0] = lo * c - hi * s;
+                        xv[1] = lo * s + hi * c;
+                    }
+                    if (item < NREP) {
+                        qs[item * AD + lane] = xv[0] * a.scale;
+                        qs[item * AD + lane + 64] = xv[1] * a.scale;
+                    } else {
+                        float* dst = item == NREP ? knew : vnew;
+                        CM_GLOBAL uint16_t* pool = (CM_GLOBAL uint16_t*)(item == NREP ? AL->kpool : AL->vpool);
+                        const size_t eoff = owner ? ((size_t)(bt[pos / a.page] * Hkv + kvh) * a.page + (pos % a.page)) * AD : 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint16_t b = f32_to_bf16(xv[j]);
+                            dst[lane + 64 * j] = bf16_to_f32(b);
+                            if (owner) pool[eoff + lane + 64 * j] = b;
+                        }
+                    }
+                }
+                cbar();
+                float qr[NREP][8];
+#pragma unroll
+                for (int h = 0; h < NREP; ++h) {
+                    const f32x4 q0 = *(const f32x4*)&qs[h * AD + dimbase];
+                    const f32x4 q1 = *(const f32x4*)&qs[h * AD + dimbase + 4];
+                    qr[h][0] = q0[0]; qr[h][1] = q0[1]; qr[h][2] = q0[2]; qr[h][3] = q0[3];
+                    qr[h][4] = q1[0]; qr[h][5] = q1[1]; qr[h][6] = q1[2]; qr[h][7] = q1[3];
+                }
+                float m[NREP], l[NREP], acc[NREP][8];
+#pragma unroll
+                for (int h = 0; h < NREP; ++h) {
+                    m[h] = -INFINITY; l[h] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+                }
+                auto consume = [&](const u32x4& kqv, const u32x4& vqv, int t) __attribute__((always_inline)) {
+                    const bool valid = t < L;
+                    float kf[8], vf[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        kf[2 * e] = bf16_lo(kqv[e]); kf[2 * e + 1] = bf16_hi(kqv[e]);
+                        vf[2 * e] = bf16_lo(vqv[e]); vf[2 * e + 1] = bf16_hi(vqv[e]);
+                    }
+                    if (t == pos) {   // the token appended by this very step: values from LDS
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { kf[e] = knew[dimbase + e]; vf[e] = vnew[dimbase + e]; }
+                    }
+#pragma unroll
+                    for (int h = 0; h < NREP; ++h) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s += qr[h][e] * kf[e];
+                        s = row16_sum(s);
+                        if (valid) {
+                            const float mn = fmaxf(m[h], s);
+                            const float alpha = expf(m[h] - mn);
+                            const float pw = expf(s - mn);
+                            l[h] = l[h] * alpha + pw;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[h][e] = acc[h][e] * alpha + pw * vf[e];
+                            m[h] = mn;
+                        }
+                    }
+                };
+                consume(kq[0], vq[0], tt[0]);
+                consume(kq[1], vq[1], tt[1]);
+                for (int j = 2; ACT * (split + nsplit * j) < L; j += 2) {       // longer contexts: two chunks per iteration
+                    const bool second = ACT * (split + nsplit * (j + 1)) < L;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        tt[u] = ACT * (split + nsplit * (j + u)) + tok_in_chunk;
+                        const size_t off = kv_off(tt[u]);          // clamped: always a valid address
+                        kq[u] = *(gw_ptr)(kp + off);
+                        vq[u] = *(gw_ptr)(vp + off);
+                    }
+                    consume(kq[0], vq[0], tt[0]);
+                    if (second) consume(kq[1], vq[1], tt[1]);
+                }
+                // ---- combine the ACT (wave, row) streams of this workgroup -> partial (m, l, o) per head -> granules ----
+                const int slot = cw * 4 + r;
+#pragma unroll
+                for (int h = 0; h < NREP; ++h) {
+                    if (sub == 0) { red_m[slot * NREP + h] = m[h]; red_l[slot * NREP + h] = l[h]; }
+                    *(f32x4*)&red_o[(slot * NREP + h) * AD + dimbase] = (f32x4){acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+                    *(f32x4*)&red_o[(slot * NREP + h) * AD + dimbase + 4] = (f32x4){acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
+                }
+                cbar();
+                u64* GP = a.gran[ENG_E_PART];
+                for (int it = tid; it < NREP * AD; it += NCW * 64) {
+                    const int h = it / AD, d = it % AD;
+                    float M = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < ACT; ++i) M = fmaxf(M, red_m[i * NREP + h]);
+                    float O = 0.f, Ls = 0.f;
+                    if (M > -INFINITY) {
+#pragma unroll
+                        for (int i = 0; i < ACT; ++i) {
+                            const float w = expf(red_m[i * NREP + h] - M);
+                            O += w * red_o[(i * NREP + h) * AD + d];
+                            Ls += w * red_l[i * NREP + h];
+                        }
+                    }
+                    const size_t pb = ((size_t)(kvh * nsplit + split) * NREP + h) * (AD + 2);
+                    gran_st(GP + pb + d, tag, O);
+                    if (d == 0) { gran_st(GP + pb + AD, tag, M); gran_st(GP + pb + AD + 1, tag, Ls); }
+                }
+                // ---- merge: this workgroup owns OPB consecutive outputs of the group's NREP * D; gather them from every split ----
+                const int OPB = NREP * AD / nsplit;                    // 16 on Qwen3-8B
+                const int o0 = split * OPB, hm = o0 / AD, d0 = o0 % AD;
+                {
+                    const int s_src = tid >> 3, e = tid & 7;           // 8 threads per source split (nsplit <= 32)
+                    const size_t pb = ((size_t)(kvh * nsplit + (s_src < nsplit ? s_src : 0)) * NREP + hm) * (AD + 2);
+                    const bool act = s_src < nsplit && 2 * e < OPB;
+                    const bool act_ml = s_src < nsplit && e < 2;
+                    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+                    uint32_t spins = 0;
+                    for (;;) {
+                        const u64 x0 = gran_ld(GP + pb + d0 + (act ? 2 * e : 0));
+                        const u64 x1 = gran_ld(GP + pb + d0 + (act ? 2 * e + 1 : 0));
+                        const u64 x2 = gran_ld(GP + pb + AD + (act_ml ? e : 0));
+                        v0 = __uint_as_float((uint32_t)x0); v1 = __uint_as_float((uint32_t)x1); v2 = __uint_as_float((uint32_t)x2);
+                        const bool ok = (!act || ((uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag)) &&
+                                        (!act_ml || (uint32_t)(x2 >> 32) == tag);
+                        if (__all(ok)) break;
+                        if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
+                        if (++spins > SPIN_GLOBAL) { fail(0x800u + (uint32_t)(p - p0)); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (act) { mo[s_src * 18 + 2 * e] = v0; mo[s_src * 18 + 2 * e + 1] = v1; }
+                    if (act_ml) mo[s_src * 18 + 16 + e] = v2;
+                }
+                cbar();
+                if (cw == 0 && lane < OPB) {
+                    float M = -INFINITY;
+                    for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, mo[s2 * 18 + 16]);
+                    float O = 0.f, Ls = 0.f;
+                    for (int s2 = 0; s2 < nsplit; ++s2) {
+                        const float mm = mo[s2 * 18 + 16];
+                        const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
+                        O += w * mo[s2 * 18 + lane];
+                        Ls += w * mo[s2 * 18 + 17];
+                    }
+                    gran_st(a.gran[ENG_E_ATTN] + (size_t)(kvh * NREP + hm) * AD + d0 + lane, tag, O * (1.0f / Ls));
+                }
+                cbar();            // `mo` is reused by the next layer's merge; qs / red_* by its prologue
+                stamp(p - p0, 2);
+            } else {
+                // stage when this workgroup's own waves are nearly through the producing phase (all but their last row group)
+                own_progress(prog_before + (uint32_t)(NSW * (prev_gpw > 1 ? prev_gpw - 1 : prev_gpw)), 0x100u + (uint32_t)(p - p0));
+                stamp(p - p0, 1);
+            }
+            // ---- stage this phase's input: 1024 granules per pass, passes cw, cw + NCW, ...; chunk c = passes 2c, 2c + 1 ----
+            {
+                gf_cptr nw = (gf_cptr)P->nw;
+                float* xs = lds + P->xoff;
+                const u64* G = gran_sel(a, P->in_edge);
+                const uint32_t tag = base + (uint32_t)P->in_tag;
+                uint32_t total_spins = 0;
+                for (int pass = cw; pass * 1024 < K; pass += NCW) {
+                    const int kb = pass * 1024 + lane;
+                    float v[16], wv[16];
+                    if (nw != nullptr) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) wv[i] = nw[kb + i * 64];
+                    }
+                    uint32_t spins = 0;
+                    for (;;) {       // cheap probe first: one granule per lane, spread over the pass
+                        const u64 x = gran_ld(G + pass * 1024 + lane * 16 + (lane & 15));
+                        if (__all((uint32_t)(x >> 32) == tag)) break;
+                        if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
+                        if (++spins > SPIN_GLOBAL) { fail(0x200u + (uint32_t)(p - p0)); break; }
+                        __builtin_amdgcn_s_sleep(6);
+                    }
                     for (;;) {
                         bool ok = true;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            const u64 x = __hip_atomic_load(G + kb + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const u64 x = gran_ld(G + kb + i * 64);
                             v[i] = __uint_as_float((uint32_t)x);
                             ok = ok && ((uint32_t)(x >> 32) == tag);
                         }
                         if (__all(ok)) break;
-                        if (lds_ld(&ctrl[2]) != 0u) break;
-                        if (++spins > SPIN_GLOBAL) { if (lane == 0) { atomicExch(&a.ctl[1], 0x200u + (uint32_t)p); ctrl[2] = 1u; } break; }
-                        __builtin_amdgcn_s_sleep(4);
+                        if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
+                        if (++spins > SPIN_GLOBAL) { fail(0x300u + (uint32_t)(p - p0)); break; }
+                        __builtin_amdgcn_s_sleep(2);
                     }
                     total_spins += spins;
-                }
+                    float ss = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float val = v[i];
-                    if (nw != nullptr) { ss += val * val; val *= wv[i]; }
-                    xs[xperm(kb + i * 64)] = val;
+                    for (int i = 0; i < 16; ++i) {
+                        float val = v[i];
+                        if (nw != nullptr) { ss += val * val; val *= wv[i]; }
+                        xs[xperm(kb + i * 64)] = val;
+                    }
+                    if (nw != nullptr) {
+                        ss = wave_sum(ss);
+                        if (lane == 0) ssq[(xbuf & 1) * 16 + pass] = ss;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) lds_add(&ctrl[C_CNT + xbuf * MAXCH + (pass >> 1)], 1u);
                 }
+                stamp(p - p0, 3, (u64)total_spins);
             }
-            if (nw != nullptr) {
-                ss = wave_sum(ss);
-                if (lane == 0) ssq[(p & 1) * NCW + cw] = ss;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_add(&ctrl[0], (uint32_t)NSW);      // NSW * NCW units per staged phase
-            stamp(p, 2);
-            stamp(p, 3, (u64)total_spins);
+            prog_before += (uint32_t)(NSW * prev_gpw);
+            prev_gpw = gpw_p;
         }
         return;
     }
 
-    // =============================== STREAM waves: rows x weights, never waiting on HBM ===============================
+    // =========================================================================================================
+    // STREAM waves: rows x weights, never waiting on HBM
+    // =========================================================================================================
     const int gwid = blockIdx.x * NSW + wave, TW = gridDim.x * NSW;
     stamp(0, 3);
 
-    // residual rows owned by this wave (same mapping in o_proj and down_proj): lane i < R of group gi.  Requested first
-    // and written to LDS only after the weight prefetch has been issued, so the wait is a counted one.
-    constexpr int MAXRES = 4;
+    // residual rows owned by this wave (same mapping in o_proj and down_proj): lane i < R of group gi.  Requested first and
+    // written to LDS only after the weight prefetch has been issued, so the wait is a counted one.
     float xv0[MAXRES];
 #pragma unroll
     for (int gi = 0; gi < MAXRES; ++gi) {
@@ -167,93 +443,109 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         row = row < a.H ? row : a.H - 1;
         xv0[gi] = a.xres[row];
     }
-    // Phase 0's input vector was written by an earlier kernel: the stream waves request their 1/NSW of it BEFORE the weight
-    // prefetch (a load issued behind this CU's 128 KiB prefetch burst returns ~5 us later: measured 7.7 us until the
-    // o_proj rows could start when the comm waves did this), and stage it once the prefetch is on its way.
-    constexpr int MAXV = 8;
-    ph_ptr P0 = (ph_ptr)a.prog;
-    const int k4n = P0->K >> 2, per = k4n / NSW;                   // f32x4 groups of the vector, per stream wave
-    f32x4 xin[MAXV];
+    // The first phase's input vector was written by an earlier kernel: stream wave w requests pass w of it (1024 floats)
+    // BEFORE the weight prefetch (a load issued behind this CU's prefetch burst returns ~5 us later) and stages it once
+    // the prefetch is on its way.  Waves past the last pass load a clamped pass and write nothing.
+    ph_ptr PF0 = (ph_ptr)a.prog + p0;
+    const int npass0 = PF0->K >> 10;
+    f32x4 xin[4], win[4];
     {
-        const CM_GLOBAL f32x4* v4 = (const CM_GLOBAL f32x4*)P0->vin;
+        const int pass = wave < npass0 ? wave : npass0 - 1;
+        const CM_GLOBAL f32x4* v4 = (const CM_GLOBAL f32x4*)a.vin + pass * 256;
+        const CM_GLOBAL f32x4* w4 = (const CM_GLOBAL f32x4*)(PF0->nw != nullptr ? PF0->nw : a.vin) + pass * 256;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            int idx = wave * per + i * 64 + lane;
-            idx = idx < k4n ? idx : k4n - 1;
-            xin[i] = v4[idx];
-        }
+        for (int i = 0; i < 4; ++i) { xin[i] = v4[i * 64 + lane]; win[i] = w4[i * 64 + lane]; }
     }
 
-    // ---- load-side cursor (runs PF batches ahead of the compute-side cursor) ----
-    ph_ptr LP = (ph_ptr)a.prog;
-    int lph = 0, lgi = 0, lkb = 0;
-    const CM_GLOBAL uint16_t* lW = (const CM_GLOBAL uint16_t*)LP->W;
-    int lN = LP->N, lK = LP->K, lgpw = LP->gpw, lnb = LP->nbpg;
+    // ---- cursors over the batch sequence: phase -> block of `gblk` row groups -> chunk kb -> group gg of the block ----
+    struct Cur {
+        ph_ptr P;
+        int ph, gb, kb, gg;
+        int N, K, gpw, nb, gblk, cnt;       // cnt = groups in the current block
+    };
+    auto cur_open = [&](Cur& c) __attribute__((always_inline)) {
+        c.N = c.P->N; c.K = c.P->K; c.gpw = c.P->gpw; c.nb = c.P->nb; c.gblk = c.P->gblk;
+        c.gb = 0; c.kb = 0; c.gg = 0;
+        c.cnt = c.gpw < c.gblk ? c.gpw : c.gblk;
+    };
+    // advance to the next batch; returns true when the phase is finished
+    auto cur_next = [&](Cur& c) __attribute__((always_inline)) -> bool {
+        if (++c.gg < c.cnt) return false;
+        c.gg = 0;
+        if (++c.kb < c.nb) return false;
+        c.kb = 0;
+        ++c.gb;
+        const int left = c.gpw - c.gb * c.gblk;
+        if (left > 0) { c.cnt = left < c.gblk ? left : c.gblk; return false; }
+        return true;
+    };
+
+    Cur lc;                                   // load side: runs PF batches ahead
+    lc.P = (ph_ptr)a.prog + p0; lc.ph = p0;
+    cur_open(lc);
+    const CM_GLOBAL uint16_t* lW = (const CM_GLOBAL uint16_t*)lc.P->W;
     bool lvalid = true;
     auto load_batch = [&](u32x4 (&q)[R][U]) __attribute__((always_inline)) {
-        const int G = lN / R;
-        const int g = gwid + lgi * TW;
+        const int g = gwid + (lc.gb * lc.gblk + lc.gg) * TW;
         // a row group past the last one, or a batch past the end of the program: every lane reads the same 16 bytes of the
         // matrix (no HBM traffic, result never used) -- the loads stay unconditional
-        const bool real = lvalid && g < G;
-        const size_t roff = real ? (size_t)g * R * (size_t)lK + (size_t)lkb * (U * 512) : 0;
+        const bool real = lvalid && g < lc.N / R;
+        const size_t roff = real ? (size_t)g * R * (size_t)lc.K + (size_t)lc.kb * CHUNK : 0;
         const int loff = real ? lane * 8 : 0;
-        const size_t sK = real ? (size_t)lK : 0;
+        const size_t sK = real ? (size_t)lc.K : 0;
         const int sU = real ? 512 : 0;
         const CM_GLOBAL uint16_t* wp = lW + roff + loff;
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
             for (int u = 0; u < U; ++u) q[i][u] = __builtin_nontemporal_load((gw_ptr)(wp + i * sK + u * sU));
-        if (++lkb == lnb) {
-            lkb = 0;
-            if (++lgi == lgpw) {
-                lgi = 0;
-                if (lph + 1 < nph) {
-                    ++lph; ++LP;
-                    lW = (const CM_GLOBAL uint16_t*)LP->W; lN = LP->N; lK = LP->K; lgpw = LP->gpw; lnb = LP->nbpg;
-                } else {
-                    lvalid = false;
-                }
-            }
+        if (lvalid && cur_next(lc)) {
+            if (lc.ph + 1 < p1) { ++lc.ph; ++lc.P; cur_open(lc); lW = (const CM_GLOBAL uint16_t*)lc.P->W; }
+            else lvalid = false;
         }
     };
 
-    // ---- compute-side cursor ----
-    ph_ptr CP = (ph_ptr)a.prog;
-    int cph = 0, cgi = 0, ckb = 0;
-    float acc[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) acc[i] = 0.f;
-    float scale = 1.f;
+    Cur cc;                                   // compute side
+    cc.P = (ph_ptr)a.prog + p0; cc.ph = p0;
+    cur_open(cc);
+    int nready = 0;                           // chunks of the current phase's input known to be staged
+    bool fresh = true;                        // first batch of a phase
     const f32x4* xs4 = (const f32x4*)lds;
-    int cN = 0, cK = 0, cgpw = 1, cnb = 1, ckind = 0, cout = -1;
-    gf_ptr cvout = nullptr;
+    int ckind = 0, cout = -1, cxbuf = 0;
+    uint32_t cneed = 0, ctag = 0;
+    bool cnorm = false, cplain = false;
+    gf_ptr cvout = (gf_ptr)a.vout;
+    float* my_accp = accp + wave * MAXGB * R;
+    float* my_xres = xres_l + wave * MAXRES * R;
 
     auto compute = [&](u32x4 (&q)[R][U]) __attribute__((always_inline)) {
-        if (cgi == 0 && ckb == 0) {
-            // ---- phase start: parameters, then wait until the comm waves have staged this phase's input ----
-            cN = CP->N; cK = CP->K; cgpw = CP->gpw; cnb = CP->nbpg; ckind = CP->kind; cout = CP->out_edge; cvout = (gf_ptr)CP->vout;
-            xs4 = (const f32x4*)(lds + CP->xoff);
-            const uint32_t want = (uint32_t)(NSW * NCW * (cph + 1));
-            stamp(cph, 0);
+        if (fresh) {
+            fresh = false;
+            ckind = cc.P->kind; cout = cc.P->out_edge; cxbuf = cc.P->xbuf; cnorm = cc.P->nw != nullptr;
+            ctag = base + (uint32_t)cc.P->out_tag;
+            cplain = a.plain_last != 0 && cc.ph == p1 - 1;
+            xs4 = (const f32x4*)(lds + cc.P->xoff);
+            // two staged passes per chunk and per phase of this launch that has used the counter row (this one included)
+            const int ub = cxbuf == 0 ? a.ub0 : cxbuf == 1 ? a.ub1 : cxbuf == 2 ? a.ub2 : a.ub3;
+            cneed = 2u * (uint32_t)(cc.P->useq - ub + 1);
+            nready = 0;
+            stamp(cc.ph - p0, 0);
+        }
+        if (cc.kb >= nready) {                // first touch of this chunk: wait until its two passes are staged
             uint32_t spins = 0;
-            while (lds_ld(&ctrl[0]) < want && lds_ld(&ctrl[2]) == 0u) {
+            const uint32_t* w = &ctrl[C_CNT + cxbuf * MAXCH + cc.kb];
+            while (lds_ld(w) < cneed && lds_ld(&ctrl[C_ABORT]) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > SPIN_LDS) { if (lane == 0) { atomicExch(&a.ctl[1], 0x300u + (uint32_t)cph); ctrl[2] = 1u; } break; }
+                if (++spins > SPIN_LDS) { fail(0x400u + (uint32_t)(cc.ph - p0)); break; }
             }
             asm volatile("" ::: "memory");
-            stamp(cph, 1);
-            scale = 1.f;
-            if (CP->nw != nullptr) {
-                const float* sp = ssq + (cph & 1) * NCW;
-                float tot = 0.f;
-                if (NCW == 4) tot = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-                else for (int c = 0; c < NCW; ++c) tot += sp[c];
-                scale = 1.0f / sqrtf(tot / (float)cK + a.eps);
-            }
+            nready = cc.kb + 1;
+            if (cc.kb == 0) stamp(cc.ph - p0, 1);
         }
-        const int cb = ckb * U;
+        float acc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = 0.f;
+        const int cb = cc.kb * U;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const f32x4 xa = xs4[(cb + u) * 128 + lane];
@@ -266,44 +558,59 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                           bf16_lo(q[i][u][3]) * xb[2] + bf16_hi(q[i][u][3]) * xb[3];
             }
         }
-        if (++ckb < cnb) return;
-        ckb = 0;
-        // ---- row group finished: reduce + epilogue ----
-        const int g = gwid + cgi * TW;
-        const int r0 = g * R;
-        float v[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) { v[i] = wave_sum(acc[i]) * scale; acc[i] = 0.f; }
-        if (r0 < cN) {
-            u64* G = cout == 0 ? a.gran0 : (cout == 1 ? a.gran1 : a.gran2);
-            const u64 tagw = (u64)(base + 1u + (uint32_t)cph) << 32;
-            const float mine = lane == 1 ? v[1] : v[0];
-            if (ckind == ENG_RESADD) {
-                float* xr = xres_l + (wave * a.gpw_res + cgi) * R;
-                if (lane < R) {
-                    const float nx = xr[lane] + mine;
-                    xr[lane] = nx;
-                    if (cout >= 0) __hip_atomic_store(G + r0 + lane, tagw | (u64)__float_as_uint(nx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else if (ckind == ENG_SILUMUL) {
-                if (lane == 0) {
-                    const float h = (v[0] / (1.0f + expf(-v[0]))) * v[1];
-                    if (cout >= 0) __hip_atomic_store(G + g, tagw | (u64)__float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else cvout[g] = h;
-                }
-            } else {
-                if (lane < R) {
-                    if (cout >= 0) __hip_atomic_store(G + r0 + lane, tagw | (u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else cvout[r0 + lane] = mine;
+        // per-batch reduction; lane i < R carries row i's running sum over the chunks in LDS between visits of the group
+        const float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
+        float run = lane == 1 ? s1 : s0;
+        float* park = my_accp + cc.gg * R;
+        if (cc.kb > 0 && lane < R) run += park[lane];
+        const bool last_chunk = cc.kb == cc.nb - 1;
+        if (!last_chunk) {
+            if (lane < R) park[lane] = run;
+        } else {
+            // ---- row group finished: epilogue ----
+            float scale = 1.f;
+            if (cnorm) {
+                const float* sp = ssq + (cxbuf & 1) * 16;
+                const int npass = cc.K >> 10;
+                float tot = 0.f;
+                for (int c2 = 0; c2 < npass; c2 += 4) tot += (sp[c2] + sp[c2 + 1]) + (sp[c2 + 2] + sp[c2 + 3]);   // K % 4096 == 0 for normed inputs
+                scale = 1.0f / sqrtf(tot / (float)cc.K + a.eps);
+            }
+            const int gi = cc.gb * cc.gblk + cc.gg;
+            const int g = gwid + gi * TW;
+            const int r0 = g * R;
+            const float mine = run * scale;
+            if (r0 < cc.N) {
+                u64* G = gran_sel(a, cout >= 0 ? cout : 0);
+                if (ckind == ENG_RESADD) {
+                    if (lane < R) {
+                        const float nx = my_xres[gi * R + lane] + mine;
+                        my_xres[gi * R + lane] = nx;
+                        if (cout >= 0) gran_st(G + r0 + lane, ctag, nx);
+                    }
+                } else if (ckind == ENG_SILUMUL) {
+                    const float up = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), 1));
+                    if (lane == 0) {
+                        const float h = (mine / (1.0f + expf(-mine))) * up;
+                        if (cplain) cvout[g] = h;
+                        else if (cout >= 0) gran_st(G + g, ctag, h);
+                    }
+                } else {
+                    if (lane < R) {
+                        if (cplain) cvout[r0 + lane] = mine;
+                        else if (cout >= 0) gran_st(G + r0 + lane, ctag, mine);
+                    }
                 }
             }
-        }
-        if (++cgi == cgpw) {
-            cgi = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_add(&ctrl[1], 1u);               // this wave is done with phase cph
-            stamp(cph, 2);
-            ++cph; ++CP;
+            if (lane == 0) lds_add(&ctrl[C_PROG], 1u);            // one more row group of this workgroup finished
+        }
+        const int phs = cc.ph - p0;
+        if (cur_next(cc)) {
+            stamp(phs, 2);
+            ++cc.ph; ++cc.P;
+            fresh = true;
+            if (cc.ph < p1) cur_open(cc);
         }
     };
 
@@ -313,19 +620,31 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     for (int j = 0; j < PF; ++j) load_batch(q[j]);
 #pragma unroll
     for (int gi = 0; gi < MAXRES; ++gi)
-        if (gi < a.gpw_res && lane < R) xres_l[(wave * a.gpw_res + gi) * R + lane] = xv0[gi];
-    {
-        float* xs0 = lds + P0->xoff;
+        if (gi < a.gpw_res && lane < R) my_xres[gi * R + lane] = xv0[gi];
+    if (wave < npass0) {                      // stage pass `wave` of the first phase's input (RMSNorm weight + sum of squares folded)
+        float* xs0 = lds + PF0->xoff;
+        const bool nrm = PF0->nw != nullptr;
+        float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-            if (i * 64 < per) *(f32x4*)(xs0 + xperm((wave * per + i * 64 + lane) << 2)) = xin[i];
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = xin[i];
+            if (nrm) {
+                ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                v[0] *= win[i][0]; v[1] *= win[i][1]; v[2] *= win[i][2]; v[3] *= win[i][3];
+            }
+            *(f32x4*)(xs0 + xperm((wave * 256 + i * 64 + lane) << 2)) = v;
+        }
+        if (nrm) {
+            ss = wave_sum(ss);
+            if (lane == 0) ssq[(PF0->xbuf & 1) * 16 + wave] = ss;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_add(&ctrl[0], (uint32_t)NCW);
+        if (lane == 0) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + (wave >> 1)], 1u);
     }
-    while (cph < nph) {
+    while (cc.ph < p1) {
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            if (cph < nph) compute(q[j]);
+            if (cc.ph < p1) compute(q[j]);
             load_batch(q[j]);
         }
     }
@@ -333,20 +652,22 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     // ---- exit: residual rows back to HBM for the kernels that follow; block 0 advances the epoch base ----
     for (int gi = 0; gi < a.gpw_res; ++gi) {
         const int row = (gwid + gi * TW) * R + lane;
-        if (lane < R && row < a.H) a.xres[row] = xres_l[(wave * a.gpw_res + gi) * R + lane];
+        if (lane < R && row < a.H) a.xres[row] = my_xres[gi * R + lane];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[0] = base + (uint32_t)nph;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[0] = base + (uint32_t)a.epoch_step;
 }
 
 size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw) {
-    return ((size_t)a.xf_total + 2 * (size_t)ncw + (size_t)nsw * a.gpw_res * R) * 4 + 64;
+    (void)ncw;
+    const size_t attn = a.attn != nullptr ? (size_t)(4 * AD + 2 * AD + 2 * ACT * 4 + ACT * 4 * AD + 32 * 18) : 0;
+    return ((size_t)a.xf_total + 32 + (size_t)nsw * MAXGB * R + (size_t)nsw * MAXRES * R + C_WORDS + attn) * 4 + 64;
 }
 
 // (stream waves per workgroup, register sets in flight per stream wave): the default, or CM_ENG_CFG="nsw,pf" (tuning only)
 EngCfg engine_config() {
     static EngCfg c{0, 0, 0};
     if (c.nsw == 0) {
-        c = EngCfg{ENG_NSW, ENG_NCW, ENG_PF};
+        c = EngCfg{8, ENG_NCW, 2};
         if (const char* e = getenv("CM_ENG_CFG")) {
             int n = 0, p = 0;
             if (sscanf(e, "%d,%d", &n, &p) == 2 && ((n == 4 && (p == 3 || p == 4)) || (n == 8 && (p == 2 || p == 3)))) { c.nsw = n; c.pf = p; }
@@ -357,8 +678,8 @@ EngCfg engine_config() {
 
 template <int NSW, int PF>
 static bool prepare_v(size_t lds_bytes) {
-    auto k = engine_chain_kernel<NSW, ENG_NCW, PF, false>;
-    auto kt = engine_chain_kernel<NSW, ENG_NCW, PF, true>;
+    auto k = engine_kernel<NSW, ENG_NCW, PF, 4, false>;
+    auto kt = engine_kernel<NSW, ENG_NCW, PF, 4, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -375,14 +696,14 @@ bool engine_prepare(size_t lds_bytes) {
 
 template <int NSW, int PF>
 static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
-    if (trace) hipLaunchKernelGGL((engine_chain_kernel<NSW, ENG_NCW, PF, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
-    else hipLaunchKernelGGL((engine_chain_kernel<NSW, ENG_NCW, PF, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    if (trace) hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, 4, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, 4, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
 }
 
-bool launch_engine_chain(const EngArgs& a, int grid, hipStream_t s, bool trace) {
+bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const EngCfg c = engine_config();
     const size_t lds = engine_lds_bytes(a, c.nsw, c.ncw);
-    if (lds > 160 * 1024 - 256 || a.gpw_res > 4) return false;
+    if (lds > 160 * 1024 - 256 || a.gpw_res > MAXRES || a.p1 <= a.p0) return false;
     const bool tr = trace && a.trace != nullptr;
     if (c.nsw == 8) { if (c.pf == 2) launch_v<8, 2>(a, grid, lds, s, tr); else launch_v<8, 3>(a, grid, lds, s, tr); }
     else { if (c.pf == 3) launch_v<4, 3>(a, grid, lds, s, tr); else launch_v<4, 4>(a, grid, lds, s, tr); }

@@ -42,7 +42,7 @@ void Model::dfree(void* p) {
 
 Model::~Model() {
     if (stream) (void)hipStreamSynchronize(stream);
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 5; ++v) {
         if (graph_exec[v]) (void)hipGraphExecDestroy(graph_exec[v]);
         if (graph[v]) (void)hipGraphDestroy(graph[v]);
     }
@@ -310,7 +310,7 @@ void Model::alloc_runtime() {
 }
 
 // ------------------------------------------------------------------------------------
-// persistent chain kernel (kernels_engine.hip): phase tables + granule buffers
+// persistent decode kernel (kernels_engine.hip): phase table, attention operands, granule buffers
 // ------------------------------------------------------------------------------------
 bool Model::engine_eligible(std::string* why) const {
     auto no = [&](const char* m) { if (why) *why = m; return false; };
@@ -319,16 +319,29 @@ bool Model::engine_eligible(std::string* why) const {
     if (tp != 1 || rccl) return no("tensor parallelism");
     const int Ko = Hq_l * cfg.D;
     if (Ko % 2048 || cfg.H % 2048 || I_l % 2048) return no("projection widths must be multiples of 2048");
-    const int TW = num_cu * engine_config().nsw;
+    const EngCfg ec = engine_config();
+    if (cfg.H / 1024 > ec.nsw || Ko / 1024 > ec.nsw) return no("input vector of the first phase too long for the stream waves");
+    if (I_l / 2048 > 8) return no("intermediate size too large for the chunk counters");
+    const int TW = num_cu * ec.nsw;
     if ((cfg.H / 2 + TW - 1) / TW > 4) return no("hidden size too large for the residual slots");
     return true;
 }
 
+// the whole token in one launch needs the attention inside the kernel: bf16 pages, head_dim 128, GQA group of 4, one
+// workgroup per (kv head, token split) with at most 32 splits
+bool Model::engine_full_eligible() const {
+    if (cfg.D != 128 || nrep != 4 || kv_mode != CM_KV_BF16 || !cfg.qk_norm) return false;
+    if (num_cu % Hkv_l) return false;
+    const int ns = num_cu / Hkv_l, opb = ns > 0 ? nrep * cfg.D / ns : 0;
+    return ns >= 1 && ns <= 32 && (nrep * cfg.D) % ns == 0 && opb >= 2 && opb <= 16 && opb % 2 == 0 && cfg.D % opb == 0;
+}
+
 void Model::build_engine() {
     engine_on = false;
+    engine_full = false;
     if (opts.engine < 0) return;
     std::string why;
-    bool ok = engine_eligible(&why);
+    const bool ok = engine_eligible(&why);
     // default (0): opt-in through CM_ENGINE=1 until the launch path is retired; 1: required
     if (opts.engine == 0) { const char* e = getenv("CM_ENGINE"); if (!(e && atoi(e) > 0)) return; }
     if (!ok) {
@@ -340,35 +353,57 @@ void Model::build_engine() {
     const int x0 = std::max(Ko, H), x1 = H, xh = I_l;
     eng_xf_total = x0 + x1 + xh;
     auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
+    auto gblk = [&](int N) { return std::min(gpw(N), 6); };
     eng_gpw_res = gpw(H);
+    engine_full = engine_full_eligible();
+    if (const char* e = getenv("CM_ENGINE_FULL")) engine_full = engine_full && atoi(e) != 0;
+    if (const char* e = getenv("CM_ENGINE_FULL_MAX")) eng_full_max_ctx = atoll(e);
     EngArgs probe{};
     probe.xf_total = eng_xf_total; probe.gpw_res = eng_gpw_res;
+    probe.attn = engine_full ? (const EngAttnL*)1 : nullptr;
     if (engine_lds_bytes(probe, ec.nsw, ec.ncw) > 160 * 1024 - 256) {
-        if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: input vectors do not fit LDS");
-        return;
+        probe.attn = nullptr;
+        engine_full = false;
+        if (engine_lds_bytes(probe, ec.nsw, ec.ncw) > 160 * 1024 - 256) {
+            if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: input vectors do not fit LDS");
+            return;
+        }
     }
     const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
-    std::vector<EngPhase> prog((size_t)cfg.L * ENG_MAXPH);
+    std::vector<EngPhase> prog((size_t)cfg.L * 4);
+    std::vector<EngAttnL> at((size_t)cfg.L);
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
-        EngPhase* p = &prog[(size_t)li * ENG_MAXPH];
-        p[0] = EngPhase{w.o, nullptr, attn, nullptr, H, Ko, ENG_RESADD, gpw(H), Ko / 2048, 0, -1, 0};
-        p[1] = EngPhase{w.gate_up, w.ln2, nullptr, nullptr, 2 * I_l, H, ENG_SILUMUL, gpw(2 * I_l), H / 2048, x0, 0, 1};
-        p[2] = EngPhase{w.down, nullptr, nullptr, nullptr, H, I_l, ENG_RESADD, gpw(H), I_l / 2048, x0 + x1, 1, li + 1 < cfg.L ? 2 : -1};
-        if (li + 1 < cfg.L) {
-            const LayerW& n = layers[(size_t)li + 1];
-            p[3] = EngPhase{n.qkv, n.ln1, nullptr, qkv, qkv_rows, H, ENG_STORE, gpw(qkv_rows), H / 2048, 0, 2, -1};
-        } else {
-            p[3] = EngPhase{};
-        }
+        EngPhase* p = &prog[(size_t)li * 4];
+        for (int k = 0; k < 4; ++k) { p[k] = EngPhase{}; p[k].layer = li; p[k].useq = li; p[k].in_tag = li + 1; p[k].out_tag = li + 1; }
+        // RMSNorm + merged QKV: input = residual after the previous layer's down_proj
+        p[0].W = w.qkv; p[0].nw = w.ln1; p[0].N = qkv_rows; p[0].K = H; p[0].kind = ENG_STORE;
+        p[0].xoff = 0; p[0].xbuf = 0; p[0].in_edge = ENG_E_X0; p[0].in_tag = li; p[0].out_edge = ENG_E_QKV;
+        // o_proj + residual: input = attention output (the comm waves run the attention first)
+        p[1].W = w.o; p[1].N = H; p[1].K = Ko; p[1].kind = ENG_RESADD;
+        p[1].xoff = 0; p[1].xbuf = 3; p[1].in_edge = ENG_E_ATTN; p[1].out_edge = ENG_E_X1; p[1].pre_attn = 1;
+        // RMSNorm + gate||up + SiLU*mul
+        p[2].W = w.gate_up; p[2].nw = w.ln2; p[2].N = 2 * I_l; p[2].K = H; p[2].kind = ENG_SILUMUL;
+        p[2].xoff = x0; p[2].xbuf = 1; p[2].in_edge = ENG_E_X1; p[2].out_edge = ENG_E_H;
+        // down_proj + residual
+        p[3].W = w.down; p[3].N = H; p[3].K = I_l; p[3].kind = ENG_RESADD;
+        p[3].xoff = x0 + x1; p[3].xbuf = 2; p[3].in_edge = ENG_E_H; p[3].out_edge = ENG_E_X0;
+        for (int k = 0; k < 4; ++k) { p[k].gpw = gpw(p[k].N); p[k].gblk = gblk(p[k].N); p[k].nb = p[k].K / 2048; }
+        at[(size_t)li] = EngAttnL{kpool(li), vpool(li), w.qn, w.kn};
     }
     eng_prog = (EngPhase*)dalloc<int>(prog.size() * sizeof(EngPhase) / sizeof(int));
     CM_HIP(hipMemcpy(eng_prog, prog.data(), prog.size() * sizeof(EngPhase), hipMemcpyHostToDevice));
-    const size_t gsz[3] = {(size_t)H, (size_t)I_l, (size_t)H};
-    for (int e = 0; e < 3; ++e) {
+    eng_attn = (EngAttnL*)dalloc<int>(at.size() * sizeof(EngAttnL) / sizeof(int));
+    CM_HIP(hipMemcpy(eng_attn, at.data(), at.size() * sizeof(EngAttnL), hipMemcpyHostToDevice));
+    const int ns = std::max(1, num_cu / std::max(1, Hkv_l));
+    const size_t gsz[ENG_NEDGE] = {(size_t)H, (size_t)qkv_rows, (size_t)Hkv_l * ns * nrep * (D + 2), (size_t)Hq_l * D, (size_t)H, (size_t)I_l};
+    for (int e = 0; e < ENG_NEDGE; ++e) {
         eng_gran[e] = (unsigned long long*)dalloc<int>(gsz[e] * 2);
         CM_HIP(hipMemset(eng_gran[e], 0, gsz[e] * 8));       // tag 0 is never a valid epoch
     }
+    // epoch base 1: every tag of the first launch is >= 2, the zero-filled granules never match
+    const uint32_t one = 1;
+    CM_HIP(hipMemcpy(&st->rsv[1], &one, 4, hipMemcpyHostToDevice));
     if (!engine_prepare(engine_lds_bytes(probe, ec.nsw, ec.ncw))) {
         if (opts.engine > 0) throw CmError(CM_ERR_DEVICE, "cm_opts.engine = 1: kernel attribute");
         return;
@@ -376,42 +411,65 @@ void Model::build_engine() {
     engine_on = true;
 }
 
-EngArgs Model::engine_args(int li) const {
+EngArgs Model::engine_args_common() const {
     EngArgs e{};
-    e.prog = eng_prog + (size_t)li * ENG_MAXPH;
-    e.gran0 = eng_gran[0]; e.gran1 = eng_gran[1]; e.gran2 = eng_gran[2];
+    e.prog = eng_prog;
+    for (int k = 0; k < ENG_NEDGE; ++k) e.gran[k] = eng_gran[k];
     e.xres = x; e.ctl = (uint32_t*)&st->rsv[1];
-    e.nph = li + 1 < cfg.L ? 4 : 3; e.H = cfg.H; e.gpw_res = eng_gpw_res; e.xf_total = eng_xf_total; e.eps = cfg.eps;
+    e.st = st; e.block_table = d_bt; e.cos = cos; e.sin = sin;
+    e.epoch_step = cfg.L + 2;
+    e.H = cfg.H; e.gpw_res = eng_gpw_res; e.xf_total = eng_xf_total;
+    e.Hkv = Hkv_l; e.page = page; e.max_pages = max_pages_per_seq;
+    e.q_off = 0; e.k_off = Hq_l * cfg.D; e.v_off = e.k_off + Hkv_l * cfg.D;
+    e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
     return e;
 }
 
-// cm_debug_read("engine_trace"): a few warm chain launches, then ONE launch of the instrumented instantiation;
-// out[((block * waves + wave) * ENG_MAXPH + phase) * 4 + event] = microseconds since the earliest stamp (0 = not recorded;
+// per-layer launch: o_proj -> gate||up -> down_proj -> QKV of the next layer (attention stays a separate launch)
+EngArgs Model::engine_args(int li) const {
+    EngArgs e = engine_args_common();
+    e.p0 = 4 * li + 1; e.p1 = std::min(4 * li + 5, 4 * cfg.L);
+    e.plain_last = li + 1 < cfg.L ? 1 : 0;
+    e.vin = attn; e.vout = qkv;
+    e.ub0 = li + 1; e.ub1 = li; e.ub2 = li; e.ub3 = li;
+    return e;
+}
+
+// whole token: every projection and the attention of every layer in one launch
+EngArgs Model::engine_args_full() const {
+    EngArgs e = engine_args_common();
+    e.p0 = 0; e.p1 = 4 * cfg.L;
+    e.attn = eng_attn;
+    e.vin = x;
+    return e;
+}
+
+// cm_debug_read("engine_trace"): a few warm launches, then ONE launch of the instrumented instantiation;
+// out[((block * waves + wave) * ENG_TRACE_PH + phase) * 4 + event] = microseconds since the earliest stamp (0 = not recorded;
 // event 3 of a comm wave = number of granule sweeps that found stale tags)
 void Model::engine_trace(float* out, size_t n) {
-    if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent chain kernel is not active on this model");
+    if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent decode kernel is not active on this model");
     const EngCfg ec = engine_config();
-    const size_t waves = (size_t)(ec.nsw + ec.ncw), total = (size_t)num_cu * waves * ENG_MAXPH * 4;
+    const size_t waves = (size_t)(ec.nsw + ec.ncw), total = (size_t)num_cu * waves * ENG_TRACE_PH * 4;
     if (n != total) throw CmError(CM_ERR_RANGE, "engine_trace: expected " + std::to_string(total) + " values");
     unsigned long long* d = nullptr;
     CM_HIP(hipMalloc((void**)&d, total * 8));
     CM_HIP(hipMemsetAsync(d, 0, total * 8, stream));
     const int layers_w = std::max(1, cfg.L - 1);
-    for (int i = 0; i < 6; ++i) launch_engine_chain(engine_args(i % layers_w), num_cu, stream);
-    EngArgs e = engine_args(6 % layers_w);
+    for (int i = 0; i < 6; ++i) launch_engine(engine_full ? engine_args_full() : engine_args(i % layers_w), num_cu, stream);
+    EngArgs e = engine_full ? engine_args_full() : engine_args(6 % layers_w);
     e.trace = d;
-    launch_engine_chain(e, num_cu, stream, true);
+    launch_engine(e, num_cu, stream, true);
     std::vector<unsigned long long> h(total);
     CM_HIP(hipStreamSynchronize(stream));
     CM_HIP(hipMemcpy(h.data(), d, total * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    auto is_count = [&](size_t i) { return (i & 3) == 3 && ((i / (4 * ENG_TRACE_PH)) % waves) >= (size_t)ec.nsw; };
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < total; ++i)
-        if ((i & 3) != 3 || ((i / 4) % ENG_MAXPH == 0 && ((i / (4 * ENG_MAXPH)) % waves) < (size_t)ec.nsw))   // stamps, not spin counts
-            if (h[i] != 0 && h[i] < t0) t0 = h[i];
+        if (!is_count(i) && h[i] != 0 && h[i] < t0) t0 = h[i];
     for (size_t i = 0; i < total; ++i) {
-        const bool is_count = (i & 3) == 3 && ((i / (4 * ENG_MAXPH)) % waves) >= (size_t)ec.nsw;
-        if (is_count) out[i] = (float)h[i];
+        if (is_count(i)) out[i] = (float)h[i];
         else out[i] = h[i] == 0 ? 0.f : (float)((double)(h[i] - t0) * 0.01) + 0.01f;    // 100 MHz -> us
     }
     engine_check();
@@ -577,9 +635,15 @@ void Model::enqueue_decode_step(bool advance) {
     if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_row_q(q_embed, st, x, H, cfg.V, s);
     else launch_embed_row(embed, st, x, H, cfg.V, 1, s);
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
+    if (engine_on && attn_variant == 4) {
+        // the whole token in ONE launch: every projection and the attention of every layer (kernels_engine.hip)
+        if (!launch_engine(engine_args_full(), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
+        enqueue_lm_head(advance);
+        return;
+    }
     if (engine_on) {
-        // persistent chain path: QKV of layer 0 as a plain launch, then per layer the attention kernels + ONE chain launch
-        // (o_proj -> gate||up -> down_proj -> QKV of the next layer)
+        // per-layer persistent launches: QKV of layer 0 as a plain launch, then per layer the attention kernels + ONE launch
+        // for o_proj -> gate||up -> down_proj -> QKV of the next layer
         GemvArgs g{};
         g.W = layers[0].qkv; g.x = x; g.nw = layers[0].ln1; g.y = qkv; g.N = qkv_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
         launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
@@ -594,7 +658,7 @@ void Model::enqueue_decode_step(bool advance) {
             if (attn_variant >= 2) {
                 if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
             } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-            if (!launch_engine_chain(engine_args(li), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent chain kernel launch");
+            if (!launch_engine(engine_args(li), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
         }
         enqueue_lm_head(advance);
         return;
@@ -943,6 +1007,7 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
     if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode != CM_KV_F32 && (cfg.D == 128 || cfg.D == 256) && (page & (page - 1)) == 0)
         attn_variant = ctx_len >= attn_mfma_wide_min ? 3 : 2;
+    if (engine_on && engine_full && ctx_len <= eng_full_max_ctx) attn_variant = 4;    // whole-token persistent launch
     const int v = attn_variant;
     logits_gathered = false;
     // Tensor parallelism: the RCCL all-reduces / all-gathers are captured INTO the decode-step graph (one launch per
@@ -1387,11 +1452,16 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
         }
         if (which == "chain") {      // the persistent chain launch of a layer that has a successor (4 phases)
             if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent chain kernel is not active on this model");
-            const int lc = cfg.L > 1 ? (int)(i % (size_t)(cfg.L - 1)) : 0;
-            if (!launch_engine_chain(engine_args(lc), num_cu, stream)) throw CmError(CM_ERR_DEVICE, "persistent chain kernel launch");
             const uint64_t Ko = (uint64_t)Hq_l * D, qrows = (uint64_t)(Hq_l + 2 * Hkv_l) * D;
-            b = ((uint64_t)H * Ko + 2ull * I_l * H + (uint64_t)H * I_l + (cfg.L > 1 ? qrows * H : 0)) * 2    // weights, bf16
-                + Ko * 4 + (uint64_t)H * 4 + 2ull * H * 4;                                                  // attn in, x in/out, 2 norm vectors
+            const uint64_t wl = ((uint64_t)H * Ko + 2ull * I_l * H + (uint64_t)H * I_l + qrows * H) * 2;     // one layer's weights, bf16
+            if (engine_full) {       // the whole-token launch: every layer's weights + the KV read at the current context
+                if (!launch_engine(engine_args_full(), num_cu, stream)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
+                b = (wl + 2ull * H * 4 + 2ull * D * 4) * (uint64_t)cfg.L + 2ull * cfg.L * Hkv_l * (uint64_t)seq(0).len * kv_row_bytes + 2ull * H * 4;
+                return;
+            }
+            const int lc = cfg.L > 1 ? (int)(i % (size_t)(cfg.L - 1)) : 0;
+            if (!launch_engine(engine_args(lc), num_cu, stream)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
+            b = (cfg.L > 1 ? wl : wl - qrows * H * 2) + Ko * 4 + (uint64_t)H * 4 + 2ull * H * 4;            // + attn in, x in/out, 2 norm vectors
             return;
         }
         GemvArgs g{};

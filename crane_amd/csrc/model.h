@@ -262,20 +262,26 @@ struct Model {
     void isq_q8_0();                   // in-situ quantisation of the loaded bf16 linears (ops/linear.rs:83-116)
     void dfree(void* p);
 
-    // persistent chain kernel (kernels_engine.hip): per layer ONE launch for o_proj -> gate||up -> down_proj -> next QKV
-    bool engine_on = false;
-    EngPhase* eng_prog = nullptr;              // device [L][ENG_MAXPH]
-    unsigned long long* eng_gran[3] = {nullptr, nullptr, nullptr};   // granule buffers of the three edges inside a chain
+    // persistent decode kernel (kernels_engine.hip): the whole token in one launch (attention inside), or per layer ONE
+    // launch for o_proj -> gate||up -> down_proj -> next QKV around the separate attention kernels
+    bool engine_on = false, engine_full = false;
+    int64_t eng_full_max_ctx = 4096;           // longer contexts: per-layer launches around the MFMA flash-decode kernel
+    EngPhase* eng_prog = nullptr;              // device [L][4]: QKV, o_proj, gate||up, down_proj
+    EngAttnL* eng_attn = nullptr;              // device [L]
+    unsigned long long* eng_gran[ENG_NEDGE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int eng_gpw_res = 0, eng_xf_total = 0;
     bool engine_eligible(std::string* why = nullptr) const;
+    bool engine_full_eligible() const;
     void build_engine();
+    EngArgs engine_args_common() const;
     EngArgs engine_args(int li) const;
-    void engine_trace(float* out, size_t n);   // debug: microsecond timestamps of one traced chain launch
-    void engine_check();                       // after a host sync: throws if a chain launch timed out (StepState.rsv[2])
+    EngArgs engine_args_full() const;
+    void engine_trace(float* out, size_t n);   // debug: microsecond timestamps of one traced launch
+    void engine_check();                       // after a host sync: throws if a launch timed out (StepState.rsv[2])
 
-    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
-    hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool graph_ok[4] = {false, false, false, false};
+    hipGraph_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
+    hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // (4 = whole-token persistent launch)
+    bool graph_ok[5] = {false, false, false, false, false};
     bool tp_graph = true, rccl_warm = false;   // capture RCCL collectives into the decode graph (CM_TP_GRAPH=0: eager)
     int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj
     int nsplit_mfma = 64;          // token splits of variant 3 (MFMA flash-decode, bf16 KV, head_dim 128, long contexts);

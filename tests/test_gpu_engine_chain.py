@@ -1,7 +1,9 @@
-"""The persistent chain kernel (kernels_engine.hip, cm_opts.engine = 1: o_proj -> gate||up -> down_proj -> next QKV as ONE
-launch per layer, hand-offs between workgroups inside the launch) against (a) the per-projection launch path it replaces
--- same arithmetic per row, so agreement is at f32 rounding level -- and (b) the numpy oracle of the reference forward.
+"""The persistent decode kernel (kernels_engine.hip, cm_opts.engine = 1) in both of its modes -- "full": every projection
+and the attention of every layer of a token in ONE launch; "layer": one launch per layer for o_proj -> gate||up ->
+down_proj -> next QKV around the separate attention kernels -- against (a) the per-projection launch path it replaces
+(same arithmetic up to summation order) and (b) the numpy oracle of the reference forward.
 """
+import os
 import numpy as np
 import pytest
 
@@ -16,11 +18,15 @@ def rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
-@pytest.fixture(scope="module")
-def trio():
+@pytest.fixture(scope="module", params=["full", "layer"])
+def trio(request):
     cfg = configs.get_config("eng-qwen3")
     w = synth.synth_weights_f32(cfg, seed=0)
-    eng = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=1)
+    os.environ["CM_ENGINE_FULL"] = "1" if request.param == "full" else "0"      # tuning switch, read at cm_create
+    try:
+        eng = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=1)
+    finally:
+        del os.environ["CM_ENGINE_FULL"]
     ref = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=-1)
     yield cfg, w, eng, ref
     eng.close()
@@ -52,7 +58,8 @@ def test_chain_generate_and_graph_replay(trio):
 
 
 def test_chain_long_context_and_bench_loop(trio):
-    """context >= 768 switches the attention kernel (MFMA flash-decode) in front of the chain launch"""
+    """context >= 768: the per-layer mode switches to the MFMA flash-decode kernel; the full mode's own split-KV attention
+    walks more than two chunks per workgroup"""
     cfg, w, eng, ref = trio
     outs = []
     for m in (eng, ref):
