@@ -2,6 +2,7 @@
 // + per-handle error strings (anyhow::Result on the Rust side).
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "model.h"
 #include "safetensors.h"
@@ -314,10 +315,22 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
         size_t avail = 0;
         const std::string w = what;
         if (w == "engine_trace") { h->m.engine_trace(out, n); return; }
+        if (w.rfind("eng_", 0) == 0) {     // value halves of a granule buffer of the persistent kernel (last writer wins)
+            static const char* names[cm::ENG_NEDGE] = {"eng_x0", "eng_qkv", "eng_part", "eng_attn", "eng_x1", "eng_h"};
+            int e = -1;
+            for (int k = 0; k < cm::ENG_NEDGE; ++k) if (w == names[k]) e = k;
+            if (e < 0 || !h->m.engine_on) throw CmError(CM_ERR_INVALID, "unknown granule buffer / engine off");
+            std::vector<unsigned long long> g(n);
+            CM_HIP(hipStreamSynchronize(h->m.stream));
+            CM_HIP(hipMemcpy(g.data(), h->m.eng_gran[e], n * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < n; ++i) { const uint32_t b = (uint32_t)g[i]; memcpy(&out[i], &b, 4); }
+            return;
+        }
         if (w == "hidden") { src = h->m.x; avail = (size_t)h->m.cfg.H; }
         else if (w == "logits") { src = h->m.logits; avail = (size_t)h->m.V_l * h->m.tp; }
         else if (w == "attn") { src = h->m.attn; avail = (size_t)h->m.Hq_l * h->m.cfg.D; }
         else if (w == "qkv") { src = h->m.qkv; avail = (size_t)(h->m.Hq_l + 2 * h->m.Hkv_l) * h->m.cfg.D; }
+        else if (w == "hbuf") { src = h->m.hbuf; avail = (size_t)h->m.I_l; }
         else throw CmError(CM_ERR_INVALID, "unknown buffer name");
         if (n > avail) throw CmError(CM_ERR_RANGE, "read beyond buffer");
         CM_HIP(hipStreamSynchronize(h->m.stream));

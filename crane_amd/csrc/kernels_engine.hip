@@ -83,7 +83,7 @@ __device__ __forceinline__ int xperm(int k) {
 }
 
 // LDS control words (uint32 index)
-enum { C_PROG = 0,      // row groups finished by this workgroup's stream waves (monotonic over the launch)
+enum { C_PROG = 0,      // batches finished by this workgroup's stream waves (monotonic over the launch)
        C_ABORT = 1,
        C_CBAR = 2,      // barrier counter of the comm waves
        C_CNT = 4,       // [4 counter rows][MAXCH]: passes staged (monotonic; 2 passes per chunk)
@@ -125,9 +125,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         // =====================================================================================================
         const int cw = wave - NSW;
         const int tid = cw * 64 + lane;
-        uint32_t prog_before = 0;                         // row groups all phases before the previous one added to C_PROG
+        uint32_t prog_before = 0;                         // batches all phases before the previous one added to C_PROG
         uint32_t nbar = 0;                                // comm-wave barriers passed
-        int prev_gpw = 0;
+        int prev_nbt = 0;                                 // batches per stream wave of the previous phase
         auto own_progress = [&](uint32_t want, uint32_t code) __attribute__((always_inline)) {
             uint32_t spins = 0;
             while (lds_ld(&ctrl[C_PROG]) < want && lds_ld(&ctrl[C_ABORT]) == 0u) {
@@ -149,9 +149,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
 
         for (int p = p0; p < p1; ++p) {
             ph_ptr P = (ph_ptr)a.prog + p;
-            const int K = P->K, xbuf = P->xbuf, gpw_p = P->gpw;
+            const int K = P->K, xbuf = P->xbuf, nbt_p = P->gpw * P->nb;
             if (p == p0) {                                // staged by the stream waves from a.vin
-                prev_gpw = gpw_p;
+                prev_nbt = nbt_p;
                 continue;
             }
             stamp(p - p0, 0);
@@ -192,25 +192,42 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 const bool owner = ((pos / ACT) % nsplit) == split;
                 const int hrot = AD >> 1;
                 // this workgroup's own stream waves must be through the QKV phase before its comm waves poll the result
-                own_progress(prog_before + (uint32_t)(NSW * prev_gpw), 0x600u + (uint32_t)(p - p0));
+                own_progress(prog_before + (uint32_t)(NSW * prev_nbt) - (uint32_t)(NSW / 2), 0x600u + (uint32_t)(p - p0));   // (nearly: the polls are tiny)
                 stamp(p - p0, 1);
                 const u64* GQ = a.gran[ENG_E_QKV];
-                for (int item = cw; item < NREP + 2; item += NCW) {      // q heads of the group, new k, new v
-                    int g0;
-                    gf_cptr nw = nullptr;
-                    if (item < NREP) { g0 = a.q_off + (kvh * NREP + item) * AD; nw = (gf_cptr)AL->qnw; }
-                    else if (item == NREP) { g0 = a.k_off + kvh * AD; nw = (gf_cptr)AL->knw; }
-                    else { g0 = a.v_off + kvh * AD; }
-                    float xv[2];
+                // q heads of the group, new k, new v: wave w takes items w and w + NCW; ALL their granules are requested in one
+                // round trip per poll
+                constexpr int NIT = (NREP + 2 + NCW - 1) / NCW;
+                int g0[NIT];
+#pragma unroll
+                for (int ii = 0; ii < NIT; ++ii) {
+                    const int item = cw + ii * NCW;
+                    g0[ii] = item < NREP ? a.q_off + (kvh * NREP + item) * AD : (item == NREP ? a.k_off + kvh * AD : a.v_off + kvh * AD);
+                    if (item >= NREP + 2) g0[ii] = a.q_off;               // idle slot: polls a q granule, result unused
+                }
+                float xin2[NIT][2];
+                {
                     uint32_t spins = 0;
                     for (;;) {
-                        const u64 x0 = gran_ld(GQ + g0 + lane), x1 = gran_ld(GQ + g0 + lane + 64);
-                        xv[0] = __uint_as_float((uint32_t)x0); xv[1] = __uint_as_float((uint32_t)x1);
-                        if (__all((uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag)) break;
+                        bool ok = true;
+#pragma unroll
+                        for (int ii = 0; ii < NIT; ++ii) {
+                            const u64 x0 = gran_ld(GQ + g0[ii] + lane), x1 = gran_ld(GQ + g0[ii] + lane + 64);
+                            xin2[ii][0] = __uint_as_float((uint32_t)x0); xin2[ii][1] = __uint_as_float((uint32_t)x1);
+                            ok = ok && (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag;
+                        }
+                        if (__all(ok)) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
                         if (++spins > SPIN_GLOBAL) { fail(0x700u + (uint32_t)(p - p0)); break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
+                }
+#pragma unroll
+                for (int ii = 0; ii < NIT; ++ii) {
+                    const int item = cw + ii * NCW;
+                    if (item >= NREP + 2) continue;
+                    gf_cptr nw = item < NREP ? (gf_cptr)AL->qnw : (item == NREP ? (gf_cptr)AL->knw : nullptr);
+                    float xv[2] = {xin2[ii][0], xin2[ii][1]};
                     if (item <= NREP) {
                         if (nw != nullptr) {
                             const float ss = wave_sum(xv[0] * xv[0] + xv[1] * xv[1]);
@@ -218,10 +235,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                             xv[0] = xv[0] * rr * nw[lane]; xv[1] = xv[1] * rr * nw[lane + 64];
                         }
                         // rotate-half RoPE over the whole head: the partner of d is d +/- D/2 = the other element of this lane
-                        const float c = ((gf_cptr)a.cos)[(size_t)rpos * hrot + lane], s = ((gf_cptr)a.sin)[(size_t)rpos * hrot + lane];
+                        const float c = ((gf_cptr)a.cos)[(size_t)rpos * hrot + lane], sn = ((gf_cptr)a.sin)[(size_t)rpos * hrot + lane];
                         const float lo = xv[0], hi = xv[1];
-                        xv[0] = lo * c - hi * s;
-                        xv[1] = lo * s + hi * c;
+                        xv[0] = lo * c - hi * sn;
+                        xv[1] = lo * sn + hi * c;
                     }
                     if (item < NREP) {
                         qs[item * AD + lane] = xv[0] * a.scale;
@@ -232,9 +249,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         const size_t eoff = owner ? ((size_t)(bt[pos / a.page] * Hkv + kvh) * a.page + (pos % a.page)) * AD : 0;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const uint16_t b = f32_to_bf16(xv[j]);
-                            dst[lane + 64 * j] = bf16_to_f32(b);
-                            if (owner) pool[eoff + lane + 64 * j] = b;
+                            const uint16_t b16 = f32_to_bf16(xv[j]);
+                            dst[lane + 64 * j] = bf16_to_f32(b16);
+                            if (owner) pool[eoff + lane + 64 * j] = b16;
                         }
                     }
                 }
@@ -345,7 +362,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (__all(ok)) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
                         if (++spins > SPIN_GLOBAL) { fail(0x800u + (uint32_t)(p - p0)); break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                     if (act) { mo[s_src * 18 + 2 * e] = v0; mo[s_src * 18 + 2 * e + 1] = v1; }
                     if (act_ml) mo[s_src * 18 + 16 + e] = v2;
@@ -363,11 +380,8 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     }
                     gran_st(a.gran[ENG_E_ATTN] + (size_t)(kvh * NREP + hm) * AD + d0 + lane, tag, O * (1.0f / Ls));
                 }
-                cbar();            // `mo` is reused by the next layer's merge; qs / red_* by its prologue
-                stamp(p - p0, 2);
+                stamp(p - p0, 2);          // (`mo`, qs, red_* are next written a whole layer later)
             } else {
-                // stage when this workgroup's own waves are nearly through the producing phase (all but their last row group)
-                own_progress(prog_before + (uint32_t)(NSW * (prev_gpw > 1 ? prev_gpw - 1 : prev_gpw)), 0x100u + (uint32_t)(p - p0));
                 stamp(p - p0, 1);
             }
             // ---- stage this phase's input: 1024 granules per pass, passes cw, cw + NCW, ...; chunk c = passes 2c, 2c + 1 ----
@@ -380,18 +394,25 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 for (int pass = cw; pass * 1024 < K; pass += NCW) {
                     const int kb = pass * 1024 + lane;
                     float v[16], wv[16];
+                    if (!P->pre_attn) {
+                        // Polling costs bandwidth next to the weight stream, so a pass is swept only when the chip has
+                        // probably finished it: every CU runs the same schedule at nearly the same pace, so "my own stream
+                        // waves closed the row groups that produce this pass, plus a margin" is a good predictor.  The
+                        // tags stay the truth: a sweep that finds stale granules simply repeats.
+                        ph_ptr Q = P - 1;                                  // the producing phase
+                        const int per_round = gridDim.x * NSW * (Q->kind == ENG_SILUMUL ? 1 : R);      // outputs one round of row groups covers
+                        int gi_last = ((pass + 1) * 1024 + per_round - 1) / per_round - 1;             // last round that writes into this pass
+                        gi_last = gi_last < Q->gpw ? gi_last : Q->gpw - 1;
+                        const int blk = gi_last / Q->gblk, left = Q->gpw - blk * Q->gblk, cnt = left < Q->gblk ? left : Q->gblk;
+                        int b_done = blk * Q->gblk * Q->nb + (Q->nb - 1) * cnt + (gi_last - blk * Q->gblk) + 1 + 1;   // + 1 batch of margin
+                        b_done = b_done < prev_nbt ? b_done : prev_nbt;
+                        own_progress(prog_before + (uint32_t)(NSW * b_done), 0x100u + (uint32_t)(p - p0));
+                    }
                     if (nw != nullptr) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) wv[i] = nw[kb + i * 64];
                     }
                     uint32_t spins = 0;
-                    for (;;) {       // cheap probe first: one granule per lane, spread over the pass
-                        const u64 x = gran_ld(G + pass * 1024 + lane * 16 + (lane & 15));
-                        if (__all((uint32_t)(x >> 32) == tag)) break;
-                        if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
-                        if (++spins > SPIN_GLOBAL) { fail(0x200u + (uint32_t)(p - p0)); break; }
-                        __builtin_amdgcn_s_sleep(6);
-                    }
                     for (;;) {
                         bool ok = true;
 #pragma unroll
@@ -403,7 +424,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (__all(ok)) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
                         if (++spins > SPIN_GLOBAL) { fail(0x300u + (uint32_t)(p - p0)); break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        if (P->pre_attn) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(12);
                     }
                     total_spins += spins;
                     float ss = 0.f;
@@ -422,8 +443,8 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 }
                 stamp(p - p0, 3, (u64)total_spins);
             }
-            prog_before += (uint32_t)(NSW * prev_gpw);
-            prev_gpw = gpw_p;
+            prog_before += (uint32_t)(NSW * prev_nbt);
+            prev_nbt = nbt_p;
         }
         return;
     }
@@ -573,7 +594,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 const float* sp = ssq + (cxbuf & 1) * 16;
                 const int npass = cc.K >> 10;
                 float tot = 0.f;
-                for (int c2 = 0; c2 < npass; c2 += 4) tot += (sp[c2] + sp[c2 + 1]) + (sp[c2 + 2] + sp[c2 + 3]);   // K % 4096 == 0 for normed inputs
+                for (int c2 = 0; c2 < npass; ++c2) tot += sp[c2];
                 scale = 1.0f / sqrtf(tot / (float)cc.K + a.eps);
             }
             const int gi = cc.gb * cc.gblk + cc.gg;
@@ -602,9 +623,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_add(&ctrl[C_PROG], 1u);            // one more row group of this workgroup finished
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) lds_add(&ctrl[C_PROG], 1u);                // one more batch of this workgroup finished
         const int phs = cc.ph - p0;
         if (cur_next(cc)) {
             stamp(phs, 2);

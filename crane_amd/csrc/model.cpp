@@ -353,7 +353,6 @@ void Model::build_engine() {
     const int x0 = std::max(Ko, H), x1 = H, xh = I_l;
     eng_xf_total = x0 + x1 + xh;
     auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
-    auto gblk = [&](int N) { return std::min(gpw(N), 6); };
     eng_gpw_res = gpw(H);
     engine_full = engine_full_eligible();
     if (const char* e = getenv("CM_ENGINE_FULL")) engine_full = engine_full && atoi(e) != 0;
@@ -388,7 +387,13 @@ void Model::build_engine() {
         // down_proj + residual
         p[3].W = w.down; p[3].N = H; p[3].K = I_l; p[3].kind = ENG_RESADD;
         p[3].xoff = x0 + x1; p[3].xbuf = 2; p[3].in_edge = ENG_E_H; p[3].out_edge = ENG_E_X0;
-        for (int k = 0; k < 4; ++k) { p[k].gpw = gpw(p[k].N); p[k].gblk = gblk(p[k].N); p[k].nb = p[k].K / 2048; }
+        for (int k = 0; k < 4; ++k) {
+            p[k].gpw = gpw(p[k].N); p[k].nb = p[k].K / 2048;
+            // row groups kept open (walked chunk-major): a consumer with few chunks needs several open groups so that the
+            // LAST chunk of its input is needed late; a producer should close groups early so that the first chunks of
+            // its output exist early.  Long rows (down_proj) go group by group, short rows three groups at a time.
+            p[k].gblk = p[k].nb > 2 ? 1 : std::min(p[k].gpw, 3);
+        }
         at[(size_t)li] = EngAttnL{kpool(li), vpool(li), w.qn, w.kn};
     }
     eng_prog = (EngPhase*)dalloc<int>(prog.size() * sizeof(EngPhase) / sizeof(int));

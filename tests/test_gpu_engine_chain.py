@@ -45,7 +45,7 @@ def test_chain_equals_launch_path_and_oracle(trio):
         c = o.forward([t], pos)
         assert rel(a, b) < 1e-4, (pos, rel(a, b))      # the sum of squares of the RMSNorm is accumulated in another order;
                                                          # a K/V element on a bf16 tie then rounds the other way (2^-9 on it)
-        assert rel(a, c) < 5e-4, (pos, rel(a, c))
+        assert rel(a, c) < 1e-3, (pos, rel(a, c))      # bf16 K/V appends: a value on a rounding tie moves by 2^-9
         assert int(a.argmax()) == int(c.argmax())
 
 
