@@ -688,10 +688,10 @@ size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw) {
 EngCfg engine_config() {
     static EngCfg c{0, 0, 0};
     if (c.nsw == 0) {
-        c = EngCfg{8, ENG_NCW, 2};
+        c = EngCfg{4, ENG_NCW, 4};
         if (const char* e = getenv("CM_ENG_CFG")) {
             int n = 0, p = 0;
-            if (sscanf(e, "%d,%d", &n, &p) == 2 && ((n == 4 && (p == 3 || p == 4)) || (n == 8 && (p == 2 || p == 3)))) { c.nsw = n; c.pf = p; }
+            if (sscanf(e, "%d,%d", &n, &p) == 2 && ((n == 4 && p >= 3 && p <= 6) || (n == 8 && (p == 2 || p == 3)))) { c.nsw = n; c.pf = p; }
         }
     }
     return c;
@@ -709,16 +709,24 @@ static bool prepare_v(size_t lds_bytes) {
     return true;
 }
 
-bool engine_prepare(size_t lds_bytes) {
-    const EngCfg c = engine_config();
-    if (c.nsw == 8) return c.pf == 2 ? prepare_v<8, 2>(lds_bytes) : prepare_v<8, 3>(lds_bytes);
-    return c.pf == 3 ? prepare_v<4, 3>(lds_bytes) : prepare_v<4, 4>(lds_bytes);
-}
-
 template <int NSW, int PF>
 static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
     if (trace) hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, 4, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
     else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, 4, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+}
+
+#define CM_ENG_DISPATCH(CALL)                                            \
+    if (c.nsw == 8) { if (c.pf == 2) { CALL(8, 2) } else { CALL(8, 3) } } \
+    else if (c.pf == 3) { CALL(4, 3) }                                     \
+    else if (c.pf == 5) { CALL(4, 5) }                                     \
+    else if (c.pf == 6) { CALL(4, 6) }                                     \
+    else { CALL(4, 4) }
+
+bool engine_prepare(size_t lds_bytes) {
+    const EngCfg c = engine_config();
+#define CM_ENG_PREP(N, P) return prepare_v<N, P>(lds_bytes);
+    CM_ENG_DISPATCH(CM_ENG_PREP)
+#undef CM_ENG_PREP
 }
 
 bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
@@ -726,8 +734,9 @@ bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const size_t lds = engine_lds_bytes(a, c.nsw, c.ncw);
     if (lds > 160 * 1024 - 256 || a.gpw_res > MAXRES || a.p1 <= a.p0) return false;
     const bool tr = trace && a.trace != nullptr;
-    if (c.nsw == 8) { if (c.pf == 2) launch_v<8, 2>(a, grid, lds, s, tr); else launch_v<8, 3>(a, grid, lds, s, tr); }
-    else { if (c.pf == 3) launch_v<4, 3>(a, grid, lds, s, tr); else launch_v<4, 4>(a, grid, lds, s, tr); }
+#define CM_ENG_LAUNCH(N, P) launch_v<N, P>(a, grid, lds, s, tr);
+    CM_ENG_DISPATCH(CM_ENG_LAUNCH)
+#undef CM_ENG_LAUNCH
     return true;
 }
 

@@ -342,8 +342,8 @@ void Model::build_engine() {
     if (opts.engine < 0) return;
     std::string why;
     const bool ok = engine_eligible(&why);
-    // default (0): opt-in through CM_ENGINE=1 until the launch path is retired; 1: required
-    if (opts.engine == 0) { const char* e = getenv("CM_ENGINE"); if (!(e && atoi(e) > 0)) return; }
+    // default (0): on whenever the shapes allow it (CM_ENGINE=0 turns it off for A/B runs); 1: required
+    if (opts.engine == 0) { const char* e = getenv("CM_ENGINE"); if (e && atoi(e) <= 0) return; }
     if (!ok) {
         if (opts.engine > 0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.engine = 1: " + why);
         return;

@@ -35,9 +35,33 @@ def _lib():
     return lib
 
 
+def host_threads() -> int:
+    """OpenMP team size for the C port: the CPUs this process may actually use -- min(affinity mask, cgroup CPU quota).
+    The GPU hosts show 256 logical CPUs but run the container under a 16-CPU quota; 128 threads there were CFS-throttled
+    into 1-2 tokens/s with 2x run-to-run noise, 16 threads stream ~350 GB/s (tools/cpu_probe.py).  QC_THREADS overrides."""
+    env = os.environ.get("QC_THREADS")
+    if env:
+        return max(1, int(env))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
 class CQwen3:
     def __init__(self, cfg: dict, seed: int = 0, max_seq: int = 2048, kv_bf16: bool = False):
         self.lib = _lib()
+        self.lib.qc_set_threads(host_threads())
         D = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
         c = QcCfg(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"],
                   cfg["num_attention_heads"], cfg["num_key_value_heads"], D, max_seq,
