@@ -224,7 +224,7 @@ def main():
                     while eq < len(ref_toks) and gt[eq] == ref_toks[eq]:
                         eq += 1
                     parity = {"tokens_checked": len(ref_toks), "tokens_equal": eq, "logit_rel": float(f"{lrel:.3e}"),
-                              "reference": "oracle/c f32 forward, bf16-rounded KV appends, identical synthetic weights + KV",
+                              "reference": "oracle/c f32 CPU forward (K/V appends unrounded), identical synthetic weights + synthetic KV",
                               "ok": bool(eq == len(ref_toks) and lrel < 1e-3)}
             except Exception as e:  # the baseline must never break the headline number
                 cpu = {"error": str(e)}
@@ -242,7 +242,7 @@ def main():
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
                                    f"{wdt} weights + {args.kv} paged KV, f32 activations",
                        "parallelism": f"tp{n}", "rccl_ranks": ranks, "graph": not args.no_graph,
-                       "decode_path": "persistent chain kernel" if m.engine_active() else "per-projection launches"},
+                       "decode_path": "persistent decode kernel (cm_opts.engine)" if m.engine_active() else "per-projection launches"},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "parity": parity, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
