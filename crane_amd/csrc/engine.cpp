@@ -322,7 +322,10 @@ int cm_engine_step_many(cm_engine* h, size_t max_steps, cm_engine_event* ev, siz
     const size_t per_step = 2 * (size_t)std::max<long>(1, e.opts.max_running > 0 ? (long)e.opts.max_running : (long)e.m->seqs.size());
     try {
         (void)hipSetDevice(e.m->dev);
-        for (size_t i = 0; i < max_steps && e.events.size() + per_step <= cap; ++i) {
+        // always make progress: with an empty event queue one step runs even when its worst case (2 events per running
+        // sequence) would not fit `cap` -- the surplus stays queued for the next call -- otherwise a small buffer would
+        // return n = 0 with work pending and the caller would spin forever
+        for (size_t i = 0; i < max_steps && (e.events.size() + per_step <= cap || (i == 0 && e.events.empty())); ++i) {
             if (e.waiting.empty() && e.running.empty()) break;
             e.step();
         }

@@ -48,7 +48,15 @@ struct TensorInfo {
     uint32_t type = 0;
     const uint8_t* data = nullptr;
     size_t nbytes = 0;
-    uint64_t numel() const { uint64_t n = 1; for (uint64_t d : shape) n *= d; return n; }
+    // element count; UINT64_MAX when the product overflows
+    uint64_t numel() const {
+        uint64_t n = 1;
+        for (uint64_t d : shape) {
+            if (d != 0 && n > UINT64_MAX / d) return UINT64_MAX;
+            n *= d;
+        }
+        return n;
+    }
 };
 
 class File {
@@ -145,15 +153,22 @@ private:
         }
         uint64_t align = 32;
         if (const Value* a = meta("general.alignment")) align = a->as_u64() ? a->as_u64() : 32;
+        if (align > (1u << 20) || (align & (align - 1))) throw std::runtime_error("bad general.alignment");
         const size_t data0 = (pos_ + align - 1) / align * align;
+        if (data0 > size_) throw std::runtime_error("truncated GGUF (no tensor data)");
         for (auto& p : infos) {
             TensorInfo& ti = p.first;
             size_t be = 0, bb = 0;
             if (type_layout(ti.type, be, bb)) {
                 const uint64_t n = ti.numel();
+                if (n == UINT64_MAX) throw std::runtime_error("tensor " + ti.name + ": shape overflows");
                 if (n % be) throw std::runtime_error("tensor " + ti.name + ": element count is not a multiple of the block size");
+                if (n / be > UINT64_MAX / bb) throw std::runtime_error("tensor " + ti.name + ": size overflows");
                 ti.nbytes = (size_t)(n / be * bb);
-                if (data0 + p.second + ti.nbytes > size_) throw std::runtime_error("tensor " + ti.name + " runs past the end of the file");
+                const size_t room = size_ - data0;                      // overflow-safe: offset and size against what is left
+                if (p.second > room || ti.nbytes > room - p.second) throw std::runtime_error("tensor " + ti.name + " runs past the end of the file");
+            } else if (p.second > size_ - data0) {
+                throw std::runtime_error("tensor " + ti.name + " starts past the end of the file");
             }
             ti.data = base_ + data0 + p.second;
             tensors_[ti.name] = ti;

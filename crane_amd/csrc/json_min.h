@@ -96,7 +96,13 @@ class Parser {
         ++p_;
         return out;
     }
+    // nesting is bounded: the parser recurses per level, and a header is attacker-controlled input
+    static constexpr int kMaxDepth = 64;
+    int depth_ = 0;
+    struct DepthGuard { int& d; explicit DepthGuard(int& x) : d(x) { ++d; } ~DepthGuard() { --d; } };
     ValuePtr value() {
+        DepthGuard guard(depth_);
+        if (depth_ > kMaxDepth) fail("nesting too deep");
         ws();
         if (p_ >= e_) fail("unexpected end");
         auto v = std::make_shared<Value>();

@@ -96,6 +96,8 @@ struct FileSource : Source {
         const uint8_t* src = t.data;
         if (t.dtype != "BF16") {
             // F32 / F16 checkpoints: round to bf16 (the model dtype) on the host
+            if (t.dtype != "F32" && t.dtype != "F16") throw CmError(CM_ERR_UNSUPPORTED, "tensor dtype " + t.dtype + " not supported (" + name + ")");
+            if ((size_t)t.nbytes != (size_t)rows * full_cols * (t.dtype == "F32" ? 4u : 2u)) throw CmError(CM_ERR_IO, "tensor " + name + " truncated");
             tmp.resize((size_t)nrows * ncols);
             for (int r = 0; r < nrows; ++r)
                 for (int c = 0; c < ncols; ++c) {
@@ -159,6 +161,7 @@ void build(Model& m, Source& src) {
     }
     if (have_head) {
         m.lm_head = m.dalloc<uint16_t>((size_t)std::max(1, v_eff) * H, true);
+        m.lm_head_owned = true;
         if (v_eff > 0) src.fetch(head_name, c.V, H, m.v0, v_eff, 0, H, m.lm_head, (size_t)H);
     } else {
         m.lm_head = m.embed + (size_t)m.v0 * H;     // tied: same tensor, no copy

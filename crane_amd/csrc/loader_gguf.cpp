@@ -366,13 +366,17 @@ void Model::isq_q8_0() {
         w.q_gate_up = quant(w.gate_up, 2 * I_l, H);
         w.q_down = quant(w.down, H, I_l);
     }
-    if (!cfg.tie) q_lm_head = quant(lm_head, tp == 1 ? cfg.V : V_l, H);     // vocabulary shard [v0, v0 + V_l) under TP
+    // only a head the model owns is quantised (and freed below): a tied head -- or the hybrid family's fallback to the
+    // embedding when the checkpoint has no lm_head.weight -- aliases the bf16 table that embed_row keeps reading.
+    // Rows = the v_eff rows the loader allocated for this rank's vocabulary shard [v0, v0 + v_eff).
+    const int v_eff_q = std::max(0, std::min(V_l, cfg.V - v0));
+    if (lm_head_owned && v_eff_q > 0) q_lm_head = quant(lm_head, v_eff_q, H);
     CM_HIP(hipStreamSynchronize(stream));
     for (LayerW& w : layers) {
         dfree(w.qkv); dfree(w.o); dfree(w.gate_up); dfree(w.down); dfree(w.in_proj); dfree(w.out_proj);
         w.qkv = w.o = w.gate_up = w.down = w.in_proj = w.out_proj = nullptr;
     }
-    if (!cfg.tie) { dfree(lm_head); lm_head = nullptr; }
+    if (lm_head_owned && q_lm_head.fmt != QFMT_NONE) { dfree(lm_head); lm_head = nullptr; lm_head_owned = false; }
     quantized = true;
 }
 

@@ -109,6 +109,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
         cfg.tie = root->has("tie_word_embeddings") ? root->boolean("tie_word_embeddings", false)
                                                    : j->boolean("tie_word_embeddings", false);
         cfg.interval = (int)root->integer("full_attention_interval", 4);
+        if (cfg.interval <= 0) throw CmError(CM_ERR_INVALID, "full_attention_interval must be positive");
         cfg.conv_k = (int)root->integer("linear_conv_kernel_dim", 4);
         cfg.Kd = (int)root->integer("linear_key_head_dim", 0);
         cfg.Vd = (int)root->integer("linear_value_head_dim", 0);
@@ -555,24 +556,39 @@ int Model::seq_fork(int src) {
     // copy-on-write of the last, partially filled page: both forks will append into it
     if (!b.pages.empty() && (a.len % page) != 0) {
         if (free_pages.empty()) { seq_free(d); throw CmError(CM_ERR_OOM, "KV pool exhausted"); }
-        const int32_t oldp = b.pages.back();
-        const int32_t newp = free_pages.back();
-        free_pages.pop_back();
-        page_ref[(size_t)newp] = 1;
-        page_ref[(size_t)oldp]--;
-        b.pages.back() = newp;
-        const size_t pitch = (size_t)n_pages * page_bytes;
-        CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_bytes, pitch, kv_pool + (size_t)oldp * page_bytes, pitch,
-                                page_bytes, (size_t)n_kv_layers * 2, hipMemcpyDeviceToDevice, stream));
+        cow_page(d, b.pages.size() - 1);
     }
     return d;
+}
+
+// give `q` a private copy of its page `idx` (all layers, K and V) when the page is shared with a fork
+void Model::cow_page(int s, size_t idx) {
+    Seq& q = seqs[(size_t)s];
+    const int32_t oldp = q.pages[idx];
+    if (page_ref[(size_t)oldp] <= 1) return;
+    if (free_pages.empty()) throw CmError(CM_ERR_OOM, "KV pool exhausted");
+    const int32_t newp = free_pages.back();
+    free_pages.pop_back();
+    page_ref[(size_t)newp] = 1;
+    page_ref[(size_t)oldp]--;
+    q.pages[idx] = newp;
+    const size_t pitch = (size_t)n_pages * page_bytes;
+    CM_HIP(hipMemcpy2DAsync(kv_pool + (size_t)newp * page_bytes, pitch, kv_pool + (size_t)oldp * page_bytes, pitch,
+                            page_bytes, (size_t)n_kv_layers * 2, hipMemcpyDeviceToDevice, stream));
+    if (active_seq == s) active_pages_uploaded = std::min(active_pages_uploaded, idx);    // re-upload the table entry
 }
 
 void Model::ensure_pages(int s, int64_t upto_len) {
     Seq& q = seq(s);
     if (upto_len > max_seq) throw CmError(CM_ERR_RANGE, "sequence longer than max_seq_len");
     const size_t need = (size_t)((upto_len + page - 1) / page);
-    // a shared (forked) last page must not be appended into
+    // A page shared with a fork must not be appended into.  seq_fork copies the partially filled last page, but a fork (or
+    // its parent) can later be cut back INTO a fully shared page (cm_seq_truncate, or forward() with start_pos < len): the
+    // page that holds the first position about to be written is made private here.
+    if (q.len < upto_len && (q.len % page) != 0) {
+        const size_t idx = (size_t)(q.len / page);
+        if (idx < q.pages.size()) cow_page(s, idx);
+    }
     while (q.pages.size() < need) {
         if (free_pages.empty()) throw CmError(CM_ERR_OOM, "KV pool exhausted");
         const int32_t p = free_pages.back();
@@ -1384,7 +1400,7 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
         }
     } else {
         // device-chained greedy decode: the arg-max kernel feeds the next step's token/pos in HBM
-        const size_t chunk = g.sync_every ? g.sync_every : 1;
+        const size_t chunk = std::min<size_t>(g.sync_every ? g.sync_every : 1, (size_t)RING);   // the device token ring holds RING steps
         Seq& q = seq(0);
         while (!stop && produced < g.max_new_tokens) {
             const size_t want = std::min(chunk, (size_t)g.max_new_tokens - produced);

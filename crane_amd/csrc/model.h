@@ -126,6 +126,8 @@ struct Model {
     // weights
     uint16_t* embed = nullptr;     // [V, H] replicated
     uint16_t* lm_head = nullptr;   // [V_l, H] (points into embed when tied)
+    bool lm_head_owned = false;    // lm_head is its own allocation of v_eff rows (false: an alias of embed -- tied, or the
+                                   // hybrid family's fallback when the checkpoint has no lm_head.weight)
     float* norm = nullptr;
     std::vector<LayerW> layers;
     float* cos = nullptr;
@@ -313,6 +315,7 @@ struct Model {
     void seq_free(int s);
     int seq_fork(int src);
     void seq_truncate(int s, size_t new_len);
+    void cow_page(int s, size_t idx);
     void ensure_pages(int s, int64_t upto_len);
     void activate(int s);
     Seq& seq(int s);

@@ -127,7 +127,9 @@ void Model::sample_enqueue(int slot, const cm_sample_params& p, const uint32_t* 
         int k = (int)p.top_k;
         if (k == 0 && top_p_active) k = 64;                        // CRANE_TOPP_FALLBACK_TOPK default (sampling.rs:263-267)
         k = std::min(std::min(k, 64), V);                          // sampling.rs:268
-        if (k > 0 && k < V) {
+        // k == V (a vocabulary of <= 64 tokens) with an active top-p still goes through the sorted top-k path: the nucleus
+        // cut needs the descending order (the reference falls back to the nucleus LogitsProcessor there)
+        if (k > 0 && (k < V || top_p_active)) {
             launch_topk(logits, V, k, cand, hist, hist + 4096, idx, val, stream);
             launch_sample_topk(idx, val, k, p.temperature, top_p_active ? p.top_p : 0.f, p.seed, p.draw, tok, stream);
         } else {

@@ -17,6 +17,7 @@
 #include <set>
 #include <sstream>
 #include <stdexcept>
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -29,7 +30,23 @@ struct TensorView {
     std::vector<int64_t> shape;
     const uint8_t* data = nullptr;
     size_t nbytes = 0;
-    int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
+    // element count with overflow / negative-dimension checks (-1: invalid)
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : shape) {
+            if (d < 0) return -1;
+            if (d != 0 && n > INT64_MAX / d) return -1;
+            n *= d;
+        }
+        return n;
+    }
+    static size_t elem_size(const std::string& dt) {
+        if (dt == "BF16" || dt == "F16" || dt == "I16" || dt == "U16") return 2;
+        if (dt == "F32" || dt == "I32" || dt == "U32") return 4;
+        if (dt == "F64" || dt == "I64" || dt == "U64") return 8;
+        if (dt == "I8" || dt == "U8" || dt == "BOOL" || dt == "F8_E4M3" || dt == "F8_E5M2") return 1;
+        return 0;                 // unknown dtype: the loader rejects the tensor when it is asked for
+    }
 };
 
 class MappedFile {
@@ -116,7 +133,7 @@ class Checkpoint {
         if (mf.size() < 8) throw std::runtime_error("truncated safetensors " + path);
         uint64_t hl = 0;
         memcpy(&hl, mf.base(), 8);
-        if (8 + hl > mf.size()) throw std::runtime_error("bad safetensors header length in " + path);
+        if (hl > mf.size() - 8) throw std::runtime_error("bad safetensors header length in " + path);    // (8 + hl would wrap)
         auto j = cmjson::Parser((const char*)mf.base() + 8, (size_t)hl).parse();
         const uint8_t* data0 = mf.base() + 8 + hl;
         const size_t data_len = mf.size() - 8 - hl;
@@ -128,11 +145,21 @@ class Checkpoint {
             const cmjson::Value* sh = t.get("shape");
             const cmjson::Value* off = t.get("data_offsets");
             if (!sh || !off || off->arr.size() != 2) throw std::runtime_error("bad tensor entry " + kv.first);
-            for (auto& d : sh->arr) tv.shape.push_back((int64_t)d->num);
-            const size_t b = (size_t)off->arr[0]->num, e = (size_t)off->arr[1]->num;
-            if (e < b || e > data_len) throw std::runtime_error("tensor out of file bounds: " + kv.first);
+            for (auto& d : sh->arr) {
+                if (!(d->num >= 0.0 && d->num <= 9.0e15)) throw std::runtime_error("bad dimension in tensor " + kv.first);
+                tv.shape.push_back((int64_t)d->num);
+            }
+            const double bo = off->arr[0]->num, eo = off->arr[1]->num;
+            if (!(bo >= 0.0 && eo >= bo && eo <= (double)data_len)) throw std::runtime_error("tensor out of file bounds: " + kv.first);
+            const size_t b = (size_t)bo, e = (size_t)eo;
             tv.data = data0 + b;
             tv.nbytes = e - b;
+            // every dtype: the byte range must be exactly numel * element size (checked multiplication)
+            const int64_t ne = tv.numel();
+            const size_t es = TensorView::elem_size(tv.dtype);
+            if (ne < 0) throw std::runtime_error("bad shape in tensor " + kv.first);
+            if (es != 0 && ((uint64_t)ne > UINT64_MAX / es || (uint64_t)ne * es != (uint64_t)tv.nbytes))
+                throw std::runtime_error("tensor " + kv.first + ": data_offsets do not match shape x dtype");
             tensors_[kv.first] = tv;
         }
     }

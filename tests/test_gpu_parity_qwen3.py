@@ -150,6 +150,33 @@ def test_sequences_fork_truncate(pair):
     assert m.active_kv_cache_bytes() == 0 or m.seq_len(0) > 0
 
 
+def test_fork_truncate_append_does_not_touch_the_sibling(pair):
+    """A fork cut back INTO a page it still shares with its parent (truncate, or forward with start_pos < len) must get a
+    private copy of that page before it appends: fork at 160 tokens (2.5 pages), truncate the child to 100 (inside the
+    fully shared second page), re-feed other tokens -- the parent's positions 100..127 must be unchanged."""
+    cfg, w, m = pair
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    V = cfg["vocab_size"]
+    a = configs.synthetic_prompt(160, V)
+    parent = m.seq_alloc()
+    m.seq_forward(parent, a, 0)
+    child = m.seq_fork(parent)
+    other = [(5 * i + 1) % V for i in range(40)]
+    lc, _ = m.seq_forward(child, other, 100)                 # start_pos < len: truncates to 100, then appends 40 tokens
+    lp, _ = m.seq_forward(parent, [9], 160)                  # the parent still attends to ITS tokens 100..159
+    o.clear_kv_cache(); o.forward(a, 0); rp = o.forward([9], 160)
+    o.clear_kv_cache(); o.forward(a[:100], 0); rc = o.forward(other, 100)
+    assert rel(lp, rp) < REL_SAME, rel(lp, rp)
+    assert rel(lc, rc) < REL_SAME, rel(lc, rc)
+    m.seq_truncate(parent, 70)                               # and the other way round: the parent is cut into a shared page
+    lp2, _ = m.seq_forward(parent, [3, 4, 5], 70)
+    lc2, _ = m.seq_forward(child, [8], 140)
+    o.clear_kv_cache(); o.forward(a[:70], 0); rp2 = o.forward([3, 4, 5], 70)
+    o.clear_kv_cache(); o.forward(a[:100], 0); o.forward(other, 100); rc2 = o.forward([8], 140)
+    assert rel(lp2, rp2) < REL_SAME and rel(lc2, rc2) < REL_SAME
+    m.seq_free(parent); m.seq_free(child)
+
+
 def test_error_behaviour(pair):
     cfg, w, m = pair
     from crane_amd._lib import CraneError

@@ -145,3 +145,57 @@ def test_safetensors_errors(tmp_path):
     (bad / "model.safetensors").write_bytes(struct.pack("<Q", len(hdr)) + hdr + b"\0" * 16)
     with pytest.raises(_lib.CraneError, match="out of file bounds"):
         checkpoint_inspect(str(bad))
+
+
+def test_safetensors_hostile_headers(tmp_path):
+    """The checkpoint parser reads an mmap'ed, attacker-controlled file: every length is checked without overflow, every
+    tensor's byte range must equal shape x dtype, and JSON nesting is bounded."""
+    from crane_amd.backend import checkpoint_inspect
+    bad = tmp_path / "hostile"
+    bad.mkdir()
+    f = bad / "model.safetensors"
+
+    def put(hdr: bytes, data: bytes = b"\0" * 64, hl=None):
+        f.write_bytes(struct.pack("<Q", len(hdr) if hl is None else hl) + hdr + data)
+
+    put(b"{}", hl=(1 << 64) - 4)                                 # 8 + hl wraps around
+    with pytest.raises(_lib.CraneError, match="header length"):
+        checkpoint_inspect(str(bad))
+    put(b'{"w": {"dtype": "F32", "shape": [4, 8], "data_offsets": [0, 64]}}')       # 32 elements x 4 B != 64 B
+    with pytest.raises(_lib.CraneError, match="do not match"):
+        checkpoint_inspect(str(bad))
+    put(b'{"w": {"dtype": "F16", "shape": [4294967296, 4294967296, 4], "data_offsets": [0, 64]}}')    # numel overflows int64
+    with pytest.raises(_lib.CraneError, match="bad shape|do not match"):
+        checkpoint_inspect(str(bad))
+    put(b'{"w": {"dtype": "BF16", "shape": [-4], "data_offsets": [0, 8]}}')
+    with pytest.raises(_lib.CraneError, match="bad dimension"):
+        checkpoint_inspect(str(bad))
+    put(b'{"w": {"dtype": "BF16", "shape": [4], "data_offsets": [8, 0]}}')
+    with pytest.raises(_lib.CraneError, match="out of file bounds"):
+        checkpoint_inspect(str(bad))
+    deep = b"[" * 5000 + b"]" * 5000
+    put(b'{"__metadata__": ' + deep + b"}")
+    with pytest.raises(_lib.CraneError, match="nesting too deep"):
+        checkpoint_inspect(str(bad))
+    put(b'{"w": {"dtype": "F32", "shape": [4, 4], "data_offsets": [0, 64]}}')       # and a well-formed one still loads
+    assert checkpoint_inspect(str(bad))["w"]["nbytes"] == 64
+
+
+def test_gguf_hostile_tensor_directory(tmp_path):
+    """Tensor shapes / offsets in a GGUF directory cannot overflow the bounds check."""
+    p = str(tmp_path / "x.gguf")
+    _minimal(p)
+    raw = bytearray(open(p, "rb").read())
+    # the directory entry of token_embd.weight: name, n_dims = 2, dims [256, 512] (innermost first), type, offset
+    at = raw.find(b"token_embd.weight") + len(b"token_embd.weight")
+    assert struct.unpack_from("<I", raw, at)[0] == 2
+    struct.pack_into("<QQ", raw, at + 4, 1 << 33, 1 << 33)      # 2^66 elements: the product overflows uint64
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(_lib.CraneError, match="overflows|past the end"):
+        gguf_config(p)
+    _minimal(p)
+    raw = bytearray(open(p, "rb").read())
+    struct.pack_into("<Q", raw, at + 4 + 16 + 4, (1 << 64) - 64)   # offset near 2^64: data0 + off would wrap
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(_lib.CraneError, match="past the end"):
+        gguf_config(p)
