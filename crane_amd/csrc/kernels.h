@@ -65,6 +65,8 @@ struct GdnArgs {
     float* pre_k = nullptr;      //   {beta, decay} [S][NV][2]; null: always the fused kernel
     float* pre_v = nullptr;
     float* pre_bd = nullptr;
+    float* gdn_scratch = nullptr;   // decode step on 4 workgroups per head: [n_seq][NV][V + 4] raw y + partial sums of squares
+    int* gdn_ticket = nullptr;      //   and [n_seq][NV] arrival tickets (zero between launches); null: one workgroup per head
     int chunked = 0;            // value-head order: 0 Interleaved (HF: key head = v / vpg), 1 Chunked (llama.cpp GGUF: v % NK; ops/gdn/config.rs:13-22)
     int n_seq, batch_proj_stride, batch_out_stride;   // batched decode step (grid.y)
     float eps;

@@ -117,6 +117,121 @@ __global__ __launch_bounds__(128) void gdn_kernel(GdnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Decode step on NV x 4 workgroups.  The fused kernel above reads and writes a value head's 64 KiB state from ONE
+// workgroup: 16 (Qwen3.5-0.8B) ... 48 (Qwen3.8-27B) of 256 CUs stream the only HBM-bound bytes of the layer (measured
+// 8.7 us per layer on the 0.8B model = 0.24 TB/s).  Here a value head is four workgroups of 32 state columns each
+// (one column = 256 threads / 32: 8 k-slices of 16 state values per thread; a wave reads 2 x 128 contiguous bytes per k).
+// Everything per token is recomputed by each of them (conv + SiLU + L2 norm of the key head's q / k: 256 channels), the
+// recurrence runs on the workgroup's own columns, and the gated RMSNorm -- which needs the head's 128 y values -- is done
+// by the LAST of the four workgroups to arrive: raw y and the partial sums of squares go out as write-through (sc1)
+// stores, every wave drains them, one lane takes a ticket; the workgroup that draws 3 reads them back with sc1 loads
+// (no fences, no polling: MI355X_MICROARCH.md "handoff-flag", Guideline 16 R1).  Same arithmetic as gdn_kernel except
+// for the association of the two 128-term sums over k (8 partial sums of 16 terms).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gdn_decode_kernel(GdnArgs a) {
+    constexpr int K = 128, V = 128, KER = 4, CB = 32, KS = 8, KP = K / KS;
+    __shared__ float qs[K], ks_[K], vs[CB];
+    __shared__ float red[8];
+    __shared__ float part[KS][CB];
+    __shared__ float bd[2];
+    __shared__ int last_flag;
+    const int h = blockIdx.x, cb = blockIdx.y, bq = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid & (CB - 1), ksl = tid / CB;              // column inside the block, k-slice
+    const int v = cb * CB + c;
+    const int nk = a.NV / a.vpg;
+    const int kh = a.chunked ? h % nk : h / a.vpg;
+    const int conv_dim = 2 * a.key_dim + a.NV * V;
+    const bool qk_writer = cb == 0 && (a.chunked ? (h < nk) : (h % a.vpg) == 0);
+    const int start_pos = a.st[bq].pos, slot = a.st[bq].slot;
+    float* conv_state = a.conv_pool + ((size_t)slot * a.gdn_layers + a.layer_idx) * 2 * conv_dim * (KER - 1);
+    const float* cs_in = conv_state + (size_t)(start_pos & 1) * conv_dim * (KER - 1);
+    float* cs_out = conv_state + (size_t)((start_pos + 1) & 1) * conv_dim * (KER - 1);
+    const float* pr = a.proj + (size_t)bq * a.batch_proj_stride;
+    // state slice: requested first (the only HBM-bound bytes)
+    float* Sg = a.state_pool + (((size_t)slot * a.gdn_layers + a.layer_idx) * a.NV + h) * K * V;
+    float S[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) S[k] = __builtin_nontemporal_load(&Sg[(ksl * KP + k) * V + v]);
+    // conv + SiLU: threads 0..127 the q channel, 128..255 the k channel of the key head; threads < 32 also this block's v columns
+    {
+        const int ch = (tid < K ? kh * K + tid : a.key_dim + kh * K + (tid - K));
+        const float w0 = a.conv_w[ch * KER], w1 = a.conv_w[ch * KER + 1], w2 = a.conv_w[ch * KER + 2], w3 = a.conv_w[ch * KER + 3];
+        const float h0 = cs_in[ch * (KER - 1)], h1 = cs_in[ch * (KER - 1) + 1], h2 = cs_in[ch * (KER - 1) + 2];
+        const float x = pr[ch];
+        const float y = silu_f(h0 * w0 + h1 * w1 + h2 * w2 + x * w3);
+        if (qk_writer) { cs_out[ch * (KER - 1)] = h1; cs_out[ch * (KER - 1) + 1] = h2; cs_out[ch * (KER - 1) + 2] = x; }
+        const float ss = wave_sum(y * y);                      // waves 0,1 = q; 2,3 = k
+        if (lane == 0) red[wave] = ss;
+        if (tid < K) qs[tid] = y; else ks_[tid - K] = y;
+        if (tid < CB) {
+            const int cv = 2 * a.key_dim + h * V + v;          // v == cb * CB + tid here
+            const float u0 = a.conv_w[cv * KER], u1 = a.conv_w[cv * KER + 1], u2 = a.conv_w[cv * KER + 2], u3 = a.conv_w[cv * KER + 3];
+            const float g0 = cs_in[cv * (KER - 1)], g1 = cs_in[cv * (KER - 1) + 1], g2 = cs_in[cv * (KER - 1) + 2];
+            const float xv = pr[cv];
+            vs[tid] = silu_f(g0 * u0 + g1 * u1 + g2 * u2 + xv * u3);
+            cs_out[cv * (KER - 1)] = g1; cs_out[cv * (KER - 1) + 1] = g2; cs_out[cv * (KER - 1) + 2] = xv;
+        }
+        if (tid == 0) {
+            const float beta = 1.0f / (1.0f + expf(-pr[conv_dim + a.NV * V + h]));
+            const float av = pr[conv_dim + a.NV * V + a.NV + h] + a.dt_bias[h];
+            bd[0] = beta;
+            bd[1] = expf(-expf(a.A_log[h]) * logf(1.0f + expf(av)));
+        }
+    }
+    __syncthreads();
+    const float dq = sqrtf(red[0] + red[1] + 1e-6f), dk = sqrtf(red[2] + red[3] + 1e-6f);
+    const float beta = bd[0], decay = bd[1];
+    float kf[KP], qf[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { kf[k] = ks_[ksl * KP + k] / dk; qf[k] = qs[ksl * KP + k] / dq * 0.08838834764831845f; }   // 1/sqrt(128)
+    // ---- recurrence on this thread's 16 state values of column v ----
+    float kv2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { S[k] *= decay; kv2[k & 1] += S[k] * kf[k]; }
+    part[ksl][c] = kv2[0] + kv2[1];
+    __syncthreads();
+    float kv = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) kv += part[j][c];
+    const float delta = (vs[c] - kv) * beta;
+    float y2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { S[k] += kf[k] * delta; y2[k & 1] += S[k] * qf[k]; }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) __builtin_nontemporal_store(S[k], &Sg[(ksl * KP + k) * V + v]);
+    __syncthreads();                                           // everyone has read part[][] (kv)
+    part[ksl][c] = y2[0] + y2[1];
+    __syncthreads();
+    // ---- raw y of the block's 32 columns + partial sum of squares -> write-through; ticket; last arriver normalises ----
+    float* yraw = a.gdn_scratch + ((size_t)bq * a.NV + h) * (V + 4);
+    int* ticket = a.gdn_ticket + (size_t)bq * a.NV + h;
+    if (tid < CB) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) y += part[j][tid];
+        __hip_atomic_store(&yraw[cb * CB + tid], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float sy = y * y;
+        sy += __shfl_xor(sy, 16); sy += __shfl_xor(sy, 8); sy += __shfl_xor(sy, 4); sy += __shfl_xor(sy, 2); sy += __shfl_xor(sy, 1);
+        if (tid == 0) __hip_atomic_store(&yraw[V + cb], sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) last_flag = (atomicAdd(ticket, 1) == (int)gridDim.y - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_flag) return;
+    if (tid < V) {
+        const float y = __hip_atomic_load(&yraw[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float tot = 0.f;
+        for (int j = 0; j < (int)gridDim.y; ++j) tot += __hip_atomic_load(&yraw[V + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float rms = 1.0f / sqrtf(tot / (float)V + a.eps);
+        const float z = pr[conv_dim + h * V + tid];
+        a.out[(size_t)bq * a.batch_out_stride + h * V + tid] = y * rms * a.gnorm_w[tid] * silu_f(z);
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // next launch starts from 0
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Prefill in three passes.  The fused kernel above walks a prompt with 4 barriers, two block reductions and a handful
 // of transcendental functions per token on ONE block per value head (~5 us per token and layer).  Everything except
 // the state recurrence is independent across tokens, so:
@@ -272,6 +387,10 @@ void launch_gdn(const GdnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(gdn_pre_kernel, dim3(a.S, nk + a.NV), dim3(128), 0, s, a);
         hipLaunchKernelGGL(gdn_scan_kernel, dim3(a.NV, 4), dim3(512), 0, s, a);
         hipLaunchKernelGGL(gdn_post_kernel, dim3(a.S, a.NV), dim3(128), 0, s, a);
+        return;
+    }
+    if (a.st != nullptr && a.S == 1 && a.gdn_scratch != nullptr && a.gdn_ticket != nullptr) {     // decode step: 4 workgroups per value head
+        hipLaunchKernelGGL(gdn_decode_kernel, dim3(a.NV, 4, a.n_seq > 0 ? a.n_seq : 1), dim3(256), 0, s, a);
         return;
     }
     hipLaunchKernelGGL(gdn_kernel, dim3(a.NV, a.n_seq > 0 ? a.n_seq : 1), dim3(128), 0, s, a);

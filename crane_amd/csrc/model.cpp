@@ -243,6 +243,9 @@ void Model::alloc_runtime() {
         state_slot_elems = (size_t)gdn_layers * cfg.NV * cfg.Kd * cfg.Vd;
         conv_pool = dalloc<float>(conv_slot_elems * seqs.size());
         state_pool = dalloc<float>(state_slot_elems * seqs.size());
+        gdn_scratch = dalloc<float>((size_t)MAXB * cfg.NV * (cfg.Vd + 4));
+        gdn_ticket = dalloc<int>((size_t)MAXB * cfg.NV);
+        CM_HIP(hipMemsetAsync(gdn_ticket, 0, (size_t)MAXB * cfg.NV * sizeof(int), stream));
         CM_HIP(hipMemsetAsync(conv_pool, 0, conv_slot_elems * seqs.size() * sizeof(float), stream));
         CM_HIP(hipMemsetAsync(state_pool, 0, state_slot_elems * seqs.size() * sizeof(float), stream));
     }
@@ -697,6 +700,7 @@ void Model::enqueue_decode_step(bool advance) {
             ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
             ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
             ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
+            ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
             launch_gdn(ga, s);
             g = GemvArgs{};
             g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K;
@@ -777,6 +781,7 @@ void Model::enqueue_quant_layer(int li) {
         ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
         ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
         ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
+            ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
         launch_gdn(ga, s);
         qg(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attn, nullptr, x, x);
     } else {
@@ -1201,6 +1206,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
+                ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
                 launch_gdn(ga, s);
                 if (quantized) qrp(w.q_out_proj, attnb, (int)at_cols);
                 else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());

@@ -171,6 +171,8 @@ struct Model {
     int gdn_layers = 0, in_proj_rows = 0, in_proj_pad = 0;
     float* conv_pool = nullptr;
     float* state_pool = nullptr;
+    float* gdn_scratch = nullptr;      // decode step: raw y + partial sums of the 4 workgroups of a value head
+    int* gdn_ticket = nullptr;
     size_t conv_slot_elems = 0, state_slot_elems = 0;
     void reset_gdn_state(int slot);
 
