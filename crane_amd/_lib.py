@@ -23,7 +23,7 @@ EXPORTS = [
     "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_tp_ranks", "cm_engine_active", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
-    "cm_decode_batch", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
+    "cm_decode_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
     "cm_gguf_config", "cm_checkpoint_inspect", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv",
 ]
 
@@ -37,6 +37,11 @@ class CmOpts(C.Structure):
         ("prefill_split", C.c_int32), ("isq", C.c_uint32), ("engine", C.c_int32), ("debug_flags", C.c_uint32),
         ("reserved", C.c_uint32 * 5),
     ]
+
+
+class CmPreprocConfig(C.Structure):
+    _fields_ = [("patch_size", C.c_uint32), ("temporal_patch_size", C.c_uint32), ("merge_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("min_pixels", C.c_uint64), ("max_pixels", C.c_uint64), ("image_mean", C.c_float * 3), ("image_std", C.c_float * 3)]
 
 
 class CmGenConfig(C.Structure):
@@ -138,6 +143,9 @@ def load():
     lib.cm_seq_truncate.argtypes = [vp, C.c_int32, C.c_size_t]
     lib.cm_seq_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, u32p]
     lib.cm_decode_batch.argtypes = [vp, P(C.c_int32), u32p, C.c_size_t, f32p, u32p]
+    lib.cm_image_smart_resize.argtypes = [P(CmPreprocConfig), C.c_uint32, C.c_uint32, u32p, u32p]
+    lib.cm_image_preprocess.argtypes = [P(CmPreprocConfig), C.c_char_p, C.c_uint32, C.c_uint32, f32p, C.c_size_t, u32p, P(C.c_size_t)]
+    lib.cm_preprocess_last_error.restype = C.c_char_p
     lib.cm_image_token_id.argtypes = [vp]
     lib.cm_image_token_id.restype = C.c_int64
     lib.cm_vision_encode.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, P(C.c_size_t)]

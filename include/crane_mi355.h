@@ -269,6 +269,30 @@ int cm_vision_encode(cm_model* m, const float* pixel_values, size_t n_patches, c
 int cm_vlm_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, const float* pixel_values,
                    size_t n_patches, const uint32_t* grid_thw, size_t n_images, float* logits_out, uint32_t* greedy_out);
 
+/* ---- image preprocessor (host only; PreprocessorConfig::process, qwen3_5/processor.rs:114-210) ----------------------- */
+
+/* preprocessor_config.json (processor.rs:20-35): size.shortest_edge / longest_edge are the min / max PIXEL counts */
+typedef struct cm_preproc_config {
+    uint32_t patch_size, temporal_patch_size, merge_size, reserved;
+    uint64_t min_pixels;         /* size.shortest_edge */
+    uint64_t max_pixels;         /* size.longest_edge  */
+    float    image_mean[3];
+    float    image_std[3];
+} cm_preproc_config;
+
+/* smart_resize (processor.rs:64-88): both sides to the NEAREST multiple of patch_size * merge_size, then scaled into
+ * [min_pixels, max_pixels] */
+int cm_image_smart_resize(const cm_preproc_config* cfg, uint32_t height, uint32_t width, uint32_t* h_out, uint32_t* w_out);
+
+/* One RGB8 image [height][width][3] -> pixel_values [n_patches, 3 * temporal_patch_size * patch_size^2] f32 exactly as
+ * cm_vision_encode / cm_vlm_forward expect them (rows merge-block-major, a row = (channel, temporal copy, y, x), the
+ * still image duplicated over the temporal patch) + grid_thw = (1, h / patch, w / patch).  Bicubic (Catmull-Rom,
+ * PIL / HF `resample: 3`) resize when smart_resize changes the size.  pixel_values_out == NULL: only *n_patches_out
+ * and grid_thw_out are written.  Errors: cm_preprocess_last_error(). */
+int cm_image_preprocess(const cm_preproc_config* cfg, const uint8_t* rgb, uint32_t height, uint32_t width, float* pixel_values_out,
+                        size_t cap_floats, uint32_t grid_thw_out[3], size_t* n_patches_out);
+const char* cm_preprocess_last_error(void);
+
 /* ---- continuous-batching engine on the paged KV pool ------------------------------
  * Replaces InferenceEngine's scheduling core (crane-serve/src/engine/mod.rs:622-1057 execute_step /
  * step_prefill / step_decode_batch / evict_if_needed) and Scheduler (scheduler.rs:67-98): FIFO, prefill-priority

@@ -1,0 +1,72 @@
+"""Image preprocessor (cm_image_preprocess, host only): the reference's own KATs (qwen3_5/processor.rs:262-329), the numpy
+oracle, and -- for the resampling the reference says it mirrors -- PIL's BICUBIC bit for bit."""
+import numpy as np
+import pytest
+
+from crane_amd import _lib
+from crane_amd.processor import PreprocessorConfig, batch_images
+from oracle import preprocess_oracle as PO
+
+
+def kat_cfg():
+    """processor.rs:266-279: min_pixels tiny so the small synthetic images are not resized"""
+    return PreprocessorConfig(shortest_edge=16, longest_edge=16777216, patch_size=16, temporal_patch_size=2, merge_size=2,
+                              image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+
+
+def test_smart_resize_rounds_to_nearest_not_up():
+    """processor.rs:284-297, verbatim"""
+    pc = PreprocessorConfig(shortest_edge=65536, longest_edge=16777216)
+    assert pc.smart_resize(294, 1024) == (288, 1024)
+    assert pc.smart_resize(300, 1024) == (288, 1024)
+    assert pc.smart_resize(310, 1024) == (320, 1024)
+    assert pc.smart_resize(288, 1024) == (288, 1024)
+    for h, w in [(294, 1024), (37, 5000), (9000, 9000), (10, 10), (448, 448), (1, 70000)]:
+        assert pc.smart_resize(h, w) == PO.smart_resize(h, w, 32, 65536, 16777216), (h, w)
+
+
+def test_patch_layout_is_merge_block_major_and_channel_major():
+    """processor.rs:305-329, verbatim: 4 x 2 patches, the raster patch index encoded in the red channel"""
+    pc = kat_cfg()
+    P, wp, hp = 16, 4, 2
+    img = np.zeros((hp * P, wp * P, 3), np.uint8)
+    for y in range(hp * P):
+        for x in range(wp * P):
+            img[y, x] = ((y // P) * wp + x // P, 7, 9)
+    pix, grid = pc.process(img)
+    assert grid == (1, hp, wp) and pix.shape == (hp * wp, 3 * 2 * P * P)
+    dec = lambda v: int(round((v * 0.5 + 0.5) * 255.0))
+    assert [dec(r[0]) for r in pix] == [0, 1, 4, 5, 2, 3, 6, 7]              # merge-block-major
+    pp = P * P
+    for r in pix:
+        for c, want in ((1, 7), (2, 9)):
+            for t in range(2):
+                assert dec(r[c * 2 * pp + t * pp]) == want                   # (channel, temporal, y, x)
+
+
+@pytest.mark.parametrize("hw", [(448, 448), (300, 500), (97, 1031), (640, 480), (33, 33)])
+def test_matches_oracle_and_pil_resize(hw):
+    rng = np.random.default_rng(hw[0] * 131 + hw[1])
+    img = rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
+    img[: hw[0] // 2] = np.clip(img[: hw[0] // 2].astype(np.int32) // 4 + np.arange(hw[1])[None, :, None] % 200, 0, 255).astype(np.uint8)
+    pc = PreprocessorConfig(shortest_edge=65536, longest_edge=1048576,
+                            image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711])
+    pix, grid = pc.process(img)
+    ref, rgrid = PO.process(img, min_pixels=65536, max_pixels=1048576, mean=pc.image_mean, std=pc.image_std)
+    assert grid == rgrid and pix.shape == ref.shape
+    # the resize is PIL's fixed-point arithmetic restated: identical bytes, so identical floats
+    assert np.array_equal(pix, ref), float(np.abs(pix - ref).max())
+
+
+def test_errors_and_batching():
+    pc = kat_cfg()
+    with pytest.raises(ValueError):
+        pc.process(np.zeros((32, 32), np.uint8))
+    bad = PreprocessorConfig(image_std=[0.5, 0.0, 0.5])
+    with pytest.raises(_lib.CraneError):
+        bad.process(np.zeros((32, 32, 3), np.uint8))
+    a = pc.process(np.zeros((32, 64, 3), np.uint8))
+    b = pc.process(np.full((64, 32, 3), 255, np.uint8))
+    pix, grid = batch_images([a, b])
+    assert pix.shape == (16, 1536) and grid.tolist() == [[1, 2, 4], [1, 4, 2]]
+    assert np.all(pix[:8] == -1.0) and np.all(pix[8:] == 1.0)
