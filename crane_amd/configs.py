@@ -94,6 +94,36 @@ CONFIGS.update({
 })
 
 
+# Qwen3-VL (BASELINE configs[3]): dense Qwen3 text model with 3-axis interleaved MRoPE + the same vision tower plus DeepStack
+# mergers after the listed blocks (reference: crane-core/src/models/qwen3_vl/; HF Qwen3VLConfig)
+_QWEN3VL_TEXT = dict(model_type="qwen3_vl_text", rms_norm_eps=1e-6, attention_bias=False, hidden_act="silu", torch_dtype="bfloat16",
+                     rope_parameters=dict(rope_type="default", rope_theta=5_000_000.0, mrope_section=[24, 20, 20], mrope_interleaved=True))
+
+
+def _vl3(text: dict, vision: dict, image_token_id: int) -> dict:
+    t = dict(_QWEN3VL_TEXT, **text)
+    tie = t.pop("tie_word_embeddings", True)
+    return dict(model_type="qwen3_vl", text_config=t, vision_config=dict(vision, model_type="qwen3_vl"), tie_word_embeddings=tie,
+                image_token_id=image_token_id, video_token_id=image_token_id + 1, vision_start_token_id=image_token_id - 3,
+                vision_end_token_id=image_token_id - 2, torch_dtype="bfloat16")
+
+
+CONFIGS.update({
+    # Qwen3-VL-2B ([external]): text 2048 / 28 layers / 16 q / 8 kv / 128 / 6144 / 151 936 tied;
+    # vision depth 24, hidden 1024, 16 heads, inter 4096, patch 16, merge 2, out 2048, pos-emb 2304, deepstack [5, 11, 17]
+    "qwen3-vl-2b": _vl3(dict(vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=28,
+                             num_attention_heads=16, num_key_value_heads=8, head_dim=128, tie_word_embeddings=True,
+                             max_position_embeddings=262144),
+                        dict(_VISION_COMMON, depth=24, hidden_size=1024, num_heads=16, intermediate_size=4096, out_hidden_size=2048,
+                             num_position_embeddings=2304, deepstack_visual_indexes=[5, 11, 17]), 151655),
+    "tiny-qwen3-vl": _vl3(dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=3,
+                               num_attention_heads=4, num_key_value_heads=2, head_dim=128, tie_word_embeddings=False,
+                               max_position_embeddings=4096),
+                          dict(_VISION_COMMON, depth=3, hidden_size=256, num_heads=4, intermediate_size=512, out_hidden_size=256,
+                               num_position_embeddings=64, deepstack_visual_indexes=[0, 1]), 500),
+})
+
+
 def get_config(name: str) -> dict:
     if name not in CONFIGS:
         raise KeyError(f"unknown config {name!r}; have {sorted(CONFIGS)}")

@@ -142,6 +142,7 @@ void launch_pos_embed_add(float* x, const uint16_t* table, const int32_t* idx, c
 void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, float* kpool,
                         float* vpool, int N, int heads, float scale, hipStream_t s);
 void launch_splice_rows(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s);
+void launch_add_rows_map(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s);
 
 // ---- batched decode (kernels_decode_batch.hip) ----
 struct GemvBArgs {

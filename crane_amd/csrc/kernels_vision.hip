@@ -105,6 +105,21 @@ void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint
                         float* vpool, int N, int heads, float scale, hipStream_t s) {
     hipLaunchKernelGGL(vit_rope_kv_kernel, dim3(N, 3 * heads), dim3(64), 0, s, qkv, cs, sn, q_hi, q_lo, kpool, vpool, heads, scale);
 }
+// DeepStack injection (qwen3_vl/text.rs:280-333): dst[s, :] += src[map[s], :] for the visual positions (map[s] >= 0)
+__global__ __launch_bounds__(256) void add_rows_map_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                           const int32_t* __restrict__ map, int H) {
+    const int r = map[blockIdx.x];
+    if (r < 0) return;
+    float* d = dst + (size_t)blockIdx.x * H;
+    const float* v = src + (size_t)r * H;
+    for (int i = threadIdx.x * 4; i < H; i += 1024) {
+        const f32x4 a = *(const f32x4*)(d + i), b = *(const f32x4*)(v + i);
+        *(f32x4*)(d + i) = (f32x4){a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+    }
+}
+void launch_add_rows_map(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s) {
+    hipLaunchKernelGGL(add_rows_map_kernel, dim3(S), dim3(256), 0, s, dst, src, map, H);
+}
 void launch_splice_rows(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s) {
     hipLaunchKernelGGL(splice_rows_kernel, dim3(S), dim3(256), 0, s, dst, src, map, H);
 }

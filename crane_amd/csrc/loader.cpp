@@ -57,7 +57,7 @@ struct SynthSource : Source {
             else if (ends("pos_embed.weight")) std = 0.5;
             else if (ends("patch_embed.proj.weight")) std = 1.0 / std::sqrt((double)v.patch_dim());
             else if (ends("mlp.linear_fc2.weight")) std = 1.0 / std::sqrt((double)v.inter);
-            else if (ends("merger.linear_fc1.weight") || ends("merger.linear_fc2.weight")) std = 1.0 / std::sqrt((double)MH);
+            else if (name.find("merger") != std::string::npos && (ends("linear_fc1.weight") || ends("linear_fc2.weight"))) std = 1.0 / std::sqrt((double)MH);
             else std = 1.0 / std::sqrt((double)v.hidden);
             return;
         }
@@ -266,6 +266,15 @@ void build(Model& m, Source& src) {
         m.vw.mn_w = fetch_f32(m, src, vp + "merger.norm.weight", VH, 0.f); m.vw.mn_b = fetch_f32(m, src, vp + "merger.norm.bias", VH, 0.f);
         m.vw.mfc1_w = mat(vp + "merger.linear_fc1.weight", MH, MH); m.vw.mfc1_b = fetch_f32(m, src, vp + "merger.linear_fc1.bias", MH, 0.f);
         m.vw.mfc2_w = mat(vp + "merger.linear_fc2.weight", v.out_hidden, MH); m.vw.mfc2_b = fetch_f32(m, src, vp + "merger.linear_fc2.bias", v.out_hidden, 0.f);
+        // DeepStack mergers (qwen3_vl/vision.rs:335-341): PatchMerger with use_postshuffle_norm = true
+        m.vw.deep.resize(v.deepstack.size());
+        for (size_t k = 0; k < v.deepstack.size(); ++k) {
+            VisionW::Merger& d = m.vw.deep[k];
+            const std::string dp = vp + "deepstack_merger_list." + std::to_string(k) + ".";
+            d.n_w = fetch_f32(m, src, dp + "norm.weight", MH, 0.f); d.n_b = fetch_f32(m, src, dp + "norm.bias", MH, 0.f);
+            d.fc1_w = mat(dp + "linear_fc1.weight", MH, MH); d.fc1_b = fetch_f32(m, src, dp + "linear_fc1.bias", MH, 0.f);
+            d.fc2_w = mat(dp + "linear_fc2.weight", v.out_hidden, MH); d.fc2_b = fetch_f32(m, src, dp + "linear_fc2.bias", v.out_hidden, 0.f);
+        }
     }
     CM_HIP(hipStreamSynchronize(m.stream));
 }

@@ -101,6 +101,50 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (cfg.V <= 0 || cfg.H <= 0 || cfg.I <= 0 || cfg.L <= 0 || cfg.Hq <= 0 || cfg.Hkv <= 0 || cfg.max_pos <= 0)
         throw CmError(CM_ERR_IO, "config.json: missing required field");
     cfg.rot_dim = cfg.D;
+    if (const cmjson::Value* vc = j->get("vision_config")) {     // VisionConfig (qwen3_5/config.rs:120-160, qwen3_vl/config.rs:18-44)
+        if (vc->kind == cmjson::Value::Obj && root != j.get()) {
+            vcfg.present = true;
+            vcfg.depth = (int)vc->integer("depth", 0);
+            vcfg.hidden = (int)vc->integer("hidden_size", 0);
+            vcfg.heads = (int)vc->integer("num_heads", 0);
+            vcfg.inter = (int)vc->integer("intermediate_size", 0);
+            vcfg.patch = (int)vc->integer("patch_size", 16);
+            vcfg.tpatch = (int)vc->integer("temporal_patch_size", 2);
+            vcfg.merge = (int)vc->integer("spatial_merge_size", 2);
+            vcfg.in_ch = (int)vc->integer(vc->has("in_channels") ? "in_channels" : "in_chans", 3);
+            vcfg.out_hidden = (int)vc->integer("out_hidden_size", 0);
+            vcfg.num_pos = (int)vc->integer("num_position_embeddings", 0);
+            vcfg.act = vc->string("hidden_act", "gelu_pytorch_tanh") == "gelu_pytorch_tanh" ? 1 : 2;
+            const char* mg = getenv("CM_VISION_MERGER_GELU");
+            vcfg.merger_act = (mg && std::string(mg) == "erf") ? 2 : 1;
+            vcfg.image_token = j->integer("image_token_id", -1);
+            if (const cmjson::Value* ds = vc->get("deepstack_visual_indexes"))
+                for (auto& e : ds->arr) vcfg.deepstack.push_back((int)e->num);
+            for (size_t k = 0; k < vcfg.deepstack.size(); ++k)
+                if (vcfg.deepstack[k] < 0 || vcfg.deepstack[k] >= vcfg.depth || (k && vcfg.deepstack[k] <= vcfg.deepstack[k - 1]))
+                    throw CmError(CM_ERR_IO, "bad deepstack_visual_indexes");
+            if (vcfg.depth <= 0 || vcfg.heads <= 0 || vcfg.hidden % vcfg.heads) throw CmError(CM_ERR_IO, "bad vision_config");
+            if (vcfg.hidden / vcfg.heads != 64) throw CmError(CM_ERR_UNSUPPORTED, "vision head_dim must be 64 (72 not implemented)");
+            const int side = (int)std::lround(std::sqrt((double)vcfg.num_pos));
+            if (side * side != vcfg.num_pos) throw CmError(CM_ERR_IO, "num_position_embeddings is not a perfect square");
+        }
+    }
+    if (cfg.model_type == "qwen3_vl" || cfg.model_type == "qwen3_vl_text") {
+        // Qwen3-VL: the dense Qwen3 decoder (qwen3_vl/text.rs:34-260) + 3-axis interleaved MRoPE over the whole head (HF
+        // Qwen3VLTextRotaryEmbedding; the reference's dead code rotates at a 1-D offset, identical for text-only prompts)
+        cfg.model_type = "qwen3";
+        cfg.tie = root->has("tie_word_embeddings") ? root->boolean("tie_word_embeddings", true) : j->boolean("tie_word_embeddings", true);
+        cfg.theta = root->number("rope_theta", 5e6);
+        cfg.mrope_sec[0] = 24; cfg.mrope_sec[1] = 20; cfg.mrope_sec[2] = 20;
+        for (const char* key : {"rope_parameters", "rope_scaling"})
+            if (const cmjson::Value* rp = root->get(key)) {
+                if (rp->kind != cmjson::Value::Obj) continue;
+                cfg.theta = rp->number("rope_theta", cfg.theta);
+                if (const cmjson::Value* ms = rp->get("mrope_section"))
+                    for (size_t i = 0; i < ms->arr.size() && i < 3; ++i) cfg.mrope_sec[i] = (int)ms->arr[i]->num;
+            }
+        if (cfg.mrope_sec[0] + cfg.mrope_sec[1] + cfg.mrope_sec[2] != cfg.D / 2) throw CmError(CM_ERR_INVALID, "mrope_section must sum to head_dim / 2");
+    }
     if (cfg.model_type == "qwen3_5" || cfg.model_type == "qwen3_5_text") {
         // TextConfig (qwen3_5/config.rs:47-110); tie_word_embeddings defaults to FALSE here (:80-81)
         cfg.hybrid = true;
@@ -126,29 +170,6 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
         if (const cmjson::Value* rp = root->get("rope_parameters"))
             if (const cmjson::Value* ms = rp->get("mrope_section"))
                 for (size_t i = 0; i < ms->arr.size() && i < 3; ++i) cfg.mrope_sec[i] = (int)ms->arr[i]->num;
-        if (const cmjson::Value* vc = j->get("vision_config")) {     // VisionConfig (qwen3_5/config.rs:120-160)
-            if (vc->kind == cmjson::Value::Obj) {
-                vcfg.present = true;
-                vcfg.depth = (int)vc->integer("depth", 0);
-                vcfg.hidden = (int)vc->integer("hidden_size", 0);
-                vcfg.heads = (int)vc->integer("num_heads", 0);
-                vcfg.inter = (int)vc->integer("intermediate_size", 0);
-                vcfg.patch = (int)vc->integer("patch_size", 16);
-                vcfg.tpatch = (int)vc->integer("temporal_patch_size", 2);
-                vcfg.merge = (int)vc->integer("spatial_merge_size", 2);
-                vcfg.in_ch = (int)vc->integer("in_channels", 3);
-                vcfg.out_hidden = (int)vc->integer("out_hidden_size", 0);
-                vcfg.num_pos = (int)vc->integer("num_position_embeddings", 0);
-                vcfg.act = vc->string("hidden_act", "gelu_pytorch_tanh") == "gelu_pytorch_tanh" ? 1 : 2;
-                const char* mg = getenv("CM_VISION_MERGER_GELU");
-                vcfg.merger_act = (mg && std::string(mg) == "erf") ? 2 : 1;
-                vcfg.image_token = j->integer("image_token_id", -1);
-                if (vcfg.depth <= 0 || vcfg.heads <= 0 || vcfg.hidden % vcfg.heads) throw CmError(CM_ERR_IO, "bad vision_config");
-                if (vcfg.hidden / vcfg.heads != 64) throw CmError(CM_ERR_UNSUPPORTED, "vision head_dim must be 64 (72 not implemented)");
-                const int side = (int)std::lround(std::sqrt((double)vcfg.num_pos));
-                if (side * side != vcfg.num_pos) throw CmError(CM_ERR_IO, "num_position_embeddings is not a perfect square");
-            }
-        }
         if (const cmjson::Value* lt = root->get("layer_types")) {   // HF spelling; must agree with the interval rule
             for (size_t i = 0; i < lt->arr.size() && (int)i < cfg.L; ++i) {
                 const bool full = lt->arr[i]->str == "full_attention";
@@ -1016,6 +1037,10 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                 rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
                 launch_add_rows(pX, pY, (size_t)S * H, s);
             }
+            // DeepStack (qwen3_vl/text.rs:262-333): the li-th feature map of the vision tower is added onto the hidden states
+            // of the visual positions after decoder layer li
+            if (li < deep_layers && splice_map_dev != nullptr)
+                launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
         }
         if (off + (size_t)S >= n) {     // last chunk: logits of the LAST position only (modeling.rs:1032-1035)
             CM_HIP(hipMemcpyAsync(x, pX + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -96,6 +96,7 @@ struct VisionCfg {
     int act = 1;          // block MLP: 1 = gelu_pytorch_tanh, 2 = gelu (erf)
     int merger_act = 1;   // PatchMerger `xs.gelu()` (vision.rs:276): tanh form in the reference, erf in HF (CM_VISION_MERGER_GELU=erf)
     long long image_token = -1;
+    std::vector<int> deepstack;   // blocks after which a DeepStack merger taps the hidden states (Qwen3-VL: [5, 11, 17])
     int patch_dim() const { return in_ch * tpatch * patch * patch; }
 };
 struct VisionBlockW {
@@ -108,6 +109,8 @@ struct VisionW {
     std::vector<VisionBlockW> blocks;
     float *mn_w = nullptr, *mn_b = nullptr;
     uint16_t *mfc1_w = nullptr, *mfc2_w = nullptr; float *mfc1_b = nullptr, *mfc2_b = nullptr;
+    struct Merger { float *n_w = nullptr, *n_b = nullptr, *fc1_b = nullptr, *fc2_b = nullptr; uint16_t *fc1_w = nullptr, *fc2_w = nullptr; };
+    std::vector<Merger> deep;     // deepstack_merger_list.k: LayerNorm over the regrouped 4 x hidden row, fc1 + GELU, fc2
 };
 
 struct Rccl;   // dlopen'ed RCCL entry points + communicator (tp.cpp)
@@ -161,6 +164,9 @@ struct Model {
     int32_t *vIdx = nullptr, *vBt = nullptr, *dMap = nullptr, *dPos3 = nullptr;
     const int32_t* pos3_dev = nullptr;   // set only while a VLM prefill runs
     const int32_t* splice_map_dev = nullptr;
+    float* vDeep = nullptr;              // [n_deepstack][v_cap / merge^2 + 1][out_hidden] DeepStack feature maps of the last encode
+    size_t deep_stride = 0;
+    int deep_layers = 0;                 // set only while a VLM prefill runs: decoder layers li < deep_layers get vDeep[li] added
     int pos3_stride = 0;
     void ensure_vision_buffers(int n_patches);
     int vision_encode(const float* pix, size_t n_patches, const uint32_t* grid, size_t n_img);   // -> vFeat, returns rows

@@ -23,6 +23,8 @@ void Model::ensure_vision_buffers(int n_patches) {
     vQKV = dalloc<float>((size_t)cap * 3 * VH);
     vPix = dalloc<float>((size_t)cap * vcfg.patch_dim());
     vFeat = dalloc<float>((size_t)(cap / M + 1) * vcfg.out_hidden);
+    deep_stride = (size_t)(cap / M + 1) * vcfg.out_hidden;
+    if (!vcfg.deepstack.empty()) vDeep = dalloc<float>(deep_stride * vcfg.deepstack.size());
     vCos = dalloc<float>((size_t)cap * 64);
     vSin = dalloc<float>((size_t)cap * 64);
     const size_t pages = (size_t)(cap + 63) / 64;
@@ -129,6 +131,16 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
         launch_layernorm_rows(vX, b.n2w, b.n2b, vA_hi, vA_lo, N, VH, 1e-6f, s);
         gemm(vA_hi, vA_lo, b.fc1_w, b.fc1_b, N, vcfg.inter, VH, GEPI_ACT_SPLIT, nullptr, vB_hi, vB_lo, vcfg.act);
         gemm(vB_hi, vB_lo, b.fc2_w, b.fc2_b, N, VH, vcfg.inter, GEPI_RESADD, vX, nullptr, nullptr, 0);
+        // DeepStack tap (qwen3_vl/vision.rs:572-579): PatchMerger with the LayerNorm over the regrouped 4 x hidden row
+        // (use_postshuffle_norm, :236-276; the regrouping is free in merge-block-major order)
+        for (size_t k = 0; k < vcfg.deepstack.size(); ++k) {
+            if (vcfg.deepstack[k] != li) continue;
+            const VisionW::Merger& d = vw.deep[k];
+            const int Gd = N / M, MH = VH * M;
+            launch_layernorm_rows(vX, d.n_w, d.n_b, vA_hi, vA_lo, Gd, MH, 1e-6f, s);
+            gemm(vA_hi, vA_lo, d.fc1_w, d.fc1_b, Gd, MH, MH, GEPI_ACT_SPLIT, nullptr, vB_hi, vB_lo, vcfg.merger_act);
+            gemm(vB_hi, vB_lo, d.fc2_w, d.fc2_b, Gd, vcfg.out_hidden, MH, GEPI_STORE, vDeep + k * deep_stride, nullptr, nullptr, 0);
+        }
     }
     // PatchMerger (vision.rs:254-278): LayerNorm over hidden, rows regrouped 4 -> 1 (free: block-major order)
     launch_layernorm_rows(vX, vw.mn_w, vw.mn_b, vA_hi, vA_lo, N, VH, 1e-6f, s);
@@ -185,13 +197,15 @@ void Model::vlm_forward(int sidx, const uint32_t* ids, size_t n, size_t start_po
     ensure_pages(sidx, (int64_t)(start_pos + n));
     activate(sidx);
     splice_map_dev = dMap; pos3_dev = dPos3; pos3_stride = (int)n;
+    deep_layers = n_img > 0 ? (int)vcfg.deepstack.size() : 0;     // DeepStack injection after the first decoder layers (qwen3_vl/text.rs:262-278)
+    if (deep_layers > cfg.L) throw CmError(CM_ERR_INVALID, "more DeepStack feature maps than decoder layers");
     try {
         prefill(ids, n, start_pos);
     } catch (...) {
-        splice_map_dev = nullptr; pos3_dev = nullptr;
+        splice_map_dev = nullptr; pos3_dev = nullptr; deep_layers = 0;
         throw;
     }
-    splice_map_dev = nullptr; pos3_dev = nullptr;
+    splice_map_dev = nullptr; pos3_dev = nullptr; deep_layers = 0;
     q.len = (int64_t)(start_pos + n);
     q.rope_delta = nxt - (int32_t)q.len;
     if (greedy_out) {

@@ -184,8 +184,9 @@ def qwen3_5_vl_specs(cfg: dict) -> List[Spec]:
     vision tower under `model.visual.` (qwen3_5/vlm.rs:125; shapes: tests/test_qwen35_family_shapes.py:104-131)."""
     t, v = cfg["text_config"], cfg["vision_config"]
     text = dict(t, tie_word_embeddings=cfg.get("tie_word_embeddings", t.get("tie_word_embeddings", False)))
+    dense = str(t.get("model_type", "")).startswith("qwen3_vl")          # Qwen3-VL: the dense Qwen3 decoder as language model
     sp = [((n.replace("model.", "model.language_model.", 1) if n.startswith("model.") else n), s, sd, o)
-          for n, s, sd, o in qwen3_5_specs(text)]
+          for n, s, sd, o in (qwen3_specs(text) if dense else qwen3_5_specs(text))]
     VH, VI, P, T, C = v["hidden_size"], v["intermediate_size"], v["patch_size"], v["temporal_patch_size"], v.get("in_channels", 3)
     M = v.get("spatial_merge_size", 2) ** 2
     p = "model.visual."
@@ -205,6 +206,12 @@ def qwen3_5_vl_specs(cfg: dict) -> List[Spec]:
            (m + "linear_fc1.weight", (VH * M, VH * M), 1 / math.sqrt(VH * M), 0.0), (m + "linear_fc1.bias", (VH * M,), 0.1, 0.0),
            (m + "linear_fc2.weight", (v["out_hidden_size"], VH * M), 1 / math.sqrt(VH * M), 0.0),
            (m + "linear_fc2.bias", (v["out_hidden_size"],), 0.1, 0.0)]
+    for k in range(len(v.get("deepstack_visual_indexes", []))):          # DeepStack mergers: LayerNorm over the regrouped 4 x hidden row
+        m = f"{p}deepstack_merger_list.{k}."
+        sp += [(m + "norm.weight", (VH * M,), 0.1, 1.0), (m + "norm.bias", (VH * M,), 0.1, 0.0),
+               (m + "linear_fc1.weight", (VH * M, VH * M), 1 / math.sqrt(VH * M), 0.0), (m + "linear_fc1.bias", (VH * M,), 0.1, 0.0),
+               (m + "linear_fc2.weight", (v["out_hidden_size"], VH * M), 1 / math.sqrt(VH * M), 0.0),
+               (m + "linear_fc2.bias", (v["out_hidden_size"],), 0.1, 0.0)]
     return sp
 
 

@@ -104,8 +104,9 @@ class VisionOracle:
                 rows += [r for r, _ in base]; cols += [c for _, c in base]
         return np.concatenate([table[np.array(rows)], table[np.array(cols)]], axis=-1)      # [N, hd/2]
 
-    def forward(self, pixel_values: np.ndarray, grid: Sequence[Sequence[int]]) -> np.ndarray:
-        """pixel_values [N_patches, C*T*P*P] -> merged image tokens [N/merge^2, out_hidden] (vision.rs:558-584)."""
+    def forward(self, pixel_values: np.ndarray, grid: Sequence[Sequence[int]], block_hook=None) -> np.ndarray:
+        """pixel_values [N_patches, C*T*P*P] -> merged image tokens [N/merge^2, out_hidden] (vision.rs:558-584).
+        `block_hook(li, x)` sees the hidden states after block li (the DeepStack taps, vision.rs:572-579)."""
         w, p = self.w, self.p
         pw = w[p + "patch_embed.proj.weight"].reshape(self.hidden, -1)
         x = (pixel_values.astype(F32) @ pw.T + w[p + "patch_embed.proj.bias"]).astype(F32)
@@ -138,6 +139,8 @@ class VisionOracle:
             xn = layer_norm(x, w[b + "norm2.weight"], w[b + "norm2.bias"])
             hmid = act((xn @ w[b + "mlp.linear_fc1.weight"].T + w[b + "mlp.linear_fc1.bias"]).astype(F32))
             x = x + (hmid @ w[b + "mlp.linear_fc2.weight"].T + w[b + "mlp.linear_fc2.bias"]).astype(F32)
+            if block_hook is not None:
+                block_hook(li, x)
         mp = p + "merger."
         xn = layer_norm(x, w[mp + "norm.weight"], w[mp + "norm.bias"]).reshape(-1, self.hidden * self.merge ** 2)
         hmid = self.merger_act((xn @ w[mp + "linear_fc1.weight"].T + w[mp + "linear_fc1.bias"]).astype(F32))

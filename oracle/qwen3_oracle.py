@@ -224,6 +224,8 @@ class Qwen3Oracle:
             q = rms_norm(q, lw["q_norm"], cfg.rms_norm_eps)
             k = rms_norm(k, lw["k_norm"], cfg.rms_norm_eps)
         cos, sin = self.cos[start_pos:start_pos + S], self.sin[start_pos:start_pos + S]
+        if self._rope_override is not None:                             # multimodal rotary rows (oracle/qwen3_vl_oracle.py)
+            cos, sin = self._rope_override
         q = rope_thd(q, cos, sin)                                       # :358-359
         k = rope_thd(k, cos, sin)
         K, V = self._append_kv(li, k.transpose(1, 0, 2), v.transpose(1, 0, 2), start_pos)  # :362-366
@@ -250,13 +252,20 @@ class Qwen3Oracle:
         return self._mm(_act(h, self.act_dtype), li, "down").astype(F32)
 
     # -- Qwen3Model::forward/decode (modeling.rs:942-953, 984-1036) ----------
-    def forward_hidden(self, input_ids: Sequence[int], start_pos: int) -> np.ndarray:
+    _rope_override = None       # (cos, sin) rows [S, D/2] replacing the table slice (multimodal rotary positions)
+
+    def forward_hidden(self, input_ids: Sequence[int], start_pos: int, embeds: Optional[np.ndarray] = None,
+                       after_layer=None) -> np.ndarray:
+        """`embeds` [S, H] replaces the embedding rows (image features spliced in); `after_layer(li, h)` runs after each
+        decoder layer (DeepStack injection) -- both only used by the vision-language oracle."""
         cfg = self.cfg
         ids = np.asarray(input_ids, dtype=np.int64)
-        h = self.embed[ids].astype(F32)
+        h = self.embed[ids].astype(F32) if embeds is None else np.asarray(embeds, dtype=F32)
         for li, lw in enumerate(self.layers):                           # DecoderLayer::forward :698-716
             h = h + self._attention(li, rms_norm(h, lw["ln1"], cfg.rms_norm_eps), start_pos)
             h = h + self._mlp(li, rms_norm(h, lw["ln2"], cfg.rms_norm_eps))
+            if after_layer is not None:
+                h = after_layer(li, h)
         self.cache_len = start_pos + len(ids)
         return h
 

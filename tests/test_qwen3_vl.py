@@ -1,0 +1,87 @@
+"""Qwen3-VL (BASELINE configs[3]): vision tower with DeepStack mergers + dense Qwen3 decoder with 3-axis MRoPE.
+CPU: the oracle (oracle/qwen3_vl_oracle.py) against the HF golden (tests/golden/make_golden_qwen3_vl.py).
+GPU: the HIP path through the C ABI against the oracle (reference GELU form) and the HF golden (erf form)."""
+import os
+
+import numpy as np
+import pytest
+
+from crane_amd import configs, synth
+from oracle.qwen3_vl_oracle import Qwen3VLOracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen3_vl_tiny.npz")
+
+
+def rel(a, ref):
+    return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+
+def _setup():
+    g = np.load(GOLD)
+    cfg = configs.get_config("tiny-qwen3-vl")
+    return g, cfg, synth.synth_weights_f32(cfg, int(g["seed"][0]))
+
+
+def _oracle_run(cfg, w, ids, pix, grid, gelu, n_new):
+    o = Qwen3VLOracle(cfg, w, merger_gelu=gelu)
+    feat, deep, logits = o.prefill(ids, pix, grid)
+    toks, lg = [], logits
+    for _ in range(n_new):
+        t = int(np.argmax(lg)); toks.append(t)
+        lg = o.decode(t)
+    return feat, deep, logits, toks
+
+
+def test_oracle_matches_hf_golden():
+    g, cfg, w = _setup()
+    ids = g["input_ids"].tolist()
+    feat, deep, logits, toks = _oracle_run(cfg, w, ids, g["pixel_values"], g["grid_thw"].tolist(), "erf", 6)
+    assert rel(feat, g["features"]) < 2e-5
+    assert len(deep) == g["deepstack"].shape[0] == 2
+    for k in range(2):
+        assert rel(deep[k], g["deepstack"][k]) < 2e-5, k
+    assert rel(logits, g["prefill_logits"]) < 5e-5
+    assert toks == g["greedy_tokens"].tolist()[len(ids):]
+
+
+def test_text_only_prompt_equals_dense_qwen3():
+    """without images T = H = W: the MRoPE rows are the plain RoPE rows and nothing is injected"""
+    from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+    g, cfg, w = _setup()
+    o = Qwen3VLOracle(cfg, w)
+    ids = configs.synthetic_prompt(9, 400)
+    _, _, a = o.prefill(ids, np.zeros((0, 1536), np.float32), [])
+    t = dict(cfg["text_config"], model_type="qwen3", tie_word_embeddings=cfg["tie_word_embeddings"], rope_theta=5e6)
+    text_w = {k.replace("model.language_model.", "model."): v for k, v in w.items() if not k.startswith("model.visual.")}
+    b = Qwen3Oracle(Qwen3Config.from_json(t), text_w).forward(ids, 0)
+    assert rel(a, b) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gelu", ["tanh", "erf"])
+def test_hip_qwen3_vl(gelu):
+    from crane_amd.backend import Model
+    g, cfg, w = _setup()
+    ids, pix, grid = g["input_ids"].tolist(), g["pixel_values"], g["grid_thw"].tolist()
+    if gelu == "erf":
+        os.environ["CM_VISION_MERGER_GELU"] = "erf"
+    try:
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
+    finally:
+        os.environ.pop("CM_VISION_MERGER_GELU", None)
+    try:
+        assert m.image_token_id() == cfg["image_token_id"]
+        feat_ref, deep_ref, logits_ref, toks_ref = _oracle_run(cfg, w, ids, pix, grid, gelu, 6)
+        feat = m.encode_images(pix, grid)
+        assert feat.shape == feat_ref.shape and rel(feat, feat_ref) < 1e-4
+        logits, nxt = m.vlm_forward(ids, pix, grid)
+        assert rel(logits, logits_ref) < 1e-4 and nxt == toks_ref[0]
+        toks, pos = [nxt], len(ids)
+        for _ in range(5):                                  # decode continues with the MRoPE counter
+            toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+        assert toks == toks_ref
+        if gelu == "erf":                                   # independent implementation (HF)
+            assert rel(feat, g["features"]) < 1e-4 and rel(logits, g["prefill_logits"]) < 1e-4
+            assert toks == g["greedy_tokens"].tolist()[len(ids):]
+    finally:
+        m.close()
