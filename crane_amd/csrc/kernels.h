@@ -187,6 +187,7 @@ void launch_bf16_to_f32(const uint16_t* src, float* dst, size_t n, float add, hi
 enum { ENG_STORE = 0, ENG_RESADD = 1, ENG_SILUMUL = 2 };
 constexpr int ENG_NCW = 4;                 // comm waves per workgroup
 constexpr int ENG_TRACE_PH = 8;            // phases the debug instantiation records
+constexpr int ENG_TRACE_EV = 8;            // event slots per (wave, phase)
 // granule buffers: one per kind of vector handed between workgroups inside a launch
 enum { ENG_E_X0 = 0,      // [H]   residual after down_proj  -> input of the next layer's QKV
        ENG_E_QKV = 1,     // [qkv rows] merged q | k | v of the token -> attention
@@ -224,7 +225,7 @@ struct EngArgs {
     float* vout;                  // plain_last: output vector of phase p1 - 1 (read by a later kernel)
     float* xres;                  // [H] residual stream (read at entry, written back at exit)
     uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)
-    unsigned long long* trace;    // debug instantiation only: [grid][waves][ENG_TRACE_PH][4] 100 MHz timestamps
+    unsigned long long* trace;    // debug instantiation only: [grid][waves][ENG_TRACE_PH][ENG_TRACE_EV] 100 MHz timestamps
     const StepState* st;          // attention: position of the token
     const int32_t* block_table;
     const float* cos;             // [max_pos, D/2]

@@ -106,7 +106,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     auto stamp = [&](int ph, int k, u64 val = ~0ull) __attribute__((always_inline)) {
         if constexpr (TRACE) {
             if (lane == 0 && ph < ENG_TRACE_PH)
-                a.trace[(((size_t)blockIdx.x * (NSW + NCW) + wave) * ENG_TRACE_PH + ph) * 4 + k] = val == ~0ull ? __builtin_amdgcn_s_memrealtime() : val;
+                a.trace[(((size_t)blockIdx.x * (NSW + NCW) + wave) * ENG_TRACE_PH + ph) * ENG_TRACE_EV + k] = val == ~0ull ? __builtin_amdgcn_s_memrealtime() : val;
         }
     };
     if (__builtin_nontemporal_load(&a.ctl[1]) != 0u) return;       // an earlier launch timed out: do nothing
@@ -147,6 +147,44 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             asm volatile("" ::: "memory");
         };
 
+        // ---- attention: everything that depends only on the token (one token per launch) is fetched ONCE, ahead of the
+        // first layer: position, RoPE row, the page-table entries of this workgroup's token chunks.  Between "QKV of the
+        // layer has arrived" and "partials published" a comm wave then issues no global load at all -- such a load would
+        // queue behind this CU's own weight-prefetch burst (~3-5 us) on the critical path of every layer.
+        constexpr int NPRE = 4;                           // K/V chunks requested ahead per layer (contexts <= NPRE * nsplit * ACT)
+        int a_pos = 0, a_L = 1;
+        float a_cos = 0.f, a_sin = 0.f;
+        size_t a_koff[NPRE], a_eoff = 0;
+        int a_tt[NPRE];
+        bool a_owner = false;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) { a_koff[u] = 0; a_tt[u] = 0; }
+        if (a.attn != nullptr) {
+            const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = gridDim.x / Hkv;
+            const int tok_in_chunk = cw * 4 + (lane >> 4), dimbase = (lane & 15) * 8;
+            const CM_GLOBAL int32_t* bt = (const CM_GLOBAL int32_t*)a.block_table;
+            a_pos = ((const CM_GLOBAL StepState*)a.st)->pos;
+            const int rpos = a_pos + ((const CM_GLOBAL StepState*)a.st)->rsv[0];
+            a_L = a_pos + 1;
+            a_cos = ((gf_cptr)a.cos)[(size_t)rpos * (AD >> 1) + lane];
+            a_sin = ((gf_cptr)a.sin)[(size_t)rpos * (AD >> 1) + lane];
+            a_owner = ((a_pos / ACT) % nsplit) == split;
+            int bte[NPRE];
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) {
+                // a chunk past the context reads chunk 0's rows again (cache hits, never consumed)
+                const bool cv = ACT * (split + nsplit * u) < a_L;
+                a_tt[u] = ACT * (split + nsplit * (cv ? u : 0)) + tok_in_chunk;
+                int pi = a_tt[u] / a.page;
+                pi = pi < a.max_pages ? pi : a.max_pages - 1;         // speculative loads stay inside the table
+                bte[u] = bt[pi];
+            }
+            const int bto = bt[a_pos / a.page];
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) a_koff[u] = ((size_t)(bte[u] * Hkv + kvh) * a.page + (a_tt[u] % a.page)) * AD + dimbase;
+            a_eoff = ((size_t)(bto * Hkv + kvh) * a.page + (a_pos % a.page)) * AD;
+        }
+
         for (int p = p0; p < p1; ++p) {
             ph_ptr P = (ph_ptr)a.prog + p;
             const int K = P->K, xbuf = P->xbuf, nbt_p = P->gpw * P->nb;
@@ -176,28 +214,33 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     pi = pi < a.max_pages ? pi : a.max_pages - 1;     // speculative loads stay inside the table
                     return ((size_t)(bt[pi] * Hkv + kvh) * a.page + (t % a.page)) * AD + dimbase;
                 };
-                // K/V rows of this block's first two chunks: requested before anything else (independent of this layer's QKV)
-                u32x4 kq[2], vq[2];
-                int tt[2];
+                // K/V rows of this block's first NPRE chunks and the QK-norm weights: requested before anything else
+                // (independent of this layer's QKV)
+                u32x4 kq[NPRE], vq[NPRE];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    tt[u] = ACT * (split + nsplit * u) + tok_in_chunk;
-                    const size_t off = kv_off(tt[u]);
-                    kq[u] = *(gw_ptr)(kp + off);
-                    vq[u] = *(gw_ptr)(vp + off);
+                for (int u = 0; u < NPRE; ++u) {
+                    kq[u] = *(gw_ptr)(kp + a_koff[u]);
+                    vq[u] = *(gw_ptr)(vp + a_koff[u]);
                 }
-                const int pos = ((const CM_GLOBAL StepState*)a.st)->pos;
-                const int rpos = pos + ((const CM_GLOBAL StepState*)a.st)->rsv[0];
-                const int L = pos + 1;
-                const bool owner = ((pos / ACT) % nsplit) == split;
-                const int hrot = AD >> 1;
+                constexpr int NIT = (NREP + 2 + NCW - 1) / NCW;
+                float nwv[NIT][2];
+#pragma unroll
+                for (int ii = 0; ii < NIT; ++ii) {
+                    const int item = cw + ii * NCW;
+                    gf_cptr nw = item < NREP ? (gf_cptr)AL->qnw : (gf_cptr)AL->knw;
+                    const bool has = item <= NREP && nw != nullptr;
+                    if (!has) nw = (gf_cptr)a.cos;                    // any readable address: the loads stay unconditional
+                    nwv[ii][0] = nw[lane]; nwv[ii][1] = nw[lane + 64];
+                    if (!has) { nwv[ii][0] = 0.f; nwv[ii][1] = 0.f; }
+                }
+                const int pos = a_pos, L = a_L;
+                const bool owner = a_owner;
                 // this workgroup's own stream waves must be through the QKV phase before its comm waves poll the result
                 own_progress(prog_before + (uint32_t)(NSW * prev_nbt) - (uint32_t)(NSW / 2), 0x600u + (uint32_t)(p - p0));   // (nearly: the polls are tiny)
                 stamp(p - p0, 1);
                 const u64* GQ = a.gran[ENG_E_QKV];
                 // q heads of the group, new k, new v: wave w takes items w and w + NCW; ALL their granules are requested in one
                 // round trip per poll
-                constexpr int NIT = (NREP + 2 + NCW - 1) / NCW;
                 int g0[NIT];
 #pragma unroll
                 for (int ii = 0; ii < NIT; ++ii) {
@@ -226,19 +269,18 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 for (int ii = 0; ii < NIT; ++ii) {
                     const int item = cw + ii * NCW;
                     if (item >= NREP + 2) continue;
-                    gf_cptr nw = item < NREP ? (gf_cptr)AL->qnw : (item == NREP ? (gf_cptr)AL->knw : nullptr);
+                    const bool normed = (item < NREP ? AL->qnw : AL->knw) != nullptr;
                     float xv[2] = {xin2[ii][0], xin2[ii][1]};
                     if (item <= NREP) {
-                        if (nw != nullptr) {
+                        if (normed) {
                             const float ss = wave_sum(xv[0] * xv[0] + xv[1] * xv[1]);
                             const float rr = 1.0f / sqrtf(ss / (float)AD + a.eps);
-                            xv[0] = xv[0] * rr * nw[lane]; xv[1] = xv[1] * rr * nw[lane + 64];
+                            xv[0] = xv[0] * rr * nwv[ii][0]; xv[1] = xv[1] * rr * nwv[ii][1];
                         }
                         // rotate-half RoPE over the whole head: the partner of d is d +/- D/2 = the other element of this lane
-                        const float c = ((gf_cptr)a.cos)[(size_t)rpos * hrot + lane], sn = ((gf_cptr)a.sin)[(size_t)rpos * hrot + lane];
                         const float lo = xv[0], hi = xv[1];
-                        xv[0] = lo * c - hi * sn;
-                        xv[1] = lo * sn + hi * c;
+                        xv[0] = lo * a_cos - hi * a_sin;
+                        xv[1] = lo * a_sin + hi * a_cos;
                     }
                     if (item < NREP) {
                         qs[item * AD + lane] = xv[0] * a.scale;
@@ -246,7 +288,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     } else {
                         float* dst = item == NREP ? knew : vnew;
                         CM_GLOBAL uint16_t* pool = (CM_GLOBAL uint16_t*)(item == NREP ? AL->kpool : AL->vpool);
-                        const size_t eoff = owner ? ((size_t)(bt[pos / a.page] * Hkv + kvh) * a.page + (pos % a.page)) * AD : 0;
+                        const size_t eoff = owner ? a_eoff : 0;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const uint16_t b16 = f32_to_bf16(xv[j]);
@@ -300,10 +342,13 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         }
                     }
                 };
-                consume(kq[0], vq[0], tt[0]);
-                consume(kq[1], vq[1], tt[1]);
-                for (int j = 2; ACT * (split + nsplit * j) < L; j += 2) {       // longer contexts: two chunks per iteration
+                stamp(p - p0, 4);
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u)
+                    if (ACT * (split + nsplit * u) < L) consume(kq[u], vq[u], a_tt[u]);
+                for (int j = NPRE; ACT * (split + nsplit * j) < L; j += 2) {    // longer contexts: two more chunks per iteration
                     const bool second = ACT * (split + nsplit * (j + 1)) < L;
+                    int tt[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         tt[u] = ACT * (split + nsplit * (j + u)) + tok_in_chunk;
@@ -314,6 +359,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     consume(kq[0], vq[0], tt[0]);
                     if (second) consume(kq[1], vq[1], tt[1]);
                 }
+                stamp(p - p0, 5);
                 // ---- combine the ACT (wave, row) streams of this workgroup -> partial (m, l, o) per head -> granules ----
                 const int slot = cw * 4 + r;
 #pragma unroll
@@ -367,18 +413,30 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     if (act) { mo[s_src * 18 + 2 * e] = v0; mo[s_src * 18 + 2 * e + 1] = v1; }
                     if (act_ml) mo[s_src * 18 + 16 + e] = v2;
                 }
+                stamp(p - p0, 6);
                 cbar();
-                if (cw == 0 && lane < OPB) {
+                if (cw == 0) {
+                    // one wave, all 64 lanes: lane = (output d, group of 8 source splits); every LDS read is independent
+                    // of the others (a serial walk over 32 splits cost ~5 us of dependent LDS round trips)
+                    const int d = lane & 15, sg = lane >> 4;
                     float M = -INFINITY;
-                    for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, mo[s2 * 18 + 16]);
-                    float O = 0.f, Ls = 0.f;
-                    for (int s2 = 0; s2 < nsplit; ++s2) {
-                        const float mm = mo[s2 * 18 + 16];
-                        const float w = (mm > -INFINITY) ? expf(mm - M) : 0.f;
-                        O += w * mo[s2 * 18 + lane];
-                        Ls += w * mo[s2 * 18 + 17];
+#pragma unroll
+                    for (int s2 = 0; s2 < 32; ++s2) {
+                        const float mv = mo[(s2 < nsplit ? s2 : 0) * 18 + 16];
+                        M = fmaxf(M, mv);
                     }
-                    gran_st(a.gran[ENG_E_ATTN] + (size_t)(kvh * NREP + hm) * AD + d0 + lane, tag, O * (1.0f / Ls));
+                    float O = 0.f, Ls = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int s2 = sg * 8 + i, sc = s2 < nsplit ? s2 : 0;
+                        const float mm = mo[sc * 18 + 16];
+                        const float w = (s2 < nsplit && mm > -INFINITY) ? expf(mm - M) : 0.f;
+                        O += w * mo[sc * 18 + d];
+                        Ls += w * mo[sc * 18 + 17];
+                    }
+                    O += __shfl_xor(O, 16); Ls += __shfl_xor(Ls, 16);
+                    O += __shfl_xor(O, 32); Ls += __shfl_xor(Ls, 32);
+                    if (lane < OPB) gran_st(a.gran[ENG_E_ATTN] + (size_t)(kvh * NREP + hm) * AD + d0 + lane, tag, O * (1.0f / Ls));
                 }
                 stamp(p - p0, 2);          // (`mo`, qs, red_* are next written a whole layer later)
             } else {

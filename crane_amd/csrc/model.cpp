@@ -475,12 +475,12 @@ EngArgs Model::engine_args_full() const {
 }
 
 // cm_debug_read("engine_trace"): a few warm launches, then ONE launch of the instrumented instantiation;
-// out[((block * waves + wave) * ENG_TRACE_PH + phase) * 4 + event] = microseconds since the earliest stamp (0 = not recorded;
+// out[((block * waves + wave) * ENG_TRACE_PH + phase) * ENG_TRACE_EV + event] = microseconds since the earliest stamp (0 = not recorded;
 // event 3 of a comm wave = number of granule sweeps that found stale tags)
 void Model::engine_trace(float* out, size_t n) {
     if (!engine_on) throw CmError(CM_ERR_INVALID, "the persistent decode kernel is not active on this model");
     const EngCfg ec = engine_config();
-    const size_t waves = (size_t)(ec.nsw + ec.ncw), total = (size_t)num_cu * waves * ENG_TRACE_PH * 4;
+    const size_t waves = (size_t)(ec.nsw + ec.ncw), total = (size_t)num_cu * waves * ENG_TRACE_PH * ENG_TRACE_EV;
     if (n != total) throw CmError(CM_ERR_RANGE, "engine_trace: expected " + std::to_string(total) + " values");
     unsigned long long* d = nullptr;
     CM_HIP(hipMalloc((void**)&d, total * 8));
@@ -494,7 +494,7 @@ void Model::engine_trace(float* out, size_t n) {
     CM_HIP(hipStreamSynchronize(stream));
     CM_HIP(hipMemcpy(h.data(), d, total * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d);
-    auto is_count = [&](size_t i) { return (i & 3) == 3 && ((i / (4 * ENG_TRACE_PH)) % waves) >= (size_t)ec.nsw; };
+    auto is_count = [&](size_t i) { return (i % ENG_TRACE_EV) == 3 && ((i / (ENG_TRACE_EV * ENG_TRACE_PH)) % waves) >= (size_t)ec.nsw; };
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < total; ++i)
         if (!is_count(i) && h[i] != 0 && h[i] < t0) t0 = h[i];

@@ -18,10 +18,10 @@ if len(sys.argv) > 2:
 m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, engine=1)
 m.debug_fill_kv(1024, seed=1)
 m.bench_decode(3, 8)
-NSW = int(os.environ.get('CM_ENG_CFG', '8,2').split(',')[0])
-NB, NW, MAXPH = 256, NSW + 4, 8
+NSW = int(os.environ.get('CM_ENG_CFG', '4,4').split(',')[0])
+NB, NW, MAXPH, NEV = 256, NSW + 4, 8, 8
 for rep in range(2):
-    t = m.debug_read("engine_trace", NB * NW * MAXPH * 4).reshape(NB, NW, MAXPH, 4)
+    t = m.debug_read("engine_trace", NB * NW * MAXPH * NEV).reshape(NB, NW, MAXPH, NEV)
     print(f"--- traced launch {rep} (CM_ENG_CFG={os.environ.get('CM_ENG_CFG', 'default')}) ---")
     ent = t[:, :NSW, 0, 3]
     print(f"kernel entry (stream waves): min {ent.min():.2f} med {np.median(ent):.2f} max {ent.max():.2f}")
@@ -34,5 +34,7 @@ for rep in range(2):
         s, c = t[:, :NSW, p, :], t[:, NSW:, p, :]
         print(f"phase {p} {names[p]:9s} stream: arrive[{st(s[..., 0])}] go[{st(s[..., 1])}] done[{st(s[..., 2])}]")
         print(f"                  comm  : begin [{st(c[..., 0])}] poll[{st(c[..., 1])}] attn[{st(c[..., 2])}] stale sweeps avg {c[..., 3].mean():.1f} max {c[..., 3].max():.0f}")
+        if (c[..., 4] > 0).any():
+            print(f"                  attn  : qkv+rope[{st(c[..., 4])}] scores[{st(c[..., 5])}] gathered[{st(c[..., 6])}]")
     print(f"end of launch: {t[..., :3].max():.2f} us")
 m.close()
