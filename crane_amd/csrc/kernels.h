@@ -235,6 +235,8 @@ struct EngArgs {
     int H, gpw_res, xf_total;     // hidden size; row groups per wave of the residual phases; LDS floats of the input buffers
     int Hkv, page, max_pages, q_off, k_off, v_off;
     float eps, scale;
+    int tune;                     // polling parameters (CM_ENG_TUNE while tuning), see kernels_engine.hip
+    int dbg;                      // timing experiments (CM_ENG_DBG), see kernels_engine.hip; 0 in production
 };
 struct EngCfg { int nsw, ncw, pf; };
 EngCfg engine_config();           // the instantiation the launcher uses (default, or CM_ENG_CFG while tuning)

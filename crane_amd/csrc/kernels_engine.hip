@@ -115,11 +115,20 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     __syncthreads();
 
     const int p0 = a.p0, p1 = a.p1;
+    // timing experiments only (CM_ENG_DBG; results are garbage): 1 = never wait for an input, 2 = weight loads hit one cache
+    // line (no HBM traffic), 64 = no comm waves, 128 = comm waves skip the staging sweeps, 256 = ... skip the attention
+    const bool dbg_nowait = (a.dbg & 1) != 0, dbg_noload = (a.dbg & 2) != 0, dbg_nocomm = (a.dbg & 64) != 0,
+               dbg_nostage = (a.dbg & 128) != 0, dbg_noattn = (a.dbg & 256) != 0;
+    // tuning word (CM_ENG_TUNE): bit 0 = attention-output staging sweeps without a probe; bits 4-7 = margin (batches of the
+    // CU's own stream) before an input is probed; bits 8-12 = s_sleep between probes of a gated input
+    const bool t_noprobe_attn = (a.tune & 1) != 0;
+    const int t_margin = (a.tune >> 4) & 15, t_psleep = (a.tune >> 8) & 31;
     auto fail = [&](uint32_t code) __attribute__((always_inline)) {
         if (lane == 0) { atomicExch(&a.ctl[1], code); ctrl[C_ABORT] = 1u; }
     };
 
     if (wave >= NSW) {
+        if (dbg_nocomm) return;
         // =====================================================================================================
         // COMM waves: stage the input vector of every phase into LDS (chunk by chunk); run the attention
         // =====================================================================================================
@@ -130,7 +139,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         int prev_nbt = 0;                                 // batches per stream wave of the previous phase
         auto own_progress = [&](uint32_t want, uint32_t code) __attribute__((always_inline)) {
             uint32_t spins = 0;
-            while (lds_ld(&ctrl[C_PROG]) < want && lds_ld(&ctrl[C_ABORT]) == 0u) {
+            while (!dbg_nowait && lds_ld(&ctrl[C_PROG]) < want && lds_ld(&ctrl[C_ABORT]) == 0u) {
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > SPIN_LDS) { fail(code); break; }
             }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 continue;
             }
             stamp(p - p0, 0);
-            if (P->pre_attn) {
+            if (P->pre_attn && !dbg_noattn) {
                 // ================= attention of this layer (split `blockIdx / Hkv` of kv head `blockIdx % Hkv`) =================
                 const CM_CONST EngAttnL* AL = (const CM_CONST EngAttnL*)a.attn + P->layer;
                 const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = gridDim.x / Hkv;
@@ -259,7 +268,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                             xin2[ii][0] = __uint_as_float((uint32_t)x0); xin2[ii][1] = __uint_as_float((uint32_t)x1);
                             ok = ok && (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag;
                         }
-                        if (__all(ok)) break;
+                        if (__all(ok) || dbg_nowait) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
                         if (++spins > SPIN_GLOBAL) { fail(0x700u + (uint32_t)(p - p0)); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -405,7 +414,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         v0 = __uint_as_float((uint32_t)x0); v1 = __uint_as_float((uint32_t)x1); v2 = __uint_as_float((uint32_t)x2);
                         const bool ok = (!act || ((uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag)) &&
                                         (!act_ml || (uint32_t)(x2 >> 32) == tag);
-                        if (__all(ok)) break;
+                        if (__all(ok) || dbg_nowait) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
                         if (++spins > SPIN_GLOBAL) { fail(0x800u + (uint32_t)(p - p0)); break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -449,7 +458,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 const u64* G = gran_sel(a, P->in_edge);
                 const uint32_t tag = base + (uint32_t)P->in_tag;
                 uint32_t total_spins = 0;
-                for (int pass = cw; pass * 1024 < K; pass += NCW) {
+                for (int pass = cw; pass * 1024 < K && !dbg_nostage; pass += NCW) {
                     const int kb = pass * 1024 + lane;
                     float v[16], wv[16];
                     if (!P->pre_attn) {
@@ -462,7 +471,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         int gi_last = ((pass + 1) * 1024 + per_round - 1) / per_round - 1;             // last round that writes into this pass
                         gi_last = gi_last < Q->gpw ? gi_last : Q->gpw - 1;
                         const int blk = gi_last / Q->gblk, left = Q->gpw - blk * Q->gblk, cnt = left < Q->gblk ? left : Q->gblk;
-                        int b_done = blk * Q->gblk * Q->nb + (Q->nb - 1) * cnt + (gi_last - blk * Q->gblk) + 1 + 1;   // + 1 batch of margin
+                        int b_done = blk * Q->gblk * Q->nb + (Q->nb - 1) * cnt + (gi_last - blk * Q->gblk) + 1 + t_margin;   // + margin
                         b_done = b_done < prev_nbt ? b_done : prev_nbt;
                         own_progress(prog_before + (uint32_t)(NSW * b_done), 0x100u + (uint32_t)(p - p0));
                     }
@@ -471,6 +480,21 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         for (int i = 0; i < 16; ++i) wv[i] = nw[kb + i * 64];
                     }
                     uint32_t spins = 0;
+                    // A sweep of the pass costs 64 cache-line requests per CU whether it finds the pass complete or not, and
+                    // the sweeps of all CUs travel the same fabric as the weight stream.  So the pass is first PROBED: 8 lines
+                    // spread over it (the granules of 64 producer waves on 16 CUs), an eighth of a sweep; only a clean probe
+                    // is followed by the sweep.
+                    if (!(P->pre_attn && t_noprobe_attn)) {
+                        const u64* GP0 = G + pass * 1024 + (lane >> 3) * 128 + (lane & 7) * 2 + 1;
+                        for (;;) {
+                            const u64 x = gran_ld(GP0);
+                            if (__all((uint32_t)(x >> 32) == tag) || dbg_nowait) break;
+                            if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
+                            if (++spins > SPIN_GLOBAL) { fail(0x200u + (uint32_t)(p - p0)); break; }
+                            if (P->pre_attn) __builtin_amdgcn_s_sleep(1); else for (int z = 0; z < t_psleep; ++z) __builtin_amdgcn_s_sleep(1);
+                        }
+                        spins = 0;
+                    }
                     for (;;) {
                         bool ok = true;
 #pragma unroll
@@ -479,7 +503,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                             v[i] = __uint_as_float((uint32_t)x);
                             ok = ok && ((uint32_t)(x >> 32) == tag);
                         }
-                        if (__all(ok)) break;
+                        if (__all(ok) || dbg_nowait) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
                         if (++spins > SPIN_GLOBAL) { fail(0x300u + (uint32_t)(p - p0)); break; }
                         if (P->pre_attn) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(12);
@@ -568,7 +592,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         const int g = gwid + (lc.gb * lc.gblk + lc.gg) * TW;
         // a row group past the last one, or a batch past the end of the program: every lane reads the same 16 bytes of the
         // matrix (no HBM traffic, result never used) -- the loads stay unconditional
-        const bool real = lvalid && g < lc.N / R;
+        const bool real = lvalid && g < lc.N / R && !dbg_noload;
         const size_t roff = real ? (size_t)g * R * (size_t)lc.K + (size_t)lc.kb * CHUNK : 0;
         const int loff = real ? lane * 8 : 0;
         const size_t sK = real ? (size_t)lc.K : 0;
@@ -613,7 +637,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         if (cc.kb >= nready) {                // first touch of this chunk: wait until its two passes are staged
             uint32_t spins = 0;
             const uint32_t* w = &ctrl[C_CNT + cxbuf * MAXCH + cc.kb];
-            while (lds_ld(w) < cneed && lds_ld(&ctrl[C_ABORT]) == 0u) {
+            while (!dbg_nowait && lds_ld(w) < cneed && lds_ld(&ctrl[C_ABORT]) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > SPIN_LDS) { fail(0x400u + (uint32_t)(cc.ph - p0)); break; }
             }

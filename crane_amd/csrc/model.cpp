@@ -382,6 +382,8 @@ void Model::build_engine() {
     engine_full = engine_full_eligible();
     if (const char* e = getenv("CM_ENGINE_FULL")) engine_full = engine_full && atoi(e) != 0;
     if (const char* e = getenv("CM_ENGINE_FULL_MAX")) eng_full_max_ctx = atoll(e);
+    if (const char* e = getenv("CM_ENG_TUNE")) eng_tune = (int)strtol(e, nullptr, 0);
+    if (const char* e = getenv("CM_ENG_DBG")) eng_dbg = atoi(e);          // kernel timing experiments, results invalid
     EngArgs probe{};
     probe.xf_total = eng_xf_total; probe.gpw_res = eng_gpw_res;
     probe.attn = engine_full ? (const EngAttnL*)1 : nullptr;
@@ -452,6 +454,7 @@ EngArgs Model::engine_args_common() const {
     e.Hkv = Hkv_l; e.page = page; e.max_pages = max_pages_per_seq;
     e.q_off = 0; e.k_off = Hq_l * cfg.D; e.v_off = e.k_off + Hkv_l * cfg.D;
     e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
+    e.dbg = eng_dbg; e.tune = eng_tune;
     return e;
 }
 

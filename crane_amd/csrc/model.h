@@ -275,6 +275,8 @@ struct Model {
     // persistent decode kernel (kernels_engine.hip): the whole token in one launch (attention inside), or per layer ONE
     // launch for o_proj -> gate||up -> down_proj -> next QKV around the separate attention kernels
     bool engine_on = false, engine_full = false;
+    int eng_tune = (8 << 8) | (8 << 4);        // polling parameters of the persistent kernel (EngArgs::tune)
+    int eng_dbg = 0;                           // CM_ENG_DBG (timing experiments only)
     int64_t eng_full_max_ctx = 4096;           // longer contexts: per-layer launches around the MFMA flash-decode kernel
     EngPhase* eng_prog = nullptr;              // device [L][4]: QKV, o_proj, gate||up, down_proj
     EngAttnL* eng_attn = nullptr;              // device [L]
