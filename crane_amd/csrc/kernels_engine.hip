@@ -258,8 +258,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     if (item >= NREP + 2) g0[ii] = a.q_off;               // idle slot: polls a q granule, result unused
                 }
                 float xin2[NIT][2];
+                uint32_t tr_spins = 0;
                 {
-                    uint32_t spins = 0;
+                    uint32_t spins = 0;      // (its final value is traced as event 7, low half)
                     for (;;) {
                         bool ok = true;
 #pragma unroll
@@ -273,6 +274,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (++spins > SPIN_GLOBAL) { fail(0x700u + (uint32_t)(p - p0)); break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    tr_spins = spins;
                 }
 #pragma unroll
                 for (int ii = 0; ii < NIT; ++ii) {
@@ -421,8 +423,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     }
                     if (act) { mo[s_src * 18 + 2 * e] = v0; mo[s_src * 18 + 2 * e + 1] = v1; }
                     if (act_ml) mo[s_src * 18 + 16 + e] = v2;
+                    tr_spins |= spins << 16;
                 }
                 stamp(p - p0, 6);
+                stamp(p - p0, 7, (u64)tr_spins);
                 cbar();
                 if (cw == 0) {
                     // one wave, all 64 lanes: lane = (output d, group of 8 source splits); every LDS read is independent

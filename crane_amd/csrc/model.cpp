@@ -396,6 +396,8 @@ void Model::build_engine() {
         }
     }
     const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    int gblk_env[4] = {0, 0, 0, 0};
+    if (const char* e = getenv("CM_ENG_GBLK")) sscanf(e, "%d,%d,%d,%d", &gblk_env[0], &gblk_env[1], &gblk_env[2], &gblk_env[3]);
     std::vector<EngPhase> prog((size_t)cfg.L * 4);
     std::vector<EngAttnL> at((size_t)cfg.L);
     for (int li = 0; li < cfg.L; ++li) {
@@ -420,6 +422,7 @@ void Model::build_engine() {
             // LAST chunk of its input is needed late; a producer should close groups early so that the first chunks of
             // its output exist early.  Long rows (down_proj) go group by group, short rows three groups at a time.
             p[k].gblk = p[k].nb > 2 ? 1 : std::min(p[k].gpw, 3);
+            if (gblk_env[k] > 0) p[k].gblk = std::min(std::min(p[k].gpw, 6), gblk_env[k]);      // CM_ENG_GBLK (tuning)
         }
         at[(size_t)li] = EngAttnL{kpool(li), vpool(li), w.qn, w.kn};
     }
@@ -497,7 +500,7 @@ void Model::engine_trace(float* out, size_t n) {
     CM_HIP(hipStreamSynchronize(stream));
     CM_HIP(hipMemcpy(h.data(), d, total * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d);
-    auto is_count = [&](size_t i) { return (i % ENG_TRACE_EV) == 3 && ((i / (ENG_TRACE_EV * ENG_TRACE_PH)) % waves) >= (size_t)ec.nsw; };
+    auto is_count = [&](size_t i) { return ((i % ENG_TRACE_EV) == 3 || (i % ENG_TRACE_EV) == 7) && ((i / (ENG_TRACE_EV * ENG_TRACE_PH)) % waves) >= (size_t)ec.nsw; };
     unsigned long long t0 = ~0ull;
     for (size_t i = 0; i < total; ++i)
         if (!is_count(i) && h[i] != 0 && h[i] < t0) t0 = h[i];

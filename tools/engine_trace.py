@@ -35,6 +35,19 @@ for rep in range(2):
         print(f"phase {p} {names[p]:9s} stream: arrive[{st(s[..., 0])}] go[{st(s[..., 1])}] done[{st(s[..., 2])}]")
         print(f"                  comm  : begin [{st(c[..., 0])}] poll[{st(c[..., 1])}] attn[{st(c[..., 2])}] stale sweeps avg {c[..., 3].mean():.1f} max {c[..., 3].max():.0f}")
         if (c[..., 4] > 0).any():
-            print(f"                  attn  : qkv+rope[{st(c[..., 4])}] scores[{st(c[..., 5])}] gathered[{st(c[..., 6])}]")
+            sp = c[..., 7].astype(np.int64)
+            print(f"                  attn  : qkv+rope[{st(c[..., 4])}] scores[{st(c[..., 5])}] gathered[{st(c[..., 6])}]  failed polls: qkv avg {(sp & 0xFFFF).mean():.2f} max {(sp & 0xFFFF).max()}, gather avg {(sp >> 16).mean():.2f} max {(sp >> 16).max()}")
+    if os.environ.get("TRACE_XCD"):
+        # stream-wave finish time of every phase by XCD (workgroup b runs on XCD b % 8) and by position inside the XCD
+        for p in range(MAXPH):
+            d = t[:, :NSW, p, 2]
+            byx = [np.median(d[x::8][d[x::8] > 0]) for x in range(8)]
+            print(f"phase {p} done by XCD: " + " ".join(f"{v:7.2f}" for v in byx) + f"   spread of CU medians {np.ptp(np.median(d, axis=1)):.2f}")
+            c0 = t[:, NSW, p, :]                     # comm wave 0 of every workgroup: the attention stamps
+            if (c0[:, 2] > 0).any() and (c0[:, 4] > 0).any():
+                for ev, nm in ((4, "qkv+rope"), (5, "scores"), (6, "gathered"), (2, "published")):
+                    v = c0[:, ev]
+                    print(f"    attn {nm:9s} by XCD (= kv head): " + " ".join(f"{np.median(v[x::8]):7.2f}" for x in range(8)) +
+                          "   by split 0-9 / 10-31: " + f"{np.median(v[:80]):7.2f} {np.median(v[80:]):7.2f}   max {v.max():7.2f} at wg {int(v.argmax())}")
     print(f"end of launch: {t[..., :3].max():.2f} us")
 m.close()
