@@ -153,7 +153,7 @@ def main():
     # chain launch itself (o_proj + gate||up + down_proj + next QKV: every weight byte of a layer)
     roof = None
     dom = "chain" if m.engine_active() else "gate_up"
-    pmc_key = "engine_chain_kernel" if m.engine_active() else "gemv_bf16_kernel<1, 2,"
+    pmc_key = "engine_kernel" if m.engine_active() else "gemv_bf16_kernel<1, 2,"
     try:
         kb = m.bench_kernel(dom, 360)
         roof = {"bound": "hbm", "kernel": kb["kernel"], "achieved": round(kb["bytes"] / (kb["ms"] * 1e-3) / 1e9, 1),
