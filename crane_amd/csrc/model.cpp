@@ -231,7 +231,12 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
                                   : (int64_t)max_seqs * max_pages_per_seq;
     if (n_pages < max_pages_per_seq) n_pages = max_pages_per_seq;
     nsplit = std::max(1, std::min(64, num_cu / std::max(1, Hkv_l)));
+    // every environment switch of the model is read here, once, at cm_create (tuning / A-B switches; none changes results
+    // beyond summation order except CM_QUANT_ACT and CM_QUANT_PREFILL, which select a documented arithmetic)
     if (const char* e = getenv("CM_TP_GRAPH")) tp_graph = atoi(e) != 0;
+    if (const char* e = getenv("CM_QUANT_PREFILL")) quant_prefill = atoi(e) != 0;
+    no_prefill = getenv("CM_NO_PREFILL") != nullptr;
+    if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
@@ -1159,7 +1164,6 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         CM_HIP(hipMemcpyAsync(d_btb, h_btb, (size_t)nb * max_pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
         if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_row_q(q_embed, stb, xb, H, cfg.V, s, nb);
         else launch_embed_row(embed, stb, xb, H, cfg.V, nb, s);
-        static const bool use_mfma_gemv = getenv("CM_GEMVM") == nullptr || atoi(getenv("CM_GEMVM")) != 0;
         auto gb = [&](int pro, int epi, const uint16_t* W, const float* xin, int ldx, const float* nw, float* y, int ldy, int N, int K) {
             GemvBArgs g{};
             g.W = W; g.x = xin; g.nw = nw; g.y = y; g.res = y; g.N = N; g.K = K; g.ldw = K; g.ldx = ldx; g.ldy = ldy; g.n_seq = nb;
@@ -1348,9 +1352,7 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     bool use_prefill = false;
     // quantised weights: each matrix is dequantised to a bf16 scratch in front of its MFMA GEMM (CM_QUANT_PREFILL=0:
     // token-serial, i.e. the decode kernels' integer-dot arithmetic for the prompt too)
-    const char* qpe = getenv("CM_QUANT_PREFILL");
-    const bool qprefill = qpe == nullptr || atoi(qpe) != 0;
-    if (n >= 2 && (!quantized || qprefill) && getenv("CM_NO_PREFILL") == nullptr) {
+    if (n >= 2 && (!quantized || quant_prefill) && !no_prefill) {
         ensure_prefill_buffers();
         use_prefill = prefill_ok;
     }

@@ -168,8 +168,10 @@ int cm_warmup(cm_model* m);
 /* ---- generation loop (B1) --------------------------------------------------- */
 
 /* GenerationConfig (generation/mod.rs:62-99).  temperature < 0 means None
- * (greedy arg-max: qwen3/model.rs:284); sampling with temperature >= 0 is
- * "next" tier (device sampler) and returns CM_ERR_UNSUPPORTED for now. */
+ * (greedy arg-max: qwen3/model.rs:284); temperature >= 0 samples on the device
+ * (top-k / top-p / Gumbel-max and the penalties of sampling.rs:169-478, see the
+ * device-side sampler section below); the draw uses its own counter-based RNG
+ * stream (the reference pins none). */
 typedef struct cm_gen_config {
     uint32_t max_new_tokens;
     float    temperature;        /* < 0 : None */
