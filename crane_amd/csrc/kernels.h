@@ -73,7 +73,7 @@ struct GdnArgs {
 };
 
 // ---- prefill (S > 1) ----
-enum { GEPI_STORE = 0, GEPI_RESADD = 1, GEPI_SILUMUL = 2, GEPI_ACT_SPLIT = 3 };
+enum { GEPI_STORE = 0, GEPI_RESADD = 1, GEPI_SILUMUL = 2, GEPI_ACT_SPLIT = 3, GEPI_PARTIAL = 4 /* internal: split-K partial tile */ };
 
 struct GemmArgs {
     const uint16_t* A_hi;   // [Mpad, K] bf16 activations (hi term)
@@ -85,6 +85,9 @@ struct GemmArgs {
     const float* bias;      // [N] f32 added before the epilogue, or null
     int act;                // GEPI_ACT_SPLIT: 0 identity, 1 gelu (tanh form), 2 gelu (erf form)
     int M, N, K, ldc;
+    float* ws;              // split-K workspace (or null: never split) of ws_floats f32; launch_gemm decides the split
+    size_t ws_floats;
+    int ksplit;             // set by launch_gemm
 };
 
 struct QkRopeArgs {

@@ -221,8 +221,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     const int tiles_m = (a.M + GBM - 1) / GBM;
     // XCD-aware order: blocks that share a weight tile (same n-tile, different m-tile) get
     // consecutive logical ids AND the same XCD (hardware places block b on XCD b % 8)
-    int bid = blockIdx.x;
-    const int nb = gridDim.x;
+    // split-K (a.ksplit > 1; short prompts: one or two m-tiles leave most CUs idle and every block walks all of K as one
+    // serial chain of k-tiles): blockIdx = ks * tiles + tile, block ks multiplies k-tiles [ks, ks + 1) * nk / ksplit and
+    // stores its raw partial tile (EPI == GEPI_PARTIAL); gemm_splitk_epilogue_kernel adds the partials in a fixed order
+    const int nb = tiles_m * (a.N / GBN);
+    const int ks = (int)blockIdx.x / nb;
+    int bid = (int)blockIdx.x % nb;
     if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;
     const int tn = bid / tiles_m, tm = bid % tiles_m;
     const int m0 = tm * GBM, n0 = tn * GBN;
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     // else hides the latency (24 ms per 128-token prefill on Qwen3-8B with a single stage).  Loads are unconditional
     // (tile index clamped) and the stages are statically named (loop unrolled by PD).
     constexpr int PD = 4;
-    const int nk = K / GBK;
+    const int nk_all = K / GBK, kpb = nk_all / a.ksplit;      // k-tiles per block (launch_gemm: ksplit divides nk_all)
+    const int kbeg = ks * kpb, nk = kbeg + kpb;                // this block's k-tiles [kbeg, nk)
     u32x4 ra[PD][SPLIT][2], rb[PD][2];
     auto g_load = [&](u32x4 (&qa)[SPLIT][2], u32x4 (&qb)[2], int tile) {
         const int k0 = min(tile, nk - 1) * GBK;
@@ -280,13 +285,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     };
 
 #pragma unroll
-    for (int d = 0; d < PD; ++d) g_load(ra[d], rb[d], d);          // tiles 0 .. PD-1 -> stages 0 .. PD-1
+    for (int d = 0; d < PD; ++d) g_load(ra[d], rb[d], kbeg + d);   // tiles 0 .. PD-1 -> stages 0 .. PD-1
     s_store(ra[0], rb[0], 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += PD) {
+    for (int kt = kbeg; kt < nk; kt += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
-            const int i = kt + d;                                   // tile in LDS buffer d & 1 (kt is a multiple of PD)
+            const int i = kt + d;                                   // tile in LDS buffer d & 1 (kt - kbeg is a multiple of PD)
             if (i >= nk) break;
             g_load(ra[d], rb[d], i + PD);                           // stage d was parked in LDS one step ago: refill it
             compute(d & 1);
@@ -296,6 +301,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     }
 
     // epilogue: C layout of mfma 16x16: col = lane & 15 (n), row = (lane >> 4) * 4 + reg (m)
+    if (EPI == GEPI_PARTIAL) {
+        float* P = a.ws + (size_t)ks * a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    if (m < a.M) P[(size_t)m * a.N + n0 + wc * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+                }
+        return;
+    }
     float bv[4] = {0.f, 0.f, 0.f, 0.f};                      // a lane's 4 columns: the bias is loaded once, not per element
     if (a.bias != nullptr) {
 #pragma unroll
@@ -548,10 +566,70 @@ void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s) {
     int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
     hipLaunchKernelGGL(add_rows_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, x, y, n4);
 }
-bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if (a.N % GBN != 0 || a.K % GBK != 0) return false;
+// second half of a split-K GEMM: thread = 4 consecutive columns of one row; partials added in the order ks = 0, 1, ...
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs a) {
+    const size_t n4 = (size_t)a.N / 4, total = (size_t)a.M * n4;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int m = (int)(t / n4), n = (int)(t % n4) * 4;
+        f32x4 v = *(const f32x4*)(a.ws + (size_t)m * a.N + n);
+        for (int k = 1; k < a.ksplit; ++k) {
+            const f32x4 p = *(const f32x4*)(a.ws + ((size_t)k * a.M + m) * a.N + n);
+            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        }
+        if (a.bias != nullptr) {
+            const f32x4 b = *(const f32x4*)(a.bias + n);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        if (EPI == GEPI_STORE) {
+            *(f32x4*)(a.C + (size_t)m * a.ldc + n) = v;
+        } else if (EPI == GEPI_RESADD) {
+            f32x4 c = *(const f32x4*)(a.C + (size_t)m * a.ldc + n);
+            c[0] += v[0]; c[1] += v[1]; c[2] += v[2]; c[3] += v[3];
+            *(f32x4*)(a.C + (size_t)m * a.ldc + n) = c;
+        } else if (EPI == GEPI_ACT_SPLIT) {
+            float h[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = v[i];
+                h[i] = a.act == 1 ? 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)))
+                     : a.act == 2 ? 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)) : x;
+            }
+            split_store4(a.H_hi, a.H_lo, (size_t)m * a.N + n, h);
+        } else {   // GEPI_SILUMUL: columns (gate_j, up_j) interleaved -> two outputs per thread
+            const float h0 = (v[0] / (1.0f + expf(-v[0]))) * v[1], h1 = (v[2] / (1.0f + expf(-v[2]))) * v[3];
+            const size_t off = (size_t)m * (a.N / 2) + (n >> 1);
+            const uint16_t a0 = f32_to_bf16(h0), a1 = f32_to_bf16(h1);
+            *(uint32_t*)(a.H_hi + off) = (uint32_t)a0 | ((uint32_t)a1 << 16);
+            if (a.H_lo) *(uint32_t*)(a.H_lo + off) = (uint32_t)f32_to_bf16(h0 - bf16_to_f32(a0)) | ((uint32_t)f32_to_bf16(h1 - bf16_to_f32(a1)) << 16);
+        }
+    }
+}
+
+// split factor for a GEMM of `tiles` output tiles and nk k-tiles: only when the tiles alone leave the chip mostly idle
+static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
+    if (M > 4 * GBM || ws_floats == 0) return 1;
+    int S = 1;
+    while (S < 8 && tiles * (S * 2) <= 512 && nk % (S * 2 * 4) == 0 && nk / (S * 2) >= 8 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
+    return S;
+}
+
+bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
+    if (a0.N % GBN != 0 || a0.K % GBK != 0) return false;
+    GemmArgs a = a0;
     const int tiles = ((a.M + GBM - 1) / GBM) * (a.N / GBN);
     const bool split = a.A_lo != nullptr;
+    a.ksplit = a.ws != nullptr ? gemm_ksplit(a.M, a.N, tiles, a.K / GBK, a.ws_floats) : 1;
+    if (a.ksplit > 1) {
+        if (split) hipLaunchKernelGGL((gemm_bf16_kernel<2, GEPI_PARTIAL>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<1, GEPI_PARTIAL>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
+        const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
+        if (epi == GEPI_STORE) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_STORE>), dim3(eb), dim3(256), 0, s, a);
+        else if (epi == GEPI_RESADD) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_RESADD>), dim3(eb), dim3(256), 0, s, a);
+        else if (epi == GEPI_ACT_SPLIT) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_ACT_SPLIT>), dim3(eb), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_SILUMUL>), dim3(eb), dim3(256), 0, s, a);
+        return true;
+    }
 #define CM_GEMM(SP, EP) hipLaunchKernelGGL((gemm_bf16_kernel<SP, EP>), dim3(tiles), dim3(256), 0, s, a)
     if (split) {
         if (epi == GEPI_STORE) CM_GEMM(2, GEPI_STORE); else if (epi == GEPI_RESADD) CM_GEMM(2, GEPI_RESADD);

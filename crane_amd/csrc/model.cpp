@@ -896,6 +896,7 @@ void Model::ensure_prefill_buffers() {
                  (!cfg.hybrid || cfg.value_dim() % 32 == 0);
     if (!prefill_ok) return;
     pX = dalloc<float>((size_t)chunk * H);
+    pWS = dalloc<float>(gemm_ws_floats);             // split-K partial tiles of short prompts (launch_gemm)
     if (rccl) pY = dalloc<float>((size_t)chunk * H);
     pQKV = dalloc<float>((size_t)chunk * std::max(qkv_rows, in_proj_pad));
     if (cfg.hybrid) {
@@ -947,6 +948,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             const LayerW& w = layers[(size_t)li];
             launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
             GemmArgs g{};
+            g.ws = pWS; g.ws_floats = gemm_ws_floats;
             if (!w.full) {
                 // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
                 g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
@@ -978,7 +980,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                     done += part;
                 }
                 launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
-                g = GemmArgs{};
+                g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
                 g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
                 if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
                 if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
@@ -1019,7 +1021,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             at.page = page; at.start_pos = sp; at.causal = 1;
             at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
             launch_attn_prefill(at, D, kv_f32 || kvq, s);
-            g = GemmArgs{};
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
@@ -1030,7 +1032,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             }
             }   // full-attention layer
             launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
-            g = GemmArgs{};
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
             if (quantized) {
                 if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
@@ -1039,7 +1041,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             }
             g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
             launch_gemm(g, GEPI_SILUMUL, s);
-            g = GemmArgs{};
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
             g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }

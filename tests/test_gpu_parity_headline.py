@@ -72,6 +72,14 @@ def test_prefill_1024_and_batched_step_qwen3_8b_geometry(oracle8b):
         # a decode step on top of the prefilled cache
         t = int(ref.argmax())
         assert rel(m.forward_step([t], 1024)[0, 0], c.forward([t], 1024)) < BAR
+        # short prompts (one or two m-tiles): the split-K GEMMs (partial tiles + fixed-order epilogue kernel)
+        for n_short in (100, 200):
+            ids_s = configs.synthetic_prompt(n_short, V)
+            m.clear_kv_cache()
+            got_s = m.forward_step(ids_s, 0)[0, 0]
+            ref_s = c.forward(ids_s, 0)
+            assert rel(got_s, ref_s) < BAR, (n_short, rel(got_s, ref_s))
+            assert int(got_s.argmax()) == int(ref_s.argmax())
         # batched step: 3 sequences of different lengths share one pass over the weights (gemvm, 4x4x4 MFMA)
         prompts = [[(7 * i + 3 + 11 * b) % V for i in range(40 + 17 * b)] for b in range(3)]
         seqs, last = [], []
