@@ -11,6 +11,8 @@
 //   * attention is a causal flash kernel over the paged KV cache: S^T = K.Q^T
 //     (mfma 16x16x32), online softmax with lane-local row statistics, O^T = V^T.P^T
 //     (mfma 16x16x16, V fragments through ds_read_b64_tr_b16), nothing O(S*L) in HBM.
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -608,9 +610,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs a) {
 
 // split factor for a GEMM of `tiles` output tiles and nk k-tiles: only when the tiles alone leave the chip mostly idle
 static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
-    if (M > 4 * GBM || ws_floats == 0) return 1;
+    static const int ksplit_cap = getenv("CM_KSPLIT_CAP") ? atoi(getenv("CM_KSPLIT_CAP")) : 768;      // blocks (tuning)
+    if (ws_floats == 0) return 1;      // (any M: a GEMM of <= 256 tiles leaves half of the 2-blocks-per-CU slots empty)
     int S = 1;
-    while (S < 8 && tiles * (S * 2) <= 512 && nk % (S * 2 * 4) == 0 && nk / (S * 2) >= 8 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
+    while (S < 8 && tiles * (S * 2) <= ksplit_cap && nk % (S * 2 * 4) == 0 && nk / (S * 2) >= 8 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
     return S;
 }
 

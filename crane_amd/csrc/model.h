@@ -206,8 +206,8 @@ struct Model {
     int chunk = 2048, chunk_pad = 2048;
     bool prefill_ok = false, prefill_split2 = true;
     float* pX = nullptr;        // [chunk, H] f32 residual stream
-    float* pWS = nullptr;       // split-K workspace of the prefill GEMMs: at most 512 partial tiles of 128 x 128 f32
-    static constexpr size_t gemm_ws_floats = (size_t)512 * 128 * 128;
+    float* pWS = nullptr;       // split-K workspace of the prefill GEMMs: at most 1024 partial tiles of 128 x 128 f32
+    static constexpr size_t gemm_ws_floats = (size_t)1024 * 128 * 128;
     float* pY = nullptr;        // [chunk, H] TP partial
     float* pQKV = nullptr;      // [chunk, qkv_rows] f32
     uint16_t *pXN_hi = nullptr, *pXN_lo = nullptr;     // [chunk_pad, H]
