@@ -384,6 +384,10 @@ class Model:
     def debug_fill_kv(self, ctx: int, seed: int = 0) -> None:
         self._check(self._lib.cm_debug_fill_kv(self._h, ctx, seed))
 
+    def debug_set(self, key: str, value: int) -> None:
+        """test hook: "no_prefill" / "quant_prefill" path switches of a live model (cm_debug_set)"""
+        self._check(self._lib.cm_debug_set(self._h, key.encode(), int(value)))
+
     def debug_read(self, what: str, n: int) -> np.ndarray:
         out = np.empty(n, dtype=np.float32)
         self._check(self._lib.cm_debug_read(self._h, what.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), n))

@@ -338,4 +338,14 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
     });
 }
 
+int cm_debug_set(cm_model* h, const char* key, int64_t value) {
+    if (!h || !key) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        const std::string k = key;
+        if (k == "no_prefill") h->m.no_prefill = value != 0;
+        else if (k == "quant_prefill") h->m.quant_prefill = value != 0;
+        else throw CmError(CM_ERR_INVALID, "unknown debug switch");
+    });
+}
+
 }  // extern "C"

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
     auto s_store = [&](const u32x4 (&qa)[SPLIT][2], const u32x4 (&qb)[2], int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 8;
+            const int c = tid + 256 * i, row = c >> 2;
             const int so = row * GLD + ((((c & 3) ^ gemm_swz(row))) << 3);
             *(u32x4*)&As[buf][0][so] = qa[0][i];
             if (SPLIT == 2) *(u32x4*)&As[buf][SPLIT - 1][so] = qa[SPLIT - 1][i];

@@ -40,36 +40,42 @@ struct Packed {
     std::vector<uint8_t> p0, p1, p2, p3;
 };
 
-void pack_rows(const TensorInfo& t, int row0, int nrows, int K, Packed& out) {
+// rows [row0, row0 + nrows) of a [*, Kfull] tensor, columns [k0, k0 + K) of them (K < 0: all; tensor parallelism cuts the
+// row-parallel matrices along K -- on whole ggml blocks, so a rank's blocks are the blocks of the unsharded matrix)
+void pack_rows(const TensorInfo& t, int row0, int nrows, int Kfull, Packed& out, int k0 = 0, int K = -1) {
+    if (K < 0) K = Kfull;
     const size_t nb32 = (size_t)K / 32, nb256 = (size_t)K / 256;
+    const size_t fb32 = (size_t)Kfull / 32, fb256 = (size_t)Kfull / 256, b32_0 = (size_t)k0 / 32, b256_0 = (size_t)k0 / 256;
+    const int blk = t.type == cmgguf::Q8_0 ? 32 : 256;
+    if (k0 % blk || K % blk) throw CmError(CM_ERR_UNSUPPORTED, "tensor-parallel cut of " + t.name + " does not fall on a quantisation block");
     if (t.type == cmgguf::Q8_0) {
-        if (K % 32) throw CmError(CM_ERR_UNSUPPORTED, "Q8_0 needs K % 32 == 0 (" + t.name + ")");
+        if (Kfull % 32) throw CmError(CM_ERR_UNSUPPORTED, "Q8_0 needs K % 32 == 0 (" + t.name + ")");
         out.fmt = QFMT_Q8_0;
         const size_t o0 = out.p0.size(), o1 = out.p1.size();
         out.p0.resize(o0 + (size_t)nrows * K);
         out.p1.resize(o1 + (size_t)nrows * nb32 * 2);
         for (int r = 0; r < nrows; ++r) {
-            const uint8_t* src = t.data + (size_t)(row0 + r) * nb32 * 34;
+            const uint8_t* src = t.data + ((size_t)(row0 + r) * fb32 + b32_0) * 34;
             for (size_t b = 0; b < nb32; ++b) {
                 memcpy(&out.p1[o1 + ((size_t)r * nb32 + b) * 2], src + b * 34, 2);
                 memcpy(&out.p0[o0 + (size_t)r * K + b * 32], src + b * 34 + 2, 32);
             }
         }
     } else if (t.type == cmgguf::Q4_K) {
-        if (K % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q4_K needs K % 256 == 0 (" + t.name + ")");
+        if (Kfull % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q4_K needs K % 256 == 0 (" + t.name + ")");
         out.fmt = QFMT_Q4_K;
         const size_t o0 = out.p0.size(), o1 = out.p1.size();
         out.p0.resize(o0 + (size_t)nrows * K / 2);
         out.p1.resize(o1 + (size_t)nrows * nb256 * 16);
         for (int r = 0; r < nrows; ++r) {
-            const uint8_t* src = t.data + (size_t)(row0 + r) * nb256 * 144;
+            const uint8_t* src = t.data + ((size_t)(row0 + r) * fb256 + b256_0) * 144;
             for (size_t b = 0; b < nb256; ++b) {
                 memcpy(&out.p1[o1 + ((size_t)r * nb256 + b) * 16], src + b * 144, 16);
                 memcpy(&out.p0[o0 + ((size_t)r * nb256 + b) * 128], src + b * 144 + 16, 128);
             }
         }
     } else if (t.type == cmgguf::Q6_K) {
-        if (K % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q6_K needs K % 256 == 0 (" + t.name + ")");
+        if (Kfull % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q6_K needs K % 256 == 0 (" + t.name + ")");
         out.fmt = QFMT_Q6_K;
         const size_t o0 = out.p0.size(), o1 = out.p1.size(), o2 = out.p2.size(), o3 = out.p3.size();
         out.p0.resize(o0 + (size_t)nrows * K / 2);
@@ -77,7 +83,7 @@ void pack_rows(const TensorInfo& t, int row0, int nrows, int K, Packed& out) {
         out.p2.resize(o2 + (size_t)nrows * K / 16);
         out.p3.resize(o3 + (size_t)nrows * nb256 * 2);
         for (int r = 0; r < nrows; ++r) {
-            const uint8_t* src = t.data + (size_t)(row0 + r) * nb256 * 210;
+            const uint8_t* src = t.data + ((size_t)(row0 + r) * fb256 + b256_0) * 210;
             for (size_t b = 0; b < nb256; ++b) {
                 const size_t bi = (size_t)r * nb256 + b;
                 memcpy(&out.p0[o0 + bi * 128], src + b * 210, 128);
@@ -118,6 +124,15 @@ QWeight load_matrix(Model& m, const File& g, const std::string& name, int N, int
     Packed p;
     pack_rows(t, 0, N, K, p);
     return to_device(m, p, N, K);
+}
+
+// rows [row0, row0 + nrows) x columns [k0, k0 + Kl) of the [N, K] tensor `name`
+QWeight load_matrix_part(Model& m, const File& g, const std::string& name, int N, int K, int row0, int nrows, int k0, int Kl) {
+    const TensorInfo& t = g.tensor(name);
+    check_shape(t, (uint64_t)N, (uint64_t)K);
+    Packed p;
+    pack_rows(t, row0, nrows, K, p, k0, Kl);
+    return to_device(m, p, nrows, Kl);
 }
 
 float* load_vec_f32(Model& m, const File& g, const std::string& name, int n) {
@@ -207,19 +222,68 @@ std::string gguf_config_json(const std::string& path) {
     return buf;
 }
 
+// Dense Qwen3 under tensor parallelism: the Megatron cut of loader.cpp on the quantised tensors -- q heads, the kv heads of
+// this rank (replicated when there are fewer kv heads than ranks) and the gate / up rows by ROW; o_proj and down_proj by
+// COLUMN, i.e. along K, on whole ggml blocks (32 for Q8_0, 256 for the K-quants: a rank's blocks are the file's blocks).
+static void load_dense_shard(Model& m, const File& g) {
+    const Config& c = m.cfg;
+    const int H = c.H, D = c.D, I = c.I, qd = m.Hq_l * D, kd = m.Hkv_l * D, Il = m.I_l, r = m.rank;
+    for (int li = 0; li < c.L; ++li) {
+        LayerW& w = m.layers[(size_t)li];
+        w.full = true;
+        const std::string p = "blk." + std::to_string(li) + ".";
+        const TensorInfo &tq = g.tensor(p + "attn_q.weight"), &tk = g.tensor(p + "attn_k.weight"), &tv = g.tensor(p + "attn_v.weight");
+        check_shape(tq, (uint64_t)c.Hq * D, (uint64_t)H); check_shape(tk, (uint64_t)c.Hkv * D, (uint64_t)H); check_shape(tv, (uint64_t)c.Hkv * D, (uint64_t)H);
+        if (tq.type == tk.type && tk.type == tv.type) {
+            Packed pk;
+            pack_rows(tq, r * qd, qd, H, pk); pack_rows(tk, m.kvh0 * D, kd, H, pk); pack_rows(tv, m.kvh0 * D, kd, H, pk);
+            w.q_qkv[0] = to_device(m, pk, qd + 2 * kd, H);
+            w.n_qkv = 1; w.qkv_row0[0] = 0;
+        } else {
+            w.q_qkv[0] = load_matrix_part(m, g, p + "attn_q.weight", c.Hq * D, H, r * qd, qd, 0, H);
+            w.q_qkv[1] = load_matrix_part(m, g, p + "attn_k.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H);
+            w.q_qkv[2] = load_matrix_part(m, g, p + "attn_v.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H);
+            w.n_qkv = 3; w.qkv_row0[0] = 0; w.qkv_row0[1] = qd; w.qkv_row0[2] = qd + kd;
+        }
+        w.q_o = load_matrix_part(m, g, p + "attn_output.weight", H, c.Hq * D, 0, H, r * qd, qd);
+        if (c.qk_norm) {
+            w.qn = load_vec_f32(m, g, p + "attn_q_norm.weight", D);
+            w.kn = load_vec_f32(m, g, p + "attn_k_norm.weight", D);
+        }
+        const TensorInfo &tg = g.tensor(p + "ffn_gate.weight"), &tu = g.tensor(p + "ffn_up.weight");
+        check_shape(tg, (uint64_t)I, (uint64_t)H); check_shape(tu, (uint64_t)I, (uint64_t)H);
+        if (tg.type == tu.type) {
+            Packed pk;                                              // row 2j = gate_j, row 2j+1 = up_j of this rank's columns
+            for (int j = 0; j < Il; ++j) { pack_rows(tg, r * Il + j, 1, H, pk); pack_rows(tu, r * Il + j, 1, H, pk); }
+            w.q_gate_up = to_device(m, pk, 2 * Il, H);
+        } else {
+            w.split_gate_up = true;
+            w.q_gate = load_matrix_part(m, g, p + "ffn_gate.weight", I, H, r * Il, Il, 0, H);
+            w.q_up = load_matrix_part(m, g, p + "ffn_up.weight", I, H, r * Il, Il, 0, H);
+            if (!m.gu_tmp) m.gu_tmp = m.dalloc<float>((size_t)2 * Il);
+        }
+        w.q_down = load_matrix_part(m, g, p + "ffn_down.weight", H, I, 0, H, r * Il, Il);
+        w.ln1 = load_vec_f32(m, g, p + "attn_norm.weight", H);
+        w.ln2 = load_vec_f32(m, g, p + "ffn_norm.weight", H);
+    }
+}
+
 void load_from_gguf(Model& m, const std::string& path) {
-    if (m.tp != 1) throw CmError(CM_ERR_UNSUPPORTED, "quantised (GGUF) weights under tensor parallelism are not implemented");
+    if (m.tp != 1 && m.cfg.hybrid) throw CmError(CM_ERR_UNSUPPORTED, "GGUF weights of the hybrid family under tensor parallelism are not implemented");
     try {
         File g(path);
         const Config& c = m.cfg;
         const int H = c.H, D = c.D, I = c.I;
         m.quantized = true;
-        m.q_embed = load_matrix(m, g, "token_embd.weight", c.V, H);
+        m.q_embed = load_matrix(m, g, "token_embd.weight", c.V, H);          // replicated: every rank embeds the token itself
         m.quant_weight_bytes -= m.q_embed.bytes();                 // only one row is read per token
         m.norm = load_vec_f32(m, g, "output_norm.weight", H);
-        if (!c.tie) m.q_lm_head = load_matrix(m, g, "output.weight", c.V, H);
-        else { m.q_lm_head = m.q_embed; m.quant_weight_bytes += m.q_embed.bytes(); }
+        // lm_head: this rank's vocabulary rows [v0, v0 + v_eff) (tensor parallelism; everything at tp = 1)
+        const int v_eff = std::max(0, std::min(m.V_l, c.V - m.v0));
+        if (!c.tie) { if (v_eff > 0) m.q_lm_head = load_matrix_part(m, g, "output.weight", c.V, H, m.v0, v_eff, 0, H); }
+        else { m.q_lm_head = m.q_embed.rows(m.v0, v_eff); m.quant_weight_bytes += m.q_lm_head.bytes(); }
         m.layers.resize((size_t)c.L);
+        if (m.tp != 1) { load_dense_shard(m, g); CM_HIP(hipStreamSynchronize(m.stream)); return; }
         const int qd = c.Hq * D, kd = c.Hkv * D;
         m.gdn_chunked = c.hybrid;                  // llama.cpp orders the GDN value heads Chunked (ops/gdn/config.rs:13-22)
         int gdn_idx = 0;

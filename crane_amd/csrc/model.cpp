@@ -838,8 +838,8 @@ void Model::enqueue_quant_layer(int li) {
         qg(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, x, w.ln2, hbuf, nullptr);
     } else {
         qg(PRO_RMSNORM, EPI_STORE, w.q_gate, x, w.ln2, gu_tmp, nullptr);
-        qg(PRO_RMSNORM, EPI_STORE, w.q_up, x, w.ln2, gu_tmp + cfg.I, nullptr);
-        launch_silu_mul(gu_tmp, gu_tmp + cfg.I, hbuf, cfg.I, s);
+        qg(PRO_RMSNORM, EPI_STORE, w.q_up, x, w.ln2, gu_tmp + I_l, nullptr);
+        launch_silu_mul(gu_tmp, gu_tmp + I_l, hbuf, I_l, s);
     }
     if (!rccl) qg(PRO_PLAIN, EPI_RESADD, w.q_down, hbuf, nullptr, x, x);
     else {
@@ -1124,7 +1124,7 @@ void Model::ensure_batch_buffers() {
     if (rccl) yb = dalloc<float>((size_t)MAXB * H);
     int g = std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu));
     if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu));
-    if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * cfg.I);
+    if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * I_l);
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
     lm_gridb = g;
@@ -1279,9 +1279,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (!w.split_gate_up) {
                     qb(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, xb, H, w.ln2, hbb, I_l);
                 } else {
-                    qb(PRO_RMSNORM, EPI_STORE, w.q_gate, xb, H, w.ln2, gu_tmpb, 2 * cfg.I);
-                    qb(PRO_RMSNORM, EPI_STORE, w.q_up, xb, H, w.ln2, gu_tmpb + cfg.I, 2 * cfg.I);
-                    launch_silu_mul(gu_tmpb, gu_tmpb + cfg.I, hbb, cfg.I, s, nb, 2 * cfg.I, I_l);
+                    qb(PRO_RMSNORM, EPI_STORE, w.q_gate, xb, H, w.ln2, gu_tmpb, 2 * I_l);
+                    qb(PRO_RMSNORM, EPI_STORE, w.q_up, xb, H, w.ln2, gu_tmpb + I_l, 2 * I_l);
+                    launch_silu_mul(gu_tmpb, gu_tmpb + I_l, hbb, I_l, s, nb, 2 * I_l, I_l);
                 }
                 qrp(w.q_down, hbb, I_l);
                 continue;

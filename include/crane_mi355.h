@@ -389,6 +389,11 @@ int cm_debug_read(cm_model* m, const char* what, float* out, size_t n);
  * 2j = gate_j, 2j+1 = up_j) | "gate" | "up", "down", "lm_head".  Kernel-level parity hook for tests. */
 int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n);
 
+/* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at
+ * cm_create).  "no_prefill" = 1: prompts run token by token through the decode kernels; "quant_prefill" = 0: prompts over
+ * quantised weights run through the integer-dot decode kernels instead of the dequantised MFMA GEMMs. */
+int cm_debug_set(cm_model* m, const char* key, int64_t value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,12 +199,11 @@ def test_error_behaviour(pair):
 # prefill (MFMA GEMM + flash attention) path
 # ---------------------------------------------------------------------------------------------
 def _serial(m, ids, start):
-    import os
-    os.environ["CM_NO_PREFILL"] = "1"
+    m.debug_set("no_prefill", 1)
     try:
         return m.forward_step(ids, start)[0, 0]
     finally:
-        del os.environ["CM_NO_PREFILL"]
+        m.debug_set("no_prefill", 0)
 
 
 @pytest.mark.parametrize("n", [2, 17, 64, 65, 200])

@@ -148,15 +148,19 @@ def test_quantised_prefill_through_dequantised_gemm(tmp_path, monkeypatch, kind)
     monkeypatch.setenv("CM_QUANT_ACT", "f32")
     ids = configs.synthetic_prompt(70, cfg["vocab_size"])
     ref = oracle.forward(ids, 0)
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")                       # (environment switches are read at cm_create)
+    ms = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    try:
+        serial = ms.forward_step(ids, 0).reshape(-1)                  # token-serial decode kernels
+    finally:
+        ms.close()
+    monkeypatch.delenv("CM_QUANT_PREFILL")
     m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
     try:
         got = m.forward_step(ids, 0).reshape(-1)                      # MFMA prefill (dequant -> bf16 scratch)
-        monkeypatch.setenv("CM_QUANT_PREFILL", "0")
-        serial = m.forward_step(ids, 0).reshape(-1)                   # token-serial decode kernels
         assert rel(serial, ref) < 2e-4
         assert rel(got, ref) < 1e-2 and rel(got, serial) < 1e-2, (rel(got, ref), rel(got, serial))
         assert int(got.argmax()) == int(ref.argmax())
-        monkeypatch.delenv("CM_QUANT_PREFILL")
         # decode continues on the KV written by the prefill path
         tok = int(ref.argmax())
         r2 = oracle.forward([tok], 70)
@@ -219,7 +223,7 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
     ids = configs.synthetic_prompt(33, V)
     m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
     try:
-        monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+        m.debug_set("quant_prefill", 0)
         ref = o.forward(ids, 0)
         got = m.forward_step(ids, 0).reshape(-1)
         assert rel(got, ref) < 2e-4, rel(got, ref)
@@ -229,7 +233,7 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
             got = m.forward_step([tok], 33 + step).reshape(-1)
             assert rel(got, ref) < 2e-4, (step, rel(got, ref))
             tok = int(ref.argmax())
-        monkeypatch.delenv("CM_QUANT_PREFILL")
+        m.debug_set("quant_prefill", 1)
         ref = o.forward(ids, 0)
         got = m.forward_step(ids, 0).reshape(-1)                 # MFMA prefill on the bf16 scratch
         assert rel(got, ref) < 1e-2 and int(got.argmax()) == int(ref.argmax()), rel(got, ref)
@@ -239,7 +243,7 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
     monkeypatch.delenv("CM_QUANT_ACT")
     m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
     try:
-        monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+        m.debug_set("quant_prefill", 0)
         got = m.forward_step(ids, 0).reshape(-1)
         ref = o.forward(ids, 0)
         assert rel(got, ref) < 5e-2, rel(got, ref)
@@ -285,7 +289,7 @@ def test_qwen35_gguf_checkpoint(tmp_path, monkeypatch, kind):
             got = m.forward_step([tok], 21 + step).reshape(-1)
             assert rel(got, ref) < 3e-4, (step, rel(got, ref))
             tok = int(ref.argmax())
-        monkeypatch.delenv("CM_QUANT_PREFILL")
+        m.debug_set("quant_prefill", 1)
         ref = o.forward(ids, 0)
         got = m.forward_step(ids, 0).reshape(-1)                 # MFMA prefill on the dequantised bf16 scratch
         assert rel(got, ref) < 2e-2, rel(got, ref)

@@ -125,3 +125,37 @@ def test_batched_decode_on_a_rank(name, nb, isq):
                 toks = [int(g) for g in greedy]
         finally:
             m.close()
+
+
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "mixed"])
+def test_dense_rank_shards_gguf(tmp_path, monkeypatch, kind):
+    """GGUF checkpoints under TP: the loader cuts the quantised tensors by row (q / kv heads, gate / up, vocabulary) and by
+    COLUMN on whole ggml blocks (o_proj, down_proj: 32 for Q8_0, 256 for the K-quants), so a rank's codes are the file's
+    codes.  Checked with f32 activations against the f32 oracle on the dequantised shard."""
+    from crane_amd.backend import Model
+    from oracle import gguf_oracle as G
+    from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+    from tests.test_gpu_quant import _types
+    monkeypatch.setenv("CM_QUANT_ACT", "f32")
+    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+    cfg = configs.get_config("tiny-qwen3-untied")            # per rank at tp = 2: 512 o_proj columns, 768 down_proj columns
+    w = synth.synth_weights_f32(cfg, 0)
+    path = str(tmp_path / f"tp-{kind}.gguf")
+    deq, _ = G.write_qwen3_gguf(path, cfg, w, _types(kind), want_qmats=True)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    world = 2
+    for rank in range(world):
+        plan = tp.shard_plan(cfg, world, rank)
+        sw = tp.shard_weights(cfg, deq, plan)
+        local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads),
+                     intermediate_size=len(plan.inter))
+        o = Qwen3Oracle(Qwen3Config.from_json(local), sw)
+        m = Model.from_pretrained(path, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
+                                  tp_unique_id=b"\0" * 128, debug_tp_local=True)
+        try:
+            got_a = m.forward_step(ids, 0)[0, 0]
+            got_b = m.forward_step([5], len(ids))[0, 0]
+        finally:
+            m.close()
+        v = slice(plan.vocab.start, plan.vocab.stop)
+        assert rel(got_a[v], o.forward(ids, 0)) < 2e-4 and rel(got_b[v], o.forward([5], len(ids))) < 2e-4

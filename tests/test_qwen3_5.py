@@ -146,12 +146,12 @@ def test_hip_qwen35_prefill_equals_token_serial(n):
         ids = configs.synthetic_prompt(n, cfg["vocab_size"])
         a = m.forward_step(ids, 0)[0, 0]
         nxt = m.forward_step([5], n)[0, 0]
-        os.environ["CM_NO_PREFILL"] = "1"
+        m.debug_set("no_prefill", 1)
         try:
             m.clear_kv_cache()
             b = m.forward_step(ids, 0)[0, 0]
         finally:
-            del os.environ["CM_NO_PREFILL"]
+            m.debug_set("no_prefill", 0)
         ref = o.forward(ids, 0)
         assert rel(a, b) < 1e-4 and rel(a, ref) < 1e-4
         assert rel(nxt, o.forward([5], n)) < 1e-4
