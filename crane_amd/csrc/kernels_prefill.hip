@@ -651,7 +651,9 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     // 256-wide tiles (one 8-wave block per CU) when they give every CU at least two blocks (1024-token gate||up: 428 -> ~370 us;
     // fewer, and the tail of the last round costs more than the tile saves); CM_GEMM_BN = 128 | 256 forces a width (A/B)
     static const int bn_env = getenv("CM_GEMM_BN") ? atoi(getenv("CM_GEMM_BN")) : 0;
-    const bool wide = a.N % 256 == 0 && (bn_env == 256 || (bn_env == 0 && tiles_m * (a.N / 256) >= 512));
+    const int t256 = tiles_m * (a.N / 256);
+    static const int wide_lo = getenv("CM_GEMM_WIDE_LO") ? atoi(getenv("CM_GEMM_WIDE_LO")) : 192;      // (tuning)
+    const bool wide = a.N % 256 == 0 && (bn_env == 256 || (bn_env == 0 && (t256 >= 512 || (t256 >= wide_lo && t256 <= 256))));
     if (wide) {
         const int tiles = tiles_m * (a.N / 256);
 #define CM_GEMM(SP, EP) hipLaunchKernelGGL((gemm_bf16_kernel<SP, EP, 256>), dim3(tiles), dim3(512), 0, s, a)
