@@ -71,6 +71,25 @@ def test_chain_long_context_and_bench_loop(trio):
     assert rel(outs[0][1], outs[1][1]) < 1e-4
 
 
+@pytest.mark.parametrize("ctx", [2500, 5000])
+def test_chain_context_beyond_the_prefetched_chunks(ctx):
+    """whole-token mode: a workgroup prefetches 4 K/V chunks per layer (contexts up to 2048); longer contexts walk the rest
+    in the generic two-chunks-per-iteration loop -- same tokens and logits as the launch path"""
+    cfg = configs.get_config("eng-qwen3")
+    outs = []
+    for engine in (1, -1):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=ctx + 128, max_seqs=1, engine=engine)
+        try:
+            m.debug_fill_kv(ctx, seed=5)
+            toks, _ = m.bench_decode(5, 12)
+            lg = m.forward_step([7], ctx + 12)[0, 0]
+            outs.append(([int(t) for t in toks], lg))
+        finally:
+            m.close()
+    assert outs[0][0] == outs[1][0]
+    assert rel(outs[0][1], outs[1][1]) < 1e-4
+
+
 def test_engine_refused_when_shapes_do_not_fit():
     from crane_amd._lib import CraneError
     cfg = configs.get_config("tiny-qwen3")               # hidden 256: not a multiple of 2048
