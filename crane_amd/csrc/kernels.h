@@ -164,10 +164,10 @@ struct GemvBArgs {
     int ns = 0, dshift = 0, gate_stride = 0;
 };
 int gemvb_grid(int N, int K, int num_cu);
-// matrix-core variant (kernels_decode_mfma.hip): <= 8 sequences
+// matrix-core variant (kernels_decode_mfma.hip): <= 32 sequences (2 / 4 groups of <= 8 above 8)
 bool gemvm_ok(int epi, int n_seq, int K);
 int gemvm_nkt(int K);
-int gemvm_grid(int N, int K, int num_cu);
+int gemvm_grid(int N, int K, int num_cu, int n_seq = 1);
 void launch_gemvm(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
 void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
 

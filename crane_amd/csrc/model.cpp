@@ -237,6 +237,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_QUANT_PREFILL")) quant_prefill = atoi(e) != 0;
     no_prefill = getenv("CM_NO_PREFILL") != nullptr;
     if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
+    if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)MAXB, atoi(e) / 8 * 8));
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
@@ -1122,7 +1123,7 @@ void Model::ensure_batch_buffers() {
     part_ob = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     if (rccl) yb = dalloc<float>((size_t)MAXB * H);
-    int g = std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu));
+    int g = std::max(std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu)), gemvm_grid(cfg.V, H, num_cu, MAXB));
     if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu));
     if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * I_l);
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
@@ -1144,8 +1145,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     hipStream_t s = stream;
     const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
-    for (size_t g0 = 0; g0 < n; g0 += MAXB) {
-        const int nb = (int)std::min<size_t>(MAXB, n - g0);
+    // sequences per pass over the weights: up to 32 on the bf16 matrix-core GEMVs (groups of 8 share the stream through the
+    // L2), 8 on the VALU / quantised kernels
+    const size_t gsz = (use_mfma_gemv && !quantized) ? (size_t)batch_max : (size_t)8;
+    for (size_t g0 = 0; g0 < n; g0 += gsz) {
+        const int nb = (int)std::min<size_t>(gsz, n - g0);
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
         int64_t longest = 0;
         for (int b = 0; b < nb; ++b) longest = std::max(longest, seq(sq[g0 + b]).len + 1);
@@ -1172,7 +1176,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             g.eps = cfg.eps;
             if (use_mfma_gemv && gemvm_ok(epi, nb, K)) {       // sequences as MFMA rows: the weight stream is the only cost
                 if (gemvm_nkt(K) > 1 && epi == EPI_STORE) CM_HIP(hipMemsetAsync(y, 0, (size_t)nb * ldy * sizeof(float), s));
-                launch_gemvm(pro, epi, g, gemvm_grid(N, K, num_cu), s);
+                launch_gemvm(pro, epi, g, gemvm_grid(N, K, num_cu, nb), s);
                 return;
             }
             launch_gemvb(pro, epi, g, gemvb_grid(N, K, num_cu), s);
@@ -1191,7 +1195,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     else CM_HIP(hipMemsetAsync(yb, 0, (size_t)nb * H * sizeof(float), s));
                     epi = EPI_STORE;
                 }
-                launch_gemvm(PRO_PLAIN, epi, g, gemvm_grid(H, K, num_cu), s);
+                launch_gemvm(PRO_PLAIN, epi, g, gemvm_grid(H, K, num_cu, nb), s);
             } else {
                 launch_gemvb(PRO_PLAIN, carry ? EPI_RESADD : EPI_STORE, g, gemvb_grid(H, K, num_cu), s);
             }
@@ -1311,7 +1315,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
             g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab; g.pidx = pidxb + (size_t)rank * slab; g.idx_base = v0;
             const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nb, H);
-            lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu) : gemvb_grid(v_eff, H, num_cu);
+            lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu, nb) : gemvb_grid(v_eff, H, num_cu);
             if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
             else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
         }
