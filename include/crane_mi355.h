@@ -245,10 +245,10 @@ int cm_seq_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size
 
 /* step_batch_decode (backend.rs:107-121, modeling.rs:1202-1234): one token
  * for each of `n` sequences at their own positions, no padding, no mask.
- * logits_out [n, vocab] (or NULL), greedy_out [n] (or NULL).  Up to 8 sequences
- * share one pass over the weights (bf16, and quantised weights in the default
- * integer-dot mode; under tensor parallelism when tp_size divides vocab_size);
- * the remaining combinations decode one sequence at a time. */
+ * logits_out [n, vocab] (or NULL), greedy_out [n] (or NULL).  Up to 32 sequences
+ * share one pass over bf16 weights, up to 8 over quantised weights in the default
+ * integer-dot mode (larger n: in groups; under tensor parallelism when tp_size
+ * divides vocab_size); the remaining combinations decode one sequence at a time. */
 int cm_decode_batch(cm_model* m, const int32_t* seqs, const uint32_t* last_tokens, size_t n,
                     float* logits_out, uint32_t* greedy_out);
 
