@@ -164,7 +164,7 @@ struct GemvBArgs {
     int ns = 0, dshift = 0, gate_stride = 0;
 };
 int gemvb_grid(int N, int K, int num_cu);
-// matrix-core variant (kernels_decode_mfma.hip): <= 32 sequences (2 / 4 groups of <= 8 above 8)
+// matrix-core variant (kernels_decode_mfma.hip): <= 64 sequences (2 / 4 / 8 groups of <= 8 above 8)
 bool gemvm_ok(int epi, int n_seq, int K);
 int gemvm_nkt(int K);
 int gemvm_grid(int N, int K, int num_cu, int n_seq = 1);

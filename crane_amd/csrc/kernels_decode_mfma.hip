@@ -38,11 +38,11 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     float* fsc = (float*)(xl + GM_MB * GM_LD);     // [GM_MB] 1/rms per sequence, then arg-max scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, N = a.N;
-    // 9..32 sequences: 2 or 4 GROUPS of <= 8 share the weight stream through the L2 -- block ids (8 ngrp) k + 8 g + j (j < 8)
+    // 9..64 sequences: 2, 4 or 8 GROUPS of <= 8 share the weight stream through the L2 -- block ids (8 ngrp) k + 8 g + j (j < 8)
     // are the logical block 8 k + j of group g: the blocks that stream the same weight rows are dispatched back to back onto
     // the SAME XCD (block b runs on XCD b % 8), so the later readers of a line find it in that XCD's L2 and HBM is read once
     // (measured through the engine, Qwen3-8B: 16 running sequences 1574 -> 2152 tok/s)
-    const int lg = a.n_seq > 2 * GM_MB ? 2 : (a.n_seq > GM_MB ? 1 : 0), ngrp = 1 << lg;
+    const int lg = a.n_seq > 4 * GM_MB ? 3 : (a.n_seq > 2 * GM_MB ? 2 : (a.n_seq > GM_MB ? 1 : 0)), ngrp = 1 << lg;
     const int grp = ((int)blockIdx.x >> 3) & (ngrp - 1);
     const int lblk = ((int)blockIdx.x >> (3 + lg)) * 8 + ((int)blockIdx.x & 7);
     const int nlb = (int)gridDim.x >> lg;
@@ -279,12 +279,12 @@ __global__ __launch_bounds__(512, 1) void gemvm_kernel(GemvBArgs a, int nkt) {
     }
 }
 
-// usable: 3..32 sequences (9..32: 2 / 4 groups of <= 8 share the weight stream through the L2) (measured on Qwen3-8B, ms/step VALU gemvb vs this kernel: 2 seq 4.12 / 4.51, 4 seq 4.88 / 4.73,
+// usable: 3..64 sequences (9..64: 2 / 4 / 8 groups of <= 8 share the weight stream through the L2) (measured on Qwen3-8B, ms/step VALU gemvb vs this kernel: 2 seq 4.12 / 4.51, 4 seq 4.88 / 4.73,
 // 8 seq 7.85 / 5.27), K % 8 == 0, and no K split for the epilogues that need complete sums
 bool gemvm_ok(int epi, int n_seq, int K) {
     static int min_seq = -1;
     if (min_seq < 0) { min_seq = 3; if (const char* e = getenv("CM_GEMVM_MIN")) min_seq = atoi(e); }
-    if (n_seq < min_seq || n_seq > 4 * GM_MB || K % 8 != 0) return false;
+    if (n_seq < min_seq || n_seq > 8 * GM_MB || K % 8 != 0) return false;
     const int nkt = (K + GM_KT - 1) / GM_KT;
     return nkt == 1 || epi == EPI_STORE || epi == EPI_RESADD;
 }
@@ -295,8 +295,8 @@ int gemvm_grid(int N, int K, int num_cu, int n_seq) {
         const int per = std::max(1, std::min((G + GM_W - 1) / GM_W, std::max(1, num_cu / nkt)));
         return per * nkt;
     }
-    // 2 / 4 sequence groups: 1 / ngrp of the CUs per group; logical blocks per group a multiple of 8 (the id mapping) and of nkt
-    const int ngrp = n_seq > 2 * GM_MB ? 4 : 2;
+    // 2 / 4 / 8 sequence groups: 1 / ngrp of the CUs per group; logical blocks per group a multiple of 8 (the id mapping) and of nkt
+    const int ngrp = n_seq > 4 * GM_MB ? 8 : (n_seq > 2 * GM_MB ? 4 : 2);
     int per = std::max(1, std::min((G + GM_W - 1) / GM_W, std::max(1, num_cu / ngrp / nkt)));
     while ((per * nkt) % 8 != 0) ++per;
     return ngrp * per * nkt;

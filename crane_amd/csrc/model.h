@@ -219,8 +219,8 @@ struct Model {
     uint32_t* h_ids = nullptr;
 
     // batched decode scratch (<= 8 sequences per step)
-    static constexpr int MAXB = 32;            // sequences of one batched step (2 / 4 groups of 8 on the matrix-core GEMVs)
-    int batch_max = 32;                        // CM_BATCH_MAX = 8 | 16 | 32 (A/B)
+    static constexpr int MAXB = 64;            // sequences of one batched step (2 / 4 / 8 groups of 8 on the matrix-core GEMVs)
+    int batch_max = 64;                        // CM_BATCH_MAX = 8 | 16 | 32 | 64 (A/B)
     StepState* stb = nullptr;          // device [MAXB]
     StepState* h_stb = nullptr;        // pinned [MAXB]
     int32_t* d_btb = nullptr;          // device [MAXB][max_pages_per_seq]
@@ -251,7 +251,7 @@ struct Model {
     void topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out);
     uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false, float* dev_logits = nullptr);
     // pipelined form for the engine's decode rounds: enqueue one row per slot (own scratch, no host sync), then ONE sync
-    static constexpr int SAMPLE_SLOTS = 32;    // = MAXB: every sampled row of a batched group has its own slot
+    static constexpr int SAMPLE_SLOTS = 64;    // = MAXB: every sampled row of a batched group has its own slot
     void sample_enqueue(int slot, const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div, float* dev_logits);
     void sample_collect(int n_slots, uint32_t* tokens_out);
     unsigned long long* tk_cand_rows = nullptr; size_t tk_cand_row_cap = 0;

@@ -245,7 +245,7 @@ int cm_seq_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size
 
 /* step_batch_decode (backend.rs:107-121, modeling.rs:1202-1234): one token
  * for each of `n` sequences at their own positions, no padding, no mask.
- * logits_out [n, vocab] (or NULL), greedy_out [n] (or NULL).  Up to 32 sequences
+ * logits_out [n, vocab] (or NULL), greedy_out [n] (or NULL).  Up to 64 sequences
  * share one pass over bf16 weights, up to 8 over quantised weights in the default
  * integer-dot mode (larger n: in groups; under tensor parallelism when tp_size
  * divides vocab_size); the remaining combinations decode one sequence at a time. */
