@@ -621,8 +621,28 @@ bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s)
 //   block = 512 threads (8 waves); LDS per sequence = Kpad codes + block scales (+ Kpad/8 code sums for K-quants)
 // ---------------------------------------------------------------------------------------------------------
 template <int FMT, int PRO, int EPI, int MB>
-__global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
+__global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a0) {
     using F = QF<FMT>;
+    // 9..64 sequences: 2 / 4 / 8 GROUPS of <= 8 share the stream of codes through the L2, exactly as the bf16 matrix-core
+    // GEMV does (kernels_decode_mfma.hip): block ids (8 ngrp) k + 8 g + j = logical block 8 k + j of group g, same XCD
+    GemvQBArgs a = a0;
+    const int lgq = a0.n_seq > 32 ? 3 : (a0.n_seq > 16 ? 2 : (a0.n_seq > 8 ? 1 : 0)), ngq = 1 << lgq;
+    const int gq = ((int)blockIdx.x >> 3) & (ngq - 1);
+    const int lblk = ngq > 1 ? ((int)blockIdx.x >> (3 + lgq)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    const int nlb = (int)gridDim.x >> lgq;
+    if (ngq > 1) {
+        a.x = a0.x + (size_t)gq * 8 * a0.ldx;
+        a.y = a0.y + (size_t)gq * 8 * a0.ldy;
+        a.res = a0.res == a0.y ? a.y : (a0.res != nullptr ? a0.res + (size_t)gq * 8 * a0.ldy : nullptr);
+        a.n_seq = max(0, min(8, a0.n_seq - gq * 8));
+        if (a.n_seq == 0) {                                   // padding group
+            if (EPI == EPI_ARGMAX && (int)threadIdx.x < a0.n_seq) {
+                a0.pmax[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = -INFINITY;
+                a0.pidx[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = 0x7FFFFFFF;
+            }
+            return;
+        }
+    }
     constexpr bool KQ = FMT != QFMT_Q8_0;
     // rows per wave: 4 for Q8_0 up to 4 sequences (halves the LDS reads per weight), 2 otherwise (measured: Q8_0 at 8
     // sequences 5.95 ms/step with 2 rows vs 6.67 with 4; the K-quants sit at the 256-VGPR budget with 2).  U chunks per
@@ -640,8 +660,8 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
 
     const int lane_k = (FMT == QFMT_Q8_0) ? lane * 16 : (lane >> 3) * 256;
     const int G = (N + R - 1) / R;
-    const int gstride = gridDim.x * NW;
-    const int gfirst = blockIdx.x * NW + wave;
+    const int gstride = nlb * NW;
+    const int gfirst = lblk * NW + wave;
     QRow q[R][U], qn[R][U];
     // unconditional, clamped loads (see gemvq_i8_kernel): lanes / steps past K or N re-read in-bounds bytes whose
     // product is zero (codes, scales and code sums are zero past K) or that are never consumed
@@ -983,7 +1003,12 @@ __global__ __launch_bounds__(512, 2) void gemvqb_i8_kernel(GemvQBArgs a) {
             float bb = red[tid]; int bbi = redi[tid];
             for (int w = 1; w < NW; ++w)
                 if (red[w * MB + tid] > bb || (red[w * MB + tid] == bb && redi[w * MB + tid] < bbi)) { bb = red[w * MB + tid]; bbi = redi[w * MB + tid]; }
-            a.pmax[(size_t)tid * gridDim.x + blockIdx.x] = bb; a.pidx[(size_t)tid * gridDim.x + blockIdx.x] = bbi;
+            a.pmax[(size_t)(gq * 8 + tid) * gridDim.x + blockIdx.x] = bb; a.pidx[(size_t)(gq * 8 + tid) * gridDim.x + blockIdx.x] = bbi;
+        }
+        // several groups: this block's column of the OTHER groups' rows must not win (argmax_final scans every column)
+        if (ngq > 1 && tid < ngq * 8 && (tid >> 3) != gq && tid < a0.n_seq) {
+            a.pmax[(size_t)tid * gridDim.x + blockIdx.x] = -INFINITY;
+            a.pidx[(size_t)tid * gridDim.x + blockIdx.x] = 0x7FFFFFFF;
         }
     }
 }
@@ -1005,7 +1030,12 @@ int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu) {
     // every block re-quantises the activation rows and the K-quant kernels hold > 128 VGPRs: one fat block per CU
     const int rows = (fmt == QFMT_Q8_0 && n_seq <= 4) ? 4 : 2;
     const int groups = (N + rows - 1) / rows;
-    return std::max(1, std::min((groups + 7) / 8, num_cu));
+    if (n_seq <= 8) return std::max(1, std::min((groups + 7) / 8, num_cu));
+    // 2 / 4 / 8 sequence groups: 1 / ngrp of the CUs each, logical blocks per group a multiple of 8 (the id mapping)
+    const int ngrp = n_seq > 32 ? 8 : (n_seq > 16 ? 4 : 2);
+    int per = std::max(1, std::min((groups + 7) / 8, std::max(8, num_cu / ngrp)));
+    per = (per + 7) / 8 * 8;
+    return ngrp * per;
 }
 
 template <int FMT, int MB>
@@ -1024,7 +1054,7 @@ static void launch_gemvqb_t(int pro, int epi, const GemvQBArgs& a, int grid, hip
 
 // n_seq <= gemvqb_max_seqs(fmt, K); the (prologue, epilogue) pairs the decoder uses
 bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s) {
-    if (a.n_seq < 1 || a.n_seq > 8) return false;
+    if (a.n_seq < 1 || a.n_seq > 64 || (a.n_seq > 8 && gemvqb_max_seqs(a.w.fmt, a.w.K) < 8)) return false;
 #define CM_QBF(F) { if (a.n_seq <= 4) launch_gemvqb_t<F, 4>(pro, epi, a, grid, s); else launch_gemvqb_t<F, 8>(pro, epi, a, grid, s); return true; }
     switch (a.w.fmt) {
         case QFMT_Q8_0: CM_QBF(QFMT_Q8_0)

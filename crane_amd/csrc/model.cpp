@@ -714,7 +714,7 @@ void Model::enqueue_decode_step(bool advance) {
             a.scale = (float)(1.0 / std::sqrt((double)D));
             if (attn_variant >= 2) {
                 if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-            } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+            } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
             if (!launch_engine(engine_args(li), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
         }
         enqueue_lm_head(advance);
@@ -761,7 +761,7 @@ void Model::enqueue_decode_step(bool advance) {
             if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
         } else if (attn_variant >= 2) {      // bf16 KV: matrix-core flash-decode (32 token splits, 64 for long contexts)
             if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-        } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         // (3) o_proj + residual
         g = GemvArgs{};
         g.W = w.o; g.x = attn; g.N = H; g.K = Hq_l * D; g.ldw = g.K;
@@ -828,7 +828,7 @@ void Model::enqueue_quant_layer(int li) {
         a.scale = (float)(1.0 / std::sqrt((double)D));
         if (attn_variant >= 2) {
             if (!launch_attn_decode_mfma(a, D, nrep, attn_variant == 3 ? nsplit_mfma : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-        } else if (!launch_attn_decode(a, D, nrep, nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+        } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : nsplit, kv_mode, attn, 0, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
         if (!rccl) qg(PRO_PLAIN, EPI_RESADD, w.q_o, attn, nullptr, x, x);
         else {       // row-parallel: partial sums over this rank's heads, rank 0 carries the residual
             qg(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, w.q_o, attn, nullptr, y, x);
@@ -1124,7 +1124,7 @@ void Model::ensure_batch_buffers() {
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     if (rccl) yb = dalloc<float>((size_t)MAXB * H);
     int g = std::max(std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu)), gemvm_grid(cfg.V, H, num_cu, MAXB));
-    if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu));
+    if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu)), gemvqb_grid(q_lm_head.fmt, cfg.V, H, 8, num_cu));
     if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * I_l);
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
@@ -1147,13 +1147,15 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     // sequences per pass over the weights: up to 32 on the bf16 matrix-core GEMVs (groups of 8 share the stream through the
     // L2), 8 on the VALU / quantised kernels
-    const size_t gsz = (use_mfma_gemv && !quantized) ? (size_t)batch_max : (size_t)8;
+    // (8 where a VALU batched GEMV is part of the step: bf16 without the matrix-core kernel, and the hybrid family's quantised
+    // layers, whose a / b gate rows stay bf16)
+    const size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
     for (size_t g0 = 0; g0 < n; g0 += gsz) {
         const int nb = (int)std::min<size_t>(gsz, n - g0);
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
         int64_t longest = 0;
         for (int b = 0; b < nb; ++b) longest = std::max(longest, seq(sq[g0 + b]).len + 1);
-        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && kv_mode < CM_KV_INT8;
+        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && kv_mode < CM_KV_INT8 && nb <= 8;
         for (int b = 0; b < nb; ++b) {
             const int sidx = sq[g0 + b];
             Seq& q = seq(sidx);
@@ -1206,10 +1208,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy) {
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
-            for (int m0 = 0; m0 < nb; m0 += cap) {
+            const int stepq = cap == 8 ? (int)MAXB : cap;          // 8-sequence kernels take up to 64 (L2-sharing groups of 8)
+            for (int m0 = 0; m0 < nb; m0 += stepq) {
                 GemvQBArgs q{};
                 q.w = qw; q.x = xin + (size_t)m0 * ldx; q.nw = nw; q.y = y + (size_t)m0 * ldy; q.res = q.y;
-                q.n_seq = std::min(cap, nb - m0); q.ldx = ldx; q.ldy = ldy; q.eps = cfg.eps;
+                q.n_seq = std::min(stepq, nb - m0); q.ldx = ldx; q.ldy = ldy; q.eps = cfg.eps;
                 const int grid = gemvqb_grid(qw.fmt, qw.N, qw.K, q.n_seq, num_cu);
                 if (!launch_gemvqb(pro, epi, q, grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
             }
@@ -1219,10 +1222,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             const bool carry = rank == 0 || rccl->fake;
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
-            for (int m0 = 0; m0 < nb; m0 += cap) {
+            const int stepq = cap == 8 ? (int)MAXB : cap;
+            for (int m0 = 0; m0 < nb; m0 += stepq) {
                 GemvQBArgs q{};
                 q.w = qw; q.x = xin + (size_t)m0 * ldx; q.y = yb + (size_t)m0 * H; q.res = xb + (size_t)m0 * H;
-                q.n_seq = std::min(cap, nb - m0); q.ldx = ldx; q.ldy = H; q.eps = cfg.eps;
+                q.n_seq = std::min(stepq, nb - m0); q.ldx = ldx; q.ldy = H; q.eps = cfg.eps;
                 const int grid = gemvqb_grid(qw.fmt, qw.N, qw.K, q.n_seq, num_cu);
                 if (!launch_gemvqb(PRO_PLAIN, carry ? EPI_RESADD : EPI_STORE, q, grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
             }
@@ -1274,7 +1278,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
                     const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                } else if (!launch_attn_decode(a, D, nrep, std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols);
                 else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }
@@ -1301,13 +1305,14 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         if (quantized && q_lm_head.fmt != QFMT_NONE) {
             const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
-            lmg = gemvqb_grid(q_lm_head.fmt, v_eff, H, std::min(cap, nb), num_cu);
-            for (int m0 = 0; m0 < nb; m0 += cap) {
+            const int stepq = cap == 8 ? (int)MAXB : cap;
+            lmg = gemvqb_grid(q_lm_head.fmt, v_eff, H, std::min(stepq, nb), num_cu);
+            for (int m0 = 0; m0 < nb; m0 += stepq) {
                 GemvQBArgs q{};
                 q.w = q_lm_head.rows(0, v_eff); q.x = xb + (size_t)m0 * H; q.nw = norm;
                 q.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l; q.res = q.y;
                 q.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lmg; q.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lmg;
-                q.idx_base = v0; q.n_seq = std::min(cap, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
+                q.idx_base = v0; q.n_seq = std::min(stepq, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
                 if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
             }
         } else {

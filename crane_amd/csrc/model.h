@@ -307,6 +307,7 @@ struct Model {
     int64_t attn_mfma_min = 768;   // contexts of at least this many tokens use the MFMA kernel (CM_ATTN_MFMA_MIN; 0 = never);
                                    // Qwen3-8B ms/token split vs MFMA(32 splits): 256: 3.056 / 3.068, 1 K: 3.11 / 3.085, 4 K: 3.44 / 3.26
     int attn_ns = 2;               // token splits per head of variant 1
+    int attn_splits_force = 0;     // cm_debug_set("attn_splits"): one split count for the single AND the batched VALU attention (tests)
     int64_t attn_heads_max = 0;    // contexts up to this many tokens use variant 1 (CM_ATTN_HEADS_MAX; 0 = never: measured
                                    // slower on MI355X at every context tried)
     bool use_graph = true;

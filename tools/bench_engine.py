@@ -10,11 +10,13 @@ model = sys.argv[1] if len(sys.argv) > 1 else "qwen3-8b"
 N, P, G = (int(x) for x in (sys.argv[2:5] + ["32", "128", "128"][len(sys.argv[2:5]):]))
 SPC = int(sys.argv[5]) if len(sys.argv) > 5 else 1          # scheduler steps per native call (cm_engine_step_many)
 MAXR = [int(x) for x in sys.argv[6].split(',')] if len(sys.argv) > 6 else [1, 8]      # max_running values to run
+ISQ = sys.argv[7] if len(sys.argv) > 7 else None                                        # in-situ quantisation ("q8_0", "q4_k")
 cfg = configs.get_config(model)
-m = Model.synthetic(cfg, seed=0, max_seq_len=P + G + 64, max_seqs=max(MAXR) + 1)
+m = Model.synthetic(cfg, seed=0, max_seq_len=P + G + 64, max_seqs=max(MAXR) + 1, **({"isq": ISQ} if ISQ else {}))
 V = cfg["vocab_size"]
-for label, params in [("greedy", GenerationParams.greedy(G)),
-                      ("server defaults (T 0.8, top_p 0.95, top_k 40, rep 1.05)", GenerationParams(max_tokens=G))]:
+MODES = [("greedy", GenerationParams.greedy(G)),
+         ("server defaults (T 0.8, top_p 0.95, top_k 40, rep 1.05)", GenerationParams(max_tokens=G))]
+for label, params in (MODES[:1] if ISQ else MODES):
     for max_running in MAXR:
         eng = InferenceEngine(m, max_running=max_running, seed=1)
         for j in range(N):
