@@ -200,6 +200,14 @@ def main():
         tp0 = time.perf_counter(); m.forward_step_greedy(ids, 0); tp1 = time.perf_counter()
         prefill = {"tokens": 1024, "ms": round((tp1 - tp0) * 1e3, 3), "tokens_per_s": round(1024 / (tp1 - tp0), 1),
                    "activations": "bf16x2 split (parity mode)"}
+        # the same prompt with plain bf16 activations (one MFMA per product: the arithmetic of a bf16 GPU forward of the
+        # reference; logits move by ~5e-3, outside the 1e-3 bar, so it is an option, not the default)
+        m.debug_set("prefill_split", 1)
+        m.clear_kv_cache(); m.forward_step_greedy(ids, 0); m.clear_kv_cache()
+        barrier()
+        tp0 = time.perf_counter(); m.forward_step_greedy(ids, 0); tp1 = time.perf_counter()
+        m.debug_set("prefill_split", 0)
+        prefill["plain_bf16"] = {"ms": round((tp1 - tp0) * 1e3, 3), "tokens_per_s": round(1024 / (tp1 - tp0), 1)}
     except Exception as e:
         prefill = {"error": str(e)}
 
