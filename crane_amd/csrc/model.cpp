@@ -237,6 +237,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_QUANT_PREFILL")) quant_prefill = atoi(e) != 0;
     no_prefill = getenv("CM_NO_PREFILL") != nullptr;
     if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
+    if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, atoi(e));
     if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)MAXB, atoi(e) / 8 * 8));
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
@@ -1150,12 +1151,30 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     // (8 where a VALU batched GEMV is part of the step: bf16 without the matrix-core kernel, and the hybrid family's quantised
     // layers, whose a / b gate rows stay bf16)
     const size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
+    // batch_gemm_min or more sequences (bf16 dense family, one rank): the four projections of a layer run as the prompt pass's
+    // MFMA GEMMs over the nb rows (M = nb, split-K; activations as bf16 hi + lo like the parity-mode prompt, whatever
+    // cm_opts.prefill_split says) -- from ~17 sequences on the batched GEMVs are issue-bound, the GEMM still streams the
+    // weights once.  Rows then differ from the single-sequence step by the GEMM's summation order (~1e-6), not bit for bit.
+    bool gemm_b_ok = false;
+    if (!quantized && !rccl && !cfg.hybrid && batch_gemm_min > 0 && n >= (size_t)batch_gemm_min) {
+        ensure_prefill_buffers();
+        gemm_b_ok = prefill_ok;
+    }
     for (size_t g0 = 0; g0 < n; g0 += gsz) {
         const int nb = (int)std::min<size_t>(gsz, n - g0);
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
         int64_t longest = 0;
         for (int b = 0; b < nb; ++b) longest = std::max(longest, seq(sq[g0 + b]).len + 1);
         const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && kv_mode < CM_KV_INT8 && nb <= 8;
+        const bool gemm_b = gemm_b_ok && nb >= batch_gemm_min && nb <= chunk;
+        // y[nb, N] (+)= A[nb, K] . W^T through launch_gemm; A = the bf16 hi + lo rows produced by rows_in
+        auto gm = [&](int epi, const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, float* C, int ldc, int N, int K) {
+            GemmArgs g{};
+            g.ws = pWS; g.ws_floats = gemm_ws_floats;
+            g.A_hi = A_hi; g.A_lo = A_lo; g.W = W; g.C = C; g.ldc = ldc; g.M = nb; g.N = N; g.K = K;
+            g.H_hi = pHH_hi; g.H_lo = pHH_lo;
+            if (!launch_gemm(g, epi, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+        };
         for (int b = 0; b < nb; ++b) {
             const int sidx = sq[g0 + b];
             Seq& q = seq(sidx);
@@ -1257,7 +1276,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
                 if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
-                else gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
+                else if (gemm_b) {
+                    launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+                    gm(GEPI_STORE, pXN_hi, pXN_lo, w.qkv, qkvb, ldq, qkv_rows, H);
+                } else gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
                 AttnDecArgs a{};
                 a.qkv = qkvb; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = stb; a.block_table = d_btb;
                 a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_ob; a.part_ml = part_mlb;
@@ -1280,7 +1302,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols);
-                else rp(w.o, attnb, (int)at_cols, Hq_l * D);
+                else if (gemm_b) {
+                    launch_split_rows(attnb, pAT_hi, pAT_lo, (size_t)nb * at_cols, s);        // dense family: at_cols = Hq_l * D
+                    gm(GEPI_RESADD, pAT_hi, pAT_lo, w.o, xb, H, H, Hq_l * D);
+                } else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }
             }
             if (quantized) {
@@ -1292,6 +1317,12 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     launch_silu_mul(gu_tmpb, gu_tmpb + I_l, hbb, I_l, s, nb, 2 * I_l, I_l);
                 }
                 qrp(w.q_down, hbb, I_l);
+                continue;
+            }
+            if (gemm_b) {
+                launch_rmsnorm_rows(xb, w.ln2, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+                gm(GEPI_SILUMUL, pXN_hi, pXN_lo, w.gate_up, nullptr, 0, 2 * I_l, H);         // -> pHH_hi / pHH_lo
+                gm(GEPI_RESADD, pHH_hi, pHH_lo, w.down, xb, H, H, I_l);
                 continue;
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);

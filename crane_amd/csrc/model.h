@@ -221,6 +221,7 @@ struct Model {
     // batched decode scratch (<= 8 sequences per step)
     static constexpr int MAXB = 64;            // sequences of one batched step (2 / 4 / 8 groups of 8 on the matrix-core GEMVs)
     int batch_max = 64;                        // CM_BATCH_MAX = 8 | 16 | 32 | 64 (A/B)
+    int batch_gemm_min = 17;                   // CM_BATCH_GEMM_MIN: batched decode of this many sequences or more runs its projections as MFMA GEMMs (0 = never)
     StepState* stb = nullptr;          // device [MAXB]
     StepState* h_stb = nullptr;        // pinned [MAXB]
     int32_t* d_btb = nullptr;          // device [MAXB][max_pages_per_seq]

@@ -392,7 +392,9 @@ int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x
 /* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at
  * cm_create).  "no_prefill" = 1: prompts run token by token through the decode kernels; "quant_prefill" = 0: prompts over
  * quantised weights run through the integer-dot decode kernels instead of the dequantised MFMA GEMMs; "prefill_split" = 1 / 0:
- * cm_opts.prefill_split of the live model (plain bf16 / bf16 hi + lo prompt activations); "attn_splits" = n > 0:
+ * cm_opts.prefill_split of the live model (plain bf16 / bf16 hi + lo prompt activations); "batch_gemm_min" = n: cm_decode_batch
+ * runs the projections of n or more sequences as MFMA GEMMs (0 = never: batched GEMVs, rows bit-equal to cm_forward_step);
+ * "attn_splits" = n > 0:
  * the VALU decode attention uses n token splits per kv head in the single AND the batched step (their automatic counts differ,
  * which changes the order of the split merge), 0 = automatic. */
 int cm_debug_set(cm_model* m, const char* key, int64_t value);

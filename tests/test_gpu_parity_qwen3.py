@@ -333,6 +333,39 @@ def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
             m.close()
 
 
+@pytest.mark.parametrize("nseq", [17, 40, 64])
+def test_batched_decode_gemm_path_against_gemv_path(nseq):
+    """From 17 sequences on cm_decode_batch runs the projections as MFMA GEMMs over the rows of the batch (M = nseq,
+    split-K) instead of the batched matrix-core GEMVs.  The same step through both paths (the step is taken back with
+    cm_seq_truncate in between): logits agree to the summation order of two bf16 hi + lo products, tokens are equal."""
+    cfg = configs.get_config("tiny-qwen3-untied")
+    V = cfg["vocab_size"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=nseq + 2, kv_dtype="f32")
+    try:
+        seqs, lens = [], []
+        for i in range(nseq):
+            n = 2 + (7 * i) % 45
+            s = m.seq_alloc()
+            m.seq_forward(s, [(13 * i + 5 * k + 1) % V for k in range(n)], 0, want_logits=False)
+            seqs.append(s); lens.append(n)
+        toks = [(3 + 2 * i) % V for i in range(nseq)]
+        for step in range(2):
+            m.debug_set("batch_gemm_min", 0)
+            lg_v, gr_v = m.step_batch_decode(seqs, toks)
+            for s_, n_ in zip(seqs, lens):
+                m.seq_truncate(s_, n_ + step)              # take the step back: the GEMM path appends the same K / V rows
+            m.debug_set("batch_gemm_min", 17)
+            lg_m, gr_m = m.step_batch_decode(seqs, toks)
+            assert not np.array_equal(lg_m, lg_v)          # (the other path did run)
+            for i in range(nseq):
+                assert rel(lg_m[i, 0], lg_v[i, 0]) < 1e-4, (step, i)
+                assert m.seq_len(seqs[i]) == lens[i] + step + 1
+            assert [int(t) for t in gr_m] == [int(t) for t in gr_v]
+            toks = [int(t) for t in gr_m]
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("name", ["tiny-qwen3-untied", "tiny-qwen3.5"])
 @pytest.mark.parametrize("heads_max,ns", [(0, 2), (4096, 1), (4096, 2), (4096, 4), (150, 2)])
 def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
