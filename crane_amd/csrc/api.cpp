@@ -231,7 +231,7 @@ int cm_decode_batch(cm_model* h, const int32_t* seqs, const uint32_t* last_token
     if (!h) return CM_ERR_INVALID;
     return guard(h, [&] {
         if (!seqs || !last_tokens || n == 0) throw CmError(CM_ERR_INVALID, "empty batch");
-        // One pass over the weights for up to 8 sequences at a time (kernels_decode_batch.hip); a single sequence, and
+        // One pass over the weights for a group of sequences (Model::decode_batch: up to 128 / 64 / 8); a single sequence, and
         // the combinations the batched step does not cover (quantised weights with f32 activations, TP with a vocabulary
         // that does not divide), take the ordinary decode path one sequence at a time.
         const size_t V = (size_t)h->m.cfg.V;

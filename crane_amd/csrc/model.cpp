@@ -237,8 +237,8 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_QUANT_PREFILL")) quant_prefill = atoi(e) != 0;
     no_prefill = getenv("CM_NO_PREFILL") != nullptr;
     if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
-    if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, atoi(e));
-    if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)MAXB, atoi(e) / 8 * 8));
+    if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, std::min((int)GEMV_MAXB, atoi(e)));
+    if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)GEMV_MAXB, atoi(e) / 8 * 8));
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
@@ -1124,8 +1124,8 @@ void Model::ensure_batch_buffers() {
     part_ob = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_mlb = dalloc<float>((size_t)MAXB * Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     if (rccl) yb = dalloc<float>((size_t)MAXB * H);
-    int g = std::max(std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu)), gemvm_grid(cfg.V, H, num_cu, MAXB));
-    if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, MAXB, num_cu)), gemvqb_grid(q_lm_head.fmt, cfg.V, H, 8, num_cu));
+    int g = std::max(std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu)), gemvm_grid(cfg.V, H, num_cu, GEMV_MAXB));
+    if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, GEMV_MAXB, num_cu)), gemvqb_grid(q_lm_head.fmt, cfg.V, H, 8, num_cu));
     if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * I_l);
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
@@ -1150,7 +1150,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     // L2), 8 on the VALU / quantised kernels
     // (8 where a VALU batched GEMV is part of the step: bf16 without the matrix-core kernel, and the hybrid family's quantised
     // layers, whose a / b gate rows stay bf16)
-    const size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
+    size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
     // batch_gemm_min or more sequences (bf16 dense family, one rank): the four projections of a layer run as the prompt pass's
     // MFMA GEMMs over the nb rows (M = nb, split-K; activations as bf16 hi + lo like the parity-mode prompt, whatever
     // cm_opts.prefill_split says) -- from ~17 sequences on the batched GEMVs are issue-bound, the GEMM still streams the
@@ -1159,6 +1159,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     if (!quantized && !rccl && !cfg.hybrid && batch_gemm_min > 0 && n >= (size_t)batch_gemm_min) {
         ensure_prefill_buffers();
         gemm_b_ok = prefill_ok;
+        // one 128-row M tile costs the GEMM what 64 rows cost: groups of up to MAXB (batch_gemm_min <= GEMV_MAXB, so a group
+        // beyond the GEMV kernels' 64 always takes the GEMM path)
+        if (gemm_b_ok && use_mfma_gemv) gsz = std::max(gsz, std::min<size_t>((size_t)MAXB, (size_t)chunk));
     }
     for (size_t g0 = 0; g0 < n; g0 += gsz) {
         const int nb = (int)std::min<size_t>(gsz, n - g0);
@@ -1227,7 +1230,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy) {
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
-            const int stepq = cap == 8 ? (int)MAXB : cap;          // 8-sequence kernels take up to 64 (L2-sharing groups of 8)
+            const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;          // 8-sequence kernels take up to 64 (L2-sharing groups of 8)
             for (int m0 = 0; m0 < nb; m0 += stepq) {
                 GemvQBArgs q{};
                 q.w = qw; q.x = xin + (size_t)m0 * ldx; q.nw = nw; q.y = y + (size_t)m0 * ldy; q.res = q.y;
@@ -1241,7 +1244,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             const bool carry = rank == 0 || rccl->fake;
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
-            const int stepq = cap == 8 ? (int)MAXB : cap;
+            const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;
             for (int m0 = 0; m0 < nb; m0 += stepq) {
                 GemvQBArgs q{};
                 q.w = qw; q.x = xin + (size_t)m0 * ldx; q.y = yb + (size_t)m0 * H; q.res = xb + (size_t)m0 * H;
@@ -1336,7 +1339,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         if (quantized && q_lm_head.fmt != QFMT_NONE) {
             const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
-            const int stepq = cap == 8 ? (int)MAXB : cap;
+            const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;
             lmg = gemvqb_grid(q_lm_head.fmt, v_eff, H, std::min(stepq, nb), num_cu);
             for (int m0 = 0; m0 < nb; m0 += stepq) {
                 GemvQBArgs q{};
@@ -1347,13 +1350,21 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
             }
         } else {
-            GemvBArgs g{};
-            g.W = lm_head; g.x = xb; g.nw = norm; g.y = logitsb + (size_t)rank * V_l; g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nb;
-            g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab; g.pidx = pidxb + (size_t)rank * slab; g.idx_base = v0;
-            const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nb, H);
-            lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu, nb) : gemvb_grid(v_eff, H, num_cu);
-            if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
-            else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+            // (more than GEMV_MAXB rows -- GEMM path, one rank -- take the matrix-core GEMV in two passes, each with its own
+            // grid and arg-max reduction)
+            for (int m0 = 0; m0 < nb; m0 += GEMV_MAXB) {
+                const int nc = std::min((int)GEMV_MAXB, nb - m0);
+                GemvBArgs g{};
+                g.W = lm_head; g.x = xb + (size_t)m0 * H; g.nw = norm; g.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l;
+                g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nc;
+                g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lm_gridb; g.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lm_gridb;
+                g.idx_base = v0;
+                const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nc, H);
+                lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu, nc) : gemvb_grid(v_eff, H, num_cu);
+                if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+                else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+                if (nb > GEMV_MAXB) launch_argmax_final(g.pmax, g.pidx, lmg, stb + m0, ring, RING - 1, 0, nc, s);
+            }
         }
         if (rccl && !rccl->fake) {
             rccl->all_gather(pmaxb + (size_t)rank * slab, pmaxb, slab * sizeof(float), s);
@@ -1362,7 +1373,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             if (logits_out || after_group)         // full rows only when somebody reads them (host copy / device sampler)
                 for (int b = 0; b < nb; ++b)
                     rccl->all_gather(logitsb + (size_t)b * cfg.V + (size_t)rank * V_l, logitsb + (size_t)b * cfg.V, (size_t)V_l * sizeof(float), s);
-        } else {
+        } else if (nb <= GEMV_MAXB) {
             launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
         }
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));

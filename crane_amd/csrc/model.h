@@ -219,7 +219,8 @@ struct Model {
     uint32_t* h_ids = nullptr;
 
     // batched decode scratch (<= 8 sequences per step)
-    static constexpr int MAXB = 64;            // sequences of one batched step (2 / 4 / 8 groups of 8 on the matrix-core GEMVs)
+    static constexpr int MAXB = 128;           // sequences of one batched step: one 128-row M tile of the MFMA GEMM projections
+    static constexpr int GEMV_MAXB = 64;       // ... on the batched GEMVs (2 / 4 / 8 L2-sharing groups of 8)
     int batch_max = 64;                        // CM_BATCH_MAX = 8 | 16 | 32 | 64 (A/B)
     int batch_gemm_min = 17;                   // CM_BATCH_GEMM_MIN: batched decode of this many sequences or more runs its projections as MFMA GEMMs (0 = never)
     StepState* stb = nullptr;          // device [MAXB]
@@ -252,7 +253,7 @@ struct Model {
     void topk(const float* host_logits, size_t n, uint32_t k, uint32_t* idx_out, float* val_out);
     uint32_t sample(const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div = false, float* dev_logits = nullptr);
     // pipelined form for the engine's decode rounds: enqueue one row per slot (own scratch, no host sync), then ONE sync
-    static constexpr int SAMPLE_SLOTS = 64;    // = MAXB: every sampled row of a batched group has its own slot
+    static constexpr int SAMPLE_SLOTS = 128;    // = MAXB: every sampled row of a batched group has its own slot
     void sample_enqueue(int slot, const cm_sample_params& p, const uint32_t* ctx, size_t n_ctx, bool true_div, float* dev_logits);
     void sample_collect(int n_slots, uint32_t* tokens_out);
     unsigned long long* tk_cand_rows = nullptr; size_t tk_cand_row_cap = 0;

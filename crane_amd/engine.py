@@ -55,7 +55,7 @@ class InferenceEngine:
         if rc != 0:
             raise _lib.CraneError(rc, "cm_engine_create failed")
         self._h = h
-        self._ev = (_lib.CmEngineEvent * 256)()
+        self._ev = (_lib.CmEngineEvent * 2048)()          # room for 8 scheduler steps of 128 running sequences per native call
 
     def close(self):
         if self._h:

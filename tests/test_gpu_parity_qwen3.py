@@ -333,7 +333,7 @@ def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
             m.close()
 
 
-@pytest.mark.parametrize("nseq", [17, 40, 64])
+@pytest.mark.parametrize("nseq", [17, 40, 64, 65, 100, 128])
 def test_batched_decode_gemm_path_against_gemv_path(nseq):
     """From 17 sequences on cm_decode_batch runs the projections as MFMA GEMMs over the rows of the batch (M = nseq,
     split-K) instead of the batched matrix-core GEMVs.  The same step through both paths (the step is taken back with
