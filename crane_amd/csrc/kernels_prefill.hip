@@ -229,15 +229,18 @@ __device__ __forceinline__ int gemm_swz(int row) { return (4 - ((row >> 2) & 3))
 // the activation tile (hi + lo: twice the bytes of a weight tile) is fetched and written to LDS once for 256 output columns
 // instead of once per 128: a third less L2 -> CU traffic per flop (the waves of the 128-wide kernel spend ~39 % of their
 // cycles waiting for global loads).
-template <int SPLIT, int EPI, int BN>
+// BM = 64 (BN = 128 only; launch_gemm: M <= 64 -- the rows of a large decode batch, very short prompts): the two wave rows
+// take 32 rows each, half the activation tile and half the MFMAs of a tile whose upper 64 rows would be padding.
+template <int SPLIT, int EPI, int BN, int BM = 128>
 __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
+    constexpr int WM = BM / 2, NI = WM / 16;                            // rows per wave row, 16-row MFMA tiles of them
     constexpr int GBN = BN, NT = BN * 2, NWC = BN / 64;                 // threads, wave columns
-    constexpr int LA = (GBM * 4) / NT, LB = (GBN * 4) / NT;             // 16-byte loads per thread, k-tile and operand
-    __shared__ __attribute__((aligned(16))) uint16_t As[2][SPLIT][GBM * GLD];
+    constexpr int LA = (BM * 4) / NT, LB = (GBN * 4) / NT;             // 16-byte loads per thread, k-tile and operand
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][SPLIT][BM * GLD];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[2][GBN * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / NWC, wc = wave % NWC;
-    const int tiles_m = (a.M + GBM - 1) / GBM;
+    const int tiles_m = (a.M + BM - 1) / BM;
     // XCD-aware order: blocks that share a weight tile (same n-tile, different m-tile) get
     // consecutive logical ids AND the same XCD (hardware places block b on XCD b % 8)
     // split-K (a.ksplit > 1; short prompts: one or two m-tiles leave most CUs idle and every block walks all of K as one
@@ -248,12 +251,12 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
     int bid = (int)blockIdx.x % nb;
     if (nb % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;
     const int tn = bid / tiles_m, tm = bid % tiles_m;
-    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int m0 = tm * BM, n0 = tn * GBN;
     const int K = a.K;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -300,12 +303,12 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfrag[j] = *(const bf16x8*)&Bs[buf][(wc * 64 + j * 16 + fr) * GLD + fk];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16x8 ah = *(const bf16x8*)&As[buf][0][(wr * 64 + i * 16 + fr) * GLD + fk];
+        for (int i = 0; i < NI; ++i) {
+            const bf16x8 ah = *(const bf16x8*)&As[buf][0][(wr * WM + i * 16 + fr) * GLD + fk];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfrag[j], acc[i][j], 0, 0, 0);
             if (SPLIT == 2) {
-                const bf16x8 al = *(const bf16x8*)&As[buf][SPLIT - 1][(wr * 64 + i * 16 + fr) * GLD + fk];
+                const bf16x8 al = *(const bf16x8*)&As[buf][SPLIT - 1][(wr * WM + i * 16 + fr) * GLD + fk];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfrag[j], acc[i][j], 0, 0, 0);
             }
@@ -332,12 +335,12 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
     if (EPI == GEPI_PARTIAL) {
         float* P = a.ws + (size_t)ks * a.M * a.N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    const int m = m0 + wr * WM + i * 16 + (lane >> 4) * 4 + r;
                     if (m < a.M) P[(size_t)m * a.N + n0 + wc * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
                 }
         return;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
         for (int j = 0; j < 4; ++j) bv[j] = a.bias[n0 + wc * 64 + j * 16 + (lane & 15)];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         // residual add: the 16 old values of this row band are requested in ONE batch from clamped (always valid)
         // addresses -- a load under the `m < M` guard is followed by vmcnt(0), i.e. 64 serial round trips per lane
         float cold[4][4];
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = min(m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r, a.M - 1);
+                    const int m = min(m0 + wr * WM + i * 16 + (lane >> 4) * 4 + r, a.M - 1);
                     cold[j][r] = a.C[(size_t)m * a.ldc + n0 + wc * 64 + j * 16 + (lane & 15)];
                 }
         }
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
             const int n = n0 + wc * 64 + j * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wr * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int m = m0 + wr * WM + i * 16 + (lane >> 4) * 4 + r;
                 float v = acc[i][j][r];
                 if (a.bias != nullptr) v += bv[j];
                 if (EPI == GEPI_STORE) {
@@ -671,6 +674,11 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     const int tiles = tiles_m * (a.N / 128);
     a.ksplit = a.ws != nullptr ? gemm_ksplit(a.M, a.N, tiles, a.K / GBK, a.ws_floats) : 1;
     if (a.ksplit > 1) {
+        static const int bm_env = getenv("CM_GEMM_BM") ? atoi(getenv("CM_GEMM_BM")) : 0;       // 128: never the 64-row tile (A/B)
+        if (a.M <= 64 && bm_env != 128) {        // one m-tile of <= 64 rows: the 64 x 128 tile (same block count, same partial layout)
+            if (split) hipLaunchKernelGGL((gemm_bf16_kernel<2, GEPI_PARTIAL, 128, 64>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<1, GEPI_PARTIAL, 128, 64>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
+        } else
         if (split) hipLaunchKernelGGL((gemm_bf16_kernel<2, GEPI_PARTIAL, 128>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_bf16_kernel<1, GEPI_PARTIAL, 128>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
         const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);

@@ -1,6 +1,6 @@
 """Serving-loop throughput of the continuous-batching engine (cm_engine_*): N requests, prompt P, G generated tokens,
 on synthetic Qwen3-8B.  Prints generated tokens/s over the whole run (prefills included)."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 from crane_amd import configs
 from crane_amd.backend import Model
@@ -16,7 +16,7 @@ m = Model.synthetic(cfg, seed=0, max_seq_len=P + G + 64, max_seqs=max(MAXR) + 1,
 V = cfg["vocab_size"]
 MODES = [("greedy", GenerationParams.greedy(G)),
          ("server defaults (T 0.8, top_p 0.95, top_k 40, rep 1.05)", GenerationParams(max_tokens=G))]
-for label, params in (MODES[:1] if ISQ else MODES):
+for label, params in (MODES[:1] if ISQ or os.environ.get("BENCH_GREEDY") else MODES):     # BENCH_GREEDY=1: greedy runs only
     for max_running in MAXR:
         eng = InferenceEngine(m, max_running=max_running, seed=1)
         for j in range(N):
