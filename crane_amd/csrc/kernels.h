@@ -134,6 +134,7 @@ void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, int kv_mode, hipSt
 void launch_kvq_dequant_prefix(const void* kpool, const void* vpool, const int32_t* block_table, float* kshadow, float* vshadow,
                                int tokens, int Hkv, int page, int D, int kv_mode, size_t page_bytes, hipStream_t s);
 void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hipStream_t s);
+void launch_split_rows2d(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int rows, int cols, hipStream_t s);   // cols % 4 == 0, ldx % 4 == 0
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s);

@@ -196,6 +196,16 @@ __global__ void split_rows_kernel(const float* __restrict__ x, uint16_t* __restr
     }
 }
 
+// the same for `rows` rows of `cols` columns that sit ldx floats apart (batched decode: the attention / GDN output rows)
+__global__ void split_rows2d_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int cols) {
+    const float* xr = x + (size_t)blockIdx.x * ldx;
+    for (int c = threadIdx.x * 4; c < cols; c += blockDim.x * 4) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        const float o[4] = {v[0], v[1], v[2], v[3]};
+        split_store4(hi, lo, (size_t)blockIdx.x * cols + c, o);
+    }
+}
+
 __global__ void add_rows_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 a = ((const f32x4*)x)[i];
@@ -591,6 +601,9 @@ void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hip
     const size_t n4 = n / 4;
     int blocks = (int)std::min<size_t>((n4 + 255) / 256, 4096);
     hipLaunchKernelGGL(split_rows_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, x, hi, lo, n4);
+}
+void launch_split_rows2d(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(split_rows2d_kernel, dim3(rows), dim3(256), 0, s, x, ldx, hi, lo, cols);
 }
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s) {
     const size_t n4 = n / 4;

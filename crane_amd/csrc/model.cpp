@@ -1151,12 +1151,12 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     // (8 where a VALU batched GEMV is part of the step: bf16 without the matrix-core kernel, and the hybrid family's quantised
     // layers, whose a / b gate rows stay bf16)
     size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
-    // batch_gemm_min or more sequences (bf16 dense family, one rank): the four projections of a layer run as the prompt pass's
+    // batch_gemm_min or more sequences (bf16 weights, one rank): the four projections of a layer run as the prompt pass's
     // MFMA GEMMs over the nb rows (M = nb, split-K; activations as bf16 hi + lo like the parity-mode prompt, whatever
     // cm_opts.prefill_split says) -- from ~17 sequences on the batched GEMVs are issue-bound, the GEMM still streams the
     // weights once.  Rows then differ from the single-sequence step by the GEMM's summation order (~1e-6), not bit for bit.
     bool gemm_b_ok = false;
-    if (!quantized && !rccl && !cfg.hybrid && batch_gemm_min > 0 && n >= (size_t)batch_gemm_min) {
+    if (!quantized && !rccl && batch_gemm_min > 0 && n >= (size_t)batch_gemm_min) {
         ensure_prefill_buffers();
         gemm_b_ok = prefill_ok;
         // one 128-row M tile costs the GEMM what 64 rows cost: groups of up to MAXB (batch_gemm_min <= GEMV_MAXB, so a group
@@ -1265,6 +1265,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.W = w.in_proj_ba; g.x = xb; g.nw = w.ln1; g.y = qkvb + qz; g.res = g.y; g.N = 2 * cfg.NV; g.K = H; g.ldw = H;
                     g.ldx = H; g.ldy = ldq; g.n_seq = nb; g.eps = cfg.eps;
                     launch_gemvb(PRO_RMSNORM, EPI_STORE, g, gemvb_grid(g.N, g.K, num_cu), s);
+                } else if (gemm_b) {
+                    launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+                    gm(GEPI_STORE, pXN_hi, pXN_lo, w.in_proj, qkvb, ldq, in_proj_pad, H);      // (rows padded to 128 with zero weights)
                 } else
                 gb(PRO_RMSNORM, EPI_STORE, w.in_proj, xb, H, w.ln1, qkvb, ldq, in_proj_rows, H);
                 GdnArgs ga{};
@@ -1276,7 +1279,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
                 launch_gdn(ga, s);
                 if (quantized) qrp(w.q_out_proj, attnb, (int)at_cols);
-                else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
+                else if (gemm_b) {
+                    launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, cfg.value_dim(), s);
+                    gm(GEPI_RESADD, pAT_hi, pAT_lo, w.out_proj, xb, H, H, cfg.value_dim());
+                } else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
                 if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
                 else if (gemm_b) {
@@ -1306,7 +1312,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols);
                 else if (gemm_b) {
-                    launch_split_rows(attnb, pAT_hi, pAT_lo, (size_t)nb * at_cols, s);        // dense family: at_cols = Hq_l * D
+                    launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);
                     gm(GEPI_RESADD, pAT_hi, pAT_lo, w.o, xb, H, H, Hq_l * D);
                 } else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }

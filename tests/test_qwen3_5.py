@@ -189,6 +189,45 @@ def test_hip_qwen35_batched_decode():
 
 
 @pytest.mark.gpu
+def test_hip_qwen35_batched_decode_gemm_path():
+    """24 hybrid sequences in one batched step: from 17 sequences on the projections (in_proj / out_proj of the GDN layers,
+    QKV / o_proj of the gated-attention layers, the MLP) run as MFMA GEMMs over the batch rows.  Every row against its own
+    oracle, and against a twin set of sequences stepped through the batched-GEMV path."""
+    from crane_amd.backend import Model
+    g, cfg, w = _load()
+    V = cfg["vocab_size"]
+    nseq = 24
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2 * nseq + 2, kv_dtype="f32")
+    try:
+        oracles, sa, sb, lens = [], [], [], []
+        for i in range(nseq):
+            n = 2 + (5 * i) % 37
+            ids = [(13 * i + 7 * k + 3) % V for k in range(n)]
+            if i % 6 == 0:                                  # (the numpy oracle is slow: every sixth row is checked against it)
+                o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+                o.forward(ids, 0)
+                oracles.append((i, o))
+            for dst in (sa, sb):
+                s_ = m.seq_alloc(); m.seq_forward(s_, ids, 0, want_logits=False); dst.append(s_)
+            lens.append(n)
+        toks = [(5 + 3 * i) % V for i in range(nseq)]
+        for step in range(2):
+            m.debug_set("batch_gemm_min", 0)
+            lg_v, gr_v = m.step_batch_decode(sa, toks)
+            m.debug_set("batch_gemm_min", 17)
+            lg_m, gr_m = m.step_batch_decode(sb, toks)
+            assert not np.array_equal(lg_m, lg_v)
+            for i in range(nseq):
+                assert rel(lg_m[i, 0], lg_v[i, 0]) < 1e-4, (step, i)
+            for i, o in oracles:
+                assert rel(lg_m[i, 0], o.forward([toks[i]], lens[i] + step)) < 1e-4, (step, i)
+            assert [int(t) for t in gr_m] == [int(t) for t in gr_v]
+            toks = [int(t) for t in gr_m]
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
 def test_hip_qwen38_27b_geometry():
     """Real Qwen3.8-27B layer geometry (qwen3_5/config.rs:298-324: H 5120, 24q/4kv x 256, 16 key / 48 value GDN heads,
     I 17408) with 4 layers and a small vocabulary so the CPU oracle stays fast -- the analogue of the reference's
