@@ -1151,17 +1151,18 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     // (8 where a VALU batched GEMV is part of the step: bf16 without the matrix-core kernel, and the hybrid family's quantised
     // layers, whose a / b gate rows stay bf16)
     size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
-    // batch_gemm_min or more sequences (bf16 weights, one rank): the four projections of a layer run as the prompt pass's
+    // batch_gemm_min or more sequences (bf16 weights): the four projections of a layer run as the prompt pass's
     // MFMA GEMMs over the nb rows (M = nb, split-K; activations as bf16 hi + lo like the parity-mode prompt, whatever
     // cm_opts.prefill_split says) -- from ~17 sequences on the batched GEMVs are issue-bound, the GEMM still streams the
     // weights once.  Rows then differ from the single-sequence step by the GEMM's summation order (~1e-6), not bit for bit.
     bool gemm_b_ok = false;
-    if (!quantized && !rccl && batch_gemm_min > 0 && n >= (size_t)batch_gemm_min) {
+    if (!quantized && batch_gemm_min > 0 && n >= (size_t)batch_gemm_min) {
         ensure_prefill_buffers();
         gemm_b_ok = prefill_ok;
         // one 128-row M tile costs the GEMM what 64 rows cost: groups of up to MAXB (batch_gemm_min <= GEMV_MAXB, so a group
         // beyond the GEMV kernels' 64 always takes the GEMM path)
-        if (gemm_b_ok && use_mfma_gemv) gsz = std::max(gsz, std::min<size_t>((size_t)MAXB, (size_t)chunk));
+        // (tensor parallelism: groups stay at GEMV_MAXB, the size the sharded lm_head's gather is laid out for)
+        if (gemm_b_ok && use_mfma_gemv && !rccl) gsz = std::max(gsz, std::min<size_t>((size_t)MAXB, (size_t)chunk));
     }
     for (size_t g0 = 0; g0 < n; g0 += gsz) {
         const int nb = (int)std::min<size_t>(gsz, n - g0);
@@ -1177,6 +1178,16 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             g.A_hi = A_hi; g.A_lo = A_lo; g.W = W; g.C = C; g.ldc = ldc; g.M = nb; g.N = N; g.K = K;
             g.H_hi = pHH_hi; g.H_lo = pHH_lo;
             if (!launch_gemm(g, epi, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+        };
+        // row-parallel projection + residual into xb; TP: partial sums over this rank's K slice in yb (rank 0 carries the
+        // residual), one all-reduce for all nb rows -- the arrangement of rp above
+        auto gmr = [&](const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, int K) {
+            if (!rccl) { gm(GEPI_RESADD, A_hi, A_lo, W, xb, H, H, K); return; }
+            if (rank == 0 || rccl->fake) {
+                CM_HIP(hipMemcpyAsync(yb, xb, (size_t)nb * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+                gm(GEPI_RESADD, A_hi, A_lo, W, yb, H, H, K);
+            } else gm(GEPI_STORE, A_hi, A_lo, W, yb, H, H, K);
+            rccl->all_reduce_sum_f32(yb, xb, (size_t)nb * H, s);
         };
         for (int b = 0; b < nb; ++b) {
             const int sidx = sq[g0 + b];
@@ -1281,7 +1292,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (quantized) qrp(w.q_out_proj, attnb, (int)at_cols);
                 else if (gemm_b) {
                     launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, cfg.value_dim(), s);
-                    gm(GEPI_RESADD, pAT_hi, pAT_lo, w.out_proj, xb, H, H, cfg.value_dim());
+                    gmr(pAT_hi, pAT_lo, w.out_proj, cfg.value_dim());
                 } else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
                 if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
@@ -1313,7 +1324,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols);
                 else if (gemm_b) {
                     launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);
-                    gm(GEPI_RESADD, pAT_hi, pAT_lo, w.o, xb, H, H, Hq_l * D);
+                    gmr(pAT_hi, pAT_lo, w.o, Hq_l * D);
                 } else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }
             }
@@ -1331,7 +1342,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             if (gemm_b) {
                 launch_rmsnorm_rows(xb, w.ln2, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
                 gm(GEPI_SILUMUL, pXN_hi, pXN_lo, w.gate_up, nullptr, 0, 2 * I_l, H);         // -> pHH_hi / pHH_lo
-                gm(GEPI_RESADD, pHH_hi, pHH_lo, w.down, xb, H, H, I_l);
+                gmr(pHH_hi, pHH_lo, w.down, I_l);
                 continue;
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);

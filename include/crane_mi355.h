@@ -246,10 +246,11 @@ int cm_seq_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size
 /* step_batch_decode (backend.rs:107-121, modeling.rs:1202-1234): one token
  * for each of `n` sequences at their own positions, no padding, no mask.
  * logits_out [n, vocab] (or NULL), greedy_out [n] (or NULL).  Up to 128 sequences
- * share one pass over bf16 weights on one rank (17 or more: the
- * projections run as MFMA GEMMs over the batch rows), up to 64 elsewhere (quantised
- * weights in the default integer-dot mode, tensor parallelism when tp_size divides
- * vocab_size), up to 8 for the hybrid family's quantised layers; larger n: in groups;
+ * share one pass over bf16 weights on one rank (17 or more, also under tensor
+ * parallelism: the projections run as MFMA GEMMs over the batch rows), up to 64
+ * elsewhere (quantised weights in the default integer-dot mode, tensor parallelism
+ * when tp_size divides vocab_size), up to 8 for the hybrid family's quantised layers;
+ * larger n: in groups;
  * the remaining combinations decode one sequence at a time. */
 int cm_decode_batch(cm_model* m, const int32_t* seqs, const uint32_t* last_tokens, size_t n,
                     float* logits_out, uint32_t* greedy_out);

@@ -91,7 +91,7 @@ def test_dense_rank_shards_isq_q8_0(monkeypatch):
 
 
 @pytest.mark.parametrize("name,nb,isq", [("tiny-qwen3-untied", 2, None), ("tiny-qwen3-untied", 5, None), ("tiny-qwen3.5", 3, None),
-                                         ("tiny-qwen3-untied", 5, "q8_0")])
+                                         ("tiny-qwen3-untied", 5, "q8_0"), ("tiny-qwen3-untied", 21, None), ("tiny-qwen3.5", 19, None)])
 def test_batched_decode_on_a_rank(name, nb, isq):
     """cm_decode_batch under TP: the row-parallel projections of all sequences go through ONE all-reduce per layer and the
     vocabulary-sharded lm_head through one gather.  With CM_DEBUG_TP_LOCAL a rank's batched step must agree with its own
@@ -103,13 +103,13 @@ def test_batched_decode_on_a_rank(name, nb, isq):
     for rank in range(world):
         plan = tp.shard_plan(cfg, world, rank)
         v = slice(plan.vocab.start, plan.vocab.stop)
-        m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=12, kv_dtype="f32", tp_rank=rank, tp_size=world,
+        m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=nb + 2, kv_dtype="f32", tp_rank=rank, tp_size=world,
                             tp_unique_id=b"\0" * 128, isq=isq, debug_tp_local=True)
         try:
             seqs, toks = [], []
             for b in range(nb):
                 s = 0 if b == 0 else m.seq_alloc()
-                _, g = m.seq_forward(s, [(7 * i + 3 + 11 * b) % V for i in range(5 + 3 * b)], 0, want_logits=False)
+                _, g = m.seq_forward(s, [(7 * i + 3 + 11 * b) % V for i in range(5 + 3 * (b % 12))], 0, want_logits=False)
                 seqs.append(s); toks.append(int(g))
             for r in range(2):
                 want = []
@@ -120,7 +120,8 @@ def test_batched_decode_on_a_rank(name, nb, isq):
                     m.seq_free(f)
                 lg, greedy = m.step_batch_decode(seqs, toks)
                 for b in range(nb):
-                    assert rel(lg[b, 0][v], want[b][0]) < 3e-5, (rank, r, b)
+                    # (17+ sequences: the projections are MFMA GEMMs over the batch rows -- another summation order)
+                    assert rel(lg[b, 0][v], want[b][0]) < (3e-5 if nb < 17 else 1e-4), (rank, r, b)
                     assert int(greedy[b]) == want[b][1]
                 toks = [int(g) for g in greedy]
         finally:
