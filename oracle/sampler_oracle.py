@@ -4,7 +4,8 @@ Follows crane-serve/src/engine/sampling.rs:
   apply_penalties      :422-478  (distinct-token counts; multiplicative repetition penalty first -- candle's
                                   `Tensor / f64` is a multiply by (f32)(1/rp) -- then count*freq + presence subtracted)
   topk_indices         crane-core/src/ops (CPU fallback = stable sort, value descending / index ascending;
-                       pinned by crane-core/tests/rocm_kernels.rs:86-200)
+                       pinned by crane-core/tests/rocm_kernels.rs:86-200 and, bit for bit, on the reference's own
+                       top-k kernels built into oracle/_ref/ -- tests/test_gpu_ref_kernels.py)
   sample               :169-373  (greedy at temperature <= 0; top_k==0 with top_p -> 64; top_k = min(top_k, 64, vocab);
                                   softmax(topk/T), cumsum, keep i if cumsum[i] <= p or cumsum[i-1] <= p; Gumbel-max)
   sample_gumbel_max_idx:382-392  (u ~ U(1e-7, 0.999), argmax(logits/T - log(-log u)))
