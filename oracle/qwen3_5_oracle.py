@@ -20,7 +20,7 @@ Follows (paths under /root/reference/crane-core/src):
 Text-only path: the three MRoPE position components are equal, so cos/sin are plain table rows.
 Pinned by HF transformers ``Qwen3_5ForCausalLM`` on identical synthetic weights
 (tests/golden/qwen3_5_*.npz) -- HF is what the reference claims bit-exact arg-max parity with
-(reference README.md:402-404) -- and by the reference's own KATs replayed in tests/test_oracle_kat_qwen35.py; the
+(reference README.md:402-404) -- and by the reference's own KATs replayed in tests/test_oracle_kat.py and tests/test_qwen3_5.py; the
 recurrence `gated_delta_rule` is additionally pinned on the reference's fused GPU kernel itself (kernels/cuda/gdn.cu built
 into oracle/_ref/ by oracle/build_ref.sh; tests/test_gpu_ref_kernels.py, 2e-5).
 Parity unpinned: matmul/softmax summation order, arg-max tie-break (as for qwen3).
