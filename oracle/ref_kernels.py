@@ -46,6 +46,11 @@ class _Hip:
         L.hipFree.argtypes = [C.c_void_p]
         L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        L.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        L.hipEventSynchronize.argtypes = [C.c_void_p]
+        L.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        L.hipEventDestroy.argtypes = [C.c_void_p]
         self.ck(L.hipSetDevice(0))
 
     def ck(self, rc):
@@ -87,12 +92,31 @@ class _Hip:
         for p in ptrs:
             self.lib.hipFree(p)
 
-    def launch(self, fn, grid, block, shared, args):
+    def launch(self, fn, grid, block, shared, args, sync=True):
         """args: ctypes scalars / c_void_p device pointers, passed by address like the reference's `arg(&x)` list."""
         arr = (C.c_void_p * len(args))(*[C.cast(C.pointer(a), C.c_void_p) for a in args])
         gx, gy = (grid if isinstance(grid, tuple) else (grid, 1))
         self.ck(self.lib.hipModuleLaunchKernel(fn, gx, gy, 1, block, 1, 1, shared, None, arr, None))
-        self.ck(self.lib.hipDeviceSynchronize())
+        if sync:
+            self.ck(self.lib.hipDeviceSynchronize())
+
+    def time_launches(self, fn, grid, block, shared, args, iters, warmup=3) -> float:
+        """Average microseconds per launch of `iters` back-to-back launches on the null stream (HIP events)."""
+        L = self.lib
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        self.ck(L.hipEventCreate(C.byref(e0))); self.ck(L.hipEventCreate(C.byref(e1)))
+        for _ in range(warmup):
+            self.launch(fn, grid, block, shared, args, sync=False)
+        self.ck(L.hipDeviceSynchronize())
+        self.ck(L.hipEventRecord(e0, None))
+        for _ in range(iters):
+            self.launch(fn, grid, block, shared, args, sync=False)
+        self.ck(L.hipEventRecord(e1, None))
+        self.ck(L.hipEventSynchronize(e1))
+        ms = C.c_float(0)
+        self.ck(L.hipEventElapsedTime(C.byref(ms), e0, e1))
+        L.hipEventDestroy(e0); L.hipEventDestroy(e1)
+        return float(ms.value) * 1e3 / iters
 
 
 class RefKernels:
@@ -131,6 +155,28 @@ class RefKernels:
             return h.to_host(dy, (BH, S, V), np.float32), h.to_host(dso, (BH, K, V), np.float32)
         finally:
             h.free(dq, dk, dv, dg, db, ds, dy, dso)
+
+    def time_gdn_recurrence(self, BH, S, K=128, V=128, iters=20) -> float:
+        """Microseconds per launch of the reference recurrence on bin/gdn_bench.rs-style inputs (state in != state out)."""
+        r = np.random.default_rng(0)
+        q = (r.standard_normal((BH, S, K)) / math.sqrt(K)).astype(np.float32)
+        k = r.standard_normal((BH, S, K)).astype(np.float32)
+        k /= np.linalg.norm(k, axis=-1, keepdims=True)
+        v = r.standard_normal((BH, S, V)).astype(np.float32)
+        g = (0.01 * r.standard_normal((BH, S)) - 0.05).astype(np.float32)
+        beta = (1.0 / (1.0 + np.exp(-r.standard_normal((BH, S))))).astype(np.float32)
+        h = self.hip
+        dq, dk, dv, dg, db = (h.to_device(a) for a in (q, k, v, g, beta))
+        ds, dso, dy = h.alloc(BH * K * V * 4), h.alloc(BH * K * V * 4), h.alloc(BH * S * V * 4)
+        args = [dq, dk, dv, dg, db, ds, dso, dy, C.c_int(BH), C.c_int(S)]
+        fn = self.f_gdn_k128
+        if K != 128:
+            args.append(C.c_int(K)); fn = self.f_gdn
+        args += [C.c_int(V), C.c_int(V)]
+        try:
+            return h.time_launches(fn, BH, V, 2 * K * 4, args, iters)
+        finally:
+            h.free(dq, dk, dv, dg, db, ds, dso, dy)
 
     def topk_indices(self, x, k):
         """Indices of the k largest values of the 1-D f32 vector x: value descending, index ascending."""

@@ -102,3 +102,22 @@ def test_topk_ties_signed_zeros_and_awkward_lengths(ref, model):
         want = ref.topk_indices(x, k)
         np.testing.assert_array_equal(S.topk_indices(x, k), want, err_msg=f"oracle n={x.size} k={k}")
         np.testing.assert_array_equal(model.topk(k, x)[0], want, err_msg=f"cm_topk n={x.size} k={k}")
+
+
+def test_reference_gdn_kernel_timing_report(ref):
+    """Not a parity check: the reference's fused recurrence timed on the MI355X at the shapes of the committed rocprof profiles
+    of crane_amd's own GDN kernels (profiles/README.md), so the two can be read side by side.  Written to
+    gpurun_out/ref_gdn_timing.json when that directory exists; the assertion only guards against a dead kernel."""
+    import json, os
+    rows = []
+    for name, BH, S_ in [("qwen3.5-0.8b decode step", 16, 1), ("qwen3.8-27b decode step", 48, 1),
+                         ("qwen3.5-0.8b 1024-token prompt", 16, 1024), ("qwen3.8-27b 1024-token prompt", 48, 1024),
+                         ("bin/gdn_bench.rs shape", 16, 512)]:
+        us = ref.time_gdn_recurrence(BH, S_, iters=50 if S_ == 1 else 5)
+        rows.append({"case": name, "BH": BH, "S": S_, "K": 128, "V": 128, "kernel": "gdn_recurrence_f32_k128 (reference gdn.cu)",
+                     "us_per_launch": round(us, 2)})
+        assert 0.0 < us < 1e6
+    print(json.dumps(rows, indent=1))
+    if os.path.isdir("gpurun_out"):
+        with open(os.path.join("gpurun_out", "ref_gdn_timing.json"), "w") as f:
+            json.dump(rows, f, indent=1)
