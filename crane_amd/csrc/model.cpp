@@ -1146,10 +1146,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     hipStream_t s = stream;
     const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
-    // sequences per pass over the weights: up to 32 on the bf16 matrix-core GEMVs (groups of 8 share the stream through the
-    // L2), 8 on the VALU / quantised kernels
-    // (8 where a VALU batched GEMV is part of the step: bf16 without the matrix-core kernel, and the hybrid family's quantised
-    // layers, whose a / b gate rows stay bf16)
+    // sequences per pass over the weights: up to batch_max (64) on the bf16 matrix-core GEMVs and the integer-dot quantised
+    // GEMVs (groups of 8 share the stream through the L2); 8 where a VALU batched GEMV is part of the step (bf16 without the
+    // matrix-core kernel, and the hybrid family's quantised layers, whose a / b gate rows stay bf16)
     size_t gsz = ((quantized && !cfg.hybrid) || (!quantized && use_mfma_gemv)) ? (size_t)batch_max : (size_t)8;
     // batch_gemm_min or more sequences (bf16 weights): the four projections of a layer run as the prompt pass's
     // MFMA GEMMs over the nb rows (M = nb, split-K; activations as bf16 hi + lo like the parity-mode prompt, whatever
