@@ -345,7 +345,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         if (k == "no_prefill") h->m.no_prefill = value != 0;
         else if (k == "quant_prefill") h->m.quant_prefill = value != 0;
         else if (k == "prefill_split") h->m.prefill_split2 = value != 1;
-        else if (k == "batch_gemm_min") h->m.batch_gemm_min = (int)std::max<long long>(0, std::min<long long>(value, 1 << 20));
+        else if (k == "batch_gemm_min") h->m.batch_gemm_min = (int)std::max<long long>(0, std::min<long long>(value, Model::GEMV_MAXB));   // a group beyond the GEMV kernels' 64 must take the GEMM path
         else if (k == "attn_splits") h->m.attn_splits_force = (int)std::max<long long>(0, std::min<long long>(value, h->m.nsplit));
         else throw CmError(CM_ERR_INVALID, "unknown debug switch");
     });
