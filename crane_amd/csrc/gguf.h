@@ -116,7 +116,9 @@ private:
                 if (depth > 2) throw std::runtime_error("GGUF array nesting too deep");
                 const uint32_t et = rd<uint32_t>();
                 const uint64_t n = rd<uint64_t>();
-                if (n > size_) throw std::runtime_error("bad GGUF array length");
+                // every element takes at least one byte of the file; 2^26 bounds the memory a hostile length can claim
+                // (real tokenizer arrays hold ~10^5 .. 10^6 entries)
+                if (n > size_ || n > (1ull << 26)) throw std::runtime_error("bad GGUF array length");
                 v.arr.reserve((size_t)std::min<uint64_t>(n, 1 << 20));
                 for (uint64_t i = 0; i < n; ++i) v.arr.push_back(rval(et, depth + 1));
                 break;

@@ -199,3 +199,36 @@ def test_gguf_hostile_tensor_directory(tmp_path):
     open(p, "wb").write(bytes(raw))
     with pytest.raises(_lib.CraneError, match="past the end"):
         gguf_config(p)
+
+
+def test_fuzzed_files_through_the_abi(tmp_path):
+    """3000 mutated GGUF / safetensors files (tests/fuzz_host_parsers.py: bit flips, boundary values in length / offset fields,
+    truncations, structured edits of the safetensors header) through cm_gguf_config / cm_checkpoint_inspect in a SUBPROCESS:
+    every file is answered with a status code; a crash or hang of the parser fails here instead of killing pytest."""
+    import os, subprocess, sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_host_parsers.py")
+    p = subprocess.run([sys.executable, script, "1", "3000", str(tmp_path / "w")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert "3000 files" in p.stdout
+
+
+def test_fuzzed_files_under_address_sanitizer(tmp_path):
+    """The same mutations against the two container parsers compiled with -fsanitize=address,undefined
+    (tests/fuzz_harness.cpp: mmap replaced by an exact-size heap copy, so one byte past the end of the file is a report)."""
+    import os, shutil, subprocess, sys
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "fuzz_harness")
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-I", os.path.join(here, "..", "crane_amd", "csrc"), os.path.join(here, "fuzz_harness.cpp"), "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and ("asan" in b.stderr.lower() or "sanitize" in b.stderr.lower()):
+        pytest.skip("g++ without the sanitizer runtimes")
+    assert b.returncode == 0, b.stderr[-3000:]
+    indir = str(tmp_path / "in")
+    e = subprocess.run([sys.executable, os.path.join(here, "fuzz_host_parsers.py"), "2", "3000", indir, "--emit"],
+                       capture_output=True, text=True, timeout=300)
+    assert e.returncode == 0, e.stderr[-2000:]
+    r = subprocess.run([exe, indir], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "3000 inputs, no sanitizer report" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
