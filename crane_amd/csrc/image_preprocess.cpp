@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -22,22 +23,25 @@ thread_local std::string g_pre_err;
 // processor.rs:64-88
 void smart_resize(uint32_t h, uint32_t w, uint32_t factor, uint64_t min_pixels, uint64_t max_pixels, uint32_t* ho, uint32_t* wo) {
     const double hf = (double)h, wf = (double)w;
+    // multiples of `factor` as a count q, clamped so that q * factor stays inside uint32 whatever the configuration says
+    // (the caller rejects a result it cannot hold; a hostile min_pixels must not become an out-of-range float -> int cast)
+    const double qmax = std::floor(4294967295.0 / (double)factor);
+    auto count = [&](double q) { return (uint32_t)(q < 0.0 || q != q ? 0.0 : (q > qmax ? qmax : q)); };
     auto round_by_factor = [&](double x) {
         // Rust's f64::round: half away from zero
         const double r = std::floor(x / (double)factor + 0.5);
-        uint32_t q = (uint32_t)(r < 1.0 ? 1.0 : r);
-        return q * factor;
+        return count(r < 1.0 ? 1.0 : r) * factor;
     };
     uint32_t hb = round_by_factor(hf), wb = round_by_factor(wf);
     const uint64_t area = (uint64_t)hb * (uint64_t)wb;
     if (area > max_pixels) {
         const double beta = std::sqrt(hf * wf / (double)max_pixels);
-        hb = (uint32_t)std::floor(hf / beta / (double)factor) * factor;
-        wb = (uint32_t)std::floor(wf / beta / (double)factor) * factor;
+        hb = count(std::floor(hf / beta / (double)factor)) * factor;
+        wb = count(std::floor(wf / beta / (double)factor)) * factor;
     } else if (area < min_pixels) {
         const double beta = std::sqrt((double)min_pixels / (hf * wf));
-        hb = (uint32_t)std::ceil(hf * beta / (double)factor) * factor;
-        wb = (uint32_t)std::ceil(wf * beta / (double)factor) * factor;
+        hb = count(std::ceil(hf * beta / (double)factor)) * factor;
+        wb = count(std::ceil(wf * beta / (double)factor)) * factor;
     }
     *ho = hb < factor ? factor : hb;
     *wo = wb < factor ? factor : wb;
@@ -130,6 +134,9 @@ std::vector<uint8_t> resize_bicubic(const uint8_t* src, int h, int w, int ho, in
 
 bool check_cfg(const cm_preproc_config* c) {
     if (!c || c->patch_size == 0 || c->temporal_patch_size == 0 || c->merge_size == 0 || c->max_pixels == 0) { g_pre_err = "bad preprocessor config"; return false; }
+    // bounds far above any real configuration (patch 14 / 16, temporal 2, merge 2): they keep patch_size * merge_size and the
+    // row length T * 3 * P^2 inside 32 bits
+    if (c->patch_size > 1024 || c->temporal_patch_size > 64 || c->merge_size > 64) { g_pre_err = "preprocessor config out of range"; return false; }
     for (int i = 0; i < 3; ++i) if (!(c->image_std[i] > 0.f)) { g_pre_err = "image_std must be positive"; return false; }
     return true;
 }
@@ -153,6 +160,8 @@ int cm_image_preprocess(const cm_preproc_config* cfg, const uint8_t* rgb, uint32
     const uint32_t P = cfg->patch_size, T = cfg->temporal_patch_size, M = cfg->merge_size;
     uint32_t hn = 0, wn = 0;
     smart_resize(height, width, P * M, cfg->min_pixels, cfg->max_pixels, &hn, &wn);
+    // 2^28 pixels (16384 x 16384) bounds what a configuration can make this call allocate
+    if ((uint64_t)hn * (uint64_t)wn > (1ull << 28)) { g_pre_err = "resized image too large (min_pixels / max_pixels out of range)"; return CM_ERR_RANGE; }
     const uint32_t hp = hn / P, wp = wn / P;
     const size_t n_patches = (size_t)hp * wp, in_dim = (size_t)T * 3 * P * P;
     grid_thw_out[0] = 1; grid_thw_out[1] = hp; grid_thw_out[2] = wp;
@@ -160,8 +169,14 @@ int cm_image_preprocess(const cm_preproc_config* cfg, const uint8_t* rgb, uint32
     if (pixel_values_out == nullptr || cap_floats == 0) return CM_OK;                 // size query
     if (cap_floats < n_patches * in_dim) { g_pre_err = "pixel_values buffer too small"; return CM_ERR_RANGE; }
     if (hp % M || wp % M) { g_pre_err = "resized grid is not a multiple of the merge size"; return CM_ERR_INVALID; }
-    std::vector<uint8_t> img = (hn == height && wn == width) ? std::vector<uint8_t>(rgb, rgb + (size_t)height * width * 3)
-                                                             : resize_bicubic(rgb, (int)height, (int)width, (int)hn, (int)wn);
+    std::vector<uint8_t> img;
+    try {
+        img = (hn == height && wn == width) ? std::vector<uint8_t>(rgb, rgb + (size_t)height * width * 3)
+                                            : resize_bicubic(rgb, (int)height, (int)width, (int)hn, (int)wn);
+    } catch (const std::exception& e) {                       // (bad_alloc must not cross the C ABI)
+        g_pre_err = std::string("image resize failed: ") + e.what();
+        return CM_ERR_OOM;
+    }
     // rows ordered (h block, w block, row in block, col in block): the 2x2 patches of a merge block are contiguous;
     // each row laid out (channel, temporal copy, y, x) -- processor.rs:150-196
     const size_t pp = (size_t)P * P;

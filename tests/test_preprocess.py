@@ -70,3 +70,33 @@ def test_errors_and_batching():
     pix, grid = batch_images([a, b])
     assert pix.shape == (16, 1536) and grid.tolist() == [[1, 2, 4], [1, 4, 2]]
     assert np.all(pix[:8] == -1.0) and np.all(pix[8:] == 1.0)
+
+
+def test_hostile_configurations_are_answered_with_a_status_code():
+    """preprocessor_config.json comes from the model directory: whatever it says, cm_image_preprocess / cm_image_smart_resize
+    return a status (no out-of-range float -> int cast, no allocation request the size of min_pixels, no exception across the
+    C ABI).  Run in a subprocess so that an abort would fail this test rather than pytest."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        from crane_amd import _lib
+        from crane_amd.processor import PreprocessorConfig
+        img = np.zeros((48, 80, 3), np.uint8)
+        answered = 0
+        for kw in [dict(shortest_edge=10**18), dict(shortest_edge=2**63), dict(shortest_edge=2**40, longest_edge=2**41),
+                   dict(longest_edge=1), dict(patch_size=2**31), dict(patch_size=65536, merge_size=65536), dict(merge_size=2**20),
+                   dict(temporal_patch_size=2**31), dict(patch_size=1024, merge_size=64, shortest_edge=2**50),
+                   dict(shortest_edge=3 * 10**8, longest_edge=4 * 10**8)]:
+            pc = PreprocessorConfig(**kw)
+            for call in (lambda: pc.smart_resize(48, 80), lambda: pc.process(img)):
+                try:
+                    call()
+                except _lib.CraneError:
+                    pass
+                answered += 1
+        ok = PreprocessorConfig(shortest_edge=16).process(img)          # and a sane one still works afterwards
+        assert ok[0].shape == (24, 1536) and ok[1] == (1, 4, 6), (ok[0].shape, ok[1])      # 48 x 80 -> 64 x 96 (nearest multiples of 32)
+        print("answered", answered)
+    """)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(__import__("pathlib").Path(__file__).parent.parent))
+    assert p.returncode == 0 and "answered 20" in p.stdout, (p.returncode, p.stdout[-1000:], p.stderr[-2000:])
