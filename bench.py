@@ -95,6 +95,7 @@ def main():
         import torch.distributed as dist
         if torch.cuda.device_count() < world:
             raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} visible device(s)")
+        torch.cuda.set_device(local_rank)       # torch.cuda.synchronize() below then waits on THIS rank's device
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from crane_amd import _lib
