@@ -100,3 +100,22 @@ def test_hostile_configurations_are_answered_with_a_status_code():
     """)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(__import__("pathlib").Path(__file__).parent.parent))
     assert p.returncode == 0 and "answered 20" in p.stdout, (p.returncode, p.stdout[-1000:], p.stderr[-2000:])
+
+
+def test_random_configurations_under_address_sanitizer(tmp_path):
+    """tests/fuzz_preprocess.cpp: 1500 random (configuration, image) pairs through cm_image_preprocess compiled with
+    -fsanitize=address,undefined, the output buffer sized exactly -- the resampling loops index three buffers by hand."""
+    import os, shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ppfuzz")
+    b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-I", os.path.join(root, "include"), os.path.join(root, "tests", "fuzz_preprocess.cpp"),
+                        os.path.join(root, "crane_amd", "csrc", "image_preprocess.cpp"), "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "sanitize" in b.stderr.lower():
+        pytest.skip("g++ without the sanitizer runtimes")
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe, "5", "1500"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "1500 ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
