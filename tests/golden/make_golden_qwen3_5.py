@@ -18,8 +18,13 @@ PROMPT_LEN, NEW = 19, 10
 
 def main():
     torch.set_num_threads(8)
-    for name in ("tiny-qwen3.5",):
-        cfg = configs.get_config(name)
+    # "qwen3.8-27b-geom4": the real Qwen3.8-27B layer geometry (H 5120, 24 q / 4 kv heads x 256, 16 key / 48 value GDN heads,
+    # I 17408) with 4 layers and a 4096-entry vocabulary -- the configuration of test_hip_qwen38_27b_geometry
+    for name in ("tiny-qwen3.5", "qwen3.8-27b-geom4"):
+        if name == "qwen3.8-27b-geom4":
+            cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+        else:
+            cfg = configs.get_config(name)
         w = synth.synth_weights_f32(cfg, seed=0)
         hc = Qwen3_5TextConfig(**{k: v for k, v in cfg.items()
                                   if k not in ("model_type", "torch_dtype", "full_attention_interval", "attn_output_gate")})

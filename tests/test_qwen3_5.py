@@ -82,6 +82,21 @@ def test_oracle_matches_hf_golden():
     assert o.generate(ids, len(g["greedy_tokens"]) - len(ids)) == g["greedy_tokens"].tolist()
 
 
+def test_oracle_matches_hf_golden_at_27b_geometry():
+    """The oracle against HF Qwen3_5ForCausalLM at the REAL Qwen3.8-27B layer geometry (qwen3_5/config.rs:298-324: n_rep 6,
+    3 value heads per key head, head_dim 256 with 64 rotary dims, K = 5120 / 17408), 4 layers and a 4096-entry vocabulary --
+    the configuration the HIP path is compared with the oracle on in test_hip_qwen38_27b_geometry.  (~1 min: 1.56 G
+    synthetic parameters.)"""
+    g = np.load(os.path.join(GOLD, "qwen3_5_qwen3.8-27b-geom4.npz"))
+    cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+    w = synth.synth_weights_f32(cfg, seed=int(g["seed"][0]))
+    o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+    ids = g["prompt"].tolist()
+    assert rel(o.forward(ids, 0), g["prefill_logits"]) < 2e-5
+    assert rel(o.forward(g["decode_token"].tolist(), len(ids)), g["decode_logits"]) < 2e-5
+    assert o.generate(ids, len(g["greedy_tokens"]) - len(ids)) == g["greedy_tokens"].tolist()
+
+
 # ---------------------------------------------------------------- GPU: HIP path ----------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("kv", ["f32", "bf16"])
