@@ -37,3 +37,27 @@ def test_c_port_kv_rounding_mode():
     # land on the other side of a bf16 tie (2^-9 on those elements, ~1e-4 on logits)
     assert np.abs(a - b).max() / np.abs(a).max() < 2e-4
     c.close()
+
+
+def test_c_port_matches_hf_golden_at_the_headline_geometry():
+    """oracle/c is the checker of the headline parity tests (tests/test_gpu_parity_headline.py) and of bench.py's parity leg.
+    Here it is pinned itself, at that geometry: Qwen3-8B widths, GQA 4, the 151 936-row untied lm_head, 2 layers, against HF
+    Qwen3ForCausalLM on the same synthetic checkpoint (tests/golden/make_golden_qwen3.py): prompt logits, one decode step,
+    12 greedy tokens."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen3_qwen3-8b-2l.npz"))
+    cfg = configs.get_config("qwen3-8b-2l")
+    c = c_oracle.CQwen3(cfg, seed=int(g["seed"][0]), max_seq=64)
+    try:
+        ids = g["prompt"].tolist()
+        a = c.forward(ids, 0)
+        assert np.abs(a - g["prefill_logits"]).max() / np.abs(g["prefill_logits"]).max() < 2e-5
+        b = c.forward(g["decode_token"].tolist(), len(ids))
+        assert np.abs(b - g["decode_logits"]).max() / np.abs(g["decode_logits"]).max() < 2e-5
+        want = g["greedy_tokens"].tolist()
+        lg, toks = c.forward(ids, 0), list(ids)
+        for _ in range(len(want) - len(ids)):
+            toks.append(int(lg.argmax()))
+            lg = c.forward([toks[-1]], len(toks) - 1)
+        assert toks == want
+    finally:
+        c.close()
