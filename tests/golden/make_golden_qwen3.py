@@ -30,7 +30,8 @@ def main():
     torch.set_num_threads(8)
     # "qwen3-8b-2l": the headline geometry (every projection shape of Qwen3-8B, GQA 4, the 151 936-row untied lm_head) at
     # 2 layers -- the configuration tests/test_gpu_parity_headline.py compares the HIP path with oracle/c on
-    for name in ("tiny-qwen3", "tiny-qwen3-untied", "qwen3-8b-2l"):
+    # "qwen3-0.6b-2l": the same for BASELINE configs[0] (Qwen3-0.6B widths, 16 q / 8 kv heads, TIED 151 936-row table)
+    for name in ("tiny-qwen3", "tiny-qwen3-untied", "qwen3-8b-2l", "qwen3-0.6b-2l"):
         cfg = configs.get_config(name)
         w = synth.synth_weights_f32(cfg, seed=0)
         hc = Qwen3Config(**{k: v for k, v in cfg.items() if k not in ("model_type", "torch_dtype", "use_qk_norm")})

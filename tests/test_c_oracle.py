@@ -39,13 +39,14 @@ def test_c_port_kv_rounding_mode():
     c.close()
 
 
-def test_c_port_matches_hf_golden_at_the_headline_geometry():
+@pytest.mark.parametrize("name", ["qwen3-8b-2l", "qwen3-0.6b-2l"])
+def test_c_port_matches_hf_golden_at_the_headline_geometry(name):
     """oracle/c is the checker of the headline parity tests (tests/test_gpu_parity_headline.py) and of bench.py's parity leg.
-    Here it is pinned itself, at that geometry: Qwen3-8B widths, GQA 4, the 151 936-row untied lm_head, 2 layers, against HF
-    Qwen3ForCausalLM on the same synthetic checkpoint (tests/golden/make_golden_qwen3.py): prompt logits, one decode step,
-    12 greedy tokens."""
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen3_qwen3-8b-2l.npz"))
-    cfg = configs.get_config("qwen3-8b-2l")
+    Here it is pinned itself, at those geometries: Qwen3-8B widths, GQA 4, the 151 936-row untied lm_head (BASELINE
+    configs[1]) and Qwen3-0.6B widths with the tied table (configs[0]), 2 layers each, against HF Qwen3ForCausalLM on the
+    same synthetic checkpoint (tests/golden/make_golden_qwen3.py): prompt logits, one decode step, 12 greedy tokens."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"qwen3_{name}.npz"))
+    cfg = configs.get_config(name)
     c = c_oracle.CQwen3(cfg, seed=int(g["seed"][0]), max_seq=64)
     try:
         ids = g["prompt"].tolist()
