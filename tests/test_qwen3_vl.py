@@ -44,6 +44,27 @@ def test_oracle_matches_hf_golden():
     assert toks == g["greedy_tokens"].tolist()[len(ids):]
 
 
+def test_oracle_matches_hf_golden_at_the_real_tower_size():
+    """The same at the REAL Qwen3-VL-2B vision tower (depth 24, hidden 1024, 16 heads of 64, 2304 interpolated position
+    embeddings, DeepStack after blocks 5 / 11 / 17, merger to 2048) and text widths (4 of the 28 decoder layers, 151 936-entry
+    tied table): 96 patches -> 24 merged tokens, golden from tests/golden/make_golden_qwen3_vl.py tower24.  (~1 min of
+    synthetic-weight generation.)"""
+    g = np.load(os.path.join(os.path.dirname(GOLD), "qwen3_vl_tower24.npz"))
+    cfg = configs.get_config("qwen3-vl-2b")
+    cfg = dict(cfg, text_config=dict(cfg["text_config"], num_hidden_layers=4, max_position_embeddings=4096))
+    w = synth.synth_weights_f32(cfg, int(g["seed"][0]))
+    grid = g["grid_thw"].tolist()
+    pix = np.random.default_rng(0).standard_normal((grid[0][1] * grid[0][2], 3 * 2 * 16 * 16)).astype(np.float32)
+    ids = g["input_ids"].tolist()
+    feat, deep, logits, toks = _oracle_run(cfg, w, ids, pix, grid, "erf", 6)
+    assert feat.shape == (24, 2048) and rel(feat, g["features"]) < 2e-5
+    assert len(deep) == g["deepstack"].shape[0] == 3
+    for k in range(3):
+        assert rel(deep[k], g["deepstack"][k]) < 2e-5, k
+    assert rel(logits, g["prefill_logits"]) < 5e-5
+    assert toks == g["greedy_tokens"].tolist()[len(ids):]
+
+
 def test_text_only_prompt_equals_dense_qwen3():
     """without images T = H = W: the MRoPE rows are the plain RoPE rows and nothing is injected"""
     from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
