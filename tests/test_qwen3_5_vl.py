@@ -79,6 +79,25 @@ def test_oracle_matches_hf_golden():
     assert toks == g["greedy_tokens"].tolist()[len(g["input_ids"]):]
 
 
+def test_oracle_matches_hf_golden_at_the_real_size():
+    """The reference's LIVE image path at real size: the 24 x 1024 tower of qwen3.5-vl-0.8b in front of the Qwen3.5-0.8B text
+    geometry (H 1024, 8 q / 2 kv heads of 256 with 64 rotary dims and 3-axis MRoPE, 16 GDN heads of 128, I 3584, the
+    248 320-entry tied table; 4 layers = 3 GDN + 1 gated attention).  96 patches -> 24 merged tokens; golden from
+    tests/golden/make_golden_qwen3_5_vl.py tower24."""
+    g = np.load(os.path.join(os.path.dirname(GOLD), "qwen3_5_vl_tower24.npz"))
+    cfg = configs.get_config("qwen3.5-vl-0.8b")
+    cfg = dict(cfg, text_config=dict(cfg["text_config"], num_hidden_layers=4, max_position_embeddings=4096))
+    w = synth.synth_weights_f32(cfg, int(g["seed"][0]))
+    text_w = {k.replace("model.language_model.", "model."): v for k, v in w.items() if not k.startswith("model.visual.")}
+    grid = g["grid_thw"].tolist()
+    pix = np.random.default_rng(0).standard_normal((grid[0][1] * grid[0][2], 3 * 2 * 16 * 16)).astype(np.float32)
+    ids = g["input_ids"].tolist()
+    feat, logits, toks = _oracle_vlm(cfg, w, text_w, ids, pix, grid, "erf", 6)
+    assert feat.shape == (24, 1024) and rel(feat, g["features"]) < 2e-5
+    assert rel(logits, g["prefill_logits"]) < 5e-5
+    assert toks == g["greedy_tokens"].tolist()[len(ids):]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("gelu", ["tanh", "erf"])
 def test_hip_vision_and_vlm(gelu):
