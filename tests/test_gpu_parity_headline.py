@@ -125,3 +125,25 @@ def test_decode_and_prefill_qwen3_0p6b_geometry():
     finally:
         m.close()
         c.close()
+
+
+@pytest.mark.parametrize("name", ["qwen3-8b-2l", "qwen3-0.6b-2l"])
+def test_short_prompt_and_step_against_the_hf_golden(name):
+    """The committed HF fixtures at the real widths (tests/golden/qwen3_<name>.npz, make_golden_qwen3.py: Qwen3ForCausalLM in
+    f32 on the same synthetic checkpoint): a 21-token prompt -- one m-tile of <= 64 rows, i.e. the 64 x 128 split-K GEMM tiles
+    at K = 4096 / 12288 resp. 1024 / 3072 -- and one decode step on top of it, benchmarked KV mode (bf16 pages), bar 1e-3."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"qwen3_{name}.npz"))
+    cfg = configs.get_config(name)
+    m = Model.synthetic(cfg, seed=int(g["seed"][0]), max_seq_len=256, max_seqs=2)
+    try:
+        ids = g["prompt"].tolist()
+        a = m.forward_step(ids, 0)[0, 0]
+        ref = g["prefill_logits"]
+        assert rel(a, ref) < BAR, rel(a, ref)
+        top = np.sort(ref)[-2:]
+        if top[1] - top[0] > 10 * BAR * np.abs(ref).max():           # (a clear winner: the arg-max must agree)
+            assert int(a.argmax()) == int(ref.argmax())
+        b = m.forward_step(g["decode_token"].tolist(), len(ids))[0, 0]
+        assert rel(b, g["decode_logits"]) < BAR, rel(b, g["decode_logits"])
+    finally:
+        m.close()
