@@ -32,10 +32,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 
 
 def cpu_leg(model_name: str, ctx: int, budget_s: float):
     """oracle/c on the host cores: greedy decode of the same workload (KV filled with the device's synthetic values).
-    Returns (cpu_baseline dict, reference tokens, logits of the first step) -- the checker side of `parity`."""
+    Returns (cpu_baseline dict, reference tokens, logits of the first step, model-written-cache reference) -- the checker
+    side of `parity`."""
     so = os.path.join(ROOT, "oracle", "c", "libqwen3_cpu.so")
     if not os.path.exists(so):
-        return None, None, None
+        return None, None, None, None
     from oracle.c_oracle import time_decode
     return time_decode(model_name, ctx, budget_s)
 
@@ -69,7 +70,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU decode steps for cpu_baseline / parity")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--engine", type=int, default=0, choices=[-1, 0, 1], help="persistent chain kernel: 1 require, -1 off, 0 library default")
-    ap.add_argument("--kv", default="bf16", choices=["bf16", "f32", "int8", "int4"], help="KV cache element type (bf16 = headline)")
+    ap.add_argument("--kv", default="f16", choices=["f16", "bf16", "f32", "int8", "int4"],
+                    help="KV page element type (f16 = library default and headline: 2 bytes per element like bf16, inside the 1e-3 parity bar)")
     ap.add_argument("--isq", default=None, help="in-situ weight quantisation (q8_0): a DIFFERENT workload than the bf16 headline")
     args = ap.parse_args()
 
@@ -204,10 +206,12 @@ def main():
         # the same prompt with plain bf16 activations (one MFMA per product: the arithmetic of a bf16 GPU forward of the
         # reference; logits move by ~5e-3, outside the 1e-3 bar, so it is an option, not the default)
         m.debug_set("prefill_split", 1)
-        m.clear_kv_cache(); m.forward_step_greedy(ids, 0); m.clear_kv_cache()
-        barrier()
-        tp0 = time.perf_counter(); m.forward_step_greedy(ids, 0); tp1 = time.perf_counter()
-        m.debug_set("prefill_split", 0)
+        try:
+            m.clear_kv_cache(); m.forward_step_greedy(ids, 0); m.clear_kv_cache()
+            barrier()
+            tp0 = time.perf_counter(); m.forward_step_greedy(ids, 0); tp1 = time.perf_counter()
+        finally:
+            m.debug_set("prefill_split", -1)                         # back to cm_opts.prefill_split
         prefill["plain_bf16"] = {"ms": round((tp1 - tp0) * 1e3, 3), "tokens_per_s": round(1024 / (tp1 - tp0), 1)}
     except Exception as e:
         prefill = {"error": str(e)}
@@ -221,26 +225,48 @@ def main():
                               "oracle (tests/), too slow to time at this size"}
         else:
             try:
-                cpu, ref_toks, ref_logits = cpu_leg(args.model, ctx, args.cpu_budget)
+                cpu, ref_toks, ref_logits, wr = cpu_leg(args.model, ctx, args.cpu_budget)
                 if ref_toks:
+                    def relerr(a, b):
+                        return float(np.abs(a - b).max() / np.abs(b).max())
+                    # (1) the parity figure: a cache the MODEL wrote.  Prompt through the MFMA prefill, one decode step and the
+                    # greedy continuation through the decode kernels over the pages that prefill wrote, in the benchmarked KV mode
+                    m.clear_kv_cache()
+                    pl = m.forward_step(wr["prompt"], 0)[0, 0]
+                    dl = m.forward_step([wr["greedy"][0]], len(wr["prompt"]))[0, 0]
+                    from crane_amd.backend import GenerationConfig
+                    gen = m.generate(wr["prompt"], GenerationConfig.greedy(len(wr["greedy"])))[len(wr["prompt"]):]
+                    eqw = 0
+                    while eqw < len(gen) and gen[eqw] == wr["greedy"][eqw]:
+                        eqw += 1
+                    rp, rd = relerr(pl, wr["prefill_logits"]), relerr(dl, wr["decode_logits"])
+                    # (2) the timed configuration itself (synthetic KV at the benchmark context: bf16-exact fill values, so this
+                    # checks the kernels at the timed shapes, not the KV rounding)
                     m.debug_fill_kv(ctx, seed=1)
                     got0 = m.forward_step([3], ctx)[0, 0]
-                    lrel = float(np.abs(got0 - ref_logits).max() / np.abs(ref_logits).max())
+                    lrel = relerr(got0, ref_logits)
                     m.debug_fill_kv(ctx, seed=1)
                     gt, _ = m.bench_decode(3, len(ref_toks))
                     gt = [int(t) for t in gt]
                     eq = 0
                     while eq < len(ref_toks) and gt[eq] == ref_toks[eq]:
                         eq += 1
-                    parity = {"tokens_checked": len(ref_toks), "tokens_equal": eq, "logit_rel": float(f"{lrel:.3e}"),
-                              "reference": "oracle/c f32 CPU forward (K/V appends unrounded), identical synthetic weights + synthetic KV",
-                              "ok": bool(eq == len(ref_toks) and lrel < 1e-3)}
+                    parity = {"reference": "oracle/c: the f32 CPU forward (K/V appends unrounded) on identical synthetic weights",
+                              "kv_pages": args.kv,
+                              "model_written_cache": {"prompt_tokens": len(wr["prompt"]), "prefill_logit_rel": float(f"{rp:.3e}"),
+                                                      "decode_logit_rel": float(f"{rd:.3e}"), "greedy_checked": len(wr["greedy"]),
+                                                      "greedy_equal": eqw},
+                              "timed_configuration": {"note": "synthetic KV of the benchmark context (bf16-exact fill values)",
+                                                      "tokens_checked": len(ref_toks), "tokens_equal": eq,
+                                                      "logit_rel": float(f"{lrel:.3e}")},
+                              "logit_rel": float(f"{max(rp, rd):.3e}"),
+                              "ok": bool(eqw == len(wr["greedy"]) and eq == len(ref_toks) and max(rp, rd, lrel) < 1e-3)}
             except Exception as e:  # the baseline must never break the headline number
                 cpu = {"error": str(e)}
 
     wdt = args.isq or "bf16"
     if rank == 0:
-        headline = args.model == "qwen3-8b" and not args.isq and args.kv == "bf16" and ctx == 1024
+        headline = args.model == "qwen3-8b" and not args.isq and args.kv == "f16" and ctx == 1024
         line = {
             "metric": "decode tokens/s Qwen3-8B bf16 greedy, ctx 1024" if headline
                       else f"decode tokens/s {args.model} {wdt} weights / {args.kv} KV greedy, ctx {ctx}",

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrane_mi355.so")
 
-CM_ABI_VERSION = 1
+CM_ABI_VERSION = 2
 CM_OK = 0
 STATUS_NAMES = {0: "CM_OK", -1: "CM_ERR_INVALID", -2: "CM_ERR_IO", -3: "CM_ERR_UNSUPPORTED",
                 -4: "CM_ERR_DEVICE", -5: "CM_ERR_OOM", -6: "CM_ERR_RANGE"}
@@ -23,7 +23,7 @@ EXPORTS = [
     "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_tp_ranks", "cm_engine_active", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
-    "cm_decode_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
+    "cm_decode_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_embed_tokens", "cm_forward_embeds", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
     "cm_gguf_config", "cm_checkpoint_inspect", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv", "cm_debug_set",
 ]
 
@@ -150,6 +150,8 @@ def load():
     lib.cm_image_token_id.restype = C.c_int64
     lib.cm_vision_encode.argtypes = [vp, f32p, C.c_size_t, u32p, C.c_size_t, f32p, P(C.c_size_t)]
     lib.cm_vlm_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t, u32p, C.c_size_t, f32p, u32p]
+    lib.cm_embed_tokens.argtypes = [vp, u32p, C.c_size_t, f32p]
+    lib.cm_forward_embeds.argtypes = [vp, C.c_int32, f32p, C.c_size_t, P(C.c_int32), C.c_size_t, f32p, u32p]
     lib.cm_sample.argtypes = [vp, P(CmSampleParams), u32p, C.c_size_t, u32p]
     lib.cm_topk.argtypes = [vp, f32p, C.c_size_t, C.c_uint32, u32p, f32p]
     lib.cm_read_logits.argtypes = [vp, f32p]

@@ -119,14 +119,14 @@ class Model:
     @staticmethod
     def _opts(device=0, max_seq_len=0, max_seqs=0, kv_block_size=0, kv_pool_tokens=0, use_graph=0,
               tp_rank=0, tp_size=1, tp_unique_id: Optional[bytes] = None, prefill_chunk=0, prefill_split=0,
-              kv_dtype="bf16", isq: Optional[str] = None, engine=0, debug_tp_local=False, debug_force_rccl=False):
+              kv_dtype="f16", isq: Optional[str] = None, engine=0, debug_tp_local=False, debug_force_rccl=False):
         o = _lib.CmOpts()
         o.abi_version = _lib.CM_ABI_VERSION
         o.device, o.tp_rank, o.tp_size = device, tp_rank, tp_size
         o.max_seq_len, o.max_seqs, o.kv_block_size = max_seq_len, max_seqs, kv_block_size
         o.kv_pool_tokens, o.use_graph = kv_pool_tokens, use_graph
         o.prefill_chunk, o.prefill_split = prefill_chunk, prefill_split
-        o.kv_dtype = {"bf16": 0, "f32": 1, "int8": 2, "int4": 3}[kv_dtype]
+        o.kv_dtype = {"f16": 0, "f32": 1, "int8": 2, "int4": 3, "bf16": 4}[kv_dtype]
         o.isq = {None: 0, "none": 0, "q8_0": 8}[isq.lower() if isinstance(isq, str) else isq]     # --quant / CRANE_ISQ
         o.engine = int(engine)                                    # persistent chain kernel: 0 default, 1 require, -1 off
         o.debug_flags = (1 if debug_tp_local else 0) | (2 if debug_force_rccl else 0)
@@ -361,6 +361,27 @@ class Model:
         self._check(self._lib.cm_vlm_forward(self._h, seq, p, arr.size, start_pos, pv.ctypes.data_as(C.POINTER(C.c_float)),
                                              pv.shape[0], g.ctypes.data_as(C.POINTER(C.c_uint32)), g.shape[0],
                                              out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(t)))
+        return out, int(t.value)
+
+    def embed_tokens(self, input_ids: Sequence[int]) -> np.ndarray:
+        """Qwen3_5TextModel::embed_only (qwen3_5/model.rs:368-370) -> [n, hidden] f32."""
+        arr, p = _u32(input_ids)
+        out = np.empty((arr.size, self.hidden_size), dtype=np.float32)
+        self._check(self._lib.cm_embed_tokens(self._h, p, arr.size, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def forward_embeds(self, embeds: np.ndarray, position_ids=None, start_pos: int = 0, seq: int = 0):
+        """Qwen3_5TextModel::forward_embeds (qwen3_5/model.rs:430-510): logits [V] of the last row and its arg-max.
+        position_ids: [3, n] (T, H, W) or None (the sequence's own counter on all axes)."""
+        e = np.ascontiguousarray(embeds, dtype=np.float32).reshape(-1, self.hidden_size)
+        pp = None
+        if position_ids is not None:
+            pos = np.ascontiguousarray(np.asarray(position_ids, dtype=np.int32).reshape(3, e.shape[0]))
+            pp = pos.ctypes.data_as(C.POINTER(C.c_int32))
+        out = np.empty(self.vocab_size, dtype=np.float32)
+        t = C.c_uint32()
+        self._check(self._lib.cm_forward_embeds(self._h, seq, e.ctypes.data_as(C.POINTER(C.c_float)), e.shape[0], pp, start_pos,
+                                                out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(t)))
         return out, int(t.value)
 
     # -- measurement hooks --------------------------------------------------------

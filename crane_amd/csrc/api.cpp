@@ -267,6 +267,17 @@ int cm_vlm_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size
     return guard(h, [&] { h->m.vlm_forward(seq, ids, n, start_pos, pixel_values, n_patches, grid_thw, n_images, logits_out, greedy_out); });
 }
 
+int cm_embed_tokens(cm_model* h, const uint32_t* ids, size_t n, float* embeds_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.embed_tokens(ids, n, embeds_out); });
+}
+
+int cm_forward_embeds(cm_model* h, int32_t seq, const float* embeds, size_t n, const int32_t* pos3, size_t start_pos,
+                      float* logits_out, uint32_t* greedy_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] { h->m.forward_embeds(seq, embeds, n, pos3, start_pos, logits_out, greedy_out); });
+}
+
 int cm_sample(cm_model* h, const cm_sample_params* p, const uint32_t* context, size_t n_context, uint32_t* token_out) {
     if (!h) return CM_ERR_INVALID;
     return guard(h, [&] {
@@ -320,10 +331,19 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
             int e = -1;
             for (int k = 0; k < cm::ENG_NEDGE; ++k) if (w == names[k]) e = k;
             if (e < 0 || !h->m.engine_on) throw CmError(CM_ERR_INVALID, "unknown granule buffer / engine off");
+            if (n > h->m.eng_gsz[e]) throw CmError(CM_ERR_RANGE, "read beyond granule buffer");
             std::vector<unsigned long long> g(n);
             CM_HIP(hipStreamSynchronize(h->m.stream));
             CM_HIP(hipMemcpy(g.data(), h->m.eng_gran[e], n * 8, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < n; ++i) { const uint32_t b = (uint32_t)g[i]; memcpy(&out[i], &b, 4); }
+            return;
+        }
+        if (w == "deepstack") {            // [n_deepstack][rows][out_hidden] DeepStack feature maps of the LAST cm_vision_encode / cm_vlm_forward
+            const size_t nd = h->m.vcfg.deepstack.size(), oh = (size_t)h->m.vcfg.out_hidden;
+            if (nd == 0 || !h->m.vDeep || n % (nd * oh) != 0 || n / nd > h->m.deep_stride) throw CmError(CM_ERR_RANGE, "deepstack: n must be n_maps * rows * out_hidden");
+            CM_HIP(hipStreamSynchronize(h->m.stream));
+            for (size_t k = 0; k < nd; ++k)
+                CM_HIP(hipMemcpy(out + k * (n / nd), h->m.vDeep + k * h->m.deep_stride, (n / nd) * sizeof(float), hipMemcpyDeviceToHost));
             return;
         }
         if (w == "hidden") { src = h->m.x; avail = (size_t)h->m.cfg.H; }
@@ -344,7 +364,17 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         const std::string k = key;
         if (k == "no_prefill") h->m.no_prefill = value != 0;
         else if (k == "quant_prefill") h->m.quant_prefill = value != 0;
-        else if (k == "prefill_split") h->m.prefill_split2 = value != 1;
+        else if (k == "prefill_split") h->m.prefill_split2 = value < 0 ? h->m.opts.prefill_split != 1 : value != 1;   // 1: plain bf16, 0 / 2: hi + lo, -1: back to cm_opts
+        // which decode-attention kernel / persistent-kernel mode a step uses (tests and A/B runs; one hipGraph per variant, so
+        // the thresholds switch live -- a switch that changes what a variant enqueues drops the captured graphs)
+        else if (k == "attn_mfma_min") h->m.attn_mfma_min = value;
+        else if (k == "attn_mfma_wide_min") h->m.attn_mfma_wide_min = value;
+        else if (k == "attn_heads_max") h->m.attn_heads_max = value;
+        else if (k == "attn_ns") { h->m.attn_ns = (int)std::max<long long>(1, std::min<long long>(value, h->m.nsplit)); h->m.drop_graphs(); }
+        else if (k == "quant_act_int") h->m.quant_act_int = value != 0;          // CM_QUANT_ACT: 1 = ggml vec_dot (integer) semantics, 0 = f32 activations
+        else if (k == "vision_merger_gelu") h->m.vcfg.merger_act = value == 2 ? 2 : 1;   // CM_VISION_MERGER_GELU: 1 tanh form (reference), 2 erf (HF)
+        else if (k == "engine") { h->m.drop_graphs(); h->m.engine_on = value > 0 && h->m.engine_capable; }
+        else if (k == "engine_full") { h->m.drop_graphs(); h->m.engine_full = value != 0 && h->m.engine_full_capable; }
         else if (k == "batch_gemm_min") h->m.batch_gemm_min = (int)std::max<long long>(0, std::min<long long>(value, Model::GEMV_MAXB));   // a group beyond the GEMV kernels' 64 must take the GEMM path
         else if (k == "attn_splits") h->m.attn_splits_force = (int)std::max<long long>(0, std::min<long long>(value, h->m.nsplit));
         else throw CmError(CM_ERR_INVALID, "unknown debug switch");

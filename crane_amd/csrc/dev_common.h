@@ -30,6 +30,39 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 
+// ---- f16 <-> f32 (CM_KV_F16 pages: K/V cached as IEEE binary16 -- the bytes of a bf16 page, 11 significand bits instead
+// of 8; v_cvt_f16_f32 rounds to nearest even and keeps subnormals, the clamp saturates instead of overflowing to inf) ----
+typedef __attribute__((ext_vector_type(2))) _Float16 cm_f16x2;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ float f16_lo(uint32_t packed) { return (float)__builtin_bit_cast(cm_f16x2, packed)[0]; }
+__device__ __forceinline__ float f16_hi(uint32_t packed) { return (float)__builtin_bit_cast(cm_f16x2, packed)[1]; }
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+    const _Float16 h = (_Float16)fminf(fmaxf(f, -65504.f), 65504.f);
+    return __builtin_bit_cast(uint16_t, h);
+}
+// internal KV-page element types (template parameter KVT of the attention kernels, Model::kv_mode)
+enum { KV_BF16 = 0, KV_F32 = 1, KV_INT8 = 2, KV_INT4 = 3, KV_F16 = 4 };
+// one cached 16-bit element pair -> f32 (bf16: bit shifts; f16: v_cvt_f32_f16)
+template <int KVT> __device__ __forceinline__ float kv16_lo(uint32_t p) { return KVT == KV_F16 ? f16_lo(p) : bf16_lo(p); }
+template <int KVT> __device__ __forceinline__ float kv16_hi(uint32_t p) { return KVT == KV_F16 ? f16_hi(p) : bf16_hi(p); }
+template <int KVT> __device__ __forceinline__ uint16_t kv16_from_f32(float f) { return KVT == KV_F16 ? f32_to_f16(f) : f32_to_bf16(f); }
+template <int KVT> __device__ __forceinline__ float kv16_to_f32(uint16_t h) { return KVT == KV_F16 ? f16_to_f32(h) : bf16_to_f32(h); }
+
+// KVT = 4 (f16 pages): the same tiles on the f16 matrix-core instructions -- K rows and V^T fragments are the cached halves,
+// q and p are split into f16 hi + lo (q is O(10) after the QK-norm, p <= 1: both far inside the binary16 range).
+template <int KVT>
+__device__ __forceinline__ f32x4 mma_k32(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    if constexpr (KVT == KV_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int KVT>
+__device__ __forceinline__ f32x4 mma_k16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
+    if constexpr (KVT == KV_F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // ---- streaming (non-temporal) 16-byte load: weights are read once ----------
 __device__ __forceinline__ u32x4 ld_nt16(const void* p) {
     return __builtin_nontemporal_load((const u32x4*)p);

@@ -103,7 +103,8 @@ struct QkRopeArgs {
     uint16_t* q_lo;
     int Hq, Hkv, page, start_pos;
     int row_stride, q_off, k_off, v_off, rot_dim;   // layout of one token's projection row
-    const int32_t* pos3;         // MRoPE positions (T, H, W): pos3[axis * pos3_stride + s], or null (position = start_pos + s)
+    const int32_t* pos3;         // MRoPE positions (T, H, W): pos3[axis * pos3_stride + s], or null (position = start_pos + s + rope_delta)
+    int rope_delta = 0;          // rotary position - cache position of a sequence that holds an image prompt (vlm.rs:294-301)
     int pos3_stride, sec_h, sec_w;   // mrope_section[1], [2]
     float eps, scale;
     // int8 / int4 KV: codes + scales go to kpool / vpool (page_bytes layout), the DEQUANTISED row goes to the f32 shadow
@@ -137,7 +138,7 @@ void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hip
 void launch_split_rows2d(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int rows, int cols, hipStream_t s);   // cols % 4 == 0, ldx % 4 == 0
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
-void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s);
+void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s);   // kvt: KV_BF16 | KV_F16 | KV_F32 (what the kernel reads)
 
 // ---- vision tower (kernels_vision.hip) ----
 void launch_layernorm_rows(const float* x, const float* w, const float* b, uint16_t* hi, uint16_t* lo, int N, int H, float eps,
@@ -216,7 +217,7 @@ struct EngPhase {                 // one row-streaming projection of the program
     int pre_attn;                 // the comm waves run this layer's attention before staging this phase's input
 };
 struct EngAttnL {                 // attention operands of one layer
-    void* kpool;                  // [pages][Hkv][PAGE][D] bf16
+    void* kpool;                  // [pages][Hkv][PAGE][D] bf16 or f16 (EngArgs::kv_f16)
     void* vpool;
     const float* qnw;             // [D] f32 or null
     const float* knw;
@@ -238,6 +239,7 @@ struct EngArgs {
     int ub0, ub1, ub2, ub3;       // useq of the first phase of THIS launch on each counter row
     int H, gpw_res, xf_total;     // hidden size; row groups per wave of the residual phases; LDS floats of the input buffers
     int Hkv, page, max_pages, q_off, k_off, v_off;
+    int kv_f16;                   // K/V pages hold IEEE binary16 (CM_KV_F16) instead of bf16
     float eps, scale;
     int tune;                     // polling parameters (CM_ENG_TUNE while tuning), see kernels_engine.hip
     int dbg;                      // timing experiments (CM_ENG_DBG), see kernels_engine.hip; 0 in production
@@ -253,7 +255,7 @@ bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace = false
 void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncols, int row0, int col0,
                        int full_cols, uint32_t tseed, float mul, float off, hipStream_t s);
 void launch_kv_fill_quant(void* pool, const int32_t* pages, int npages, size_t page_bytes, size_t code_bytes, uint32_t tseed, hipStream_t s);
-void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
+void launch_kv_fill(void* pool, int kvt, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s);
 
 // ---- quantised weights (kernels_quant.hip) ----

@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
     // `pos`: their block-table entries and K/V rows are requested first (pos, q, RoPE rows load
     // meanwhile); validity (t <= pos) is a mask.  Perfectly balanced for any context length.
     const int tok_in_chunk = wave * RPW + r;
-    // KVT: 0 bf16, 1 f32 (element offsets into [pages][Hkv][PAGE][D]); 2 int8, 3 int4 (per-token symmetric codes +
+    // KVT: 0 bf16, 4 f16, 1 f32 (element offsets into [pages][Hkv][PAGE][D]); 2 int8, 3 int4 (per-token symmetric codes +
     // f32 scale, qwen3_5/kv_cache.rs:253-301; byte offsets, each page = codes [Hkv][PAGE][row] then scales [Hkv][PAGE])
-    constexpr bool KVQ = KVT >= 2;
+    constexpr bool KVQ = KVT == KV_INT8 || KVT == KV_INT4;
     constexpr bool KVF32 = KVT == 1;
     constexpr int ROWB = KVT == 2 ? D : D / 2;            // code bytes per token row (quantised modes)
     auto kv_off = [&](int t) -> size_t {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
         KV8 v;
         v.s = 1.f;
         if (KVT == 1) { v.a = ld16((const float*)pool + off); v.b = ld16((const float*)pool + off + 4); }
-        else if (KVT == 0) { v.a = ld16((const uint16_t*)pool + off); v.b = v.a; }
+        else if (!KVQ) { v.a = ld16((const uint16_t*)pool + off); v.b = v.a; }
         else {
             const uint8_t* p = (const uint8_t*)pool;
             if (KVT == 2) { const u32x2 c = *(const u32x2*)(p + off + dimbase); v.a = (u32x4){c[0], c[1], 0, 0}; }
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
                     dst[d] = xv[j];
                     if (owner) ((float*)pool)[eoff + d] = xv[j];
                 } else {
-                    const uint16_t b = f32_to_bf16(xv[j]);
-                    dst[d] = bf16_to_f32(b);
+                    const uint16_t b = kv16_from_f32<KVT>(xv[j]);
+                    dst[d] = kv16_to_f32<KVT>(b);
                     if (owner) ((uint16_t*)pool)[eoff + d] = b;
                 }
             }
@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
                 kf[e] = __uint_as_float(kqv.a[e]); kf[4 + e] = __uint_as_float(kqv.b[e]);
                 vf[e] = __uint_as_float(vqv.a[e]); vf[4 + e] = __uint_as_float(vqv.b[e]);
             } else {
-                kf[2 * e] = bf16_lo(kqv.a[e]); kf[2 * e + 1] = bf16_hi(kqv.a[e]);
-                vf[2 * e] = bf16_lo(vqv.a[e]); vf[2 * e + 1] = bf16_hi(vqv.a[e]);
+                kf[2 * e] = kv16_lo<KVT>(kqv.a[e]); kf[2 * e + 1] = kv16_hi<KVT>(kqv.a[e]);
+                vf[2 * e] = kv16_lo<KVT>(vqv.a[e]); vf[2 * e + 1] = kv16_hi<KVT>(vqv.a[e]);
             }
         }
         if (t == pos) {   // the token appended by this very step: values from LDS
@@ -578,7 +578,7 @@ bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, boo
 // their token and p by the V scale before it becomes the P^T operand (l uses the unscaled p).
 template <int D, int NREP, int KVT>
 __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
-    constexpr bool KVQ = KVT >= 2;
+    constexpr bool KVQ = KVT == KV_INT8 || KVT == KV_INT4;
     constexpr int ROWB = KVT == 2 ? D : D / 2;                   // code bytes per token row
     constexpr float OFFS = KVT == 2 ? 128.f : 8.f, QMAX = KVT == 2 ? 127.f : 7.f;
     constexpr int NKS = D / 32, NNT = D / 16, VLD = D + 16, EPL = D / 64, TB = 64;
@@ -721,9 +721,9 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 const float x = xv[j] * a.scale;
-                const uint16_t h = f32_to_bf16(x);
+                const uint16_t h = kv16_from_f32<KVT>(x);
                 q_hi[item * D + lane + 64 * j] = h;
-                q_lo[item * D + lane + 64 * j] = f32_to_bf16(x - bf16_to_f32(h));
+                q_lo[item * D + lane + 64 * j] = kv16_from_f32<KVT>(x - kv16_to_f32<KVT>(h));
             }
         } else {
             uint16_t* dst = (item == NREP) ? knew : vnew;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 const int d = lane + 64 * j;
-                const uint16_t b = f32_to_bf16(xv[j]);
+                const uint16_t b = kv16_from_f32<KVT>(xv[j]);
                 dst[d] = b;
                 if (owner) pool[eoff + d] = b;
             }
@@ -791,8 +791,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qh[ks], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], ql[ks], sc, 0, 0, 0);
+            sc = mma_k32<KVT>(kf[ks], qh[ks], sc);
+            sc = mma_k32<KVT>(kf[ks], ql[ks], sc);
         }
         float mt = -INFINITY;
 #pragma unroll
@@ -812,9 +812,9 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
             const float p = expf(sc[r] - m_new);
             psum += p;
             const float pv = KVQ ? p * vscl[r] : p;              // V scale of the token folded into the P^T operand
-            const uint16_t hh = f32_to_bf16(pv);
+            const uint16_t hh = kv16_from_f32<KVT>(pv);
             ph[r] = (short)hh;
-            pl[r] = (short)f32_to_bf16(pv - bf16_to_f32(hh));
+            pl[r] = (short)kv16_from_f32<KVT>(pv - kv16_to_f32<KVT>(hh));
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -825,8 +825,8 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         for (int nt = 0; nt < NNT; ++nt) {
             const uint16_t* vp = &Vw[(g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
             const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, ph, o[nt], 0, 0, 0);
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, pl, o[nt], 0, 0, 0);
+            o[nt] = mma_k16<KVT>(vh, ph, o[nt]);
+            o[nt] = mma_k16<KVT>(vh, pl, o[nt]);
         }
         __builtin_amdgcn_wave_barrier();                         // tile consumed before the next step overwrites it
     };
@@ -904,6 +904,7 @@ static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode,
     dim3 grid(nsplit, a.Hkv, n_seq), block(256);
 #define CM_MF(N) case N: if (kv_mode == 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, 2>), grid, block, 0, s, a); \
                          else if (kv_mode == 3) hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, 3>), grid, block, 0, s, a); \
+                         else if (kv_mode == KV_F16) hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, KV_F16>), grid, block, 0, s, a); \
                          else hipLaunchKernelGGL((attn_decode_mfma_kernel<D, N, 0>), grid, block, 0, s, a); return true;
     switch (nrep) {
         CM_MF(1) CM_MF(2) CM_MF(3) CM_MF(4) CM_MF(6) CM_MF(8)
@@ -912,7 +913,7 @@ static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode,
 #undef CM_MF
 }
 
-// bf16 / int8 / int4 KV (not f32); same partial format and combine kernel as launch_attn_decode
+// bf16 / f16 / int8 / int4 KV (not f32); same partial format and combine kernel as launch_attn_decode
 bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq, hipStream_t s) {
     if (a.page <= 0 || (a.page & (a.page - 1)) != 0 || kv_mode == 1) return false;
     if (D == 128) {
@@ -936,6 +937,7 @@ static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode
     case N: if (kv_mode == 1) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 1>), grid, block, 0, s, a); \
             else if (kv_mode == 2) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 2>), grid, block, 0, s, a); \
             else if (kv_mode == 3) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 3>), grid, block, 0, s, a); \
+            else if (kv_mode == KV_F16) hipLaunchKernelGGL((attn_decode_split_kernel<D, N, KV_F16>), grid, block, 0, s, a); \
             else hipLaunchKernelGGL((attn_decode_split_kernel<D, N, 0>), grid, block, 0, s, a); return true;
     switch (nrep) {
         CM_ATTN_CASE(1) CM_ATTN_CASE(2) CM_ATTN_CASE(3) CM_ATTN_CASE(4) CM_ATTN_CASE(6) CM_ATTN_CASE(8)

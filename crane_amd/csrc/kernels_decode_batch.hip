@@ -244,7 +244,24 @@ static void launch_gemvb_t(const GemvBArgs& a, int grid, hipStream_t s) {
         static bool attr_##MBV = false; \
         if (!attr_##MBV) { (void)hipFuncSetAttribute((const void*)gemvb_kernel<PRO, EPI, MBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##MBV = true; } \
         hipLaunchKernelGGL((gemvb_kernel<PRO, EPI, MBV>), g, b, lds, s, a); }
-    if (a.n_seq <= 2) CM_GB(2) else if (a.n_seq <= 4) CM_GB(4) else CM_GB(8)
+    if (a.n_seq <= 2) CM_GB(2) else if (a.n_seq <= 4) CM_GB(4) else if (a.n_seq <= 8) CM_GB(8)
+    else {
+        // more rows than the kernel keeps in LDS (the caller formed a group of up to 128 sequences for the matrix-core kernels and
+        // this projection -- SiLU*mul or arg-max with K > 4096, Qwen3.8-27B / Qwen3-14B -- has no matrix-core form): passes of 8 rows,
+        // every per-sequence array advanced by the pass (pmax / pidx rows are `grid` entries long)
+        for (int m0 = 0; m0 < a.n_seq; m0 += 8) {
+            GemvBArgs b8 = a;
+            b8.n_seq = std::min(8, a.n_seq - m0);
+            b8.x = a.x + (size_t)m0 * a.ldx;
+            if (a.y) b8.y = a.y + (size_t)m0 * a.ldy;
+            if (a.res) b8.res = a.res + (size_t)m0 * a.ldy;
+            if (a.pmax) b8.pmax = a.pmax + (size_t)m0 * grid;
+            if (a.pidx) b8.pidx = a.pidx + (size_t)m0 * grid;
+            if (a.part_ml) b8.part_ml = a.part_ml + (size_t)m0 * (a.K >> a.dshift) * a.ns * 2;
+            if (a.gate) b8.gate = a.gate + (size_t)m0 * a.gate_stride;
+            launch_gemvb_t<PRO, EPI>(b8, grid, s);
+        }
+    }
 #undef CM_GB
 }
 

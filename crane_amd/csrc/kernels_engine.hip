@@ -301,9 +301,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         CM_GLOBAL uint16_t* pool = (CM_GLOBAL uint16_t*)(item == NREP ? AL->kpool : AL->vpool);
                         const size_t eoff = owner ? a_eoff : 0;
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const uint16_t b16 = f32_to_bf16(xv[j]);
-                            dst[lane + 64 * j] = bf16_to_f32(b16);
+                        for (int j = 0; j < 2; ++j) {       // (kv_f16 is launch-uniform: a scalar branch)
+                            const uint16_t b16 = a.kv_f16 ? f32_to_f16(xv[j]) : f32_to_bf16(xv[j]);
+                            dst[lane + 64 * j] = a.kv_f16 ? f16_to_f32(b16) : bf16_to_f32(b16);
                             if (owner) pool[eoff + lane + 64 * j] = b16;
                         }
                     }
@@ -327,10 +327,18 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 auto consume = [&](const u32x4& kqv, const u32x4& vqv, int t) __attribute__((always_inline)) {
                     const bool valid = t < L;
                     float kf[8], vf[8];
+                    if (a.kv_f16) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        kf[2 * e] = bf16_lo(kqv[e]); kf[2 * e + 1] = bf16_hi(kqv[e]);
-                        vf[2 * e] = bf16_lo(vqv[e]); vf[2 * e + 1] = bf16_hi(vqv[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            kf[2 * e] = f16_lo(kqv[e]); kf[2 * e + 1] = f16_hi(kqv[e]);
+                            vf[2 * e] = f16_lo(vqv[e]); vf[2 * e + 1] = f16_hi(vqv[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            kf[2 * e] = bf16_lo(kqv[e]); kf[2 * e + 1] = bf16_hi(kqv[e]);
+                            vf[2 * e] = bf16_lo(vqv[e]); vf[2 * e + 1] = bf16_hi(vqv[e]);
+                        }
                     }
                     if (t == pos) {   // the token appended by this very step: values from LDS
 #pragma unroll
@@ -789,6 +797,13 @@ static bool prepare_v(size_t lds_bytes) {
     auto kt = engine_kernel<NSW, ENG_NCW, PF, 4, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // the workgroups spin on each other: at least one must fit a CU with this much dynamic LDS (the launch then covers the
+    // device with one workgroup per CU; co-residency with OTHER work is the caller's contract, see crane_mi355.h)
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), (NSW + ENG_NCW) * 64, lds_bytes) != hipSuccess || nb < 1) {
         (void)hipGetLastError();
         return false;
     }

@@ -25,7 +25,8 @@ void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncol
 }
 
 // pool: [n_pages][page_elems]; fill the listed pages with N(0,1)-like bf16-representable values
-template <typename T>
+// (values k / 147.8 rounded to bf16: |v| < 3.5 with 8 significand bits, so the f16 page holds the same number exactly)
+template <typename T, bool F16>
 __global__ void kv_fill_kernel(T* __restrict__ pool, const int32_t* __restrict__ pages, int npages,
                                size_t page_elems, uint32_t tseed) {
     const size_t total = (size_t)npages * page_elems;
@@ -35,7 +36,7 @@ __global__ void kv_fill_kernel(T* __restrict__ pool, const int32_t* __restrict__
         const int p = (int)(i / page_elems);
         const size_t e = i % page_elems;
         const uint16_t b = f32_to_bf16(synth_val((uint32_t)i, tseed, mul, 0.f));
-        if constexpr (sizeof(T) == 2) pool[(size_t)pages[p] * page_elems + e] = b;
+        if constexpr (sizeof(T) == 2) pool[(size_t)pages[p] * page_elems + e] = F16 ? f32_to_f16(bf16_to_f32(b)) : b;
         else pool[(size_t)pages[p] * page_elems + e] = bf16_to_f32(b);
     }
 }
@@ -59,13 +60,14 @@ void launch_kv_fill_quant(void* pool, const int32_t* pages, int npages, size_t p
     hipLaunchKernelGGL(kv_fill_quant_kernel, dim3(blocks), dim3(256), 0, s, (uint8_t*)pool, pages, npages, page_bytes, code_bytes, tseed);
 }
 
-void launch_kv_fill(void* pool, bool f32, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
+void launch_kv_fill(void* pool, int kvt, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
                     hipStream_t s) {
     const size_t total = (size_t)npages * page_elems;
     int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
     if (blocks < 1) blocks = 1;
-    if (f32) hipLaunchKernelGGL(kv_fill_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)pool, pages, npages, page_elems, tseed);
-    else hipLaunchKernelGGL(kv_fill_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed);
+    if (kvt == KV_F32) hipLaunchKernelGGL((kv_fill_kernel<float, false>), dim3(blocks), dim3(256), 0, s, (float*)pool, pages, npages, page_elems, tseed);
+    else if (kvt == KV_F16) hipLaunchKernelGGL((kv_fill_kernel<uint16_t, true>), dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed);
+    else hipLaunchKernelGGL((kv_fill_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed);
 }
 
 }  // namespace cm

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
             const int d = lane + 64 * j;
             if (d < rot) {
                 const int i = d < hrot ? d : d - hrot;
-                int rp = pos;
+                int rp = pos + a.rope_delta;
                 if (a.pos3 != nullptr) {   // index-interleaved MRoPE (qwen3_5/modeling.rs:156-245): column i -> axis i % 3
                     const int ax = (i % 3 == 1 && i < 3 * a.sec_h) ? 1 : ((i % 3 == 2 && i < 3 * a.sec_w) ? 2 : 0);
                     rp = a.pos3[ax * a.pos3_stride + s];
@@ -118,12 +118,13 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
         const size_t off = ((size_t)s * Hq + item) * D;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
+            // (f16 pages: the flash kernel multiplies cached halves with q on the f16 matrix-core path, so q is split into f16 hi + lo)
             const float x = xv[j] * a.scale;
-            const uint16_t h = f32_to_bf16(x);
+            const uint16_t h = kv16_from_f32<KVT>(x);
             a.q_hi[off + lane + 64 * j] = h;
-            a.q_lo[off + lane + 64 * j] = f32_to_bf16(x - bf16_to_f32(h));
+            a.q_lo[off + lane + 64 * j] = kv16_from_f32<KVT>(x - kv16_to_f32<KVT>(h));
         }
-    } else if (KVT >= 2) {
+    } else if (KVT == KV_INT8 || KVT == KV_INT4) {
         // quantize_per_token (qwen3_5/kv_cache.rs:253-268), same arithmetic as the decode kernel's append
         constexpr float QMAX = KVT == 2 ? 127.f : 7.f, OFFS = KVT == 2 ? 128.f : 8.f;
         constexpr int ROWB = KVT == 2 ? D : D / 2;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             if (KVF32) ((float*)pool)[off + lane + 64 * j] = xv[j];
-            else ((uint16_t*)pool)[off + lane + 64 * j] = f32_to_bf16(xv[j]);
+            else ((uint16_t*)pool)[off + lane + 64 * j] = kv16_from_f32<KVT>(xv[j]);
         }
     }
 }
@@ -415,8 +416,11 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
 // causal flash attention over the paged cache.  grid (ceil(S/64), Hq), 4 waves x 16 query rows.
 // ---------------------------------------------------------------------------------------------
 // V tile row stride in LDS = D + 16 elements: the 4 key rows of a tr-read group land on disjoint banks
-template <int D, bool KVF32>
+// KVT: KV_BF16 pages (K rows / V^T fragments feed the bf16 MFMAs as cached), KV_F16 pages (the same on the f16 MFMAs; q_hi / q_lo
+// and P are then f16 hi + lo), KV_F32 (f32 rows split into bf16 hi + lo on load: the ViT scratch, f32 pages, the int8 / int4 shadow)
+template <int D, int KVT>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
+    constexpr bool KVF32 = KVT == KV_F32;
     constexpr int KT = 64, VLD = D + 16, NKS = D / 32, NNT = D / 16;
     __shared__ __attribute__((aligned(16))) uint16_t Vs[KVF32 ? 2 : 1][KT * VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -493,9 +497,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
                 } else {
                     kh = *(const bf16x8*)((const uint16_t*)a.kpool + kb + ks * 32);
                 }
-                s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], s[tt], 0, 0, 0);
-                s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], s[tt], 0, 0, 0);
-                if (KVF32) s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], s[tt], 0, 0, 0);
+                s[tt] = mma_k32<KVT>(kh, qh[ks], s[tt]);
+                s[tt] = mma_k32<KVT>(kh, ql[ks], s[tt]);
+                if (KVF32) s[tt] = mma_k32<KVT>(kl, qh[ks], s[tt]);
             }
         }
         // ---- causal mask + online softmax (row statistics live in the lanes with the same `sub`) ----
@@ -520,9 +524,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const float p = expf(s[tt][r] - m_new);      // exp(-inf) = 0 for masked tokens
                 psum += p;
-                const uint16_t hh = f32_to_bf16(p);
+                const uint16_t hh = kv16_from_f32<KVT>(p);
                 ph[tt][r] = (short)hh;
-                pl[tt][r] = (short)f32_to_bf16(p - bf16_to_f32(hh));
+                pl[tt][r] = (short)kv16_from_f32<KVT>(p - kv16_to_f32<KVT>(hh));
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -536,12 +540,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
             for (int nt = 0; nt < NNT; ++nt) {
                 const uint16_t* vp = &Vs[0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
                 const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, ph[tt], o[nt], 0, 0, 0);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vh, pl[tt], o[nt], 0, 0, 0);
+                o[nt] = mma_k16<KVT>(vh, ph[tt], o[nt]);
+                o[nt] = mma_k16<KVT>(vh, pl[tt], o[nt]);
                 if (KVF32) {
                     const uint16_t* vq = &Vs[KVF32 ? 1 : 0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
                     const bf16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vq);
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vl, ph[tt], o[nt], 0, 0, 0);
+                    o[nt] = mma_k16<KVT>(vl, ph[tt], o[nt]);
                 }
             }
         }
@@ -580,6 +584,7 @@ void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, int kv_mode, hipSt
     if (kv_mode == 1) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 1>), grid, dim3(64), 0, s, a); \
     else if (kv_mode == 2) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 2>), grid, dim3(64), 0, s, a); \
     else if (kv_mode == 3) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 3>), grid, dim3(64), 0, s, a); \
+    else if (kv_mode == KV_F16) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, KV_F16>), grid, dim3(64), 0, s, a); \
     else hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 0>), grid, dim3(64), 0, s, a);
     if (D == 128) { CM_QK(128) } else { CM_QK(256) }
 #undef CM_QK
@@ -712,16 +717,19 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
 #undef CM_GEMM
     return true;
 }
-void launch_attn_prefill(const AttnPreArgs& a, int D, bool kv_f32, hipStream_t s) {
+// kvt: KV_BF16 | KV_F16 | KV_F32 (the element type the kernel READS: f32 for the ViT scratch and the int8 / int4 shadow)
+void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s) {
     dim3 grid((a.S + 63) / 64, a.Hq);
     if (D == 64) {
-        hipLaunchKernelGGL((attn_prefill_kernel<64, true>), grid, dim3(256), 0, s, a);     // ViT: f32 K/V scratch
+        hipLaunchKernelGGL((attn_prefill_kernel<64, KV_F32>), grid, dim3(256), 0, s, a);     // ViT: f32 K/V scratch
     } else if (D == 128) {
-        if (kv_f32) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, dim3(256), 0, s, a);
+        if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F32>), grid, dim3(256), 0, s, a);
+        else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F16>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<128, KV_BF16>), grid, dim3(256), 0, s, a);
     } else {
-        if (kv_f32) hipLaunchKernelGGL((attn_prefill_kernel<256, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((attn_prefill_kernel<256, false>), grid, dim3(256), 0, s, a);
+        if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<256, KV_F32>), grid, dim3(256), 0, s, a);
+        else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<256, KV_F16>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_prefill_kernel<256, KV_BF16>), grid, dim3(256), 0, s, a);
     }
 }
 

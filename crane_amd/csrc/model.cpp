@@ -247,10 +247,17 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     nsplit_mfma = std::max(nsplit, std::min(64, 2 * num_cu / std::max(1, Hkv_l)));
     if (const char* e = getenv("CM_ATTN_MFMA_NSPLIT")) nsplit_mfma = std::max(1, std::min(64, atoi(e)));
     use_graph = opts.use_graph >= 0;
-    if (opts.kv_dtype > CM_KV_INT4) throw CmError(CM_ERR_INVALID, "bad kv_dtype");
-    kv_mode = (int)opts.kv_dtype;
-    kv_f32 = kv_mode == CM_KV_F32;
-    kv_esize = kv_f32 ? 4 : (kv_mode >= CM_KV_INT8 ? 1 : 2);
+    // public cm_kv_dtype -> internal page element type (KV_*, the template parameter of the attention kernels)
+    switch (opts.kv_dtype) {
+        case CM_KV_F16: kv_mode = KV_F16; break;
+        case CM_KV_F32: kv_mode = KV_F32; break;
+        case CM_KV_INT8: kv_mode = KV_INT8; break;
+        case CM_KV_INT4: kv_mode = KV_INT4; break;
+        case CM_KV_BF16: kv_mode = KV_BF16; break;
+        default: throw CmError(CM_ERR_INVALID, "bad kv_dtype");
+    }
+    kv_f32 = kv_mode == KV_F32;
+    kv_esize = kv_f32 ? 4 : (kvq() ? 1 : 2);
     seqs.resize((size_t)max_seqs + 1);
     seqs[0].used = true;
 }
@@ -300,8 +307,8 @@ void Model::alloc_runtime() {
     kv_index.assign((size_t)cfg.L, -1);
     n_kv_layers = 0;
     for (int i = 0; i < cfg.L; ++i) if (cfg.layer_full(i)) kv_index[(size_t)i] = n_kv_layers++;
-    kv_row_bytes = kv_mode == CM_KV_F32 ? (size_t)D * 4 : (kv_mode == CM_KV_INT8 ? (size_t)D : (kv_mode == CM_KV_INT4 ? (size_t)D / 2 : (size_t)D * 2));
-    page_bytes = (size_t)Hkv_l * page * (kv_row_bytes + (kv_mode >= CM_KV_INT8 ? 4 : 0));
+    kv_row_bytes = kv_mode == KV_F32 ? (size_t)D * 4 : (kv_mode == KV_INT8 ? (size_t)D : (kv_mode == KV_INT4 ? (size_t)D / 2 : (size_t)D * 2));
+    page_bytes = (size_t)Hkv_l * page * (kv_row_bytes + (kvq() ? 4 : 0));
     kv_pool = (uint8_t*)dalloc<uint16_t>(((size_t)n_kv_layers * 2 * n_pages * page_bytes + 1) / 2);
     free_pages.resize((size_t)n_pages);
     for (int64_t i = 0; i < n_pages; ++i) free_pages[(size_t)i] = (int32_t)(n_pages - 1 - i);
@@ -362,7 +369,7 @@ bool Model::engine_eligible(std::string* why) const {
 // the whole token in one launch needs the attention inside the kernel: bf16 pages, head_dim 128, GQA group of 4, one
 // workgroup per (kv head, token split) with at most 32 splits
 bool Model::engine_full_eligible() const {
-    if (cfg.D != 128 || nrep != 4 || kv_mode != CM_KV_BF16 || !cfg.qk_norm) return false;
+    if (cfg.D != 128 || nrep != 4 || (kv_mode != KV_BF16 && kv_mode != KV_F16) || !cfg.qk_norm) return false;
     if (num_cu % Hkv_l) return false;
     const int ns = num_cu / Hkv_l, opb = ns > 0 ? nrep * cfg.D / ns : 0;
     return ns >= 1 && ns <= 32 && (nrep * cfg.D) % ns == 0 && opb >= 2 && opb <= 16 && opb % 2 == 0 && cfg.D % opb == 0;
@@ -440,6 +447,7 @@ void Model::build_engine() {
     const int ns = std::max(1, num_cu / std::max(1, Hkv_l));
     const size_t gsz[ENG_NEDGE] = {(size_t)H, (size_t)qkv_rows, (size_t)Hkv_l * ns * nrep * (D + 2), (size_t)Hq_l * D, (size_t)H, (size_t)I_l};
     for (int e = 0; e < ENG_NEDGE; ++e) {
+        eng_gsz[e] = gsz[e];
         eng_gran[e] = (unsigned long long*)dalloc<int>(gsz[e] * 2);
         CM_HIP(hipMemset(eng_gran[e], 0, gsz[e] * 8));       // tag 0 is never a valid epoch
     }
@@ -451,6 +459,17 @@ void Model::build_engine() {
         return;
     }
     engine_on = true;
+    engine_capable = true;
+    engine_full_capable = engine_full;
+}
+
+void Model::drop_graphs() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (int v = 0; v < 5; ++v) {
+        if (graph_exec[v]) { (void)hipGraphExecDestroy(graph_exec[v]); graph_exec[v] = nullptr; }
+        if (graph[v]) { (void)hipGraphDestroy(graph[v]); graph[v] = nullptr; }
+        graph_ok[v] = false;
+    }
 }
 
 EngArgs Model::engine_args_common() const {
@@ -464,6 +483,7 @@ EngArgs Model::engine_args_common() const {
     e.Hkv = Hkv_l; e.page = page; e.max_pages = max_pages_per_seq;
     e.q_off = 0; e.k_off = Hq_l * cfg.D; e.v_off = e.k_off + Hkv_l * cfg.D;
     e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
+    e.kv_f16 = kv_mode == KV_F16 ? 1 : 0;
     e.dbg = eng_dbg; e.tune = eng_tune;
     return e;
 }
@@ -518,15 +538,31 @@ void Model::engine_trace(float* out, size_t n) {
     engine_check();
 }
 
-void Model::engine_check() {
-    if (!engine_on) return;
+// The persistent kernel spin-waits across all of its workgroups, so every one of them must be resident at the same time: one
+// workgroup per CU on an otherwise idle device (see crane_mi355.h).  A second tenant -- another handle's kernels, another
+// process, a profiler's serialisation -- can break that; the bounded spins then raise the error word and the launch ends with
+// garbage in the residual stream and in the K/V rows of the step.  That must not kill the handle: the word is cleared, the
+// persistent kernel switched off for this handle (the per-projection launch path takes over), the captured graphs dropped,
+// and the caller replays the step(s) it had enqueued -- a replay rewrites the same K/V rows.
+bool Model::engine_failed() {
+    if (!engine_on) return false;
     CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
-    if (h_st->rsv[2] != 0) {
-        char b[96];
-        snprintf(b, sizeof b, "persistent chain kernel timed out (code 0x%x): workgroups not co-resident?", (unsigned)h_st->rsv[2]);
-        throw CmError(CM_ERR_DEVICE, b);
-    }
+    if (h_st->rsv[2] == 0) return false;
+    eng_fail_code = (uint32_t)h_st->rsv[2];
+    const int32_t zero = 0;
+    CM_HIP(hipMemcpy(&st->rsv[2], &zero, 4, hipMemcpyHostToDevice));
+    engine_on = false;
+    drop_graphs();
+    return true;
+}
+
+void Model::engine_check() {
+    if (!engine_failed()) return;
+    char b[192];
+    snprintf(b, sizeof b, "persistent decode kernel timed out (code 0x%x): its workgroups were not co-resident; it is now switched "
+             "off for this handle (per-projection launches), repeat the call", (unsigned)eng_fail_code);
+    throw CmError(CM_ERR_DEVICE, b);
 }
 
 // ------------------------------------------------------------------------------------
@@ -665,7 +701,7 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
         if (cfg.layer_full(i)) {
             const uint64_t qrows = (uint64_t)(cfg.hybrid ? 2 * Hq_l : Hq_l) * D;
             w_elems += (qrows + 2ull * Hkv_l * D) * H + H * (uint64_t)Hq_l * D + (cfg.qk_norm ? 2 * D : 0) + mlp;
-            extra += 2ull * Hkv_l * ctx * (kv_row_bytes + (kv_mode >= CM_KV_INT8 ? 4 : 0));
+            extra += 2ull * Hkv_l * ctx * (kv_row_bytes + (kvq() ? 4 : 0));
         } else {
             w_elems += (uint64_t)in_proj_rows * H + H * (uint64_t)cfg.value_dim() + mlp;
             extra += 2ull * cfg.NV * cfg.Kd * cfg.Vd * 4 + 2ull * cfg.conv_dim() * (cfg.conv_k - 1) * 4 +
@@ -757,7 +793,7 @@ void Model::enqueue_decode_step(bool advance) {
         a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr;
         a.rot_dim = cfg.rot_dim;
         a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps; a.scale = (float)(1.0 / std::sqrt((double)D));
-        const bool heads = attn_variant == 1 && kv_mode < CM_KV_INT8;      // short context: per-head blocks, merge fused into o_proj's prologue
+        const bool heads = attn_variant == 1 && (kv_mode == KV_BF16 || kv_mode == KV_F32);      // short context: per-head blocks, merge fused into o_proj's prologue
         if (heads) {
             if (!launch_attn_decode_heads(a, D, nrep, attn_ns, kv_f32, 1, s)) throw CmError(CM_ERR_UNSUPPORTED, "head_dim");
         } else if (attn_variant >= 2) {      // bf16 KV: matrix-core flash-decode (32 token splits, 64 for long contexts)
@@ -918,7 +954,7 @@ void Model::ensure_prefill_buffers() {
     const size_t at_cols = std::max((size_t)Hq_l * D, (size_t)(cfg.hybrid ? cfg.value_dim() : 0));
     pAT_hi = z((size_t)chunk_pad * at_cols); pAT_lo = z((size_t)chunk_pad * at_cols);
     pHH_hi = z((size_t)chunk_pad * I_l); pHH_lo = z((size_t)chunk_pad * I_l);
-    if (kv_mode >= CM_KV_INT8) {
+    if (kvq()) {
         const size_t shadow = (size_t)max_pages_per_seq * Hkv_l * page * D;
         kshadow = dalloc<float>(shadow);
         vshadow = dalloc<float>(shadow);
@@ -941,10 +977,15 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         const int S = (int)std::min<size_t>((size_t)chunk, n - off);
         const int sp = (int)(start_pos + off);
         CM_HIP(hipStreamSynchronize(s));                       // h_ids reuse
+        if (embeds_host != nullptr) {                          // forward_embeds: the caller's hidden rows ARE the layer-0 input
+            CM_HIP(hipMemcpyAsync(pX, embeds_host + off * (size_t)H, (size_t)S * H * sizeof(float), hipMemcpyHostToDevice, s));
+            CM_HIP(hipStreamSynchronize(s));                   // (pageable source: do not let the caller's buffer race)
+        } else {
         memcpy(h_ids, ids + off, (size_t)S * sizeof(uint32_t));
         CM_HIP(hipMemcpyAsync(d_ids, h_ids, (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_rows_q(q_embed, d_ids, pX, S, H, cfg.V, s);
         else launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, s);
+        }
         if (splice_map_dev) launch_splice_rows(pX, vFeat, splice_map_dev + off, S, H, s);   // image rows over <|image_pad|>
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
@@ -1005,9 +1046,10 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = sp; q.eps = cfg.eps;
             q.row_stride = qkv_rows; q.q_off = 0; q.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; q.v_off = q.k_off + Hkv_l * D;
             q.rot_dim = cfg.rot_dim; q.pos3 = pos3_dev ? pos3_dev + off : nullptr; q.pos3_stride = pos3_stride;
+            q.rope_delta = seqs[(size_t)active_seq].rope_delta;      // text tokens after an image prompt rotate at pos + delta, like the decode step
             q.sec_h = cfg.mrope_sec[1]; q.sec_w = cfg.mrope_sec[2];
             q.scale = (float)(1.0 / std::sqrt((double)D));
-            const bool kvq = kv_mode >= CM_KV_INT8;
+            const bool kvq = this->kvq();
             if (kvq) {
                 // KvCache::Quant (qwen3_5/kv_cache.rs:303-325): append() returns dequantize(full cache); the attention of this
                 // chunk therefore reads an f32 shadow of the layer: old tokens dequantised from the pages, new tokens written
@@ -1022,7 +1064,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             at.out_hi = pAT_hi; at.out_lo = pAT_lo; at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
             at.page = page; at.start_pos = sp; at.causal = 1;
             at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
-            launch_attn_prefill(at, D, kv_f32 || kvq, s);
+            launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
             g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
@@ -1059,7 +1101,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         }
         if (off + (size_t)S >= n) {     // last chunk: logits of the LAST position only (modeling.rs:1032-1035)
             CM_HIP(hipMemcpyAsync(x, pX + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-            launch_set_state(st, ids[n - 1], (int32_t)(start_pos + n - 1), active_seq, seqs[(size_t)active_seq].rope_delta, s);
+            launch_set_state(st, ids ? ids[n - 1] : 0u, (int32_t)(start_pos + n - 1), active_seq, seqs[(size_t)active_seq].rope_delta, s);
             ++ring_count;
             enqueue_lm_head(true);
         }
@@ -1071,7 +1113,7 @@ void Model::run_decode_step(bool advance, int64_t ctx_len) {
     ++ring_count;    // host mirror of st->pad (ring write index)
     // attention variant by context length (host-known): one captured graph per variant
     attn_variant = (attn_heads_max > 0 && ctx_len <= attn_heads_max) ? 1 : 0;
-    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode != CM_KV_F32 && (cfg.D == 128 || cfg.D == 256) && (page & (page - 1)) == 0)
+    if (attn_mfma_min > 0 && ctx_len >= attn_mfma_min && kv_mode != KV_F32 && (cfg.D == 128 || cfg.D == 256) && (page & (page - 1)) == 0)
         attn_variant = ctx_len >= attn_mfma_wide_min ? 3 : 2;
     if (engine_on && engine_full && ctx_len <= eng_full_max_ctx) attn_variant = 4;    // whole-token persistent launch
     const int v = attn_variant;
@@ -1168,7 +1210,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
         int64_t longest = 0;
         for (int b = 0; b < nb; ++b) longest = std::max(longest, seq(sq[g0 + b]).len + 1);
-        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && kv_mode < CM_KV_INT8 && nb <= 8;
+        const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && (kv_mode == KV_BF16 || kv_mode == KV_F32) && nb <= 8;
         const bool gemm_b = gemm_b_ok && nb >= batch_gemm_min && nb <= chunk;
         // y[nb, N] (+)= A[nb, K] . W^T through launch_gemm; A = the bf16 hi + lo rows produced by rows_in
         auto gm = [&](int epi, const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, float* C, int ldc, int N, int K) {
@@ -1314,7 +1356,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.dshift = D == 128 ? 7 : 8;
                     launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else {
-                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode != CM_KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
+                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode != KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
                 if (mf) {
                     // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
                     const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
@@ -1428,9 +1470,14 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     if (use_prefill) {
         prefill(ids, n, start_pos);
     } else {
-        for (size_t i = 0; i < n; ++i) {     // token-serial path (also the parity cross-check of prefill)
-            launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, q.rope_delta, stream);
-            run_decode_step(true, (int64_t)(start_pos + i + 1));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (size_t i = 0; i < n; ++i) {     // token-serial path (also the parity cross-check of prefill)
+                launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, q.rope_delta, stream);
+                run_decode_step(true, (int64_t)(start_pos + i + 1));
+            }
+            // a timed-out persistent launch switched itself off: the same steps again on the per-projection launches
+            // (they rewrite the K/V rows of these positions; the recurrent GDN family never runs the persistent kernel)
+            if (!engine_on || !engine_failed()) break;
         }
     }
     q.len = (int64_t)(start_pos + n);
@@ -1441,10 +1488,6 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     }
     if (logits_out) fetch_logits(logits_out);
     if (!greedy_out && !logits_out) CM_HIP(hipStreamSynchronize(stream));
-    if (engine_on && !use_prefill) {
-        if (greedy_out) { if (h_st->rsv[2] != 0) engine_check(); }      // h_st was just copied
-        else engine_check();
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1519,7 +1562,7 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
             for (size_t i = 0; i < want; ++i) run_decode_step(true, q.len + (int64_t)i + 1);
             CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CM_HIP(hipStreamSynchronize(stream));
-            engine_check();
+            if (engine_on && engine_failed()) continue;     // nothing of this chunk was emitted: the same steps again, launch path
             size_t used = 0;
             for (size_t i = 0; i < want && !stop; ++i) { emit(h_ring[(ring0 + i) & (RING - 1)]); ++used; }
             q.len += (int64_t)used;     // tokens decoded past an EOS/stop stay beyond len and are overwritten later
@@ -1669,14 +1712,14 @@ void Model::debug_fill_kv(size_t ctx, uint64_t seed) {
     Seq& q = seq(0);
     for (int li = 0; li < cfg.L; ++li) {
         if (!cfg.layer_full(li)) continue;
-        if (kv_mode >= CM_KV_INT8) {
+        if (kvq()) {
             const size_t code_bytes = (size_t)Hkv_l * page * kv_row_bytes;
             launch_kv_fill_quant(kpool(li), d_bt, (int)q.pages.size(), page_bytes, code_bytes, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
             launch_kv_fill_quant(vpool(li), d_bt, (int)q.pages.size(), page_bytes, code_bytes, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
             continue;
         }
-        launch_kv_fill(kpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
-        launch_kv_fill(vpool(li), kv_f32, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
+        launch_kv_fill(kpool(li), kv_mode, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
+        launch_kv_fill(vpool(li), kv_mode, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
     }
     CM_HIP(hipStreamSynchronize(stream));
     q.len = (int64_t)ctx;

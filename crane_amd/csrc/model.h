@@ -139,12 +139,14 @@ struct Model {
     std::vector<void*> allocs;
     std::vector<size_t> alloc_sizes;   // weight bytes of each allocation (0 for scratch)
 
-    // paged KV pool: [L][2][n_pages][Hkv_l][page][D] bf16 (or f32: cm_opts.kv_dtype)
+    // paged KV pool: [L][2][n_pages][Hkv_l][page][D] f16 (default) / bf16 / f32, or int8 / int4 codes + scales: cm_opts.kv_dtype
     uint8_t* kv_pool = nullptr;
     size_t page_elems = 0;
     size_t kv_esize = 2;               // bytes per cached element for the roofline accounting (int4: counted as 1/2 below)
     bool kv_f32 = false;
-    int kv_mode = 0;                   // cm_kv_dtype: 0 bf16, 1 f32, 2 int8, 3 int4 (per-token symmetric, qwen3_5/kv_cache.rs:209-342)
+    int kv_mode = KV_F16;              // internal page element type (dev_common.h KV_*: bf16, f32, int8 / int4 per-token symmetric
+                                       // -- qwen3_5/kv_cache.rs:209-342 --, f16), mapped from cm_opts.kv_dtype in init_common
+    bool kvq() const { return kv_mode == KV_INT8 || kv_mode == KV_INT4; }
     size_t kv_row_bytes = 0;           // bytes of one token row of one KV head
     size_t page_bytes = 0;             // bytes of one page of one (layer, K|V): rows + (quantised) f32 scales
     std::vector<int32_t> free_pages;
@@ -172,6 +174,11 @@ struct Model {
     int vision_encode(const float* pix, size_t n_patches, const uint32_t* grid, size_t n_img);   // -> vFeat, returns rows
     void vlm_forward(int s, const uint32_t* ids, size_t n, size_t start_pos, const float* pix, size_t n_patches,
                      const uint32_t* grid, size_t n_img, float* logits_out, uint32_t* greedy_out);
+    // Qwen3_5TextModel::embed_only / forward_embeds (qwen3_5/model.rs:368,430): the decoder over caller-supplied hidden rows
+    void embed_tokens(const uint32_t* ids, size_t n, float* out);
+    void forward_embeds(int s, const float* embeds, size_t n, const int32_t* pos3, size_t start_pos, float* logits_out, uint32_t* greedy_out);
+    const float* embeds_host = nullptr;  // set only while forward_embeds runs: prefill() uploads these rows instead of gathering ids
+    float* dEmb = nullptr;               // device staging of embed_tokens
 
     // per-sequence GDN state pools (Qwen3.5): [slots][gdn_layers][...]
     int gdn_layers = 0, in_proj_rows = 0, in_proj_pad = 0;
@@ -294,8 +301,16 @@ struct Model {
     EngArgs engine_args_common() const;
     EngArgs engine_args(int li) const;
     EngArgs engine_args_full() const;
-    void engine_trace(float* out, size_t n);   // debug: microsecond timestamps of one traced launch
-    void engine_check();                       // after a host sync: throws if a launch timed out (StepState.rsv[2])
+    void engine_trace(float* out, size_t n);   // debug: microsecond timestamps of one traced launch; runs on a scratch sequence state
+    void engine_check();                       // after a host sync: throws if a launch timed out (StepState.rsv[2]); the kernel is
+                                               // then already switched off for this handle (engine_failed), later calls work
+    bool engine_failed();                      // syncs; true if a launch timed out: error word cleared, persistent kernel disabled,
+                                               // graphs dropped -- the caller replays its step(s) on the per-projection launches
+    bool engine_capable = false;               // build_engine succeeded (cm_debug_set("engine", 1) may switch it back on)
+    bool engine_full_capable = false;
+    size_t eng_gsz[ENG_NEDGE] = {0, 0, 0, 0, 0, 0};   // granules per edge buffer (bounds of cm_debug_read("eng_*"))
+    uint32_t eng_fail_code = 0;                // code of the last timeout (0: none)
+    void drop_graphs();                        // forget every captured decode step (a switch that changes what a step enqueues)
 
     hipGraph_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
     hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // (4 = whole-token persistent launch)

@@ -125,7 +125,7 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
             at.out_hi = vB_hi + (size_t)fr.first * VH; at.out_lo = vB_lo + (size_t)fr.first * VH;
             at.S = fr.second - fr.first; at.Hq = heads; at.Hkv = heads; at.nrep = 1; at.page = 64;
             at.start_pos = fr.first; at.causal = 0; at.kv_lo = fr.first; at.kv_hi = fr.second;
-            launch_attn_prefill(at, 64, true, s);
+            launch_attn_prefill(at, 64, KV_F32, s);
         }
         gemm(vB_hi, vB_lo, b.proj_w, b.proj_b, N, VH, VH, GEPI_RESADD, vX, nullptr, nullptr, 0);
         launch_layernorm_rows(vX, b.n2w, b.n2b, vA_hi, vA_lo, N, VH, 1e-6f, s);
@@ -208,6 +208,71 @@ void Model::vlm_forward(int sidx, const uint32_t* ids, size_t n, size_t start_po
     splice_map_dev = nullptr; pos3_dev = nullptr; deep_layers = 0;
     q.len = (int64_t)(start_pos + n);
     q.rope_delta = nxt - (int32_t)q.len;
+    if (greedy_out) {
+        CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
+        CM_HIP(hipStreamSynchronize(stream));
+        *greedy_out = h_st->next;
+    }
+    if (logits_out) fetch_logits(logits_out);
+    if (!greedy_out && !logits_out) CM_HIP(hipStreamSynchronize(stream));
+}
+
+// Qwen3_5TextModel::embed_only (qwen3_5/model.rs:368-370): rows of the embedding table as f32 (exact: bf16 -> f32)
+void Model::embed_tokens(const uint32_t* ids, size_t n, float* out) {
+    if (!ids || !out || n == 0) throw CmError(CM_ERR_INVALID, "empty input");
+    for (size_t i = 0; i < n; ++i) if (ids[i] >= (uint32_t)cfg.V) throw CmError(CM_ERR_RANGE, "token id >= vocab_size");
+    ensure_prefill_buffers();
+    if (!prefill_ok) throw CmError(CM_ERR_UNSUPPORTED, "prefill buffers unavailable for this model");
+    const int H = cfg.H;
+    for (size_t off = 0; off < n; off += (size_t)chunk) {
+        const int S = (int)std::min<size_t>((size_t)chunk, n - off);
+        CM_HIP(hipStreamSynchronize(stream));
+        memcpy(h_ids, ids + off, (size_t)S * sizeof(uint32_t));
+        CM_HIP(hipMemcpyAsync(d_ids, h_ids, (size_t)S * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_rows_q(q_embed, d_ids, pX, S, H, cfg.V, stream);
+        else launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, stream);
+        CM_HIP(hipMemcpyAsync(out + off * (size_t)H, pX, (size_t)S * H * sizeof(float), hipMemcpyDeviceToHost, stream));
+        CM_HIP(hipStreamSynchronize(stream));
+    }
+}
+
+// Qwen3_5TextModel::forward_embeds (qwen3_5/model.rs:430-510): run the decoder over hidden rows the caller built (text
+// embeddings with image features spliced in) at explicit 3-axis MRoPE positions; logits of the last position only.  Causal
+// over the cached prefix + these rows (the reference's default mask, prefill.rs:56-136).  pos3 == null: positions
+// start_pos + i + rope_delta on all three axes (a text-only continuation).  The sequence's MRoPE counter for later decode
+// steps becomes max(pos3) + 1 (vlm.rs:294-301: rope_delta = counter - cached length).
+void Model::forward_embeds(int sidx, const float* embeds, size_t n, const int32_t* pos3, size_t start_pos, float* logits_out,
+                           uint32_t* greedy_out) {
+    if (n == 0 || !embeds) throw CmError(CM_ERR_INVALID, "empty input");
+    Seq& q = seq(sidx);
+    if ((int64_t)start_pos != q.len) throw CmError(CM_ERR_RANGE, "forward_embeds must continue exactly at the cached length");
+    if (start_pos + n > (size_t)max_seq) throw CmError(CM_ERR_RANGE, "start_pos + n exceeds max_seq_len");
+    ensure_prefill_buffers();
+    if (!prefill_ok) throw CmError(CM_ERR_UNSUPPORTED, "prefill GEMM shapes unsupported for this model");
+    int32_t top = -1;
+    if (pos3) {
+        if ((int)n > chunk) throw CmError(CM_ERR_UNSUPPORTED, "explicit positions for more rows than prefill_chunk are not implemented");
+        for (size_t i = 0; i < 3 * n; ++i) {
+            if (pos3[i] < 0 || pos3[i] >= max_seq) throw CmError(CM_ERR_RANGE, "position id outside the rotary table");
+            top = std::max(top, pos3[i]);
+        }
+        if (!dMap) { dMap = dalloc<int>(chunk); dPos3 = dalloc<int>((size_t)3 * chunk); }
+        CM_HIP(hipMemcpyAsync(dPos3, pos3, 3 * n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        CM_HIP(hipStreamSynchronize(stream));
+    }
+    ensure_pages(sidx, (int64_t)(start_pos + n));
+    activate(sidx);
+    embeds_host = embeds;
+    pos3_dev = pos3 ? dPos3 : nullptr; pos3_stride = (int)n;
+    try {
+        prefill(nullptr, n, start_pos);
+    } catch (...) {
+        embeds_host = nullptr; pos3_dev = nullptr;
+        throw;
+    }
+    embeds_host = nullptr; pos3_dev = nullptr;
+    q.len = (int64_t)(start_pos + n);
+    if (pos3) q.rope_delta = top + 1 - (int32_t)q.len;
     if (greedy_out) {
         CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
         CM_HIP(hipStreamSynchronize(stream));

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 1
+#define CM_ABI_VERSION 2
 
 typedef enum cm_status {
     CM_OK = 0,
@@ -48,10 +48,19 @@ typedef enum cm_status {
     CM_ERR_RANGE = -6         /* position / token id out of range             */
 } cm_status;
 
-/* KV cache element type.  INT8 / INT4 = KvCache::Quant (qwen3_5/kv_cache.rs:209-342): per-token symmetric codes
+/* KV cache element type.
+ * F16 (the default, 0): K/V pages hold IEEE binary16.  The reference keeps its cache in the model dtype
+ * (modules/kv_cache.rs:38-101) -- F32 on its CPU path, the forward the parity bar is stated against -- and a bf16 page
+ * (8 significand bits) moves Qwen3-8B-width logits by 1.06e-3 relative to that forward (measured on the HF fixture
+ * tests/golden/qwen3_qwen3-8b-2l.npz).  A binary16 page costs the same 2 bytes per element, keeps 11 significand bits
+ * (1.35e-4 on the same fixture) and converts in one instruction (v_cvt_f32_f16) or feeds the f16 matrix-core
+ * instructions directly; values saturate at +-65504 (K is bounded by the QK-norm, V is a projection of a normalised row).
+ * BF16: the model dtype of a bf16 checkpoint on the reference's GPU path.  F32: 4-byte pages (bit-comparable with the
+ * f32 CPU forward; not available inside the persistent decode kernel).
+ * INT8 / INT4 = KvCache::Quant (qwen3_5/kv_cache.rs:209-342): per-token symmetric codes
  * (scale = amax/qmax + 1e-8, code = round(x/scale) + 128|8, int4 nibble-packed lo + 16*hi) + one f32 scale per
  * (token, kv head); dequantisation is fused into the attention kernel instead of re-materialising the cache. */
-typedef enum cm_kv_dtype { CM_KV_BF16 = 0, CM_KV_F32 = 1, CM_KV_INT8 = 2, CM_KV_INT4 = 3 } cm_kv_dtype;
+typedef enum cm_kv_dtype { CM_KV_F16 = 0, CM_KV_F32 = 1, CM_KV_INT8 = 2, CM_KV_INT4 = 3, CM_KV_BF16 = 4 } cm_kv_dtype;
 
 /* Options of Model::new / select_device / create_backend
  * (qwen3/model.rs:45-106, crane-serve/src/lib.rs:432-499,
@@ -67,15 +76,20 @@ typedef struct cm_opts {
     uint32_t max_seqs;         /* concurrently allocated sequences (default 8)       */
     uint32_t kv_block_size;    /* tokens per KV page (default 64)                    */
     uint64_t kv_pool_tokens;   /* pool capacity in tokens (0: max_seqs*max_seq_len)  */
-    int32_t  kv_dtype;         /* cm_kv_dtype                                        */
+    int32_t  kv_dtype;         /* cm_kv_dtype; default CM_KV_F16 (binary16 pages)    */
     int32_t  use_graph;        /* 0 default(on), 1 on, -1 off: hipGraph decode step  */
     uint32_t prefill_chunk;    /* tokens per prefill chunk (default 2048,            */
                                /*   PREFILL_CHUNK_SIZE engine/mod.rs:65)             */
     int32_t  prefill_split;    /* activation split terms for MFMA GEMMs: 0/2 = bf16x2 (parity), 1 = bf16 */
     uint32_t isq;              /* in-situ quantisation of the linears at load: 0 none, CM_ISQ_Q8_0       */
                                /*   (--quant / CRANE_ISQ, ops/linear.rs:53-116; also read from CRANE_ISQ) */
-    int32_t  engine;           /* persistent per-layer chain kernel for the decode step: 0 default (on when the  */
-                               /*   shapes allow it), 1 require (cm_create fails otherwise), -1 off              */
+    int32_t  engine;           /* persistent decode kernel (one launch per token): 0 default (on when the shapes */
+                               /*   allow it), 1 require (cm_create fails otherwise), -1 off.  The kernel runs   */
+                               /*   one workgroup per CU and its workgroups wait on each other, so it needs the  */
+                               /*   device to itself while it runs: no second handle, process or serialising     */
+                               /*   profiler on the same GPU.  If that is violated the bounded spins time out:   */
+                               /*   the handle then switches the kernel off for good, replays the step on the    */
+                               /*   per-projection launches and carries on (cm_engine_active turns 0).           */
     uint32_t debug_flags;      /* CM_DEBUG_* bits; test hooks only, never set in production                      */
     uint32_t reserved[5];
 } cm_opts;
@@ -274,6 +288,21 @@ int cm_vision_encode(cm_model* m, const float* pixel_values, size_t n_patches, c
 int cm_vlm_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, const float* pixel_values,
                    size_t n_patches, const uint32_t* grid_thw, size_t n_images, float* logits_out, uint32_t* greedy_out);
 
+/* Qwen3_5TextModel::embed_only (qwen3_5/model.rs:368-370): the embedding rows of `ids` as host f32 [n, hidden]
+ * (what the multimodal wrapper splices image features into, vlm.rs:250-285). */
+int cm_embed_tokens(cm_model* m, const uint32_t* ids, size_t n, float* embeds_out);
+
+/* Qwen3_5TextModel::forward_embeds (qwen3_5/model.rs:430-510): every decoder layer over caller-built hidden rows
+ * embeds [n, hidden] (host f32) at explicit MRoPE positions pos3 [3, n] (host i32; axes T, H, W as build_position_ids
+ * emits them, vlm.rs:190-241), appended to sequence `seq` at start_pos == cm_seq_len(seq); causal over the cached prefix
+ * and these rows; logits of the LAST row only (and / or its arg-max).  pos3 == NULL: positions continue the sequence's
+ * own counter on all three axes (text-only rows: identical to cm_seq_forward on the same tokens).  Afterwards the
+ * sequence's MRoPE counter is max(pos3) + 1, so cm_seq_forward / cm_forward_step decode steps continue like
+ * Qwen3_5VLModel::decode_step (vlm.rs:294-301).  No DeepStack injection (the reference's forward_embeds has none; the
+ * Qwen3-VL path with DeepStack is cm_vlm_forward). */
+int cm_forward_embeds(cm_model* m, int32_t seq, const float* embeds, size_t n, const int32_t* pos3, size_t start_pos,
+                      float* logits_out, uint32_t* greedy_out);
+
 /* ---- image preprocessor (host only; PreprocessorConfig::process, qwen3_5/processor.rs:114-210) ----------------------- */
 
 /* preprocessor_config.json (processor.rs:20-35): size.shortest_edge / longest_edge are the min / max PIXEL counts */
@@ -399,7 +428,13 @@ int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x
  * runs the projections of n or more sequences as MFMA GEMMs (0 = never: batched GEMVs, rows bit-equal to cm_forward_step);
  * "attn_splits" = n > 0:
  * the VALU decode attention uses n token splits per kv head in the single AND the batched step (their automatic counts differ,
- * which changes the order of the split merge), 0 = automatic. */
+ * which changes the order of the split merge), 0 = automatic; "prefill_split" = -1 restores cm_opts.prefill_split;
+ * "attn_mfma_min" / "attn_mfma_wide_min" / "attn_heads_max" / "attn_ns": the context thresholds and split counts that pick the
+ * decode-attention kernel (CM_ATTN_* read at cm_create); "engine" = 0 / 1 and "engine_full" = 0 / 1: the persistent decode
+ * kernel off / on and its per-layer / whole-token mode (only where cm_create found the shapes eligible); "quant_act_int" = 1 / 0
+ * and "vision_merger_gelu" = 1 (tanh) / 2 (erf): CM_QUANT_ACT and CM_VISION_MERGER_GELU of the live model.
+ * cm_debug_read("engine_trace") launches the persistent kernel several times on the live state of sequence 0: the K/V rows at
+ * the current position and the residual stream are overwritten -- clear the sequence afterwards. */
 int cm_debug_set(cm_model* m, const char* key, int64_t value);
 
 #ifdef __cplusplus

@@ -11,6 +11,8 @@
  *   B=1 flash attention, online softmax, f32 accumulators, GQA by integer division :380-456
  *   o_proj, SwiGLU MLP (merged gate||up) :419, :608-631
  *   final norm + lm_head on the LAST position only :1024-1035
+ * cfg.kv_bf16 selects the rounding of K/V rows as they enter the cache: 0 none (the reference's F32 CPU cache), 1 bf16 (the
+ * model dtype of its GPU path), 2 IEEE binary16 (the device's default CM_KV_F16 pages).
  * Weights are bf16-stored / f32-computed (candle CPU has no bf16 matmul, modeling.rs:1630-1631:
  * the reference's CPU dtype is F32; we keep the bf16 storage so a 8B model fits and state so).
  * Deterministic synthetic weights: same generator as crane_amd/synth.py (bit-identical).
@@ -49,6 +51,29 @@ typedef struct qc_model {
 
 static inline float bf2f(uint16_t b) { uint32_t u = ((uint32_t)b) << 16; float f; memcpy(&f, &u, 4); return f; }
 static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); }
+
+/* round to IEEE binary16 and back (RNE, saturating at +-65504, subnormals kept): the rounding point of the device's
+ * CM_KV_F16 pages (v_cvt_f16_f32 + clamp).  kv_bf16 == 2 selects it. */
+static inline float f16_round(float f) {
+    if (f > 65504.f) f = 65504.f;
+    if (f < -65504.f) f = -65504.f;
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7FFFFFFFu;
+    float r;
+    if (a >= 0x38800000u) {                     /* |f| >= 2^-14: normal half, keep 10 mantissa bits (RNE on bit 13) */
+        a = (a + 0xFFFu + ((a >> 13) & 1u)) & ~0x1FFFu;
+        memcpy(&r, &a, 4);
+        if (r > 65504.f) r = 65504.f;
+    } else {                                    /* subnormal half: multiples of 2^-24 */
+        float m; memcpy(&m, &a, 4);
+        r = rintf(m * 16777216.0f) * (1.0f / 16777216.0f);   /* rintf = RNE under the default rounding mode */
+    }
+    uint32_t o; memcpy(&o, &r, 4); o |= sign; memcpy(&r, &o, 4);
+    return r;
+}
+
+float qc_f16_round(float f) { return f16_round(f); }     /* known-answer hook: tests/test_c_oracle.py pins it on numpy's float16 */
 
 static uint32_t fnv1a32(const char* s) { uint32_t h = 0x811C9DC5u; for (; *s; ++s) { h ^= (unsigned char)*s; h *= 0x01000193u; } return h; }
 static inline uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
@@ -210,7 +235,8 @@ static void decode_one(qc_model* m, uint32_t tok, int pos, float* logits /* or N
         for (int g = 0; g < Hkv; ++g)
             for (int i = 0; i < D; ++i) {
                 float kk = k[(size_t)g * D + i], vv = v[(size_t)g * D + i];
-                if (c->kv_bf16) { kk = bf2f(f2bf(kk)); vv = bf2f(f2bf(vv)); }
+                if (c->kv_bf16 == 1) { kk = bf2f(f2bf(kk)); vv = bf2f(f2bf(vv)); }
+                else if (c->kv_bf16 == 2) { kk = f16_round(kk); vv = f16_round(vv); }
                 w->k[((size_t)g * c->max_seq + pos) * D + i] = kk;
                 w->v[((size_t)g * c->max_seq + pos) * D + i] = vv;
             }

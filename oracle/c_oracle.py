@@ -19,7 +19,7 @@ SO = os.path.join(_HERE, "c", "libqwen3_cpu.so")
 class QcCfg(C.Structure):
     _fields_ = [("V", C.c_int), ("H", C.c_int), ("I", C.c_int), ("L", C.c_int), ("Hq", C.c_int),
                 ("Hkv", C.c_int), ("D", C.c_int), ("max_seq", C.c_int), ("eps", C.c_float),
-                ("theta", C.c_double), ("tie", C.c_int), ("qk_norm", C.c_int), ("kv_bf16", C.c_int)]
+                ("theta", C.c_double), ("tie", C.c_int), ("qk_norm", C.c_int), ("kv_bf16", C.c_int)]   # kv_bf16: 0 f32, 1 bf16, 2 f16 K/V rounding
 
 
 def _lib():
@@ -101,17 +101,30 @@ class CQwen3:
             pass
 
 
-def time_decode(model_name: str, ctx: int, budget_s: float = 20.0):
-    """bench.py's CPU leg: (cpu_baseline dict, greedy tokens, logits of the first step).
+def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: int = 48, n_new: int = 16):
+    """bench.py's CPU leg: (cpu_baseline dict, greedy tokens, logits of the first step, model-written-cache reference).
 
-    The KV cache of positions [0, ctx) holds the values cm_debug_fill_kv writes on the device and the first token is
-    bench.py's (3), so the tokens / first logits double as the parity reference of the benchmarked configuration.
-    The forward is the f32 CPU forward (K/V appends unrounded)."""
+    Timing: the KV cache of positions [0, ctx) holds the values cm_debug_fill_kv writes on the device and the first token is
+    bench.py's (3) -- the SAME workload the GPU is timed on; the tokens / first logits of that run are returned too, but they
+    only check the kernels at the timed shapes: the filled values are bf16-exact on both sides, so they say nothing about
+    what the device's K/V pages do to values the model wrote itself.
+    Parity proper (4th result): a `prompt_len`-token prompt fed from an EMPTY cache, one decode step and `n_new` greedy tokens
+    -- the f32 CPU forward (K/V appends unrounded) on a cache the model wrote itself; bench.py runs the same through the
+    HIP path (MFMA prefill, then the decode kernels over the pages that prefill wrote) and compares logits and ids."""
     from crane_amd import configs
     cfg = configs.get_config(model_name)
     t0 = time.perf_counter()
     m = CQwen3(cfg, seed=0, max_seq=ctx + 64, kv_bf16=False)
     t_build = time.perf_counter() - t0
+    prompt = configs.synthetic_prompt(prompt_len, cfg["vocab_size"])
+    p_logits = m.forward(prompt, 0)
+    gen = [int(p_logits.argmax())]
+    d_logits = m.forward([gen[0]], prompt_len)                       # the decode step right after the prompt
+    lg = d_logits
+    for i in range(1, n_new):
+        gen.append(int(lg.argmax()))
+        lg = m.forward([gen[-1]], prompt_len + i)
+    written = {"prompt": prompt, "prefill_logits": p_logits, "decode_logits": d_logits, "greedy": gen}
     m.fill_kv_paged(ctx, 1, 64)
     first = m.forward([3], ctx)                # untimed first step (page-in); its logits are the parity reference
     tok = int(first.argmax())
@@ -129,4 +142,4 @@ def time_decode(model_name: str, ctx: int, budget_s: float = 20.0):
     base = {"value": round(n / dt, 3), "unit": "tokens/s", "cores": thr, "kind": "port",
             "sample": f"{n} greedy decode steps of {model_name} at context {ctx} (bf16-stored weights, f32 compute, "
                       f"OpenMP over {thr} host threads; weight synthesis {t_build:.1f}s excluded)"}
-    return base, toks, first
+    return base, toks, first, written

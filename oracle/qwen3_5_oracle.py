@@ -34,7 +34,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .qwen3_oracle import bf16_round, silu, softmax_last
+from .qwen3_oracle import bf16_round, f16_round, silu, softmax_last
 
 F32 = np.float32
 
@@ -191,6 +191,8 @@ class Qwen35Oracle:
         k, v = k.transpose(1, 0, 2), v.transpose(1, 0, 2)
         if self.kv_dtype == "bf16":
             k, v = bf16_round(k), bf16_round(v)
+        elif self.kv_dtype == "f16":                  # CM_KV_F16 pages: IEEE binary16, RNE, saturating at +-65504
+            k, v = f16_round(k), f16_round(v)
         elif self.kv_dtype in ("int8", "int4"):       # KvCache::Quant (qwen3_5/kv_cache.rs:209-342)
             from oracle.kv_quant_oracle import roundtrip
             bits = 8 if self.kv_dtype == "int8" else 4

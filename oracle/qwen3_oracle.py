@@ -72,6 +72,11 @@ class Qwen3Config:
 # --------------------------------------------------------------------------
 # bf16 helpers (round-to-nearest-even, same bit trick as the HIP side)
 # --------------------------------------------------------------------------
+def f16_round(x: np.ndarray) -> np.ndarray:
+    """Rounding point of the device's CM_KV_F16 pages (v_cvt_f16_f32 after a clamp): IEEE binary16, RNE, subnormals kept."""
+    return np.clip(np.asarray(x, dtype=np.float32), -65504.0, 65504.0).astype(np.float16).astype(np.float32)
+
+
 def bf16_round(x: np.ndarray) -> np.ndarray:
     """f32 -> nearest-even bf16 -> f32 (finite inputs)."""
     u = np.ascontiguousarray(x, dtype=F32).view(np.uint32)
@@ -200,6 +205,8 @@ class Qwen3Oracle:
         # k, v: [Hkv, S, D]
         if self.kv_dtype == "bf16":
             k, v = bf16_round(k), bf16_round(v)
+        elif self.kv_dtype == "f16":                  # CM_KV_F16 pages: IEEE binary16, RNE, saturating at +-65504
+            k, v = f16_round(k), f16_round(v)
         elif self.kv_dtype in ("int8", "int4"):       # KvCache::Quant (qwen3_5/kv_cache.rs:209-342)
             from oracle.kv_quant_oracle import roundtrip
             bits = 8 if self.kv_dtype == "int8" else 4

@@ -51,14 +51,16 @@ def test_c_port_matches_hf_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("kv", ["f32", "bf16"])
+@pytest.mark.parametrize("kv", ["f32", "f16", "bf16"])
 def test_hip_path_matches_hf_golden(name, kv):
     from crane_amd.backend import GenerationConfig, Model
     g, cfg, _ = _load(name)
     m = Model.synthetic(cfg, seed=int(g["seed"][0]), max_seq_len=128, max_seqs=2, kv_dtype=kv)
     try:
         ids = g["prompt"].tolist()
-        tol = 1e-4 if kv == "f32" else 4e-3       # f32 KV: well inside the 1e-3 north-star bar; bf16 KV: one bf16 eps
+        # vs the HF f32 forward.  f32 pages: 1e-4; f16 pages (default, benchmarked): the 1e-3 north-star bar; bf16 pages
+        # (opt-in): one bf16 epsilon, not claimed to meet the bar
+        tol = {"f32": 1e-4, "f16": 1e-3, "bf16": 4e-3}[kv]
         assert rel(m.forward_step(ids, 0)[0, 0], g["prefill_logits"]) < tol
         assert rel(m.forward_step(g["decode_token"].tolist(), len(ids))[0, 0], g["decode_logits"]) < tol
         n_new = len(g["greedy_tokens"]) - len(ids)

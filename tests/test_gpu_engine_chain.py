@@ -18,16 +18,15 @@ def rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
-@pytest.fixture(scope="module", params=["full", "layer"])
+@pytest.fixture(scope="module", params=[("full", "f16"), ("layer", "f16"), ("full", "bf16")], ids=lambda p: f"{p[0]}-{p[1]}")
 def trio(request):
+    mode, kv = request.param
     cfg = configs.get_config("eng-qwen3")
     w = synth.synth_weights_f32(cfg, seed=0)
-    os.environ["CM_ENGINE_FULL"] = "1" if request.param == "full" else "0"      # tuning switch, read at cm_create
-    try:
-        eng = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=1)
-    finally:
-        del os.environ["CM_ENGINE_FULL"]
-    ref = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=-1)
+    eng = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=1, kv_dtype=kv)
+    eng.debug_set("engine_full", 1 if mode == "full" else 0)          # whole-token launch / one launch per layer
+    eng.kv = kv
+    ref = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=-1, kv_dtype=kv)
     yield cfg, w, eng, ref
     eng.close()
     ref.close()
@@ -35,7 +34,8 @@ def trio(request):
 
 def test_chain_equals_launch_path_and_oracle(trio):
     cfg, w, eng, ref = trio
-    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=eng.kv)
+    o32 = Qwen3Oracle(Qwen3Config.from_json(cfg), w)                  # the pure f32 CPU forward
     ids = configs.synthetic_prompt(12, cfg["vocab_size"])
     for m in (eng, ref):
         m.clear_kv_cache()
@@ -47,6 +47,9 @@ def test_chain_equals_launch_path_and_oracle(trio):
                                                          # a K/V element on a bf16 tie then rounds the other way (2^-9 on it)
         assert rel(a, c) < 1e-3, (pos, rel(a, c))      # bf16 K/V appends: a value on a rounding tie moves by 2^-9
         assert int(a.argmax()) == int(c.argmax())
+        d = o32.forward([t], pos)
+        if eng.kv == "f16":                              # the default pages: north_star's bar against the unrounded forward
+            assert rel(a, d) < 1e-3, (pos, rel(a, d))
 
 
 def test_chain_generate_and_graph_replay(trio):
@@ -78,7 +81,7 @@ def test_chain_context_beyond_the_prefetched_chunks(ctx):
     cfg = configs.get_config("eng-qwen3")
     outs = []
     for engine in (1, -1):
-        m = Model.synthetic(cfg, seed=0, max_seq_len=ctx + 128, max_seqs=1, engine=engine)
+        m = Model.synthetic(cfg, seed=0, max_seq_len=ctx + 128, max_seqs=1, engine=engine)      # (f16 pages, the default)
         try:
             m.debug_fill_kv(ctx, seed=5)
             toks, _ = m.bench_decode(5, 12)

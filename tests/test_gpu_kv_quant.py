@@ -84,9 +84,9 @@ def test_quantised_kv_chunked_prefill_and_serial_agree(monkeypatch, name, kv):
             outs.append(nxt)
         finally:
             m.close()
-    monkeypatch.setenv("CM_NO_PREFILL", "1")
     m = Model.synthetic(cfg, seed=0, max_seq_len=256, kv_dtype=kv)
     try:
+        m.debug_set("no_prefill", 1)
         serial = m.forward_step(ids, 0).reshape(-1).copy()
     finally:
         m.close()
@@ -113,13 +113,11 @@ def test_quantised_kv_is_close_to_full_precision():
 
 @pytest.mark.parametrize("kv", ["int8", "int4"])
 @pytest.mark.parametrize("mfma_min,wide_min", [(1, 8192), (160, 166)])
-def test_quantised_kv_on_the_mfma_decode_kernel(monkeypatch, kv, mfma_min, wide_min):
+def test_quantised_kv_on_the_mfma_decode_kernel(kv, mfma_min, wide_min):
     """Long-context decode attention on the matrix cores over int8 / int4 pages: (code - offset) are exact bf16 integers
     fed straight to the MFMAs, the per-token scales multiply S^T rows (K) and p (V).  Forced from the first token and
     switched in mid-generation; single sequence and batched."""
     from crane_amd.backend import Model
-    monkeypatch.setenv("CM_ATTN_MFMA_MIN", str(mfma_min))
-    monkeypatch.setenv("CM_ATTN_MFMA_WIDE_MIN", str(wide_min))
     name = "tiny-qwen3-untied"
     cfg = configs.get_config(name)
     w = synth.synth_weights_f32(cfg, seed=0)
@@ -127,6 +125,8 @@ def test_quantised_kv_on_the_mfma_decode_kernel(monkeypatch, kv, mfma_min, wide_
     tol = 2e-3 if kv == "int8" else 1e-3
     m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype=kv)
     try:
+        m.debug_set("attn_mfma_min", mfma_min)
+        m.debug_set("attn_mfma_wide_min", wide_min)
         V = cfg["vocab_size"]
         ids = configs.synthetic_prompt(150, V)
         ref = o.forward(ids, 0)

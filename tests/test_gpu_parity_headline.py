@@ -4,8 +4,9 @@ MFMA prefill tiles over 1024 tokens, the batched step) is compared with the C po
 (oracle/c, f32 compute, pure-f32 KV) on identical synthetic bf16 weights.
 
 The models keep the full width / head / vocabulary geometry and cut the depth to 2 layers so that the CPU side finishes
-in seconds.  The KV mode is the benchmarked one (bf16 pages); the bar is BASELINE.json's: logits within 1e-3 relative of
-the f32 CPU forward, greedy ids equal.  Both decode paths are covered: the per-projection launches and the persistent
+in seconds.  The KV mode is the benchmarked one (f16 pages, the default: bf16 pages measure 1.03e-3 on the 21-token HF
+fixture below -- outside the bar -- and are an opt-in mode that is not claimed to meet it); the bar is BASELINE.json's:
+logits within 1e-3 relative of the f32 CPU forward, greedy ids equal.  Both decode paths are covered: the per-projection launches and the persistent
 chain kernel (cm_opts.engine).
 """
 import os
@@ -131,7 +132,9 @@ def test_decode_and_prefill_qwen3_0p6b_geometry():
 def test_short_prompt_and_step_against_the_hf_golden(name):
     """The committed HF fixtures at the real widths (tests/golden/qwen3_<name>.npz, make_golden_qwen3.py: Qwen3ForCausalLM in
     f32 on the same synthetic checkpoint): a 21-token prompt -- one m-tile of <= 64 rows, i.e. the 64 x 128 split-K GEMM tiles
-    at K = 4096 / 12288 resp. 1024 / 3072 -- and one decode step on top of it, benchmarked KV mode (bf16 pages), bar 1e-3."""
+    at K = 4096 / 12288 resp. 1024 / 3072 -- and one decode step on top of it (the persistent kernel at the 8B widths, over a
+    cache the model wrote itself), benchmarked KV mode (f16 pages), bar 1e-3; then the same prompt token by token (every
+    step a decode step) and the greedy continuation."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"qwen3_{name}.npz"))
     cfg = configs.get_config(name)
     m = Model.synthetic(cfg, seed=int(g["seed"][0]), max_seq_len=256, max_seqs=2)
@@ -145,5 +148,15 @@ def test_short_prompt_and_step_against_the_hf_golden(name):
             assert int(a.argmax()) == int(ref.argmax())
         b = m.forward_step(g["decode_token"].tolist(), len(ids))[0, 0]
         assert rel(b, g["decode_logits"]) < BAR, rel(b, g["decode_logits"])
+        m.debug_set("no_prefill", 1)
+        try:
+            m.clear_kv_cache()
+            c = m.forward_step(ids, 0)[0, 0]
+        finally:
+            m.debug_set("no_prefill", 0)
+        assert rel(c, ref) < BAR, rel(c, ref)
+        from crane_amd.backend import GenerationConfig
+        want = g["greedy_tokens"].tolist()
+        assert m.generate(ids, GenerationConfig.greedy(len(want) - len(ids))) == want
     finally:
         m.close()

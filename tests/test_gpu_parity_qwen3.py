@@ -13,24 +13,28 @@ from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
 
 pytestmark = pytest.mark.gpu
 
-REL_SAME = 5e-4     # vs the oracle with the same KV rounding (bf16 cache = model dtype, kv_cache.rs:38-101):
-                    # two summation orders put a few K/V elements on opposite sides of a bf16 tie
-                    # (2^-9 on those elements; measured <= 2.6e-4 on logits).  The f32-KV tests below
-                    # have no such flips and hold 1e-4.
-REL_F32 = 4e-3      # bf16-KV path vs the pure-f32 CPU forward: one bf16 epsilon (2^-8).  A 1-token
-                    # context returns bf16(v) exactly, i.e. up to 2^-9 relative on every element;
-                    # the 1e-3 north-star bar is asserted on the f32-KV configuration below.
+REL_SAME = 5e-4     # vs the oracle with the same KV rounding: two summation orders put a few K/V elements on opposite
+                    # sides of a rounding tie (bf16 pages: 2^-9 on those elements, measured <= 2.6e-4 on logits; f16
+                    # pages: 2^-12).  The f32-KV tests below have no such flips and hold 1e-4.
+# vs the PURE-f32 CPU forward (the reference's CPU path; BASELINE.json north_star: 1e-3 relative):
+#   f16 pages (the default and the benchmarked mode) are held to the north-star bar itself;
+#   bf16 pages (opt-in: the model dtype of the reference's GPU path) carry one bf16 epsilon -- a 1-token context returns
+#   bf16(v) exactly, 2^-9 on every element -- and are NOT claimed to meet it.
+REL_F32 = {"f16": 1e-3, "bf16": 4e-3}
 
 
 def rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
-@pytest.fixture(scope="module", params=["tiny-qwen3", "tiny-qwen3-untied"])
+@pytest.fixture(scope="module", params=[("tiny-qwen3", "f16"), ("tiny-qwen3-untied", "f16"), ("tiny-qwen3", "bf16")],
+                ids=lambda p: f"{p[0]}-{p[1]}")
 def pair(request):
-    cfg = configs.get_config(request.param)
+    name, kv = request.param
+    cfg = configs.get_config(name)
     w = synth.synth_weights_f32(cfg, seed=0)
-    m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=4)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=4, kv_dtype=kv)
+    m.kv = kv                                   # the oracle of a test rounds K/V at the same point
     yield cfg, w, m
     m.close()
 
@@ -38,7 +42,7 @@ def pair(request):
 def test_decode_logits_match_oracle(pair):
     cfg, w, m = pair
     c = Qwen3Config.from_json(cfg)
-    o_same = Qwen3Oracle(c, w, kv_dtype="bf16")
+    o_same = Qwen3Oracle(c, w, kv_dtype=m.kv)
     o_f32 = Qwen3Oracle(c, w)
     ids = configs.synthetic_prompt(24, cfg["vocab_size"])
     m.clear_kv_cache()
@@ -48,7 +52,7 @@ def test_decode_logits_match_oracle(pair):
         a = o_same.forward([t], pos)
         b = o_f32.forward([t], pos)
         assert rel(got[0, 0], a) < REL_SAME, (pos, rel(got[0, 0], a))
-        assert rel(got[0, 0], b) < REL_F32, (pos, rel(got[0, 0], b))
+        assert rel(got[0, 0], b) < REL_F32[m.kv], (pos, rel(got[0, 0], b))
         assert int(got[0, 0].argmax()) == int(b.argmax())
 
 
@@ -70,7 +74,7 @@ def test_f32_kv_meets_north_star_bar():
 
 def test_prompt_forward_and_greedy(pair):
     cfg, w, m = pair
-    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=m.kv)
     ids = configs.synthetic_prompt(33, cfg["vocab_size"])
     m.clear_kv_cache()
     got = m.forward_step(ids, 0)[0, 0]
@@ -114,7 +118,7 @@ def test_generate_eos_and_repeat_penalty(pair):
 def test_from_pretrained_equals_synthetic(pair, tmp_path):
     cfg, w, m = pair
     d = synth.write_model_dir(str(tmp_path / "ckpt"), cfg, seed=0, shards=2)
-    m2 = Model.from_pretrained(d, max_seq_len=256, max_seqs=2)
+    m2 = Model.from_pretrained(d, max_seq_len=256, max_seqs=2, kv_dtype=m.kv)
     try:
         ids = configs.synthetic_prompt(7, cfg["vocab_size"])
         m.clear_kv_cache()
@@ -128,7 +132,7 @@ def test_from_pretrained_equals_synthetic(pair, tmp_path):
 
 def test_sequences_fork_truncate(pair):
     cfg, w, m = pair
-    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=m.kv)
     V = cfg["vocab_size"]
     a = configs.synthetic_prompt(70, V)                      # crosses a 64-token page
     s1 = m.seq_alloc()
@@ -155,7 +159,7 @@ def test_fork_truncate_append_does_not_touch_the_sibling(pair):
     private copy of that page before it appends: fork at 160 tokens (2.5 pages), truncate the child to 100 (inside the
     fully shared second page), re-feed other tokens -- the parent's positions 100..127 must be unchanged."""
     cfg, w, m = pair
-    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=m.kv)
     V = cfg["vocab_size"]
     a = configs.synthetic_prompt(160, V)
     parent = m.seq_alloc()
@@ -210,7 +214,7 @@ def _serial(m, ids, start):
 def test_prefill_matches_token_serial_and_oracle(pair, n):
     """MFMA prefill == token-by-token GEMV path == oracle (ragged / page-crossing lengths)."""
     cfg, w, m = pair
-    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
+    o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=m.kv)
     ids = configs.synthetic_prompt(n, cfg["vocab_size"])
     m.clear_kv_cache()
     a = m.forward_step(ids, 0)[0, 0]
@@ -236,7 +240,7 @@ def test_chunked_prefill_matches_single(pair):
     m.forward_step(ids[70:], 70)            # second chunk attends to the cached prefix (kv_offset > 0)
     chunked = m.forward_step([6], 150)[0, 0]
     assert rel(single, chunked) < 1e-4
-    m2 = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=2, prefill_chunk=48)   # internal chunk loop
+    m2 = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=2, prefill_chunk=48, kv_dtype=m.kv)   # internal chunk loop
     try:
         m2.forward_step(ids, 0)
         assert rel(m2.forward_step([6], 150)[0, 0], single) < 1e-4
@@ -309,7 +313,7 @@ def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
         for i in range(nseq):
             n = 3 + 5 * i + (60 if i == 1 else 0)              # ragged lengths, one crossing a page
             ids = [(11 * i + 7 * k + 3) % V for k in range(n)]
-            o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16" if nseq <= 3 else "f32")
+            o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=m.kv if nseq <= 3 else "f32")
             o.forward(ids, 0)
             s = m.seq_alloc()
             m.seq_forward(s, ids, 0, want_logits=False)
@@ -368,12 +372,10 @@ def test_batched_decode_gemm_path_against_gemv_path(nseq):
 
 @pytest.mark.parametrize("name", ["tiny-qwen3-untied", "tiny-qwen3.5"])
 @pytest.mark.parametrize("heads_max,ns", [(0, 2), (4096, 1), (4096, 2), (4096, 4), (150, 2)])
-def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
+def test_decode_attention_variants(name, heads_max, ns):
     """The two decode-attention formulations (split-KV + combine launch; per-head blocks with the merge fused into
     o_proj's prologue) and the switch between them at a context threshold must all reproduce the oracle -- single
     sequence (graph per variant) and batched, over a context that spans several pages."""
-    monkeypatch.setenv("CM_ATTN_HEADS_MAX", str(heads_max))
-    monkeypatch.setenv("CM_ATTN_NS", str(ns))
     cfg = configs.get_config(name)
     w = synth.synth_weights_f32(cfg, seed=0)
     if name == "tiny-qwen3.5":
@@ -385,6 +387,8 @@ def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
         o2 = Qwen3Oracle(Qwen3Config.from_json(cfg), w)
     m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype="f32")
     try:
+        m.debug_set("attn_heads_max", heads_max)
+        m.debug_set("attn_ns", ns)
         V = cfg["vocab_size"]
         ids = configs.synthetic_prompt(140, V)
         ref = o.forward(ids, 0)
@@ -410,20 +414,21 @@ def test_decode_attention_variants(monkeypatch, name, heads_max, ns):
         m.close()
 
 
+@pytest.mark.parametrize("kv", ["f16", "bf16"])
 @pytest.mark.parametrize("mfma_min,wide_min", [(1, 8192), (200, 206), (1, 1)])
-def test_decode_attention_mfma_variant(monkeypatch, mfma_min, wide_min):
-    """Long-context decode attention on the matrix cores (bf16 KV, head_dim 128): S^T = K.Q^T over the GQA group and
+def test_decode_attention_mfma_variant(mfma_min, wide_min, kv):
+    """Long-context decode attention on the matrix cores (f16 / bf16 KV, head_dim 128): S^T = K.Q^T over the GQA group and
     O^T += V^T.P^T through ds_read_tr, same partial format / combine kernel.  Forced on from the first token (1) and
     switched on mid-generation (200): must match the oracle with the same KV rounding, single sequence and batched."""
-    monkeypatch.setenv("CM_ATTN_MFMA_MIN", str(mfma_min))
-    monkeypatch.setenv("CM_ATTN_MFMA_WIDE_MIN", str(wide_min))      # 32 -> 64 token splits (a third captured graph)
     for name in ("tiny-qwen3-untied", "tiny-qwen3"):
         cfg = configs.get_config(name)
         w = synth.synth_weights_f32(cfg, seed=0)
-        o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
-        o2 = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype="bf16")
-        m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3)
+        o = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=kv)
+        o2 = Qwen3Oracle(Qwen3Config.from_json(cfg), w, kv_dtype=kv)
+        m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype=kv)
         try:
+            m.debug_set("attn_mfma_min", mfma_min)
+            m.debug_set("attn_mfma_wide_min", wide_min)          # 32 -> 64 token splits (a third captured graph)
             V = cfg["vocab_size"]
             ids = configs.synthetic_prompt(190, V)
             ref = o.forward(ids, 0)

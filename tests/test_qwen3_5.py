@@ -98,15 +98,20 @@ def test_oracle_matches_hf_golden_at_27b_geometry():
 
 
 # ---------------------------------------------------------------- GPU: HIP path ----------------
+# HIP path vs the HF f32 forward: f32 pages 1e-4; f16 pages (the default, the benchmarked mode) the north-star bar 1e-3;
+# bf16 pages (opt-in) one bf16 epsilon -- not claimed to meet the bar
+HF_TOL = {"f32": 1e-4, "f16": 1e-3, "bf16": 4e-3}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kv", ["f32", "bf16"])
+@pytest.mark.parametrize("kv", ["f32", "f16", "bf16"])
 def test_hip_qwen35_matches_hf_golden_and_oracle(kv):
     from crane_amd.backend import GenerationConfig, Model
     g, cfg, w = _load()
     m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=3, kv_dtype=kv)
     try:
         ids = g["prompt"].tolist()
-        tol = 1e-4 if kv == "f32" else 4e-3
+        tol = HF_TOL[kv]
         assert rel(m.forward_step(ids, 0)[0, 0], g["prefill_logits"]) < tol
         assert rel(m.forward_step(g["decode_token"].tolist(), len(ids))[0, 0], g["decode_logits"]) < tol
         n_new = len(g["greedy_tokens"]) - len(ids)
@@ -269,21 +274,79 @@ def test_hip_qwen38_27b_geometry():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kv", ["bf16", "int8"])
-def test_hybrid_decode_attention_on_the_mfma_kernel(monkeypatch, kv):
+def test_hip_qwen38_27b_geometry_against_the_hf_golden():
+    """The HIP path against HF Qwen3_5ForCausalLM (f32) at the REAL Qwen3.8-27B layer geometry -- H 5120, 24 q / 4 kv heads x 256
+    (n_rep 6), 16 key / 48 value GDN heads, I 17408; 4 layers, 4096-entry vocabulary -- on the committed fixture
+    tests/golden/qwen3_5_qwen3.8-27b-geom4.npz (make_golden_qwen3_5.py), in the benchmarked KV mode (f16 pages, the default):
+    prompt logits through the MFMA prefill, one decode step, and the greedy continuation.  Bar: north_star's 1e-3."""
+    from crane_amd.backend import GenerationConfig, Model
+    g = np.load(os.path.join(GOLD, "qwen3_5_qwen3.8-27b-geom4.npz"))
+    cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+    m = Model.synthetic(cfg, seed=int(g["seed"][0]), max_seq_len=256, max_seqs=2)
+    try:
+        ids = g["prompt"].tolist()
+        a = m.forward_step(ids, 0)[0, 0]
+        assert rel(a, g["prefill_logits"]) < 1e-3, rel(a, g["prefill_logits"])
+        b = m.forward_step(g["decode_token"].tolist(), len(ids))[0, 0]
+        assert rel(b, g["decode_logits"]) < 1e-3, rel(b, g["decode_logits"])
+        # token-serial prompt (every step a decode step: the GEMV / gdn_decode / split-KV kernels) on the same fixture
+        m.debug_set("no_prefill", 1)
+        try:
+            m.clear_kv_cache()
+            c = m.forward_step(ids, 0)[0, 0]
+        finally:
+            m.debug_set("no_prefill", 0)
+        assert rel(c, g["prefill_logits"]) < 1e-3, rel(c, g["prefill_logits"])
+        want = g["greedy_tokens"].tolist()
+        assert m.generate(ids, GenerationConfig.greedy(len(want) - len(ids))) == want
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nseq", [9, 17, 64])
+def test_batched_decode_at_hidden_5120(nseq):
+    """K = H = 5120 > 4096: the SiLU*mul and arg-max projections have no matrix-core GEMV form (gemvm_ok), so groups of more than
+    8 sequences reach the VALU batched GEMV, which keeps 8 rows in LDS -- it must run in passes of 8 (9 sequences: gate||up
+    and lm_head; 17 / 64: lm_head behind the GEMM projections).  Every row of the batched step against the same sequence
+    stepped alone (a fork taken before the step), Qwen3.8-27B layer geometry."""
+    from crane_amd.backend import Model
+    cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+    V = cfg["vocab_size"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2 * nseq + 2, kv_dtype="f32")
+    try:
+        seqs, twins, lens = [], [], []
+        for i in range(nseq):
+            n = 2 + (5 * i) % 23
+            s_ = m.seq_alloc()
+            m.seq_forward(s_, [(13 * i + 7 * k + 3) % V for k in range(n)], 0, want_logits=False)
+            seqs.append(s_); twins.append(m.seq_fork(s_)); lens.append(n)
+        toks = [(5 + 3 * i) % V for i in range(nseq)]
+        lg, greedy = m.step_batch_decode(seqs, toks)
+        for i in range(nseq):
+            ref, gr = m.seq_forward(twins[i], [toks[i]], lens[i])
+            assert rel(lg[i, 0], ref.reshape(-1)) < 1e-4, (i, rel(lg[i, 0], ref.reshape(-1)))
+            assert int(greedy[i]) == int(lg[i, 0].argmax())
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv", ["f16", "bf16", "int8"])
+def test_hybrid_decode_attention_on_the_mfma_kernel(kv):
     """head_dim 256 gated attention of the hybrid family through the matrix-core flash-decode kernel (single register
     set; the sigmoid gate stays in the combine kernel), forced from the first token and with the 32 -> 64 split switch."""
     from crane_amd import configs, synth
     from crane_amd.backend import Model
     from oracle import qwen3_5_oracle as O5
-    monkeypatch.setenv("CM_ATTN_MFMA_MIN", "1")
-    monkeypatch.setenv("CM_ATTN_MFMA_WIDE_MIN", "150")
     cfg = configs.get_config("tiny-qwen3.5")
     w = synth.synth_weights_f32(cfg, seed=0)
     o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), w, kv_dtype=kv)
     m = Model.synthetic(cfg, seed=0, max_seq_len=512, max_seqs=3, kv_dtype=kv)
-    tol = 5e-4 if kv == "bf16" else 2e-3
+    tol = 2e-3 if kv == "int8" else 5e-4
     try:
+        m.debug_set("attn_mfma_min", 1)
+        m.debug_set("attn_mfma_wide_min", 150)
         ids = configs.synthetic_prompt(140, cfg["vocab_size"])
         ref = o.forward(ids, 0)
         assert np.abs(m.forward_step(ids, 0).reshape(-1) - ref).max() / np.abs(ref).max() < tol

@@ -104,13 +104,9 @@ def test_hip_vision_and_vlm(gelu):
     from crane_amd.backend import Model
     g, cfg, w, text_w = _setup()
     ids, pix, grid = g["input_ids"].tolist(), g["pixel_values"], g["grid_thw"].tolist()
-    if gelu == "erf":
-        os.environ["CM_VISION_MERGER_GELU"] = "erf"
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
     try:
-        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
-    finally:
-        os.environ.pop("CM_VISION_MERGER_GELU", None)
-    try:
+        m.debug_set("vision_merger_gelu", 2 if gelu == "erf" else 1)      # PatchMerger GELU: tanh form (reference) / erf (HF)
         assert m.image_token_id() == cfg["image_token_id"]
         feat_ref, logits_ref, toks_ref = _oracle_vlm(cfg, w, text_w, ids, pix, grid, gelu, 6)
         feat = m.encode_images(pix, grid)
@@ -129,5 +125,80 @@ def test_hip_vision_and_vlm(gelu):
         o = Qwen35Oracle(Qwen35Config.from_json(cfg), text_w)
         t_ids = configs.synthetic_prompt(11, 400)
         assert rel(m.forward_step(t_ids, 0)[0, 0], o.forward(t_ids, 0)) < 1e-4
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_forward_embeds_equals_seq_forward_and_vlm_forward():
+    """cm_embed_tokens / cm_forward_embeds = Qwen3_5TextModel::embed_only / forward_embeds (qwen3_5/model.rs:368,430): text-only
+    rows at 1-D positions must reproduce cm_seq_forward bit for bit (same kernels, the rows are exactly the table's), and the
+    image prompt assembled BY THE CALLER -- text embeddings, image features from cm_vision_encode spliced over the placeholder
+    rows (vlm.rs:433-468), 3-axis positions (vlm.rs:190-241) -- must reproduce cm_vlm_forward, decode steps included."""
+    from crane_amd.backend import Model
+    g, cfg, w, text_w = _setup()
+    ids, pix, grid = g["input_ids"].tolist(), g["pixel_values"], g["grid_thw"].tolist()
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4, kv_dtype="f32")
+    try:
+        t_ids = configs.synthetic_prompt(23, 400)
+        emb = m.embed_tokens(t_ids)
+        assert np.array_equal(emb, text_w["model.embed_tokens.weight"][np.asarray(t_ids)])
+        a, ga = m.seq_forward(0, t_ids, 0)
+        s1 = m.seq_alloc()
+        pos = np.tile(np.arange(len(t_ids), dtype=np.int32), (3, 1))
+        b, gb = m.forward_embeds(emb, pos, 0, seq=s1)
+        assert np.array_equal(a, b) and ga == gb
+        s2 = m.seq_alloc()
+        c, gc = m.forward_embeds(emb, None, 0, seq=s2)               # no positions: the sequence's own counter
+        assert np.array_equal(a, c) and ga == gc
+        a2, _ = m.seq_forward(0, [7], len(t_ids)); b2, _ = m.seq_forward(s1, [7], len(t_ids))
+        assert np.array_equal(a2, b2)                                # decode continues identically
+        # image prompt
+        m.clear_kv_cache(); m.seq_free(s1); m.seq_free(s2)
+        ref, nxt = m.vlm_forward(ids, pix, grid)
+        ref2 = m.forward_step([nxt], len(ids))[0, 0]
+        feat = m.encode_images(pix, grid)
+        e = m.embed_tokens(ids)
+        img_tok = cfg["image_token_id"]
+        rows = [i for i, t in enumerate(ids) if t == img_tok]
+        assert len(rows) == feat.shape[0]
+        e[rows] = feat
+        merge = cfg["vision_config"]["spatial_merge_size"]
+        s3 = m.seq_alloc()
+        pos3, _ = VO.build_position_ids(ids, grid, img_tok, merge)   # build_position_ids (qwen3_5/vlm.rs:190-241) as the oracle restates it
+        got, g3 = m.forward_embeds(e, np.asarray(pos3, dtype=np.int32).reshape(3, len(ids)), 0, seq=s3)
+        assert rel(got, ref) < 1e-6 and g3 == nxt, rel(got, ref)
+        got2, _ = m.seq_forward(s3, [nxt], len(ids))                 # rotary position = cache position + MRoPE delta
+        assert rel(got2, ref2) < 1e-6, rel(got2, ref2)
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_hip_live_image_path_at_the_real_size_against_the_hf_golden():
+    """The reference's LIVE image path at real size on the GPU: the 24 x 1024 tower (16 heads of 64, 2304 interpolated position
+    embeddings, merger to 1024) in front of the Qwen3.5-0.8B text geometry (3 GDN + 1 gated-attention layer, 248 320-entry tied
+    table, 3-axis MRoPE) against HF Qwen3_5ForConditionalGeneration on the committed fixture
+    tests/golden/qwen3_5_vl_tower24.npz (make_golden_qwen3_5_vl.py tower24): tower features, image+text prompt logits, the
+    greedy continuation -- default KV pages (f16), bar 1e-3 (features: 1e-4, no cache involved)."""
+    from crane_amd.backend import Model
+    g = np.load(os.path.join(os.path.dirname(GOLD), "qwen3_5_vl_tower24.npz"))
+    cfg = configs.get_config("qwen3.5-vl-0.8b")
+    cfg = dict(cfg, text_config=dict(cfg["text_config"], num_hidden_layers=4, max_position_embeddings=4096))
+    grid = g["grid_thw"].tolist()
+    pix = np.random.default_rng(0).standard_normal((grid[0][1] * grid[0][2], 3 * 2 * 16 * 16)).astype(np.float32)
+    ids = g["input_ids"].tolist()
+    m = Model.synthetic(cfg, seed=int(g["seed"][0]), max_seq_len=256, max_seqs=2)
+    try:
+        m.debug_set("vision_merger_gelu", 2)                         # HF's erf form
+        feat = m.encode_images(pix, grid)
+        assert feat.shape == (24, 1024) and rel(feat, g["features"]) < 1e-4, rel(feat, g["features"])
+        logits, nxt = m.vlm_forward(ids, pix, grid)
+        assert rel(logits, g["prefill_logits"]) < 1e-3, rel(logits, g["prefill_logits"])
+        toks, pos = [nxt], len(ids)
+        want = g["greedy_tokens"].tolist()[len(ids):]
+        for _ in range(len(want) - 1):
+            toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+        assert toks == want
     finally:
         m.close()

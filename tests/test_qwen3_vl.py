@@ -84,13 +84,9 @@ def test_hip_qwen3_vl(gelu):
     from crane_amd.backend import Model
     g, cfg, w = _setup()
     ids, pix, grid = g["input_ids"].tolist(), g["pixel_values"], g["grid_thw"].tolist()
-    if gelu == "erf":
-        os.environ["CM_VISION_MERGER_GELU"] = "erf"
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
     try:
-        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
-    finally:
-        os.environ.pop("CM_VISION_MERGER_GELU", None)
-    try:
+        m.debug_set("vision_merger_gelu", 2 if gelu == "erf" else 1)      # PatchMerger GELU: tanh form (reference) / erf (HF)
         assert m.image_token_id() == cfg["image_token_id"]
         feat_ref, deep_ref, logits_ref, toks_ref = _oracle_run(cfg, w, ids, pix, grid, gelu, 6)
         feat = m.encode_images(pix, grid)
@@ -104,5 +100,39 @@ def test_hip_qwen3_vl(gelu):
         if gelu == "erf":                                   # independent implementation (HF)
             assert rel(feat, g["features"]) < 1e-4 and rel(logits, g["prefill_logits"]) < 1e-4
             assert toks == g["greedy_tokens"].tolist()[len(ids):]
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_hip_qwen3_vl_at_the_real_tower_size_against_the_hf_golden():
+    """BASELINE configs[3] on the GPU at the REAL Qwen3-VL-2B vision tower (depth 24, hidden 1024, 16 heads of 64, DeepStack taps
+    after blocks 5 / 11 / 17, merger to 2048) and text widths (2048 / 16 q / 8 kv heads -- GQA group 2 -- 4 of the 28 layers, the
+    151 936-entry tied table) against HF Qwen3VLForConditionalGeneration on the committed fixture
+    tests/golden/qwen3_vl_tower24.npz (make_golden_qwen3_vl.py tower24): tower features, the three DeepStack feature maps,
+    image+text prompt logits with the DeepStack injection after decoder layers 0-2 (qwen3_vl/text.rs:280-333), and the greedy
+    continuation -- default KV pages (f16), bar 1e-3 on logits, 1e-4 on the tower outputs."""
+    from crane_amd.backend import Model
+    g = np.load(os.path.join(os.path.dirname(GOLD), "qwen3_vl_tower24.npz"))
+    cfg = configs.get_config("qwen3-vl-2b")
+    cfg = dict(cfg, text_config=dict(cfg["text_config"], num_hidden_layers=4, max_position_embeddings=4096))
+    grid = g["grid_thw"].tolist()
+    pix = np.random.default_rng(0).standard_normal((grid[0][1] * grid[0][2], 3 * 2 * 16 * 16)).astype(np.float32)
+    ids = g["input_ids"].tolist()
+    m = Model.synthetic(cfg, seed=int(g["seed"][0]), max_seq_len=256, max_seqs=2)
+    try:
+        m.debug_set("vision_merger_gelu", 2)                         # HF's erf form
+        feat = m.encode_images(pix, grid)
+        assert feat.shape == (24, 2048) and rel(feat, g["features"]) < 1e-4, rel(feat, g["features"])
+        deep = m.debug_read("deepstack", 3 * 24 * 2048).reshape(3, 24, 2048)
+        for k in range(3):
+            assert rel(deep[k], g["deepstack"][k]) < 1e-4, (k, rel(deep[k], g["deepstack"][k]))
+        logits, nxt = m.vlm_forward(ids, pix, grid)
+        assert rel(logits, g["prefill_logits"]) < 1e-3, rel(logits, g["prefill_logits"])
+        toks, pos = [nxt], len(ids)
+        want = g["greedy_tokens"].tolist()[len(ids):]
+        for _ in range(len(want) - 1):
+            toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+        assert toks == want
     finally:
         m.close()
