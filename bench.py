@@ -219,10 +219,12 @@ def main():
     # CPU leg (rank 0, one GPU): baseline + parity of THIS configuration (same synthetic weights, same synthetic KV)
     cpu, parity = None, None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
-        dense = cfg.get("model_type", "qwen3") == "qwen3"
-        if not dense:
-            cpu = {"skipped": "oracle/c restates the dense Qwen3 CPU path only; the hybrid family's checker is the numpy "
-                              "oracle (tests/), too slow to time at this size"}
+        # oracle/c holds the model as bf16 on the host: a model that would not leave half of the host's RAM free is not timed
+        import psutil
+        need = m.weight_bytes() * 1.05
+        if need > 0.5 * psutil.virtual_memory().total:
+            cpu = {"skipped": f"the CPU port needs {need / 2**30:.0f} GiB of host memory for this model (host: "
+                              f"{psutil.virtual_memory().total / 2**30:.0f} GiB); BASELINE configs[0] / [2] are the CPU-sized cases"}
         else:
             try:
                 cpu, ref_toks, ref_logits, wr = cpu_leg(args.model, ctx, args.cpu_budget)

@@ -22,8 +22,20 @@ class QcCfg(C.Structure):
                 ("theta", C.c_double), ("tie", C.c_int), ("qk_norm", C.c_int), ("kv_bf16", C.c_int)]   # kv_bf16: 0 f32, 1 bf16, 2 f16 K/V rounding
 
 
+class Q5Cfg(C.Structure):
+    _fields_ = [("V", C.c_int), ("H", C.c_int), ("I", C.c_int), ("L", C.c_int), ("Hq", C.c_int),
+                ("Hkv", C.c_int), ("D", C.c_int), ("max_seq", C.c_int), ("eps", C.c_float),
+                ("theta", C.c_double), ("tie", C.c_int), ("rot_dim", C.c_int), ("interval", C.c_int), ("NK", C.c_int),
+                ("NV", C.c_int), ("Kd", C.c_int), ("Vd", C.c_int), ("conv_k", C.c_int), ("kv_round", C.c_int)]
+
+
 def _lib():
     lib = C.CDLL(SO)
+    lib.q5_create.argtypes = [C.POINTER(Q5Cfg), C.c_uint64]
+    lib.q5_create.restype = C.c_void_p
+    lib.q5_destroy.argtypes = [C.c_void_p]
+    lib.q5_forward.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.q5_fill_kv_paged.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     lib.qc_create.argtypes = [C.POINTER(QcCfg), C.c_uint64]
     lib.qc_create.restype = C.c_void_p
     lib.qc_destroy.argtypes = [C.c_void_p]
@@ -101,6 +113,45 @@ class CQwen3:
             pass
 
 
+class CQwen35(CQwen3):
+    """oracle/c/qwen35_cpu.c: the Qwen 3.5 / 3.6 / 3.8 hybrid decode path (Gated Delta Net + gated attention), token-serial."""
+
+    def __init__(self, cfg: dict, seed: int = 0, max_seq: int = 2048, kv_round: int = 0):
+        self.lib = _lib()
+        self.lib.qc_set_threads(host_threads())
+        t = cfg.get("text_config", cfg)
+        rp = t.get("rope_parameters") or {}
+        D = t["head_dim"]
+        tie = t.get("tie_word_embeddings", cfg.get("tie_word_embeddings", False))
+        c = Q5Cfg(t["vocab_size"], t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"], t["num_attention_heads"],
+                  t["num_key_value_heads"], D, max_seq, t.get("rms_norm_eps", 1e-6), rp.get("rope_theta", t.get("rope_theta", 1e7)),
+                  int(tie), int(D * rp.get("partial_rotary_factor", t.get("partial_rotary_factor", 0.25))),
+                  t.get("full_attention_interval", 4), t["linear_num_key_heads"], t["linear_num_value_heads"],
+                  t["linear_key_head_dim"], t["linear_value_head_dim"], t.get("linear_conv_kernel_dim", 4), int(kv_round))
+        self.V = t["vocab_size"]
+        self.h = self.lib.q5_create(C.byref(c), seed)
+
+    def forward(self, ids, start_pos: int) -> np.ndarray:
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32))
+        out = np.empty(self.V, dtype=np.float32)
+        rc = self.lib.q5_forward(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size, start_pos,
+                                 out.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != 0:
+            raise RuntimeError(f"q5_forward failed: {rc}")
+        return out
+
+    def fill_kv(self, ctx: int, seed: int = 1):
+        raise NotImplementedError
+
+    def fill_kv_paged(self, ctx: int, seed: int = 1, page: int = 64):
+        self.lib.q5_fill_kv_paged(self.h, ctx, seed, page)
+
+    def close(self):
+        if self.h:
+            self.lib.q5_destroy(self.h)
+            self.h = None
+
+
 def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: int = 48, n_new: int = 16):
     """bench.py's CPU leg: (cpu_baseline dict, greedy tokens, logits of the first step, model-written-cache reference).
 
@@ -114,9 +165,10 @@ def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: i
     from crane_amd import configs
     cfg = configs.get_config(model_name)
     t0 = time.perf_counter()
-    m = CQwen3(cfg, seed=0, max_seq=ctx + 64, kv_bf16=False)
+    hybrid = cfg.get("text_config", cfg).get("model_type", cfg.get("model_type", "qwen3")).startswith("qwen3_5")
+    m = CQwen35(cfg, seed=0, max_seq=ctx + 64) if hybrid else CQwen3(cfg, seed=0, max_seq=ctx + 64, kv_bf16=False)
     t_build = time.perf_counter() - t0
-    prompt = configs.synthetic_prompt(prompt_len, cfg["vocab_size"])
+    prompt = configs.synthetic_prompt(prompt_len, cfg.get("text_config", cfg)["vocab_size"])
     p_logits = m.forward(prompt, 0)
     gen = [int(p_logits.argmax())]
     d_logits = m.forward([gen[0]], prompt_len)                       # the decode step right after the prompt

@@ -81,6 +81,44 @@ def test_kv_page_precision_against_the_hf_golden(name, bar_f16, bf16_over):
         assert errs["bf16"] > 1e-3, errs
 
 
+@pytest.mark.parametrize("fixture", ["tiny-qwen3.5", "qwen3.8-27b-geom4"])
+def test_hybrid_c_port_matches_hf_golden(fixture):
+    """oracle/c/qwen35_cpu.c (Gated Delta Net + gated attention, token-serial) is bench.py's CPU baseline and in-run parity checker
+    for BASELINE configs[2].  Pinned here on HF Qwen3_5ForCausalLM (make_golden_qwen3_5.py): the tiny configuration and the REAL
+    Qwen3.8-27B layer geometry (H 5120, n_rep 6, 3 value heads per key head, head_dim 256 with 64 rotary dims; 4 layers) --
+    prompt logits, one decode step, the greedy continuation; and on the numpy oracle it is independent of."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"qwen3_5_{fixture}.npz"))
+    if fixture == "tiny-qwen3.5":
+        cfg = configs.get_config(fixture)
+    else:
+        cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+    c = c_oracle.CQwen35(cfg, seed=int(g["seed"][0]), max_seq=128)
+    try:
+        ids = g["prompt"].tolist()
+        a = c.forward(ids, 0)
+        assert np.abs(a - g["prefill_logits"]).max() / np.abs(g["prefill_logits"]).max() < 2e-5
+        b = c.forward(g["decode_token"].tolist(), len(ids))
+        assert np.abs(b - g["decode_logits"]).max() / np.abs(g["decode_logits"]).max() < 2e-5
+        want = g["greedy_tokens"].tolist()
+        lg, toks = c.forward(ids, 0), list(ids)
+        for _ in range(len(want) - len(ids)):
+            toks.append(int(lg.argmax()))
+            lg = c.forward([toks[-1]], len(toks) - 1)
+        assert toks == want
+        if fixture == "tiny-qwen3.5":
+            from oracle import qwen3_5_oracle as O5
+            w = synth.synth_weights_f32(cfg, int(g["seed"][0]))
+            for kv, mode in (("f32", 0), ("f16", 2)):
+                o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), w, kv_dtype=kv)
+                c2 = c_oracle.CQwen35(cfg, seed=int(g["seed"][0]), max_seq=128, kv_round=mode)
+                p = configs.synthetic_prompt(70, cfg["vocab_size"])
+                x, y = o.forward(p, 0), c2.forward(p, 0)
+                assert np.abs(x - y).max() / np.abs(x).max() < (2e-5 if mode == 0 else 1e-4)
+                c2.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("name", ["qwen3-8b-2l", "qwen3-0.6b-2l"])
 def test_c_port_matches_hf_golden_at_the_headline_geometry(name):
     """oracle/c is the checker of the headline parity tests (tests/test_gpu_parity_headline.py) and of bench.py's parity leg.
