@@ -431,8 +431,9 @@ class Model:
         """ranks of the RCCL communicator (1: no tensor parallelism, 0: collectives are debug no-ops)"""
         return int(self._lib.cm_tp_ranks(self._h))
 
-    def engine_active(self) -> bool:
-        return bool(self._lib.cm_engine_active(self._h))
+    def engine_active(self) -> int:
+        """0: per-projection launches; 1: persistent kernel per layer; 2: the whole token in one persistent launch"""
+        return int(self._lib.cm_engine_active(self._h))
 
 
 # the reference's adapter name for this family (backend.rs:609-748)

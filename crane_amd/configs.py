@@ -34,6 +34,10 @@ CONFIGS = {
     "eng-qwen3": dict(_QWEN3_COMMON, vocab_size=2048, hidden_size=2048, intermediate_size=4096,
                       num_hidden_layers=3, num_attention_heads=32, num_key_value_heads=8,
                       head_dim=128, tie_word_embeddings=False, max_position_embeddings=8192),
+    # the same with a GQA group of 2 (16 q / 8 kv heads: the text decoder of Qwen3-VL-2B, Qwen3-1.7B)
+    "eng-qwen3-gqa2": dict(_QWEN3_COMMON, vocab_size=2048, hidden_size=2048, intermediate_size=6144,
+                           num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=8,
+                           head_dim=128, tie_word_embeddings=True, max_position_embeddings=8192),
     # small shapes for CPU-oracle parity
     "tiny-qwen3": dict(_QWEN3_COMMON, vocab_size=512, hidden_size=256, intermediate_size=512,
                        num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,

@@ -155,7 +155,7 @@ int cm_tp_ranks(const cm_model* h) {
     if (!h->m.rccl) return 1;
     return h->m.rccl->fake ? 0 : h->m.rccl->nranks;
 }
-int cm_engine_active(const cm_model* h) { return h && h->m.engine_on ? 1 : 0; }
+int cm_engine_active(const cm_model* h) { return h && h->m.engine_on ? (h->m.engine_full ? 2 : 1) : 0; }
 
 int cm_forward_step(cm_model* h, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out) {
     if (!h) return CM_ERR_INVALID;
@@ -371,6 +371,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         else if (k == "attn_mfma_wide_min") h->m.attn_mfma_wide_min = value;
         else if (k == "attn_heads_max") h->m.attn_heads_max = value;
         else if (k == "attn_ns") { h->m.attn_ns = (int)std::max<long long>(1, std::min<long long>(value, h->m.nsplit)); h->m.drop_graphs(); }
+        else if (k == "gemm256") h->m.gemm256 = value != 0;
         else if (k == "quant_act_int") h->m.quant_act_int = value != 0;          // CM_QUANT_ACT: 1 = ggml vec_dot (integer) semantics, 0 = f32 activations
         else if (k == "vision_merger_gelu") h->m.vcfg.merger_act = value == 2 ? 2 : 1;   // CM_VISION_MERGER_GELU: 1 tanh form (reference), 2 erf (HF)
         else if (k == "engine") { h->m.drop_graphs(); h->m.engine_on = value > 0 && h->m.engine_capable; }

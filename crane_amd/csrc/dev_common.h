@@ -43,7 +43,8 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {
     return __builtin_bit_cast(uint16_t, h);
 }
 // internal KV-page element types (template parameter KVT of the attention kernels, Model::kv_mode)
-enum { KV_BF16 = 0, KV_F32 = 1, KV_INT8 = 2, KV_INT4 = 3, KV_F16 = 4 };
+// (KV_BF16X2: not a cache mode -- the vision tower's per-call K/V scratch, every f32 value pre-split into bf16 hi + lo)
+enum { KV_BF16 = 0, KV_F32 = 1, KV_INT8 = 2, KV_INT4 = 3, KV_F16 = 4, KV_BF16X2 = 5 };
 // one cached 16-bit element pair -> f32 (bf16: bit shifts; f16: v_cvt_f32_f16)
 template <int KVT> __device__ __forceinline__ float kv16_lo(uint32_t p) { return KVT == KV_F16 ? f16_lo(p) : bf16_lo(p); }
 template <int KVT> __device__ __forceinline__ float kv16_hi(uint32_t p) { return KVT == KV_F16 ? f16_hi(p) : bf16_hi(p); }

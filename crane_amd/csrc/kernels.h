@@ -88,6 +88,7 @@ struct GemmArgs {
     float* ws;              // split-K workspace (or null: never split) of ws_floats f32; launch_gemm decides the split
     size_t ws_floats;
     int ksplit;             // set by launch_gemm
+    int wide256 = 1;        // 0: never the 256-row LDS-DMA kernel (kernels_gemm256.hip) -- A/B switch, cm_debug_set("gemm256")
 };
 
 struct QkRopeArgs {
@@ -120,6 +121,7 @@ struct AttnPreArgs {
     const int32_t* block_table;
     const void* kpool;
     const void* vpool;
+    size_t kv_lo_off = 0;        // KV_BF16X2: element offset of the lo halves behind the hi halves in kpool / vpool
     uint16_t* out_hi;            // [Spad, Hq * D] bf16 hi (+lo) -> A operand of the o_proj GEMM
     uint16_t* out_lo;
     const float* gate;           // [S, gate_stride] f32 (Qwen3.5 output gate) or null
@@ -138,14 +140,15 @@ void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hip
 void launch_split_rows2d(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int rows, int cols, hipStream_t s);   // cols % 4 == 0, ldx % 4 == 0
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s);   // kernels_gemm256.hip; a.ksplit set by the caller (launch_gemm)
 void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s);   // kvt: KV_BF16 | KV_F16 | KV_F32 (what the kernel reads)
 
 // ---- vision tower (kernels_vision.hip) ----
 void launch_layernorm_rows(const float* x, const float* w, const float* b, uint16_t* hi, uint16_t* lo, int N, int H, float eps,
                            hipStream_t s);
 void launch_pos_embed_add(float* x, const uint16_t* table, const int32_t* idx, const float* wts, int N, int H, hipStream_t s);
-void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, float* kpool,
-                        float* vpool, int N, int heads, float scale, hipStream_t s);
+void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, uint16_t* kpool,
+                        uint16_t* vpool, size_t lo_off, int N, int heads, float scale, hipStream_t s);
 void launch_splice_rows(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s);
 void launch_add_rows_map(float* dst, const float* src, const int32_t* map, int S, int H, hipStream_t s);
 
@@ -240,6 +243,7 @@ struct EngArgs {
     int H, gpw_res, xf_total;     // hidden size; row groups per wave of the residual phases; LDS floats of the input buffers
     int Hkv, page, max_pages, q_off, k_off, v_off;
     int kv_f16;                   // K/V pages hold IEEE binary16 (CM_KV_F16) instead of bf16
+    int nrep;                     // GQA group size of the in-kernel attention: 4 (Qwen3-8B) or 2 (Qwen3-VL-2B text, Qwen3-1.7B)
     float eps, scale;
     int tune;                     // polling parameters (CM_ENG_TUNE while tuning), see kernels_engine.hip
     int dbg;                      // timing experiments (CM_ENG_DBG), see kernels_engine.hip; 0 in production
@@ -247,7 +251,8 @@ struct EngArgs {
 struct EngCfg { int nsw, ncw, pf; };
 EngCfg engine_config();           // the instantiation the launcher uses (default, or CM_ENG_CFG while tuning)
 size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw);
-bool engine_prepare(size_t lds_bytes);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
+bool engine_prepare(size_t lds_bytes, int nrep);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
+bool engine_has_nrep(int nrep);          // the in-kernel attention is instantiated for this GQA group size
 bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace = false);
 
 // ---- synthetic weights / utility ----

@@ -791,10 +791,10 @@ EngCfg engine_config() {
     return c;
 }
 
-template <int NSW, int PF>
+template <int NSW, int PF, int NREP = 4>
 static bool prepare_v(size_t lds_bytes) {
-    auto k = engine_kernel<NSW, ENG_NCW, PF, 4, false>;
-    auto kt = engine_kernel<NSW, ENG_NCW, PF, 4, true>;
+    auto k = engine_kernel<NSW, ENG_NCW, PF, NREP, false>;
+    auto kt = engine_kernel<NSW, ENG_NCW, PF, NREP, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -810,10 +810,16 @@ static bool prepare_v(size_t lds_bytes) {
     return true;
 }
 
-template <int NSW, int PF>
+template <int NSW, int PF, int NREP = 4>
 static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
-    if (trace) hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, 4, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
-    else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, 4, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    if (trace) hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+}
+
+// GQA group sizes of the in-kernel attention: 4 in every tuning configuration, 2 in the default one
+bool engine_has_nrep(int nrep) {
+    const EngCfg c = engine_config();
+    return nrep == 4 || (nrep == 2 && c.nsw == 4 && c.pf == 4);
 }
 
 #define CM_ENG_DISPATCH(CALL)                                            \
@@ -823,8 +829,9 @@ static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool
     else if (c.pf == 6) { CALL(4, 6) }                                     \
     else { CALL(4, 4) }
 
-bool engine_prepare(size_t lds_bytes) {
+bool engine_prepare(size_t lds_bytes, int nrep) {
     const EngCfg c = engine_config();
+    if (nrep == 2 && engine_has_nrep(2)) return prepare_v<4, 4, 2>(lds_bytes) && prepare_v<4, 4, 4>(lds_bytes);
 #define CM_ENG_PREP(N, P) return prepare_v<N, P>(lds_bytes);
     CM_ENG_DISPATCH(CM_ENG_PREP)
 #undef CM_ENG_PREP
@@ -835,6 +842,11 @@ bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const size_t lds = engine_lds_bytes(a, c.nsw, c.ncw);
     if (lds > 160 * 1024 - 256 || a.gpw_res > MAXRES || a.p1 <= a.p0) return false;
     const bool tr = trace && a.trace != nullptr;
+    if (a.attn != nullptr && a.nrep == 2) {
+        if (!engine_has_nrep(2)) return false;
+        launch_v<4, 4, 2>(a, grid, lds, s, tr);
+        return true;
+    }
 #define CM_ENG_LAUNCH(N, P) launch_v<N, P>(a, grid, lds, s, tr);
     CM_ENG_DISPATCH(CM_ENG_LAUNCH)
 #undef CM_ENG_LAUNCH

@@ -418,11 +418,13 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
 // V tile row stride in LDS = D + 16 elements: the 4 key rows of a tr-read group land on disjoint banks
 // KVT: KV_BF16 pages (K rows / V^T fragments feed the bf16 MFMAs as cached), KV_F16 pages (the same on the f16 MFMAs; q_hi / q_lo
 // and P are then f16 hi + lo), KV_F32 (f32 rows split into bf16 hi + lo on load: the ViT scratch, f32 pages, the int8 / int4 shadow)
+// KV_BF16X2 (the ViT scratch): K/V rows arrive pre-split into bf16 hi + lo arrays -- the three-product arithmetic of KV_F32
+// without a conversion in the loop.
 template <int D, int KVT>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
-    constexpr bool KVF32 = KVT == KV_F32;
+    constexpr bool KVF32 = KVT == KV_F32, X2 = KVT == KV_BF16X2, THREE = KVF32 || X2;
     constexpr int KT = 64, VLD = D + 16, NKS = D / 32, NNT = D / 16;
-    __shared__ __attribute__((aligned(16))) uint16_t Vs[KVF32 ? 2 : 1][KT * VLD];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[THREE ? 2 : 1][KT * VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, g = lane >> 4;
     const int h = blockIdx.y, kvh = h / a.nrep;
@@ -468,7 +470,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
                     lo[e] = pack_bf16x2(vv[2 * e] - bf16_to_f32(h0), vv[2 * e + 1] - bf16_to_f32(h1));
                 }
                 *(u32x4*)&Vs[0][tok * VLD + d8] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-                *(u32x4*)&Vs[KVF32 ? 1 : 0][tok * VLD + d8] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+                *(u32x4*)&Vs[THREE ? 1 : 0][tok * VLD + d8] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+            } else if (X2) {
+                *(u32x4*)&Vs[0][tok * VLD + d8] = ld16((const uint16_t*)a.vpool + off);
+                *(u32x4*)&Vs[THREE ? 1 : 0][tok * VLD + d8] = ld16((const uint16_t*)a.vpool + a.kv_lo_off + off);
             } else {
                 *(u32x4*)&Vs[0][tok * VLD + d8] = ld16((const uint16_t*)a.vpool + off);
             }
@@ -496,10 +501,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
                     }
                 } else {
                     kh = *(const bf16x8*)((const uint16_t*)a.kpool + kb + ks * 32);
+                    if (X2) kl = *(const bf16x8*)((const uint16_t*)a.kpool + a.kv_lo_off + kb + ks * 32);
                 }
                 s[tt] = mma_k32<KVT>(kh, qh[ks], s[tt]);
                 s[tt] = mma_k32<KVT>(kh, ql[ks], s[tt]);
-                if (KVF32) s[tt] = mma_k32<KVT>(kl, qh[ks], s[tt]);
+                if (THREE) s[tt] = mma_k32<KVT>(kl, qh[ks], s[tt]);
             }
         }
         // ---- causal mask + online softmax (row statistics live in the lanes with the same `sub`) ----
@@ -542,8 +548,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
                 const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
                 o[nt] = mma_k16<KVT>(vh, ph[tt], o[nt]);
                 o[nt] = mma_k16<KVT>(vh, pl[tt], o[nt]);
-                if (KVF32) {
-                    const uint16_t* vq = &Vs[KVF32 ? 1 : 0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
+                if (THREE) {
+                    const uint16_t* vq = &Vs[THREE ? 1 : 0][(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
                     const bf16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vq);
                     o[nt] = mma_k16<KVT>(vl, ph[tt], o[nt]);
                 }
@@ -664,9 +670,52 @@ static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
     return S;
 }
 
+// Large M (>= 512 rows): the 256-row LDS-DMA kernel (kernels_gemm256.hip) where one of its tile shapes fills the chip in whole
+// rounds -- (tile width, k-slices) by a small cost model: rounds of 256 CUs x one block's MFMA time + the f32 partial-tile
+// traffic of a split.  Returns false when the 128-row kernel should run.
+static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
+    static const int env = getenv("CM_GEMM256") ? atoi(getenv("CM_GEMM256")) : 1;
+    static const int force_bn = getenv("CM_GEMM256_BN") ? atoi(getenv("CM_GEMM256_BN")) : 0;     // tuning
+    static const int force_ks = getenv("CM_GEMM256_KS") ? atoi(getenv("CM_GEMM256_KS")) : 0;
+    if (!env || !a.wide256 || a.M < 512 || a.K % 32 != 0) return false;
+    const int tiles_m = (a.M + 255) / 256, nk = a.K / 32;
+    const double terms = a.A_lo ? 2.0 : 1.0;
+    double best = 1e30;
+    int best_bn = 0, best_ks = 1;
+    for (int bn : {256, 192}) {
+        if (a.N % bn != 0 || (force_bn && bn != force_bn)) continue;
+        const int tiles = tiles_m * (a.N / bn);
+        for (int ks = 1; ks <= 8; ks *= 2) {
+            if (force_ks && ks != force_ks) continue;
+            if (nk % ks != 0 || nk / ks < 16) break;
+            if (ks > 1 && (a.ws == nullptr || (size_t)ks * a.M * a.N > a.ws_floats)) break;
+            const int blocks = tiles * ks, rounds = (blocks + 255) / 256;
+            const double t_blk = 256.0 * bn * (double)(a.K / ks) * 2.0 * terms / 6.0e12;                  // ~60 % of a CU's MFMA peak
+            const double t_split = ks > 1 ? ((double)(2 * ks + 1) * a.M * a.N * 4.0) / 3.0e12 + 6e-6 : 0.0;   // partial tiles out and back + a launch
+            const double t = rounds * t_blk + t_split;
+            if (t < best) { best = t; best_bn = bn; best_ks = ks; }
+        }
+    }
+    if (best_bn == 0) return false;
+    // the chip must be reasonably full: otherwise the 128-row kernel's own split-K heuristics do better
+    const int blocks = tiles_m * (a.N / best_bn) * best_ks;
+    if (blocks < 192 && !force_bn) return false;
+    a.ksplit = best_ks;
+    if (!launch_gemm256(a, epi, best_bn, s)) return false;
+    if (best_ks > 1) {
+        const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
+        if (epi == GEPI_STORE) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_STORE>), dim3(eb), dim3(256), 0, s, a);
+        else if (epi == GEPI_RESADD) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_RESADD>), dim3(eb), dim3(256), 0, s, a);
+        else if (epi == GEPI_ACT_SPLIT) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_ACT_SPLIT>), dim3(eb), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_SILUMUL>), dim3(eb), dim3(256), 0, s, a);
+    }
+    return true;
+}
+
 bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     if (a0.N % 128 != 0 || a0.K % GBK != 0) return false;
     GemmArgs a = a0;
+    if (try_gemm256(a, epi, s)) return true;
     const int tiles_m = (a.M + GBM - 1) / GBM;
     const bool split = a.A_lo != nullptr;
     // 256-wide tiles (one 8-wave block per CU) when they give every CU at least two blocks (1024-token gate||up: 428 -> ~370 us;
@@ -721,7 +770,7 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
 void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s) {
     dim3 grid((a.S + 63) / 64, a.Hq);
     if (D == 64) {
-        hipLaunchKernelGGL((attn_prefill_kernel<64, KV_F32>), grid, dim3(256), 0, s, a);     // ViT: f32 K/V scratch
+        hipLaunchKernelGGL((attn_prefill_kernel<64, KV_BF16X2>), grid, dim3(256), 0, s, a);     // ViT: K/V scratch pre-split into bf16 hi + lo
     } else if (D == 128) {
         if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F32>), grid, dim3(256), 0, s, a);
         else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F16>), grid, dim3(256), 0, s, a);

@@ -59,12 +59,14 @@ __global__ void pos_embed_add_kernel(float* __restrict__ x, const uint16_t* __re
 }
 
 // grid (N, 3 * heads), block 64 (one lane per head dim, hd == 64): q/k get q*cos + rotate_half(q)*sin over the
-// whole head (vision.rs:86-106); q scaled by 1/sqrt(hd) -> bf16 hi/lo [N, heads, hd]; k, v -> f32 scratch in the
-// paged layout [page][heads][64 tokens][hd] with an identity block table.
+// whole head (vision.rs:86-106); q scaled by 1/sqrt(hd) -> bf16 hi/lo [N, heads, hd]; k, v -> scratch in the paged layout
+// [page][heads][64 tokens][hd] with an identity block table, every f32 value split ONCE here into bf16 hi + lo (two arrays
+// lo_off elements apart): the attention kernel reads each K/V row from ceil(N / 64) query blocks and used to redo the
+// split (3 conversions per element) in every one of them -- it was VALU-bound on that.
 __global__ __launch_bounds__(64) void vit_rope_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
                                                          const float* __restrict__ sn, uint16_t* __restrict__ q_hi,
-                                                         uint16_t* __restrict__ q_lo, float* __restrict__ kpool,
-                                                         float* __restrict__ vpool, int heads, float scale) {
+                                                         uint16_t* __restrict__ q_lo, uint16_t* __restrict__ kpool,
+                                                         uint16_t* __restrict__ vpool, size_t lo_off, int heads, float scale) {
     constexpr int HD = 64;
     const int n = blockIdx.x, item = blockIdx.y, d = threadIdx.x;
     const int which = item / heads, h = item % heads;            // 0 q, 1 k, 2 v  (reshape (N, 3, heads, hd))
@@ -81,8 +83,10 @@ __global__ __launch_bounds__(64) void vit_rope_kv_kernel(const float* __restrict
         const uint16_t hh = f32_to_bf16(o);
         q_hi[off] = hh; q_lo[off] = f32_to_bf16(o - bf16_to_f32(hh));
     } else {
-        float* pool = which == 1 ? kpool : vpool;
-        pool[((size_t)((n >> 6) * heads + h) * 64 + (n & 63)) * HD + d] = o;
+        uint16_t* pool = which == 1 ? kpool : vpool;
+        const size_t off = ((size_t)((n >> 6) * heads + h) * 64 + (n & 63)) * HD + d;
+        const uint16_t hh = f32_to_bf16(o);
+        pool[off] = hh; pool[lo_off + off] = f32_to_bf16(o - bf16_to_f32(hh));
     }
 }
 
@@ -101,9 +105,9 @@ void launch_layernorm_rows(const float* x, const float* w, const float* b, uint1
 void launch_pos_embed_add(float* x, const uint16_t* table, const int32_t* idx, const float* wts, int N, int H, hipStream_t s) {
     hipLaunchKernelGGL(pos_embed_add_kernel, dim3(N), dim3(256), 0, s, x, table, idx, wts, N, H);
 }
-void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, float* kpool,
-                        float* vpool, int N, int heads, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(vit_rope_kv_kernel, dim3(N, 3 * heads), dim3(64), 0, s, qkv, cs, sn, q_hi, q_lo, kpool, vpool, heads, scale);
+void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, uint16_t* kpool,
+                        uint16_t* vpool, size_t lo_off, int N, int heads, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(vit_rope_kv_kernel, dim3(N, 3 * heads), dim3(64), 0, s, qkv, cs, sn, q_hi, q_lo, kpool, vpool, lo_off, heads, scale);
 }
 // DeepStack injection (qwen3_vl/text.rs:280-333): dst[s, :] += src[map[s], :] for the visual positions (map[s] >= 0)
 __global__ __launch_bounds__(256) void add_rows_map_kernel(float* __restrict__ dst, const float* __restrict__ src,

@@ -369,7 +369,7 @@ bool Model::engine_eligible(std::string* why) const {
 // the whole token in one launch needs the attention inside the kernel: bf16 pages, head_dim 128, GQA group of 4, one
 // workgroup per (kv head, token split) with at most 32 splits
 bool Model::engine_full_eligible() const {
-    if (cfg.D != 128 || nrep != 4 || (kv_mode != KV_BF16 && kv_mode != KV_F16) || !cfg.qk_norm) return false;
+    if (cfg.D != 128 || !engine_has_nrep(nrep) || (kv_mode != KV_BF16 && kv_mode != KV_F16) || !cfg.qk_norm) return false;
     if (num_cu % Hkv_l) return false;
     const int ns = num_cu / Hkv_l, opb = ns > 0 ? nrep * cfg.D / ns : 0;
     return ns >= 1 && ns <= 32 && (nrep * cfg.D) % ns == 0 && opb >= 2 && opb <= 16 && opb % 2 == 0 && cfg.D % opb == 0;
@@ -454,7 +454,7 @@ void Model::build_engine() {
     // epoch base 1: every tag of the first launch is >= 2, the zero-filled granules never match
     const uint32_t one = 1;
     CM_HIP(hipMemcpy(&st->rsv[1], &one, 4, hipMemcpyHostToDevice));
-    if (!engine_prepare(engine_lds_bytes(probe, ec.nsw, ec.ncw))) {
+    if (!engine_prepare(engine_lds_bytes(probe, ec.nsw, ec.ncw), engine_full ? nrep : 4)) {
         if (opts.engine > 0) throw CmError(CM_ERR_DEVICE, "cm_opts.engine = 1: kernel attribute");
         return;
     }
@@ -484,6 +484,7 @@ EngArgs Model::engine_args_common() const {
     e.q_off = 0; e.k_off = Hq_l * cfg.D; e.v_off = e.k_off + Hkv_l * cfg.D;
     e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
     e.kv_f16 = kv_mode == KV_F16 ? 1 : 0;
+    e.nrep = nrep;
     e.dbg = eng_dbg; e.tune = eng_tune;
     return e;
 }
@@ -991,7 +992,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             const LayerW& w = layers[(size_t)li];
             launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
             GemmArgs g{};
-            g.ws = pWS; g.ws_floats = gemm_ws_floats;
+            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             if (!w.full) {
                 // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
                 g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
@@ -1023,7 +1024,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
                     done += part;
                 }
                 launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
-                g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
+                g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
                 g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
                 if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
                 if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
@@ -1065,7 +1066,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             at.page = page; at.start_pos = sp; at.causal = 1;
             at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
             launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
@@ -1076,7 +1077,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             }
             }   // full-attention layer
             launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
             if (quantized) {
                 if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
@@ -1085,7 +1086,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
             }
             g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
             launch_gemm(g, GEPI_SILUMUL, s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats;
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
             if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
@@ -1215,7 +1216,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         // y[nb, N] (+)= A[nb, K] . W^T through launch_gemm; A = the bf16 hi + lo rows produced by rows_in
         auto gm = [&](int epi, const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, float* C, int ldc, int N, int K) {
             GemmArgs g{};
-            g.ws = pWS; g.ws_floats = gemm_ws_floats;
+            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = A_hi; g.A_lo = A_lo; g.W = W; g.C = C; g.ldc = ldc; g.M = nb; g.N = N; g.K = K;
             g.H_hi = pHH_hi; g.H_lo = pHH_lo;
             if (!launch_gemm(g, epi, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
@@ -1603,8 +1604,43 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
     const int H = cfg.H, D = cfg.D;
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     uint64_t b = 0;
+    // "pgemm_<qkv|o|gate_up|down>@<M>": one prompt-pass GEMM of a layer over M rows of random activations, through launch_gemm
+    // exactly as prefill() calls it (cycling through the layers' weights); *bytes_out = useful flops 2 M N K of one launch
+    int pg_M = 0;
+    std::string pg;
+    if (which.rfind("pgemm_", 0) == 0) {
+        const size_t at = which.find('@');
+        if (at == std::string::npos) throw CmError(CM_ERR_INVALID, "pgemm_<proj>@<rows>");
+        pg = which.substr(6, at - 6);
+        pg_M = atoi(which.c_str() + at + 1);
+        ensure_prefill_buffers();
+        if (!prefill_ok || quantized || pg_M < 1 || pg_M > chunk) throw CmError(CM_ERR_INVALID, "pgemm: rows must be in 1..prefill_chunk (bf16 weights)");
+        const uint32_t ts = fmix32(0x1234567u);
+        launch_synth_fill(pXN_hi, (size_t)H, pg_M, H, 0, 0, H, ts, 0.01f, 0.f, stream);
+        launch_synth_fill(pXN_lo, (size_t)H, pg_M, H, 0, 0, H, ts + 1, 0.00004f, 0.f, stream);
+        launch_synth_fill(pAT_hi, (size_t)Hq_l * D, pg_M, Hq_l * D, 0, 0, Hq_l * D, ts + 2, 0.01f, 0.f, stream);
+        launch_synth_fill(pAT_lo, (size_t)Hq_l * D, pg_M, Hq_l * D, 0, 0, Hq_l * D, ts + 3, 0.00004f, 0.f, stream);
+        launch_synth_fill(pHH_hi, (size_t)I_l, pg_M, I_l, 0, 0, I_l, ts + 4, 0.01f, 0.f, stream);
+        launch_synth_fill(pHH_lo, (size_t)I_l, pg_M, I_l, 0, 0, I_l, ts + 5, 0.00004f, 0.f, stream);
+    }
     auto one = [&](size_t i) {
         size_t li = i % (size_t)cfg.L;
+        if (pg_M > 0) {
+            while (!layers[li].full) li = (li + 1) % (size_t)cfg.L;
+            const LayerW& w = layers[li];
+            const bool sp2 = prefill_split2;
+            GemmArgs g{};
+            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0; g.M = pg_M;
+            int epi = GEPI_STORE;
+            if (pg == "qkv") { g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.N = (Hq_l + 2 * Hkv_l) * D; g.K = H; g.ldc = g.N; }
+            else if (pg == "o") { g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.C = pX; g.N = H; g.K = Hq_l * D; g.ldc = H; epi = GEPI_RESADD; }
+            else if (pg == "gate_up") { g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.N = 2 * I_l; g.K = H; g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr; epi = GEPI_SILUMUL; }
+            else if (pg == "down") { g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.C = pX; g.N = H; g.K = I_l; g.ldc = H; epi = GEPI_RESADD; }
+            else throw CmError(CM_ERR_INVALID, "pgemm: qkv | o | gate_up | down");
+            if (!launch_gemm(g, epi, stream)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+            b = 2ull * (uint64_t)g.M * (uint64_t)g.N * (uint64_t)g.K;
+            return;
+        }
         if ((which == "qkv" || which == "o") && !layers[li].full) li = (size_t)(cfg.interval - 1);
         const LayerW& w = layers[li];
         if (quantized) {

@@ -161,7 +161,9 @@ struct Model {
     VisionCfg vcfg;
     VisionW vw;
     int v_cap = 0;                 // patches the vision scratch is sized for
-    float *vX = nullptr, *vQKV = nullptr, *vFeat = nullptr, *vCos = nullptr, *vSin = nullptr, *vK = nullptr, *vV = nullptr, *vPix = nullptr, *vW4 = nullptr;
+    float *vX = nullptr, *vQKV = nullptr, *vFeat = nullptr, *vCos = nullptr, *vSin = nullptr, *vPix = nullptr, *vW4 = nullptr;
+    uint16_t *vK = nullptr, *vV = nullptr;   // [2 (bf16 hi, lo)][pages][heads][64][64] K / V scratch of one block
+    size_t vkv_lo_off = 0;
     uint16_t *vA_hi = nullptr, *vA_lo = nullptr, *vB_hi = nullptr, *vB_lo = nullptr, *vQ_hi = nullptr, *vQ_lo = nullptr;
     int32_t *vIdx = nullptr, *vBt = nullptr, *dMap = nullptr, *dPos3 = nullptr;
     const int32_t* pos3_dev = nullptr;   // set only while a VLM prefill runs
@@ -212,6 +214,7 @@ struct Model {
     // prefill scratch (allocated on first use; sized for one chunk)
     int chunk = 2048, chunk_pad = 2048;
     bool prefill_ok = false, prefill_split2 = true;
+    bool gemm256 = true;       // prompt-pass GEMMs of >= 512 rows may use the 256-row LDS-DMA kernel (cm_debug_set("gemm256"))
     float* pX = nullptr;        // [chunk, H] f32 residual stream
     float* pWS = nullptr;       // split-K workspace of the prefill GEMMs: at most 1024 partial tiles of 128 x 128 f32
     static constexpr size_t gemm_ws_floats = (size_t)1024 * 128 * 128;

@@ -28,8 +28,9 @@ void Model::ensure_vision_buffers(int n_patches) {
     vCos = dalloc<float>((size_t)cap * 64);
     vSin = dalloc<float>((size_t)cap * 64);
     const size_t pages = (size_t)(cap + 63) / 64;
-    vK = dalloc<float>(pages * vcfg.heads * 64 * 64);
-    vV = dalloc<float>(pages * vcfg.heads * 64 * 64);
+    vkv_lo_off = pages * vcfg.heads * 64 * 64;
+    vK = dalloc<uint16_t>(2 * vkv_lo_off);
+    vV = dalloc<uint16_t>(2 * vkv_lo_off);
     vW4 = dalloc<float>((size_t)4 * cap);
     vIdx = dalloc<int>((size_t)4 * cap);
     vBt = dalloc<int>(pages);
@@ -54,6 +55,7 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     }
     if (expect != n_patches) throw CmError(CM_ERR_INVALID, "pixel_values rows != sum(t*h*w) of grid_thw");
     ensure_vision_buffers((int)n_patches);
+    ensure_prefill_buffers();                  // (the split-K workspace of the GEMMs)
     const int N = (int)n_patches;
     hipStream_t s = stream;
 
@@ -104,6 +106,7 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     auto gemm = [&](const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* W, const float* bias, int Mrows, int Ncols, int K,
                     int epi, float* C, uint16_t* h_hi, uint16_t* h_lo, int act) {
         GemmArgs g{};
+        g.ws = pWS; g.ws_floats = pWS ? gemm_ws_floats : 0;      // split-K: at 784 patches a GEMM has 56-224 output tiles for 256 CUs
         g.A_hi = a_hi; g.A_lo = a_lo; g.W = W; g.bias = bias; g.M = Mrows; g.N = Ncols; g.K = K; g.C = C; g.ldc = Ncols;
         g.H_hi = h_hi; g.H_lo = h_lo; g.act = act;
         if (!launch_gemm(g, epi, s)) throw CmError(CM_ERR_UNSUPPORTED, "vision GEMM shape (N % 128, K % 32)");
@@ -117,15 +120,15 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
         const VisionBlockW& b = vw.blocks[(size_t)li];
         launch_layernorm_rows(vX, b.n1w, b.n1b, vA_hi, vA_lo, N, VH, 1e-6f, s);
         gemm(vA_hi, vA_lo, b.qkv_w, b.qkv_b, N, 3 * VH, VH, GEPI_STORE, vQKV, nullptr, nullptr, 0);
-        launch_vit_rope_kv(vQKV, vCos, vSin, vQ_hi, vQ_lo, vK, vV, N, heads, scale, s);
+        launch_vit_rope_kv(vQKV, vCos, vSin, vQ_hi, vQ_lo, vK, vV, vkv_lo_off, N, heads, scale, s);
         for (auto& fr : frames) {                                  // full attention inside each frame (vision.rs:145-172)
             AttnPreArgs at{};
             at.q_hi = vQ_hi + (size_t)fr.first * VH; at.q_lo = vQ_lo + (size_t)fr.first * VH;
-            at.block_table = vBt; at.kpool = vK; at.vpool = vV;
+            at.block_table = vBt; at.kpool = vK; at.vpool = vV; at.kv_lo_off = vkv_lo_off;
             at.out_hi = vB_hi + (size_t)fr.first * VH; at.out_lo = vB_lo + (size_t)fr.first * VH;
             at.S = fr.second - fr.first; at.Hq = heads; at.Hkv = heads; at.nrep = 1; at.page = 64;
             at.start_pos = fr.first; at.causal = 0; at.kv_lo = fr.first; at.kv_hi = fr.second;
-            launch_attn_prefill(at, 64, KV_F32, s);
+            launch_attn_prefill(at, 64, KV_BF16X2, s);
         }
         gemm(vB_hi, vB_lo, b.proj_w, b.proj_b, N, VH, VH, GEPI_RESADD, vX, nullptr, nullptr, 0);
         launch_layernorm_rows(vX, b.n2w, b.n2b, vA_hi, vA_lo, N, VH, 1e-6f, s);

@@ -155,7 +155,8 @@ uint64_t cm_decode_bytes_per_token(const cm_model* m, size_t ctx);
 /* ranks of the RCCL communicator this handle reduces over: 1 without tensor parallelism, tp_size once the communicator
  * is up, 0 when the collectives are local no-ops (CM_DEBUG_TP_LOCAL) -- bench.py asserts it equals --gpus */
 int cm_tp_ranks(const cm_model* m);
-/* 1 when the decode step runs on the persistent per-layer chain kernel (cm_opts.engine), else 0 */
+/* decode path of this handle: 0 per-projection launches; 1 persistent kernel, one launch per layer around the separate attention
+ * kernels; 2 persistent kernel, the whole token (every projection and the attention of every layer) in one launch */
 int cm_engine_active(const cm_model* m);
 
 /* ---- single-sequence path (the implicit sequence of B1/B2) ----------------- */

@@ -18,13 +18,15 @@ def rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
-@pytest.fixture(scope="module", params=[("full", "f16"), ("layer", "f16"), ("full", "bf16")], ids=lambda p: f"{p[0]}-{p[1]}")
+@pytest.fixture(scope="module", params=[("full", "f16", "eng-qwen3"), ("layer", "f16", "eng-qwen3"), ("full", "bf16", "eng-qwen3"),
+                                        ("full", "f16", "eng-qwen3-gqa2")], ids=lambda p: f"{p[0]}-{p[1]}-{p[2]}")
 def trio(request):
-    mode, kv = request.param
-    cfg = configs.get_config("eng-qwen3")
+    mode, kv, name = request.param
+    cfg = configs.get_config(name)
     w = synth.synth_weights_f32(cfg, seed=0)
     eng = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=1, kv_dtype=kv)
     eng.debug_set("engine_full", 1 if mode == "full" else 0)          # whole-token launch / one launch per layer
+    assert eng.engine_active() == (2 if mode == "full" else 1)
     eng.kv = kv
     ref = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=-1, kv_dtype=kv)
     yield cfg, w, eng, ref

@@ -102,6 +102,32 @@ def test_prefill_1024_and_batched_step_qwen3_8b_geometry(oracle8b):
         m.close()
 
 
+@pytest.mark.parametrize("split", [0, 1])
+def test_wide_gemm_kernel_is_bit_equal_to_the_128_row_kernel(split):
+    """The 256-row LDS-DMA GEMM (kernels_gemm256.hip: global_load_lds tiles, source-side bank swizzle, three LDS stages behind a
+    counted vmcnt) multiplies the same k-tiles in the same order into every accumulator as gemm_bf16_kernel: a 1024-token prompt
+    through either kernel must give IDENTICAL logits wherever neither launch splits K (gate||up at 1024 rows: 256 x 192 tiles),
+    and logits within the split-K summation order elsewhere.  Parity mode (hi + lo planes) and plain bf16 activations."""
+    cfg = configs.get_config("qwen3-8b-2l")
+    V = cfg["vocab_size"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, prefill_split=split)
+    try:
+        outs = []
+        for n in (1024, 1536):                       # 4 and 6 m-tiles of 256 rows (1536: a ragged tile count for the XCD order)
+            ids = configs.synthetic_prompt(n, V)
+            pair = []
+            for mode in (0, 1):
+                m.debug_set("gemm256", mode)
+                m.clear_kv_cache()
+                pair.append(m.forward_step(ids, 0)[0, 0].copy())
+            outs.append(pair)
+            # (plain bf16: a split-K order difference of 1e-7 flips bf16 roundings of the next activation, 2^-9 on those elements)
+            assert rel(pair[1], pair[0]) < (2e-5 if split == 0 else 5e-3), (n, rel(pair[1], pair[0]))
+            assert int(pair[0].argmax()) == int(pair[1].argmax())
+    finally:
+        m.close()
+
+
 def test_decode_and_prefill_qwen3_0p6b_geometry():
     """BASELINE configs[0] geometry (H 1024, tied 151 936-row head): the K = 1024 / 3072 GEMV instantiations."""
     cfg = configs.get_config("qwen3-0.6b-2l")
