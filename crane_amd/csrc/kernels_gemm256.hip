@@ -1,24 +1,26 @@
-// Prompt-pass GEMM for LARGE M on 256-row tiles fed by LDS-DMA:  C[M, N] (+)= A[M, K] . W[N, K]^T, bf16 operands, f32 accumulate,
-// the activation operand as one bf16 plane (SPLIT = 1) or as bf16 hi + lo planes (SPLIT = 2, the parity mode: two MFMAs per
-// product).  Same epilogues and the same arithmetic per output element as gemm_bf16_kernel (kernels_prefill.hip) up to
-// the order of the k-tiles inside one accumulator, which is identical (k ascending) -- results are bit-equal to that kernel's
-// un-split launch.
+// Prompt-pass GEMM for LARGE M fed by LDS-DMA in FULL cache lines:  C[M, N] (+)= A[M, K] . W[N, K]^T, bf16 operands, f32
+// accumulate, the activation operand as one bf16 plane (SPLIT = 1) or as bf16 hi + lo planes (SPLIT = 2, the parity mode: two
+// MFMAs per product).  Same epilogues and, per accumulator, the same sequence of MFMAs (k ascending; hi then lo) as
+// gemm_bf16_kernel (kernels_prefill.hip): an un-split launch is bit-equal to that kernel's.
 //
-// Why a second kernel.  gemm_bf16_kernel stages a k-tile global -> VGPR -> ds_write_b128 -> LDS.  On gfx950 a ds_write_b128 costs
-// 13 LDS cycles per wave-instruction (79 B/clk/CU, MI355X_MICROARCH.md, LDS): a 128 x 256 x 32 tile with hi + lo activations writes
-// 32 KB = 416 cycles and reads 384 (12 ds_read_b128 x 8 waves x 4) per k-tile against 1024 cycles of MFMA on the four SIMDs --
-// 78 % of the LDS pipe at best overlap, and plain bf16 activations exceed it (568 vs 512): that, not the matrix cores, is what
-// the 47 % MFMA-busy of the round-2 profile was waiting for.  Here
-//   * tiles arrive by global_load_lds_dwordx4 (LDS-DMA): no staging VGPRs, no ds_write pass.  The LDS image is lane-linear per
-//     wave-instruction (16 rows x 64 B), so the bank swizzle is applied to the SOURCE address: lane (row, slot p) fetches the
-//     16-byte k-chunk p ^ swz(row) of its row, and the fragment reads apply the same involution (cdna_hip_programming.md rule 21);
-//   * three LDS stages and a COUNTED vmcnt: while tile t is multiplied, tile t + 1 has landed or is landing and tile t + 2 was
-//     just requested.  The DMA is issued from inline asm: the compiler's own wait-count pass would otherwise make every ds_read
-//     wait for ALL outstanding LDS-DMA (vmcnt(0)) and serialise the pipeline;
-//   * the two wave rows of the workgroup ping-pong (see the schedule comment in the kernel): one multiplies from registers while
-//     the other fetches, so the matrix cores do not idle through the fetch;
-//   * 256 x 256 x 32 per workgroup of 8 waves (2 x 4), 128 x 64 per wave: 20 ds_read_b128 per 64 MFMAs (hi + lo; 12 per 32 plain),
-//     half the LDS reads and half the L2 -> CU bytes per flop of the 128 x 256 tile.
+// Why a second kernel -- what the round-2 profile's 47 % MFMA-busy was waiting for.  gemm_bf16_kernel walks K in 32-element
+// k-tiles: every operand row contributes a 64-byte segment per tile, i.e. HALF of a 128-byte cache line, and the other half is
+// fetched again from the L2 one k-tile later (the 32 KB vector L1 does not keep a 40 KB tile stream).  The L2 -> L1 fill path
+// moves 64 B/clk per CU: a 128 x 256 x 32 tile with hi + lo activations needs 512 rows x 128 B = 64 KB of line fills per
+// 1024 MFMA cycles -- 100 % of it.  On top, the tile went global -> VGPR -> ds_write_b128 (13 LDS cycles per wave-instruction,
+// MI355X_MICROARCH.md) -> LDS.  A first version of this file kept the 32-deep tiles and only replaced the staging by LDS-DMA and
+// a ping-pong of the two wave rows: 552 -> 632 TFLOP/s useful on the 1024-row gate||up, still fill-bound.  This version
+//   * walks K in 64-element tiles: an operand row is one whole 128-byte line per tile, fetched once;
+//   * brings tiles in by global_load_lds_dwordx4 (LDS-DMA, 8 rows x 128 B per wave-instruction): no staging VGPRs, no ds_write
+//     pass.  The LDS image of a DMA is lane-linear, so the bank swizzle sits on the SOURCE address: lane (row, slot p) fetches
+//     the 16-byte chunk p ^ ((row >> 1) & 7) of its row and the fragment reads apply the same involution
+//     (cdna_hip_programming.md rule 21) -- the 16 lanes of every ds_read_b128 group then fall on 16 different 16-byte slots of
+//     the 256-byte bank row;
+//   * two LDS stages + the register file as the third, and the two wave rows of the workgroup half a tile apart: one row
+//     multiplies from registers while the other fetches the next tile's fragments (schedule comment in the kernel).  The DMA
+//     is issued from inline asm: the compiler's own wait-count pass would make every ds_read wait for ALL outstanding LDS-DMA;
+//   * parity mode: 128 x BN x 64 tiles (two activation planes: 64 KB per stage at BN = 256); plain bf16: 256 x BN x 64;
+//     8 waves as 2 (M) x 4 (N); BN = 256 or 192 (whole rounds of 256 CUs: N = 24576 at M = 1024).
 #include <cstdlib>
 
 #include "dev_common.h"
@@ -28,10 +30,8 @@ namespace cm {
 
 namespace {
 
-constexpr int TBK = 32;              // k-tile depth (elements): one 64-byte row segment per operand row
-constexpr int TST = 3;               // LDS stages
-
-__device__ __forceinline__ int swz256(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // = gemm_swz (kernels_prefill.hip)
+constexpr int TBK = 64;              // k-tile depth (elements): one 128-byte line per operand row
+constexpr int TST = 2;               // LDS stages
 
 // one LDS-DMA piece: every lane's 16 bytes at `gsrc` land at lds_base + 16 * lane.  M0 carries the LDS base and belongs to the
 // compiler, so it is saved and restored around the instruction (cdna_hip_programming.md, inline-asm notes).
@@ -45,17 +45,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_base) {
 
 }  // namespace
 
-// BN = 256: 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64.  BN = 192: the same with 48 columns per wave (N = 24576 at M = 1024:
-// 4 x 128 = 512 tiles = two full rounds of 256 CUs instead of 384 = one and a half).
 template <int SPLIT, int EPI, int BN>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
-    constexpr int BM = 256, NI = 8, NJ = BN / 64, WN = BN / 4;           // per wave: NI x NJ tiles of 16 x 16
+    constexpr int BM = SPLIT == 2 ? 128 : 256;                            // rows of a tile (two planes double the activation bytes)
+    constexpr int NI = BM / 32, NJ = BN / 64, WM = BM / 2, WN = BN / 4;  // per wave: NI x NJ tiles of 16 x 16
     constexpr int PLANE = BM * TBK;                                       // elements of one activation plane of a stage
-    constexpr int BROWS = BN;                                             // weight rows of a stage
-    constexpr int STAGE = SPLIT * PLANE + BROWS * TBK;                    // elements per stage
-    constexpr int APIECES = BM / 16 / 8;                                  // 16-row DMA pieces per wave and plane (2)
-    constexpr int BPIECES = (BROWS / 16 + 7) / 8;                         // ... of the weight tile (2; BN = 192: 12 pieces, waves 4-7 repeat one)
-    constexpr int NLOAD = SPLIT * APIECES + BPIECES;                      // DMA instructions per wave and k-tile
+    constexpr int STAGE = SPLIT * PLANE + BN * TBK;                       // elements per stage
+    constexpr int APC = BM / 8, NPC = SPLIT * APC + BN / 8;               // 8-row DMA pieces per plane / per stage
+    constexpr int NLOAD = (NPC + 7) / 8;                                  // DMA instructions per wave and k-tile (7 or 8)
+    static_assert(NPC > 8 * (NLOAD - 1) && NLOAD <= 8, "piece distribution");
     extern __shared__ __attribute__((aligned(16))) uint16_t lds256[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,114 +75,133 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- DMA source addresses of this lane (k-tile 0), one per piece; rows past M are clamped (their products are dropped) ----
-    const int prow = lane >> 2, pslot = lane & 3;
+    // ---- DMA pieces of this wave: piece p = wave + 8 i covers 8 rows x 128 B of plane hi, plane lo or the weight tile.  A wave
+    // whose last slot has no piece (NPC not a multiple of 8) repeats its first one: equal DMA counts keep the waits uniform.
+    // Rows past M are clamped (their products are dropped in the epilogue). ----
+    const int prow = lane >> 3, pslot = lane & 7;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds256;                    // LDS byte offset of the dynamic segment (low half of the flat address)
-    const uint16_t* srcA[SPLIT][APIECES];
-    const uint16_t* srcB[BPIECES];
-    uint32_t dstA[APIECES], dstB[BPIECES];
+    const uint16_t* src[NLOAD];
+    uint32_t dst[NLOAD];
 #pragma unroll
-    for (int i = 0; i < APIECES; ++i) {
-        const int piece = wave + 8 * i, row = piece * 16 + prow;
-        const int grow = min(m0 + row, a.M - 1);
-        const size_t off = (size_t)grow * K + (size_t)kbeg * TBK + ((pslot ^ swz256(row)) << 3);
-        srcA[0][i] = a.A_hi + off;
-        if (SPLIT == 2) srcA[SPLIT - 1][i] = a.A_lo + off;
-        dstA[i] = lds0 + (uint32_t)(piece * 16 * TBK) * 2u;
-    }
-#pragma unroll
-    for (int i = 0; i < BPIECES; ++i) {
-        int piece = wave + 8 * i;
-        if (piece >= BROWS / 16) piece -= 8;                              // BN = 192: waves 4-7 fetch their first piece twice (equal DMA counts)
-        const int row = piece * 16 + prow;
-        srcB[i] = a.W + (size_t)(n0 + row) * K + (size_t)kbeg * TBK + ((pslot ^ swz256(row)) << 3);
-        dstB[i] = lds0 + (uint32_t)(SPLIT * PLANE + piece * 16 * TBK) * 2u;
-    }
-    auto issue = [&](int tile, int stage) __attribute__((always_inline)) {          // tile relative to kbeg, clamped by the caller
-        const size_t ko = (size_t)tile * TBK;
-        const uint32_t so = (uint32_t)(stage * STAGE) * 2u;
-#pragma unroll
-        for (int i = 0; i < APIECES; ++i) {
-            glds16(srcA[0][i] + ko, dstA[i] + so);
-            if (SPLIT == 2) glds16(srcA[SPLIT - 1][i] + ko, dstA[i] + so + (uint32_t)PLANE * 2u);
+    for (int i = 0; i < NLOAD; ++i) {
+        int p = wave + 8 * i;
+        if (p >= NPC) p = wave;
+        const int plane = p < SPLIT * APC ? p / APC : SPLIT;              // SPLIT: the weight tile
+        const int r0 = (plane < SPLIT ? p - plane * APC : p - SPLIT * APC) * 8, row = r0 + prow;
+        const size_t kc = (size_t)kbeg * TBK + (size_t)((pslot ^ ((row >> 1) & 7)) << 3);
+        if (plane < SPLIT) {
+            const uint16_t* base = (SPLIT == 2 && plane == 1) ? a.A_lo : a.A_hi;
+            src[i] = base + (size_t)min(m0 + row, a.M - 1) * K + kc;
+        } else {
+            src[i] = a.W + (size_t)(n0 + row) * K + kc;
         }
-#pragma unroll
-        for (int i = 0; i < BPIECES; ++i) glds16(srcB[i] + ko, dstB[i] + so);
-    };
+        dst[i] = lds0 + (uint32_t)(plane * PLANE + r0 * TBK) * 2u;        // (plane == SPLIT: SPLIT * PLANE = start of the weight rows)
+    }
 
-    // ---- ping-pong schedule: the two wave rows (waves 0-3 / 4-7; each SIMD hosts one wave of either) run half a k-tile apart.
-    // A k-tile is two phases, each closed by the workgroup barrier:
-    //   FETCH  : request tile t + 2 by LDS-DMA, read ALL of tile t's fragments into registers, wait for this wave's share of
-    //            tile t + 1 (counted vmcnt: tile t + 2 stays in flight), barrier
-    //   MULTIPLY: the tile's MFMAs from registers (no memory instruction at all), barrier
-    // Wave row 1 enters the loop one barrier late, so while one row multiplies the other fetches: every SIMD's matrix core always
-    // has one wave feeding it, and the fetch phase (6 DMA requests + 20 ds_read_b128, ~400 cycles) hides under the partner's 1024
-    // MFMA cycles.  In lock step (both rows fetching, then both multiplying: the first version of this kernel) the matrix cores
-    // idled through every fetch: 605 TFLOP/s useful on the 1024-row gate||up instead of 552 for the register-staged kernel.
-    // Hazards, with three stages: the DMA of tile t + 2 overwrites the stage of tile t - 1, whose last reader (the late row's
-    // FETCH of tile t - 1) finished before the barrier the early row passed to get here; a row's FETCH of tile t + 1 comes after a
-    // barrier that every wave passed AFTER waiting for its own share of tile t + 1.
-    const int fr = lane & 15, fk = (((lane >> 4) ^ swz256(fr)) << 3);
-    bf16x8 ah[NI], al[NI], bfrag[NJ];
+    const int fr = lane & 15, sw = (fr >> 1) & 7;
+    const int fk0 = ((0 + (lane >> 4)) ^ sw) << 3, fk1 = ((4 + (lane >> 4)) ^ sw) << 3;      // element offsets of the lane's chunk, k-steps 0 / 1
+    bf16x8 ah[2][NI], al[2][NI], bfr[2][NJ];
     auto fetch = [&](int stage) __attribute__((always_inline)) {
         const uint16_t* S = lds256 + stage * STAGE;
         const uint16_t* Bs = S + SPLIT * PLANE;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bfrag[j] = *(const bf16x8*)&Bs[(wc * WN + j * 16 + fr) * TBK + fk];
+        for (int s = 0; s < 2; ++s) {
+            const int fk = s ? fk1 : fk0;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            ah[i] = *(const bf16x8*)&S[(wr * 128 + i * 16 + fr) * TBK + fk];
-            if (SPLIT == 2) al[i] = *(const bf16x8*)&S[PLANE + (wr * 128 + i * 16 + fr) * TBK + fk];
-        }
-    };
-    auto multiply = [&]() __attribute__((always_inline)) {
+            for (int j = 0; j < NJ; ++j) bfr[s][j] = *(const bf16x8*)&Bs[(wc * WN + j * 16 + fr) * TBK + fk];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bfrag[j], acc[i][j], 0, 0, 0);
-            if (SPLIT == 2) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bfrag[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < NI; ++i) {
+                ah[s][i] = *(const bf16x8*)&S[(wr * WM + i * 16 + fr) * TBK + fk];
+                if (SPLIT == 2) al[s][i] = *(const bf16x8*)&S[PLANE + (wr * WM + i * 16 + fr) * TBK + fk];
             }
         }
     };
-    // barrier closing a FETCH: at most one k-tile of this wave's DMA outstanding (tile t + 1 has landed), fragment reads done
-    auto turn_fetch = [&]() __attribute__((always_inline)) {
-        if constexpr (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if constexpr (NLOAD == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else static_assert(NLOAD == 4 || NLOAD == 6, "DMA count per k-tile");
-        __builtin_amdgcn_sched_barrier(0);
+    // ---- schedule: the two wave rows (waves 0-3 / 4-7; every SIMD hosts one wave of either) run half a tile apart.  A tile is two
+    // phases per row, each closed by the workgroup barrier: FETCH (all fragments of tile t: LDS -> registers) and MULTIPLY (the
+    // tile's MFMAs from registers).  Row 1 enters one barrier late, so while one row multiplies the other fetches and every
+    // SIMD's matrix core always has a wave feeding it.  With the fragments in registers a stage is free once BOTH rows fetched it
+    // -- two stages suffice if tile t + 1's DMA is requested by both rows in the SAME slot (the one in which row 0 fetches tile t
+    // and row 1 multiplies tile t - 1: the stage of tile t - 1 was fetched by row 1 one slot earlier) and waited for one slot
+    // later: row 0 requests its share at the start of its FETCH and waits at the end of its MULTIPLY, row 1 requests its share
+    // BETWEEN THE MFMA BANDS of its MULTIPLY (a request costs ~60 cycles of issue there, ~150 in a fetch phase next to the
+    // ds_reads: MI355X_MICROARCH.md) and waits at the end of its next FETCH.  Every DMA has a whole slot (> 1000 cycles) to land.
+    auto multiply = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                if (SPLIT == 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                }
+            }
     };
-    auto turn = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+    auto issue_all = [&](int tile, int stage) __attribute__((always_inline)) {
+        const size_t ko = (size_t)tile * TBK;
+        const uint32_t so = (uint32_t)(stage * STAGE) * 2u;
+#pragma unroll
+        for (int g = 0; g < NLOAD; ++g) glds16(src[g] + ko, dst[g] + so);
     };
-    auto step = [&](int t, int stage) __attribute__((always_inline)) {
-        issue(min(t + 2, kpb - 1), (stage + 2) % TST);                    // past the end: a clamped tile into a stage nobody reads
-        fetch(stage);
-        turn_fetch();
-        __builtin_amdgcn_s_setprio(1);                                    // the multiplying wave wins the SIMD's issue slot
-        multiply();
-        __builtin_amdgcn_s_setprio(0);
-        turn();
+    // row 1: the MFMAs in 2 * NI row bands, one DMA request of the tile after next behind each of the first NLOAD bands (pinned:
+    // left alone the scheduler hoists every MFMA above the requests)
+    auto multiply_dma = [&](int tile, int stage) __attribute__((always_inline)) {
+        const size_t ko = (size_t)tile * TBK;
+        const uint32_t so = (uint32_t)(stage * STAGE) * 2u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                if (SPLIT == 2) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
+                }
+                constexpr int PER = (NLOAD + 2 * NI - 1) / (2 * NI);         // requests per band (1; 2 * NI >= NLOAD)
+                const int g = (s * NI + i) * PER;
+                if (g < NLOAD) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    glds16(src[g] + ko, dst[g] + so);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
     };
 
-    issue(0, 0);
-    issue(min(1, kpb - 1), 1);
-    if constexpr (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    if (wr == 1) turn();                                                  // the late row: one barrier behind
-    for (int t = 0; t < kpb; t += TST) {
-        step(t, 0);
-        if (t + 1 < kpb) step(t + 1, 1);
-        if (t + 2 < kpb) step(t + 2, 2);
+    issue_all(0, 0);                                                      // tile 0: every wave its share
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wr == 0) {
+        for (int t = 0; t < kpb; ++t) {
+            issue_all(min(t + 1, kpb - 1), (t + 1) & 1);                  // (past the end: a clamped tile into a stage nobody reads)
+            fetch(t & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            multiply();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // this wave's share of tile t + 1 has landed
+        }
+        asm volatile("s_barrier" ::: "memory");                           // (every wave executes the same number of barriers)
+    } else {
+        issue_all(min(1, kpb - 1), 1);                                    // its share of tile 1, in the slot in which row 0 fetches tile 0
+        asm volatile("s_barrier" ::: "memory");                           // the late row: one barrier behind
+        for (int t = 0; t < kpb; ++t) {
+            fetch(t & 1);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // its share of tile t + 1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            multiply_dma(min(t + 2, kpb - 1), t & 1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+        }
     }
-    if (wr == 0) turn();                                                  // (every wave executes the same number of barriers)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the clamped tail requests: nothing of this wave's DMA may land later
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the clamped tail requests: no DMA of this wave may land after it exits
 
     // ---- epilogue (gemm_bf16_kernel's): C layout of mfma 16x16: col = lane & 15 (n), row = (lane >> 4) * 4 + reg (m) ----
-    const int mw = m0 + wr * 128, nw = n0 + wc * WN;
+    const int mw = m0 + wr * WM, nw = n0 + wc * WN;
     if (EPI == GEPI_PARTIAL) {
         float* P = a.ws + (size_t)ks * a.M * a.N;
 #pragma unroll
@@ -250,8 +267,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     }
 }
 
-// dynamic LDS of an instantiation (bytes)
-static size_t gemm256_lds(int split, int bn) { return (size_t)TST * ((size_t)split * 256 * TBK + (size_t)bn * TBK) * 2; }
+// rows of a tile / dynamic LDS of an instantiation
+int gemm256_rows(bool split) { return split ? 128 : 256; }
+static size_t gemm256_lds(int split, int bn) { return (size_t)TST * ((size_t)split * gemm256_rows(split == 2) * TBK + (size_t)bn * TBK) * 2; }
 
 template <int SPLIT, int EPI, int BN>
 static void launch_one(const GemmArgs& a, int blocks, hipStream_t s) {
@@ -264,8 +282,9 @@ static void launch_one(const GemmArgs& a, int blocks, hipStream_t s) {
 // a.ksplit set by the caller (1: epilogue `epi`; > 1: GEPI_PARTIAL tiles, the caller runs gemm_splitk_epilogue_kernel)
 bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if ((bn != 256 && bn != 192) || a.N % bn != 0 || a.K % TBK != 0 || (a.K / TBK) % a.ksplit != 0) return false;
-    const int blocks = ((a.M + 255) / 256) * (a.N / bn) * a.ksplit;
     const bool split = a.A_lo != nullptr;
+    const int bm = gemm256_rows(split);
+    const int blocks = ((a.M + bm - 1) / bm) * (a.N / bn) * a.ksplit;
     const int e = a.ksplit > 1 ? (int)GEPI_PARTIAL : epi;
 #define CM_G256(SP, EP) do { if (bn == 256) launch_one<SP, EP, 256>(a, blocks, s); else launch_one<SP, EP, 192>(a, blocks, s); } while (0)
 #define CM_G256_EPI(SP) do { if (e == GEPI_STORE) CM_G256(SP, GEPI_STORE); else if (e == GEPI_RESADD) CM_G256(SP, GEPI_RESADD); \

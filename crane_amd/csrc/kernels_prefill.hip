@@ -670,15 +670,17 @@ static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
     return S;
 }
 
-// Large M (>= 512 rows): the 256-row LDS-DMA kernel (kernels_gemm256.hip) where one of its tile shapes fills the chip in whole
-// rounds -- (tile width, k-slices) by a small cost model: rounds of 256 CUs x one block's MFMA time + the f32 partial-tile
-// traffic of a split.  Returns false when the 128-row kernel should run.
+// Large M (>= 512 rows): the LDS-DMA kernel on full cache lines (kernels_gemm256.hip; 128-row tiles with hi + lo activations,
+// 256-row tiles with plain bf16) where one of its tile widths fills the chip in whole rounds -- (width, k-slices) by a small cost
+// model: rounds of 256 CUs x one block's MFMA time + the f32 partial-tile traffic of a split.  Returns false when the
+// register-staged kernel should run.
 static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     static const int env = getenv("CM_GEMM256") ? atoi(getenv("CM_GEMM256")) : 1;
     static const int force_bn = getenv("CM_GEMM256_BN") ? atoi(getenv("CM_GEMM256_BN")) : 0;     // tuning
     static const int force_ks = getenv("CM_GEMM256_KS") ? atoi(getenv("CM_GEMM256_KS")) : 0;
-    if (!env || !a.wide256 || a.M < 512 || a.K % 32 != 0) return false;
-    const int tiles_m = (a.M + 255) / 256, nk = a.K / 32;
+    if (!env || !a.wide256 || a.M < 512 || a.K % 64 != 0) return false;
+    const int bm = a.A_lo ? 128 : 256;
+    const int tiles_m = (a.M + bm - 1) / bm, nk = a.K / 64;
     const double terms = a.A_lo ? 2.0 : 1.0;
     double best = 1e30;
     int best_bn = 0, best_ks = 1;
@@ -687,10 +689,10 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
         const int tiles = tiles_m * (a.N / bn);
         for (int ks = 1; ks <= 8; ks *= 2) {
             if (force_ks && ks != force_ks) continue;
-            if (nk % ks != 0 || nk / ks < 16) break;
+            if (nk % ks != 0 || nk / ks < 8) break;
             if (ks > 1 && (a.ws == nullptr || (size_t)ks * a.M * a.N > a.ws_floats)) break;
             const int blocks = tiles * ks, rounds = (blocks + 255) / 256;
-            const double t_blk = 256.0 * bn * (double)(a.K / ks) * 2.0 * terms / 6.0e12;                  // ~60 % of a CU's MFMA peak
+            const double t_blk = (double)bm * bn * (double)(a.K / ks) * 2.0 * terms / 6.0e12;                   // ~60 % of a CU's MFMA peak
             const double t_split = ks > 1 ? ((double)(2 * ks + 1) * a.M * a.N * 4.0) / 3.0e12 + 6e-6 : 0.0;   // partial tiles out and back + a launch
             const double t = rounds * t_blk + t_split;
             if (t < best) { best = t; best_bn = bn; best_ks = ks; }
