@@ -100,6 +100,22 @@ def gguf_config(path: str) -> dict:
     return _host_json("cm_gguf_config", path)
 
 
+def tp_shard_plan(cfg: dict, tp_size: int, tp_rank: int) -> dict:
+    """The copies the C++ loader makes for one tensor-parallel rank + the rank's geometry (cm_tp_shard_plan; host only)."""
+    import json
+    lib = _lib.load()
+    txt = json.dumps(cfg).encode()
+    need = C.c_size_t(0)
+    rc = lib.cm_tp_shard_plan(txt, tp_size, tp_rank, None, 0, C.byref(need))
+    if rc != 0:
+        raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
+    buf = C.create_string_buffer(need.value)
+    rc = lib.cm_tp_shard_plan(txt, tp_size, tp_rank, buf, need.value, C.byref(need))
+    if rc != 0:
+        raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
+    return json.loads(buf.value.decode())
+
+
 def checkpoint_inspect(model_dir: str) -> dict:
     """Tensor directory of a (sharded) safetensors checkpoint as the C++ loader sees it (cm_checkpoint_inspect; host only)."""
     return _host_json("cm_checkpoint_inspect", model_dir)

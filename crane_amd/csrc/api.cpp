@@ -128,6 +128,11 @@ int cm_checkpoint_inspect(const char* model_dir, char* json_out, size_t cap, siz
     });
 }
 
+int cm_tp_shard_plan(const char* config_json, int32_t tp_size, int32_t tp_rank, char* json_out, size_t cap, size_t* needed) {
+    if (!config_json || !needed || (cap && !json_out)) { g_err = "null argument"; return CM_ERR_INVALID; }
+    return guard(nullptr, [&] { emit(cm::tp_shard_plan_json(config_json, tp_size, tp_rank), json_out, cap, needed); });
+}
+
 int cm_gguf_config(const char* path, char* json_out, size_t cap, size_t* needed) {
     if (!path || !needed || (cap && !json_out)) { g_err = "null argument"; return CM_ERR_INVALID; }
     return guard(nullptr, [&] {

@@ -14,6 +14,7 @@
 
 #include "model.h"
 #include "safetensors.h"
+#include "tp.h"
 
 namespace cm {
 
@@ -125,6 +126,28 @@ struct FileSource : Source {
     }
 };
 
+// cm_tp_shard_plan: records what build() would copy for this rank instead of copying it
+struct PlanSource : Source {
+    Model& m;
+    std::string js;
+    explicit PlanSource(Model& mm) : m(mm) {}
+    bool has(const std::string& name) override {
+        return name.compare(0, 21, "model.language_model.") != 0 && name.compare(0, 15, "language_model.") != 0;
+    }
+    void fetch(const std::string& name, int rows, int full_cols, int row0, int nrows, int col0, int ncols, uint16_t* dst,
+               size_t dst_stride) override {
+        const size_t addr = (size_t)dst;
+        size_t ai = 0, off = 0;
+        for (size_t i = 0; i < m.plan_allocs.size(); ++i)
+            if (addr >= m.plan_allocs[i].first && addr < m.plan_allocs[i].first + m.plan_allocs[i].second) { ai = i; off = (addr - m.plan_allocs[i].first) / 2; }
+        if (!js.empty()) js += ", ";
+        js += "{\"tensor\": \"" + name + "\", \"rows\": " + std::to_string(rows) + ", \"cols\": " + std::to_string(full_cols) +
+              ", \"row0\": " + std::to_string(row0) + ", \"nrows\": " + std::to_string(nrows) + ", \"col0\": " + std::to_string(col0) +
+              ", \"ncols\": " + std::to_string(ncols) + ", \"dst\": " + std::to_string(ai) + ", \"dst_off\": " + std::to_string(off) +
+              ", \"dst_stride\": " + std::to_string(dst_stride) + "}";
+    }
+};
+
 // small tensors the kernels want in f32 (norm weights with the Qwen3.5 "+1" folded in, conv taps, A_log, dt_bias):
 // fetched as bf16 like everything else, then widened on the device
 float* fetch_f32(Model& m, Source& src, const std::string& name, int n, float add, int total = -1, int start = 0) {
@@ -132,7 +155,7 @@ float* fetch_f32(Model& m, Source& src, const std::string& name, int n, float ad
     uint16_t* tmp = m.dalloc<uint16_t>((size_t)n);
     src.fetch(name, 1, total, 0, 1, start, n, tmp, (size_t)n);
     float* out = m.dalloc<float>((size_t)n, true);
-    launch_bf16_to_f32(tmp, out, (size_t)n, add, m.stream);
+    if (!m.plan_only) launch_bf16_to_f32(tmp, out, (size_t)n, add, m.stream);
     return out;
 }
 
@@ -204,7 +227,7 @@ void build(Model& m, Source& src) {
             const int KDg = c.NK_g * c.Kd, VDg = c.NV_g * c.Vd, CDg = 2 * KDg + VDg, r = m.rank;
             const int rows = cd + vd + 2 * nv, rows_pad = (rows + 127) / 128 * 128;
             w.in_proj = m.dalloc<uint16_t>((size_t)rows_pad * H, true);
-            CM_HIP(hipMemsetAsync(w.in_proj, 0, (size_t)rows_pad * H * sizeof(uint16_t), m.stream));
+            if (!m.plan_only) CM_HIP(hipMemsetAsync(w.in_proj, 0, (size_t)rows_pad * H * sizeof(uint16_t), m.stream));
             const std::string qn = p + "linear_attn.in_proj_qkv.weight";
             src.fetch(qn, CDg, H, r * kdl, kdl, 0, H, w.in_proj, (size_t)H);                                   // q
             src.fetch(qn, CDg, H, KDg + r * kdl, kdl, 0, H, w.in_proj + (size_t)kdl * H, (size_t)H);           // k
@@ -225,7 +248,7 @@ void build(Model& m, Source& src) {
                 src.fetch(cn, 1, CDg * ck, 0, 1, (KDg + r * kdl) * ck, kdl * ck, tmp + (size_t)kdl * ck, (size_t)kdl * ck);
                 src.fetch(cn, 1, CDg * ck, 0, 1, (2 * KDg + r * vd) * ck, vd * ck, tmp + (size_t)2 * kdl * ck, (size_t)vd * ck);
                 w.conv_w = m.dalloc<float>((size_t)cd * ck, true);
-                launch_bf16_to_f32(tmp, w.conv_w, (size_t)cd * ck, 0.f, m.stream);
+                if (!m.plan_only) launch_bf16_to_f32(tmp, w.conv_w, (size_t)cd * ck, 0.f, m.stream);
             }
             w.A_log = fetch_f32(m, src, p + "linear_attn.A_log", nv, 0.f, c.NV_g, r * nv);
             w.dt_bias = fetch_f32(m, src, p + "linear_attn.dt_bias", nv, 0.f, c.NV_g, r * nv);
@@ -276,10 +299,28 @@ void build(Model& m, Source& src) {
             d.fc2_w = mat(dp + "linear_fc2.weight", v.out_hidden, MH); d.fc2_b = fetch_f32(m, src, dp + "linear_fc2.bias", v.out_hidden, 0.f);
         }
     }
-    CM_HIP(hipStreamSynchronize(m.stream));
+    if (!m.plan_only) CM_HIP(hipStreamSynchronize(m.stream));
 }
 
 }  // namespace
+
+// Host only: the copies load_from_dir would make for rank `tp_rank` of `tp_size` -- every (tensor, row range, column range) ->
+// (allocation, element offset, row stride) -- and the rank's shard geometry.  The SAME build() the device loader runs, over a
+// recording source and a model that never touches a device: what tests/test_tp_sharding.py compares with crane_amd/tp.py.
+std::string tp_shard_plan_json(const std::string& config_json, int tp_size, int tp_rank) {
+    Model m;
+    m.plan_only = true;
+    cm_opts o{};
+    o.tp_size = tp_size; o.tp_rank = tp_rank;
+    m.init_common(config_json, &o);
+    PlanSource src(m);
+    build(m, src);
+    std::string js = "{\"tp\": " + std::to_string(m.tp) + ", \"rank\": " + std::to_string(m.rank) + ", \"Hq_l\": " + std::to_string(m.Hq_l) +
+                     ", \"Hkv_l\": " + std::to_string(m.Hkv_l) + ", \"kvh0\": " + std::to_string(m.kvh0) + ", \"I_l\": " + std::to_string(m.I_l) +
+                     ", \"V_l\": " + std::to_string(m.V_l) + ", \"v0\": " + std::to_string(m.v0) + ", \"NK_l\": " + std::to_string(m.cfg.NK) +
+                     ", \"NV_l\": " + std::to_string(m.cfg.NV) + ", \"weight_bytes\": " + std::to_string(m.weight_bytes) + ", \"copies\": [" + src.js + "]}";
+    return js;
+}
 
 void load_from_dir(Model& m, const std::string& dir) {
     try {

@@ -17,6 +17,13 @@ template <typename T>
 T* Model::dalloc(size_t n, bool count_weight) {
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (plan_only) {
+        const size_t base = 0x10000000ull + plan_bump;
+        plan_bump += (bytes + 255) / 256 * 256;
+        plan_allocs.emplace_back(base, bytes);
+        if (count_weight) weight_bytes += bytes;
+        return (T*)base;
+    }
     CM_HIP(hipMalloc(&p, bytes));
     allocs.push_back(p);
     alloc_sizes.push_back(count_weight ? bytes : 0);
@@ -41,6 +48,7 @@ void Model::dfree(void* p) {
 }
 
 Model::~Model() {
+    if (plan_only) return;
     if (stream) (void)hipStreamSynchronize(stream);
     for (int v = 0; v < 5; ++v) {
         if (graph_exec[v]) (void)hipGraphExecDestroy(graph_exec[v]);
@@ -199,11 +207,13 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (cfg.Hq % cfg.Hkv) throw CmError(CM_ERR_INVALID, "num_attention_heads % num_key_value_heads != 0");
 
     dev = opts.device;
-    CM_HIP(hipSetDevice(dev));
-    hipDeviceProp_t prop;
-    CM_HIP(hipGetDeviceProperties(&prop, dev));
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!plan_only) {
+        CM_HIP(hipSetDevice(dev));
+        hipDeviceProp_t prop;
+        CM_HIP(hipGetDeviceProperties(&prop, dev));
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        CM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
 
     tp = opts.tp_size > 0 ? opts.tp_size : 1;
     rank = opts.tp_rank;

@@ -120,6 +120,11 @@ struct Model {
     cm_opts opts{};
     int dev = 0, num_cu = 256;
     int tp = 1, rank = 0;
+    // host-only "plan" instance (cm_tp_shard_plan): no device is touched -- dalloc hands out fake addresses and records them,
+    // the loader's fetch calls are recorded instead of executed
+    bool plan_only = false;
+    size_t plan_bump = 0;
+    std::vector<std::pair<size_t, size_t>> plan_allocs;      // (fake base address, bytes)
     // local (per-rank) shard geometry
     int Hq_l = 0, Hkv_l = 0, I_l = 0, V_l = 0, v0 = 0, kvh0 = 0, nrep = 1;
     int page = 64, max_seq = 0, max_pages_per_seq = 0, nsplit = 32;
@@ -377,6 +382,7 @@ struct Model {
 // loaders (loader.cpp)
 void load_from_dir(Model& m, const std::string& dir);
 void load_synthetic(Model& m, uint64_t seed);
+std::string tp_shard_plan_json(const std::string& config_json, int tp_size, int tp_rank);   // loader.cpp, host only
 std::string gguf_config_json(const std::string& path);     // loader_gguf.cpp
 void load_from_gguf(Model& m, const std::string& path);
 

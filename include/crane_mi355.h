@@ -139,6 +139,14 @@ int cm_gguf_config(const char* path, char* json_out, size_t cap, size_t* needed)
  * an FNV-1a hash of each tensor's bytes.  Same buffer protocol as cm_gguf_config. */
 int cm_checkpoint_inspect(const char* model_dir, char* json_out, size_t cap, size_t* needed);
 
+/* Tensor-parallel shard plan of rank `tp_rank` of `tp_size` for the model described by config.json text: every copy the loader
+ * makes for that rank -- {"tensor", "rows", "cols", "row0", "nrows", "col0", "ncols", "dst", "dst_off", "dst_stride"}: rows
+ * [row0, row0 + nrows) x columns [col0, col0 + ncols) of checkpoint tensor `tensor` ([rows, cols]) land at element offset
+ * dst_off of device allocation number dst, dst_stride elements per row -- plus the rank's geometry (Hq_l, Hkv_l, kvh0, I_l, V_l,
+ * v0, NK_l, NV_l, weight_bytes).  Host only (the loader's own code path over a recording source; no device is touched): how a
+ * multi-process launcher or a test checks the partition of SURVEY 8(e) without GPUs.  Same buffer protocol as cm_gguf_config. */
+int cm_tp_shard_plan(const char* config_json, int32_t tp_size, int32_t tp_rank, char* json_out, size_t cap, size_t* needed);
+
 /* ---- introspection (ModelBackend::num_layers/dtype/..., backend.rs:47-60) --- */
 size_t cm_num_layers(const cm_model* m);
 size_t cm_vocab_size(const cm_model* m);

@@ -177,3 +177,91 @@ def test_plan_shapes_qwen38_27b_tp8():
         assert list(p.gdn_key_heads) == [2 * r, 2 * r + 1] and list(p.gdn_value_heads) == list(range(6 * r, 6 * r + 6))
         assert all(v // 3 in p.gdn_key_heads for v in p.gdn_value_heads)      # interleaved pairing stays rank-local
         assert list(p.kv_heads) == [r // 2] and len(p.q_heads) == 3 and len(p.inter) == 2176 and len(p.vocab) == 31040
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The C++ loader's own slicing (csrc/loader.cpp build(), through the host-only cm_tp_shard_plan: the loader's code path over a
+# recording source, no device) against crane_amd/tp.py -- the plan the gloo runs above prove -- at the REAL geometries.
+# ---------------------------------------------------------------------------------------------------------------------------
+COL_SLICED = ("self_attn.o_proj.weight", "mlp.down_proj.weight", "linear_attn.out_proj.weight")
+
+
+def _expected_ids(cfg, name, shape, plan):
+    """source row ids (or column ids for the row-parallel matrices) of `name` that tp.shard_weights hands to this rank, in order"""
+    from crane_amd import tp
+    t = cfg.get("text_config", cfg)
+    if name.endswith(COL_SLICED):
+        probe = np.arange(shape[1], dtype=np.int64).reshape(1, -1)
+        return tp.shard_weights(t, {name: probe}, plan)[name].reshape(-1)
+    probe = np.arange(shape[0], dtype=np.int64).reshape(-1, *([1] * (len(shape) - 1)))
+    return tp.shard_weights(t, {name: probe}, plan)[name].reshape(-1)
+
+
+@pytest.mark.parametrize("name,world", [("qwen3-8b", 8), ("qwen3.8-27b", 8), ("qwen3-0.6b", 4), ("qwen3.5-0.8b", 2), ("tiny-qwen3", 2)])
+def test_cpp_loader_slices_what_the_plan_says(name, world):
+    """Every rank of TP = 8 on Qwen3-8B (4 q heads + 1 kv head + 1536 MLP columns + 18 992 vocabulary rows per rank) and on
+    Qwen3.8-27B (3 q heads, KV head floor(r / 2) replicated on two ranks, 2 GDN key heads + their 6 value heads in HF interleaved
+    order, 2176 MLP columns, 31 040 vocabulary rows -- SURVEY 8e): the row / column ranges csrc/loader.cpp copies are exactly
+    crane_amd.tp.shard_weights', nothing is copied twice into one shard, and the ranks together cover every tensor."""
+    from crane_amd import configs, synth, tp
+    from crane_amd.backend import tp_shard_plan
+    cfg = configs.get_config(name)
+    t = cfg.get("text_config", cfg)
+    shapes = {n: s for n, s, *_ in synth.specs_for(cfg)}
+    D = t.get("head_dim") or t["hidden_size"] // t["num_attention_heads"]
+    hybrid = "linear_num_key_heads" in t
+    cover = {}
+    for r in range(world):
+        plan = tp.shard_plan(t, world, r)
+        got = tp_shard_plan(cfg, world, r)
+        assert (got["Hq_l"], got["Hkv_l"], got["kvh0"], got["I_l"]) == (len(plan.q_heads), len(plan.kv_heads), plan.kv_heads.start, len(plan.inter))
+        assert got["v0"] == (t["vocab_size"] + world - 1) // world * r
+        if hybrid:
+            assert (got["NK_l"], got["NV_l"]) == (len(plan.gdn_key_heads), len(plan.gdn_value_heads))
+        by_tensor = {}
+        for c in got["copies"]:
+            by_tensor.setdefault(c["tensor"], []).append(c)
+        assert set(by_tensor) <= set(shapes), set(by_tensor) - set(shapes)
+        for tn, copies in by_tensor.items():
+            shape = shapes[tn]
+            copies = sorted(copies, key=lambda c: (c["dst"], c["dst_off"]))
+            if tn.endswith("conv1d.weight"):          # fetched as one row of conv_dim * k taps: column ranges -> channel ranges
+                k = shape[-1]
+                ids = np.concatenate([np.arange(c["col0"] // k, (c["col0"] + c["ncols"]) // k) for c in copies])
+                assert all(c["col0"] % k == 0 and c["ncols"] % k == 0 for c in copies)
+            elif len(shape) == 1:                     # vectors are fetched as [1, n]
+                ids = np.concatenate([np.arange(c["col0"], c["col0"] + c["ncols"]) for c in copies])
+            elif tn.endswith(COL_SLICED):
+                assert all(c["row0"] == 0 and c["nrows"] == shape[0] for c in copies)
+                ids = np.concatenate([np.arange(c["col0"], c["col0"] + c["ncols"]) for c in copies])
+            else:
+                cols = int(np.prod(shape[1:]))
+                assert all(c["col0"] == 0 and c["ncols"] == cols for c in copies), tn
+                ids = np.concatenate([np.arange(c["row0"], c["row0"] + c["nrows"]) for c in copies])
+            assert len(set(ids.tolist())) == len(ids), f"{tn}: an element is copied twice into rank {r}'s shard"
+            want = _expected_ids(cfg, tn.replace("model.language_model.", "model."), shape, plan)
+            if hybrid and tn.endswith("self_attn.q_proj.weight"):
+                # the loader de-interleaves the per-head [q | gate] rows into [all q | all gate]: same rows, another order
+                assert sorted(ids.tolist()) == sorted(want.tolist()), tn
+                q_rows = [h * 2 * D + d for h in plan.q_heads for d in range(D)]
+                assert ids.tolist() == q_rows + [x + D for x in q_rows], tn
+            else:
+                assert ids.tolist() == want.tolist(), (tn, r)
+            cover.setdefault(tn, []).append(ids)
+    # the ranks together: every element of a sharded tensor exactly once -- K / V heads tp / Hkv times when Hkv < tp
+    for tn, parts in cover.items():
+        allids = np.concatenate(parts)
+        n = shapes[tn][1] if (tn.endswith(COL_SLICED) and len(shapes[tn]) > 1) else shapes[tn][0]
+        counts = np.bincount(allids, minlength=n)
+        replicated = not any(tn.endswith(s) for s in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weight", "gate_proj.weight",
+                                                      "up_proj.weight", "down_proj.weight", "lm_head.weight", "in_proj_qkv.weight",
+                                                      "in_proj_z.weight", "in_proj_b.weight", "in_proj_a.weight", "out_proj.weight",
+                                                      "conv1d.weight", "A_log", "dt_bias"))
+        if replicated:
+            assert (counts == world).all(), tn
+        elif tn.endswith(("k_proj.weight", "v_proj.weight")):
+            assert (counts == max(1, world // t["num_key_value_heads"])).all(), tn
+        elif tn == "lm_head.weight":
+            assert (counts[: t["vocab_size"]] == 1).all(), tn
+        else:
+            assert (counts == 1).all(), tn
