@@ -167,7 +167,7 @@ def main():
         # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch
         try:
             if args.model == "qwen3-8b" and not args.isq and n == 1:
-                for src in ("r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json"):
+                for src in ("r03_pmc_traffic_decode.json", "r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json"):
                     path = os.path.join(ROOT, "profiles", src)
                     if not os.path.exists(path):
                         continue
@@ -175,7 +175,7 @@ def main():
                     for r in pm["kernels"]:
                         if pmc_key in r["kernel"]:
                             roof["traffic"] = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
-                            roof["traffic_source"] = "profiles/" + src
+                            roof["traffic_source"] = "profiles/" + src + " -- " + pm.get("source", "")       # (names the tree it was measured on)
                     if roof["traffic"] is not None:
                         break
         except Exception:
@@ -279,7 +279,8 @@ def main():
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
                                    f"{wdt} weights + {args.kv} paged KV, f32 activations",
                        "parallelism": f"tp{n}", "rccl_ranks": ranks, "graph": not args.no_graph,
-                       "decode_path": "persistent decode kernel (cm_opts.engine)" if m.engine_active() else "per-projection launches"},
+                       "decode_path": {0: "per-projection launches", 1: "persistent kernel per layer + attention launches",
+                                       2: "persistent decode kernel: one launch per token (cm_opts.engine)"}[m.engine_active()]},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "parity": parity, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
