@@ -23,7 +23,7 @@ EXPORTS = [
     "cm_kv_bytes", "cm_weight_bytes", "cm_decode_bytes_per_token", "cm_tp_ranks", "cm_engine_active", "cm_forward_step",
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
-    "cm_decode_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_embed_tokens", "cm_forward_embeds", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
+    "cm_decode_batch", "cm_prefill_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_embed_tokens", "cm_forward_embeds", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
     "cm_gguf_config", "cm_checkpoint_inspect", "cm_tp_shard_plan", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv", "cm_debug_set",
 ]
 
@@ -62,7 +62,8 @@ class CmSampleParams(C.Structure):
 
 
 class CmEngineOpts(C.Structure):
-    _fields_ = [("max_running", C.c_uint32), ("repeat_last_n", C.c_uint32), ("seed", C.c_uint64), ("reserved", C.c_uint32 * 8)]
+    _fields_ = [("max_running", C.c_uint32), ("repeat_last_n", C.c_uint32), ("seed", C.c_uint64), ("batch_prefill", C.c_int32),
+                ("reserved", C.c_uint32 * 7)]
 
 
 class CmRequest(C.Structure):
@@ -143,6 +144,7 @@ def load():
     lib.cm_seq_truncate.argtypes = [vp, C.c_int32, C.c_size_t]
     lib.cm_seq_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, u32p]
     lib.cm_decode_batch.argtypes = [vp, P(C.c_int32), u32p, C.c_size_t, f32p, u32p]
+    lib.cm_prefill_batch.argtypes = [vp, P(C.c_int32), P(P(C.c_uint32)), P(C.c_size_t), C.c_size_t, f32p, u32p]
     lib.cm_image_smart_resize.argtypes = [P(CmPreprocConfig), C.c_uint32, C.c_uint32, u32p, u32p]
     lib.cm_image_preprocess.argtypes = [P(CmPreprocConfig), C.c_char_p, C.c_uint32, C.c_uint32, f32p, C.c_size_t, u32p, P(C.c_size_t)]
     lib.cm_preprocess_last_error.restype = C.c_char_p

@@ -269,6 +269,20 @@ class Model:
             out.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, C.byref(t)))
         return out, int(t.value)
 
+    def prefill_batch(self, seqs: Sequence[int], prompts: Sequence[Sequence[int]], want_logits=True):
+        """cm_prefill_batch: whole prompts of several sequences in one pass -> ([N, V] logits of the last positions or None, greedy ids [N])."""
+        n = len(seqs)
+        sa = np.ascontiguousarray(np.asarray(seqs, dtype=np.int32))
+        arrs = [np.ascontiguousarray(np.asarray(p, dtype=np.uint32)) for p in prompts]
+        ptrs = (C.POINTER(C.c_uint32) * n)(*[a.ctypes.data_as(C.POINTER(C.c_uint32)) for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        out = np.empty((n, self.vocab_size), dtype=np.float32) if want_logits else None
+        g = np.empty(n, dtype=np.uint32)
+        self._check(self._lib.cm_prefill_batch(
+            self._h, sa.ctypes.data_as(C.POINTER(C.c_int32)), ptrs, lens, n,
+            out.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, g.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out, g
+
     def step_batch_decode(self, seqs: Sequence[int], tokens: Sequence[int], want_logits=True):
         """step_batch_decode (backend.rs:107-121): returns ([N,1,V] logits or None, greedy ids [N])."""
         n = len(seqs)

@@ -231,6 +231,19 @@ int cm_seq_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size
     return guard(h, [&] { h->m.forward(seq, ids, n, start_pos, logits_out, greedy_out); });
 }
 
+int cm_prefill_batch(cm_model* h, const int32_t* seqs, const uint32_t* const* ids, const size_t* lens, size_t n, float* logits_out,
+                     uint32_t* greedy_out) {
+    if (!h) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (!seqs || !ids || !lens) throw cm::CmError(CM_ERR_INVALID, "null argument");
+        h->m.prefill_multi(seqs, ids, lens, n, greedy_out);
+        if (logits_out) {
+            h->m.ensure_batch_buffers();
+            CM_HIP(hipMemcpy(logits_out, h->m.logitsb, n * (size_t)h->m.cfg.V * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    });
+}
+
 int cm_decode_batch(cm_model* h, const int32_t* seqs, const uint32_t* last_tokens, size_t n, float* logits_out,
                     uint32_t* greedy_out) {
     if (!h) return CM_ERR_INVALID;

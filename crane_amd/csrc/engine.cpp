@@ -141,6 +141,58 @@ struct Engine {
         }
     }
 
+    // Several waiting prompts in ONE pass over the weights (Model::prefill_multi).  The reference prefills one whole prompt per
+    // step while running < max_running (scheduler.rs:67-98) -- back to back when several are waiting; batching them changes no
+    // token and no event order, only the cost: a 128-token prompt alone occupies one m-tile of every GEMM and costs what 1024
+    // rows cost.  Returns false when the pass is not applicable (the caller falls back to step_prefill of the first prompt).
+    bool step_prefill_many(size_t cap) {
+        if (!opts.batch_prefill || m->kvq() || m->no_prefill || (m->quantized && !m->quant_prefill) || (m->rccl && m->cfg.V % m->tp != 0)) return false;
+        m->ensure_prefill_buffers();
+        if (!m->prefill_ok) return false;
+        std::vector<uint64_t> ids;
+        size_t total = 0, pages = 0;
+        for (uint64_t id : waiting) {
+            if (running.size() + ids.size() >= cap || ids.size() >= (size_t)Model::MAXB) break;
+            const Request& r = req(id);
+            if (total + r.tokens.size() > (size_t)m->chunk) break;                    // FIFO: never skip ahead of a long prompt
+            const size_t need = pages_for(r.tokens.size() + 1);
+            if (pages + need > m->free_pages.size()) break;                           // no eviction for the batched pass
+            total += r.tokens.size(); pages += need;
+            ids.push_back(id);
+        }
+        if (ids.size() < 2) return false;
+        for (size_t k = 0; k < ids.size(); ++k) waiting.pop_front();
+        std::vector<int32_t> sq(ids.size());
+        std::vector<const uint32_t*> ptr(ids.size());
+        std::vector<size_t> len(ids.size());
+        std::vector<uint32_t> greedy(ids.size());
+        try {
+            for (size_t k = 0; k < ids.size(); ++k) {
+                Request& r = req(ids[k]);
+                if (r.seq < 0) r.seq = m->seq_alloc();
+                sq[k] = r.seq; ptr[k] = r.tokens.data(); len[k] = r.tokens.size();
+            }
+            m->prefill_multi(sq.data(), ptr.data(), len.data(), ids.size(), greedy.data());
+        } catch (const CmError& e) {
+            for (uint64_t id : ids) if (reqs.count(id)) fail(id, e.code, e.what());
+            return true;
+        }
+        for (size_t k = 0; k < ids.size(); ++k) {
+            Request& r = req(ids[k]);
+            stats.prefill_steps++;
+            try {
+                const uint32_t t = pick(r, m->logitsb + k * (size_t)m->cfg.V, greedy[k]);
+                r.tokens.push_back(t);
+                emit_token(r, t);
+                if (r.should_stop()) finish(ids[k], r.last_is_eos() ? CM_FINISH_STOP : CM_FINISH_LENGTH);
+                else running.push_back(ids[k]);
+            } catch (const CmError& e) {
+                fail(ids[k], e.code, e.what());
+            }
+        }
+        return true;
+    }
+
     void step_decode(std::vector<uint64_t> batch) {
         // every sequence appends one token: make sure the pages exist, evicting if the pool is short
         size_t reserved = 0;
@@ -218,6 +270,7 @@ struct Engine {
         // Scheduler::schedule (scheduler.rs:67-98)
         const size_t cap = effective_max_running >= 0 ? (size_t)effective_max_running : max_running;
         if (running.size() < cap && !waiting.empty()) {
+            if (waiting.size() >= 2 && cap - running.size() >= 2 && step_prefill_many(cap)) return;
             const uint64_t id = waiting.front(); waiting.pop_front();
             step_prefill(id);
         } else if (!running.empty()) {
@@ -244,6 +297,7 @@ int cm_engine_create(cm_model* m, const cm_engine_opts* opts, cm_engine** out) {
     h->e.m = &cm::model_of(m);
     if (opts) h->e.opts = *opts;
     if (h->e.opts.repeat_last_n == 0) h->e.opts.repeat_last_n = 64;
+    h->e.opts.batch_prefill = opts ? (opts->batch_prefill >= 0) : 1;      // 0 default (on), 1 on, -1 off -> stored as bool
     const size_t slots = h->e.m->seqs.size() > 1 ? h->e.m->seqs.size() - 1 : 1;
     h->e.max_running = h->e.opts.max_running ? std::min<size_t>(h->e.opts.max_running, slots) : slots;
     if (h->e.opts.seed == 0) h->e.opts.seed = 299792458ull;

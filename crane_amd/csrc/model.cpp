@@ -979,11 +979,200 @@ void Model::ensure_prefill_buffers() {
     CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
 }
 
-void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
+// the decoder layers over the S rows of pX.  The row-wise work (norms, every GEMM) runs once over all rows; what mixes tokens --
+// QK-norm / RoPE / KV append, the causal attention, the Gated-Delta-Net scan -- runs per SEGMENT: rows [row0, row0 + S) of one
+// sequence at positions start_pos..., on that sequence's pages and state slot.  One segment = the classic single-prompt chunk;
+// several = the prompts of several requests sharing one pass over the weights (prefill_multi).
+void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) {
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     const bool sp2 = prefill_split2;
+    for (int li = 0; li < cfg.L; ++li) {
+        const LayerW& w = layers[(size_t)li];
+        launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+        GemmArgs g{};
+        g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        if (!w.full) {
+            // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
+            g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
+            if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
+                const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
+                launch_dequant_bf16(w.q_in_proj, wq_scratch, 1, 0, s);
+                if (w.q_in_proj_z.fmt != QFMT_NONE) launch_dequant_bf16(w.q_in_proj_z, wq_scratch + (size_t)w.q_in_proj.N * H, 1, 0, s);
+                CM_HIP(hipMemcpyAsync(wq_scratch + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+                CM_HIP(hipMemsetAsync(wq_scratch + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
+                g.W = wq_scratch;
+            }
+            g.M = S; g.N = in_proj_pad; g.K = H;
+            if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+            GdnArgs ga{};
+            ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
+            ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.st = nullptr;
+            ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
+            ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
+            ga.n_seq = 1;
+            ga.pre_q = gdn_pre_q; ga.pre_k = gdn_pre_k; ga.pre_v = gdn_pre_v; ga.pre_bd = gdn_pre_bd;
+            // the conv windows are double-buffered by position parity: every launch must advance an ODD
+            // number of positions, so an even chunk is scanned as (S-1) + 1.  One scan per sequence of the pass (its own state slot).
+            for (int gi = 0; gi < nseg; ++gi) {
+                const PrefillSeg& sg = segs[gi];
+                ga.slot = sg.seq;
+                int done = 0;
+                while (done < sg.S) {
+                    const int part = ((sg.S - done) % 2 == 1) ? (sg.S - done) : (sg.S - done - 1);
+                    ga.proj = pQKV + (size_t)(sg.row0 + done) * in_proj_pad; ga.out = pGY + (size_t)(sg.row0 + done) * cfg.value_dim();
+                    ga.start_pos = sg.start_pos + done; ga.S = part;
+                    launch_gdn(ga, s);
+                    done += part;
+                }
+            }
+            launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+            g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
+            if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
+            if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+            else {
+                g.C = pY; launch_gemm(g, GEPI_STORE, s);
+                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+                launch_add_rows(pX, pY, (size_t)S * H, s);
+            }
+        } else {
+        g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
+        if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
+            for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], wq_scratch + (size_t)w.qkv_row0[i] * H, 1, 0, s);
+            g.W = wq_scratch;
+        }
+        g.M = S; g.N = qkv_rows; g.K = H;
+        if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+        // QK-norm + RoPE + KV append and the causal attention run once per sequence of the pass (its own pages and positions)
+        const bool kvq = this->kvq();
+        if (kvq && nseg != 1) throw CmError(CM_ERR_UNSUPPORTED, "multi-sequence prompt pass over quantised KV pages");
+        for (int gi = 0; gi < nseg; ++gi) {
+        const PrefillSeg& sg = segs[gi];
+        const int sp = sg.start_pos;
+        QkRopeArgs q{};
+        q.qkv = pQKV + (size_t)sg.row0 * qkv_rows; q.qnw = w.qn; q.knw = w.kn; q.cos = cos; q.sin = sin; q.block_table = sg.bt;
+        q.kpool = kpool(li); q.vpool = vpool(li); q.q_hi = pQ_hi + (size_t)sg.row0 * Hq_l * D; q.q_lo = pQ_lo + (size_t)sg.row0 * Hq_l * D;
+        q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = sp; q.eps = cfg.eps;
+        q.row_stride = qkv_rows; q.q_off = 0; q.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; q.v_off = q.k_off + Hkv_l * D;
+        q.rot_dim = cfg.rot_dim; q.pos3 = (pos3_dev && nseg == 1) ? pos3_dev + off : nullptr; q.pos3_stride = pos3_stride;
+        q.rope_delta = sg.rope_delta;      // text tokens after an image prompt rotate at pos + delta, like the decode step
+        q.sec_h = cfg.mrope_sec[1]; q.sec_w = cfg.mrope_sec[2];
+        q.scale = (float)(1.0 / std::sqrt((double)D));
+        if (kvq) {
+            // KvCache::Quant (qwen3_5/kv_cache.rs:303-325): append() returns dequantize(full cache); the attention of this
+            // chunk therefore reads an f32 shadow of the layer: old tokens dequantised from the pages, new tokens written
+            // next to their codes by the append kernel
+            q.page_bytes = page_bytes; q.kshadow = kshadow; q.vshadow = vshadow;
+            launch_kvq_dequant_prefix(kpool(li), vpool(li), sg.bt, kshadow, vshadow, sp, Hkv_l, page, D, kv_mode, page_bytes, s);
+        }
+        launch_qknorm_rope_kv(q, D, sg.S, kv_mode, s);
+        AttnPreArgs at{};
+        at.q_hi = q.q_hi; at.q_lo = q.q_lo; at.block_table = kvq ? d_ident_bt : sg.bt;
+        at.kpool = kvq ? (void*)kshadow : kpool(li); at.vpool = kvq ? (void*)vshadow : vpool(li);
+        at.out_hi = pAT_hi + (size_t)sg.row0 * Hq_l * D; at.out_lo = pAT_lo + (size_t)sg.row0 * Hq_l * D;
+        at.S = sg.S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
+        at.page = page; at.start_pos = sp; at.causal = 1;
+        at.gate = cfg.hybrid ? pQKV + (size_t)sg.row0 * qkv_rows + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
+        launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
+        }
+        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
+        if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
+        if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+        else {
+            g.C = pY; launch_gemm(g, GEPI_STORE, s);
+            rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+            launch_add_rows(pX, pY, (size_t)S * H, s);
+        }
+        }   // full-attention layer
+        launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
+        if (quantized) {
+            if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
+            else { launch_dequant_bf16(w.q_gate, wq_scratch, 2, 0, s); launch_dequant_bf16(w.q_up, wq_scratch, 2, 1, s); }
+            g.W = wq_scratch;
+        }
+        g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
+        launch_gemm(g, GEPI_SILUMUL, s);
+        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
+        if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
+        if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+        else {
+            g.C = pY; launch_gemm(g, GEPI_STORE, s);
+            rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+            launch_add_rows(pX, pY, (size_t)S * H, s);
+        }
+        // DeepStack (qwen3_vl/text.rs:262-333): the li-th feature map of the vision tower is added onto the hidden states
+        // of the visual positions after decoder layer li
+        if (li < deep_layers && splice_map_dev != nullptr)
+            launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
+    }
+}
+
+// Whole prompts of several sequences in ONE pass over the weights (the continuous-batching engine's prefill step: a prompt of
+// 128 tokens alone fills one m-tile and costs what 1024 rows cost).  Every sequence starts at position 0 (a re-prefill after
+// preemption included); together at most prefill_chunk tokens and MAXB sequences.  Per sequence the result is what forward()
+// gives: its K/V pages (and GDN state), the arg-max of its last position in greedy_out[i], its logits in logitsb[i * V].
+void Model::prefill_multi(const int32_t* sq, const uint32_t* const* ids, const size_t* lens, size_t n_items, uint32_t* greedy_out) {
+    if (n_items == 0 || n_items > (size_t)MAXB) throw CmError(CM_ERR_INVALID, "prefill_multi: 1..128 sequences");
+    if (kvq()) throw CmError(CM_ERR_UNSUPPORTED, "prefill_multi over quantised KV pages");
+    if (rccl && cfg.V % tp != 0) throw CmError(CM_ERR_UNSUPPORTED, "prefill_multi under tensor parallelism needs vocab_size divisible by tp_size");
+    ensure_prefill_buffers();
+    if (!prefill_ok || no_prefill || (quantized && !quant_prefill)) throw CmError(CM_ERR_UNSUPPORTED, "prefill_multi: the MFMA prompt pass is not available for this model / mode");
+    ensure_batch_buffers();
+    const int H = cfg.H;
+    hipStream_t s = stream;
+    size_t total = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        if (!ids[i] || lens[i] == 0) throw CmError(CM_ERR_INVALID, "empty input");
+        for (size_t c = 0; c < i; ++c) if (sq[c] == sq[i]) throw CmError(CM_ERR_INVALID, "sequence appears twice in one pass");
+        if (lens[i] > (size_t)max_seq) throw CmError(CM_ERR_RANGE, "sequence longer than max_seq_len");
+        for (size_t k = 0; k < lens[i]; ++k) if (ids[i][k] >= (uint32_t)cfg.V) throw CmError(CM_ERR_RANGE, "token id >= vocab_size");
+        (void)seq(sq[i]);
+        total += lens[i];
+    }
+    if (total > (size_t)chunk) throw CmError(CM_ERR_RANGE, "prefill_multi: more tokens than one prefill chunk");
+    CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
+    std::vector<PrefillSeg> segs(n_items);
+    int row = 0;
+    for (size_t i = 0; i < n_items; ++i) {
+        seq_truncate(sq[i], 0);                                  // self.clear_kv_cache() of a fresh prompt (also resets the GDN state)
+        ensure_pages(sq[i], (int64_t)lens[i]);
+        Seq& q = seq(sq[i]);
+        memcpy(h_ids + row, ids[i], lens[i] * sizeof(uint32_t));
+        memcpy(h_btb + i * (size_t)max_pages_per_seq, q.pages.data(), q.pages.size() * sizeof(int32_t));
+        segs[i] = PrefillSeg{row, (int)lens[i], 0, sq[i], 0, d_btb + i * (size_t)max_pages_per_seq};
+        StepState& hs = h_stb[i];
+        memset(&hs, 0, sizeof hs);
+        hs.token = ids[i][lens[i] - 1]; hs.pos = (int32_t)lens[i] - 1; hs.slot = sq[i];
+        row += (int)lens[i];
+    }
+    if (active_seq >= 0) { active_seq = -1; active_pages_uploaded = 0; }     // d_bt is not touched, but GDN slots / states moved on
+    CM_HIP(hipMemcpyAsync(d_ids, h_ids, total * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    CM_HIP(hipMemcpyAsync(d_btb, h_btb, n_items * (size_t)max_pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    CM_HIP(hipMemcpyAsync(stb, h_stb, n_items * sizeof(StepState), hipMemcpyHostToDevice, s));
+    if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_rows_q(q_embed, d_ids, pX, (int)total, H, cfg.V, s);
+    else launch_embed_rows(embed, d_ids, pX, (int)total, H, cfg.V, s);
+    prefill_layers((int)total, segs.data(), (int)n_items, 0);
+    for (size_t i = 0; i < n_items; ++i)                         // last position of every prompt -> the rows of the batched head
+        CM_HIP(hipMemcpyAsync(xb + i * (size_t)H, pX + (size_t)(segs[i].row0 + segs[i].S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    lm_head_rows((int)n_items, true);
+    CM_HIP(hipMemcpyAsync(h_stb, stb, n_items * sizeof(StepState), hipMemcpyDeviceToHost, s));
+    CM_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n_items; ++i) {
+        seq(sq[i]).len = (int64_t)lens[i];
+        if (greedy_out) greedy_out[i] = h_stb[i].next;
+    }
+    logits_gathered = false;
+}
+
+void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
+    const int H = cfg.H;
+    hipStream_t s = stream;
     for (size_t off = 0; off < n; off += (size_t)chunk) {
         const int S = (int)std::min<size_t>((size_t)chunk, n - off);
         const int sp = (int)(start_pos + off);
@@ -998,118 +1187,7 @@ void Model::prefill(const uint32_t* ids, size_t n, size_t start_pos) {
         else launch_embed_rows(embed, d_ids, pX, S, H, cfg.V, s);
         }
         if (splice_map_dev) launch_splice_rows(pX, vFeat, splice_map_dev + off, S, H, s);   // image rows over <|image_pad|>
-        for (int li = 0; li < cfg.L; ++li) {
-            const LayerW& w = layers[(size_t)li];
-            launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
-            GemmArgs g{};
-            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-            if (!w.full) {
-                // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
-                g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
-                if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
-                    const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
-                    launch_dequant_bf16(w.q_in_proj, wq_scratch, 1, 0, s);
-                    if (w.q_in_proj_z.fmt != QFMT_NONE) launch_dequant_bf16(w.q_in_proj_z, wq_scratch + (size_t)w.q_in_proj.N * H, 1, 0, s);
-                    CM_HIP(hipMemcpyAsync(wq_scratch + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-                    CM_HIP(hipMemsetAsync(wq_scratch + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
-                    g.W = wq_scratch;
-                }
-                g.M = S; g.N = in_proj_pad; g.K = H;
-                if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
-                GdnArgs ga{};
-                ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
-                ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.st = nullptr;
-                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
-                ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
-                ga.slot = active_seq; ga.n_seq = 1;
-                ga.pre_q = gdn_pre_q; ga.pre_k = gdn_pre_k; ga.pre_v = gdn_pre_v; ga.pre_bd = gdn_pre_bd;
-                // the conv windows are double-buffered by position parity: every launch must advance an ODD
-                // number of positions, so an even chunk is scanned as (S-1) + 1
-                int done = 0;
-                while (done < S) {
-                    const int part = ((S - done) % 2 == 1) ? (S - done) : (S - done - 1);
-                    ga.proj = pQKV + (size_t)done * in_proj_pad; ga.out = pGY + (size_t)done * cfg.value_dim();
-                    ga.start_pos = sp + done; ga.S = part;
-                    launch_gdn(ga, s);
-                    done += part;
-                }
-                launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
-                g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-                g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
-                if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
-                if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
-                else {
-                    g.C = pY; launch_gemm(g, GEPI_STORE, s);
-                    rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
-                    launch_add_rows(pX, pY, (size_t)S * H, s);
-                }
-            } else {
-            g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
-            if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
-                for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], wq_scratch + (size_t)w.qkv_row0[i] * H, 1, 0, s);
-                g.W = wq_scratch;
-            }
-            g.M = S; g.N = qkv_rows; g.K = H;
-            if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
-            QkRopeArgs q{};
-            q.qkv = pQKV; q.qnw = w.qn; q.knw = w.kn; q.cos = cos; q.sin = sin; q.block_table = d_bt;
-            q.kpool = kpool(li); q.vpool = vpool(li); q.q_hi = pQ_hi; q.q_lo = pQ_lo;
-            q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = sp; q.eps = cfg.eps;
-            q.row_stride = qkv_rows; q.q_off = 0; q.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; q.v_off = q.k_off + Hkv_l * D;
-            q.rot_dim = cfg.rot_dim; q.pos3 = pos3_dev ? pos3_dev + off : nullptr; q.pos3_stride = pos3_stride;
-            q.rope_delta = seqs[(size_t)active_seq].rope_delta;      // text tokens after an image prompt rotate at pos + delta, like the decode step
-            q.sec_h = cfg.mrope_sec[1]; q.sec_w = cfg.mrope_sec[2];
-            q.scale = (float)(1.0 / std::sqrt((double)D));
-            const bool kvq = this->kvq();
-            if (kvq) {
-                // KvCache::Quant (qwen3_5/kv_cache.rs:303-325): append() returns dequantize(full cache); the attention of this
-                // chunk therefore reads an f32 shadow of the layer: old tokens dequantised from the pages, new tokens written
-                // next to their codes by the append kernel
-                q.page_bytes = page_bytes; q.kshadow = kshadow; q.vshadow = vshadow;
-                launch_kvq_dequant_prefix(kpool(li), vpool(li), d_bt, kshadow, vshadow, sp, Hkv_l, page, D, kv_mode, page_bytes, s);
-            }
-            launch_qknorm_rope_kv(q, D, S, kv_mode, s);
-            AttnPreArgs at{};
-            at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = kvq ? d_ident_bt : d_bt;
-            at.kpool = kvq ? (void*)kshadow : kpool(li); at.vpool = kvq ? (void*)vshadow : vpool(li);
-            at.out_hi = pAT_hi; at.out_lo = pAT_lo; at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
-            at.page = page; at.start_pos = sp; at.causal = 1;
-            at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
-            launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-            g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
-            if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
-            if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
-            else {
-                g.C = pY; launch_gemm(g, GEPI_STORE, s);
-                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
-                launch_add_rows(pX, pY, (size_t)S * H, s);
-            }
-            }   // full-attention layer
-            launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-            g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
-            if (quantized) {
-                if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
-                else { launch_dequant_bf16(w.q_gate, wq_scratch, 2, 0, s); launch_dequant_bf16(w.q_up, wq_scratch, 2, 1, s); }
-                g.W = wq_scratch;
-            }
-            g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
-            launch_gemm(g, GEPI_SILUMUL, s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-            g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
-            if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
-            if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
-            else {
-                g.C = pY; launch_gemm(g, GEPI_STORE, s);
-                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
-                launch_add_rows(pX, pY, (size_t)S * H, s);
-            }
-            // DeepStack (qwen3_vl/text.rs:262-333): the li-th feature map of the vision tower is added onto the hidden states
-            // of the visual positions after decoder layer li
-            if (li < deep_layers && splice_map_dev != nullptr)
-                launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
-        }
+        { const PrefillSeg one{0, S, sp, active_seq, seqs[(size_t)active_seq].rope_delta, d_bt}; prefill_layers(S, &one, 1, off); }
         if (off + (size_t)S >= n) {     // last chunk: logits of the LAST position only (modeling.rs:1032-1035)
             CM_HIP(hipMemcpyAsync(x, pX + (size_t)(S - 1) * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
             launch_set_state(st, ids ? ids[n - 1] : 0u, (int32_t)(start_pos + n - 1), active_seq, seqs[(size_t)active_seq].rope_delta, s);
@@ -1155,6 +1233,58 @@ void Model::fetch_logits(float* out) {
     CM_HIP(hipMemcpyAsync(h_logits, logits, (size_t)V_l * tp * sizeof(float), hipMemcpyDeviceToHost, stream));
     CM_HIP(hipStreamSynchronize(stream));
     memcpy(out, h_logits, (size_t)cfg.V * sizeof(float));
+}
+
+// final norm + lm_head + arg-max over the nb rows of xb (one sequence per row): logits into logitsb[b * V], the winners into
+// stb[b].next.  Shared by the batched decode step and the multi-prompt prefill.
+void Model::lm_head_rows(int nb, bool want_rows) {
+    const int H = cfg.H;
+    hipStream_t s = stream;
+    // lm_head over the vocabulary shard [v0, v0 + V_l) of this rank (TP = 1: the whole table): logits land in their
+    // columns of the [nb][V] rows, the per-block maxima in this rank's [MAXB][lm_gridb] slab of pmaxb / pidxb
+    const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
+    const size_t slab = (size_t)MAXB * lm_gridb;
+    int lmg = 0;
+    if (quantized && q_lm_head.fmt != QFMT_NONE) {
+        const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
+        if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
+        const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;
+        lmg = gemvqb_grid(q_lm_head.fmt, v_eff, H, std::min(stepq, nb), num_cu);
+        for (int m0 = 0; m0 < nb; m0 += stepq) {
+            GemvQBArgs q{};
+            q.w = q_lm_head.rows(0, v_eff); q.x = xb + (size_t)m0 * H; q.nw = norm;
+            q.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l; q.res = q.y;
+            q.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lmg; q.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lmg;
+            q.idx_base = v0; q.n_seq = std::min(stepq, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
+            if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
+        }
+    } else {
+        // (more than GEMV_MAXB rows -- GEMM path, one rank -- take the matrix-core GEMV in two passes, each with its own
+        // grid and arg-max reduction)
+        for (int m0 = 0; m0 < nb; m0 += GEMV_MAXB) {
+            const int nc = std::min((int)GEMV_MAXB, nb - m0);
+            GemvBArgs g{};
+            g.W = lm_head; g.x = xb + (size_t)m0 * H; g.nw = norm; g.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l;
+            g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nc;
+            g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lm_gridb; g.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lm_gridb;
+            g.idx_base = v0;
+            const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nc, H);
+            lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu, nc) : gemvb_grid(v_eff, H, num_cu);
+            if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+            else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
+            if (nb > GEMV_MAXB) launch_argmax_final(g.pmax, g.pidx, lmg, stb + m0, ring, RING - 1, 0, nc, s);
+        }
+    }
+    if (rccl && !rccl->fake) {
+        rccl->all_gather(pmaxb + (size_t)rank * slab, pmaxb, slab * sizeof(float), s);
+        rccl->all_gather(pidxb + (size_t)rank * slab, pidxb, slab * sizeof(int), s);
+        launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s, tp, slab);
+        if (want_rows)         // full rows only when somebody reads them (host copy / device sampler)
+            for (int b = 0; b < nb; ++b)
+                rccl->all_gather(logitsb + (size_t)b * cfg.V + (size_t)rank * V_l, logitsb + (size_t)b * cfg.V, (size_t)V_l * sizeof(float), s);
+    } else if (nb <= GEMV_MAXB) {
+        launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1400,51 +1530,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
             rp(w.down, hbb, I_l, I_l);
         }
-        // lm_head over the vocabulary shard [v0, v0 + V_l) of this rank (TP = 1: the whole table): logits land in their
-        // columns of the [nb][V] rows, the per-block maxima in this rank's [MAXB][lm_gridb] slab of pmaxb / pidxb
-        const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
-        const size_t slab = (size_t)MAXB * lm_gridb;
-        int lmg = 0;
-        if (quantized && q_lm_head.fmt != QFMT_NONE) {
-            const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
-            if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
-            const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;
-            lmg = gemvqb_grid(q_lm_head.fmt, v_eff, H, std::min(stepq, nb), num_cu);
-            for (int m0 = 0; m0 < nb; m0 += stepq) {
-                GemvQBArgs q{};
-                q.w = q_lm_head.rows(0, v_eff); q.x = xb + (size_t)m0 * H; q.nw = norm;
-                q.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l; q.res = q.y;
-                q.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lmg; q.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lmg;
-                q.idx_base = v0; q.n_seq = std::min(stepq, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
-                if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
-            }
-        } else {
-            // (more than GEMV_MAXB rows -- GEMM path, one rank -- take the matrix-core GEMV in two passes, each with its own
-            // grid and arg-max reduction)
-            for (int m0 = 0; m0 < nb; m0 += GEMV_MAXB) {
-                const int nc = std::min((int)GEMV_MAXB, nb - m0);
-                GemvBArgs g{};
-                g.W = lm_head; g.x = xb + (size_t)m0 * H; g.nw = norm; g.y = logitsb + (size_t)m0 * cfg.V + (size_t)rank * V_l;
-                g.N = v_eff; g.K = H; g.ldw = H; g.ldx = H; g.ldy = cfg.V; g.n_seq = nc;
-                g.eps = cfg.eps; g.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lm_gridb; g.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lm_gridb;
-                g.idx_base = v0;
-                const bool lm_mfma = use_mfma_gemv && gemvm_ok(EPI_ARGMAX, nc, H);
-                lmg = lm_mfma ? gemvm_grid(v_eff, H, num_cu, nc) : gemvb_grid(v_eff, H, num_cu);
-                if (lm_mfma) launch_gemvm(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
-                else launch_gemvb(PRO_RMSNORM, EPI_ARGMAX, g, lmg, s);
-                if (nb > GEMV_MAXB) launch_argmax_final(g.pmax, g.pidx, lmg, stb + m0, ring, RING - 1, 0, nc, s);
-            }
-        }
-        if (rccl && !rccl->fake) {
-            rccl->all_gather(pmaxb + (size_t)rank * slab, pmaxb, slab * sizeof(float), s);
-            rccl->all_gather(pidxb + (size_t)rank * slab, pidxb, slab * sizeof(int), s);
-            launch_argmax_final(pmaxb, pidxb, lmg, stb, ring, RING - 1, 0, nb, s, tp, slab);
-            if (logits_out || after_group)         // full rows only when somebody reads them (host copy / device sampler)
-                for (int b = 0; b < nb; ++b)
-                    rccl->all_gather(logitsb + (size_t)b * cfg.V + (size_t)rank * V_l, logitsb + (size_t)b * cfg.V, (size_t)V_l * sizeof(float), s);
-        } else if (nb <= GEMV_MAXB) {
-            launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
-        }
+        lm_head_rows(nb, logits_out != nullptr || after_group != nullptr);
         CM_HIP(hipMemcpyAsync(h_stb, stb, (size_t)nb * sizeof(StepState), hipMemcpyDeviceToHost, s));
         if (logits_out) CM_HIP(hipMemcpyAsync(h_logitsb, logitsb, (size_t)nb * cfg.V * sizeof(float), hipMemcpyDeviceToHost, s));
         CM_HIP(hipStreamSynchronize(s));

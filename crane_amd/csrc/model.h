@@ -368,6 +368,11 @@ struct Model {
     void enqueue_quant_layer(int li);           // dense layer over GGUF / ISQ weights
     void ensure_prefill_buffers();
     void prefill(const uint32_t* ids, size_t n, size_t start_pos);   // active sequence, pages ensured
+    struct PrefillSeg { int row0, S, start_pos, seq, rope_delta; const int32_t* bt; };   // rows of ONE sequence inside a prompt pass
+    void prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off);
+    // whole prompts of several sequences (each from position 0, together <= prefill_chunk tokens) in ONE pass over the weights
+    void prefill_multi(const int32_t* sq, const uint32_t* const* ids, const size_t* lens, size_t n_items, uint32_t* greedy_out);
+    void lm_head_rows(int nb, bool want_rows);                        // xb rows -> logitsb rows, stb[b].next
     void run_decode_step(bool advance, int64_t ctx_len);   // graph replay or eager; ctx_len = tokens attended (pos + 1)
     void forward(int s, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out, uint32_t* greedy_out);
     void generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_config* g, uint32_t* out, size_t* n_out,

@@ -45,11 +45,12 @@ class Event:
 class InferenceEngine:
     """InferenceEngine::{accept_request, run-loop body} (engine/mod.rs:169-271, 525-599, 622-641)."""
 
-    def __init__(self, model, max_running: int = 0, repeat_last_n: int = 64, seed: int = 0):
+    def __init__(self, model, max_running: int = 0, repeat_last_n: int = 64, seed: int = 0, batch_prefill: bool = True):
         self._lib = _lib.load()
         self._model = model                       # keeps the model alive
         o = _lib.CmEngineOpts()
         o.max_running, o.repeat_last_n, o.seed = max_running, repeat_last_n, seed
+        o.batch_prefill = 0 if batch_prefill else -1       # several waiting prompts per pass over the weights (cm_prefill_batch)
         h = C.c_void_p()
         rc = self._lib.cm_engine_create(model._h, C.byref(o), C.byref(h))
         if rc != 0:

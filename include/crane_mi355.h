@@ -278,6 +278,16 @@ int cm_seq_forward(cm_model* m, int32_t seq, const uint32_t* ids, size_t n, size
 int cm_decode_batch(cm_model* m, const int32_t* seqs, const uint32_t* last_tokens, size_t n,
                     float* logits_out, uint32_t* greedy_out);
 
+/* Whole prompts of n sequences in ONE pass over the weights: sequence seqs[i] is cleared and prefilled with ids[i][0 .. lens[i])
+ * from position 0 (what cm_seq_forward(seq, ids, n, 0, ...) does for one), together at most prefill_chunk tokens and 128
+ * sequences.  The row-wise work (norms, every GEMM) runs once over all rows; RoPE / KV append / causal attention / the
+ * Gated-Delta-Net scan run per sequence on its own pages and state.  greedy_out[i] = arg-max of sequence i's last position;
+ * logits_out (may be NULL) = [n, vocab] f32 rows.  The continuous-batching engine's prefill step (cm_engine_opts.batch_prefill):
+ * a 128-token prompt alone occupies one m-tile of every GEMM and costs what 1024 rows cost.  Not available over int8 / int4 KV
+ * pages (CM_ERR_UNSUPPORTED). */
+int cm_prefill_batch(cm_model* m, const int32_t* seqs, const uint32_t* const* ids, const size_t* lens, size_t n,
+                     float* logits_out, uint32_t* greedy_out);
+
 /* ---- vision-language path (Qwen 3.5-VL; reference crane-core/src/models/qwen3_5/{vision,vlm}.rs) -------- */
 
 /* image placeholder token of the checkpoint (config.json image_token_id), -1 when the model has no vision tower */
@@ -348,7 +358,9 @@ typedef struct cm_engine_opts {
     uint32_t max_running;        /* Scheduler::max_running (scheduler.rs:31); 0: max_seqs - 1 */
     uint32_t repeat_last_n;      /* penalty window; 0: 64 (engine/mod.rs:588) */
     uint64_t seed;               /* base of the per-request sampling seeds (sampling.rs:480-491 uses the clock) */
-    uint32_t reserved[8];
+    int32_t  batch_prefill;      /* 0 default (on), 1 on, -1 off: several waiting prompts share one pass over the weights     */
+                                 /*   (cm_prefill_batch) instead of one prompt per step -- same tokens, same event order       */
+    uint32_t reserved[7];
 } cm_engine_opts;
 
 /* EngineRequest (engine/types.rs:11-24) */

@@ -52,10 +52,11 @@ def test_engine_greedy_matches_single_request_generate(name):
 
 
 def test_schedule_is_prefill_priority_then_batched_decode():
+    """the reference's schedule, step by step: ONE prompt per prefill step (scheduler.rs:67-98) -- batch_prefill off"""
     from crane_amd.engine import GenerationParams, InferenceEngine
     m = _model()
     try:
-        eng = InferenceEngine(m, max_running=2)
+        eng = InferenceEngine(m, max_running=2, batch_prefill=False)
         prompts = _prompts(m.vocab_size, 3)
         a, b, c = (eng.submit(p, GenerationParams.greedy(n)) for p, n in zip(prompts, [3, 5, 2]))
         ev = eng.step(); assert [(e.req_id, e.kind) for e in ev] == [(a, "token")]          # prefill a
@@ -98,7 +99,7 @@ def test_submit_rejections_and_cancel():
     from crane_amd.engine import GenerationParams, InferenceEngine
     m = _model()
     try:
-        eng = InferenceEngine(m)
+        eng = InferenceEngine(m, batch_prefill=False)          # (the step counts below are the one-prompt-per-step schedule's)
         with pytest.raises(CraneError):
             eng.submit([], GenerationParams.greedy(4))
         with pytest.raises(CraneError, match="exceeds server max_seq_len"):
@@ -188,3 +189,70 @@ def test_step_many_matches_single_steps():
         finally:
             m.close()
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3.5", "tiny-qwen3-untied"])
+def test_batched_prompt_pass_changes_no_token(name):
+    """cm_engine_opts.batch_prefill (default on): waiting prompts share ONE pass over the weights (cm_prefill_batch: GEMMs over all
+    rows, RoPE / KV append / causal attention / GDN scan per sequence).  Same tokens, same finish events as the
+    one-prompt-per-step schedule -- greedy and with the server-default sampler (per-request seeds) -- and the prompts of a step
+    arrive in queue order."""
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model(name, max_seqs=12)
+    try:
+        V = m.vocab_size
+        prompts = [[(7 * i + 3 + 11 * j) % V for i in range(2 + (5 * j) % 23)] for j in range(10)]
+        lens = [4 + (3 * j) % 7 for j in range(10)]
+        outs = []
+        for bp in (False, True):
+            m.clear_kv_cache()
+            eng = InferenceEngine(m, max_running=6, batch_prefill=bp, seed=7)
+            ids = []
+            for j, (p, n) in enumerate(zip(prompts, lens)):
+                gp = GenerationParams.greedy(n) if j % 2 == 0 else GenerationParams(max_tokens=n, temperature=0.8, top_p=0.95, top_k=40, repetition_penalty=1.05)
+                ids.append(eng.submit(p, gp))
+            first = []
+            if bp:
+                first = eng.step()                  # 6 slots: the first six prompts in one pass, in queue order
+                assert [(e.req_id, e.kind) for e in first if e.kind == "token"] == [(i, "token") for i in ids[:6]]
+            toks, done = eng.run_until_idle()
+            for e in reversed(first):               # (the events of the step taken by hand belong in front)
+                if e.kind == "token":
+                    toks.setdefault(e.req_id, []).insert(0, e.token)
+                else:
+                    done[e.req_id] = e
+            outs.append(([toks[i] for i in ids], [(done[i].finish_reason, done[i].completion_tokens) for i in ids]))
+            assert eng.stats()["prefill_steps"] == 10 and eng.stats()["free_pages"] == eng.stats()["total_pages"]
+            eng.close()
+        assert outs[0] == outs[1]
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3-untied", "tiny-qwen3.5"])
+def test_prefill_batch_equals_per_sequence_prefill(name):
+    """cm_prefill_batch against cm_seq_forward on the same prompts: last-position logits (the rows only meet other rows inside
+    GEMM tiles: summation order of a split-K at most), greedy ids, and the decode step that follows (pages / GDN state written
+    by the batched pass)."""
+    m = _model(name, max_seqs=12, max_seq_len=512)
+    try:
+        V = m.vocab_size
+        prompts = [[(13 * j + 7 * k + 3) % V for k in range(n)] for j, n in enumerate([1, 5, 64, 65, 130, 2, 33])]
+        ref = []
+        for p in prompts:
+            s_ = m.seq_alloc()
+            lg, g = m.seq_forward(s_, p, 0)
+            nxt, _ = m.seq_forward(s_, [int(g)], len(p))
+            ref.append((lg.copy(), int(g), nxt.copy()))
+            m.seq_free(s_)
+        seqs = [m.seq_alloc() for _ in prompts]
+        lg, gr = m.prefill_batch(seqs, prompts)
+        for i, p in enumerate(prompts):
+            assert float(np.abs(lg[i] - ref[i][0]).max() / np.abs(ref[i][0]).max()) < 2e-5, i
+            assert int(gr[i]) == ref[i][1]
+            assert m.seq_len(seqs[i]) == len(p)
+        lg2, _ = m.step_batch_decode(seqs, [int(t) for t in gr])
+        for i in range(len(prompts)):
+            assert float(np.abs(lg2[i, 0] - ref[i][2]).max() / np.abs(ref[i][2]).max()) < 2e-5, i
+    finally:
+        m.close()

@@ -18,7 +18,7 @@ MODES = [("greedy", GenerationParams.greedy(G)),
          ("server defaults (T 0.8, top_p 0.95, top_k 40, rep 1.05)", GenerationParams(max_tokens=G))]
 for label, params in (MODES[:1] if ISQ or os.environ.get("BENCH_GREEDY") else MODES):     # BENCH_GREEDY=1: greedy runs only
     for max_running in MAXR:
-        eng = InferenceEngine(m, max_running=max_running, seed=1)
+        eng = InferenceEngine(m, max_running=max_running, seed=1, batch_prefill=os.environ.get("BENCH_BATCH_PREFILL", "1") != "0")
         for j in range(N):
             eng.submit([(7 * i + 3 + 11 * j) % V for i in range(P)], params)
         t0 = time.perf_counter()
