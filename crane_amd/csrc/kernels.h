@@ -175,6 +175,8 @@ int gemvm_nkt(int K);
 int gemvm_grid(int N, int K, int num_cu, int n_seq = 1);
 void launch_gemvm(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
 void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s);
+// per row of logits [n_rows][ld] (n valid columns): nblk partial (max, lowest index of the max) pairs -> pmax / pidx [row][nblk]
+void launch_argmax_rows(const float* logits, int ld, int n, int idx_base, float* pmax, int* pidx, int nblk, int n_rows, hipStream_t s);
 
 // ---- decode ----
 int gemv_rows_per_group(int K);

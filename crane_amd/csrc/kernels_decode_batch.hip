@@ -265,6 +265,43 @@ static void launch_gemvb_t(const GemvBArgs& a, int grid, hipStream_t s) {
 #undef CM_GB
 }
 
+// grid (nblk, rows): block (b, r) scans its slice of row r -- strict > and the lowest index on ties, like every arg-max level
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int ld, int n, int idx_base,
+                                                          float* __restrict__ pmax, int* __restrict__ pidx) {
+    __shared__ float sm[256];
+    __shared__ int si[256];
+    const int row = blockIdx.y, nblk = gridDim.x;
+    const int per = ((n + nblk - 1) / nblk + 3) & ~3;                    // columns per block, a multiple of 4 (rows are 16-byte aligned)
+    const int c0 = blockIdx.x * per, c1 = min(n, c0 + per);
+    const float* r = logits + (size_t)row * ld;
+    float b = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int c = c0 + threadIdx.x * 4; c < c1; c += 1024) {
+        if (c + 4 <= c1) {
+            const f32x4 v = *(const f32x4*)(r + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (v[e] > b) { b = v[e]; bi = c + e; }
+        } else {
+            for (int e = 0; c + e < c1; ++e) if (r[c + e] > b) { b = r[c + e]; bi = c + e; }
+        }
+    }
+    sm[threadIdx.x] = b; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float v = sm[threadIdx.x + s]; const int ix = si[threadIdx.x + s];
+            if (v > sm[threadIdx.x] || (v == sm[threadIdx.x] && ix < si[threadIdx.x])) { sm[threadIdx.x] = v; si[threadIdx.x] = ix; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pmax[(size_t)row * nblk + blockIdx.x] = sm[0];
+        pidx[(size_t)row * nblk + blockIdx.x] = si[0] == 0x7FFFFFFF ? 0x7FFFFFFF : idx_base + si[0];
+    }
+}
+void launch_argmax_rows(const float* logits, int ld, int n, int idx_base, float* pmax, int* pidx, int nblk, int n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(nblk, n_rows), dim3(256), 0, s, logits, ld, n, idx_base, pmax, pidx);
+}
+
 void launch_gemvb(int pro, int epi, const GemvBArgs& a, int grid, hipStream_t s) {
     if (pro == PRO_ATTNCOMB) {
         if (epi == EPI_STORE) launch_gemvb_t<PRO_ATTNCOMB, EPI_STORE>(a, grid, s);

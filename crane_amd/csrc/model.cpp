@@ -248,6 +248,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     no_prefill = getenv("CM_NO_PREFILL") != nullptr;
     if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
     if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, std::min((int)GEMV_MAXB, atoi(e)));
+    if (const char* e = getenv("CM_LM_HEAD_GEMM_MIN")) lm_head_gemm_min = std::max(0, atoi(e));
     if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)GEMV_MAXB, atoi(e) / 8 * 8));
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
@@ -1258,6 +1259,20 @@ void Model::lm_head_rows(int nb, bool want_rows) {
             q.idx_base = v0; q.n_seq = std::min(stepq, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
             if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
         }
+    } else if (lm_head_gemm_min > 0 && nb >= lm_head_gemm_min && pXN_hi != nullptr && prefill_ok && nb <= chunk && v_eff % 128 == 0 && H % 32 == 0) {
+        // Large groups: the head as ONE MFMA GEMM over the rows of the group (final RMSNorm rows as bf16 hi + lo, like the
+        // projections of the step) + a row arg-max over the logits it wrote.  The matrix-core GEMV is issue-bound from ~17 rows
+        // on: 1.25 ms per 64-row pass over the 1.24 GB table at Qwen3-8B -- two passes for 128 sequences were 2.5 ms of a 14 ms
+        // round; the GEMM streams the table once.
+        launch_rmsnorm_rows(xb, norm, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+        GemmArgs g{};
+        g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = 0;
+        g.A_hi = pXN_hi; g.A_lo = pXN_lo; g.W = lm_head; g.C = logitsb + (size_t)rank * V_l; g.ldc = cfg.V; g.M = nb; g.N = v_eff; g.K = H;
+        if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+        lmg = std::min(lm_gridb, 64);
+        launch_argmax_rows(logitsb + (size_t)rank * V_l, cfg.V, v_eff, v0, pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, nb, s);
+        if (nb > GEMV_MAXB && !(rccl && !rccl->fake))
+            launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
     } else {
         // (more than GEMV_MAXB rows -- GEMM path, one rank -- take the matrix-core GEMV in two passes, each with its own
         // grid and arg-max reduction)

@@ -102,6 +102,32 @@ def test_prefill_1024_and_batched_step_qwen3_8b_geometry(oracle8b):
         m.close()
 
 
+@pytest.mark.parametrize("nseq", [40, 80, 128])
+def test_large_decode_groups_equal_the_sequence_stepped_alone(nseq):
+    """Decode groups of more than 32 sequences at the 8B widths: the projections run as MFMA GEMMs over the group's rows (from 65
+    rows on the LDS-DMA kernel with 128-row tiles, kernels_gemm256.hip) and the 151 936-row lm_head as ONE GEMM + row arg-max
+    (lm_head_rows) instead of per-8-row GEMV passes.  Every row against the same sequence stepped alone from a fork; the greedy
+    ids of the batched step are the arg-max of the logits it returns."""
+    cfg = configs.get_config("qwen3-8b-2l")
+    V = cfg["vocab_size"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2 * nseq + 2)
+    try:
+        seqs, twins, lens = [], [], []
+        for i in range(nseq):
+            n = 2 + (5 * i) % 23
+            s_ = m.seq_alloc()
+            m.seq_forward(s_, [(13 * i + 7 * k + 3) % V for k in range(n)], 0, want_logits=False)
+            seqs.append(s_); twins.append(m.seq_fork(s_)); lens.append(n)
+        toks = [(5 + 3 * i) % V for i in range(nseq)]
+        lg, greedy = m.step_batch_decode(seqs, toks)
+        for i in range(nseq):
+            ref, _ = m.seq_forward(twins[i], [toks[i]], lens[i])
+            assert rel(lg[i, 0], ref.reshape(-1)) < 1e-4, (i, rel(lg[i, 0], ref.reshape(-1)))
+            assert int(greedy[i]) == int(lg[i, 0].argmax())
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("split", [0, 1])
 def test_wide_gemm_kernel_is_bit_equal_to_the_128_row_kernel(split):
     """The 256-row LDS-DMA GEMM (kernels_gemm256.hip: global_load_lds tiles, source-side bank swizzle, three LDS stages behind a

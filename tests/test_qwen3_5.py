@@ -304,11 +304,11 @@ def test_hip_qwen38_27b_geometry_against_the_hf_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nseq", [9, 17, 64])
+@pytest.mark.parametrize("nseq", [9, 17, 64, 96])
 def test_batched_decode_at_hidden_5120(nseq):
     """K = H = 5120 > 4096: the SiLU*mul and arg-max projections have no matrix-core GEMV form (gemvm_ok), so groups of more than
     8 sequences reach the VALU batched GEMV, which keeps 8 rows in LDS -- it must run in passes of 8 (9 sequences: gate||up
-    and lm_head; 17 / 64: lm_head behind the GEMM projections).  Every row of the batched step against the same sequence
+    and lm_head; 17 / 64: lm_head behind the GEMM projections; 96: the 128-row LDS-DMA GEMM tiles and the lm_head GEMM).  Every row of the batched step against the same sequence
     stepped alone (a fork taken before the step), Qwen3.8-27B layer geometry."""
     from crane_amd.backend import Model
     cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
