@@ -283,6 +283,15 @@ def main():
                                        2: "persistent decode kernel: one launch per token (cm_opts.engine)"}[m.engine_active()]},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "parity": parity, "cpu_baseline": cpu,
         }
+        if n > 1:
+            # the exchange steps of one token under TP: one f32 [H] all-reduce behind each row-parallel projection
+            # (o_proj / GDN out_proj, down_proj), one all-gather of the ranks' (max, index) arg-max partials behind lm_head
+            L, H = cfg["num_hidden_layers"], cfg["hidden_size"]
+            line["collectives"] = {"library": "RCCL", "all_reduce_per_token": 2 * L, "bytes_per_all_reduce": 4 * H,
+                                   "all_reduce_bytes_per_token": 8 * L * H, "all_gather_per_token": 1,
+                                   "bytes_per_all_gather": 8 * n, "captured_in_hipgraph": not args.no_graph,
+                                   "measured": "per-rank roofline_step above; no multi-GPU box was available to the build, "
+                                               "the first real > 1-rank run is the driver's"}
         print(json.dumps(line), flush=True)
     m.close()
     if dist is not None:

@@ -180,7 +180,7 @@ void launch_argmax_rows(const float* logits, int ld, int n, int idx_base, float*
 
 // ---- decode ----
 int gemv_rows_per_group(int K);
-int gemv_grid(int N, int K, int num_cu);
+int gemv_grid(int N, int K, int num_cu, bool allow_nw5 = true);      // < 0: -blocks of five-wave workgroups (launch_gemv decodes it)
 void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s);
 void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H, int V, int n_seq, hipStream_t s);
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s);

@@ -51,9 +51,12 @@ __global__ void set_state_kernel(StepState* st, uint32_t token, int32_t pos, int
 // wave-instruction, non-temporal.  x lives in LDS as f32, permuted so that the two
 // ds_read_b128 a lane needs per chunk are conflict-free (lane-linear 16-B slots).
 // =====================================================================================
-template <int PRO, int EPI, int R, int U, bool PIPE, bool KGUARD>
-__global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [Kpad] + [8] scratch
+// NW = waves per workgroup: 4, or 5 where that makes the row groups divide evenly over the CUs (Qwen3.8-27B: 5120 rows = 2560
+// two-row groups = 10 per CU; with 4-wave blocks the 640 blocks of down_proj -- 70 KB of x each, two per CU -- ran in 1.25 rounds).
+template <int PRO, int EPI, int R, int U, bool PIPE, bool KGUARD, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? (PIPE ? 3 : 4) : 2) void gemv_bf16_kernel(GemvArgs a) {
+    constexpr int NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [Kpad] + [16] scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, N = a.N;
     const int nch = (K + 511) >> 9;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
     //      through two register buffers so HBM loads stay in flight across the x staging,
     //      the barrier, the FMAs and the reductions.
     const int G = (N + R - 1) / R;
-    const int gw = blockIdx.x * 4 + wave, TW = gridDim.x * 4;
+    const int gw = blockIdx.x * NW + wave, TW = gridDim.x * NW;
     const int nbpg = nch / U;
     const int my_groups = (gw < G) ? (G - gw + TW - 1) / TW : 0;
     const int NB = my_groups * nbpg;
@@ -127,24 +130,24 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
     };
     const int n4 = K >> 2;                       // K % 8 == 0
     int k4 = tid;
-    for (; k4 + 768 < n4; k4 += 1024) {          // 4 independent loads in flight per thread
+    for (; k4 + 3 * NT < n4; k4 += 4 * NT) {     // 4 independent loads in flight per thread
         f32x4 v[4]; f32x4 w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = xload(k4 + i * 256);
-            if (PRO == PRO_RMSNORM) w[i] = *(const f32x4*)(a.nw + ((k4 + i * 256) << 2));
+            v[i] = xload(k4 + i * NT);
+            if (PRO == PRO_RMSNORM) w[i] = *(const f32x4*)(a.nw + ((k4 + i * NT) << 2));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stage_one(k4 + i * 256, v[i], w[i]);
+        for (int i = 0; i < 4; ++i) stage_one(k4 + i * NT, v[i], w[i]);
     }
-    for (; k4 < n4; k4 += 256) {
+    for (; k4 < n4; k4 += NT) {
         f32x4 v = xload(k4);
         f32x4 w = {0.f, 0.f, 0.f, 0.f};
         if (PRO == PRO_RMSNORM) w = *(const f32x4*)(a.nw + (k4 << 2));
         stage_one(k4, v, w);
     }
     if (KGUARD) {                                 // zero the K..Kpad tail
-        for (int z = n4 + tid; z < (Kpad >> 2); z += 256) {
+        for (int z = n4 + tid; z < (Kpad >> 2); z += NT) {
             const int k = z << 2, c = k >> 9, j = k & 511;
             ((f32x4*)xs)[c * 128 + ((j >> 2) & 1) * 64 + (j >> 3)] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
     __syncthreads();
     if (PRO == PRO_RMSNORM) {
         float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (NW > 4) { for (int w2 = 4; w2 < NW; ++w2) tot += red[w2]; }
         scale = 1.0f / sqrtf(tot / (float)K + a.eps);
     }
 
@@ -246,12 +250,12 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void gemv_bf16_kernel(GemvArgs a
     }
     if (EPI == EPI_ARGMAX) {
         __syncthreads();
-        int* redi = (int*)(red + 4);
+        int* redi = (int*)(red + 8);
         if (lane == 0) { red[wave] = best; redi[wave] = besti; }
         __syncthreads();
         if (tid == 0) {
             float bb = red[0]; int bbi = redi[0];
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NW; ++w)
                 if (red[w] > bb || (red[w] == bb && redi[w] < bbi)) { bb = red[w]; bbi = redi[w]; }
             a.pmax[blockIdx.x] = bb; a.pidx[blockIdx.x] = bbi;
         }
@@ -323,8 +327,12 @@ template <int PRO, int EPI>
 static void launch_gemv_t(const GemvArgs& a, int grid, hipStream_t s) {
     const int nch = (a.K + 511) / 512;
     const size_t lds = (size_t)nch * 512 * 4 + 64;
-    const dim3 g(grid), b(256);
+    const dim3 g(grid < 0 ? -grid : grid), b(256);
     const GemvCfg c = gemv_cfg(a.K);
+    if (grid < 0) {            // five-wave workgroups (gemv_grid's encoding): |grid| blocks of 320 threads, two per CU
+        if (c.R == 2 && c.U == 2 && c.P == 1) { hipLaunchKernelGGL((gemv_bf16_kernel<PRO, EPI, 2, 2, true, false, 5>), dim3(-grid), dim3(320), lds, s, a); return; }
+        if (c.R == 2 && c.U == 4 && c.P == 0) { hipLaunchKernelGGL((gemv_bf16_kernel<PRO, EPI, 2, 4, false, false, 5>), dim3(-grid), dim3(320), lds, s, a); return; }
+    }
 #define CM_GEMV_CASE(RR, UU, PP) \
     if (c.R == RR && c.U == UU && c.P == PP) { hipLaunchKernelGGL((gemv_bf16_kernel<PRO, EPI, RR, UU, PP != 0, false>), g, b, lds, s, a); return; }
     if (a.K % 512 != 0) { hipLaunchKernelGGL((gemv_bf16_kernel<PRO, EPI, 2, 1, false, true>), g, b, lds, s, a); return; }
@@ -339,10 +347,18 @@ static void launch_gemv_t(const GemvArgs& a, int grid, hipStream_t s) {
 
 int gemv_rows_per_group(int K) { return gemv_cfg(K).R; }
 
-int gemv_grid(int N, int K, int num_cu) {
+int gemv_grid(int N, int K, int num_cu, bool allow_nw5) {
     // one wave per row group until the chip is full, then grid-stride
     const GemvCfg c = gemv_cfg(K);
     const int groups = (N + c.R - 1) / c.R;
+    // five-wave workgroups, returned as a NEGATIVE block count: when the groups are exactly 5 or 10 per CU (one wave each, no
+    // grid stride, every CU the same share) and the four-wave grid would not be co-resident or even
+    static int nw5 = -1;
+    if (nw5 < 0) nw5 = getenv("CM_GEMV_NW5") ? atoi(getenv("CM_GEMV_NW5")) : 1;
+    if (nw5 && allow_nw5 && K % 512 == 0 && ((c.R == 2 && c.U == 2 && c.P == 1) || (c.R == 2 && c.U == 4 && c.P == 0)) && N % c.R == 0 &&
+        groups % 5 == 0 && (groups / 5 == num_cu || groups / 5 == 2 * num_cu) &&
+        (size_t)(groups / 5 / num_cu) * ((size_t)((K + 511) / 512) * 2048 + 64) <= 160 * 1024 - 1024)
+        return -(groups / 5);
     int blocks = (groups + 3) / 4;
     static int per_cu = -1;
     if (per_cu < 0) { per_cu = 0; if (const char* e = getenv("CM_GEMV_BLOCKS_PER_CU")) per_cu = atoi(e); }

@@ -300,7 +300,7 @@ void Model::alloc_runtime() {
     part_o = dalloc<float>((size_t)Hq_l * std::max(nsplit, nsplit_mfma) * D);
     part_ml = dalloc<float>((size_t)Hq_l * std::max(nsplit, nsplit_mfma) * 2);
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
-    lm_grid = (quantized && q_lm_head.fmt != QFMT_NONE) ? gemvq_grid(v_eff, num_cu, q_lm_head.fmt) : gemv_grid(v_eff, H, num_cu);
+    lm_grid = (quantized && q_lm_head.fmt != QFMT_NONE) ? gemvq_grid(v_eff, num_cu, q_lm_head.fmt) : gemv_grid(v_eff, H, num_cu, false);
     pmax = dalloc<float>((size_t)lm_grid * tp);
     pidx = dalloc<int>((size_t)lm_grid * tp);
     st = (StepState*)dalloc<int>(sizeof(StepState) / sizeof(int));
