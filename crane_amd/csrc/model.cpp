@@ -937,7 +937,10 @@ void Model::ensure_prefill_buffers() {
     if (pX) return;
     const int H = cfg.H, D = cfg.D;
     chunk = opts.prefill_chunk ? (int)opts.prefill_chunk : 2048;      // PREFILL_CHUNK_SIZE engine/mod.rs:65
-    if (chunk > max_seq) chunk = max_seq;
+    // one sequence never has more than max_seq rows in a pass, but the prompts of several sequences share one (prefill_multi):
+    // the row capacity is bounded by what all slots together can hold, not by one sequence
+    const long all_rows = (long)max_seq * (long)std::max<size_t>(1, seqs.size());
+    if ((long)chunk > all_rows) chunk = (int)all_rows;
     if (chunk < 1) chunk = 1;
     chunk_pad = (chunk + 127) / 128 * 128;
     prefill_split2 = opts.prefill_split != 1;

@@ -17,10 +17,9 @@ print(json.dumps(out))
 ''' % ROOT
 cfgs = sys.argv[1].split(";") if len(sys.argv) > 1 else [None, "4,2,1", "4,2,0", "8,2,0", "8,2,1", "8,1,0"]
 for cfg in cfgs:
-    for bpc in (0, 2):
+    for bpc in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 2)):
         env = dict(os.environ)
         if cfg and cfg != "-": env["CM_GEMV_CFG"] = cfg
-        elif bpc: continue
         if bpc: env["CM_GEMV_BLOCKS_PER_CU"] = str(bpc)
         try:
             r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
