@@ -254,6 +254,8 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN")) attn_mfma_min = atoll(e);
+    if (const char* e = getenv("CM_ATTN_BATCH_NS_MIN")) attn_batch_ns_min = std::max(1, atoi(e));
+    if (const char* e = getenv("CM_ATTN_MFMA_MIN_BATCH")) attn_mfma_min_batch = atoll(e);
     if (const char* e = getenv("CM_ATTN_MFMA_WIDE_MIN")) attn_mfma_wide_min = atoll(e);
     nsplit_mfma = std::max(nsplit, std::min(64, 2 * num_cu / std::max(1, Hkv_l)));
     if (const char* e = getenv("CM_ATTN_MFMA_NSPLIT")) nsplit_mfma = std::max(1, std::min(64, atoi(e)));
@@ -1515,12 +1517,17 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.dshift = D == 128 ? 7 : 8;
                     launch_gemvb(PRO_ATTNCOMB, EPI_RESADD, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else {
-                const bool mf = attn_mfma_min > 0 && longest >= attn_mfma_min && kv_mode != KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
+                // a group whose (kv head, sequence) pairs alone fill the chip twice takes ONE token split per sequence and the
+                // matrix-core kernel from 64 tokens on (the VALU kernel's 16-lane rows pay per token, not per tile): engine at
+                // max_running 128, contexts 128-256: 9567 -> 10264 tok/s
+                const bool full_b = Hkv_l * nb >= 2 * num_cu;
+                const int64_t mf_min = full_b && attn_mfma_min > 0 ? std::min<int64_t>(attn_mfma_min, attn_mfma_min_batch) : attn_mfma_min;
+                const bool mf = mf_min > 0 && longest >= mf_min && kv_mode != KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
                 if (mf) {
                     // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
-                    const int ns_b = std::max(4, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
+                    const int ns_b = std::max(attn_batch_ns_min, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : std::max(4, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : std::max(attn_batch_ns_min, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols);
                 else if (gemm_b) {
                     launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);

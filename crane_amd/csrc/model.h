@@ -330,7 +330,9 @@ struct Model {
     int nsplit_mfma = 64;          // token splits of variant 3 (MFMA flash-decode, bf16 KV, head_dim 128, long contexts);
                                    // variant 2 = the same kernel with `nsplit` (32) splits for mid-size contexts
     int64_t attn_mfma_wide_min = 8192;   // measured: 32 splits win up to 4 K (3.26 vs 3.30 ms), 64 at 32 K (3.96 vs 4.08)
-    int64_t attn_mfma_min = 768;   // contexts of at least this many tokens use the MFMA kernel (CM_ATTN_MFMA_MIN; 0 = never);
+int attn_batch_ns_min = 1;            // fewest token splits per sequence in the batched decode attention (CM_ATTN_BATCH_NS_MIN)
+    int64_t attn_mfma_min_batch = 64;     // matrix-core decode attention from this context on when the group fills the chip (CM_ATTN_MFMA_MIN_BATCH)
+        int64_t attn_mfma_min = 768;   // contexts of at least this many tokens use the MFMA kernel (CM_ATTN_MFMA_MIN; 0 = never);
                                    // Qwen3-8B ms/token split vs MFMA(32 splits): 256: 3.056 / 3.068, 1 K: 3.11 / 3.085, 4 K: 3.44 / 3.26
     int attn_ns = 2;               // token splits per head of variant 1
     int attn_splits_force = 0;     // cm_debug_set("attn_splits"): one split count for the single AND the batched VALU attention (tests)
