@@ -41,6 +41,88 @@ def cpu_leg(model_name: str, ctx: int, budget_s: float):
     return time_decode(model_name, ctx, budget_s)
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of the MI355X (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
+
+
+def vision_leg(m, cfg, model_name: str, cpu: bool):
+    """BASELINE configs[3] (image + text): one 448 x 448 RGB image -> cm_image_preprocess (784 patches) -> the vision tower
+    (+ DeepStack mergers) -> 196 merged tokens -> image+text prefill -> decode.  The tower is the MFMA-bound stage of the path
+    (`roofline_tower`: USEFUL flops of the tower's GEMMs and attention / time; the parity mode multiplies bf16 hi + lo
+    activation planes, i.e. issues twice that on the matrix cores); decode after the image is the HBM-bound text model the
+    main line measures.  cpu_baseline: the numpy tower oracle (oracle/qwen3_5_vision_oracle.py, f32) timed on a SMALL image
+    (64 x 64 = 16 patches, labelled) on the host cores, and compared with the HIP tower on that image in the same run."""
+    import time
+    import numpy as np
+    from crane_amd.processor import PreprocessorConfig
+    vc = cfg["vision_config"]
+    rng = np.random.default_rng(0)
+    image = rng.integers(0, 256, size=(448, 448, 3), dtype=np.uint8)
+    t0 = time.perf_counter()
+    pix, g = PreprocessorConfig().process(image)
+    t_pp = time.perf_counter() - t0
+    grid = [list(g)]
+    npatch = int(pix.shape[0])
+    feat = m.encode_images(pix, grid)                                   # warm-up (allocates the tower scratch)
+    reps = 8
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        feat = m.encode_images(pix, grid)                               # synchronous: features come back to the host (1.6 MB)
+    t_enc = (time.perf_counter() - t0) / reps
+    Hv, Iv, L = vc["hidden_size"], vc["intermediate_size"], vc["depth"]
+    flops = npatch * L * 2 * (4 * Hv * Hv + 2 * Hv * Iv) + L * 4 * npatch * npatch * Hv
+    tf = flops / t_enc / 1e12
+    img = cfg["image_token_id"]
+    ids = [5, 6, 7, cfg["vision_start_token_id"]] + [img] * int(feat.shape[0]) + [cfg["vision_end_token_id"], 8, 9, 10]
+    m.clear_kv_cache(); m.vlm_forward(ids, pix, grid); m.clear_kv_cache()
+    t0 = time.perf_counter()
+    _, nxt = m.vlm_forward(ids, pix, grid)
+    t_pre = time.perf_counter() - t0
+    toks, pos = [nxt], len(ids)
+    t0 = time.perf_counter()
+    for _ in range(16):
+        toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+    t_dec = (time.perf_counter() - t0) / 16
+    out = {"image": "448x448 RGB, synthetic", "patches": npatch, "merged_tokens": int(feat.shape[0]),
+           "preprocess_ms": round(t_pp * 1e3, 3), "tower_ms": round(t_enc * 1e3, 3),
+           "roofline_tower": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "flops": int(flops),
+                              "note": "useful flops (GEMMs + attention of the tower); bf16 hi + lo activations issue 2 MFMAs per product"},
+           "image_text_prefill_ms": round(t_pre * 1e3, 3), "prompt_tokens": len(ids),
+           "decode_after_image_ms_per_token": round(t_dec * 1e3, 3)}
+    if cpu:
+        try:
+            from crane_amd import synth
+            from oracle.qwen3_vl_oracle import DeepstackVisionOracle
+            t0 = time.perf_counter()
+            w = {}
+            for name, shape, std, off in synth.specs_for(cfg):
+                if name.startswith("model.visual."):
+                    w[name] = synth.bf16_bits_to_f32(synth.synth_bf16_bits(name, int(np.prod(shape)), 0, std, off)).reshape(shape)
+            t_build = time.perf_counter() - t0
+            o = DeepstackVisionOracle(vc, w)
+            small = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
+            spix, sg = PreprocessorConfig().process(small)
+            t0 = time.perf_counter()
+            ref, _ = o.forward_with_deepstack(spix, [list(sg)])
+            t_cpu = time.perf_counter() - t0
+            got = m.encode_images(spix, [list(sg)])
+            rel = float(np.abs(got - ref).max() / np.abs(ref).max())
+            try:
+                from threadpoolctl import threadpool_info
+                cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [1])       # numpy's BLAS pool
+            except Exception:
+                cores = 1
+            out["cpu_baseline"] = {"value": round(spix.shape[0] / t_cpu, 2), "unit": "patches/s", "cores": cores,
+                                   "kind": "port", "sample": f"numpy f32 tower oracle on a 64 x 64 image (smart_resize -> {spix.shape[0]} patches, "
+                                   f"{t_cpu:.2f}s; numpy BLAS threads; weight synthesis {t_build:.1f}s excluded); the HIP tower does "
+                                   f"{npatch / t_enc:.0f} patches/s at 784 patches"}
+            out["parity"] = {"reference": "oracle/qwen3_vl_oracle.py DeepstackVisionOracle (f32) on the same synthetic weights, 64 x 64 image",
+                             "feature_rel": float(f"{rel:.3e}"), "ok": bool(rel < 1e-3)}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": str(e)}
+    return out
+
+
 def relaunch_under_torchrun(n: int) -> int:
     """`python bench.py --gpus N` (no torchrun): start the N ranks ourselves, one process per GPU."""
     import torch
@@ -196,7 +278,7 @@ def main():
     try:
         if args.isq:
             raise RuntimeError("quantised weights: not part of the bf16 headline")
-        ids = configs.synthetic_prompt(1024, cfg["vocab_size"])
+        ids = configs.synthetic_prompt(1024, cfg.get("text_config", cfg)["vocab_size"])
         m.clear_kv_cache(); m.forward_step_greedy(ids, 0)            # warm-up (allocates chunk buffers)
         m.clear_kv_cache()
         barrier()
@@ -266,6 +348,13 @@ def main():
             except Exception as e:  # the baseline must never break the headline number
                 cpu = {"error": str(e)}
 
+    vision = None
+    if rank == 0 and n == 1 and "vision_config" in cfg:
+        try:
+            vision = vision_leg(m, cfg, args.model, not args.no_cpu_baseline)
+        except Exception as e:
+            vision = {"error": str(e)}
+
     wdt = args.isq or "bf16"
     if rank == 0:
         headline = args.model == "qwen3-8b" and not args.isq and args.kv == "f16" and ctx == 1024
@@ -283,10 +372,12 @@ def main():
                                        2: "persistent decode kernel: one launch per token (cm_opts.engine)"}[m.engine_active()]},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "parity": parity, "cpu_baseline": cpu,
         }
+        if vision is not None:
+            line["vision"] = vision
         if n > 1:
             # the exchange steps of one token under TP: one f32 [H] all-reduce behind each row-parallel projection
             # (o_proj / GDN out_proj, down_proj), one all-gather of the ranks' (max, index) arg-max partials behind lm_head
-            L, H = cfg["num_hidden_layers"], cfg["hidden_size"]
+            L, H = cfg.get("text_config", cfg)["num_hidden_layers"], cfg.get("text_config", cfg)["hidden_size"]
             line["collectives"] = {"library": "RCCL", "all_reduce_per_token": 2 * L, "bytes_per_all_reduce": 4 * H,
                                    "all_reduce_bytes_per_token": 8 * L * H, "all_gather_per_token": 1,
                                    "bytes_per_all_gather": 8 * n, "captured_in_hipgraph": not args.no_graph,

@@ -44,6 +44,11 @@ typedef struct qc_model {
 
 float qc_f16_round(float f) { return f16_round(f); }     /* known-answer hook: tests/test_c_oracle.py pins it on numpy's float16 */
 
+/* checkpoint name prefix of the decoder's tensors: "model." (Qwen3ForCausalLM), "model.language_model." when the decoder is the
+ * text model of a vision-language checkpoint (prefix probing, qwen3_5/model.rs:65-74); applies to the next qc_create */
+static char g_prefix[64] = "model.";
+void qc_set_name_prefix(const char* p) { snprintf(g_prefix, sizeof g_prefix, "%s", p && *p ? p : "model."); }
+
 qc_model* qc_create(const qc_cfg* cfg, uint64_t seed) {
     qc_model* m = (qc_model*)calloc(1, sizeof *m);
     m->c = *cfg;
@@ -51,16 +56,18 @@ qc_model* qc_create(const qc_cfg* cfg, uint64_t seed) {
     const int H = c->H, D = c->D, I = c->I, qd = c->Hq * D, kd = c->Hkv * D;
     char name[256];
     m->embed = xmalloc((size_t)c->V * H * 2);
-    synth_rows(m->embed, H, "model.embed_tokens.weight", seed, 1.0, 0.f, 0, c->V, H);
+    snprintf(name, sizeof name, "%sembed_tokens.weight", g_prefix);
+    synth_rows(m->embed, H, name, seed, 1.0, 0.f, 0, c->V, H);
     m->norm = xmalloc((size_t)H * 2);
-    synth_rows(m->norm, H, "model.norm.weight", seed, 0.1, 1.f, 0, 1, H);
+    snprintf(name, sizeof name, "%snorm.weight", g_prefix);
+    synth_rows(m->norm, H, name, seed, 0.1, 1.f, 0, 1, H);
     if (c->tie) m->lm_head = m->embed;      /* tied: same tensor (modeling.rs:786-794) */
     else { m->lm_head = xmalloc((size_t)c->V * H * 2); synth_rows(m->lm_head, H, "lm_head.weight", seed, 1.0 / sqrt((double)H), 0.f, 0, c->V, H); }
     m->layers = (qc_layer*)calloc((size_t)c->L, sizeof(qc_layer));
     for (int li = 0; li < c->L; ++li) {
         qc_layer* w = &m->layers[li];
         const double sH = 1.0 / sqrt((double)H);
-#define NM(suffix) (snprintf(name, sizeof name, "model.layers.%d.%s", li, suffix), name)
+#define NM(suffix) (snprintf(name, sizeof name, "%slayers.%d.%s", g_prefix, li, suffix), name)
         w->qkv = xmalloc((size_t)(qd + 2 * kd) * H * 2);          /* cat(q,k,v) rows (modeling.rs:187-204) */
         synth_rows(w->qkv, H, NM("self_attn.q_proj.weight"), seed, sH, 0.f, 0, qd, H);
         synth_rows(w->qkv + (size_t)qd * H, H, NM("self_attn.k_proj.weight"), seed, sH, 0.f, 0, kd, H);

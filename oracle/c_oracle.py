@@ -44,6 +44,7 @@ def _lib():
     lib.qc_fill_kv_paged.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     lib.qc_num_threads.restype = C.c_int
     lib.qc_set_threads.argtypes = [C.c_int]
+    lib.qc_set_name_prefix.argtypes = [C.c_char_p]
     return lib
 
 
@@ -74,6 +75,14 @@ class CQwen3:
     def __init__(self, cfg: dict, seed: int = 0, max_seq: int = 2048, kv_bf16: bool = False):
         self.lib = _lib()
         self.lib.qc_set_threads(host_threads())
+        if "text_config" in cfg:         # the dense text model of a vision-language checkpoint (Qwen3-VL): tensors under model.language_model.
+            tie = cfg.get("tie_word_embeddings", True)
+            rp = cfg["text_config"].get("rope_parameters") or {}
+            cfg = dict(cfg["text_config"], tie_word_embeddings=cfg["text_config"].get("tie_word_embeddings", tie))
+            cfg.setdefault("rope_theta", rp.get("rope_theta", 1e6))
+            self.lib.qc_set_name_prefix(b"model.language_model.")
+        else:
+            self.lib.qc_set_name_prefix(b"model.")
         D = cfg.get("head_dim") or cfg["hidden_size"] // cfg["num_attention_heads"]
         c = QcCfg(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"],
                   cfg["num_attention_heads"], cfg["num_key_value_heads"], D, max_seq,

@@ -142,3 +142,23 @@ def test_c_port_matches_hf_golden_at_the_headline_geometry(name):
         assert toks == want
     finally:
         c.close()
+
+
+def test_c_port_runs_the_text_model_of_a_vl_checkpoint():
+    """bench.py --model qwen3-vl-2b checks its decode against the C port too: the dense decoder of a Qwen3-VL checkpoint keeps its
+    tensors under model.language_model. (qc_set_name_prefix) and rotates text rows like plain RoPE (T = H = W): the port equals
+    the numpy Qwen3-VL oracle on a text-only prompt and a decode step."""
+    from oracle.qwen3_vl_oracle import Qwen3VLOracle
+    cfg = configs.get_config("tiny-qwen3-vl")
+    c = c_oracle.CQwen3(cfg, seed=0, max_seq=64)
+    try:
+        ids = configs.synthetic_prompt(9, 400)
+        a = c.forward(ids, 0)
+        o = Qwen3VLOracle(cfg, synth.synth_weights_f32(cfg, 0))
+        _, _, b = o.prefill(ids, np.zeros((0, 1536), np.float32), [])
+        assert np.abs(a - b).max() / np.abs(a).max() < 2e-5
+        a2, b2 = c.forward([int(a.argmax())], 9), np.asarray(o.decode(int(b.argmax()))).reshape(-1)
+        assert np.abs(a2 - b2).max() / np.abs(a2).max() < 2e-5
+    finally:
+        c.close()
+        c_oracle.CQwen3(configs.get_config("tiny-qwen3"), seed=0, max_seq=16).close()      # (resets the name prefix)

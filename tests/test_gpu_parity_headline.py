@@ -102,7 +102,7 @@ def test_prefill_1024_and_batched_step_qwen3_8b_geometry(oracle8b):
         m.close()
 
 
-@pytest.mark.parametrize("nseq", [40, 80, 128])
+@pytest.mark.parametrize("nseq", [20, 40, 80, 128])
 def test_large_decode_groups_equal_the_sequence_stepped_alone(nseq):
     """Decode groups of more than 32 sequences at the 8B widths: the projections run as MFMA GEMMs over the group's rows (from 65
     rows on the LDS-DMA kernel with 128-row tiles, kernels_gemm256.hip) and the 151 936-row lm_head as ONE GEMM + row arg-max
