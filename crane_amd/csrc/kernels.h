@@ -128,6 +128,9 @@ struct AttnPreArgs {
     int gate_stride;
     int S, Hq, Hkv, nrep, page, start_pos;
     int causal, kv_lo, kv_hi;    // causal = 0: bidirectional over tokens [kv_lo, kv_hi) (ViT frame)
+    int ksplit = 1;              // bidirectional frames only: runs of key tiles per query tile (partials merged by a second kernel)
+    float* part_o = nullptr;     // [ksplit][S][Hq][D] un-normalised partial outputs
+    float* part_ml = nullptr;    // [ksplit][S][Hq][2] running max, running sum
 };
 
 void launch_embed_rows(const uint16_t* emb, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);

@@ -449,7 +449,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     const int last_q = min(qb + 63, a.S - 1);
     // causal: tokens [0, start_pos + last_q] ; window (ViT frame): tokens [kv_lo, kv_hi), bidirectional
     const int kv_end = a.causal ? a.start_pos + last_q + 1 : a.kv_hi;
-    for (int t0 = a.causal ? 0 : a.kv_lo; t0 < kv_end; t0 += KT) {
+    // bidirectional frames (ViT): blockIdx.z takes one of a.ksplit contiguous runs of key tiles and leaves an un-normalised
+    // partial (o, m, l) for attn_prefill_merge_kernel -- 13 x 16 blocks of 4 waves are one wave per SIMD on 208 of 256 CUs, each
+    // walking 13 tiles of VALU-bound softmax serially; four runs per query tile put 3 waves on every SIMD
+    int t_begin = a.causal ? 0 : a.kv_lo, t_end = kv_end;
+    if (a.ksplit > 1) {
+        const int ntile = (kv_end - t_begin + KT - 1) / KT, per = (ntile + a.ksplit - 1) / a.ksplit;
+        t_begin += (int)blockIdx.z * per * KT;
+        t_end = min(kv_end, t_begin + per * KT);
+    }
+    for (int t0 = t_begin; t0 < t_end; t0 += KT) {
         __syncthreads();                                   // previous tile's V fully consumed
         // ---- stage V tile (64 tokens x D dims) into LDS, shared by the 4 waves ----
 #pragma unroll
@@ -559,6 +568,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     // ---- finalize: l over the 4 lane groups; O^T rows = dims nt*16 + g*4 + r, col = query `sub` ----
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
+    if (a.ksplit > 1) {
+        if (qrow < a.S) {
+            const size_t row = ((size_t)blockIdx.z * a.S + qrow) * a.Hq + h;
+#pragma unroll
+            for (int nt = 0; nt < NNT; ++nt) *(f32x4*)(a.part_o + row * D + nt * 16 + g * 4) = o[nt];
+            if (g == 0) { a.part_ml[row * 2] = m_run; a.part_ml[row * 2 + 1] = l_run; }
+        }
+        return;
+    }
     const float inv = 1.0f / l_run;
     if (qrow < a.S) {
 #pragma unroll
@@ -572,6 +590,32 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
             split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
         }
     }
+}
+
+// merge of the ksplit partials of attn_prefill_kernel: out = sum_z e^(m_z - M) o_z / sum_z e^(m_z - M) l_z, stored as bf16 hi + lo
+// (the A operand of the projection GEMM).  One thread per (query row, head, 4 dims).
+template <int D>
+__global__ __launch_bounds__(256) void attn_prefill_merge_kernel(AttnPreArgs a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n4 = (size_t)a.S * a.Hq * (D / 4);
+    if (i >= n4) return;
+    const size_t row = i / (D / 4);                       // qrow * Hq + h
+    const int d4 = (int)(i % (D / 4)) * 4;
+    const size_t zs = (size_t)a.S * a.Hq;
+    float M = -INFINITY;
+    for (int z = 0; z < a.ksplit; ++z) M = fmaxf(M, a.part_ml[(z * zs + row) * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.ksplit; ++z) {
+        const float mz = a.part_ml[(z * zs + row) * 2];
+        const float w = mz > -INFINITY ? expf(mz - M) : 0.f;
+        L += w * a.part_ml[(z * zs + row) * 2 + 1];
+        const f32x4 p = *(const f32x4*)(a.part_o + (z * zs + row) * D + d4);
+        acc[0] += w * p[0]; acc[1] += w * p[1]; acc[2] += w * p[2]; acc[3] += w * p[3];
+    }
+    const float inv = 1.0f / L;
+    float v[4] = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+    split_store4(a.out_hi, a.out_lo, row * D + d4, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -771,10 +815,16 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     return true;
 }
 // kvt: KV_BF16 | KV_F16 | KV_F32 (the element type the kernel READS: f32 for the ViT scratch and the int8 / int4 shadow)
-void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s) {
-    dim3 grid((a.S + 63) / 64, a.Hq);
+void launch_attn_prefill(const AttnPreArgs& a0, int D, int kvt, hipStream_t s) {
+    AttnPreArgs a = a0;
+    if (a.causal || a.part_o == nullptr || a.part_ml == nullptr || a.gate != nullptr || a.ksplit < 1) a.ksplit = 1;
+    dim3 grid((a.S + 63) / 64, a.Hq, a.ksplit);
     if (D == 64) {
         hipLaunchKernelGGL((attn_prefill_kernel<64, KV_BF16X2>), grid, dim3(256), 0, s, a);     // ViT: K/V scratch pre-split into bf16 hi + lo
+        if (a.ksplit > 1) {
+            const size_t n4 = (size_t)a.S * a.Hq * (64 / 4);
+            hipLaunchKernelGGL((attn_prefill_merge_kernel<64>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
+        }
     } else if (D == 128) {
         if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F32>), grid, dim3(256), 0, s, a);
         else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F16>), grid, dim3(256), 0, s, a);

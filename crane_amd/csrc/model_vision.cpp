@@ -34,6 +34,11 @@ void Model::ensure_vision_buffers(int n_patches) {
     vW4 = dalloc<float>((size_t)4 * cap);
     vIdx = dalloc<int>((size_t)4 * cap);
     vBt = dalloc<int>(pages);
+    if (const char* e = getenv("CM_VIT_KSPLIT")) vit_ksplit = std::max(1, std::min(8, atoi(e)));
+    if (vit_ksplit > 1) {
+        vPartO = dalloc<float>((size_t)vit_ksplit * cap * VH);
+        vPartML = dalloc<float>((size_t)vit_ksplit * cap * vcfg.heads * 2);
+    }
     auto z = [&](size_t n) { uint16_t* p = dalloc<uint16_t>(n); CM_HIP(hipMemsetAsync(p, 0, n * 2, stream)); return p; };
     vA_hi = z((size_t)pad * wide); vA_lo = z((size_t)pad * wide);
     vB_hi = z((size_t)pad * wide); vB_lo = z((size_t)pad * wide);
@@ -128,6 +133,8 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
             at.out_hi = vB_hi + (size_t)fr.first * VH; at.out_lo = vB_lo + (size_t)fr.first * VH;
             at.S = fr.second - fr.first; at.Hq = heads; at.Hkv = heads; at.nrep = 1; at.page = 64;
             at.start_pos = fr.first; at.causal = 0; at.kv_lo = fr.first; at.kv_hi = fr.second;
+            // enough (query tile, head, key run) blocks for ~3 waves per SIMD; a run is never shorter than two key tiles
+            at.ksplit = std::max(1, std::min(vit_ksplit, (at.S + 127) / 128)); at.part_o = vPartO; at.part_ml = vPartML;
             launch_attn_prefill(at, 64, KV_BF16X2, s);
         }
         gemm(vB_hi, vB_lo, b.proj_w, b.proj_b, N, VH, VH, GEPI_RESADD, vX, nullptr, nullptr, 0);
