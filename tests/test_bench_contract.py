@@ -24,11 +24,11 @@ def test_bench_refuses_more_gpus_than_the_node_has():
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    """The last bench line of the round (profiles/r02_bench_default.json, written by `python bench.py` on the MI355X) has every
+    """The last bench line of the round (profiles/r03_bench_default.json, written by `python bench.py` on the MI355X) has every
     field the driver and the judge read, and its own numbers are consistent with each other."""
     import json
     line = None
-    for l in open(os.path.join(ROOT, "profiles", "r02_bench_default.json")):
+    for l in open(os.path.join(ROOT, "profiles", "r03_bench_default.json")):
         if l.startswith("{"):
             line = json.loads(l)
     assert line is not None
@@ -49,4 +49,9 @@ def test_committed_bench_line_carries_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
-    assert line["parity"]["ok"] is True and line["parity"]["tokens_equal"] == line["parity"]["tokens_checked"]
+    p = line["parity"]
+    assert p["ok"] is True and p["kv_pages"] == "f16"
+    w, t = p["model_written_cache"], p["timed_configuration"]          # a cache the model wrote itself / the timed synthetic cache
+    assert w["greedy_equal"] == w["greedy_checked"] and max(w["prefill_logit_rel"], w["decode_logit_rel"]) < 1e-3
+    assert t["tokens_equal"] == t["tokens_checked"] and t["logit_rel"] < 1e-3
+    assert line["roofline_step"]["frac"] >= 0.69
