@@ -177,11 +177,34 @@ struct Engine {
             for (uint64_t id : ids) if (reqs.count(id)) fail(id, e.code, e.what());
             return true;
         }
+        // the sampled rows of the pass: one set of sampler launches and ONE host sync instead of one per prompt
+        std::vector<uint32_t> picked(ids.size());
+        try {
+            std::vector<Model::SampleReq> rows;
+            for (size_t k = 0; k < ids.size(); ++k) {
+                Request& r = req(ids[k]);
+                if (r.greedy_plain) { picked[k] = greedy[k]; continue; }
+                const size_t w = std::min(r.tokens.size(), (size_t)opts.repeat_last_n);
+                cm_sample_params sp = r.sp;
+                sp.repeat_last_n = 0;
+                sp.draw = (uint32_t)r.num_generated();
+                rows.push_back({(int)k, sp, r.tokens.data() + (r.tokens.size() - w), w, false, m->logitsb + k * (size_t)m->cfg.V});
+            }
+            if (!rows.empty()) {
+                uint32_t got[Model::SAMPLE_SLOTS];
+                m->sample_enqueue_rows(rows.data(), (int)rows.size());
+                m->sample_collect((int)ids.size(), got);
+                for (const auto& q : rows) picked[(size_t)q.slot] = got[q.slot];
+            }
+        } catch (const CmError& e) {
+            for (uint64_t id : ids) if (reqs.count(id)) fail(id, e.code, e.what());
+            return true;
+        }
         for (size_t k = 0; k < ids.size(); ++k) {
             Request& r = req(ids[k]);
             stats.prefill_steps++;
             try {
-                const uint32_t t = pick(r, m->logitsb + k * (size_t)m->cfg.V, greedy[k]);
+                const uint32_t t = picked[k];
                 r.tokens.push_back(t);
                 emit_token(r, t);
                 if (r.should_stop()) finish(ids[k], r.last_is_eos() ? CM_FINISH_STOP : CM_FINISH_LENGTH);
@@ -227,7 +250,7 @@ struct Engine {
                 const std::function<void(size_t, int)> after = [&](size_t g0, int nb) {
                     // every sampled row of the group is enqueued on its own sampler slot; ONE host sync for the group
                     uint32_t picked[Model::SAMPLE_SLOTS];
-                    bool any = false;
+                    std::vector<Model::SampleReq> rows;
                     for (int b = 0; b < nb; ++b) {
                         Request& r = req(batch[g0 + (size_t)b]);
                         if (r.greedy_plain) continue;
@@ -235,10 +258,9 @@ struct Engine {
                         cm_sample_params sp = r.sp;
                         sp.repeat_last_n = 0;
                         sp.draw = (uint32_t)r.num_generated();
-                        m->sample_enqueue(b, sp, r.tokens.data() + (r.tokens.size() - w), w, false, m->logitsb + (size_t)b * m->cfg.V);
-                        any = true;
+                        rows.push_back({b, sp, r.tokens.data() + (r.tokens.size() - w), w, false, m->logitsb + (size_t)b * m->cfg.V});
                     }
-                    if (any) m->sample_collect(nb, picked);
+                    if (!rows.empty()) { m->sample_enqueue_rows(rows.data(), (int)rows.size()); m->sample_collect(nb, picked); }
                     for (int b = 0; b < nb; ++b) {
                         Request& r = req(batch[g0 + (size_t)b]);
                         out[g0 + (size_t)b] = r.greedy_plain ? m->h_stb[b].next : picked[b];

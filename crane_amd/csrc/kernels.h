@@ -317,6 +317,22 @@ void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void*
 void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s, int n_seq = 1, int in_stride = 0, int out_stride = 0);
 
 // sampler (kernels_sample.hip)
+// one row of a batched sampler call (launch_sample_rows): the row's logits, its private scratch, its parameters
+struct SampleRowDev {
+    float* logits;
+    uint32_t* hist;              // [4096] zeroed histogram
+    uint32_t* sel;               // [4] select record
+    unsigned long long* cand;
+    uint32_t* idx_out;           // top-k ids: the row's idx scratch (sampled) or its token slot (greedy: k = 1)
+    float* val;
+    uint32_t* tok;
+    const uint32_t* pen_ids;
+    const uint32_t* pen_counts;
+    int pen_n, k, kp, sample, true_div;
+    float temperature, top_p, rp, rp_inv, fp, pp;
+    uint32_t seed_lo, seed_hi, draw;
+};
+void launch_sample_rows(const SampleRowDev* tab, int nrows, int V, int max_pen, hipStream_t s);
 int topk_pad(int k);
 int topk_blocks(int n);
 void launch_topk(const float* logits, int n, int k, unsigned long long* cand, uint32_t* hist, uint32_t* sel, uint32_t* idx_out,

@@ -41,8 +41,8 @@ __device__ void bitonic_desc(unsigned long long* s, int n) {
 constexpr int TK_SLICE = 4096;
 
 // stage 1: block b sorts logits[b*4096 .. +4096) and emits its kp best keys
-__global__ __launch_bounds__(1024) void topk_stage1_kernel(const float* __restrict__ logits, int n, int kp,
-                                                           unsigned long long* __restrict__ cand, const uint32_t* __restrict__ sel) {
+__device__ __forceinline__ void topk_stage1_body(const float* __restrict__ logits, int n, int kp,
+                                                 unsigned long long* __restrict__ cand, const uint32_t* __restrict__ sel) {
     __shared__ unsigned long long s[TK_SLICE];
     if (sel[2] != 0) return;                                   // the radix-select path already produced the answer
     const int base = blockIdx.x * TK_SLICE;
@@ -56,9 +56,9 @@ __global__ __launch_bounds__(1024) void topk_stage1_kernel(const float* __restri
 }
 
 // stage 2: one block folds all candidates, keeping the running best kp at the front
-__global__ __launch_bounds__(1024) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int kp, int k,
-                                                           uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
-                                                           const float* __restrict__ logits, const uint32_t* __restrict__ sel) {
+__device__ __forceinline__ void topk_stage2_body(const unsigned long long* __restrict__ cand, int ncand, int kp, int k,
+                                                 uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                 const float* __restrict__ logits, const uint32_t* __restrict__ sel) {
     __shared__ unsigned long long s[TK_SLICE];
     if (sel[2] != 0) return;
     int consumed = 0;
@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t topk_ord(float v) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict__ logits, int n, uint32_t* __restrict__ hist) {
+__device__ __forceinline__ void topk_hist_body(const float* __restrict__ logits, int n, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[TK_BINS];
     for (int i = threadIdx.x; i < TK_BINS; i += blockDim.x) h[i] = 0;
     __syncthreads();
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-__global__ __launch_bounds__(1024) void topk_select_kernel(uint32_t* __restrict__ hist, int k, uint32_t* __restrict__ sel) {
+__device__ __forceinline__ void topk_select_body(uint32_t* __restrict__ hist, int k, uint32_t* __restrict__ sel) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     uint32_t c[4], sum = 0;
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(uint32_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(1024) void topk_collect_kernel(const float* __restrict__ logits, int n, uint32_t* __restrict__ sel,
-                                                            unsigned long long* __restrict__ cand) {
+__device__ __forceinline__ void topk_collect_body(const float* __restrict__ logits, int n, uint32_t* __restrict__ sel,
+                                                  unsigned long long* __restrict__ cand) {
     if (sel[2] == 0) return;
     const uint32_t T = sel[0];
     const int base = blockIdx.x * TK_SLICE;
@@ -159,9 +159,9 @@ __global__ __launch_bounds__(1024) void topk_collect_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ cand, const uint32_t* __restrict__ sel,
-                                                          int k, uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
-                                                          const float* __restrict__ logits) {
+__device__ __forceinline__ void topk_final_body(const unsigned long long* __restrict__ cand, const uint32_t* __restrict__ sel,
+                                                int k, uint32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                const float* __restrict__ logits) {
     __shared__ unsigned long long s[TK_CAP];
     if (sel[2] == 0) return;
     const int n = (int)sel[1];
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long lo
     }
 }
 
-__global__ void penalties_kernel(float* __restrict__ logits, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts,
-                                 int n, float rp, float rp_inv, int true_div, float fp, float pp, int V) {
+__device__ __forceinline__ void penalties_body(float* __restrict__ logits, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts,
+                                               int n, float rp, float rp_inv, int true_div, float fp, float pp, int V) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t t = ids[i];
@@ -199,9 +199,9 @@ __device__ __forceinline__ float uniform_open(uint32_t seed_lo, uint32_t seed_hi
 }
 
 // one wave: k <= 64 candidates (sorted, best first)
-__global__ __launch_bounds__(64) void sample_topk_kernel(const uint32_t* __restrict__ idx, const float* __restrict__ val, int k,
-                                                         float temperature, float top_p, uint32_t seed_lo, uint32_t seed_hi,
-                                                         uint32_t draw, uint32_t* __restrict__ token_out) {
+__device__ __forceinline__ void sample_topk_body(const uint32_t* __restrict__ idx, const float* __restrict__ val, int k,
+                                                 float temperature, float top_p, uint32_t seed_lo, uint32_t seed_hi,
+                                                 uint32_t draw, uint32_t* __restrict__ token_out) {
     const int lane = threadIdx.x;
     const bool act = lane < k;
     const float lg = act ? val[lane] : -INFINITY;
@@ -278,6 +278,65 @@ __global__ __launch_bounds__(256) void gumbel_final_kernel(const float* __restri
     if (threadIdx.x == 0) token_out[0] = (uint32_t)si[0];
 }
 
+// ---- the kernels: one row (pointers as arguments) or a table of rows (blockIdx.y = row; every row has its own scratch) ----
+__global__ __launch_bounds__(1024) void topk_stage1_kernel(const float* logits, int n, int kp, unsigned long long* cand, const uint32_t* sel) {
+    topk_stage1_body(logits, n, kp, cand, sel);
+}
+__global__ __launch_bounds__(1024) void topk_stage2_kernel(const unsigned long long* cand, int ncand, int kp, int k, uint32_t* idx_out,
+                                                           float* val_out, const float* logits, const uint32_t* sel) {
+    topk_stage2_body(cand, ncand, kp, k, idx_out, val_out, logits, sel);
+}
+__global__ __launch_bounds__(1024) void topk_hist_kernel(const float* logits, int n, uint32_t* hist) { topk_hist_body(logits, n, hist); }
+__global__ __launch_bounds__(1024) void topk_select_kernel(uint32_t* hist, int k, uint32_t* sel) { topk_select_body(hist, k, sel); }
+__global__ __launch_bounds__(1024) void topk_collect_kernel(const float* logits, int n, uint32_t* sel, unsigned long long* cand) {
+    topk_collect_body(logits, n, sel, cand);
+}
+__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* cand, const uint32_t* sel, int k, uint32_t* idx_out,
+                                                          float* val_out, const float* logits) {
+    topk_final_body(cand, sel, k, idx_out, val_out, logits);
+}
+__global__ void penalties_kernel(float* logits, const uint32_t* ids, const uint32_t* counts, int n, float rp, float rp_inv, int true_div,
+                                 float fp, float pp, int V) {
+    penalties_body(logits, ids, counts, n, rp, rp_inv, true_div, fp, pp, V);
+}
+__global__ __launch_bounds__(64) void sample_topk_kernel(const uint32_t* idx, const float* val, int k, float temperature, float top_p,
+                                                         uint32_t seed_lo, uint32_t seed_hi, uint32_t draw, uint32_t* token_out) {
+    sample_topk_body(idx, val, k, temperature, top_p, seed_lo, seed_hi, draw, token_out);
+}
+
+__global__ __launch_bounds__(1024) void topk_stage1_rows_kernel(const SampleRowDev* tab, int n) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    topk_stage1_body(r.logits, n, r.kp, r.cand, r.sel);
+}
+__global__ __launch_bounds__(1024) void topk_stage2_rows_kernel(const SampleRowDev* tab, int nb) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    topk_stage2_body(r.cand, nb * r.kp, r.kp, r.k, r.idx_out, r.val, r.logits, r.sel);
+}
+__global__ __launch_bounds__(1024) void topk_hist_rows_kernel(const SampleRowDev* tab, int n) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    topk_hist_body(r.logits, n, r.hist);
+}
+__global__ __launch_bounds__(1024) void topk_select_rows_kernel(const SampleRowDev* tab) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    topk_select_body(r.hist, r.k, r.sel);
+}
+__global__ __launch_bounds__(1024) void topk_collect_rows_kernel(const SampleRowDev* tab, int n) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    topk_collect_body(r.logits, n, r.sel, r.cand);
+}
+__global__ __launch_bounds__(1024) void topk_final_rows_kernel(const SampleRowDev* tab) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    topk_final_body(r.cand, r.sel, r.k, r.idx_out, r.val, r.logits);
+}
+__global__ void penalties_rows_kernel(const SampleRowDev* tab, int V) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    penalties_body(r.logits, r.pen_ids, r.pen_counts, r.pen_n, r.rp, r.rp_inv, r.true_div, r.fp, r.pp, V);
+}
+__global__ __launch_bounds__(64) void sample_topk_rows_kernel(const SampleRowDev* tab) {
+    const SampleRowDev& r = tab[blockIdx.y];
+    if (r.sample) sample_topk_body(r.idx_out, r.val, r.k, r.temperature, r.top_p, r.seed_lo, r.seed_hi, r.draw, r.tok);
+}
+
 int topk_pad(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 int topk_blocks(int n) { return (n + TK_SLICE - 1) / TK_SLICE; }
 
@@ -310,6 +369,20 @@ void launch_gumbel_full(const float* logits, int V, float temperature, uint64_t 
     hipLaunchKernelGGL(gumbel_full_kernel, dim3(blocks), dim3(256), 0, s, logits, V, temperature, (uint32_t)seed, (uint32_t)(seed >> 32),
                        draw, pmax, pidx);
     hipLaunchKernelGGL(gumbel_final_kernel, dim3(1), dim3(256), 0, s, pmax, pidx, blocks, token_out);
+}
+
+// every row of a decode group in the same eight launches (the per-row path costs eight launches and a copy PER ROW: 128 rows x 9
+// stream operations of ~3 us each were a quarter of a 128-sequence engine round)
+void launch_sample_rows(const SampleRowDev* tab, int nrows, int V, int max_pen, hipStream_t s) {
+    const int nb = topk_blocks(V);
+    if (max_pen > 0) hipLaunchKernelGGL(penalties_rows_kernel, dim3((max_pen + 255) / 256, nrows), dim3(256), 0, s, tab, V);
+    hipLaunchKernelGGL(topk_hist_rows_kernel, dim3(nb, nrows), dim3(1024), 0, s, tab, V);
+    hipLaunchKernelGGL(topk_select_rows_kernel, dim3(1, nrows), dim3(1024), 0, s, tab);
+    hipLaunchKernelGGL(topk_collect_rows_kernel, dim3(nb, nrows), dim3(1024), 0, s, tab, V);
+    hipLaunchKernelGGL(topk_final_rows_kernel, dim3(1, nrows), dim3(1024), 0, s, tab);
+    hipLaunchKernelGGL(topk_stage1_rows_kernel, dim3(nb, nrows), dim3(1024), 0, s, tab, V);
+    hipLaunchKernelGGL(topk_stage2_rows_kernel, dim3(1, nrows), dim3(1024), 0, s, tab, nb);
+    hipLaunchKernelGGL(sample_topk_rows_kernel, dim3(1, nrows), dim3(64), 0, s, tab);
 }
 
 }  // namespace cm

@@ -263,6 +263,11 @@ struct Model {
     uint32_t* d_pen = nullptr;         // [2][PEN_CAP] distinct ids, counts
     uint32_t* h_pen = nullptr;         // pinned
     uint32_t* d_tok = nullptr;
+    struct SampleReq { int slot; cm_sample_params p; const uint32_t* ctx; size_t n_ctx; bool true_div; float* dev_logits; };
+    void sample_enqueue_rows(const SampleReq* rq, int n);      // every row in one set of launches (model_sample.cpp)
+    struct SampleRowDev* d_stab = nullptr;                      // device / pinned row tables of sample_enqueue_rows
+    struct SampleRowDev* h_stab = nullptr;
+    bool sample_rows_on = true;                                 // cm_debug_set("sample_rows", 0): the per-row path (A/B, tests)
     uint32_t* h_tk = nullptr;          // pinned [1 + 512 + 512]
     float* sm_pmax = nullptr; int* sm_pidx = nullptr;
     static constexpr int PEN_CAP = 8192;

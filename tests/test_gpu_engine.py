@@ -169,6 +169,37 @@ def test_sampled_requests_are_seeded_and_bounded():
         m.close()
 
 
+def test_row_sampler_equals_the_per_row_sampler():
+    """Model::sample_enqueue_rows (every sampled row of a decode group / prompt pass in one set of launches, blockIdx.y = row)
+    runs the per-row sampler's device code on per-slot scratch: the same tokens as cm_debug_set("sample_rows", 0) -- mixed
+    rows: top-k + top-p with penalties, top-k only, greedy with a repetition penalty, plain greedy, and a full-vocabulary
+    Gumbel row (no top-k / top-p: stays on the per-row path inside the same group)."""
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    m = _model(max_seqs=16)
+    try:
+        prompts = _prompts(m.vocab_size, 20)
+        params = [GenerationParams(max_tokens=14, temperature=0.9, top_p=0.95, top_k=40, repetition_penalty=1.05),
+                  GenerationParams(max_tokens=14, temperature=1.3, top_p=None, top_k=8, repetition_penalty=1.0),
+                  GenerationParams(max_tokens=14, temperature=0.0, top_p=None, top_k=0, repetition_penalty=1.3),
+                  GenerationParams.greedy(14),
+                  GenerationParams(max_tokens=14, temperature=1.1, top_p=None, top_k=0, repetition_penalty=1.0, frequency_penalty=0.2)]
+
+        def run(rows):
+            m.debug_set("sample_rows", rows)
+            eng = InferenceEngine(m, seed=3)
+            ids = [eng.submit(p, params[i % len(params)]) for i, p in enumerate(prompts)]
+            toks, done = eng.run_until_idle()
+            eng.close()
+            return [toks[i] for i in ids]
+
+        a, b = run(1), run(0)
+        assert a == b
+        assert all(len(t) == 14 for t in a)
+    finally:
+        m.debug_set("sample_rows", 1)
+        m.close()
+
+
 def test_step_many_matches_single_steps():
     """cm_engine_step_many: several scheduling decisions per native call, same event stream."""
     from crane_amd import configs
