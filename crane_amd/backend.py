@@ -156,12 +156,14 @@ class Model:
     def from_pretrained(cls, model_dir: str, **kw) -> "Model":
         """Model::new / from_pretrained (qwen3/model.rs:45-106)."""
         lib = _lib.load()
+        live = cls._live_switches(kw)
         o, keep = cls._opts(**kw)
         h = C.c_void_p()
         rc = lib.cm_create(model_dir.encode(), C.byref(o), C.byref(h))
         if rc != 0:
             raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
         m = cls(h, lib)
+        m._apply_live(live)
         try:
             with open(f"{model_dir}/config.json") as f:
                 e = json.load(f).get("eos_token_id")
@@ -176,12 +178,27 @@ class Model:
     @classmethod
     def synthetic(cls, config: dict, seed: int = 0, **kw) -> "Model":
         lib = _lib.load()
+        live = cls._live_switches(kw)
         o, keep = cls._opts(**kw)
         h = C.c_void_p()
         rc = lib.cm_create_synthetic(json.dumps(config).encode(), seed, C.byref(o), C.byref(h))
         if rc != 0:
             raise _lib.CraneError(rc, lib.cm_last_global_error().decode())
-        return cls(h, lib)
+        m = cls(h, lib)
+        m._apply_live(live)
+        return m
+
+    # test / A-B switches that are not part of cm_opts: applied with cm_debug_set right after creation (before any step), so that
+    # tests do not have to steer the library through the process environment
+    @staticmethod
+    def _live_switches(kw: dict) -> dict:
+        return {k: kw.pop(k) for k in ("quant_act", "quant_prefill") if k in kw}
+
+    def _apply_live(self, live: dict):
+        if "quant_act" in live:          # "int": ggml vec_dot semantics (Q8 activations, integer dots); "f32": exact dequant x f32
+            self.debug_set("quant_act_int", 0 if live["quant_act"] == "f32" else 1)
+        if "quant_prefill" in live:      # False: prompts over quantised weights through the decode kernels (token-serial)
+            self.debug_set("quant_prefill", 1 if live["quant_prefill"] else 0)
 
     def close(self):
         if self._h:

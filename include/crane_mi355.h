@@ -453,7 +453,11 @@ int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x
  * "attn_mfma_min" / "attn_mfma_wide_min" / "attn_heads_max" / "attn_ns": the context thresholds and split counts that pick the
  * decode-attention kernel (CM_ATTN_* read at cm_create); "engine" = 0 / 1 and "engine_full" = 0 / 1: the persistent decode
  * kernel off / on and its per-layer / whole-token mode (only where cm_create found the shapes eligible); "quant_act_int" = 1 / 0
- * and "vision_merger_gelu" = 1 (tanh) / 2 (erf): CM_QUANT_ACT and CM_VISION_MERGER_GELU of the live model.
+ * and "vision_merger_gelu" = 1 (tanh) / 2 (erf): CM_QUANT_ACT and CM_VISION_MERGER_GELU of the live model; "gemm256" = 0 / 1: the
+ * LDS-DMA GEMM of the prompt pass and of large decode groups; "lm_head_gemm_min" = n: decode groups of n or more sequences run
+ * lm_head as one GEMM + row arg-max (0 = never); "sample_rows" = 0 / 1: the engine's sampled rows through the per-row sampler /
+ * one set of launches for all rows (same tokens); "tp_graph" = 0 / 1: RCCL collectives launched eagerly / captured into the
+ * decode hipGraph (CM_TP_GRAPH).
  * cm_debug_read("engine_trace") launches the persistent kernel several times on the live state of sequence 0: the K/V rows at
  * the current position and the residual stream are overwritten -- clear the sequence afterwards. */
 int cm_debug_set(cm_model* m, const char* key, int64_t value);

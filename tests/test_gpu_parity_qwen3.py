@@ -268,12 +268,10 @@ def test_prefill_f32_kv_and_plain_bf16_modes():
 
 
 @pytest.mark.parametrize("tp_graph", ["1", "0"])
-def test_rccl_code_path_single_rank(tp_graph, monkeypatch):
+def test_rccl_code_path_single_rank(tp_graph):
     """cm_opts.debug_flags = CM_DEBUG_FORCE_RCCL: the tp=1 reductions go through a 1-rank RCCL communicator (dlopen, unique-id ABI,
     all-reduce + all-gather on the model's stream), captured into the decode hipGraph (CM_TP_GRAPH=1, the default) or
     launched eagerly (0).  Results must equal the collective-free path."""
-    import os
-    monkeypatch.setenv("CM_TP_GRAPH", tp_graph)
     cfg = configs.get_config("tiny-qwen3-untied")
     ids = configs.synthetic_prompt(40, cfg["vocab_size"])
     def batched(m):        # cm_decode_batch: 3 sequences (matrix-core GEMVs), all-reduce of [3, H] + in-place gathers
@@ -290,6 +288,7 @@ def test_rccl_code_path_single_rank(tp_graph, monkeypatch):
         m.close()
     m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=4, debug_force_rccl=True)
     try:
+        m.debug_set("tp_graph", int(tp_graph))
         b = m.forward_step(ids, 0)[0, 0]
         b2 = m.forward_step([7], 40)[0, 0]
         b3, h3 = batched(m)

@@ -65,10 +65,8 @@ def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
     if act == "int":
         oracle.qmats = G.qwen3_oracle_qmats(cfg, qm)
-    else:
-        monkeypatch.setenv("CM_QUANT_ACT", "f32")
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")        # prompts through the decode kernels: one arithmetic end to end
-    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    # quant_prefill=False: prompts through the decode kernels, one arithmetic end to end
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", quant_act=act, quant_prefill=False)
     try:
         assert m.vocab_size == cfg["vocab_size"] and m.num_layers() == cfg["num_hidden_layers"]
         # kernel level: ONE projection on identical inputs -- integer block sums are exact, only the f32 accumulation
@@ -119,15 +117,14 @@ def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name):
         if any(k.endswith(f"{l}.weight") for l in LINEARS) or (k == "lm_head.weight" and not cfg.get("tie_word_embeddings", True)):
             deq[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
-    monkeypatch.setenv("CM_QUANT_ACT", "f32")          # isolates the weight quantiser; the int path is covered by the GGUF test
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
+    sw = dict(quant_act="f32", quant_prefill=False)    # f32 activations isolate the weight quantiser; the int path is covered by the GGUF test
     for how in ("opt", "env"):
         if how == "env":
             monkeypatch.setenv("CRANE_ISQ", "q8_0")
-            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32")
+            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", **sw)
             monkeypatch.delenv("CRANE_ISQ")
         else:
-            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
+            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", **sw)
         try:
             _check(m, oracle, cfg["vocab_size"])
         finally:
@@ -145,17 +142,14 @@ def test_quantised_prefill_through_dequantised_gemm(tmp_path, monkeypatch, kind)
     path = str(tmp_path / f"p-{kind}.gguf")
     deq = G.write_qwen3_gguf(path, cfg, w, _types(kind))
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
-    monkeypatch.setenv("CM_QUANT_ACT", "f32")
     ids = configs.synthetic_prompt(70, cfg["vocab_size"])
     ref = oracle.forward(ids, 0)
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")                       # (environment switches are read at cm_create)
-    ms = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    ms = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", quant_act="f32", quant_prefill=False)
     try:
         serial = ms.forward_step(ids, 0).reshape(-1)                  # token-serial decode kernels
     finally:
         ms.close()
-    monkeypatch.delenv("CM_QUANT_PREFILL")
-    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", quant_act="f32")
     try:
         got = m.forward_step(ids, 0).reshape(-1)                      # MFMA prefill (dequant -> bf16 scratch)
         assert rel(serial, ref) < 2e-4
@@ -183,9 +177,8 @@ def test_quant_errors():
         del os.environ["CRANE_ISQ"]
     with pytest.raises(CraneError):
         Model.from_pretrained("/nonexistent/model.gguf")
-    os.environ["CM_QUANT_ACT"] = "f32"          # no batched kernel for f32 activations: cm_decode_batch steps one sequence at a time
-    try:
-        m = Model.synthetic(cfg, seed=0, isq="q8_0", max_seqs=4)
+    try:                                        # no batched kernel for f32 activations: cm_decode_batch steps one sequence at a time
+        m = Model.synthetic(cfg, seed=0, isq="q8_0", max_seqs=4, quant_act="f32")
         try:
             m.seq_forward(0, [4, 5], 0, want_logits=False)
             s = m.seq_alloc()
@@ -198,7 +191,7 @@ def test_quant_errors():
         finally:
             m.close()
     finally:
-        del os.environ["CM_QUANT_ACT"]
+        pass
 
 
 def test_isq_q8_0_hybrid_family(monkeypatch):
@@ -218,10 +211,9 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
             nq += 1
     assert nq > 0 and any(k.endswith("in_proj_a.weight") for k in w)
     o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), deq)
-    monkeypatch.setenv("CM_QUANT_ACT", "f32")
     V = cfg["vocab_size"]
     ids = configs.synthetic_prompt(33, V)
-    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", quant_act="f32")
     try:
         m.debug_set("quant_prefill", 0)
         ref = o.forward(ids, 0)
@@ -240,7 +232,6 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
     finally:
         m.close()
     # integer-dot default: same model, loose agreement with the float-activation result
-    monkeypatch.delenv("CM_QUANT_ACT")
     m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0")
     try:
         m.debug_set("quant_prefill", 0)
@@ -273,11 +264,9 @@ def test_qwen35_gguf_checkpoint(tmp_path, monkeypatch, kind):
     path = str(tmp_path / f"q35-{kind}.gguf")
     deq = G.write_qwen35_gguf(path, cfg, w, type_of)
     o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), deq)
-    monkeypatch.setenv("CM_QUANT_ACT", "f32")
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
     V = cfg["vocab_size"]
     ids = configs.synthetic_prompt(21, V)
-    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32")
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", quant_act="f32", quant_prefill=False)
     try:
         assert m.num_layers() == cfg["num_hidden_layers"] and m.vocab_size == V
         ref = o.forward(ids, 0)
@@ -330,8 +319,7 @@ def test_batched_decode_over_gguf_weights(tmp_path, monkeypatch, kind, nb):
     w = synth.synth_weights_f32(cfg, seed=0)
     path = str(tmp_path / f"{name}-{kind}.gguf")
     G.write_qwen3_gguf(path, cfg, w, _types(kind))
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
-    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", max_seqs=26)
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", max_seqs=26, quant_prefill=False)
     try:
         if nb > 8:
             m.debug_set("attn_splits", 8)       # the automatic split count shrinks with the batch: pin it so that the
@@ -345,8 +333,7 @@ def test_batched_decode_over_gguf_weights(tmp_path, monkeypatch, kind, nb):
 def test_batched_decode_isq_hybrid(monkeypatch, nb):
     from crane_amd.backend import Model
     cfg = configs.get_config("tiny-qwen3.5")
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
-    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", max_seqs=10)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", max_seqs=10, quant_prefill=False)
     try:
         _batched_vs_sequential(m, cfg["vocab_size"], nb, rounds=2)
     finally:

@@ -16,10 +16,10 @@ def rel(a, ref):
     return float(np.abs(a - ref).max() / np.abs(ref).max())
 
 
-def _run_rank(cfg, rank, world, ids, isq=None):
+def _run_rank(cfg, rank, world, ids, isq=None, **live):
     from crane_amd.backend import Model
     m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
-                        tp_unique_id=b"\0" * 128, isq=isq, debug_tp_local=True)
+                        tp_unique_id=b"\0" * 128, isq=isq, debug_tp_local=True, **live)
     try:
         a = m.forward_step(ids, 0)[0, 0]
         b = m.forward_step([5], len(ids))[0, 0]
@@ -69,8 +69,6 @@ def test_dense_rank_shards_isq_q8_0(monkeypatch):
     projections feed the all-reduce, the vocabulary-sharded quantised lm_head feeds the arg-max gather."""
     from oracle import gguf_oracle as G
     from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
-    monkeypatch.setenv("CM_QUANT_ACT", "f32")
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
     cfg = configs.get_config("tiny-qwen3-untied")
     w = synth.synth_weights_f32(cfg, 0)
     ids = configs.synthetic_prompt(21, cfg["vocab_size"])
@@ -85,7 +83,7 @@ def test_dense_rank_shards_isq_q8_0(monkeypatch):
         local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads),
                      intermediate_size=len(plan.inter))
         o = Qwen3Oracle(Qwen3Config.from_json(local), sw)
-        got_a, got_b = _run_rank(cfg, rank, world, ids, isq="q8_0")
+        got_a, got_b = _run_rank(cfg, rank, world, ids, isq="q8_0", quant_act="f32", quant_prefill=False)
         v = slice(plan.vocab.start, plan.vocab.stop)
         assert rel(got_a[v], o.forward(ids, 0)) < 2e-4 and rel(got_b[v], o.forward([5], len(ids))) < 2e-4
 
@@ -137,8 +135,6 @@ def test_dense_rank_shards_gguf(tmp_path, monkeypatch, kind):
     from oracle import gguf_oracle as G
     from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
     from tests.test_gpu_quant import _types
-    monkeypatch.setenv("CM_QUANT_ACT", "f32")
-    monkeypatch.setenv("CM_QUANT_PREFILL", "0")
     cfg = configs.get_config("tiny-qwen3-untied")            # per rank at tp = 2: 512 o_proj columns, 768 down_proj columns
     w = synth.synth_weights_f32(cfg, 0)
     path = str(tmp_path / f"tp-{kind}.gguf")
@@ -152,7 +148,7 @@ def test_dense_rank_shards_gguf(tmp_path, monkeypatch, kind):
                      intermediate_size=len(plan.inter))
         o = Qwen3Oracle(Qwen3Config.from_json(local), sw)
         m = Model.from_pretrained(path, max_seq_len=128, max_seqs=2, kv_dtype="f32", tp_rank=rank, tp_size=world,
-                                  tp_unique_id=b"\0" * 128, debug_tp_local=True)
+                                  tp_unique_id=b"\0" * 128, debug_tp_local=True, quant_act="f32", quant_prefill=False)
         try:
             got_a = m.forward_step(ids, 0)[0, 0]
             got_b = m.forward_step([5], len(ids))[0, 0]
