@@ -7,7 +7,7 @@
 
 namespace cm {
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_ATTNCOMB = 2 };
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_ATTNCOMB = 2, PRO_GDNNORM = 3 };
 enum { EPI_STORE = 0, EPI_RESADD = 1, EPI_SILUMUL = 2, EPI_ARGMAX = 3 };
 
 struct GemvArgs {
@@ -25,6 +25,10 @@ struct GemvArgs {
     const float* part_ml = nullptr;   // [Hq][ns][2]
     const float* gate = nullptr;      // [Hq * D] or null
     int ns = 0, dshift = 0;           // D == 1 << dshift
+    // PRO_GDNNORM: x = RAW y of the Gated-Delta-Net step [NV * 128]; the gated RMSNorm of each 128-wide value head
+    // (y * rsqrt(mean(y^2) + eps) * w * silu(z), ops/gdn/layer.rs:226-238) is applied while staging
+    const float* gdn_z = nullptr;     // [NV * 128] z gate of this token (inside the in_proj output)
+    const float* gdn_w = nullptr;     // [128] RMSNormGated weight
 };
 
 struct AttnDecArgs {
@@ -67,6 +71,8 @@ struct GdnArgs {
     float* pre_bd = nullptr;
     float* gdn_scratch = nullptr;   // decode step on 4 workgroups per head: [n_seq][NV][V + 4] raw y + partial sums of squares
     int* gdn_ticket = nullptr;      //   and [n_seq][NV] arrival tickets (zero between launches); null: one workgroup per head
+    int defer_norm = 0;         // decode step: out = RAW y, the gated RMSNorm is the out_proj GEMV's prologue (PRO_GDNNORM) -- no
+                                //   cross-workgroup hand-off inside the step
     int chunked = 0;            // value-head order: 0 Interleaved (HF: key head = v / vpg), 1 Chunked (llama.cpp GGUF: v % NK; ops/gdn/config.rs:13-22)
     int n_seq, batch_proj_stride, batch_out_stride;   // batched decode step (grid.y)
     float eps;

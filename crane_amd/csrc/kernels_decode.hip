@@ -104,6 +104,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (PIPE ? 3 : 4) : 2) void gemv_bf
     // PRO_ATTNCOMB: x is not materialised -- it is the merge of the NS per-head partials left by
     // attn_decode_head_kernel: x[h*D + d] = sum_s e^{m_s - M} o_s[d] / sum_s e^{m_s - M} l_s  (* sigmoid(gate))
     auto xload = [&](int k4i) -> f32x4 {
+        if (PRO == PRO_GDNNORM) {
+            // a value head = 128 consecutive values = the float4 of 32 consecutive lanes (an aligned half-wave: NT and K / 4 are
+            // multiples of 32, so a half-wave is active as a whole): sum of squares over the head with five xor steps
+            f32x4 v = *(const f32x4*)(a.x + (k4i << 2));
+            float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8); ss += __shfl_xor(ss, 16);
+            const float rms = 1.0f / sqrtf(ss / 128.0f + a.eps);
+            const f32x4 z = *(const f32x4*)(a.gdn_z + (k4i << 2));
+            const f32x4 w = *(const f32x4*)(a.gdn_w + ((k4i & 31) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * rms * w[e] * (z[e] / (1.0f + expf(-z[e])));
+            return v;
+        }
         if (PRO != PRO_ATTNCOMB) return *(const f32x4*)(a.x + (k4i << 2));
         const int k = k4i << 2, h = k >> a.dshift, d = k & ((1 << a.dshift) - 1);
         const float* ml = a.part_ml + (size_t)h * a.ns * 2;
@@ -372,6 +385,11 @@ void launch_gemv(int pro, int epi, const GemvArgs& a, int grid, hipStream_t s) {
     if (pro == PRO_ATTNCOMB) {          // only o_proj uses it (row-parallel under TP: store, else residual add)
         if (epi == EPI_STORE) launch_gemv_t<PRO_ATTNCOMB, EPI_STORE>(a, grid, s);
         else launch_gemv_t<PRO_ATTNCOMB, EPI_RESADD>(a, grid, s);
+        return;
+    }
+    if (pro == PRO_GDNNORM) {           // out_proj of a Gated-Delta-Net layer (row-parallel under TP: store, else residual add)
+        if (epi == EPI_STORE) launch_gemv_t<PRO_GDNNORM, EPI_STORE>(a, grid, s);
+        else launch_gemv_t<PRO_GDNNORM, EPI_RESADD>(a, grid, s);
         return;
     }
     if (pro == PRO_PLAIN) {

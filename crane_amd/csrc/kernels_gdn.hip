@@ -203,6 +203,15 @@ __global__ __launch_bounds__(256) void gdn_decode_kernel(GdnArgs a) {
     __syncthreads();                                           // everyone has read part[][] (kv)
     part[ksl][c] = y2[0] + y2[1];
     __syncthreads();
+    if (a.defer_norm) {          // single-sequence decode: the out_proj GEMV normalises while it stages x (PRO_GDNNORM)
+        if (tid < CB) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) y += part[j][tid];
+            a.out[(size_t)bq * a.batch_out_stride + h * V + cb * CB + tid] = y;
+        }
+        return;
+    }
     // ---- raw y of the block's 32 columns + partial sum of squares -> write-through; ticket; last arriver normalises ----
     float* yraw = a.gdn_scratch + ((size_t)bq * a.NV + h) * (V + 4);
     int* ticket = a.gdn_ticket + (size_t)bq * a.NV + h;

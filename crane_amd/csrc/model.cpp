@@ -254,6 +254,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN")) attn_mfma_min = atoll(e);
+    if (const char* e = getenv("CM_GDN_DEFER_NORM")) gdn_defer_norm = atoi(e) != 0;
     if (const char* e = getenv("CM_ATTN_BATCH_NS_MIN")) attn_batch_ns_min = std::max(1, atoi(e));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN_BATCH")) attn_mfma_min_batch = atoll(e);
     if (const char* e = getenv("CM_ATTN_MFMA_WIDE_MIN")) attn_mfma_wide_min = atoll(e);
@@ -785,13 +786,21 @@ void Model::enqueue_decode_step(bool advance) {
             ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
             ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
             ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
+            // the gated RMSNorm of the value heads moves into out_proj's prologue: the GDN step then ends at its raw y, without
+            // the ticket + read-back hand-off between the four workgroups of a head (gdn_defer_norm; needs the 4-workgroup step)
+            // (every GEMV workgroup repeats the norm of all heads while staging: a win for 16 heads -- Qwen3.5-0.8B 1349 -> 1394
+            // tok/s --, a loss for the 48 heads of Qwen3.8-27B, 110.2 -> 108.8: there the step keeps its own norm)
+            const bool defer = gdn_defer_norm && gdn_scratch != nullptr && cfg.value_dim() % 128 == 0 && cfg.value_dim() <= gdn_defer_max;
+            ga.defer_norm = defer ? 1 : 0;
             launch_gdn(ga, s);
             g = GemvArgs{};
-            g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K;
-            if (!rccl) { g.y = x; g.res = x; launch_gemv(PRO_PLAIN, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
+            g.W = w.out_proj; g.x = attn; g.N = H; g.K = cfg.value_dim(); g.ldw = g.K; g.eps = cfg.eps;
+            g.gdn_z = qkv + (2 * cfg.key_dim() + cfg.value_dim()); g.gdn_w = w.gnorm;
+            const int opro_g = defer ? PRO_GDNNORM : PRO_PLAIN;
+            if (!rccl) { g.y = x; g.res = x; launch_gemv(opro_g, EPI_RESADD, g, gemv_grid(g.N, g.K, num_cu), s); }
             else {
                 g.y = y; g.res = x;
-                launch_gemv(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+                launch_gemv(opro_g, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
                 rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
             }
         } else {

@@ -358,3 +358,37 @@ def test_hybrid_decode_attention_on_the_mfma_kernel(kv):
             tok = int(ref.argmax())
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_gated_norm_in_the_out_proj_prologue_equals_the_in_step_norm():
+    """Single-sequence decode: the Gated-Delta-Net step ends at its raw y and the out_proj GEMV applies the gated RMSNorm of each
+    128-wide value head while it stages x (PRO_GDNNORM, the default) -- against the step that normalises itself through the
+    last-arriving workgroup (cm_debug_set("gdn_defer_norm", 0)): same logits up to the association of the 128-term sum of squares,
+    same greedy tokens; and against the oracle."""
+    from crane_amd import configs, synth
+    from crane_amd.backend import GenerationConfig, Model
+    from oracle import qwen3_5_oracle as O5
+    cfg = configs.get_config("tiny-qwen3.5")
+    o = O5.Qwen35Oracle(O5.Qwen35Config.from_json(cfg), synth.synth_weights_f32(cfg, seed=0))
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
+    try:
+        ids = configs.synthetic_prompt(19, cfg["vocab_size"])
+        outs = []
+        for defer in (1, 0):
+            m.debug_set("gdn_defer_norm", defer)
+            m.clear_kv_cache()
+            m.forward_step(ids, 0)
+            lg = [m.forward_step([7 + i], 19 + i)[0, 0].copy() for i in range(4)]
+            m.clear_kv_cache()
+            toks = m.generate(ids, GenerationConfig.greedy(12))
+            outs.append((lg, toks))
+        o.forward(ids, 0)
+        for i in range(4):
+            ref = o.forward([7 + i], 19 + i)
+            assert rel(outs[0][0][i], ref) < 1e-4, (i, rel(outs[0][0][i], ref))
+            assert rel(outs[0][0][i], outs[1][0][i]) < 1e-5, (i, rel(outs[0][0][i], outs[1][0][i]))
+        assert outs[0][1] == outs[1][1]
+    finally:
+        m.debug_set("gdn_defer_norm", 1)
+        m.close()
