@@ -420,6 +420,10 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
 // and P are then f16 hi + lo), KV_F32 (f32 rows split into bf16 hi + lo on load: the ViT scratch, f32 pages, the int8 / int4 shadow)
 // KV_BF16X2 (the ViT scratch): K/V rows arrive pre-split into bf16 hi + lo arrays -- the three-product arithmetic of KV_F32
 // without a conversion in the loop.
+// e^x for x <= 0 (softmax numerators after the running max): v_exp_f32 (2^x, 1 ulp) on x * log2(e) -- two instructions where
+// expf()'s range reduction and polynomial are ~20; 17 of them per lane and key tile were a quarter of the tile's VALU work
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 template <int D, int KVT>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     constexpr bool KVF32 = KVT == KV_F32, X2 = KVT == KV_BF16X2, THREE = KVF32 || X2;
@@ -530,14 +534,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
         mt = fmaxf(mt, __shfl_xor(mt, 16));
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);               // finite: token 0 is visible to every query
-        const float alpha = expf(m_run - m_new);
+        const float alpha = fast_exp(m_run - m_new);
         float psum = 0.f;
         bf16x4 ph[4], pl[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = expf(s[tt][r] - m_new);      // exp(-inf) = 0 for masked tokens
+                const float p = fast_exp(s[tt][r] - m_new);  // exp(-inf) = 0 for masked tokens
                 psum += p;
                 const uint16_t hh = kv16_from_f32<KVT>(p);
                 ph[tt][r] = (short)hh;
