@@ -248,8 +248,11 @@ def main():
         # PMC traffic cannot be collected inside this process: it comes from the committed rocprofv3 --pmc passes
         # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch
         try:
-            if args.model == "qwen3-8b" and not args.isq and n == 1:
-                for src in ("r03_pmc_traffic_decode.json", "r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json"):
+            if not args.isq and n == 1:
+                san = args.model.replace("-", "_").replace(".", "_")
+                srcs = ("r03_pmc_traffic_decode.json", "r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json") \
+                    if args.model == "qwen3-8b" else (f"r03_pmc_traffic_decode_{san}.json",)
+                for src in srcs:
                     path = os.path.join(ROOT, "profiles", src)
                     if not os.path.exists(path):
                         continue
