@@ -1053,7 +1053,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
                 launch_add_rows(pX, pY, (size_t)S * H, s);
             }
         } else {
-        g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
+        g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 1)) ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
         if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
             for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], wq_scratch + (size_t)w.qkv_row0[i] * H, 1, 0, s);
             g.W = wq_scratch;
@@ -1093,7 +1093,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
         }
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-        g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
+        g.A_hi = pAT_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 2)) ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
         if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
         if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
         else {
@@ -1104,7 +1104,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         }   // full-attention layer
         launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-        g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
+        g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 4)) ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
         if (quantized) {
             if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
             else { launch_dequant_bf16(w.q_gate, wq_scratch, 2, 0, s); launch_dequant_bf16(w.q_up, wq_scratch, 2, 1, s); }
@@ -1113,7 +1113,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
         launch_gemm(g, GEPI_SILUMUL, s);
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
-        g.A_hi = pHH_hi; g.A_lo = sp2 ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
+        g.A_hi = pHH_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 8)) ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
         if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
         if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
         else {
