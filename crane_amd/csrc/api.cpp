@@ -356,6 +356,12 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
             for (size_t i = 0; i < n; ++i) { const uint32_t b = (uint32_t)g[i]; memcpy(&out[i], &b, 4); }
             return;
         }
+        if (w == "vision_ms") {            // HIP-event time of the tower's kernels in the LAST cm_vision_encode / cm_vlm_forward, milliseconds
+            if (n < 1 || !h->m.v_timed) throw CmError(CM_ERR_INVALID, "vision_ms: no vision encode has run");
+            CM_HIP(hipEventSynchronize(h->m.v_ev1));
+            CM_HIP(hipEventElapsedTime(&out[0], h->m.v_ev0, h->m.v_ev1));
+            return;
+        }
         if (w == "deepstack") {            // [n_deepstack][rows][out_hidden] DeepStack feature maps of the LAST cm_vision_encode / cm_vlm_forward
             const size_t nd = h->m.vcfg.deepstack.size(), oh = (size_t)h->m.vcfg.out_hidden;
             if (nd == 0 || !h->m.vDeep || n % (nd * oh) != 0 || n / nd > h->m.deep_stride) throw CmError(CM_ERR_RANGE, "deepstack: n must be n_maps * rows * out_hidden");

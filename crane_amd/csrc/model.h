@@ -169,6 +169,8 @@ struct Model {
     float *vX = nullptr, *vQKV = nullptr, *vFeat = nullptr, *vCos = nullptr, *vSin = nullptr, *vPix = nullptr, *vW4 = nullptr;
     uint16_t *vK = nullptr, *vV = nullptr;   // [2 (bf16 hi, lo)][pages][heads][64][64] K / V scratch of one block
     size_t vkv_lo_off = 0;
+    hipEvent_t v_ev0 = nullptr, v_ev1 = nullptr;   // around the tower's kernels of the last vision_encode (cm_debug_read "vision_ms")
+    bool v_timed = false;
     float *vPartO = nullptr, *vPartML = nullptr;   // split-KV partials of the frame attention (VIT_KSPLIT runs of key tiles)
     int vit_ksplit = 4;                             // CM_VIT_KSPLIT
     uint16_t *vA_hi = nullptr, *vA_lo = nullptr, *vB_hi = nullptr, *vB_lo = nullptr, *vQ_hi = nullptr, *vQ_lo = nullptr;

@@ -107,6 +107,9 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     CM_HIP(hipMemcpyAsync(vSin, sn.data(), sn.size() * sizeof(float), hipMemcpyHostToDevice, s));
     CM_HIP(hipMemcpyAsync(vPix, pix, (size_t)N * vcfg.patch_dim() * sizeof(float), hipMemcpyHostToDevice, s));
     CM_HIP(hipStreamSynchronize(s));          // the host vectors die at scope exit
+    // device time of the tower itself (inputs resident in HBM from here on): cm_debug_read("vision_ms") after the call
+    if (!v_ev0) { CM_HIP(hipEventCreate(&v_ev0)); CM_HIP(hipEventCreate(&v_ev1)); }
+    CM_HIP(hipEventRecord(v_ev0, s));
 
     auto gemm = [&](const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* W, const float* bias, int Mrows, int Ncols, int K,
                     int epi, float* C, uint16_t* h_hi, uint16_t* h_lo, int act) {
@@ -157,6 +160,8 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     const int G = N / M;
     gemm(vA_hi, vA_lo, vw.mfc1_w, vw.mfc1_b, G, VH * M, VH * M, GEPI_ACT_SPLIT, nullptr, vB_hi, vB_lo, vcfg.merger_act);
     gemm(vB_hi, vB_lo, vw.mfc2_w, vw.mfc2_b, G, vcfg.out_hidden, VH * M, GEPI_STORE, vFeat, nullptr, nullptr, 0);
+    CM_HIP(hipEventRecord(v_ev1, s));
+    v_timed = true;
     return G;
 }
 
