@@ -38,6 +38,10 @@ CONFIGS = {
     "eng-qwen3-gqa2": dict(_QWEN3_COMMON, vocab_size=2048, hidden_size=2048, intermediate_size=6144,
                            num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=8,
                            head_dim=128, tie_word_embeddings=True, max_position_embeddings=8192),
+    # Qwen3-0.6B widths (hidden 1024, intermediate 3072: multiples of 1024 only -> the persistent kernel's 1024-element chunks)
+    "eng-qwen3-h1024": dict(_QWEN3_COMMON, vocab_size=2048, hidden_size=1024, intermediate_size=3072,
+                            num_hidden_layers=3, num_attention_heads=16, num_key_value_heads=8,
+                            head_dim=128, tie_word_embeddings=True, max_position_embeddings=8192),
     # small shapes for CPU-oracle parity
     "tiny-qwen3": dict(_QWEN3_COMMON, vocab_size=512, hidden_size=256, intermediate_size=512,
                        num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,

@@ -255,6 +255,7 @@ struct EngArgs {
     int Hkv, page, max_pages, q_off, k_off, v_off;
     int kv_f16;                   // K/V pages hold IEEE binary16 (CM_KV_F16) instead of bf16
     int nrep;                     // GQA group size of the in-kernel attention: 4 (Qwen3-8B) or 2 (Qwen3-VL-2B text, Qwen3-1.7B)
+    int chunk;                    // input elements per dependency chunk / weight batch: 2048, or 1024 (Qwen3-0.6B widths)
     float eps, scale;
     int tune;                     // polling parameters (CM_ENG_TUNE while tuning), see kernels_engine.hip
     int dbg;                      // timing experiments (CM_ENG_DBG), see kernels_engine.hip; 0 in production
@@ -262,7 +263,8 @@ struct EngArgs {
 struct EngCfg { int nsw, ncw, pf; };
 EngCfg engine_config();           // the instantiation the launcher uses (default, or CM_ENG_CFG while tuning)
 size_t engine_lds_bytes(const EngArgs& a, int nsw, int ncw);
-bool engine_prepare(size_t lds_bytes, int nrep);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
+bool engine_prepare(size_t lds_bytes, int nrep, int chunk);   // raises the dynamic-LDS limit of the kernel; call once outside any stream capture
+bool engine_has_chunk(int chunk);        // dependency chunk size the launcher has an instantiation for (2048; 1024 in the default configuration)
 bool engine_has_nrep(int nrep);          // the in-kernel attention is instantiated for this GQA group size
 bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace = false);
 

@@ -36,8 +36,9 @@ namespace cm {
 namespace {
 
 constexpr int R = 2;            // rows per group (one wave reduces R rows at a time)
-constexpr int U = 4;            // 512-element chunks per batch: a batch = R x U 16-byte loads per lane = 8 KiB per wave
-constexpr int CHUNK = U * 512;  // input elements one batch consumes
+// U (template parameter UC of the kernel) = 512-element pieces per batch: a batch = R x U 16-byte loads per lane = 8 KiB per wave at
+// U = 4 (CHUNK = 2048 input elements, the dependency granule of widths that are multiples of 2048) or 4 KiB at U = 2 (CHUNK =
+// 1024: hidden 1024 / intermediate 3072 of Qwen3-0.6B)
 constexpr int MAXCH = 8;        // chunks per input vector (K <= 16384)
 constexpr int MAXGB = 6;        // row groups a wave keeps open
 constexpr int MAXRES = 4;       // residual row groups per wave
@@ -86,13 +87,14 @@ __device__ __forceinline__ int xperm(int k) {
 enum { C_PROG = 0,      // batches finished by this workgroup's stream waves (monotonic over the launch)
        C_ABORT = 1,
        C_CBAR = 2,      // barrier counter of the comm waves
-       C_CNT = 4,       // [4 counter rows][MAXCH]: passes staged (monotonic; 2 passes per chunk)
+       C_CNT = 4,       // [4 counter rows][MAXCH]: passes staged (monotonic; PPC = 2 or 1 passes per chunk)
        C_WORDS = 64 };
 
 }  // namespace
 
-template <int NSW, int NCW, int PF, int NREP, bool TRACE>
+template <int NSW, int NCW, int PF, int NREP, bool TRACE, int UC>
 __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_kernel(EngArgs a) {
+    constexpr int U = UC, CHUNK = UC * 512, PPC = CHUNK / 1024;      // PPC: 1024-granule staging passes per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -463,7 +465,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             } else {
                 stamp(p - p0, 1);
             }
-            // ---- stage this phase's input: 1024 granules per pass, passes cw, cw + NCW, ...; chunk c = passes 2c, 2c + 1 ----
+            // ---- stage this phase's input: 1024 granules per pass, passes cw, cw + NCW, ...; chunk c = passes PPC * c ... ----
             {
                 gf_cptr nw = (gf_cptr)P->nw;
                 float* xs = lds + P->xoff;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (lane == 0) ssq[(xbuf & 1) * 16 + pass] = ss;
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) lds_add(&ctrl[C_CNT + xbuf * MAXCH + (pass >> 1)], 1u);
+                    if (lane == 0) lds_add(&ctrl[C_CNT + xbuf * MAXCH + pass / PPC], 1u);
                 }
                 stamp(p - p0, 3, (u64)total_spins);
             }
@@ -640,13 +642,13 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             ctag = base + (uint32_t)cc.P->out_tag;
             cplain = a.plain_last != 0 && cc.ph == p1 - 1;
             xs4 = (const f32x4*)(lds + cc.P->xoff);
-            // two staged passes per chunk and per phase of this launch that has used the counter row (this one included)
+            // PPC staged passes per chunk and per phase of this launch that has used the counter row (this one included)
             const int ub = cxbuf == 0 ? a.ub0 : cxbuf == 1 ? a.ub1 : cxbuf == 2 ? a.ub2 : a.ub3;
-            cneed = 2u * (uint32_t)(cc.P->useq - ub + 1);
+            cneed = (uint32_t)PPC * (uint32_t)(cc.P->useq - ub + 1);
             nready = 0;
             stamp(cc.ph - p0, 0);
         }
-        if (cc.kb >= nready) {                // first touch of this chunk: wait until its two passes are staged
+        if (cc.kb >= nready) {                // first touch of this chunk: wait until its passes are staged
             uint32_t spins = 0;
             const uint32_t* w = &ctrl[C_CNT + cxbuf * MAXCH + cc.kb];
             while (!dbg_nowait && lds_ld(w) < cneed && lds_ld(&ctrl[C_ABORT]) == 0u) {
@@ -754,7 +756,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             if (lane == 0) ssq[(PF0->xbuf & 1) * 16 + wave] = ss;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + (wave >> 1)], 1u);
+        if (lane == 0) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + wave / PPC], 1u);
     }
     while (cc.ph < p1) {
 #pragma unroll
@@ -791,10 +793,10 @@ EngCfg engine_config() {
     return c;
 }
 
-template <int NSW, int PF, int NREP = 4>
+template <int NSW, int PF, int NREP = 4, int UC = 4>
 static bool prepare_v(size_t lds_bytes) {
-    auto k = engine_kernel<NSW, ENG_NCW, PF, NREP, false>;
-    auto kt = engine_kernel<NSW, ENG_NCW, PF, NREP, true>;
+    auto k = engine_kernel<NSW, ENG_NCW, PF, NREP, false, UC>;
+    auto kt = engine_kernel<NSW, ENG_NCW, PF, NREP, true, UC>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -810,10 +812,16 @@ static bool prepare_v(size_t lds_bytes) {
     return true;
 }
 
-template <int NSW, int PF, int NREP = 4>
+template <int NSW, int PF, int NREP = 4, int UC = 4>
 static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool trace) {
-    if (trace) hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, true>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
-    else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, false>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    if (trace) hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, true, UC>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+    else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, false, UC>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
+}
+
+// dependency chunk of 1024 input elements (widths that are multiples of 1024 but not of 2048): the default configuration only
+bool engine_has_chunk(int chunk) {
+    const EngCfg c = engine_config();
+    return chunk == 2048 || (chunk == 1024 && c.nsw == 4 && c.pf == 4);
 }
 
 // GQA group sizes of the in-kernel attention: 4 in every tuning configuration, 2 in the default one
@@ -829,8 +837,12 @@ bool engine_has_nrep(int nrep) {
     else if (c.pf == 6) { CALL(4, 6) }                                     \
     else { CALL(4, 4) }
 
-bool engine_prepare(size_t lds_bytes, int nrep) {
+bool engine_prepare(size_t lds_bytes, int nrep, int chunk) {
     const EngCfg c = engine_config();
+    if (chunk == 1024) {
+        if (!engine_has_chunk(1024)) return false;
+        return nrep == 2 ? prepare_v<4, 4, 2, 2>(lds_bytes) : prepare_v<4, 4, 4, 2>(lds_bytes);
+    }
     if (nrep == 2 && engine_has_nrep(2)) return prepare_v<4, 4, 2>(lds_bytes) && prepare_v<4, 4, 4>(lds_bytes);
 #define CM_ENG_PREP(N, P) return prepare_v<N, P>(lds_bytes);
     CM_ENG_DISPATCH(CM_ENG_PREP)
@@ -842,6 +854,12 @@ bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const size_t lds = engine_lds_bytes(a, c.nsw, c.ncw);
     if (lds > 160 * 1024 - 256 || a.gpw_res > MAXRES || a.p1 <= a.p0) return false;
     const bool tr = trace && a.trace != nullptr;
+    if (a.chunk == 1024) {
+        if (!engine_has_chunk(1024) || (a.attn != nullptr && a.nrep != 2 && a.nrep != 4)) return false;
+        if (a.attn != nullptr && a.nrep == 2) launch_v<4, 4, 2, 2>(a, grid, lds, s, tr);
+        else launch_v<4, 4, 4, 2>(a, grid, lds, s, tr);
+        return true;
+    }
     if (a.attn != nullptr && a.nrep == 2) {
         if (!engine_has_nrep(2)) return false;
         launch_v<4, 4, 2>(a, grid, lds, s, tr);

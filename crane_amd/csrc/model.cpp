@@ -371,10 +371,14 @@ bool Model::engine_eligible(std::string* why) const {
     if (quantized) return no("quantised weights");
     if (tp != 1 || rccl) return no("tensor parallelism");
     const int Ko = Hq_l * cfg.D;
-    if (Ko % 2048 || cfg.H % 2048 || I_l % 2048) return no("projection widths must be multiples of 2048");
+    // dependency chunk (= K elements of one weight batch): 2048 where every width is a multiple of it, else 1024 (Qwen3-0.6B:
+    // hidden 1024, intermediate 3072) in the default kernel configuration
+    const int ch = (Ko % 2048 || cfg.H % 2048 || I_l % 2048) ? 1024 : 2048;
+    if (Ko % ch || cfg.H % ch || I_l % ch) return no("projection widths must be multiples of 1024");
+    if (!engine_has_chunk(ch)) return no("1024-element chunks only in the default kernel configuration");
     const EngCfg ec = engine_config();
     if (cfg.H / 1024 > ec.nsw || Ko / 1024 > ec.nsw) return no("input vector of the first phase too long for the stream waves");
-    if (I_l / 2048 > 8) return no("intermediate size too large for the chunk counters");
+    if (I_l / ch > 8) return no("intermediate size too large for the chunk counters");
     const int TW = num_cu * ec.nsw;
     if ((cfg.H / 2 + TW - 1) / TW > 4) return no("hidden size too large for the residual slots");
     return true;
@@ -403,6 +407,7 @@ void Model::build_engine() {
     }
     const EngCfg ec = engine_config();
     const int H = cfg.H, D = cfg.D, Ko = Hq_l * D, TW = num_cu * ec.nsw;
+    eng_chunk = (Ko % 2048 || H % 2048 || I_l % 2048) ? 1024 : 2048;
     const int x0 = std::max(Ko, H), x1 = H, xh = I_l;
     eng_xf_total = x0 + x1 + xh;
     auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
@@ -445,7 +450,7 @@ void Model::build_engine() {
         p[3].W = w.down; p[3].N = H; p[3].K = I_l; p[3].kind = ENG_RESADD;
         p[3].xoff = x0 + x1; p[3].xbuf = 2; p[3].in_edge = ENG_E_H; p[3].out_edge = ENG_E_X0;
         for (int k = 0; k < 4; ++k) {
-            p[k].gpw = gpw(p[k].N); p[k].nb = p[k].K / 2048;
+            p[k].gpw = gpw(p[k].N); p[k].nb = p[k].K / eng_chunk;
             // row groups kept open (walked chunk-major): a consumer with few chunks needs several open groups so that the
             // LAST chunk of its input is needed late; a producer should close groups early so that the first chunks of
             // its output exist early.  Long rows (down_proj) go group by group, short rows three groups at a time.
@@ -468,7 +473,7 @@ void Model::build_engine() {
     // epoch base 1: every tag of the first launch is >= 2, the zero-filled granules never match
     const uint32_t one = 1;
     CM_HIP(hipMemcpy(&st->rsv[1], &one, 4, hipMemcpyHostToDevice));
-    if (!engine_prepare(engine_lds_bytes(probe, ec.nsw, ec.ncw), engine_full ? nrep : 4)) {
+    if (!engine_prepare(engine_lds_bytes(probe, ec.nsw, ec.ncw), engine_full ? nrep : 4, eng_chunk)) {
         if (opts.engine > 0) throw CmError(CM_ERR_DEVICE, "cm_opts.engine = 1: kernel attribute");
         return;
     }
@@ -498,7 +503,7 @@ EngArgs Model::engine_args_common() const {
     e.q_off = 0; e.k_off = Hq_l * cfg.D; e.v_off = e.k_off + Hkv_l * cfg.D;
     e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
     e.kv_f16 = kv_mode == KV_F16 ? 1 : 0;
-    e.nrep = nrep;
+    e.nrep = nrep; e.chunk = eng_chunk;
     e.dbg = eng_dbg; e.tune = eng_tune;
     return e;
 }

@@ -312,6 +312,7 @@ struct Model {
     EngPhase* eng_prog = nullptr;              // device [L][4]: QKV, o_proj, gate||up, down_proj
     EngAttnL* eng_attn = nullptr;              // device [L]
     unsigned long long* eng_gran[ENG_NEDGE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int eng_chunk = 2048;      // dependency chunk of the persistent kernel (2048; 1024 for widths that are only multiples of 1024)
     int eng_gpw_res = 0, eng_xf_total = 0;
     bool engine_eligible(std::string* why = nullptr) const;
     bool engine_full_eligible() const;

@@ -19,7 +19,8 @@ def rel(a, ref):
 
 
 @pytest.fixture(scope="module", params=[("full", "f16", "eng-qwen3"), ("layer", "f16", "eng-qwen3"), ("full", "bf16", "eng-qwen3"),
-                                        ("full", "f16", "eng-qwen3-gqa2")], ids=lambda p: f"{p[0]}-{p[1]}-{p[2]}")
+                                        ("full", "f16", "eng-qwen3-gqa2"), ("full", "f16", "eng-qwen3-h1024"),
+                                        ("layer", "f16", "eng-qwen3-h1024")], ids=lambda p: f"{p[0]}-{p[1]}-{p[2]}")
 def trio(request):
     mode, kv, name = request.param
     cfg = configs.get_config(name)
