@@ -841,7 +841,9 @@ bool engine_prepare(size_t lds_bytes, int nrep, int chunk) {
     const EngCfg c = engine_config();
     if (chunk == 1024) {
         if (!engine_has_chunk(1024)) return false;
-        return nrep == 2 ? prepare_v<4, 4, 2, 2>(lds_bytes) : prepare_v<4, 4, 4, 2>(lds_bytes);
+        // both instantiations a handle can launch (whole token with the in-kernel attention of its GQA group; per layer without):
+        // a kernel first launched inside a stream capture, unprepared, has been seen to time out on its first replay
+        return (nrep != 2 || prepare_v<4, 4, 2, 2>(lds_bytes)) && prepare_v<4, 4, 4, 2>(lds_bytes);
     }
     if (nrep == 2 && engine_has_nrep(2)) return prepare_v<4, 4, 2>(lds_bytes) && prepare_v<4, 4, 4>(lds_bytes);
 #define CM_ENG_PREP(N, P) return prepare_v<N, P>(lds_bytes);

@@ -415,6 +415,9 @@ void Model::build_engine() {
     engine_full = engine_full_eligible();
     if (const char* e = getenv("CM_ENGINE_FULL")) engine_full = engine_full && atoi(e) != 0;
     if (const char* e = getenv("CM_ENGINE_FULL_MAX")) eng_full_max_ctx = atoll(e);
+    // 1024-element chunks = Qwen3-0.6B-sized phases (a few MB of weights each): nothing for a poll to disturb, so inputs are
+    // probed at once and without a pause (0.6B: 1365 -> 1395 tok/s; the same setting costs Qwen3-8B 13 %)
+    if (eng_chunk == 1024) eng_tune = 0;
     if (const char* e = getenv("CM_ENG_TUNE")) eng_tune = (int)strtol(e, nullptr, 0);
     if (const char* e = getenv("CM_ENG_DBG")) eng_dbg = atoi(e);          // kernel timing experiments, results invalid
     EngArgs probe{};

@@ -77,6 +77,30 @@ def test_chain_long_context_and_bench_loop(trio):
     assert rel(outs[0][1], outs[1][1]) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["eng-qwen3-h1024", "eng-qwen3-gqa2", "eng-qwen3"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_graph_replay_as_the_first_use_of_a_handle(name, mode):
+    """The device-chained greedy loop (hipGraph capture + replays) as the FIRST thing a handle does, in the per-layer and the
+    whole-token mode: every kernel instantiation a handle can launch is prepared at cm_create (an instantiation whose first
+    launch happened inside a stream capture timed out on its first replay)."""
+    cfg = configs.get_config(name)
+    outs = []
+    for engine in (1, -1):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, engine=engine)
+        try:
+            if engine == 1:
+                m.debug_set("engine_full", mode)
+                assert m.engine_active() == (2 if mode else 1)
+            m.debug_fill_kv(300, seed=2)
+            toks, _ = m.bench_decode(3, 12)
+            outs.append([int(t) for t in toks])
+            if engine == 1:
+                assert m.engine_active() == (2 if mode else 1)        # (no timeout + fallback happened)
+        finally:
+            m.close()
+    assert outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("ctx", [2500, 5000])
 def test_chain_context_beyond_the_prefetched_chunks(ctx):
     """whole-token mode: a workgroup prefetches 4 K/V chunks per layer (contexts up to 2048); longer contexts walk the rest
