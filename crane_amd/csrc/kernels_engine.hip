@@ -39,7 +39,7 @@ constexpr int R = 2;            // rows per group (one wave reduces R rows at a 
 // U (template parameter UC of the kernel) = 512-element pieces per batch: a batch = R x U 16-byte loads per lane = 8 KiB per wave at
 // U = 4 (CHUNK = 2048 input elements, the dependency granule of widths that are multiples of 2048) or 4 KiB at U = 2 (CHUNK =
 // 1024: hidden 1024 / intermediate 3072 of Qwen3-0.6B)
-constexpr int MAXCH = 8;        // chunks per input vector (K <= 16384)
+constexpr int MAXCH = 20;       // chunks per input vector (K <= 20 * chunk: 17 408 = 17 chunks of 1024, Qwen3.8-27B's intermediate size)
 constexpr int MAXGB = 6;        // row groups a wave keeps open
 constexpr int MAXRES = 4;       // residual row groups per wave
 constexpr int AD = 128;         // attention head_dim
@@ -88,7 +88,7 @@ enum { C_PROG = 0,      // batches finished by this workgroup's stream waves (mo
        C_ABORT = 1,
        C_CBAR = 2,      // barrier counter of the comm waves
        C_CNT = 4,       // [4 counter rows][MAXCH]: passes staged (monotonic; PPC = 2 or 1 passes per chunk)
-       C_WORDS = 64 };
+       C_WORDS = 4 + 4 * MAXCH + 12 };
 
 }  // namespace
 
@@ -564,14 +564,16 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     // BEFORE the weight prefetch (a load issued behind this CU's prefetch burst returns ~5 us later) and stages it once
     // the prefetch is on its way.  Waves past the last pass load a clamped pass and write nothing.
     ph_ptr PF0 = (ph_ptr)a.prog + p0;
-    const int npass0 = PF0->K >> 10;
-    f32x4 xin[4], win[4];
-    {
-        const int pass = wave < npass0 ? wave : npass0 - 1;
+    const int npass0 = PF0->K >> 10;          // <= 2 * NSW (the host checks): wave w takes passes w and w + NSW
+    f32x4 xin[2][4], win[2][4];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int pw = wave + pp * NSW;
+        const int pass = pw < npass0 ? pw : npass0 - 1;
         const CM_GLOBAL f32x4* v4 = (const CM_GLOBAL f32x4*)a.vin + pass * 256;
         const CM_GLOBAL f32x4* w4 = (const CM_GLOBAL f32x4*)(PF0->nw != nullptr ? PF0->nw : a.vin) + pass * 256;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xin[i] = v4[i * 64 + lane]; win[i] = w4[i * 64 + lane]; }
+        for (int i = 0; i < 4; ++i) { xin[pp][i] = v4[i * 64 + lane]; win[pp][i] = w4[i * 64 + lane]; }
     }
 
     // ---- cursors over the batch sequence: phase -> block of `gblk` row groups -> chunk kb -> group gg of the block ----
@@ -738,25 +740,29 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
 #pragma unroll
     for (int gi = 0; gi < MAXRES; ++gi)
         if (gi < a.gpw_res && lane < R) my_xres[gi * R + lane] = xv0[gi];
-    if (wave < npass0) {                      // stage pass `wave` of the first phase's input (RMSNorm weight + sum of squares folded)
-        float* xs0 = lds + PF0->xoff;
-        const bool nrm = PF0->nw != nullptr;
-        float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = xin[i];
-            if (nrm) {
-                ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-                v[0] *= win[i][0]; v[1] *= win[i][1]; v[2] *= win[i][2]; v[3] *= win[i][3];
+    for (int pp = 0; pp < 2; ++pp) {
+        const int pw = wave + pp * NSW;
+        if (pw < npass0) {                    // stage pass pw of the first phase's input (RMSNorm weight + sum of squares folded)
+            float* xs0 = lds + PF0->xoff;
+            const bool nrm = PF0->nw != nullptr;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = xin[pp][i];
+                if (nrm) {
+                    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                    v[0] *= win[pp][i][0]; v[1] *= win[pp][i][1]; v[2] *= win[pp][i][2]; v[3] *= win[pp][i][3];
+                }
+                *(f32x4*)(xs0 + xperm((pw * 256 + i * 64 + lane) << 2)) = v;
             }
-            *(f32x4*)(xs0 + xperm((wave * 256 + i * 64 + lane) << 2)) = v;
+            if (nrm) {
+                ss = wave_sum(ss);
+                if (lane == 0) ssq[(PF0->xbuf & 1) * 16 + pw] = ss;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + pw / PPC], 1u);
         }
-        if (nrm) {
-            ss = wave_sum(ss);
-            if (lane == 0) ssq[(PF0->xbuf & 1) * 16 + wave] = ss;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + wave / PPC], 1u);
     }
     while (cc.ph < p1) {
 #pragma unroll
@@ -837,13 +843,26 @@ bool engine_has_nrep(int nrep) {
     else if (c.pf == 6) { CALL(4, 6) }                                     \
     else { CALL(4, 4) }
 
+// register sets in flight per stream wave at 1024-element chunks (4 KiB batches): CM_ENG_PF1024 = 4 | 6 | 8
+static int pf1024() {
+    static int v = -1;
+    if (v < 0) { v = getenv("CM_ENG_PF1024") ? atoi(getenv("CM_ENG_PF1024")) : 6; if (v != 4 && v != 6 && v != 8) v = 6; }
+    return v;
+}
+#define CM_ENG_1024(CALL, NR) { const int pf = pf1024(); if (pf == 4) { CALL(4, 4, NR, 2) } else if (pf == 6) { CALL(4, 6, NR, 2) } else { CALL(4, 8, NR, 2) } }
+
 bool engine_prepare(size_t lds_bytes, int nrep, int chunk) {
     const EngCfg c = engine_config();
     if (chunk == 1024) {
         if (!engine_has_chunk(1024)) return false;
         // both instantiations a handle can launch (whole token with the in-kernel attention of its GQA group; per layer without):
         // a kernel first launched inside a stream capture, unprepared, has been seen to time out on its first replay
-        return (nrep != 2 || prepare_v<4, 4, 2, 2>(lds_bytes)) && prepare_v<4, 4, 4, 2>(lds_bytes);
+#define CM_P(N, P, NR, UU) ok = ok && prepare_v<N, P, NR, UU>(lds_bytes);
+        bool ok = true;
+        if (nrep == 2) CM_ENG_1024(CM_P, 2)
+        CM_ENG_1024(CM_P, 4)
+#undef CM_P
+        return ok;
     }
     if (nrep == 2 && engine_has_nrep(2)) return prepare_v<4, 4, 2>(lds_bytes) && prepare_v<4, 4, 4>(lds_bytes);
 #define CM_ENG_PREP(N, P) return prepare_v<N, P>(lds_bytes);
@@ -858,8 +877,10 @@ bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const bool tr = trace && a.trace != nullptr;
     if (a.chunk == 1024) {
         if (!engine_has_chunk(1024) || (a.attn != nullptr && a.nrep != 2 && a.nrep != 4)) return false;
-        if (a.attn != nullptr && a.nrep == 2) launch_v<4, 4, 2, 2>(a, grid, lds, s, tr);
-        else launch_v<4, 4, 4, 2>(a, grid, lds, s, tr);
+#define CM_L(N, P, NR, UU) launch_v<N, P, NR, UU>(a, grid, lds, s, tr);
+        if (a.attn != nullptr && a.nrep == 2) CM_ENG_1024(CM_L, 2)
+        else CM_ENG_1024(CM_L, 4)
+#undef CM_L
         return true;
     }
     if (a.attn != nullptr && a.nrep == 2) {

@@ -255,6 +255,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_ATTN_NS")) attn_ns = std::max(1, std::min(nsplit, atoi(e)));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN")) attn_mfma_min = atoll(e);
     if (const char* e = getenv("CM_GDN_DEFER_NORM")) gdn_defer_norm = atoi(e) != 0;
+    if (const char* e = getenv("CM_ENGINE_HYBRID")) hybrid_engine = atoi(e) != 0;
     if (const char* e = getenv("CM_ATTN_BATCH_NS_MIN")) attn_batch_ns_min = std::max(1, atoi(e));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN_BATCH")) attn_mfma_min_batch = atoll(e);
     if (const char* e = getenv("CM_ATTN_MFMA_WIDE_MIN")) attn_mfma_wide_min = atoll(e);
@@ -367,9 +368,14 @@ void Model::alloc_runtime() {
 // ------------------------------------------------------------------------------------
 bool Model::engine_eligible(std::string* why) const {
     auto no = [&](const char* m) { if (why) *why = m; return false; };
-    if (cfg.hybrid) return no("hybrid (Gated-Delta-Net) layers");
     if (quantized) return no("quantised weights");
     if (tp != 1 || rccl) return no("tensor parallelism");
+    // hybrid family: the per-layer chain only (out_proj / o_proj -> gate||up -> down_proj -> next layer's in_proj / QKV around the
+    // separate Gated-Delta-Net / attention launches); both kinds of token mixer must hand over a vector of the same length
+    if (cfg.hybrid && Hq_l * cfg.D != cfg.value_dim()) return no("hybrid: attention output and GDN value widths differ");
+    // measured slower than the launch path on Qwen3.8-27B (103 vs 110 tok/s: its GEMVs are large enough to stream at 6.1 TB/s
+    // as separate launches, the chain's hand-off traffic costs more than the three boundaries it removes): opt-in only
+    if (cfg.hybrid && !hybrid_engine && opts.engine <= 0) return no("hybrid per-layer chain is opt-in (cm_opts.engine = 1 or CM_ENGINE_HYBRID=1)");
     const int Ko = Hq_l * cfg.D;
     // dependency chunk (= K elements of one weight batch): 2048 where every width is a multiple of it, else 1024 (Qwen3-0.6B:
     // hidden 1024, intermediate 3072) in the default kernel configuration
@@ -377,8 +383,9 @@ bool Model::engine_eligible(std::string* why) const {
     if (Ko % ch || cfg.H % ch || I_l % ch) return no("projection widths must be multiples of 1024");
     if (!engine_has_chunk(ch)) return no("1024-element chunks only in the default kernel configuration");
     const EngCfg ec = engine_config();
-    if (cfg.H / 1024 > ec.nsw || Ko / 1024 > ec.nsw) return no("input vector of the first phase too long for the stream waves");
-    if (I_l / ch > 8) return no("intermediate size too large for the chunk counters");
+    if (cfg.H / 1024 > 2 * ec.nsw || Ko / 1024 > 2 * ec.nsw) return no("input vector of the first phase too long for the stream waves");
+    if (I_l / ch > 20 || Ko / ch > 20 || cfg.H / ch > 20) return no("a projection input too long for the chunk counters");
+    if (cfg.H / 1024 > 16) return no("hidden size too large for the sum-of-squares slots");
     const int TW = num_cu * ec.nsw;
     if ((cfg.H / 2 + TW - 1) / TW > 4) return no("hidden size too large for the residual slots");
     return true;
@@ -412,12 +419,12 @@ void Model::build_engine() {
     eng_xf_total = x0 + x1 + xh;
     auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
     eng_gpw_res = gpw(H);
-    engine_full = engine_full_eligible();
+    engine_full = !cfg.hybrid && engine_full_eligible();
     if (const char* e = getenv("CM_ENGINE_FULL")) engine_full = engine_full && atoi(e) != 0;
     if (const char* e = getenv("CM_ENGINE_FULL_MAX")) eng_full_max_ctx = atoll(e);
     // 1024-element chunks = Qwen3-0.6B-sized phases (a few MB of weights each): nothing for a poll to disturb, so inputs are
     // probed at once and without a pause (0.6B: 1365 -> 1395 tok/s; the same setting costs Qwen3-8B 13 %)
-    if (eng_chunk == 1024) eng_tune = 0;
+    if (eng_chunk == 1024 && !cfg.hybrid) eng_tune = 0;
     if (const char* e = getenv("CM_ENG_TUNE")) eng_tune = (int)strtol(e, nullptr, 0);
     if (const char* e = getenv("CM_ENG_DBG")) eng_dbg = atoi(e);          // kernel timing experiments, results invalid
     EngArgs probe{};
@@ -431,7 +438,7 @@ void Model::build_engine() {
             return;
         }
     }
-    const int qkv_rows = (Hq_l + 2 * Hkv_l) * D;
+    const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;      // (hybrid: q carries its output gate)
     int gblk_env[4] = {0, 0, 0, 0};
     if (const char* e = getenv("CM_ENG_GBLK")) sscanf(e, "%d,%d,%d,%d", &gblk_env[0], &gblk_env[1], &gblk_env[2], &gblk_env[3]);
     std::vector<EngPhase> prog((size_t)cfg.L * 4);
@@ -441,10 +448,10 @@ void Model::build_engine() {
         EngPhase* p = &prog[(size_t)li * 4];
         for (int k = 0; k < 4; ++k) { p[k] = EngPhase{}; p[k].layer = li; p[k].useq = li; p[k].in_tag = li + 1; p[k].out_tag = li + 1; }
         // RMSNorm + merged QKV: input = residual after the previous layer's down_proj
-        p[0].W = w.qkv; p[0].nw = w.ln1; p[0].N = qkv_rows; p[0].K = H; p[0].kind = ENG_STORE;
+        p[0].W = w.full ? w.qkv : w.in_proj; p[0].nw = w.ln1; p[0].N = w.full ? qkv_rows : in_proj_rows; p[0].K = H; p[0].kind = ENG_STORE;
         p[0].xoff = 0; p[0].xbuf = 0; p[0].in_edge = ENG_E_X0; p[0].in_tag = li; p[0].out_edge = ENG_E_QKV;
         // o_proj + residual: input = attention output (the comm waves run the attention first)
-        p[1].W = w.o; p[1].N = H; p[1].K = Ko; p[1].kind = ENG_RESADD;
+        p[1].W = w.full ? w.o : w.out_proj; p[1].N = H; p[1].K = Ko; p[1].kind = ENG_RESADD;
         p[1].xoff = 0; p[1].xbuf = 3; p[1].in_edge = ENG_E_ATTN; p[1].out_edge = ENG_E_X1; p[1].pre_attn = 1;
         // RMSNorm + gate||up + SiLU*mul
         p[2].W = w.gate_up; p[2].nw = w.ln2; p[2].N = 2 * I_l; p[2].K = H; p[2].kind = ENG_SILUMUL;
@@ -467,7 +474,7 @@ void Model::build_engine() {
     eng_attn = (EngAttnL*)dalloc<int>(at.size() * sizeof(EngAttnL) / sizeof(int));
     CM_HIP(hipMemcpy(eng_attn, at.data(), at.size() * sizeof(EngAttnL), hipMemcpyHostToDevice));
     const int ns = std::max(1, num_cu / std::max(1, Hkv_l));
-    const size_t gsz[ENG_NEDGE] = {(size_t)H, (size_t)qkv_rows, (size_t)Hkv_l * ns * nrep * (D + 2), (size_t)Hq_l * D, (size_t)H, (size_t)I_l};
+    const size_t gsz[ENG_NEDGE] = {(size_t)H, (size_t)std::max(qkv_rows, cfg.hybrid ? in_proj_rows : 0), (size_t)Hkv_l * ns * nrep * (D + 2), (size_t)Hq_l * D, (size_t)H, (size_t)I_l};
     for (int e = 0; e < ENG_NEDGE; ++e) {
         eng_gsz[e] = gsz[e];
         eng_gran[e] = (unsigned long long*)dalloc<int>(gsz[e] * 2);
@@ -761,15 +768,30 @@ void Model::enqueue_decode_step(bool advance) {
     if (engine_on) {
         // per-layer persistent launches: QKV of layer 0 as a plain launch, then per layer the attention kernels + ONE launch
         // for o_proj -> gate||up -> down_proj -> QKV of the next layer
+        // (hybrid family: the first projection is in_proj of a Gated-Delta-Net layer, the token mixer between two chain launches
+        // is the GDN step -- with its own gated norm: the chain's out_proj stages a plain vector -- or the gated attention)
         GemvArgs g{};
-        g.W = layers[0].qkv; g.x = x; g.nw = layers[0].ln1; g.y = qkv; g.N = qkv_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
+        g.W = layers[0].full ? layers[0].qkv : layers[0].in_proj; g.x = x; g.nw = layers[0].ln1; g.y = qkv;
+        g.N = layers[0].full ? qkv_rows : in_proj_rows; g.K = H; g.ldw = H; g.eps = cfg.eps;
         launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
+            if (!w.full) {
+                GdnArgs ga{};
+                ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
+                ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
+                ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
+                ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
+                ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
+                launch_gdn(ga, s);
+                if (!launch_engine(engine_args(li), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
+                continue;
+            }
             AttnDecArgs a{};
             a.qkv = qkv; a.qnw = w.qn; a.knw = w.kn; a.cos = cos; a.sin = sin; a.st = st; a.block_table = d_bt;
             a.kpool = kpool(li); a.vpool = vpool(li); a.part_o = part_o; a.part_ml = part_ml;
-            a.q_off = 0; a.k_off = Hq_l * D; a.v_off = a.k_off + Hkv_l * D; a.gate = nullptr; a.rot_dim = cfg.rot_dim;
+            a.q_off = 0; a.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; a.v_off = a.k_off + Hkv_l * D;
+            a.gate = cfg.hybrid ? qkv + (size_t)Hq_l * D : nullptr; a.rot_dim = cfg.rot_dim;
             a.Hkv = Hkv_l; a.page = page; a.max_pages = max_pages_per_seq; a.page_bytes = page_bytes; a.eps = cfg.eps;
             a.scale = (float)(1.0 / std::sqrt((double)D));
             if (attn_variant >= 2) {
@@ -1807,6 +1829,11 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
             }
             const int lc = cfg.L > 1 ? (int)(i % (size_t)(cfg.L - 1)) : 0;
             if (!launch_engine(engine_args(lc), num_cu, stream)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
+            if (cfg.hybrid) {        // out_proj / o_proj + gate||up + down_proj of layer lc + the in-projection of layer lc + 1 (in_proj or QKV)
+                const uint64_t nxt = cfg.L > 1 ? (uint64_t)(layers[(size_t)lc + 1].full ? (2 * Hq_l + 2 * Hkv_l) * D : in_proj_rows) : 0;
+                b = ((uint64_t)H * Ko + 2ull * I_l * H + (uint64_t)H * I_l + nxt * H) * 2 + Ko * 4 + (uint64_t)H * 4 + 2ull * H * 4;
+                return;
+            }
             b = (cfg.L > 1 ? wl : wl - qrows * H * 2) + Ko * 4 + (uint64_t)H * 4 + 2ull * H * 4;            // + attn in, x in/out, 2 norm vectors
             return;
         }

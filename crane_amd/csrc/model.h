@@ -313,6 +313,7 @@ struct Model {
     EngAttnL* eng_attn = nullptr;              // device [L]
     unsigned long long* eng_gran[ENG_NEDGE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int eng_chunk = 2048;      // dependency chunk of the persistent kernel (2048; 1024 for widths that are only multiples of 1024)
+    bool hybrid_engine = false; // CM_ENGINE_HYBRID=1 (or cm_opts.engine = 1): per-layer persistent chain for the hybrid family -- measured slower, opt-in
     int eng_gpw_res = 0, eng_xf_total = 0;
     bool engine_eligible(std::string* why = nullptr) const;
     bool engine_full_eligible() const;

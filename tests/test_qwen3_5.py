@@ -392,3 +392,35 @@ def test_gated_norm_in_the_out_proj_prologue_equals_the_in_step_norm():
     finally:
         m.debug_set("gdn_defer_norm", 1)
         m.close()
+
+
+@pytest.mark.gpu
+def test_hybrid_per_layer_chain_equals_the_launch_path():
+    """Qwen3.8-27B layer geometry (hidden 5120, intermediate 17 408, 48 value heads / 24 gated q heads of 256): decode on the
+    persistent per-layer chain (out_proj / o_proj -> gate||up -> down_proj -> the next layer's in_proj / QKV in ONE launch, 1024-element
+    dependency chunks, 17 chunks for down_proj; the Gated-Delta-Net step and the attention stay launches) against the
+    per-projection launch path: logits to summation order, greedy tokens equal -- with the graph-replay loop as the first use of
+    the handle."""
+    from crane_amd import configs
+    from crane_amd.backend import GenerationConfig, Model
+    cfg = dict(configs.get_config("qwen3.8-27b"), num_hidden_layers=8, vocab_size=4096, max_position_embeddings=4096)
+    outs = []
+    for engine in (1, -1):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=2, engine=engine)
+        try:
+            assert m.engine_active() == (1 if engine == 1 else 0)
+            m.debug_fill_kv(900, seed=2)
+            toks, _ = m.bench_decode(3, 10)
+            assert m.engine_active() == (1 if engine == 1 else 0)
+            m.clear_kv_cache()
+            ids = configs.synthetic_prompt(23, cfg["vocab_size"])
+            m.forward_step(ids, 0)
+            lg = [m.forward_step([11 + i], 23 + i)[0, 0].copy() for i in range(3)]
+            m.clear_kv_cache()
+            gen = m.generate(ids, GenerationConfig.greedy(10))
+            outs.append(([int(t) for t in toks], lg, gen))
+        finally:
+            m.close()
+    assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert rel(a, b) < 1e-4, rel(a, b)
