@@ -66,6 +66,9 @@ Model::~Model() {
     if (h_logitsb) (void)hipHostFree(h_logitsb);
     if (h_pen) (void)hipHostFree(h_pen);
     if (h_tk) (void)hipHostFree(h_tk);
+    if (h_stab) (void)hipHostFree(h_stab);
+    if (v_ev0) (void)hipEventDestroy(v_ev0);
+    if (v_ev1) (void)hipEventDestroy(v_ev1);
     if (tk_cand) (void)hipFree(tk_cand);
     if (tk_in) (void)hipFree(tk_in);
     if (stream) (void)hipStreamDestroy(stream);
