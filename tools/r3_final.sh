@@ -20,6 +20,14 @@ for mdl in qwen3-0.6b qwen3.5-0.8b qwen3-vl-2b qwen3.8-27b; do
   timeout 600 python bench.py --model $mdl $([ $mdl = qwen3.8-27b ] && echo "--steps 32 --warmup 4") > $OUT/bench_$mdl.json 2> $OUT/bench_$mdl.err
 done
 timeout 300 python tools/bench_engine.py qwen3-8b 256 128 128 8 32,64,128 > $OUT/eng.log 2>&1; grep "tok/s" $OUT/eng.log | cut -c1-150
+kt() { local n=$1; shift
+    timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt_$n -o $n -- "$@" > $OUT/kt_$n.log 2>&1
+    python tools/rocpd_stats.py $(ls $OUT/kt_$n/*_results.db | head -1) $OUT/${n}_kernel_stats.csv > /dev/null 2>>$OUT/kt_$n.log
+    rm -rf $OUT/kt_$n; }
+kt decode_qwen3_8b_engine python bench.py --no-cpu-baseline --steps 32 --warmup 4
+kt decode_qwen3_0p6b_engine python bench.py --model qwen3-0.6b --no-cpu-baseline --steps 64 --warmup 4
+kt decode_qwen3_vl_2b python bench.py --model qwen3-vl-2b --no-cpu-baseline --steps 32 --warmup 4
+kt decode_qwen3_8_27b python bench.py --model qwen3.8-27b --no-cpu-baseline --steps 16 --warmup 2
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
