@@ -241,8 +241,8 @@ struct Model {
     static constexpr int MAXB = 128;           // sequences of one batched step: one 128-row M tile of the MFMA GEMM projections
     static constexpr int GEMV_MAXB = 64;       // ... on the batched GEMVs (2 / 4 / 8 L2-sharing groups of 8)
     int batch_max = 64;                        // CM_BATCH_MAX = 8 | 16 | 32 | 64 (A/B)
-    int lm_head_gemm_min = 17;                 // CM_LM_HEAD_GEMM_MIN: groups of this many sequences or more run the head as an MFMA GEMM + row arg-max (0 = never)
-    int batch_gemm_min = 17;                   // CM_BATCH_GEMM_MIN: batched decode of this many sequences or more runs its projections as MFMA GEMMs (0 = never)
+    int lm_head_gemm_min = 9;                  // CM_LM_HEAD_GEMM_MIN: groups of this many sequences or more run the head as an MFMA GEMM + row arg-max (0 = never)
+    int batch_gemm_min = 9;                    // CM_BATCH_GEMM_MIN: batched decode of this many sequences or more runs its projections as MFMA GEMMs (0 = never)
     StepState* stb = nullptr;          // device [MAXB]
     StepState* h_stb = nullptr;        // pinned [MAXB]
     int32_t* d_btb = nullptr;          // device [MAXB][max_pages_per_seq]

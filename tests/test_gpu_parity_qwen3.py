@@ -338,7 +338,7 @@ def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
 
 @pytest.mark.parametrize("nseq", [17, 40, 64, 65, 100, 128])
 def test_batched_decode_gemm_path_against_gemv_path(nseq):
-    """From 17 sequences on cm_decode_batch runs the projections as MFMA GEMMs over the rows of the batch (M = nseq,
+    """From 9 sequences on (batch_gemm_min) cm_decode_batch runs the projections as MFMA GEMMs over the rows of the batch (M = nseq,
     split-K) instead of the batched matrix-core GEMVs.  The same step through both paths (the step is taken back with
     cm_seq_truncate in between): logits agree to the summation order of two bf16 hi + lo products, tokens are equal."""
     cfg = configs.get_config("tiny-qwen3-untied")
@@ -357,7 +357,7 @@ def test_batched_decode_gemm_path_against_gemv_path(nseq):
             lg_v, gr_v = m.step_batch_decode(seqs, toks)
             for s_, n_ in zip(seqs, lens):
                 m.seq_truncate(s_, n_ + step)              # take the step back: the GEMM path appends the same K / V rows
-            m.debug_set("batch_gemm_min", 17)
+            m.debug_set("batch_gemm_min", 9)
             lg_m, gr_m = m.step_batch_decode(seqs, toks)
             assert not np.array_equal(lg_m, lg_v)          # (the other path did run)
             for i in range(nseq):

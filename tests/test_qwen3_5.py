@@ -234,7 +234,7 @@ def test_hip_qwen35_batched_decode_gemm_path():
         for step in range(2):
             m.debug_set("batch_gemm_min", 0)
             lg_v, gr_v = m.step_batch_decode(sa, toks)
-            m.debug_set("batch_gemm_min", 17)
+            m.debug_set("batch_gemm_min", 9)
             lg_m, gr_m = m.step_batch_decode(sb, toks)
             assert not np.array_equal(lg_m, lg_v)
             for i in range(nseq):
