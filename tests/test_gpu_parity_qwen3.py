@@ -336,7 +336,7 @@ def test_batched_decode_matches_per_sequence_oracle(pair, nseq):
             m.close()
 
 
-@pytest.mark.parametrize("nseq", [17, 40, 64, 65, 100, 128])
+@pytest.mark.parametrize("nseq", [9, 12, 17, 40, 64, 65, 100, 128])
 def test_batched_decode_gemm_path_against_gemv_path(nseq):
     """From 9 sequences on (batch_gemm_min) cm_decode_batch runs the projections as MFMA GEMMs over the rows of the batch (M = nseq,
     split-K) instead of the batched matrix-core GEMVs.  The same step through both paths (the step is taken back with
