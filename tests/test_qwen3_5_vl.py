@@ -202,3 +202,29 @@ def test_hip_live_image_path_at_the_real_size_against_the_hf_golden():
         assert toks == want
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_hip_vlm_two_images_of_different_grids():
+    """The live image path with n_images = 2 (24- and 16-patch frames) and text before, between and after the images: tower
+    features per frame, splice over both placeholder spans, MRoPE positions across two images, decode on the counter."""
+    from crane_amd.backend import Model
+    g, cfg, w, text_w = _setup()
+    rng = np.random.default_rng(5)
+    grid = [[1, 4, 6], [1, 2, 8]]
+    pix = rng.standard_normal((24 + 16, 3 * 2 * 16 * 16)).astype(np.float32)
+    img, vs, ve = cfg["image_token_id"], cfg["vision_start_token_id"], cfg["vision_end_token_id"]
+    ids = [5, 6, vs] + [img] * 6 + [ve, 7, 8, 9, vs] + [img] * 4 + [ve, 10, 11]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
+    try:
+        feat_ref, logits_ref, toks_ref = _oracle_vlm(cfg, w, text_w, ids, pix, grid, "tanh", 6)
+        feat = m.encode_images(pix, grid)
+        assert feat.shape == feat_ref.shape and feat.shape[0] == 10 and rel(feat, feat_ref) < 1e-4
+        logits, nxt = m.vlm_forward(ids, pix, grid)
+        assert rel(logits, logits_ref) < 1e-4 and nxt == toks_ref[0]
+        toks, pos = [nxt], len(ids)
+        for _ in range(5):
+            toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+        assert toks == toks_ref
+    finally:
+        m.close()

@@ -136,3 +136,37 @@ def test_hip_qwen3_vl_at_the_real_tower_size_against_the_hf_golden():
         assert toks == want
     finally:
         m.close()
+
+
+def _two_images(cfg, seed=5):
+    """two images of different grids with text before, between and after them"""
+    rng = np.random.default_rng(seed)
+    grid = [[1, 4, 6], [1, 2, 8]]                      # 24 + 16 patches -> 6 + 4 merged tokens
+    pix = rng.standard_normal((24 + 16, 3 * 2 * 16 * 16)).astype(np.float32)
+    img, vs, ve = cfg["image_token_id"], cfg["vision_start_token_id"], cfg["vision_end_token_id"]
+    ids = [5, 6, vs] + [img] * 6 + [ve, 7, 8, 9, vs] + [img] * 4 + [ve, 10, 11]
+    return ids, pix, grid
+
+
+@pytest.mark.gpu
+def test_hip_qwen3_vl_two_images_of_different_grids():
+    """cm_vision_encode / cm_vlm_forward with n_images = 2 (frames of 24 and 16 patches: per-frame bidirectional attention,
+    per-image position-embedding interpolation), text between the images (3-axis MRoPE positions restart from the running
+    maximum after each image, build_position_ids qwen3_5/vlm.rs:190-241), DeepStack rows of both images added after the
+    first decoder layers -- against the oracle, then 5 decode steps on the MRoPE counter."""
+    from crane_amd.backend import Model
+    g, cfg, w = _setup()
+    ids, pix, grid = _two_images(cfg)
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, kv_dtype="f32")
+    try:
+        feat_ref, deep_ref, logits_ref, toks_ref = _oracle_run(cfg, w, ids, pix, grid, "tanh", 6)
+        feat = m.encode_images(pix, grid)
+        assert feat.shape == feat_ref.shape == (10, cfg["text_config"]["hidden_size"]) and rel(feat, feat_ref) < 1e-4
+        logits, nxt = m.vlm_forward(ids, pix, grid)
+        assert rel(logits, logits_ref) < 1e-4 and nxt == toks_ref[0]
+        toks, pos = [nxt], len(ids)
+        for _ in range(5):
+            toks.append(m.forward_step_greedy([toks[-1]], pos)); pos += 1
+        assert toks == toks_ref
+    finally:
+        m.close()
