@@ -431,8 +431,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t Vs[THREE ? 2 : 1][KT * VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, kvh = h / a.nrep;
-    const int qb = blockIdx.x * 64;                 // first query row of this block
+    // causal: grid (Hq, query tiles) walked LONGEST TILE FIRST (a query tile of index i attends i + 1 key tiles): at 2048 rows the
+    // 1024 workgroups do not fit at once, and in ascending order the last ones dispatched are the longest -- the launch ended
+    // with a tail of up to 32 tile times; descending, a slot that finishes a long tile picks up a short one (LPT).
+    // bidirectional frames: grid (query tiles, Hq, key runs)
+    const int h = a.causal ? blockIdx.x : blockIdx.y, kvh = h / a.nrep;
+    const int qb = (a.causal ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x) * 64;      // first query row of this block
     const int qrow = qb + wave * 16 + sub;          // this lane's query row (as Q^T column / stats owner)
     const int qrow_c = qrow < a.S ? qrow : a.S - 1; // clamp for loads
     const int qpos = a.start_pos + qrow;
@@ -823,6 +827,7 @@ void launch_attn_prefill(const AttnPreArgs& a0, int D, int kvt, hipStream_t s) {
     AttnPreArgs a = a0;
     if (a.causal || a.part_o == nullptr || a.part_ml == nullptr || a.gate != nullptr || a.ksplit < 1) a.ksplit = 1;
     dim3 grid((a.S + 63) / 64, a.Hq, a.ksplit);
+    if (a.causal) grid = dim3(a.Hq, (a.S + 63) / 64, 1);
     if (D == 64) {
         hipLaunchKernelGGL((attn_prefill_kernel<64, KV_BF16X2>), grid, dim3(256), 0, s, a);     // ViT: K/V scratch pre-split into bf16 hi + lo
         if (a.ksplit > 1) {
