@@ -397,6 +397,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         else if (k == "attn_ns") { h->m.attn_ns = (int)std::max<long long>(1, std::min<long long>(value, h->m.nsplit)); h->m.drop_graphs(); }
         else if (k == "gemm256") h->m.gemm256 = value != 0;
         else if (k == "sample_rows") h->m.sample_rows_on = value != 0;
+        else if (k == "prefill_seg_batch") h->m.seg_batch = value != 0;
         else if (k == "prefill_lo_mask") h->m.prefill_lo_mask = (int)value;
         else if (k == "gdn_defer_norm") { h->m.gdn_defer_norm = value != 0; h->m.drop_graphs(); }
         else if (k == "tp_graph") { h->m.tp_graph = value != 0; h->m.drop_graphs(); }      // CM_TP_GRAPH: RCCL collectives captured into the decode graph

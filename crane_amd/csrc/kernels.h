@@ -97,6 +97,10 @@ struct GemmArgs {
     int wide256 = 1;        // 0: never the 256-row LDS-DMA kernel (kernels_gemm256.hip) -- A/B switch, cm_debug_set("gemm256")
 };
 
+// one sequence of a multi-sequence prompt pass (Model::prefill_multi): rows [row0, row0 + S) of the pass at positions start_pos...,
+// page table at block_table + bt_off
+struct PrefillSegDev { int row0, S, start_pos, rope_delta, bt_off, pad0, pad1, pad2; };
+
 struct QkRopeArgs {
     const float* qkv;            // [S, (Hq + 2 Hkv) D] f32
     const float* qnw;
@@ -119,6 +123,9 @@ struct QkRopeArgs {
     size_t page_bytes = 0;
     float* kshadow = nullptr;
     float* vshadow = nullptr;
+    // several sequences in one launch: row s of the pass belongs to segs[rowseg[s]] (null: one sequence, start_pos / block_table above)
+    const PrefillSegDev* segs = nullptr;
+    const int32_t* rowseg = nullptr;
 };
 
 struct AttnPreArgs {
@@ -134,6 +141,11 @@ struct AttnPreArgs {
     int gate_stride;
     int S, Hq, Hkv, nrep, page, start_pos;
     int causal, kv_lo, kv_hi;    // causal = 0: bidirectional over tokens [kv_lo, kv_hi) (ViT frame)
+    // several sequences in one causal launch: tiles[i] = {segment, query tile} ordered by ASCENDING key-tile count (walked from the
+    // back: longest first); q / out / gate / block_table above are those of the whole pass
+    const PrefillSegDev* segs = nullptr;
+    const int2* tiles = nullptr;
+    int ntiles = 0;
     int ksplit = 1;              // bidirectional frames only: runs of key tiles per query tile (partials merged by a second kernel)
     float* part_o = nullptr;     // [ksplit][S][Hq][D] un-normalised partial outputs
     float* part_ml = nullptr;    // [ksplit][S][Hq][2] running max, running sum

@@ -71,7 +71,14 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restri
 // qwen3_5/modeling.rs:464-468), rotate-half over the first rot_dim dims, q scaled by 1/sqrt(D)
 // -> bf16 hi/lo [S, Hq, D]; k, v -> paged cache at position start+s.
 template <int D, int KVT>
-__global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a) {
+__global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a_in) {
+    QkRopeArgs a = a_in;
+    if (a.segs != nullptr) {          // a pass over several sequences: this row's sequence gives position, page table and rope offset
+        const PrefillSegDev sg = a.segs[a.rowseg[blockIdx.x]];
+        a.start_pos = sg.start_pos - sg.row0;          // (position = start_pos + row of the pass)
+        a.block_table += sg.bt_off;
+        a.rope_delta = sg.rope_delta;
+    }
     constexpr int EPL = D / 64;
     constexpr bool KVF32 = KVT == 1;
     __shared__ float tmp[D];
@@ -425,7 +432,20 @@ __global__ __launch_bounds__(BN * 2) void gemm_bf16_kernel(GemmArgs a) {
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 template <int D, int KVT>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a_in) {
+    AttnPreArgs a = a_in;
+    int qt_seg = -1;
+    if (a.tiles != nullptr) {         // causal pass over several sequences: this workgroup's (sequence, query tile), longest first
+        const int2 tq = a.tiles[gridDim.y - 1 - blockIdx.y];
+        const PrefillSegDev sg = a.segs[tq.x];
+        const size_t r0 = (size_t)sg.row0 * a.Hq * D;
+        a.S = sg.S; a.start_pos = sg.start_pos; a.block_table += sg.bt_off;
+        a.q_hi += r0; a.out_hi += r0;
+        if (a.q_lo != nullptr) a.q_lo += r0;
+        if (a.out_lo != nullptr) a.out_lo += r0;
+        if (a.gate != nullptr) a.gate += (size_t)sg.row0 * a.gate_stride;
+        qt_seg = tq.y;
+    }
     constexpr bool KVF32 = KVT == KV_F32, X2 = KVT == KV_BF16X2, THREE = KVF32 || X2;
     constexpr int KT = 64, VLD = D + 16, NKS = D / 32, NNT = D / 16;
     __shared__ __attribute__((aligned(16))) uint16_t Vs[THREE ? 2 : 1][KT * VLD];
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a) {
     // with a tail of up to 32 tile times; descending, a slot that finishes a long tile picks up a short one (LPT).
     // bidirectional frames: grid (query tiles, Hq, key runs)
     const int h = a.causal ? blockIdx.x : blockIdx.y, kvh = h / a.nrep;
-    const int qb = (a.causal ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x) * 64;      // first query row of this block
+    const int qb = (qt_seg >= 0 ? qt_seg : a.causal ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x) * 64;      // first query row of this block
     const int qrow = qb + wave * 16 + sub;          // this lane's query row (as Q^T column / stats owner)
     const int qrow_c = qrow < a.S ? qrow : a.S - 1; // clamp for loads
     const int qpos = a.start_pos + qrow;
@@ -827,7 +847,7 @@ void launch_attn_prefill(const AttnPreArgs& a0, int D, int kvt, hipStream_t s) {
     AttnPreArgs a = a0;
     if (a.causal || a.part_o == nullptr || a.part_ml == nullptr || a.gate != nullptr || a.ksplit < 1) a.ksplit = 1;
     dim3 grid((a.S + 63) / 64, a.Hq, a.ksplit);
-    if (a.causal) grid = dim3(a.Hq, (a.S + 63) / 64, 1);
+    if (a.causal) grid = dim3(a.Hq, a.tiles != nullptr ? a.ntiles : (a.S + 63) / 64, 1);
     if (D == 64) {
         hipLaunchKernelGGL((attn_prefill_kernel<64, KV_BF16X2>), grid, dim3(256), 0, s, a);     // ViT: K/V scratch pre-split into bf16 hi + lo
         if (a.ksplit > 1) {

@@ -1096,6 +1096,29 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         // QK-norm + RoPE + KV append and the causal attention run once per sequence of the pass (its own pages and positions)
         const bool kvq = this->kvq();
         if (kvq && nseg != 1) throw CmError(CM_ERR_UNSUPPORTED, "multi-sequence prompt pass over quantised KV pages");
+        if (nseg > 1 && seg_batch && seg_tables_ok && !kvq) {
+            // every sequence of the pass in ONE RoPE / KV-append launch and ONE causal-attention launch (segment tables on the
+            // device; 16 prompts of 128 tokens were 16 launches of 64 workgroups each, per kernel and layer)
+            QkRopeArgs q{};
+            q.qkv = pQKV; q.qnw = w.qn; q.knw = w.kn; q.cos = cos; q.sin = sin; q.block_table = d_btb;
+            q.kpool = kpool(li); q.vpool = vpool(li); q.q_hi = pQ_hi; q.q_lo = pQ_lo;
+            q.Hq = Hq_l; q.Hkv = Hkv_l; q.page = page; q.start_pos = 0; q.eps = cfg.eps;
+            q.row_stride = qkv_rows; q.q_off = 0; q.k_off = (cfg.hybrid ? 2 * Hq_l : Hq_l) * D; q.v_off = q.k_off + Hkv_l * D;
+            q.rot_dim = cfg.rot_dim; q.pos3 = nullptr; q.pos3_stride = pos3_stride;
+            q.sec_h = cfg.mrope_sec[1]; q.sec_w = cfg.mrope_sec[2];
+            q.scale = (float)(1.0 / std::sqrt((double)D));
+            q.segs = d_segtab; q.rowseg = d_rowseg;
+            launch_qknorm_rope_kv(q, D, S, kv_mode, s);
+            AttnPreArgs at{};
+            at.q_hi = pQ_hi; at.q_lo = pQ_lo; at.block_table = d_btb;
+            at.kpool = kpool(li); at.vpool = vpool(li);
+            at.out_hi = pAT_hi; at.out_lo = pAT_lo;
+            at.S = S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
+            at.page = page; at.start_pos = 0; at.causal = 1;
+            at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
+            at.segs = d_segtab; at.tiles = d_tiles; at.ntiles = seg_ntiles;
+            launch_attn_prefill(at, D, kv_f32 ? KV_F32 : kv_mode, s);
+        } else
         for (int gi = 0; gi < nseg; ++gi) {
         const PrefillSeg& sg = segs[gi];
         const int sp = sg.start_pos;
@@ -1200,6 +1223,30 @@ void Model::prefill_multi(const int32_t* sq, const uint32_t* const* ids, const s
         row += (int)lens[i];
     }
     if (active_seq >= 0) { active_seq = -1; active_pages_uploaded = 0; }     // d_bt is not touched, but GDN slots / states moved on
+    // segment tables of the pass for the one-launch RoPE / attention kernels: row -> segment, and the (segment, query tile) list
+    // sorted by ascending key-tile count (the kernel walks it from the back: longest tiles first)
+    seg_tables_ok = false;
+    if (seg_batch && n_items > 1) {
+        if (!d_segtab) {
+            d_segtab = (PrefillSegDev*)dalloc<int>((size_t)MAXB * sizeof(PrefillSegDev) / sizeof(int));
+            d_rowseg = dalloc<int32_t>((size_t)chunk);
+            d_tiles = (int2*)dalloc<int>(2 * ((size_t)chunk / 64 + MAXB + 1));
+        }
+        std::vector<PrefillSegDev> hs(n_items);
+        std::vector<int32_t> rs(total);
+        std::vector<int2> tl;
+        for (size_t i = 0; i < n_items; ++i) {
+            hs[i] = PrefillSegDev{segs[i].row0, segs[i].S, 0, 0, (int)(i * (size_t)max_pages_per_seq), 0, 0, 0};
+            for (int r = 0; r < segs[i].S; ++r) rs[(size_t)segs[i].row0 + r] = (int32_t)i;
+            for (int qt = 0; qt < (segs[i].S + 63) / 64; ++qt) tl.push_back(int2{(int)i, qt});
+        }
+        std::stable_sort(tl.begin(), tl.end(), [](const int2& x, const int2& y) { return x.y < y.y; });     // start_pos = 0: key tiles = qt + 1
+        seg_ntiles = (int)tl.size();
+        CM_HIP(hipMemcpy(d_segtab, hs.data(), hs.size() * sizeof(PrefillSegDev), hipMemcpyHostToDevice));
+        CM_HIP(hipMemcpy(d_rowseg, rs.data(), rs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        CM_HIP(hipMemcpy(d_tiles, tl.data(), tl.size() * sizeof(int2), hipMemcpyHostToDevice));
+        seg_tables_ok = true;
+    }
     CM_HIP(hipMemcpyAsync(d_ids, h_ids, total * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     CM_HIP(hipMemcpyAsync(d_btb, h_btb, n_items * (size_t)max_pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
     CM_HIP(hipMemcpyAsync(stb, h_stb, n_items * sizeof(StepState), hipMemcpyHostToDevice, s));

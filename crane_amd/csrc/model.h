@@ -312,6 +312,13 @@ struct Model {
     EngPhase* eng_prog = nullptr;              // device [L][4]: QKV, o_proj, gate||up, down_proj
     EngAttnL* eng_attn = nullptr;              // device [L]
     unsigned long long* eng_gran[ENG_NEDGE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // multi-sequence prompt pass: device tables of the segments (Model::prefill_multi) so that RoPE / KV append / causal attention
+    // of ALL sequences are one launch each per layer instead of one per sequence (cm_debug_set("prefill_seg_batch", 0): per sequence)
+    PrefillSegDev* d_segtab = nullptr;
+    int32_t* d_rowseg = nullptr;
+    int2* d_tiles = nullptr;
+    int seg_ntiles = 0;
+    bool seg_batch = true, seg_tables_ok = false;
     int eng_chunk = 2048;      // dependency chunk of the persistent kernel (2048; 1024 for widths that are only multiples of 1024)
     bool hybrid_engine = false; // CM_ENGINE_HYBRID=1 (or cm_opts.engine = 1): per-layer persistent chain for the hybrid family -- measured slower, opt-in
     int eng_gpw_res = 0, eng_xf_total = 0;

@@ -457,7 +457,9 @@ int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x
  * LDS-DMA GEMM of the prompt pass and of large decode groups; "lm_head_gemm_min" = n: decode groups of n or more sequences run
  * lm_head as one GEMM + row arg-max (0 = never); "sample_rows" = 0 / 1: the engine's sampled rows through the per-row sampler /
  * one set of launches for all rows (same tokens); "tp_graph" = 0 / 1: RCCL collectives launched eagerly / captured into the
- * decode hipGraph (CM_TP_GRAPH); "prefill_lo_mask" (measurement only, tools/lo_mask_probe.py): bit 0 QKV, 1 o_proj, 2 gate||up,
+ * decode hipGraph (CM_TP_GRAPH); "prefill_seg_batch" = 0 / 1: cm_prefill_batch launches RoPE / KV append / attention once per
+ * sequence / once for all sequences of the pass; "gdn_defer_norm" = 0 / 1: the Gated-Delta-Net step normalises itself / leaves the
+ * gated RMSNorm to out_proj's prologue; "prefill_lo_mask" (measurement only, tools/lo_mask_probe.py): bit 0 QKV, 1 o_proj, 2 gate||up,
  * 3 down_proj -- that GEMM of the prompt pass drops the lo plane of its activations.
  * cm_debug_read("engine_trace") launches the persistent kernel several times on the live state of sequence 0: the K/V rows at
  * the current position and the residual stream are overwritten -- clear the sequence afterwards. */
