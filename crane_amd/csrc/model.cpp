@@ -259,6 +259,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_ATTN_MFMA_MIN")) attn_mfma_min = atoll(e);
     if (const char* e = getenv("CM_GDN_DEFER_NORM")) gdn_defer_norm = atoi(e) != 0;
     if (const char* e = getenv("CM_ENGINE_HYBRID")) hybrid_engine = atoi(e) != 0;
+    if (const char* e = getenv("CM_PREFILL_SEG_BATCH")) seg_batch = atoi(e) != 0;
     if (const char* e = getenv("CM_ATTN_BATCH_NS_MIN")) attn_batch_ns_min = std::max(1, atoi(e));
     if (const char* e = getenv("CM_ATTN_MFMA_MIN_BATCH")) attn_mfma_min_batch = atoll(e);
     if (const char* e = getenv("CM_ATTN_MFMA_WIDE_MIN")) attn_mfma_wide_min = atoll(e);
