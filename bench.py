@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def cpu_leg(model_name: str, ctx: int, budget_s: float):
+def cpu_leg(model_name: str, ctx: int, budget_s: float, long_ctx: int = 0, long_budget_s: float = 90.0):
     """oracle/c on the host cores: greedy decode of the same workload (KV filled with the device's synthetic values).
     Returns (cpu_baseline dict, reference tokens, logits of the first step, model-written-cache reference) -- the checker
     side of `parity`."""
@@ -38,7 +38,7 @@ def cpu_leg(model_name: str, ctx: int, budget_s: float):
     if not os.path.exists(so):
         return None, None, None, None
     from oracle.c_oracle import time_decode
-    return time_decode(model_name, ctx, budget_s)
+    return time_decode(model_name, ctx, budget_s, long_ctx=long_ctx, long_budget_s=long_budget_s)
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of the MI355X (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
@@ -154,10 +154,20 @@ def main():
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU decode steps for cpu_baseline / parity")
+    ap.add_argument("--parity-ctx", type=int, default=-1, help="parity on a model-written cache of this many tokens (default: the "
+                    "benchmark context; 0 = only the 48-token case)")
+    ap.add_argument("--parity-budget", type=float, default=90.0, help="seconds of host time the long-context parity leg may take "
+                    "(the token-serial hybrid CPU port skips it beyond this)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--engine", type=int, default=0, choices=[-1, 0, 1], help="persistent chain kernel: 1 require, -1 off, 0 library default")
     ap.add_argument("--kv", default="f16", choices=["f16", "bf16", "f32", "int8", "int4"],
                     help="KV page element type (f16 = library default and headline: 2 bytes per element like bf16, inside the 1e-3 parity bar)")
+    ap.add_argument("--tp-local", type=int, default=0, metavar="N", help="time ONE rank's shard of a TP=N model on one GPU: the C++ loader "
+                    "slices rank --rank of N, every collective is a local no-op (CM_DEBUG_TP_LOCAL).  The line is labelled "
+                    "emulated_shard r/N, rccl_ranks 1: the compute half of the 1->N scaling curve, NOT an N-GPU number")
+    ap.add_argument("--rank", type=int, default=0, help="which rank's shard --tp-local times")
+    ap.add_argument("--force-rccl", action="store_true", help="TP=1 with every reduction routed through a 1-rank RCCL communicator "
+                    "(CM_DEBUG_FORCE_RCCL): per-call enqueue cost of the collectives, one GPU")
     ap.add_argument("--isq", default=None, help="in-situ weight quantisation (q8_0): a DIFFERENT workload than the bf16 headline")
     args = ap.parse_args()
 
@@ -199,12 +209,20 @@ def main():
 
     cfg = configs.get_config(args.model)
     K, W, ctx = args.steps, args.warmup, args.ctx
+    tpl = args.tp_local
+    if tpl and (n != 1 or not (0 <= args.rank < tpl)):
+        raise SystemExit("--tp-local N needs --gpus 1 and 0 <= --rank < N")
     m = Model.synthetic(cfg, seed=0, device=local_rank if world > 1 else 0,
                         max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1,
                         use_graph=-1 if args.no_graph else 0, engine=args.engine,
-                        tp_rank=rank, tp_size=world, tp_unique_id=uid, isq=args.isq, kv_dtype=args.kv)
+                        tp_rank=args.rank if tpl else rank, tp_size=tpl if tpl else world, tp_unique_id=uid, isq=args.isq,
+                        kv_dtype=args.kv, debug_tp_local=bool(tpl), debug_force_rccl=args.force_rccl)
     ranks = m.tp_ranks()
-    if ranks != n:
+    if tpl:
+        if ranks != 0:
+            raise SystemExit(f"--tp-local: expected no communicator, library reports {ranks} rank(s)")
+        args.no_cpu_baseline = True          # a single rank's partial sums have no CPU counterpart (tests/test_gpu_tp_shards.py checks them)
+    elif ranks != n:
         raise SystemExit(f"library reports an RCCL communicator of {ranks} rank(s), expected {n}")
     m.debug_fill_kv(ctx, seed=1)            # synthetic KV for positions [0, ctx): inputs resident in HBM
     first = 3
@@ -242,8 +260,12 @@ def main():
     # chain launch itself (o_proj + gate||up + down_proj + next QKV: every weight byte of a layer)
     roof = None
     dom = "chain" if m.engine_active() else "gate_up"
+    if tpl or args.force_rccl:
+        dom = None                              # the shard line reports the whole step only
     pmc_key = "engine_kernel" if m.engine_active() else "gemv_bf16_kernel<1, 2,"
     try:
+        if dom is None:
+            raise RuntimeError("not collected for --tp-local / --force-rccl (roofline_step is the figure)")
         kb = m.bench_kernel(dom, 360)
         roof = {"bound": "hbm", "kernel": kb["kernel"], "achieved": round(kb["bytes"] / (kb["ms"] * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -285,6 +307,8 @@ def main():
     try:
         if args.isq:
             raise RuntimeError("quantised weights: not part of the bf16 headline")
+        if tpl or args.force_rccl:
+            raise RuntimeError("not timed for --tp-local / --force-rccl")
         ids = configs.synthetic_prompt(1024, cfg.get("text_config", cfg)["vocab_size"])
         m.clear_kv_cache(); m.forward_step_greedy(ids, 0)            # warm-up (allocates chunk buffers)
         m.clear_kv_cache()
@@ -316,7 +340,8 @@ def main():
                               f"{psutil.virtual_memory().total / 2**30:.0f} GiB); BASELINE configs[0] / [2] are the CPU-sized cases"}
         else:
             try:
-                cpu, ref_toks, ref_logits, wr = cpu_leg(args.model, ctx, args.cpu_budget)
+                pctx = ctx if args.parity_ctx < 0 else args.parity_ctx
+                cpu, ref_toks, ref_logits, wr = cpu_leg(args.model, ctx, args.cpu_budget, pctx, args.parity_budget)
                 if ref_toks:
                     def relerr(a, b):
                         return float(np.abs(a - b).max() / np.abs(b).max())
@@ -331,6 +356,27 @@ def main():
                     while eqw < len(gen) and gen[eqw] == wr["greedy"][eqw]:
                         eqw += 1
                     rp, rd = relerr(pl, wr["prefill_logits"]), relerr(dl, wr["decode_logits"])
+                    # (1b) the same at the benchmark's own context: every layer, a `pctx`-token prompt through the HIP prefill in
+                    # the benchmarked KV mode, one decode step + greedy ids over the pages it wrote (f16 K/V rounding grows with
+                    # depth and context: this is the headline configuration itself, not an extrapolation from 48 tokens)
+                    long_par, rl = None, 0.0
+                    wl = wr.get("long")
+                    if wl and "skipped" in wl:
+                        long_par = wl
+                    elif wl:
+                        m.clear_kv_cache()
+                        pl2 = m.forward_step(wl["prompt"], 0)[0, 0]
+                        dl2 = m.forward_step([wl["greedy"][0]], len(wl["prompt"]))[0, 0]
+                        gen2 = m.generate(wl["prompt"], GenerationConfig.greedy(len(wl["greedy"])))[len(wl["prompt"]):]
+                        eql = 0
+                        while eql < len(gen2) and gen2[eql] == wl["greedy"][eql]:
+                            eql += 1
+                        rp2, rd2 = relerr(pl2, wl["prefill_logits"]), relerr(dl2, wl["decode_logits"])
+                        rl = max(rp2, rd2)
+                        long_par = {"prompt_tokens": len(wl["prompt"]), "layers": int(cfg.get("text_config", cfg)["num_hidden_layers"]),
+                                    "prefill_logit_rel": float(f"{rp2:.3e}"), "decode_logit_rel": float(f"{rd2:.3e}"),
+                                    "greedy_checked": len(wl["greedy"]), "greedy_equal": eql, "cpu_seconds": wl["cpu_seconds"],
+                                    "ok": bool(eql == len(wl["greedy"]) and rl < 1e-3)}
                     # (2) the timed configuration itself (synthetic KV at the benchmark context: bf16-exact fill values, so this
                     # checks the kernels at the timed shapes, not the KV rounding)
                     m.debug_fill_kv(ctx, seed=1)
@@ -350,8 +396,11 @@ def main():
                               "timed_configuration": {"note": "synthetic KV of the benchmark context (bf16-exact fill values)",
                                                       "tokens_checked": len(ref_toks), "tokens_equal": eq,
                                                       "logit_rel": float(f"{lrel:.3e}")},
-                              "logit_rel": float(f"{max(rp, rd):.3e}"),
-                              "ok": bool(eqw == len(wr["greedy"]) and eq == len(ref_toks) and max(rp, rd, lrel) < 1e-3)}
+                              "logit_rel": float(f"{max(rp, rd, rl):.3e}"),
+                              "ok": bool(eqw == len(wr["greedy"]) and eq == len(ref_toks) and max(rp, rd, lrel, rl) < 1e-3
+                                         and (long_par is None or long_par.get("ok", True)))}
+                    if long_par is not None:
+                        parity[f"model_written_cache_ctx{pctx}"] = long_par
             except Exception as e:  # the baseline must never break the headline number
                 cpu = {"error": str(e)}
 
@@ -374,13 +423,24 @@ def main():
             "dtype": "bf16" if not args.isq else f"{args.isq} weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"{args.model} greedy decode, batch 1, context {ctx} (+{W}+{K} generated), "
                                    f"{wdt} weights + {args.kv} paged KV, f32 activations",
-                       "parallelism": f"tp{n}", "rccl_ranks": ranks, "graph": not args.no_graph,
+                       "parallelism": f"tp{tpl} (ONE rank's shard, collectives = local no-ops)" if tpl else f"tp{n}",
+                       "rccl_ranks": 1 if (tpl or args.force_rccl) else ranks, "graph": not args.no_graph,
                        "decode_path": {0: "per-projection launches", 1: "persistent kernel per layer + attention launches",
                                        2: "persistent decode kernel: one launch per token (cm_opts.engine)"}[m.engine_active()]},
             "roofline": roof, "roofline_step": roof_step, "prefill": prefill, "parity": parity, "cpu_baseline": cpu,
         }
         if vision is not None:
             line["vision"] = vision
+        if tpl:
+            L, H = cfg.get("text_config", cfg)["num_hidden_layers"], cfg.get("text_config", cfg)["hidden_size"]
+            line["metric"] += f" -- rank {args.rank} of TP={tpl} ALONE (emulated shard, no collectives)"
+            line["config"]["emulated_shard"] = f"{args.rank}/{tpl}"
+            line["config"]["not_an_n_gpu_number"] = ("per-rank compute time of the shard; the 2 x L all-reduces of 4 H bytes and the "
+                                                     "arg-max gather of a real TP step are NOT in it")
+            line["collectives_skipped"] = {"all_reduce_per_token": 2 * L, "bytes_per_all_reduce": 4 * H, "all_gather_per_token": 1}
+        if args.force_rccl:
+            line["metric"] += " -- reductions through a 1-rank RCCL communicator (CM_DEBUG_FORCE_RCCL)"
+            line["config"]["force_rccl"] = True
         if n > 1:
             # the exchange steps of one token under TP: one f32 [H] all-reduce behind each row-parallel projection
             # (o_proj / GDN out_proj, down_proj), one all-gather of the ranks' (max, index) arg-max partials behind lm_head

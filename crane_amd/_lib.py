@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrane_mi355.so")
 
-CM_ABI_VERSION = 2
+CM_ABI_VERSION = 3
 CM_OK = 0
 STATUS_NAMES = {0: "CM_OK", -1: "CM_ERR_INVALID", -2: "CM_ERR_IO", -3: "CM_ERR_UNSUPPORTED",
                 -4: "CM_ERR_DEVICE", -5: "CM_ERR_OOM", -6: "CM_ERR_RANGE"}
@@ -24,7 +24,7 @@ EXPORTS = [
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
     "cm_decode_batch", "cm_prefill_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_embed_tokens", "cm_forward_embeds", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
-    "cm_gguf_config", "cm_checkpoint_inspect", "cm_tp_shard_plan", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv", "cm_debug_set",
+    "cm_gguf_config", "cm_checkpoint_inspect", "cm_tp_shard_plan", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv", "cm_debug_set", "cm_debug_peer_selftest",
 ]
 
 
@@ -35,8 +35,12 @@ class CmOpts(C.Structure):
         ("max_seqs", C.c_uint32), ("kv_block_size", C.c_uint32), ("kv_pool_tokens", C.c_uint64),
         ("kv_dtype", C.c_int32), ("use_graph", C.c_int32), ("prefill_chunk", C.c_uint32),
         ("prefill_split", C.c_int32), ("isq", C.c_uint32), ("engine", C.c_int32), ("debug_flags", C.c_uint32),
-        ("reserved", C.c_uint32 * 5),
+        ("tp_mode", C.c_uint32), ("tp_devices", C.POINTER(C.c_int32)), ("tp_collective", C.c_uint32),
+        ("reserved", C.c_uint32 * 1),
     ]
+
+
+assert C.sizeof(CmOpts) == 96          # the round-4 fields live in the former reserved words (include/crane_mi355.h)
 
 
 class CmPreprocConfig(C.Structure):
@@ -141,6 +145,8 @@ def load():
     lib.cm_seq_fork.argtypes = [vp, C.c_int32, P(C.c_int32)]
     lib.cm_seq_len.argtypes = [vp, C.c_int32]
     lib.cm_seq_len.restype = C.c_int64
+    lib.cm_debug_peer_selftest.restype = C.c_long
+    lib.cm_debug_peer_selftest.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.cm_seq_truncate.argtypes = [vp, C.c_int32, C.c_size_t]
     lib.cm_seq_forward.argtypes = [vp, C.c_int32, u32p, C.c_size_t, C.c_size_t, f32p, u32p]
     lib.cm_decode_batch.argtypes = [vp, P(C.c_int32), u32p, C.c_size_t, f32p, u32p]

@@ -135,7 +135,8 @@ class Model:
     @staticmethod
     def _opts(device=0, max_seq_len=0, max_seqs=0, kv_block_size=0, kv_pool_tokens=0, use_graph=0,
               tp_rank=0, tp_size=1, tp_unique_id: Optional[bytes] = None, prefill_chunk=0, prefill_split=0,
-              kv_dtype="f16", isq: Optional[str] = None, engine=0, debug_tp_local=False, debug_force_rccl=False):
+              kv_dtype="f16", isq: Optional[str] = None, engine=0, debug_tp_local=False, debug_force_rccl=False,
+              tp_in_process=False, tp_devices: Optional[List[int]] = None, tp_collective: Optional[str] = None):
         o = _lib.CmOpts()
         o.abi_version = _lib.CM_ABI_VERSION
         o.device, o.tp_rank, o.tp_size = device, tp_rank, tp_size
@@ -150,6 +151,15 @@ class Model:
         if tp_unique_id is not None:
             keep = C.create_string_buffer(bytes(tp_unique_id), 128)
             o.tp_unique_id = C.cast(keep, C.c_void_p)
+        if tp_in_process:                # ONE handle owns all tp_size ranks (CM_TP_IN_PROCESS); tp_devices: one ordinal per rank
+            o.tp_mode = 1
+            o.tp_collective = {None: 0, "rccl": 1, "peer": 2}[tp_collective]
+            if tp_devices is not None:
+                if len(tp_devices) != tp_size:
+                    raise ValueError("tp_devices needs tp_size entries")
+                arr = (C.c_int32 * tp_size)(*[int(d) for d in tp_devices])
+                o.tp_devices = C.cast(arr, C.POINTER(C.c_int32))
+                keep = (keep, arr)
         return o, keep
 
     @classmethod

@@ -7,13 +7,26 @@
 #include "model.h"
 #include "safetensors.h"
 #include "tp.h"
+#include "tp_group.h"
 
 using cm::CmError;
 using cm::Model;
 
-struct cm_model { Model m; };
+static_assert(sizeof(cm_opts) == 96, "cm_opts grew: the round-4 fields live in the former reserved words");
 
-namespace cm { Model& model_of(cm_model* h) { return h->m; } }
+// m: the replica, the SPMD rank, or rank 0 of an in-process tensor-parallel group (grp: ranks 1 .. n-1 + their threads)
+struct cm_model {
+    Model m;
+    std::unique_ptr<cm::TpGroup> grp;
+    // rank 0's transport points into the group's shared state: it goes first, then the worker threads and the peer ranks
+    ~cm_model() { (void)hipSetDevice(m.dev); m.rccl.reset(); grp.reset(); }
+};
+
+namespace cm {
+long peer_selftest(int n, int device, int iters, int count);      // tp_group.cpp
+Model& model_of(cm_model* h) { return h->m; }
+TpGroup* group_of(cm_model* h) { return h->grp.get(); }
+}
 
 static thread_local std::string g_err;
 
@@ -35,6 +48,24 @@ static int guard(cm_model* h, F&& f) {
     }
 }
 
+// f(Model&, primary) on every rank the handle owns: the one Model of a replica / SPMD rank, or all ranks of an in-process
+// group at once (rank 0 = primary on the calling thread).  Results come from the primary; the other ranks are handed scratch
+// outputs -- they must take the same path through the collectives.
+template <typename F>
+static int guard_all(cm_model* h, F&& f) {
+    return guard(h, [&] {
+        if (!h->grp) { f(h->m, true); return; }
+        h->grp->run([&](int r) { f(h->grp->model(r), r == 0); });
+    });
+}
+// scratch output of a non-primary rank
+template <typename T>
+static T* out_or(bool primary, T* real, std::vector<T>& tmp, size_t n) {
+    if (primary || !real) return real;
+    tmp.resize(n);
+    return tmp.data();
+}
+
 // cm_opts.isq, else CRANE_ISQ (qwen3_5/model.rs:615-626 isq_from_env): only q8_0 is offered -- the K-quant
 // quantisers of ggml (make_qkx2_quants search) are not restated, see oracle/gguf_oracle.py
 static void apply_isq(cm::Model& m) {
@@ -52,6 +83,34 @@ static void apply_isq(cm::Model& m) {
     m.isq_q8_0();
 }
 
+// Model::new for every rank the options ask for.  CM_TP_IN_PROCESS: the ranks load their shards concurrently (one thread per
+// device); the transport's rendezvous happens inside alloc_runtime.
+template <typename LOAD>
+static void create_ranks(cm_model* h, const std::string& cfg, const cm_opts* opts, LOAD&& load) {
+    if (!opts || opts->tp_mode == CM_TP_SPMD) {
+        h->m.init_common(cfg, opts);
+        load(h->m);
+        h->m.alloc_runtime();
+        return;
+    }
+    if (opts->tp_mode != CM_TP_IN_PROCESS) throw CmError(CM_ERR_INVALID, "cm_opts.tp_mode");
+    if (opts->abi_version != 0 && opts->abi_version < 3) throw CmError(CM_ERR_INVALID, "cm_opts.tp_mode needs CM_ABI_VERSION >= 3");
+    if (opts->debug_flags & (CM_DEBUG_TP_LOCAL | CM_DEBUG_FORCE_RCCL)) throw CmError(CM_ERR_INVALID, "debug_flags do not apply to an in-process group");
+    h->grp.reset(new cm::TpGroup(opts->tp_size, opts->tp_devices, opts->device, opts->tp_collective));
+    cm::TpGroup& g = *h->grp;
+    g.rank0 = &h->m;
+    g.run([&](int r) {
+        Model& m = g.model(r);
+        cm_opts o = *opts;
+        o.tp_mode = CM_TP_SPMD; o.tp_devices = nullptr; o.tp_unique_id = nullptr;
+        o.tp_rank = r; o.device = g.shared.devs[(size_t)r];
+        m.peer_shared = &g.shared;
+        m.init_common(cfg, &o);
+        load(m);
+        m.alloc_runtime();
+    });
+}
+
 extern "C" {
 
 int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out) {
@@ -66,10 +125,10 @@ int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out) {
         catch (const CmError&) { throw; }
         catch (const std::exception& e) { throw CmError(CM_ERR_IO, e.what()); }
         h = new cm_model();
-        h->m.init_common(cfg, opts);
-        if (gguf) cm::load_from_gguf(h->m, path);
-        else { cm::load_from_dir(h->m, path); apply_isq(h->m); }
-        h->m.alloc_runtime();
+        create_ranks(h, cfg, opts, [&](Model& m) {
+            if (gguf) cm::load_from_gguf(m, path);
+            else { cm::load_from_dir(m, path); apply_isq(m); }
+        });
     });
     if (rc != CM_OK) { delete h; return rc; }
     *out = h;
@@ -82,10 +141,7 @@ int cm_create_synthetic(const char* config_json, uint64_t seed, const cm_opts* o
     cm_model* h = nullptr;
     int rc = guard(nullptr, [&] {
         h = new cm_model();
-        h->m.init_common(config_json, opts);
-        cm::load_synthetic(h->m, seed);
-        apply_isq(h->m);
-        h->m.alloc_runtime();
+        create_ranks(h, config_json, opts, [&](Model& m) { cm::load_synthetic(m, seed); apply_isq(m); });
     });
     if (rc != CM_OK) { delete h; return rc; }
     *out = h;
@@ -158,64 +214,92 @@ uint64_t cm_decode_bytes_per_token(const cm_model* h, size_t ctx) { return h ? h
 int cm_tp_ranks(const cm_model* h) {
     if (!h) return 0;
     if (!h->m.rccl) return 1;
-    return h->m.rccl->fake ? 0 : h->m.rccl->nranks;
+    return h->m.rccl->fake ? 0 : h->m.rccl->nranks;       // (an in-process group: its n ranks, RCCL or peer-store alike)
 }
 int cm_engine_active(const cm_model* h) { return h && h->m.engine_on ? (h->m.engine_full ? 2 : 1) : 0; }
 
 int cm_forward_step(cm_model* h, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool primary) {
         if (!logits_out) throw CmError(CM_ERR_INVALID, "logits_out is null");
-        h->m.forward(0, ids, n, start_pos, logits_out, nullptr);
+        std::vector<float> tmp;
+        m.forward(0, ids, n, start_pos, out_or(primary, logits_out, tmp, (size_t)m.cfg.V), nullptr);
     });
 }
 
 int cm_forward_step_greedy(cm_model* h, const uint32_t* ids, size_t n, size_t start_pos, uint32_t* token_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool primary) {
         if (!token_out) throw CmError(CM_ERR_INVALID, "token_out is null");
-        h->m.forward(0, ids, n, start_pos, nullptr, token_out);
+        uint32_t t = 0;
+        m.forward(0, ids, n, start_pos, nullptr, primary ? token_out : &t);
     });
 }
 
 void cm_clear_kv(cm_model* h) {
     if (!h) return;
-    (void)guard(h, [&] { h->m.seq_truncate(0, 0); });
+    (void)guard_all(h, [&](Model& m, bool) { m.seq_truncate(0, 0); });
 }
 
 int cm_warmup(cm_model* h) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool) {
         // generate(&[45, 546, 456], max 5) then clear (qwen3/model.rs:261-267)
-        uint32_t prompt[3] = {45u % (uint32_t)h->m.cfg.V, 546u % (uint32_t)h->m.cfg.V, 456u % (uint32_t)h->m.cfg.V};
+        uint32_t prompt[3] = {45u % (uint32_t)m.cfg.V, 546u % (uint32_t)m.cfg.V, 456u % (uint32_t)m.cfg.V};
         uint32_t out[8];
         size_t n = 0;
         cm_gen_config g;
         memset(&g, 0, sizeof g);
         g.max_new_tokens = 5; g.temperature = -1.f; g.top_p = -1.f; g.repetition_penalty = 1.f;
         for (int i = 0; i < 4; ++i) g.eos_token_id[i] = -1;
-        h->m.generate(prompt, 3, &g, out, &n, nullptr, nullptr);
-        h->m.seq_truncate(0, 0);
+        m.generate(prompt, 3, &g, out, &n, nullptr, nullptr);
+        m.seq_truncate(0, 0);
     });
 }
 
 int cm_generate(cm_model* h, const uint32_t* prompt, size_t n_prompt, const cm_gen_config* cfg, uint32_t* tokens_out,
                 size_t* n_out, cm_token_cb cb, void* user) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.generate(prompt, n_prompt, cfg, tokens_out, n_out, cb, user); });
+    if (!h->grp) return guard(h, [&] { h->m.generate(prompt, n_prompt, cfg, tokens_out, n_out, cb, user); });
+    // in-process group: every rank runs the same loop over identical (gathered) logits; the caller's callback runs on rank 0
+    // only and its verdict (continue / stop) is handed to the other ranks token by token
+    struct Ctx { cm::TpGroup* g; cm_token_cb cb; void* user; bool primary; size_t seen; };
+    auto tramp = [](void* u, uint32_t t) -> int {
+        Ctx* c = (Ctx*)u;
+        cm::PeerShared& ps = c->g->shared;
+        if (c->primary) {
+            const int v = c->cb(c->user, t);
+            std::lock_guard<std::mutex> lk(ps.mu);
+            c->g->cb.verdict.push_back(v);
+            ps.cv.notify_all();
+            return v;
+        }
+        std::unique_lock<std::mutex> lk(ps.mu);
+        ps.cv.wait(lk, [&] { return ps.failed || c->g->cb.verdict.size() > c->seen; });
+        if (c->g->cb.verdict.size() <= c->seen) throw CmError(CM_ERR_DEVICE, "tensor-parallel group: another rank failed");
+        return c->g->cb.verdict[c->seen++];
+    };
+    return guard_all(h, [&](Model& m, bool primary) {
+        if (!cfg || !tokens_out || !n_out) throw CmError(CM_ERR_INVALID, "null argument");
+        Ctx c{h->grp.get(), cb, user, primary, 0};
+        std::vector<uint32_t> tmp;
+        size_t n_tmp = 0;
+        uint32_t* o = primary ? tokens_out : (tmp.resize(n_prompt + cfg->max_new_tokens + 1), tmp.data());
+        m.generate(prompt, n_prompt, cfg, o, primary ? n_out : &n_tmp, cb ? +tramp : nullptr, cb ? &c : nullptr);
+    });
 }
 
 int cm_seq_alloc(cm_model* h, int32_t* seq_out) {
     if (!h || !seq_out) return CM_ERR_INVALID;
-    return guard(h, [&] { *seq_out = h->m.seq_alloc(); });
+    return guard_all(h, [&](Model& m, bool primary) { const int q = m.seq_alloc(); if (primary) *seq_out = q; });   // (the ranks' allocators are deterministic copies)
 }
 int cm_seq_free(cm_model* h, int32_t seq) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { (void)h->m.seq(seq); h->m.seq_free(seq); });
+    return guard_all(h, [&](Model& m, bool) { (void)m.seq(seq); m.seq_free(seq); });
 }
 int cm_seq_fork(cm_model* h, int32_t src, int32_t* seq_out) {
     if (!h || !seq_out) return CM_ERR_INVALID;
-    return guard(h, [&] { *seq_out = h->m.seq_fork(src); });
+    return guard_all(h, [&](Model& m, bool primary) { const int q = m.seq_fork(src); if (primary) *seq_out = q; });
 }
 int64_t cm_seq_len(const cm_model* h, int32_t seq) {
     if (!h || seq < 0 || seq >= (int32_t)h->m.seqs.size() || !h->m.seqs[(size_t)seq].used) return -1;
@@ -223,23 +307,27 @@ int64_t cm_seq_len(const cm_model* h, int32_t seq) {
 }
 int cm_seq_truncate(cm_model* h, int32_t seq, size_t new_len) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.seq_truncate(seq, new_len); });
+    return guard_all(h, [&](Model& m, bool) { m.seq_truncate(seq, new_len); });
 }
 int cm_seq_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, float* logits_out,
                    uint32_t* greedy_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.forward(seq, ids, n, start_pos, logits_out, greedy_out); });
+    return guard_all(h, [&](Model& m, bool primary) {
+        std::vector<float> tmp; uint32_t t = 0;
+        m.forward(seq, ids, n, start_pos, out_or(primary, logits_out, tmp, (size_t)m.cfg.V), (primary || !greedy_out) ? greedy_out : &t);
+    });
 }
 
 int cm_prefill_batch(cm_model* h, const int32_t* seqs, const uint32_t* const* ids, const size_t* lens, size_t n, float* logits_out,
                      uint32_t* greedy_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool primary) {
         if (!seqs || !ids || !lens) throw cm::CmError(CM_ERR_INVALID, "null argument");
-        h->m.prefill_multi(seqs, ids, lens, n, greedy_out);
-        if (logits_out) {
-            h->m.ensure_batch_buffers();
-            CM_HIP(hipMemcpy(logits_out, h->m.logitsb, n * (size_t)h->m.cfg.V * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> tg;
+        m.prefill_multi(seqs, ids, lens, n, out_or(primary, greedy_out, tg, n));
+        if (logits_out && primary) {
+            m.ensure_batch_buffers();
+            CM_HIP(hipMemcpy(logits_out, m.logitsb, n * (size_t)m.cfg.V * sizeof(float), hipMemcpyDeviceToHost));
         }
     });
 }
@@ -247,19 +335,20 @@ int cm_prefill_batch(cm_model* h, const int32_t* seqs, const uint32_t* const* id
 int cm_decode_batch(cm_model* h, const int32_t* seqs, const uint32_t* last_tokens, size_t n, float* logits_out,
                     uint32_t* greedy_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool primary) {
         if (!seqs || !last_tokens || n == 0) throw CmError(CM_ERR_INVALID, "empty batch");
+        std::vector<float> tl; std::vector<uint32_t> tg;
+        float* lo = out_or(primary, logits_out, tl, n * (size_t)m.cfg.V);
+        uint32_t* go = out_or(primary, greedy_out, tg, n);
         // One pass over the weights for a group of sequences (Model::decode_batch: up to 128 / 64 / 8); a single sequence, and
         // the combinations the batched step does not cover (quantised weights with f32 activations, TP with a vocabulary
         // that does not divide), take the ordinary decode path one sequence at a time.
-        const size_t V = (size_t)h->m.cfg.V;
-        const bool batched = (!h->m.rccl || h->m.cfg.V % h->m.tp == 0) && (!h->m.quantized || h->m.quant_act_int);
-        if (n >= 2 && batched) { h->m.decode_batch(seqs, last_tokens, n, logits_out, greedy_out); return; }
+        const size_t V = (size_t)m.cfg.V;
+        const bool batched = (!m.rccl || m.cfg.V % m.tp == 0) && (!m.quantized || m.quant_act_int);
+        if (n >= 2 && batched) { m.decode_batch(seqs, last_tokens, n, lo, go); return; }
         for (size_t i = 0; i < n; ++i) {
-            const int64_t len = cm_seq_len(h, seqs[i]);
-            if (len < 0) throw CmError(CM_ERR_INVALID, "invalid sequence handle in batch");
-            h->m.forward(seqs[i], &last_tokens[i], 1, (size_t)len, logits_out ? logits_out + i * V : nullptr,
-                         greedy_out ? greedy_out + i : nullptr);
+            const int64_t len = m.seq(seqs[i]).len;
+            m.forward(seqs[i], &last_tokens[i], 1, (size_t)len, lo ? lo + i * V : nullptr, go ? go + i : nullptr);
         }
     });
 }
@@ -269,12 +358,13 @@ int64_t cm_image_token_id(const cm_model* h) { return (h && h->m.vcfg.present) ?
 int cm_vision_encode(cm_model* h, const float* pixel_values, size_t n_patches, const uint32_t* grid_thw, size_t n_images,
                      float* features_out, size_t* rows_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
-        const int rows = h->m.vision_encode(pixel_values, n_patches, grid_thw, n_images);
+    return guard_all(h, [&](Model& m, bool primary) {      // (the tower is replicated: every rank encodes, rank 0 reports)
+        const int rows = m.vision_encode(pixel_values, n_patches, grid_thw, n_images);
+        if (!primary) return;
         if (rows_out) *rows_out = (size_t)rows;
         if (features_out) {
-            CM_HIP(hipStreamSynchronize(h->m.stream));
-            CM_HIP(hipMemcpy(features_out, h->m.vFeat, (size_t)rows * h->m.vcfg.out_hidden * sizeof(float), hipMemcpyDeviceToHost));
+            CM_HIP(hipStreamSynchronize(m.stream));
+            CM_HIP(hipMemcpy(features_out, m.vFeat, (size_t)rows * m.vcfg.out_hidden * sizeof(float), hipMemcpyDeviceToHost));
         }
     });
 }
@@ -282,7 +372,11 @@ int cm_vision_encode(cm_model* h, const float* pixel_values, size_t n_patches, c
 int cm_vlm_forward(cm_model* h, int32_t seq, const uint32_t* ids, size_t n, size_t start_pos, const float* pixel_values,
                    size_t n_patches, const uint32_t* grid_thw, size_t n_images, float* logits_out, uint32_t* greedy_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.vlm_forward(seq, ids, n, start_pos, pixel_values, n_patches, grid_thw, n_images, logits_out, greedy_out); });
+    return guard_all(h, [&](Model& m, bool primary) {
+        std::vector<float> tmp; uint32_t t = 0;
+        m.vlm_forward(seq, ids, n, start_pos, pixel_values, n_patches, grid_thw, n_images, out_or(primary, logits_out, tmp, (size_t)m.cfg.V),
+                      (primary || !greedy_out) ? greedy_out : &t);
+    });
 }
 
 int cm_embed_tokens(cm_model* h, const uint32_t* ids, size_t n, float* embeds_out) {
@@ -293,14 +387,18 @@ int cm_embed_tokens(cm_model* h, const uint32_t* ids, size_t n, float* embeds_ou
 int cm_forward_embeds(cm_model* h, int32_t seq, const float* embeds, size_t n, const int32_t* pos3, size_t start_pos,
                       float* logits_out, uint32_t* greedy_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.forward_embeds(seq, embeds, n, pos3, start_pos, logits_out, greedy_out); });
+    return guard_all(h, [&](Model& m, bool primary) {
+        std::vector<float> tmp; uint32_t t = 0;
+        m.forward_embeds(seq, embeds, n, pos3, start_pos, out_or(primary, logits_out, tmp, (size_t)m.cfg.V), (primary || !greedy_out) ? greedy_out : &t);
+    });
 }
 
 int cm_sample(cm_model* h, const cm_sample_params* p, const uint32_t* context, size_t n_context, uint32_t* token_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool primary) {     // (gathers the vocabulary shards: every rank takes part, all draw the same token)
         if (!p || !token_out) throw cm::CmError(CM_ERR_INVALID, "null argument");
-        *token_out = h->m.sample(*p, context, n_context);
+        const uint32_t t = m.sample(*p, context, n_context);
+        if (primary) *token_out = t;
     });
 }
 
@@ -311,9 +409,10 @@ int cm_topk(cm_model* h, const float* logits, size_t n, uint32_t k, uint32_t* id
 
 int cm_read_logits(cm_model* h, float* logits_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& m, bool primary) {
         if (!logits_out) throw cm::CmError(CM_ERR_INVALID, "null argument");
-        h->m.fetch_logits(logits_out);
+        std::vector<float> tmp;
+        m.fetch_logits(out_or(primary, logits_out, tmp, (size_t)m.cfg.V));
     });
 }
 
@@ -324,7 +423,10 @@ int cm_debug_qgemv(cm_model* h, int32_t layer, const char* which, const float* x
 
 int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.bench_decode(first_token, k, tokens_out, ms_out); });
+    return guard_all(h, [&](Model& m, bool primary) {
+        std::vector<uint32_t> tt; float ms = 0.f;
+        m.bench_decode(first_token, k, out_or(primary, tokens_out, tt, k), (primary || !ms_out) ? ms_out : &ms);
+    });
 }
 
 int cm_bench_kernel(cm_model* h, const char* which, size_t iters, float* ms_out, uint64_t* bytes_out) {
@@ -334,15 +436,26 @@ int cm_bench_kernel(cm_model* h, const char* which, size_t iters, float* ms_out,
 
 int cm_debug_fill_kv(cm_model* h, size_t ctx, uint64_t seed) {
     if (!h) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.debug_fill_kv(ctx, seed); });
+    return guard_all(h, [&](Model& m, bool) { m.debug_fill_kv(ctx, seed); });
 }
 
 int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
     if (!h || !what || !out) return CM_ERR_INVALID;
+    // "<name>@<r>": the buffer of rank r of an in-process group (tests: every rank must hold the same residual stream)
+    std::string w0 = what;
+    Model* mp = &h->m;
+    const size_t at = w0.find('@');
+    if (at != std::string::npos) {
+        const int r = atoi(w0.c_str() + at + 1);
+        if (!h->grp || r < 0 || r >= h->grp->n) return CM_ERR_INVALID;
+        mp = &h->grp->model(r);
+        w0.resize(at);
+    }
     return guard(h, [&] {
+        (void)hipSetDevice(mp->dev);
         const float* src = nullptr;
         size_t avail = 0;
-        const std::string w = what;
+        const std::string w = w0;
         if (w == "engine_trace") { h->m.engine_trace(out, n); return; }
         if (w.rfind("eng_", 0) == 0) {     // value halves of a granule buffer of the persistent kernel (last writer wins)
             static const char* names[cm::ENG_NEDGE] = {"eng_x0", "eng_qkv", "eng_part", "eng_attn", "eng_x1", "eng_h"};
@@ -370,44 +483,51 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
                 CM_HIP(hipMemcpy(out + k * (n / nd), h->m.vDeep + k * h->m.deep_stride, (n / nd) * sizeof(float), hipMemcpyDeviceToHost));
             return;
         }
-        if (w == "hidden") { src = h->m.x; avail = (size_t)h->m.cfg.H; }
-        else if (w == "logits") { src = h->m.logits; avail = (size_t)h->m.V_l * h->m.tp; }
-        else if (w == "attn") { src = h->m.attn; avail = (size_t)h->m.Hq_l * h->m.cfg.D; }
-        else if (w == "qkv") { src = h->m.qkv; avail = (size_t)(h->m.Hq_l + 2 * h->m.Hkv_l) * h->m.cfg.D; }
-        else if (w == "hbuf") { src = h->m.hbuf; avail = (size_t)h->m.I_l; }
+        if (w == "hidden") { src = mp->x; avail = (size_t)mp->cfg.H; }
+        else if (w == "logits") { src = mp->logits; avail = (size_t)mp->V_l * mp->tp; }
+        else if (w == "attn") { src = mp->attn; avail = (size_t)mp->Hq_l * mp->cfg.D; }
+        else if (w == "qkv") { src = mp->qkv; avail = (size_t)(mp->Hq_l + 2 * mp->Hkv_l) * mp->cfg.D; }
+        else if (w == "hbuf") { src = mp->hbuf; avail = (size_t)mp->I_l; }
         else throw CmError(CM_ERR_INVALID, "unknown buffer name");
         if (n > avail) throw CmError(CM_ERR_RANGE, "read beyond buffer");
-        CM_HIP(hipStreamSynchronize(h->m.stream));
+        CM_HIP(hipStreamSynchronize(mp->stream));
         CM_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
     });
 }
 
+// test hook: the peer-store all-reduce / all-gather alone, n rank threads on `device`; returns the number of wrong elements (< 0: error)
+long cm_debug_peer_selftest(int32_t n_ranks, int32_t device, int32_t iters, int32_t count) {
+    long bad = -1;
+    const int rc = guard(nullptr, [&] { bad = cm::peer_selftest(n_ranks, device, iters, count); });
+    return rc == CM_OK ? bad : -(long)(rc < 0 ? -rc : rc) - 1000;
+}
+
 int cm_debug_set(cm_model* h, const char* key, int64_t value) {
     if (!h || !key) return CM_ERR_INVALID;
-    return guard(h, [&] {
+    return guard_all(h, [&](Model& mm, bool) {
         const std::string k = key;
-        if (k == "no_prefill") h->m.no_prefill = value != 0;
-        else if (k == "quant_prefill") h->m.quant_prefill = value != 0;
-        else if (k == "prefill_split") h->m.prefill_split2 = value < 0 ? h->m.opts.prefill_split != 1 : value != 1;   // 1: plain bf16, 0 / 2: hi + lo, -1: back to cm_opts
+        if (k == "no_prefill") mm.no_prefill = value != 0;
+        else if (k == "quant_prefill") mm.quant_prefill = value != 0;
+        else if (k == "prefill_split") mm.prefill_split2 = value < 0 ? mm.opts.prefill_split != 1 : value != 1;   // 1: plain bf16, 0 / 2: hi + lo, -1: back to cm_opts
         // which decode-attention kernel / persistent-kernel mode a step uses (tests and A/B runs; one hipGraph per variant, so
         // the thresholds switch live -- a switch that changes what a variant enqueues drops the captured graphs)
-        else if (k == "attn_mfma_min") h->m.attn_mfma_min = value;
-        else if (k == "attn_mfma_wide_min") h->m.attn_mfma_wide_min = value;
-        else if (k == "attn_heads_max") h->m.attn_heads_max = value;
-        else if (k == "attn_ns") { h->m.attn_ns = (int)std::max<long long>(1, std::min<long long>(value, h->m.nsplit)); h->m.drop_graphs(); }
-        else if (k == "gemm256") h->m.gemm256 = value != 0;
-        else if (k == "sample_rows") h->m.sample_rows_on = value != 0;
-        else if (k == "prefill_seg_batch") h->m.seg_batch = value != 0;
-        else if (k == "prefill_lo_mask") h->m.prefill_lo_mask = (int)value;
-        else if (k == "gdn_defer_norm") { h->m.gdn_defer_norm = value != 0; h->m.drop_graphs(); }
-        else if (k == "tp_graph") { h->m.tp_graph = value != 0; h->m.drop_graphs(); }      // CM_TP_GRAPH: RCCL collectives captured into the decode graph
-        else if (k == "lm_head_gemm_min") h->m.lm_head_gemm_min = (int)std::max<long long>(0, value);
-        else if (k == "quant_act_int") h->m.quant_act_int = value != 0;          // CM_QUANT_ACT: 1 = ggml vec_dot (integer) semantics, 0 = f32 activations
-        else if (k == "vision_merger_gelu") h->m.vcfg.merger_act = value == 2 ? 2 : 1;   // CM_VISION_MERGER_GELU: 1 tanh form (reference), 2 erf (HF)
-        else if (k == "engine") { h->m.drop_graphs(); h->m.engine_on = value > 0 && h->m.engine_capable; }
-        else if (k == "engine_full") { h->m.drop_graphs(); h->m.engine_full = value != 0 && h->m.engine_full_capable; }
-        else if (k == "batch_gemm_min") h->m.batch_gemm_min = (int)std::max<long long>(0, std::min<long long>(value, Model::GEMV_MAXB));   // a group beyond the GEMV kernels' 64 must take the GEMM path
-        else if (k == "attn_splits") h->m.attn_splits_force = (int)std::max<long long>(0, std::min<long long>(value, h->m.nsplit));
+        else if (k == "attn_mfma_min") mm.attn_mfma_min = value;
+        else if (k == "attn_mfma_wide_min") mm.attn_mfma_wide_min = value;
+        else if (k == "attn_heads_max") mm.attn_heads_max = value;
+        else if (k == "attn_ns") { mm.attn_ns = (int)std::max<long long>(1, std::min<long long>(value, mm.nsplit)); mm.drop_graphs(); }
+        else if (k == "gemm256") mm.gemm256 = value != 0;
+        else if (k == "sample_rows") mm.sample_rows_on = value != 0;
+        else if (k == "prefill_seg_batch") mm.seg_batch = value != 0;
+        else if (k == "prefill_lo_mask") mm.prefill_lo_mask = (int)value;
+        else if (k == "gdn_defer_norm") { mm.gdn_defer_norm = value != 0; mm.drop_graphs(); }
+        else if (k == "tp_graph") { mm.tp_graph = value != 0; mm.drop_graphs(); }      // CM_TP_GRAPH: RCCL collectives captured into the decode graph
+        else if (k == "lm_head_gemm_min") mm.lm_head_gemm_min = (int)std::max<long long>(0, value);
+        else if (k == "quant_act_int") mm.quant_act_int = value != 0;          // CM_QUANT_ACT: 1 = ggml vec_dot (integer) semantics, 0 = f32 activations
+        else if (k == "vision_merger_gelu") mm.vcfg.merger_act = value == 2 ? 2 : 1;   // CM_VISION_MERGER_GELU: 1 tanh form (reference), 2 erf (HF)
+        else if (k == "engine") { mm.drop_graphs(); mm.engine_on = value > 0 && mm.engine_capable; }
+        else if (k == "engine_full") { mm.drop_graphs(); mm.engine_full = value != 0 && mm.engine_full_capable; }
+        else if (k == "batch_gemm_min") mm.batch_gemm_min = (int)std::max<long long>(0, std::min<long long>(value, Model::GEMV_MAXB));   // a group beyond the GEMV kernels' 64 must take the GEMM path
+        else if (k == "attn_splits") mm.attn_splits_force = (int)std::max<long long>(0, std::min<long long>(value, mm.nsplit));
         else throw CmError(CM_ERR_INVALID, "unknown debug switch");
     });
 }

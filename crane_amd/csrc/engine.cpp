@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "model.h"
+#include "tp_group.h"
 
 namespace cm {
 
@@ -145,6 +146,9 @@ struct Engine {
     // step while running < max_running (scheduler.rs:67-98) -- back to back when several are waiting; batching them changes no
     // token and no event order, only the cost: a 128-token prompt alone occupies one m-tile of every GEMM and costs what 1024
     // rows cost.  Returns false when the pass is not applicable (the caller falls back to step_prefill of the first prompt).
+    // Cancellation is looked at once per engine step (step()), i.e. once per pass of up to MAXB prompts here against once per
+    // prompt on the one-prompt path: a request cancelled while its pass runs still emits its first token, then finishes as
+    // cancelled at the next step -- the API is single-threaded, so a cancel cannot arrive inside a step anyway.
     bool step_prefill_many(size_t cap) {
         if (!opts.batch_prefill || m->kvq() || m->no_prefill || (m->quantized && !m->quant_prefill) || (m->rccl && m->cfg.V % m->tp != 0)) return false;
         m->ensure_prefill_buffers();
@@ -173,8 +177,11 @@ struct Engine {
                 sq[k] = r.seq; ptr[k] = r.tokens.data(); len[k] = r.tokens.size();
             }
             m->prefill_multi(sq.data(), ptr.data(), len.data(), ids.size(), greedy.data());
-        } catch (const CmError& e) {
-            for (uint64_t id : ids) if (reqs.count(id)) fail(id, e.code, e.what());
+        } catch (const CmError&) {
+            // isolate the offender the way the one-prompt path does: every request of the failed pass goes through
+            // step_prefill on its own, in FIFO order, so only the prompt that cannot be processed fails (its error event),
+            // the others emit exactly what the batched pass would have emitted
+            for (uint64_t id : ids) if (reqs.count(id)) step_prefill(id);
             return true;
         }
         // the sampled rows of the pass: one set of sampler launches and ONE host sync instead of one per prompt
@@ -196,8 +203,10 @@ struct Engine {
                 m->sample_collect((int)ids.size(), got);
                 for (const auto& q : rows) picked[(size_t)q.slot] = got[q.slot];
             }
-        } catch (const CmError& e) {
-            for (uint64_t id : ids) if (reqs.count(id)) fail(id, e.code, e.what());
+        } catch (const CmError&) {
+            // the row sampler failed (e.g. one request's parameters): re-run the requests one by one (the prompt pass is
+            // repeated for them -- K/V appends are idempotent, a GDN sequence restarts from position 0 in forward())
+            for (uint64_t id : ids) if (reqs.count(id)) step_prefill(id);
             return true;
         }
         for (size_t k = 0; k < ids.size(); ++k) {
@@ -306,37 +315,72 @@ struct Engine {
 
 }  // namespace cm
 
-struct cm_engine { cm::Engine e; };
+// e: the engine over the handle's model.  On an in-process tensor-parallel handle (cm_opts.tp_mode = CM_TP_IN_PROCESS) every
+// rank runs its OWN copy of the scheduler over its own shard (peers): the engines see the same submissions and cancels in the
+// same order and sample identical tokens from identical gathered logits, so they take the same decisions step by step; a
+// step runs on all ranks at once (TpGroup::run) and the caller is handed rank 0's events.
+struct cm_engine {
+    cm::Engine e;
+    cm::TpGroup* grp = nullptr;
+    std::vector<std::unique_ptr<cm::Engine>> peers;      // ranks 1 .. n-1
+    cm::Engine& rank(int r) { return r == 0 ? e : *peers[(size_t)r - 1]; }
+    int n() const { return grp ? grp->n : 1; }
+};
 
 using cm::CmError;
+
+namespace cm { TpGroup* group_of(cm_model* h); }
+
+static void engine_init(cm::Engine& e, cm_model* handle, cm::Model* m, const cm_engine_opts* opts) {
+    e.handle = handle;
+    e.m = m;
+    if (opts) e.opts = *opts;
+    if (e.opts.repeat_last_n == 0) e.opts.repeat_last_n = 64;
+    e.opts.batch_prefill = opts ? (opts->batch_prefill >= 0) : 1;      // 0 default (on), 1 on, -1 off -> stored as bool
+    const size_t slots = m->seqs.size() > 1 ? m->seqs.size() - 1 : 1;
+    e.max_running = e.opts.max_running ? std::min<size_t>(e.opts.max_running, slots) : slots;
+    if (e.opts.seed == 0) e.opts.seed = 299792458ull;
+    e.stats.total_pages = (uint64_t)m->n_pages;
+}
+
+// f(engine of rank r) on every rank (concurrently for a group); the first error wins
+template <typename F>
+static int engine_all(cm_engine* h, F&& f) {
+    int rc = CM_OK;
+    try {
+        if (!h->grp) { (void)hipSetDevice(h->e.m->dev); f(h->e); }
+        else h->grp->run([&](int r) { f(h->rank(r)); });
+    } catch (const CmError& x) { h->e.err = x.what(); rc = x.code; }
+    catch (const std::exception& x) { h->e.err = x.what(); rc = CM_ERR_INVALID; }
+    for (auto& p : h->peers) p->events.clear();           // only rank 0's events are reported
+    return rc;
+}
 
 extern "C" {
 
 int cm_engine_create(cm_model* m, const cm_engine_opts* opts, cm_engine** out) {
     if (!m || !out) return CM_ERR_INVALID;
     cm_engine* h = new cm_engine();
-    h->e.handle = m;
-    h->e.m = &cm::model_of(m);
-    if (opts) h->e.opts = *opts;
-    if (h->e.opts.repeat_last_n == 0) h->e.opts.repeat_last_n = 64;
-    h->e.opts.batch_prefill = opts ? (opts->batch_prefill >= 0) : 1;      // 0 default (on), 1 on, -1 off -> stored as bool
-    const size_t slots = h->e.m->seqs.size() > 1 ? h->e.m->seqs.size() - 1 : 1;
-    h->e.max_running = h->e.opts.max_running ? std::min<size_t>(h->e.opts.max_running, slots) : slots;
-    if (h->e.opts.seed == 0) h->e.opts.seed = 299792458ull;
-    h->e.stats.total_pages = (uint64_t)h->e.m->n_pages;
+    engine_init(h->e, m, &cm::model_of(m), opts);
+    h->grp = cm::group_of(m);
+    if (h->grp)
+        for (int r = 1; r < h->grp->n; ++r) {
+            h->peers.emplace_back(new cm::Engine());
+            engine_init(*h->peers.back(), m, &h->grp->model(r), opts);
+        }
     *out = h;
     return CM_OK;
 }
 
 void cm_engine_destroy(cm_engine* h) {
     if (!h) return;
-    for (auto& kv : h->e.reqs) if (kv.second.seq >= 0) { try { h->e.m->seq_free(kv.second.seq); } catch (...) {} }
+    (void)engine_all(h, [](cm::Engine& e) {
+        for (auto& kv : e.reqs) if (kv.second.seq >= 0) { try { e.m->seq_free(kv.second.seq); } catch (...) {} }
+    });
     delete h;
 }
 
-int cm_engine_submit(cm_engine* h, const cm_request* r, uint64_t* id_out) {
-    if (!h || !r || !id_out) return CM_ERR_INVALID;
-    cm::Engine& e = h->e;
+static int engine_submit_one(cm::Engine& e, const cm_request* r, uint64_t* id_out) {
     if (!r->tokens || r->n_tokens == 0) { e.err = "empty prompt"; e.stats.failed++; return CM_ERR_INVALID; }
     if (r->n_tokens > (size_t)e.m->max_seq - 1) {
         e.err = "Prompt length (" + std::to_string(r->n_tokens) + ") exceeds server max_seq_len (" + std::to_string(e.m->max_seq) + ")";
@@ -365,11 +409,19 @@ int cm_engine_submit(cm_engine* h, const cm_request* r, uint64_t* id_out) {
     return CM_OK;
 }
 
+int cm_engine_submit(cm_engine* h, const cm_request* r, uint64_t* id_out) {
+    if (!h || !r || !id_out) return CM_ERR_INVALID;
+    const int rc = engine_submit_one(h->e, r, id_out);       // host-only bookkeeping: the same on every rank, in the same order
+    for (auto& p : h->peers) { uint64_t id = 0; (void)engine_submit_one(*p, r, &id); }
+    return rc;
+}
+
 int cm_engine_cancel(cm_engine* h, uint64_t id) {
     if (!h) return CM_ERR_INVALID;
     auto it = h->e.reqs.find(id);
     if (it == h->e.reqs.end()) { h->e.err = "unknown request id"; return CM_ERR_INVALID; }
     it->second.cancelled = true;
+    for (auto& p : h->peers) { auto jt = p->reqs.find(id); if (jt != p->reqs.end()) jt->second.cancelled = true; }
     return CM_OK;
 }
 
@@ -377,13 +429,7 @@ int cm_engine_step(cm_engine* h, cm_engine_event* ev, size_t cap, size_t* n) {
     if (!h || !n || (cap && !ev)) return CM_ERR_INVALID;
     cm::Engine& e = h->e;
     int rc = CM_OK;
-    if (e.events.size() < cap || cap == 0) {
-        try {
-            (void)hipSetDevice(e.m->dev);
-            e.step();
-        } catch (const CmError& x) { e.err = x.what(); rc = x.code; }
-        catch (const std::exception& x) { e.err = x.what(); rc = CM_ERR_INVALID; }
-    }
+    if (e.events.size() < cap || cap == 0) rc = engine_all(h, [](cm::Engine& x) { x.step(); });
     size_t k = 0;
     while (k < cap && !e.events.empty()) { ev[k++] = e.events.front(); e.events.pop_front(); }
     *n = k;
@@ -396,17 +442,14 @@ int cm_engine_step_many(cm_engine* h, size_t max_steps, cm_engine_event* ev, siz
     int rc = CM_OK;
     // a step emits at most 2 events per running sequence (token + finished); stop while that still fits in `cap`
     const size_t per_step = 2 * (size_t)std::max<long>(1, e.opts.max_running > 0 ? (long)e.opts.max_running : (long)e.m->seqs.size());
-    try {
-        (void)hipSetDevice(e.m->dev);
-        // always make progress: with an empty event queue one step runs even when its worst case (2 events per running
-        // sequence) would not fit `cap` -- the surplus stays queued for the next call -- otherwise a small buffer would
-        // return n = 0 with work pending and the caller would spin forever
-        for (size_t i = 0; i < max_steps && (e.events.size() + per_step <= cap || (i == 0 && e.events.empty())); ++i) {
-            if (e.waiting.empty() && e.running.empty()) break;
-            e.step();
-        }
-    } catch (const CmError& x) { e.err = x.what(); rc = x.code; }
-    catch (const std::exception& x) { e.err = x.what(); rc = CM_ERR_INVALID; }
+    // always make progress: with an empty event queue one step runs even when its worst case (2 events per running
+    // sequence) would not fit `cap` -- the surplus stays queued for the next call -- otherwise a small buffer would
+    // return n = 0 with work pending and the caller would spin forever
+    // (the loop condition reads rank 0's queues only: every rank's engine is in the same state between steps)
+    for (size_t i = 0; rc == CM_OK && i < max_steps && (e.events.size() + per_step <= cap || (i == 0 && e.events.empty())); ++i) {
+        if (e.waiting.empty() && e.running.empty()) break;
+        rc = engine_all(h, [](cm::Engine& x) { x.step(); });
+    }
     size_t k = 0;
     while (k < cap && !e.events.empty()) { ev[k++] = e.events.front(); e.events.pop_front(); }
     *n = k;

@@ -5,7 +5,28 @@
 #include <stdint.h>
 #include "dev_common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace cm {
+
+// "first launch on this device" latch for hipFuncSetAttribute: function attributes are per device, and since round 4 one process
+// may drive several devices from several threads (in-process tensor-parallel groups).  run(f) calls f once per device; a thread
+// that finds the device's bit set knows the attribute call has completed.
+struct DevOnce {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    template <typename F> void run(F&& f) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        f();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_ATTNCOMB = 2, PRO_GDNNORM = 3 };
 enum { EPI_STORE = 0, EPI_RESADD = 1, EPI_SILUMUL = 2, EPI_ARGMAX = 3 };
@@ -363,5 +384,20 @@ void launch_sample_topk(const uint32_t* idx, const float* val, int k, float temp
                         uint32_t* token_out, hipStream_t s);
 void launch_gumbel_full(const float* logits, int V, float temperature, uint64_t seed, uint32_t draw, float* pmax, int* pidx, int blocks,
                         uint32_t* token_out, hipStream_t s);
+
+// peer-store collectives of an in-process tensor-parallel group (kernels_tp.hip)
+constexpr int TP_MAX_RANKS = 8;
+struct PeerCollArgs {
+    unsigned long long* inbox[TP_MAX_RANKS];   // inbox of rank d, peer-visible device memory on d's device: [2 parities][n][cap] granules
+    const uint32_t* send;                      // this rank's contribution: f32 bit patterns (sum) / 32-bit words (gather)
+    uint32_t* recv;                            // sum: [count] (may alias send); gather: [n][count] (send may alias slot `me`)
+    uint32_t* ctl;                             // this rank's control words in device memory: [0] epoch, [1] finish ticket
+    uint32_t* err;                             // host-visible (pinned, mapped) error word of this rank
+    long max_spin;                             // bound of the wait for one granule (iterations of ~0.1 us)
+    int n, me, count;
+    int recv_stride;                           // gather: elements between two ranks' slabs in recv
+    size_t cap;                                // granules per (parity, source rank) slot
+};
+void launch_peer_coll(int mode /*0 sum f32, 1 gather words*/, const PeerCollArgs& a, int blocks, hipStream_t s);
 
 }  // namespace cm

@@ -241,8 +241,8 @@ static void launch_gemvb_t(const GemvBArgs& a, int grid, hipStream_t s) {
     const dim3 g(grid), b(64 * BW);
     const int tk = ((std::min(a.K, BKT) + 511) / 512) * 512;
 #define CM_GB(MBV) { const size_t lds = (size_t)MBV * tk * 4 + 2 * BW * MBV * 4 + 64; \
-        static bool attr_##MBV = false; \
-        if (!attr_##MBV) { (void)hipFuncSetAttribute((const void*)gemvb_kernel<PRO, EPI, MBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_##MBV = true; } \
+        static DevOnce attr_##MBV; \
+        attr_##MBV.run([] { (void)hipFuncSetAttribute((const void*)gemvb_kernel<PRO, EPI, MBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((gemvb_kernel<PRO, EPI, MBV>), g, b, lds, s, a); }
     if (a.n_seq <= 2) CM_GB(2) else if (a.n_seq <= 4) CM_GB(4) else if (a.n_seq <= 8) CM_GB(8)
     else {

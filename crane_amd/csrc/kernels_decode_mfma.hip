@@ -305,12 +305,11 @@ int gemvm_grid(int N, int K, int num_cu, int n_seq) {
 template <int PRO, int EPI>
 static void launch_gemvm_t(const GemvBArgs& a, int grid, hipStream_t s) {
     const size_t ldsb = (size_t)2 * GM_MB * GM_LD * 2 + (GM_MB + 2 * GM_W * GM_MB) * 4 + 64;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;
+    attr.run([] {
         (void)hipFuncSetAttribute((const void*)gemvm_kernel<PRO, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemvm_kernel<PRO, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    });
     if (a.n_seq > 4) hipLaunchKernelGGL((gemvm_kernel<PRO, EPI, true>), dim3(grid), dim3(64 * GM_W), ldsb, s, a, gemvm_nkt(a.K));
     else hipLaunchKernelGGL((gemvm_kernel<PRO, EPI, false>), dim3(grid), dim3(64 * GM_W), ldsb, s, a, gemvm_nkt(a.K));
 }

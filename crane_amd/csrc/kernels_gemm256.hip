@@ -273,9 +273,9 @@ static size_t gemm256_lds(int split, int bn) { return (size_t)TST * ((size_t)spl
 
 template <int SPLIT, int EPI, int BN>
 static void launch_one(const GemmArgs& a, int blocks, hipStream_t s) {
-    static bool attr = false;
+    static DevOnce attr;
     const size_t lds = gemm256_lds(SPLIT, BN);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm256_kernel<SPLIT, EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    attr.run([&] { (void)hipFuncSetAttribute((const void*)gemm256_kernel<SPLIT, EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((gemm256_kernel<SPLIT, EPI, BN>), dim3(blocks), dim3(512), lds, s, a);
 }
 

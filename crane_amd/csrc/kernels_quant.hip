@@ -576,8 +576,8 @@ template <int FMT>
 static void launch_gemvq_f(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s) {
     constexpr int CK = QF<FMT>::CK;
     const size_t lds = (size_t)((a.w.K + CK - 1) / CK) * CK * 4 + 64;
-#define CM_Q(P, E) { static bool attr = false; \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemvq_kernel<FMT, P, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+#define CM_Q(P, E) { static DevOnce attr; \
+        attr.run([] { (void)hipFuncSetAttribute((const void*)gemvq_kernel<FMT, P, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((gemvq_kernel<FMT, P, E>), dim3(grid), dim3(256), lds, s, a); return; }
     if (pro == PRO_RMSNORM) {
         if (epi == EPI_STORE) CM_Q(PRO_RMSNORM, EPI_STORE)
@@ -1041,8 +1041,8 @@ int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu) {
 template <int FMT, int MB>
 static void launch_gemvqb_t(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s) {
     const size_t lds = (size_t)MB * gemvqb_seq_bytes(FMT, a.w.K) + 8 * 8 * 8;
-#define CM_QB(P, E) { static bool attr = false; \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemvqb_i8_kernel<FMT, P, E, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+#define CM_QB(P, E) { static DevOnce attr; \
+        attr.run([] { (void)hipFuncSetAttribute((const void*)gemvqb_i8_kernel<FMT, P, E, MB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((gemvqb_i8_kernel<FMT, P, E, MB>), dim3(grid), dim3(512), lds, s, a); return; }
     if (pro == PRO_RMSNORM && epi == EPI_STORE) CM_QB(PRO_RMSNORM, EPI_STORE)
     if (pro == PRO_RMSNORM && epi == EPI_SILUMUL) CM_QB(PRO_RMSNORM, EPI_SILUMUL)

@@ -25,6 +25,19 @@ T* Model::dalloc(size_t n, bool count_weight) {
         return (T*)base;
     }
     CM_HIP(hipMalloc(&p, bytes));
+    // CM_DEBUG_POISON=<byte>[,<first>,<last>]: fill every new allocation (or allocations number first..last of this handle) with
+    // the byte -- recycled device memory is not zero, a kernel that reads a buffer before anything wrote it must show up in tests
+    // on a FRESH process too (0xFF = NaN patterns)
+    static const char* poison = getenv("CM_DEBUG_POISON");
+    if (poison) {
+        int b = 0xFF, lo = 0, hi = 1 << 30;
+        sscanf(poison, "%i,%d,%d", &b, &lo, &hi);
+        const int idx = (int)allocs.size();
+        if (idx >= lo && idx <= hi) {       // on the handle's own (non-blocking) stream: ordered before whatever fills the buffer
+            CM_HIP(hipMemsetAsync(p, b, bytes, stream));
+            CM_HIP(hipStreamSynchronize(stream));
+        }
+    }
     allocs.push_back(p);
     alloc_sizes.push_back(count_weight ? bytes : 0);
     if (count_weight) weight_bytes += bytes;
@@ -80,7 +93,7 @@ Model::~Model() {
 void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (o) {
         opts = *o;
-        if (opts.abi_version != 0 && opts.abi_version != CM_ABI_VERSION)
+        if (opts.abi_version != 0 && (opts.abi_version < 2 || opts.abi_version > CM_ABI_VERSION))    // 2: the same layout with zeroed reserved words
             throw CmError(CM_ERR_INVALID, "cm_opts.abi_version mismatch");
     }
     cmjson::ValuePtr j;
@@ -361,7 +374,10 @@ void Model::alloc_runtime() {
         UniqueId self_id;
         const void* id = opts.tp_unique_id;
         if (force_cc && !id) { Rccl::unique_id(&self_id); id = &self_id; }
-        rccl->init(tp, rank, id, stream, (opts.debug_flags & CM_DEBUG_TP_LOCAL) != 0);
+        // in-process group (cm_opts.tp_mode = CM_TP_IN_PROCESS): the peer-store transport, or RCCL with the group's own id --
+        // ncclCommInitRank is called by all rank threads concurrently, as RCCL requires of ranks that share a process
+        if (peer_shared && peer_shared->use_peer) rccl->init_peer(peer_shared, rank, num_cu, stream);
+        else rccl->init(tp, rank, peer_shared ? (const void*)&peer_shared->uid : id, stream, (opts.debug_flags & CM_DEBUG_TP_LOCAL) != 0);
     }
     build_engine();
     CM_HIP(hipStreamSynchronize(stream));
@@ -577,7 +593,8 @@ void Model::engine_trace(float* out, size_t n) {
 // process, a profiler's serialisation -- can break that; the bounded spins then raise the error word and the launch ends with
 // garbage in the residual stream and in the K/V rows of the step.  That must not kill the handle: the word is cleared, the
 // persistent kernel switched off for this handle (the per-projection launch path takes over), the captured graphs dropped,
-// and the caller replays the step(s) it had enqueued -- a replay rewrites the same K/V rows.
+// and the caller replays the step(s) it had enqueued -- a replay rewrites the same K/V rows (dense family only: a hybrid
+// model's recurrent state was advanced by the failed step, so its callers raise instead -- hybrid_engine_abort).
 bool Model::engine_failed() {
     if (!engine_on) return false;
     CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
@@ -589,6 +606,17 @@ bool Model::engine_failed() {
     engine_on = false;
     drop_graphs();
     return true;
+}
+
+// Hybrid (Gated-Delta-Net) handles on the opt-in persistent chain: a timed-out launch has advanced the recurrent state, so
+// the step cannot be replayed; switch the chain off, and tell the caller the sequence state is gone.
+void Model::hybrid_engine_abort() {
+    (void)engine_failed();
+    char b[256];
+    snprintf(b, sizeof b, "persistent decode kernel timed out (code 0x%x) on a hybrid model: the Gated-Delta-Net state of the "
+             "sequence was advanced by the failed step and cannot be replayed; truncate the sequence to 0 and re-prefill "
+             "(the persistent path is now off for this handle)", (unsigned)eng_fail_code);
+    throw CmError(CM_ERR_DEVICE, b);
 }
 
 void Model::engine_check() {
@@ -622,6 +650,9 @@ void Model::seq_truncate(int s, size_t new_len) {
         if (new_len != 0) throw CmError(CM_ERR_UNSUPPORTED, "Gated-Delta-Net state cannot be truncated to a non-zero length");
         reset_gdn_state(s);
     }
+    // a sequence cut back INTO an image prompt would rotate its next tokens at cache position + rope_delta < 0
+    if (new_len != 0 && (int64_t)new_len + (int64_t)q.rope_delta < 0)
+        throw CmError(CM_ERR_RANGE, "truncate into an image prompt: rotary position would be negative (truncate to 0 instead)");
     const size_t keep = (new_len + page - 1) / page;
     while (q.pages.size() > keep) {
         const int32_t p = q.pages.back();
@@ -978,6 +1009,14 @@ void Model::enqueue_lm_head(bool advance) {
 // ------------------------------------------------------------------------------------
 // prefill (S > 1): MFMA GEMMs + causal flash attention over the paged cache
 // ------------------------------------------------------------------------------------
+// split-K partial tiles of short prompts / narrow GEMMs (launch_gemm): its own allocation so that the vision tower, which
+// only needs this workspace, does not allocate the text path's prompt buffers (and the f32 K/V shadows of int8 / int4 pages)
+void Model::ensure_gemm_workspace() {
+    if (!pWS) {
+        pWS = dalloc<float>(gemm_ws_floats);
+    }
+}
+
 void Model::ensure_prefill_buffers() {
     if (pX) return;
     const int H = cfg.H, D = cfg.D;
@@ -994,7 +1033,7 @@ void Model::ensure_prefill_buffers() {
                  (!cfg.hybrid || cfg.value_dim() % 32 == 0);
     if (!prefill_ok) return;
     pX = dalloc<float>((size_t)chunk * H);
-    pWS = dalloc<float>(gemm_ws_floats);             // split-K partial tiles of short prompts (launch_gemm)
+    ensure_gemm_workspace();
     if (rccl) pY = dalloc<float>((size_t)chunk * H);
     pQKV = dalloc<float>((size_t)chunk * std::max(qkv_rows, in_proj_pad));
     if (cfg.hybrid) {
@@ -1672,7 +1711,7 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
     // appending into a page shared with a fork is not allowed: fork already copied the partial page
     ensure_pages(s, (int64_t)(start_pos + n));
     activate(s);
-    bool use_prefill = false;
+    bool use_prefill = false, st_fresh = false;
     // quantised weights: each matrix is dequantised to a bf16 scratch in front of its MFMA GEMM (CM_QUANT_PREFILL=0:
     // token-serial, i.e. the decode kernels' integer-dot arithmetic for the prompt too)
     if (n >= 2 && (!quantized || quant_prefill) && !no_prefill) {
@@ -1687,15 +1726,26 @@ void Model::forward(int s, const uint32_t* ids, size_t n, size_t start_pos, floa
                 launch_set_state(st, ids[i], (int32_t)(start_pos + i), s, q.rope_delta, stream);
                 run_decode_step(true, (int64_t)(start_pos + i + 1));
             }
-            // a timed-out persistent launch switched itself off: the same steps again on the per-projection launches
-            // (they rewrite the K/V rows of these positions; the recurrent GDN family never runs the persistent kernel)
-            if (!engine_on || !engine_failed()) break;
+            if (!engine_on) break;
+            // ONE copy of the step state serves the time-out check and the greedy token (no second host sync per token)
+            CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
+            CM_HIP(hipStreamSynchronize(stream));
+            if (h_st->rsv[2] == 0) { st_fresh = true; break; }
+            // a timed-out persistent launch switched itself off.  Dense family: the same steps again on the per-projection
+            // launches (they rewrite the K/V rows of these positions -- appends are idempotent).  Hybrid family: the failed
+            // attempt already advanced the conv window and the delta-rule state of this sequence, possibly on garbage; a
+            // replay would advance them a second time, so there is no silent retry -- the call fails and the caller has to
+            // cm_seq_truncate(seq, 0) / re-prefill (the persistent path is off for the handle from here on).
+            if (cfg.hybrid) { q.len = (int64_t)start_pos; hybrid_engine_abort(); }
+            (void)engine_failed();
         }
     }
     q.len = (int64_t)(start_pos + n);
     if (greedy_out) {
-        CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
-        CM_HIP(hipStreamSynchronize(stream));
+        if (!st_fresh) {
+            CM_HIP(hipMemcpyAsync(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost, stream));
+            CM_HIP(hipStreamSynchronize(stream));
+        }
         *greedy_out = h_st->next;
     }
     if (logits_out) fetch_logits(logits_out);
@@ -1774,7 +1824,10 @@ void Model::generate(const uint32_t* prompt, size_t n_prompt, const cm_gen_confi
             for (size_t i = 0; i < want; ++i) run_decode_step(true, q.len + (int64_t)i + 1);
             CM_HIP(hipMemcpyAsync(h_ring, ring, RING * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             CM_HIP(hipStreamSynchronize(stream));
-            if (engine_on && engine_failed()) continue;     // nothing of this chunk was emitted: the same steps again, launch path
+            if (engine_on && cfg.hybrid) {                  // recurrent state cannot be replayed (see forward()): fail loudly
+                CM_HIP(hipMemcpy(h_st, st, sizeof(StepState), hipMemcpyDeviceToHost));
+                if (h_st->rsv[2] != 0) hybrid_engine_abort();
+            } else if (engine_on && engine_failed()) continue;   // nothing of this chunk was emitted: the same steps again, launch path
             size_t used = 0;
             for (size_t i = 0; i < want && !stop; ++i) { emit(h_ring[(ring0 + i) & (RING - 1)]); ++used; }
             q.len += (int64_t)used;     // tokens decoded past an EOS/stop stay beyond len and are overwritten later

@@ -113,7 +113,8 @@ struct VisionW {
     std::vector<Merger> deep;     // deepstack_merger_list.k: LayerNorm over the regrouped 4 x hidden row, fc1 + GELU, fc2
 };
 
-struct Rccl;   // dlopen'ed RCCL entry points + communicator (tp.cpp)
+struct Rccl;         // dlopen'ed RCCL entry points + communicator, or the peer-store transport of an in-process group (tp.cpp)
+struct PeerShared;   // state shared by the ranks of an in-process tensor-parallel group (tp.h)
 
 struct Model {
     Config cfg;
@@ -333,6 +334,7 @@ struct Model {
                                                // then already switched off for this handle (engine_failed), later calls work
     bool engine_failed();                      // syncs; true if a launch timed out: error word cleared, persistent kernel disabled,
                                                // graphs dropped -- the caller replays its step(s) on the per-projection launches
+    [[noreturn]] void hybrid_engine_abort();   // hybrid family: a timed-out chain launch advanced the recurrent state -- no replay, CM_ERR_DEVICE
     bool engine_capable = false;               // build_engine succeeded (cm_debug_set("engine", 1) may switch it back on)
     bool engine_full_capable = false;
     size_t eng_gsz[ENG_NEDGE] = {0, 0, 0, 0, 0, 0};   // granules per edge buffer (bounds of cm_debug_read("eng_*"))
@@ -362,6 +364,7 @@ int prefill_lo_mask = 0;              // EXPERIMENT (cm_debug_set "prefill_lo_ma
     bool use_graph = true;
 
     std::unique_ptr<Rccl> rccl;
+    PeerShared* peer_shared = nullptr;   // set by the TpGroup before alloc_runtime: this Model is one rank of an in-process group
     std::string err;
 
     ~Model();
@@ -391,6 +394,7 @@ int prefill_lo_mask = 0;              // EXPERIMENT (cm_debug_set "prefill_lo_ma
     void enqueue_lm_head(bool advance);         // final norm + lm_head + arg-max on x
     void enqueue_quant_layer(int li);           // dense layer over GGUF / ISQ weights
     void ensure_prefill_buffers();
+    void ensure_gemm_workspace();
     void prefill(const uint32_t* ids, size_t n, size_t start_pos);   // active sequence, pages ensured
     struct PrefillSeg { int row0, S, start_pos, seq, rope_delta; const int32_t* bt; };   // rows of ONE sequence inside a prompt pass
     void prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off);

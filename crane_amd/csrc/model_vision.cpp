@@ -60,7 +60,7 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     }
     if (expect != n_patches) throw CmError(CM_ERR_INVALID, "pixel_values rows != sum(t*h*w) of grid_thw");
     ensure_vision_buffers((int)n_patches);
-    ensure_prefill_buffers();                  // (the split-K workspace of the GEMMs)
+    ensure_gemm_workspace();                   // (the split-K workspace of the GEMMs; not the text path's prompt buffers)
     const int N = (int)n_patches;
     hipStream_t s = stream;
 
@@ -271,6 +271,11 @@ void Model::forward_embeds(int sidx, const float* embeds, size_t n, const int32_
             if (pos3[i] < 0 || pos3[i] >= max_seq) throw CmError(CM_ERR_RANGE, "position id outside the rotary table");
             top = std::max(top, pos3[i]);
         }
+        // later steps of this sequence rotate at cache position + rope_delta (= top + 1 - len, vlm.rs:294-301) and the sequence
+        // may grow to max_seq tokens: a POSITIVE delta would walk past the max_seq-row cos / sin table before the cache is
+        // full.  Image prompts compress positions (delta <= 0); a pos3 that runs ahead of the cache is refused up front.
+        if ((int64_t)top + 1 > (int64_t)(start_pos + n))
+            throw CmError(CM_ERR_RANGE, "pos3 runs ahead of the cache (max position + 1 > start_pos + n): later steps would leave the rotary table");
         if (!dMap) { dMap = dalloc<int>(chunk); dPos3 = dalloc<int>((size_t)3 * chunk); }
         CM_HIP(hipMemcpyAsync(dPos3, pos3, 3 * n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         CM_HIP(hipStreamSynchronize(stream));

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CM_ABI_VERSION 2
+#define CM_ABI_VERSION 3
 
 typedef enum cm_status {
     CM_OK = 0,
@@ -91,8 +91,27 @@ typedef struct cm_opts {
                                /*   the handle then switches the kernel off for good, replays the step on the    */
                                /*   per-projection launches and carries on (cm_engine_active turns 0).           */
     uint32_t debug_flags;      /* CM_DEBUG_* bits; test hooks only, never set in production                      */
-    uint32_t reserved[5];
+    uint32_t tp_mode;          /* how the tp_size ranks are hosted (round 4, CM_ABI_VERSION 3; same struct size):   */
+                               /*   CM_TP_SPMD (0): this handle is ONE rank (tp_rank on `device`); one process per  */
+                               /*     GPU, every process issues the same cm_* calls, RCCL id in tp_unique_id.       */
+                               /*   CM_TP_IN_PROCESS (1): this ONE handle owns ALL tp_size ranks -- one shard per    */
+                               /*     device of tp_devices, driven by library worker threads; every cm_* call on    */
+                               /*     the handle (and a cm_engine on it) runs on all ranks and returns rank 0's     */
+                               /*     results.  What a single ModelBackend object in crane-serve's one engine       */
+                               /*     thread (crane-serve/src/lib.rs:1129-1132, engine/backend.rs:30) can host.     */
+                               /*     tp_rank / tp_unique_id are ignored.                                           */
+    const int32_t* tp_devices; /* CM_TP_IN_PROCESS: tp_size device ordinals (NULL: device, device + 1, ...).        */
+                               /*   tp_size DISTINCT devices, or ONE ordinal tp_size times (test mode: every rank   */
+                               /*   on one GPU -- the sharding and the exchange steps on a 1-GPU box; exchange      */
+                               /*   through the peer-store collective, RCCL refuses two ranks per device).          */
+    uint32_t tp_collective;    /* CM_TP_IN_PROCESS: 0 default (RCCL over xGMI on distinct devices), CM_TP_COLL_RCCL, */
+                               /*   CM_TP_COLL_PEER (one-shot push all-reduce over peer-visible memory, csrc/       */
+                               /*   kernels_tp.hip: no RCCL call in the token loop; not yet measured on > 1 GPU)    */
+    uint32_t reserved[1];
 } cm_opts;
+
+enum { CM_TP_SPMD = 0u, CM_TP_IN_PROCESS = 1u };
+enum { CM_TP_COLL_DEFAULT = 0u, CM_TP_COLL_RCCL = 1u, CM_TP_COLL_PEER = 2u };
 
 /* cm_opts.debug_flags.  TP_LOCAL: no communicator is created and every collective is a local no-op, so ONE rank of a
  * tensor-parallel model can run alone and be compared with the oracle on its shard (the logits are partial sums!).
@@ -160,8 +179,9 @@ uint64_t cm_weight_bytes(const cm_model* m);
  * (SURVEY.md section 8(d) formula; used by bench.py's roofline object) */
 uint64_t cm_decode_bytes_per_token(const cm_model* m, size_t ctx);
 
-/* ranks of the RCCL communicator this handle reduces over: 1 without tensor parallelism, tp_size once the communicator
- * is up, 0 when the collectives are local no-ops (CM_DEBUG_TP_LOCAL) -- bench.py asserts it equals --gpus */
+/* ranks this handle reduces over: 1 without tensor parallelism, tp_size once the communicator (RCCL, or the peer-store
+ * group of CM_TP_IN_PROCESS) is up, 0 when the collectives are local no-ops (CM_DEBUG_TP_LOCAL) -- bench.py asserts it
+ * equals --gpus */
 int cm_tp_ranks(const cm_model* m);
 /* decode path of this handle: 0 per-projection launches; 1 persistent kernel, one launch per layer around the separate attention
  * kernels; 2 persistent kernel, the whole token (every projection and the attention of every layer) in one launch */
@@ -441,6 +461,11 @@ int cm_debug_read(cm_model* m, const char* what, float* out, size_t n);
  * model's activation mode (integer dot or f32).  which: "qkv0".."qkv2" (segments), "o", "gate_up" (interleaved rows
  * 2j = gate_j, 2j+1 = up_j) | "gate" | "up", "down", "lm_head".  Kernel-level parity hook for tests. */
 int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n);
+
+/* Test hook: the peer-store all-reduce / all-gather of an in-process group alone (csrc/kernels_tp.hip): n_ranks threads on
+ * `device`, `iters` rounds over `count` elements, every sum and gather checked on the host.  Returns the number of wrong
+ * elements (0 = pass), < 0 on error (cm_last_global_error). */
+long cm_debug_peer_selftest(int32_t n_ranks, int32_t device, int32_t iters, int32_t count);
 
 /* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at
  * cm_create).  "no_prefill" = 1: prompts run token by token through the decode kernels; "quant_prefill" = 0: prompts over

@@ -210,6 +210,166 @@ int qc_forward(qc_model* m, const uint32_t* ids, int n, int start_pos, float* lo
     return 0;
 }
 
+/* Y[t*ldy + n] = W[n,:] . X[t*ldx + :]  for T token rows: the weight matrix is streamed ONCE for all rows (a 1024-token prompt
+ * costs 1024 decode steps' flops but one pass over the 16 GB of weights instead of 1024).  Every (n, t) dot product is the
+ * arithmetic of gemv() -- the same 16 lane accumulators in ascending k, the same tail, the same fixed tree -- so a row of the
+ * result is bit-identical to the token-serial forward (tests/test_c_oracle.py::test_batched_prompt_pass_is_bit_identical). */
+#define QC_RB 4
+#define QC_TB 6
+static void gemm_rows(const uint16_t* W, const float* X, size_t ldx, float* Y, size_t ldy, int N, int K, int T) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int n0 = 0; n0 < N; n0 += QC_RB) {
+        const int nr = N - n0 < QC_RB ? N - n0 : QC_RB;
+        for (int t0 = 0; t0 < T; t0 += QC_TB) {
+            const int nt = T - t0 < QC_TB ? T - t0 : QC_TB;
+            v16f acc[QC_RB][QC_TB];
+            for (int r = 0; r < QC_RB; ++r) for (int t = 0; t < QC_TB; ++t) acc[r][t] = (v16f){0};
+            int k = 0;
+            if (nr == QC_RB && nt == QC_TB) {
+                for (; k + 16 <= K; k += 16) {
+                    v16f f[QC_RB];
+                    for (int r = 0; r < QC_RB; ++r) {
+                        v16h h; memcpy(&h, W + (size_t)(n0 + r) * K + k, sizeof h);
+                        const v16u u = __builtin_convertvector(h, v16u) << 16;
+                        memcpy(&f[r], &u, sizeof f[r]);
+                    }
+                    for (int t = 0; t < QC_TB; ++t) {
+                        v16f xv; memcpy(&xv, X + (size_t)(t0 + t) * ldx + k, sizeof xv);
+                        for (int r = 0; r < QC_RB; ++r) acc[r][t] += f[r] * xv;
+                    }
+                }
+            } else {
+                for (; k + 16 <= K; k += 16)
+                    for (int r = 0; r < nr; ++r) {
+                        v16h h; v16f f; memcpy(&h, W + (size_t)(n0 + r) * K + k, sizeof h);
+                        const v16u u = __builtin_convertvector(h, v16u) << 16;
+                        memcpy(&f, &u, sizeof f);
+                        for (int t = 0; t < nt; ++t) {
+                            v16f xv; memcpy(&xv, X + (size_t)(t0 + t) * ldx + k, sizeof xv);
+                            acc[r][t] += f * xv;
+                        }
+                    }
+            }
+            for (int r = 0; r < nr; ++r)
+                for (int t = 0; t < nt; ++t) {
+                    float a[16];
+                    memcpy(a, &acc[r][t], sizeof a);
+                    const uint16_t* w = W + (size_t)(n0 + r) * K;
+                    const float* x = X + (size_t)(t0 + t) * ldx;
+                    for (int kk = k; kk < K; ++kk) a[kk & 15] += bf2f(w[kk]) * x[kk];
+                    float s8[8];
+                    for (int j = 0; j < 8; ++j) s8[j] = a[j] + a[j + 8];
+                    Y[(size_t)(t0 + t) * ldy + n0 + r] = ((s8[0] + s8[4]) + (s8[1] + s8[5])) + ((s8[2] + s8[6]) + (s8[3] + s8[7]));
+                }
+        }
+    }
+}
+
+/* qc_forward for a whole prompt, layer-major (the shape of the reference's batched causal prefill, modeling.rs:984-1036 with
+ * seq_len > 1): per layer every position is normed, projected, rotated and appended, attends causally over the cache, and goes
+ * through the MLP; logits of the LAST position only.  Position by position it is decode_one()'s arithmetic, so the result is
+ * bit-identical to qc_forward(); what changes is that each weight matrix is read once.  Used for long model-written caches
+ * (bench.py parity.model_written_cache_ctx1024: 1024 tokens of Qwen3-8B). */
+int qc_forward_batched(qc_model* m, const uint32_t* ids, int n, int start_pos, float* logits) {
+    if (!m || n <= 0 || start_pos < 0 || start_pos + n > m->c.max_seq) return -1;
+    const qc_cfg* c = &m->c;
+    const int H = c->H, D = c->D, I = c->I, Hq = c->Hq, Hkv = c->Hkv, qd = Hq * D, kd = Hkv * D, half = D / 2;
+    const int n_rep = Hq / Hkv, QR = qd + 2 * kd;
+    const float scale = (float)(1.0 / sqrt((double)D));
+    for (int i = 0; i < n; ++i) if (ids[i] >= (uint32_t)c->V) return -2;
+    float* X = (float*)xmalloc((size_t)n * H * 4);
+    float* XN = (float*)xmalloc((size_t)n * H * 4);
+    float* QKV = (float*)xmalloc((size_t)n * QR * 4);
+    float* AT = (float*)xmalloc((size_t)n * qd * 4);
+    float* GU = (float*)xmalloc((size_t)n * 2 * I * 4);
+    float* HB = (float*)xmalloc((size_t)n * I * 4);
+    for (int t = 0; t < n; ++t)
+        for (int i = 0; i < H; ++i) X[(size_t)t * H + i] = bf2f(m->embed[(size_t)ids[t] * H + i]);
+    for (int li = 0; li < c->L; ++li) {
+        qc_layer* w = &m->layers[li];
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; ++t) rms_norm(X + (size_t)t * H, w->ln1, XN + (size_t)t * H, H, c->eps);
+        gemm_rows(w->qkv, XN, (size_t)H, QKV, (size_t)QR, QR, H, n);
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; ++t) {
+            const int pos = start_pos + t;
+            float* q = QKV + (size_t)t * QR; float* k = q + qd; float* v = q + qd + kd;
+            const float* cs = m->cos + (size_t)pos * half; const float* sn = m->sin + (size_t)pos * half;
+            for (int h = 0; h < Hq + Hkv; ++h) {
+                float* p = (h < Hq) ? q + (size_t)h * D : k + (size_t)(h - Hq) * D;
+                if (c->qk_norm) {
+                    const uint16_t* nw = (h < Hq) ? w->qn : w->kn;
+                    float ss = 0.f;
+                    for (int i = 0; i < D; ++i) ss += p[i] * p[i];
+                    const float r = 1.0f / sqrtf(ss / (float)D + c->eps);
+                    for (int i = 0; i < D; ++i) p[i] = p[i] * r * bf2f(nw[i]);
+                }
+                for (int i = 0; i < half; ++i) {
+                    const float x1 = p[i], x2 = p[i + half];
+                    p[i] = x1 * cs[i] - x2 * sn[i];
+                    p[i + half] = x1 * sn[i] + x2 * cs[i];
+                }
+            }
+            for (int g = 0; g < Hkv; ++g)
+                for (int i = 0; i < D; ++i) {
+                    float kk = k[(size_t)g * D + i], vv = v[(size_t)g * D + i];
+                    if (c->kv_bf16 == 1) { kk = bf2f(f2bf(kk)); vv = bf2f(f2bf(vv)); }
+                    else if (c->kv_bf16 == 2) { kk = f16_round(kk); vv = f16_round(vv); }
+                    w->k[((size_t)g * c->max_seq + pos) * D + i] = kk;
+                    w->v[((size_t)g * c->max_seq + pos) * D + i] = vv;
+                }
+        }
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+        for (int t = 0; t < n; ++t)
+            for (int h = 0; h < Hq; ++h) {
+                const int pos = start_pos + t;
+                const float* qh = QKV + (size_t)t * QR + (size_t)h * D;
+                const float* kh = w->k + (size_t)(h / n_rep) * c->max_seq * D;
+                const float* vh = w->v + (size_t)(h / n_rep) * c->max_seq * D;
+                float mx = -INFINITY, l = 0.f;
+                float acc[256];
+                for (int i = 0; i < D; ++i) acc[i] = 0.f;
+                for (int j = 0; j <= pos; ++j) {
+                    float s = 0.f;
+                    for (int i = 0; i < D; ++i) s += qh[i] * kh[(size_t)j * D + i];
+                    s *= scale;
+                    const float mn = s > mx ? s : mx;
+                    const float a = expf(mx - mn), p = expf(s - mn);
+                    l = l * a + p;
+                    for (int i = 0; i < D; ++i) acc[i] = acc[i] * a + p * vh[(size_t)j * D + i];
+                    mx = mn;
+                }
+                for (int i = 0; i < D; ++i) AT[(size_t)t * qd + (size_t)h * D + i] = acc[i] / l;
+            }
+        gemm_rows(w->o, AT, (size_t)qd, XN, (size_t)H, H, qd, n);
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; ++t) {
+            float* x = X + (size_t)t * H; const float* y = XN + (size_t)t * H;
+            for (int i = 0; i < H; ++i) x[i] += y[i];
+        }
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; ++t) rms_norm(X + (size_t)t * H, w->ln2, XN + (size_t)t * H, H, c->eps);
+        gemm_rows(w->gate_up, XN, (size_t)H, GU, (size_t)2 * I, 2 * I, H, n);
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; ++t)
+            for (int i = 0; i < I; ++i) { const float g = GU[(size_t)t * 2 * I + i]; HB[(size_t)t * I + i] = (g / (1.0f + expf(-g))) * GU[(size_t)t * 2 * I + I + i]; }
+        gemm_rows(w->down, HB, (size_t)I, XN, (size_t)H, H, I, n);
+#pragma omp parallel for schedule(static)
+        for (int t = 0; t < n; ++t) {
+            float* x = X + (size_t)t * H; const float* y = XN + (size_t)t * H;
+            for (int i = 0; i < H; ++i) x[i] += y[i];
+        }
+    }
+    if (logits) {
+        rms_norm(X + (size_t)(n - 1) * H, m->norm, m->xn, H, c->eps);
+        gemv(m->lm_head, m->xn, logits, c->V, H);
+    }
+    memcpy(m->x, X + (size_t)(n - 1) * H, (size_t)H * 4);
+    free(X); free(XN); free(QKV); free(AT); free(GU); free(HB);
+    m->len = start_pos + n;
+    return 0;
+}
+
 /* fill the KV cache of positions [0, ctx) with deterministic values (bench set-up only) */
 void qc_fill_kv(qc_model* m, int ctx, uint64_t seed) {
     const qc_cfg* c = &m->c;

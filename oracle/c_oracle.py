@@ -40,6 +40,7 @@ def _lib():
     lib.qc_create.restype = C.c_void_p
     lib.qc_destroy.argtypes = [C.c_void_p]
     lib.qc_forward.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.qc_forward_batched.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.qc_fill_kv.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
     lib.qc_fill_kv_paged.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int]
     lib.qc_num_threads.restype = C.c_int
@@ -98,6 +99,16 @@ class CQwen3:
                                  out.ctypes.data_as(C.POINTER(C.c_float)))
         if rc != 0:
             raise RuntimeError(f"qc_forward failed: {rc}")
+        return out
+
+    def forward_batched(self, ids, start_pos: int) -> np.ndarray:
+        """qc_forward with every weight matrix streamed once for the whole prompt (layer-major); bit-identical to forward()."""
+        a = np.ascontiguousarray(np.asarray(ids, dtype=np.uint32))
+        out = np.empty(self.V, dtype=np.float32)
+        rc = self.lib.qc_forward_batched(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size, start_pos,
+                                         out.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != 0:
+            raise RuntimeError(f"qc_forward_batched failed: {rc}")
         return out
 
     def fill_kv(self, ctx: int, seed: int = 1):
@@ -161,7 +172,8 @@ class CQwen35(CQwen3):
             self.h = None
 
 
-def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: int = 48, n_new: int = 16):
+def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: int = 48, n_new: int = 16, long_ctx: int = 0,
+                long_budget_s: float = 90.0):
     """bench.py's CPU leg: (cpu_baseline dict, greedy tokens, logits of the first step, model-written-cache reference).
 
     Timing: the KV cache of positions [0, ctx) holds the values cm_debug_fill_kv writes on the device and the first token is
@@ -170,7 +182,12 @@ def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: i
     what the device's K/V pages do to values the model wrote itself.
     Parity proper (4th result): a `prompt_len`-token prompt fed from an EMPTY cache, one decode step and `n_new` greedy tokens
     -- the f32 CPU forward (K/V appends unrounded) on a cache the model wrote itself; bench.py runs the same through the
-    HIP path (MFMA prefill, then the decode kernels over the pages that prefill wrote) and compares logits and ids."""
+    HIP path (MFMA prefill, then the decode kernels over the pages that prefill wrote) and compares logits and ids.
+    `long_ctx` > 0 adds written["long"]: the same on a `long_ctx`-token prompt (the benchmark's context: K/V rounding error of the
+    device's pages grows with depth AND context, so the headline configuration is checked at its own context, not extrapolated
+    from 48 tokens).  The dense port streams each weight matrix once for the whole prompt (qc_forward_batched, bit-identical to
+    the token-serial forward); the hybrid port is token-serial and the leg is skipped -- with the reason -- when the measured
+    decode rate says it would take longer than `long_budget_s`."""
     from crane_amd import configs
     cfg = configs.get_config(model_name)
     t0 = time.perf_counter()
@@ -199,6 +216,23 @@ def time_decode(model_name: str, ctx: int, budget_s: float = 20.0, prompt_len: i
         toks.append(tok)
         n += 1
     thr = m.threads()
+    if long_ctx > 0:
+        est = long_ctx / max(n / dt, 1e-9) if hybrid else 0.0
+        if hybrid and est > long_budget_s:
+            written["long"] = {"skipped": f"token-serial hybrid CPU port: {long_ctx} tokens at {n / dt:.1f} tokens/s = {est:.0f}s "
+                                          f"> {long_budget_s:.0f}s budget (run bench.py --parity-budget {int(est) + 60} to include it)"}
+        else:
+            t1 = time.perf_counter()
+            lp = configs.synthetic_prompt(long_ctx, cfg.get("text_config", cfg)["vocab_size"])
+            pl = m.forward(lp, 0) if hybrid else m.forward_batched(lp, 0)
+            g2 = [int(pl.argmax())]
+            dl = m.forward([g2[0]], long_ctx)
+            lg2 = dl
+            for i in range(1, n_new):
+                g2.append(int(lg2.argmax()))
+                lg2 = m.forward([g2[-1]], long_ctx + i)
+            written["long"] = {"prompt": lp, "prefill_logits": pl, "decode_logits": dl, "greedy": g2,
+                               "cpu_seconds": round(time.perf_counter() - t1, 1)}
     m.close()
     base = {"value": round(n / dt, 3), "unit": "tokens/s", "cores": thr, "kind": "port",
             "sample": f"{n} greedy decode steps of {model_name} at context {ctx} (bf16-stored weights, f32 compute, "

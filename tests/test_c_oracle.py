@@ -162,3 +162,18 @@ def test_c_port_runs_the_text_model_of_a_vl_checkpoint():
     finally:
         c.close()
         c_oracle.CQwen3(configs.get_config("tiny-qwen3"), seed=0, max_seq=16).close()      # (resets the name prefix)
+
+
+@pytest.mark.parametrize("name,n", [("tiny-qwen3", 37), ("tiny-qwen3-untied", 6)])
+def test_batched_prompt_pass_is_bit_identical(name, n):
+    """qc_forward_batched (every weight matrix streamed once for the whole prompt: what makes a 1024-token, 36-layer reference
+    affordable in bench.py's parity leg) is qc_forward's arithmetic position by position -- logits AND the cache it leaves."""
+    cfg = configs.get_config(name)
+    a = c_oracle.CQwen3(cfg, seed=0, max_seq=96)
+    b = c_oracle.CQwen3(cfg, seed=0, max_seq=96)
+    ids = configs.synthetic_prompt(n, cfg["vocab_size"])
+    assert np.array_equal(a.forward(ids, 0), b.forward_batched(ids, 0))
+    assert np.array_equal(a.forward([5], n), b.forward([5], n))                       # decode over the cache each pass wrote
+    more = configs.synthetic_prompt(9, cfg["vocab_size"])
+    assert np.array_equal(a.forward(more, n + 1), b.forward_batched(more, n + 1))     # a second chunk on a non-empty cache
+    a.close(); b.close()

@@ -74,3 +74,29 @@ def test_library_exports_every_header_symbol():
 def test_struct_sizes_match_header():
     assert ctypes.sizeof(_lib.CmOpts) == 4 * 4 + 8 + 3 * 4 + 4 + 8 + 4 * 4 + 8 * 4
     assert ctypes.sizeof(_lib.CmGenConfig) == 5 * 4 + 4 + 4 * 8 + 4 + 7 * 4 + 4 or ctypes.sizeof(_lib.CmGenConfig) % 8 == 0
+
+
+def test_in_process_tp_options_are_validated_without_a_gpu():
+    """cm_opts.tp_mode = CM_TP_IN_PROCESS (one handle owns every rank): the option block keeps its size (the new fields live in the
+    former reserved words), the fields sit where the header puts them, and a host without a device gets a status code + message,
+    not a crash."""
+    o = _lib.CmOpts
+    assert (o.debug_flags.offset, o.tp_mode.offset, o.tp_devices.offset, o.tp_collective.offset) == (72, 76, 80, 88)
+    lib = _lib.load()
+    opts = _lib.CmOpts()
+    opts.abi_version = _lib.CM_ABI_VERSION
+    opts.tp_size, opts.tp_mode = 2, 1
+    devs = (ctypes.c_int32 * 2)(0, 0)
+    opts.tp_devices = ctypes.cast(devs, ctypes.POINTER(ctypes.c_int32))
+    h = ctypes.c_void_p()
+    cfg = json.dumps(configs.get_config("tiny-qwen3-untied")).encode()
+    rc = lib.cm_create_synthetic(cfg, 0, ctypes.byref(opts), ctypes.byref(h))
+    import torch
+    if not torch.cuda.is_available():
+        assert rc != 0 and not h.value and b"device" in lib.cm_last_global_error().lower()
+    else:
+        assert rc == 0
+        lib.cm_destroy(h)
+    opts.abi_version = 2                                   # an older caller cannot ask for the new mode
+    rc = lib.cm_create_synthetic(cfg, 0, ctypes.byref(opts), ctypes.byref(h))
+    assert rc != 0
