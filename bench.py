@@ -166,11 +166,19 @@ def main():
                     "slices rank --rank of N, every collective is a local no-op (CM_DEBUG_TP_LOCAL).  The line is labelled "
                     "emulated_shard r/N, rccl_ranks 1: the compute half of the 1->N scaling curve, NOT an N-GPU number")
     ap.add_argument("--rank", type=int, default=0, help="which rank's shard --tp-local times")
+    ap.add_argument("--tp-inprocess", type=int, default=0, metavar="N", help="ONE handle that owns all N ranks (cm_opts.tp_mode = "
+                    "CM_TP_IN_PROCESS: library worker threads, what a single crane-serve ModelBackend can host).  With N visible "
+                    "GPUs: one rank per GPU (a real N-GPU number, n_gpus = N).  With fewer: every rank on GPU 0 (emulated_group: "
+                    "functional -- parity of the sharded model against the CPU oracle -- the time is NOT an N-GPU number)")
+    ap.add_argument("--tp-collective", default=None, choices=["rccl", "peer"], help="exchange steps of --tp-inprocess on distinct "
+                    "devices: RCCL (default) or the peer-store kernels")
     ap.add_argument("--force-rccl", action="store_true", help="TP=1 with every reduction routed through a 1-rank RCCL communicator "
                     "(CM_DEBUG_FORCE_RCCL): per-call enqueue cost of the collectives, one GPU")
     ap.add_argument("--isq", default=None, help="in-situ weight quantisation (q8_0): a DIFFERENT workload than the bf16 headline")
     args = ap.parse_args()
 
+    if args.tp_inprocess:      # ranks that share a device need one hardware queue per rank stream: before the HIP runtime starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     n = args.gpus
     if n < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -212,13 +220,28 @@ def main():
     tpl = args.tp_local
     if tpl and (n != 1 or not (0 <= args.rank < tpl)):
         raise SystemExit("--tp-local N needs --gpus 1 and 0 <= --rank < N")
-    m = Model.synthetic(cfg, seed=0, device=local_rank if world > 1 else 0,
+    tpg, emulated = args.tp_inprocess, False
+    if tpg:
+        if world != 1 or tpl or args.force_rccl:
+            raise SystemExit("--tp-inprocess is a single-process mode (no torchrun, no --tp-local / --force-rccl)")
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        emulated = have < tpg
+        devs = [0] * tpg if emulated else list(range(tpg))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        m = Model.synthetic(cfg, seed=0, max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1, use_graph=-1 if args.no_graph else 0,
+                            tp_size=tpg, tp_in_process=True, tp_devices=devs, tp_collective=args.tp_collective, kv_dtype=args.kv)
+        if m.tp_ranks() != tpg:
+            raise SystemExit(f"library reports {m.tp_ranks()} rank(s), expected {tpg}")
+        n = tpg if not emulated else 1
+    m = m if tpg else Model.synthetic(cfg, seed=0, device=local_rank if world > 1 else 0,
                         max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1,
                         use_graph=-1 if args.no_graph else 0, engine=args.engine,
                         tp_rank=args.rank if tpl else rank, tp_size=tpl if tpl else world, tp_unique_id=uid, isq=args.isq,
                         kv_dtype=args.kv, debug_tp_local=bool(tpl), debug_force_rccl=args.force_rccl)
     ranks = m.tp_ranks()
-    if tpl:
+    if tpg:
+        pass
+    elif tpl:
         if ranks != 0:
             raise SystemExit(f"--tp-local: expected no communicator, library reports {ranks} rank(s)")
         args.no_cpu_baseline = True          # a single rank's partial sums have no CPU counterpart (tests/test_gpu_tp_shards.py checks them)
@@ -260,7 +283,7 @@ def main():
     # chain launch itself (o_proj + gate||up + down_proj + next QKV: every weight byte of a layer)
     roof = None
     dom = "chain" if m.engine_active() else "gate_up"
-    if tpl or args.force_rccl:
+    if tpl or args.force_rccl or tpg:
         dom = None                              # the shard line reports the whole step only
     pmc_key = "engine_kernel" if m.engine_active() else "gemv_bf16_kernel<1, 2,"
     try:
@@ -307,8 +330,8 @@ def main():
     try:
         if args.isq:
             raise RuntimeError("quantised weights: not part of the bf16 headline")
-        if tpl or args.force_rccl:
-            raise RuntimeError("not timed for --tp-local / --force-rccl")
+        if tpl or args.force_rccl or (tpg and emulated):
+            raise RuntimeError("not timed for --tp-local / --force-rccl / an emulated group")
         ids = configs.synthetic_prompt(1024, cfg.get("text_config", cfg)["vocab_size"])
         m.clear_kv_cache(); m.forward_step_greedy(ids, 0)            # warm-up (allocates chunk buffers)
         m.clear_kv_cache()
@@ -331,7 +354,7 @@ def main():
 
     # CPU leg (rank 0, one GPU): baseline + parity of THIS configuration (same synthetic weights, same synthetic KV)
     cpu, parity = None, None
-    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+    if rank == 0 and (n == 1 or tpg) and not args.no_cpu_baseline:
         # oracle/c holds the model as bf16 on the host: a model that would not leave half of the host's RAM free is not timed
         import psutil
         need = m.weight_bytes() * 1.05
@@ -441,6 +464,14 @@ def main():
         if args.force_rccl:
             line["metric"] += " -- reductions through a 1-rank RCCL communicator (CM_DEBUG_FORCE_RCCL)"
             line["config"]["force_rccl"] = True
+        if tpg:
+            line["config"]["tp_host"] = "ONE handle, cm_opts.tp_mode = CM_TP_IN_PROCESS (library worker threads)"
+            line["config"]["tp_collective"] = ("peer-store kernels (kernels_tp.hip)" if emulated or args.tp_collective == "peer" else "RCCL")
+            line["config"]["parallelism"] = f"tp{tpg}"
+            if emulated:
+                line["metric"] += f" -- TP={tpg} group with EVERY rank on one GPU (emulated: functional check, not an N-GPU time)"
+                line["config"]["emulated_group"] = f"{tpg} ranks on 1 GPU"
+                line["scaling"] = "weak"
         if n > 1:
             # the exchange steps of one token under TP: one f32 [H] all-reduce behind each row-parallel projection
             # (o_proj / GDN out_proj, down_proj), one all-gather of the ranks' (max, index) arg-max partials behind lm_head

@@ -307,7 +307,7 @@ void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncol
                        int full_cols, uint32_t tseed, float mul, float off, hipStream_t s);
 void launch_kv_fill_quant(void* pool, const int32_t* pages, int npages, size_t page_bytes, size_t code_bytes, uint32_t tseed, hipStream_t s);
 void launch_kv_fill(void* pool, int kvt, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
-                    hipStream_t s);
+                    size_t head_elems, int hkv_all, int kvh0, hipStream_t s);
 
 // ---- quantised weights (kernels_quant.hip) ----
 enum { QFMT_NONE = 0, QFMT_Q8_0 = 8, QFMT_Q4_K = 12, QFMT_Q6_K = 14 };    // ggml type ids
@@ -391,7 +391,7 @@ struct PeerCollArgs {
     unsigned long long* inbox[TP_MAX_RANKS];   // inbox of rank d, peer-visible device memory on d's device: [2 parities][n][cap] granules
     const uint32_t* send;                      // this rank's contribution: f32 bit patterns (sum) / 32-bit words (gather)
     uint32_t* recv;                            // sum: [count] (may alias send); gather: [n][count] (send may alias slot `me`)
-    uint32_t* ctl;                             // this rank's control words in device memory: [0] epoch, [1] finish ticket
+    uint32_t* ctl;                             // this rank's control words in device memory: [0] epoch, [1] finish ticket, [2] gave up waiting
     uint32_t* err;                             // host-visible (pinned, mapped) error word of this rank
     long max_spin;                             // bound of the wait for one granule (iterations of ~0.1 us)
     int n, me, count;

@@ -28,14 +28,17 @@ void launch_synth_fill(uint16_t* dst, size_t dst_row_stride, int nrows, int ncol
 // (values k / 147.8 rounded to bf16: |v| < 3.5 with 8 significand bits, so the f16 page holds the same number exactly)
 template <typename T, bool F16>
 __global__ void kv_fill_kernel(T* __restrict__ pool, const int32_t* __restrict__ pages, int npages,
-                               size_t page_elems, uint32_t tseed) {
+                               size_t page_elems, uint32_t tseed, size_t head_elems, int hkv_all, int kvh0) {
     const size_t total = (size_t)npages * page_elems;
     const float mul = 1.0f / 147.80054f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int p = (int)(i / page_elems);
         const size_t e = i % page_elems;
-        const uint16_t b = f32_to_bf16(synth_val((uint32_t)i, tseed, mul, 0.f));
+        // the value is a function of the element's index in the UNSHARDED page ([page][all kv heads][token][D]): a tensor-
+        // parallel rank (its kv heads kvh0 .. of hkv_all) fills its pages with the values the whole model would hold there
+        const size_t gi = ((size_t)p * hkv_all + kvh0 + e / head_elems) * head_elems + e % head_elems;
+        const uint16_t b = f32_to_bf16(synth_val((uint32_t)gi, tseed, mul, 0.f));
         if constexpr (sizeof(T) == 2) pool[(size_t)pages[p] * page_elems + e] = F16 ? f32_to_f16(bf16_to_f32(b)) : b;
         else pool[(size_t)pages[p] * page_elems + e] = bf16_to_f32(b);
     }
@@ -61,13 +64,13 @@ void launch_kv_fill_quant(void* pool, const int32_t* pages, int npages, size_t p
 }
 
 void launch_kv_fill(void* pool, int kvt, const int32_t* pages, int npages, size_t page_elems, uint32_t tseed,
-                    hipStream_t s) {
+                    size_t head_elems, int hkv_all, int kvh0, hipStream_t s) {
     const size_t total = (size_t)npages * page_elems;
     int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
     if (blocks < 1) blocks = 1;
-    if (kvt == KV_F32) hipLaunchKernelGGL((kv_fill_kernel<float, false>), dim3(blocks), dim3(256), 0, s, (float*)pool, pages, npages, page_elems, tseed);
-    else if (kvt == KV_F16) hipLaunchKernelGGL((kv_fill_kernel<uint16_t, true>), dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed);
-    else hipLaunchKernelGGL((kv_fill_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed);
+    if (kvt == KV_F32) hipLaunchKernelGGL((kv_fill_kernel<float, false>), dim3(blocks), dim3(256), 0, s, (float*)pool, pages, npages, page_elems, tseed, head_elems, hkv_all, kvh0);
+    else if (kvt == KV_F16) hipLaunchKernelGGL((kv_fill_kernel<uint16_t, true>), dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed, head_elems, hkv_all, kvh0);
+    else hipLaunchKernelGGL((kv_fill_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, s, (uint16_t*)pool, pages, npages, page_elems, tseed, head_elems, hkv_all, kvh0);
 }
 
 }  // namespace cm

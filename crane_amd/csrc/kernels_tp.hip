@@ -48,14 +48,16 @@ __global__ void __launch_bounds__(256) peer_coll_kernel(PeerCollArgs a) {
         const size_t off = par + (size_t)a.me * a.cap + (size_t)i;
         for (int d = 0; d < a.n; ++d) st_sys64(a.inbox[d] + off, g);
     }
-    // (2) collect: what the n ranks pushed into MY inbox
+    // (2) collect: what the n ranks pushed into MY inbox.  After a first time-out the rank stops waiting for good (ctl[2]): a
+    // group whose kernels cannot run side by side would otherwise spend the bound on every later collective
+    const bool dead = __hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     bool timed_out = false;
     for (int i = i0; i < a.count; i += stride) {
         float acc = 0.f;
         for (int src = 0; src < a.n; ++src) {
             const unsigned long long* p = a.inbox[a.me] + par + (size_t)src * a.cap + (size_t)i;
             unsigned long long g = ld_sys64(p);
-            for (long spin = 0; (uint32_t)(g >> 32) != e && spin < a.max_spin; ++spin) {
+            for (long spin = 0; (uint32_t)(g >> 32) != e && spin < a.max_spin && !dead; ++spin) {
                 __builtin_amdgcn_s_sleep(4);
                 g = ld_sys64(p);
             }
@@ -65,7 +67,10 @@ __global__ void __launch_bounds__(256) peer_coll_kernel(PeerCollArgs a) {
         }
         if (MODE == 0) a.recv[i] = __float_as_uint(acc);
     }
-    if (timed_out) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (timed_out) {
+        __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // (3) the last workgroup to finish advances this rank's epoch (every workgroup has read ctl[0] by then)
     __syncthreads();
     if (threadIdx.x == 0) {

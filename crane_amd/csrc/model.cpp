@@ -2023,8 +2023,8 @@ void Model::debug_fill_kv(size_t ctx, uint64_t seed) {
             launch_kv_fill_quant(vpool(li), d_bt, (int)q.pages.size(), page_bytes, code_bytes, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
             continue;
         }
-        launch_kv_fill(kpool(li), kv_mode, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), stream);
-        launch_kv_fill(vpool(li), kv_mode, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), stream);
+        launch_kv_fill(kpool(li), kv_mode, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 1), (size_t)page * cfg.D, cfg.Hkv, kvh0, stream);
+        launch_kv_fill(vpool(li), kv_mode, d_bt, (int)q.pages.size(), page_elems, fmix32((uint32_t)seed * 2654435761u + (uint32_t)li * 2 + 2), (size_t)page * cfg.D, cfg.Hkv, kvh0, stream);
     }
     CM_HIP(hipStreamSynchronize(stream));
     q.len = (int64_t)ctx;

@@ -153,6 +153,7 @@ void Rccl::init_peer(PeerShared* ps, int r, int num_cu, hipStream_t s) {
 void Rccl::check() {
     if (h_err && *h_err != 0) {
         *h_err = 0;
+        if (ctl) { const uint32_t z = 0; (void)hipMemcpy(ctl + 2, &z, 4, hipMemcpyHostToDevice); }    // the next call waits again
         throw CmError(CM_ERR_DEVICE, "tensor-parallel exchange timed out: a rank of the group did not contribute (peer-store collective)");
     }
 }

@@ -122,12 +122,14 @@ def test_group_engine_emits_the_tokens_of_the_unsharded_engine():
     assert outs[0] == outs[1]
 
 
-def test_headline_geometry_two_layers_tp4():
-    """Qwen3-8B widths (H 4096, 32 / 8 heads, I 12288, V 151 936), 2 layers, TP = 4 on one device, f16 pages: the shard shapes of
-    the real model through the group handle, against the TP = 1 handle."""
+@pytest.mark.parametrize("tp", [4, 8])
+def test_headline_geometry_two_layers(tp):
+    """Qwen3-8B widths (H 4096, 32 / 8 heads, I 12288, V 151 936), 2 layers, TP = 4 and TP = 8 (4 q heads + 1 kv head +
+    1536 MLP columns + 18 992 vocabulary rows per rank) on one device, f16 pages: the shard shapes of the real model through the
+    group handle, against the TP = 1 handle."""
     cfg = dict(configs.get_config("qwen3-8b"), num_hidden_layers=2)
     ids = configs.synthetic_prompt(40, cfg["vocab_size"])
-    g, s = _group(cfg, 4, max_seq_len=128, max_seqs=1), _single(cfg, max_seq_len=128, max_seqs=1, engine=-1)
+    g, s = _group(cfg, tp, max_seq_len=128, max_seqs=1), _single(cfg, max_seq_len=128, max_seqs=1, engine=-1)
     try:
         a, b = g.forward_step(ids, 0)[0, 0], s.forward_step(ids, 0)[0, 0]
         assert rel(a, b) < 1e-4
