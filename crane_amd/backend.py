@@ -144,7 +144,7 @@ class Model:
         o.kv_pool_tokens, o.use_graph = kv_pool_tokens, use_graph
         o.prefill_chunk, o.prefill_split = prefill_chunk, prefill_split
         o.kv_dtype = {"f16": 0, "f32": 1, "int8": 2, "int4": 3, "bf16": 4}[kv_dtype]
-        o.isq = {None: 0, "none": 0, "q8_0": 8}[isq.lower() if isinstance(isq, str) else isq]     # --quant / CRANE_ISQ
+        o.isq = {None: 0, "none": 0, "q8_0": 8, "q4_0": 2, "q5_0": 6}[isq.lower() if isinstance(isq, str) else isq]     # --quant / CRANE_ISQ
         o.engine = int(engine)                                    # persistent chain kernel: 0 default, 1 require, -1 off
         o.debug_flags = (1 if debug_tp_local else 0) | (2 if debug_force_rccl else 0)
         keep = None

@@ -66,8 +66,9 @@ static T* out_or(bool primary, T* real, std::vector<T>& tmp, size_t n) {
     return tmp.data();
 }
 
-// cm_opts.isq, else CRANE_ISQ (qwen3_5/model.rs:615-626 isq_from_env): only q8_0 is offered -- the K-quant
-// quantisers of ggml (make_qkx2_quants search) are not restated, see oracle/gguf_oracle.py
+// cm_opts.isq, else CRANE_ISQ (qwen3_5/model.rs:615-626 isq_from_env): q8_0, q4_0, q5_0 -- the three 32-weight formats whose
+// reference quantisers are restated (oracle/gguf_oracle.py).  The K-quant quantisers of ggml (make_qkx2_quants search) are not, so the
+// K-quant names are refused instead of being quantised with a different search
 static void apply_isq(cm::Model& m) {
     uint32_t isq = m.opts.isq;
     if (isq == 0) {
@@ -75,12 +76,16 @@ static void apply_isq(cm::Model& m) {
             std::string v(e);
             for (char& c : v) c = (char)tolower((unsigned char)c);
             if (v == "q8_0") isq = CM_ISQ_Q8_0;
-            else if (!v.empty()) throw CmError(CM_ERR_UNSUPPORTED, "CRANE_ISQ='" + v + "': only q8_0 is implemented");
+            else if (v == "q4_0") isq = CM_ISQ_Q4_0;
+            else if (v == "q5_0") isq = CM_ISQ_Q5_0;
+            else if (!v.empty()) throw CmError(CM_ERR_UNSUPPORTED, "CRANE_ISQ='" + v + "': q8_0, q4_0 and q5_0 are implemented");
         }
     }
     if (isq == 0) return;
-    if (isq != CM_ISQ_Q8_0) throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.isq: only CM_ISQ_Q8_0 is implemented");
-    m.isq_q8_0();
+    if (isq == CM_ISQ_Q8_0) m.isq_q8_0(8);
+    else if (isq == CM_ISQ_Q4_0) m.isq_q8_0(4);
+    else if (isq == CM_ISQ_Q5_0) m.isq_q8_0(5);
+    else throw CmError(CM_ERR_UNSUPPORTED, "cm_opts.isq: CM_ISQ_Q8_0, CM_ISQ_Q4_0 and CM_ISQ_Q5_0 are implemented");
 }
 
 // Model::new for every rank the options ask for.  CM_TP_IN_PROCESS: the ranks load their shards concurrently (one thread per

@@ -114,6 +114,7 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 __host__ __device__ __forceinline__ float synth_val(uint32_t idx, uint32_t tseed, float mul, float off) {
+#pragma clang fp contract(off)      // (the _rn intrinsics below are plain operators in this ROCm: contraction is switched off by name)
     uint32_t h = fmix32(idx * 0x9E3779B1u + tseed);
     int c = (int)((h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + (h >> 24)) - 510;
 #if defined(__HIP_DEVICE_COMPILE__)

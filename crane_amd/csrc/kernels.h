@@ -354,7 +354,7 @@ void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, 
 void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s);
 void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s);
 void launch_embed_rows_q(const QWeight& w, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
-void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s);
+void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s, int mode = 8);   // mode 4 / 5: Q4_0 / Q5_0 quantiser, Q8_0 layout
 void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s, int n_seq = 1, int in_stride = 0, int out_stride = 0);
 
 // sampler (kernels_sample.hip)

@@ -1154,32 +1154,49 @@ void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipS
 // in-situ quantisation bf16 -> Q8_0 (ops/linear.rs:83-100 quantize_linear; ggml quantize_row_q8_0_ref:
 // d = amax / 127, id = d ? 1/d : 0, q = roundf(x * id), d stored as f16)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void isq_q8_0_kernel(const uint16_t* __restrict__ src, size_t src_stride, int N, int K, signed char* __restrict__ codes,
-                                uint16_t* __restrict__ dd) {
+// MODE 8: Q8_0.  MODE 4 / 5: ggml quantize_row_q4_0_ref / _q5_0_ref (max = the signed value of the first largest |x|, d = max / -8 | -16,
+// q = min(15 | 31, (int8)(x * id + 8.5 | 16.5)), d stored as f16); the code q - 8 | 16 is an int8 under the block's own scale, i.e. the
+// block is stored in the Q8_0 stream layout (loader_gguf.cpp pack_rows does the same to Q4_0 / Q5_0 files)
+template <int MODE>
+__global__ void isq_kernel(const uint16_t* __restrict__ src, size_t src_stride, int N, int K, signed char* __restrict__ codes,
+                           uint16_t* __restrict__ dd) {
+    // the reference computes x * id, THEN adds 8.5 / 16.5 and truncates: a fused multiply-add lands on the other side of an integer
+    // for weights that sit exactly on a code boundary (x / d = -4.5: seen on hardware, one weight in ~10^4).  hipcc contracts by
+    // default and __fmul_rn / __fadd_rn are plain operators in this ROCm (clang/22/include/__clang_hip_math.h:271), so say it here
+#pragma clang fp contract(off)
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 32-weight block per thread
     const size_t nb_row = (size_t)K >> 5;
     if (b >= (size_t)N * nb_row) return;
     const size_t row = b / nb_row, kb = b % nb_row;
     const uint16_t* p = src + row * src_stride + kb * 32;
     float v[32];
-    float amax = 0.f;
+    float amax = 0.f, mx = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { v[i] = bf16_to_f32(p[i]); amax = fmaxf(amax, fabsf(v[i])); }
-    const float d = amax / 127.0f;
+    for (int i = 0; i < 32; ++i) {
+        v[i] = bf16_to_f32(p[i]);
+        if (amax < fabsf(v[i])) { amax = fabsf(v[i]); mx = v[i]; }
+    }
+    const float d = MODE == 8 ? amax / 127.0f : MODE == 4 ? mx / -8.0f : mx / -16.0f;
     const float id = d != 0.f ? 1.0f / d : 0.f;
     signed char* q = codes + row * (size_t)K + kb * 32;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) q[i] = (signed char)(int)roundf(v[i] * id);
+    for (int i = 0; i < 32; ++i) {
+        if (MODE == 8) q[i] = (signed char)(int)roundf(v[i] * id);
+        else if (MODE == 4) { const float t = v[i] * id; q[i] = (signed char)(min(15, (int)(signed char)(t + 8.5f)) - 8); }
+        else { const float t = v[i] * id; q[i] = (signed char)(min(31, (int)(signed char)(t + 16.5f)) - 16); }
+    }
     const _Float16 h = (_Float16)d;
     uint16_t hb;
     __builtin_memcpy(&hb, &h, 2);
     dd[b] = hb;
 }
 
-void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s) {
+void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s, int mode) {
     const size_t nb = (size_t)N * (K >> 5);
-    hipLaunchKernelGGL(isq_q8_0_kernel, dim3((unsigned)((nb + 127) / 128)), dim3(128), 0, s, src, src_stride, N, K, (signed char*)codes,
-                       (uint16_t*)d);
+    const dim3 g((unsigned)((nb + 127) / 128)), b(128);
+    if (mode == 4) hipLaunchKernelGGL(isq_kernel<4>, g, b, 0, s, src, src_stride, N, K, (signed char*)codes, (uint16_t*)d);
+    else if (mode == 5) hipLaunchKernelGGL(isq_kernel<5>, g, b, 0, s, src, src_stride, N, K, (signed char*)codes, (uint16_t*)d);
+    else hipLaunchKernelGGL(isq_kernel<8>, g, b, 0, s, src, src_stride, N, K, (signed char*)codes, (uint16_t*)d);
 }
 
 }  // namespace cm

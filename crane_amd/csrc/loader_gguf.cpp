@@ -46,7 +46,8 @@ void pack_rows(const TensorInfo& t, int row0, int nrows, int Kfull, Packed& out,
     if (K < 0) K = Kfull;
     const size_t nb32 = (size_t)K / 32, nb256 = (size_t)K / 256;
     const size_t fb32 = (size_t)Kfull / 32, fb256 = (size_t)Kfull / 256, b32_0 = (size_t)k0 / 32, b256_0 = (size_t)k0 / 256;
-    const int blk = t.type == cmgguf::Q8_0 ? 32 : 256;
+    const bool b32 = t.type == cmgguf::Q8_0 || t.type == cmgguf::Q4_0 || t.type == cmgguf::Q5_0;
+    const int blk = b32 ? 32 : 256;
     if (k0 % blk || K % blk) throw CmError(CM_ERR_UNSUPPORTED, "tensor-parallel cut of " + t.name + " does not fall on a quantisation block");
     if (t.type == cmgguf::Q8_0) {
         if (Kfull % 32) throw CmError(CM_ERR_UNSUPPORTED, "Q8_0 needs K % 32 == 0 (" + t.name + ")");
@@ -59,6 +60,36 @@ void pack_rows(const TensorInfo& t, int row0, int nrows, int Kfull, Packed& out,
             for (size_t b = 0; b < nb32; ++b) {
                 memcpy(&out.p1[o1 + ((size_t)r * nb32 + b) * 2], src + b * 34, 2);
                 memcpy(&out.p0[o0 + (size_t)r * K + b * 32], src + b * 34 + 2, 32);
+            }
+        }
+    } else if (t.type == cmgguf::Q4_0 || t.type == cmgguf::Q5_0) {
+        // Q4_0: y = d (q - 8), Q5_0: y = d (q - 16) with q - offset in [-8, 7] / [-16, 15]: an int8 code under the block's own f16
+        // scale, i.e. EXACTLY a Q8_0 block.  The codes are widened at load into the Q8_0 stream layout (no re-quantisation, the
+        // same integer-dot arithmetic ggml_vec_dot_q4_0_q8_0 / _q5_0_q8_0 compute: sum (q - off) q8 times d_w d_x); the price is
+        // the footprint -- 1.06 bytes per weight in HBM instead of 0.56 / 0.69.  Format coverage, not the formats' bandwidth.
+        if (Kfull % 32) throw CmError(CM_ERR_UNSUPPORTED, "Q4_0 / Q5_0 need K % 32 == 0 (" + t.name + ")");
+        const bool q5 = t.type == cmgguf::Q5_0;
+        const size_t bs = q5 ? 22 : 18;
+        out.fmt = QFMT_Q8_0;
+        const size_t o0 = out.p0.size(), o1 = out.p1.size();
+        out.p0.resize(o0 + (size_t)nrows * K);
+        out.p1.resize(o1 + (size_t)nrows * nb32 * 2);
+        for (int r = 0; r < nrows; ++r) {
+            const uint8_t* src = t.data + ((size_t)(row0 + r) * fb32 + b32_0) * bs;
+            for (size_t b = 0; b < nb32; ++b) {
+                const uint8_t* blkp = src + b * bs;
+                memcpy(&out.p1[o1 + ((size_t)r * nb32 + b) * 2], blkp, 2);
+                int8_t* dst = (int8_t*)&out.p0[o0 + (size_t)r * K + b * 32];
+                if (!q5) {
+                    for (int j = 0; j < 16; ++j) { dst[j] = (int8_t)((blkp[2 + j] & 0xF) - 8); dst[j + 16] = (int8_t)((blkp[2 + j] >> 4) - 8); }
+                } else {
+                    uint32_t qh; memcpy(&qh, blkp + 2, 4);
+                    for (int j = 0; j < 16; ++j) {
+                        const int h0 = (int)((qh >> j) & 1u) << 4, h1 = (int)((qh >> (j + 16)) & 1u) << 4;
+                        dst[j] = (int8_t)(((blkp[6 + j] & 0xF) | h0) - 16);
+                        dst[j + 16] = (int8_t)(((blkp[6 + j] >> 4) | h1) - 16);
+                    }
+                }
             }
         }
     } else if (t.type == cmgguf::Q4_K) {
@@ -94,7 +125,7 @@ void pack_rows(const TensorInfo& t, int row0, int nrows, int Kfull, Packed& out,
         }
     } else {
         throw CmError(CM_ERR_UNSUPPORTED, "GGUF tensor " + t.name + ": ggml type " + std::to_string(t.type) +
-                                              " is not supported for matrices (Q8_0, Q4_K, Q6_K)");
+                                              " is not supported for matrices (Q4_0, Q5_0, Q8_0, Q4_K, Q6_K)");
     }
 }
 
@@ -394,7 +425,7 @@ void load_from_gguf(Model& m, const std::string& path) {
 // linear of the decoder plus (GGUF path only) keeps the embedding quantised; here: qkv, o, gate_up, down, lm_head
 // (when untied); the embedding table stays bf16 (one row per token) and so does a tied lm_head.
 // ------------------------------------------------------------------------------------
-void Model::isq_q8_0() {
+void Model::isq_q8_0(int mode) {
     // Tensor parallelism: every rank quantises ITS shard (dense family).  Q8_0 blocks run along K, and the row-parallel
     // shards (o_proj, down_proj) cut K on multiples of head_dim / of the intermediate slice, so a rank's blocks are the
     // blocks the unsharded matrix would have -- the codes are the same as quantise-then-shard.
@@ -406,7 +437,7 @@ void Model::isq_q8_0() {
         w.fmt = QFMT_Q8_0; w.N = N; w.K = K;
         uint8_t* codes = (uint8_t*)dalloc<uint16_t>(((size_t)N * K + 1) / 2, true);
         uint8_t* d = (uint8_t*)dalloc<uint16_t>((size_t)N * (K / 32), true);
-        launch_isq_q8_0(src, (size_t)K, N, K, codes, d, stream);
+        launch_isq_q8_0(src, (size_t)K, N, K, codes, d, stream, mode);
         w.p0 = codes; w.p1 = d;
         quant_weight_bytes += w.bytes();
         return w;

@@ -81,7 +81,7 @@ typedef struct cm_opts {
     uint32_t prefill_chunk;    /* tokens per prefill chunk (default 2048,            */
                                /*   PREFILL_CHUNK_SIZE engine/mod.rs:65)             */
     int32_t  prefill_split;    /* activation split terms for MFMA GEMMs: 0/2 = bf16x2 (parity), 1 = bf16 */
-    uint32_t isq;              /* in-situ quantisation of the linears at load: 0 none, CM_ISQ_Q8_0       */
+    uint32_t isq;              /* in-situ quantisation of the linears at load: 0 none, CM_ISQ_Q8_0 / _Q4_0 / _Q5_0 */
                                /*   (--quant / CRANE_ISQ, ops/linear.rs:53-116; also read from CRANE_ISQ) */
     int32_t  engine;           /* persistent decode kernel (one launch per token): 0 default (on when the shapes */
                                /*   allow it), 1 require (cm_create fails otherwise), -1 off.  The kernel runs   */
@@ -119,7 +119,7 @@ enum { CM_TP_COLL_DEFAULT = 0u, CM_TP_COLL_RCCL = 1u, CM_TP_COLL_PEER = 2u };
  * on a single GPU). */
 enum { CM_DEBUG_TP_LOCAL = 1u, CM_DEBUG_FORCE_RCCL = 2u };
 
-enum { CM_ISQ_NONE = 0, CM_ISQ_Q8_0 = 8 };
+enum { CM_ISQ_NONE = 0, CM_ISQ_Q4_0 = 2, CM_ISQ_Q5_0 = 6, CM_ISQ_Q8_0 = 8 };   /* ggml type ids */
 
 typedef struct cm_model cm_model;
 

@@ -7,11 +7,13 @@ metadata keys), hunyuan_dense/modeling.rs:14-95 (Gguf helper), ops/linear.rs:18-
 weights to F32 and requires F32 input"; ISQ falls back to Q8_0 when K % 256 != 0).
 
 Block formats (little endian):
+  Q4_0  32 weights : f16 d; u8 qs[16] (element j: low nibble of qs[j], element j + 16: high nibble)   y = d * (q - 8)
+  Q5_0  32 weights : f16 d; u32 qh; u8 qs[16] (5th bit of element j = bit j of qh)                    y = d * (q - 16)
   Q8_0  32 weights : f16 d; i8 qs[32]                                   y = d * q
   Q4_K  256 weights: f16 d; f16 dmin; u8 scales[12]; u8 qs[128]         y = d*sc_j*q - dmin*m_j   (8 sub-blocks of 32)
   Q6_K  256 weights: u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d        y = d*sc_j*(q - 32)        (16 sub-blocks of 16)
-Dequantisers are exact restatements (dequantize_row_q8_0 / _q4_K / _q6_K).  quantize_q8_0 restates
-quantize_row_q8_0_ref exactly; the Q4_K / Q6_K *quantisers* here are simple valid encoders for writing test files
+Dequantisers are exact restatements (dequantize_row_q4_0 / _q5_0 / _q8_0 / _q4_K / _q6_K).  quantize_q8_0 / _q4_0 / _q5_0 restate
+quantize_row_q8_0_ref / _q4_0_ref / _q5_0_ref exactly; the Q4_K / Q6_K *quantisers* here are simple valid encoders for writing test files
 (ggml's make_qkx2_quants search is not reproduced -- PARITY UNPINNED for K-quant ISQ, which crane_amd does not offer).
 """
 import struct
@@ -20,8 +22,79 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 GGML_F32, GGML_F16, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_BF16 = 0, 1, 8, 12, 14, 30
-BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_BF16: (1, 2), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q6_K: (256, 210)}
-TYPE_NAMES = {"f32": GGML_F32, "f16": GGML_F16, "bf16": GGML_BF16, "q8_0": GGML_Q8_0, "q4_k": GGML_Q4_K, "q6_k": GGML_Q6_K}
+GGML_Q4_0, GGML_Q5_0 = 2, 6
+BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_BF16: (1, 2), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q6_K: (256, 210),
+         GGML_Q4_0: (32, 18), GGML_Q5_0: (32, 22)}
+TYPE_NAMES = {"f32": GGML_F32, "f16": GGML_F16, "bf16": GGML_BF16, "q8_0": GGML_Q8_0, "q4_k": GGML_Q4_K, "q6_k": GGML_Q6_K,
+              "q4_0": GGML_Q4_0, "q5_0": GGML_Q5_0}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Q4_0 / Q5_0 (ggml-quants.c quantize_row_q4_0_ref / _q5_0_ref, dequantize_row_q4_0 / _q5_0)
+# ---------------------------------------------------------------------------------------------------------
+def _signed_max(xb: np.ndarray) -> np.ndarray:
+    """the value (with its sign) of the FIRST element of each row that has the largest magnitude (`if (amax < fabsf(v))`)."""
+    first = np.abs(xb).argmax(axis=1)
+    return np.take_along_axis(xb, first[:, None], axis=1)[:, 0]
+
+
+def _codes_q4_0(b: np.ndarray) -> np.ndarray:
+    """[nb, 18] bytes -> int codes q - 8 in [-8, 7], element order of the row"""
+    qs = b[:, 2:18]
+    return np.concatenate([qs & 0xF, qs >> 4], axis=1).astype(np.int32) - 8
+
+
+def _codes_q5_0(b: np.ndarray) -> np.ndarray:
+    """[nb, 22] bytes -> int codes q - 16 in [-16, 15]"""
+    qh = b[:, 2:6].copy().view(np.uint32)[:, 0]
+    qs = b[:, 6:22]
+    j = np.arange(16, dtype=np.uint32)
+    h0 = ((qh[:, None] >> j) & 1).astype(np.int32) << 4                 # xh_0 = ((qh >> j) << 4) & 0x10
+    h1 = ((qh[:, None] >> (j + 16)) & 1).astype(np.int32) << 4          # xh_1 = (qh >> (j + 12)) & 0x10
+    lo = (qs & 0xF).astype(np.int32) | h0
+    hi = (qs >> 4).astype(np.int32) | h1
+    return np.concatenate([lo, hi], axis=1) - 16
+
+
+def quantize_q4_0(x: np.ndarray) -> np.ndarray:
+    """d = max / -8 (max = signed value of the largest magnitude), id = d ? 1/d : 0, q = min(15, (int8)(x * id + 8.5f))."""
+    xb = np.asarray(x, np.float32).reshape(-1, 32)
+    d = (_signed_max(xb) / np.float32(-8.0)).astype(np.float32)
+    idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0)).astype(np.float32)
+    t = ((xb * idv[:, None]).astype(np.float32) + np.float32(8.5)).astype(np.float32)
+    q = np.minimum(15, t.astype(np.int8).astype(np.int32)).astype(np.uint8)       # C cast: truncation toward zero
+    out = np.zeros((xb.shape[0], 18), np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+    return out.reshape(-1)
+
+
+def dequantize_q4_0(raw: np.ndarray, n: int) -> np.ndarray:
+    b = np.asarray(raw, np.uint8).reshape(-1, 18)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)
+    return (_codes_q4_0(b).astype(np.float32) * d).astype(np.float32).reshape(-1)[:n]
+
+
+def quantize_q5_0(x: np.ndarray) -> np.ndarray:
+    """d = max / -16, q = min(31, (int8)(x * id + 16.5f)); low 4 bits in qs, the 5th bit of element j in bit j of qh."""
+    xb = np.asarray(x, np.float32).reshape(-1, 32)
+    d = (_signed_max(xb) / np.float32(-16.0)).astype(np.float32)
+    idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0)).astype(np.float32)
+    t = ((xb * idv[:, None]).astype(np.float32) + np.float32(16.5)).astype(np.float32)
+    q = np.minimum(31, t.astype(np.int8).astype(np.int32)).astype(np.uint32)
+    out = np.zeros((xb.shape[0], 22), np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    j = np.arange(16, dtype=np.uint32)
+    qh = (((q[:, :16] >> 4) & 1) << j).sum(axis=1, dtype=np.uint32) | (((q[:, 16:] >> 4) & 1) << (j + 16)).sum(axis=1, dtype=np.uint32)
+    out[:, 2:6] = qh.astype(np.uint32).view(np.uint8).reshape(-1, 4)
+    out[:, 6:] = ((q[:, :16] & 0xF) | ((q[:, 16:] & 0xF) << 4)).astype(np.uint8)
+    return out.reshape(-1)
+
+
+def dequantize_q5_0(raw: np.ndarray, n: int) -> np.ndarray:
+    b = np.asarray(raw, np.uint8).reshape(-1, 22)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)
+    return (_codes_q5_0(b).astype(np.float32) * d).astype(np.float32).reshape(-1)[:n]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -176,7 +249,8 @@ def quantize(x: np.ndarray, ggml_type: int) -> np.ndarray:
         return x.astype(np.float16).view(np.uint8)
     if ggml_type == GGML_BF16:
         return _bf16_bytes(x)
-    return {GGML_Q8_0: quantize_q8_0, GGML_Q4_K: quantize_q4_k, GGML_Q6_K: quantize_q6_k}[ggml_type](x)
+    return {GGML_Q8_0: quantize_q8_0, GGML_Q4_K: quantize_q4_k, GGML_Q6_K: quantize_q6_k, GGML_Q4_0: quantize_q4_0,
+            GGML_Q5_0: quantize_q5_0}[ggml_type](x)
 
 
 def dequantize(raw: np.ndarray, ggml_type: int, n: int) -> np.ndarray:
@@ -187,7 +261,8 @@ def dequantize(raw: np.ndarray, ggml_type: int, n: int) -> np.ndarray:
         return raw.view(np.float16)[:n].astype(np.float32)
     if ggml_type == GGML_BF16:
         return (raw.view(np.uint16)[:n].astype(np.uint32) << 16).view(np.float32)
-    return {GGML_Q8_0: dequantize_q8_0, GGML_Q4_K: dequantize_q4_k, GGML_Q6_K: dequantize_q6_k}[ggml_type](raw, n)
+    return {GGML_Q8_0: dequantize_q8_0, GGML_Q4_K: dequantize_q4_k, GGML_Q6_K: dequantize_q6_k, GGML_Q4_0: dequantize_q4_0,
+            GGML_Q5_0: dequantize_q5_0}[ggml_type](raw, n)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -341,7 +416,7 @@ def write_qwen3_gguf(path: str, cfg: dict, weights_f32: Dict[str, np.ndarray], t
         tensors.append((gg, w, gt))
         raw = quantize(w, gt)
         deq[hf] = dequantize(raw, gt, w.size).reshape(w.shape)
-        if want_qmats and w.ndim == 2 and gt in (GGML_Q8_0, GGML_Q4_K, GGML_Q6_K):
+        if want_qmats and w.ndim == 2 and gt in (GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_Q4_0, GGML_Q5_0):
             qm[hf] = QuantMatrix(raw, gt, w.shape)
     write_gguf(path, qwen3_metadata(cfg), tensors)
     return (deq, qm) if want_qmats else deq
@@ -410,7 +485,15 @@ class QuantMatrix:
     def __init__(self, raw: np.ndarray, ggml_type: int, shape):
         self.gt, self.shape = ggml_type, tuple(shape)
         N, K = self.shape
-        if ggml_type == GGML_Q8_0:
+        if ggml_type in (GGML_Q4_0, GGML_Q5_0):
+            # ggml_vec_dot_q4_0_q8_0 / _q5_0_q8_0: sumi = sum (q - 8 | 16) * q8 per block, sumf += sumi * d_w * d_x -- the Q8_0 x Q8_0
+            # product of the integer codes q - offset (they fit an int8) with the block's own f16 scale
+            bs = 18 if ggml_type == GGML_Q4_0 else 22
+            b = np.asarray(raw, np.uint8).reshape(N * (K // 32), bs)
+            self.d = b[:, 0:2].copy().view(np.float16).astype(np.float32)[:, 0].reshape(N, K // 32)
+            self.q = (_codes_q4_0(b) if ggml_type == GGML_Q4_0 else _codes_q5_0(b)).reshape(N, K // 32, 32)
+            self.gt = GGML_Q8_0
+        elif ggml_type == GGML_Q8_0:
             b = np.asarray(raw, np.uint8).reshape(N, K // 32, 34)
             self.d = b[:, :, 0:2].copy().view(np.float16).astype(np.float32)[:, :, 0]
             self.q = b[:, :, 2:].copy().view(np.int8).astype(np.int32)                       # [N, nb, 32]

@@ -16,6 +16,40 @@ def test_q8_0_known_block():
     assert G.dequantize_q8_0(G.quantize_q8_0(np.zeros(32)), 32).tolist() == [0.0] * 32
 
 
+def test_q4_0_and_q5_0_known_blocks():
+    """Hand-built blocks of the two 32-weight legacy formats (ggml-quants.c block_q4_0 / block_q5_0): nibble order, the 5th-bit
+    word, the -8 / -16 offsets; and the reference quantisers' rule (d = signed max / -8 | -16, truncating cast, clamp)."""
+    b = np.zeros(18, np.uint8)
+    b[0:2] = np.array([0.5], np.float16).view(np.uint8)
+    b[2] = 0x3A                                               # element 0: q = 0xA -> (10 - 8) * 0.5; element 16: q = 3 -> (3 - 8) * 0.5
+    b[2 + 15] = 0xF0                                          # element 15: q = 0 -> -4.0; element 31: q = 15 -> 3.5
+    y = G.dequantize_q4_0(b, 32)
+    assert y[0] == 1.0 and y[16] == -2.5 and y[15] == -4.0 and y[31] == 3.5 and y[1] == -4.0
+    c = np.zeros(22, np.uint8)
+    c[0:2] = np.array([2.0], np.float16).view(np.uint8)
+    c[2:6] = np.array([(1 << 3) | (1 << (16 + 5))], np.uint32).view(np.uint8)     # 5th bits of elements 3 and 21
+    c[6 + 3] = 0x07                                           # element 3: q = 7 | 16 = 23 -> (23 - 16) * 2; element 19: q = 0 -> -32
+    c[6 + 5] = 0x90                                           # element 5: q = 0 -> -32; element 21: q = 9 | 16 = 25 -> 18
+    z = G.dequantize_q5_0(c, 32)
+    assert z[3] == 14.0 and z[19] == -32.0 and z[5] == -32.0 and z[21] == 18.0
+    x = np.zeros(32, np.float32); x[4] = -8.0; x[7] = 7.0; x[9] = 0.49; x[30] = 3.5
+    raw = G.quantize_q4_0(x)                                  # max = -8 -> d = 1: q = (int8)(x + 8.5) clamped to 15
+    assert raw[:2].view(np.float16)[0] == np.float16(1.0)
+    np.testing.assert_array_equal(G.dequantize_q4_0(raw, 32)[[4, 7, 9, 30, 0]], [-8.0, 7.0, 0.0, 4.0, 0.0])
+    x[4] = -16.0; x[7] = 15.9
+    raw = G.quantize_q5_0(x)                                  # d = 1: 15.9 + 16.5 = 32.4 -> 32 -> clamped to 31 -> 15
+    np.testing.assert_array_equal(G.dequantize_q5_0(raw, 32)[[4, 7, 9, 30]], [-16.0, 15.0, 0.0, 4.0])
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((3, 64)) * 0.1).astype(np.float32)
+    for t, tol in ((G.GGML_Q4_0, 0.08), (G.GGML_Q5_0, 0.04)):
+        raw = G.quantize(w, t)
+        deq = G.dequantize(raw, t, w.size).reshape(w.shape)
+        assert np.abs(deq - w).max() <= tol * np.abs(w).max() + 1e-7
+        xv = rng.standard_normal(64).astype(np.float32)
+        qm = G.QuantMatrix(raw, t, w.shape)                   # Q4_0 x Q8_0 / Q5_0 x Q8_0 integer dots
+        assert np.abs(qm.vecdot(xv) - deq @ xv).max() < 0.02 * np.abs(deq @ xv).max() + 1e-3
+
+
 def test_q4_k_known_block():
     b = np.zeros(144, np.uint8)
     b[0:2] = np.array([2.0], np.float16).view(np.uint8)       # d

@@ -18,9 +18,17 @@ def rel(a, ref):
 
 
 def _types(kind):
-    if kind in ("q8_0", "q4_k", "q6_k"):
+    if kind in ("q8_0", "q4_k", "q6_k", "q4_0", "q5_0"):
         t = G.TYPE_NAMES[kind]
         return lambda name, shape: t
+    if kind == "legacy-mixed":       # Q4_0 projections, Q5_0 value / up / embedding rows, Q8_0 head: the legacy 32-weight formats together
+        def legacy(name, shape):
+            if "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
+                return G.GGML_Q5_0
+            if name == "output.weight":
+                return G.GGML_Q8_0
+            return G.GGML_Q4_0
+        return legacy
     # llama.cpp-style mixture: different types inside qkv and inside gate/up, quantised embedding, q8_0 head
     def mixed(name, shape):
         if "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
@@ -49,7 +57,7 @@ def _check(m, oracle, V, n_prompt=19, n_decode=6, tol=2e-4, exact_tokens=True):
 
 
 @pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
-@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed"])
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed", "q4_0", "q5_0", "legacy-mixed"])
 @pytest.mark.parametrize("act", ["int", "f32"])
 def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
     """act=int (default): ggml / candle vec_dot semantics -- the activation row is quantised to Q8_0 / Q8_K and block
@@ -77,7 +85,7 @@ def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
         xh = rng.standard_normal(H).astype(np.float32)
         xi = (rng.standard_normal(I) * np.abs(rng.standard_normal(I))).astype(np.float32)
         mats = {"o": (P + "self_attn.o_proj.weight", None), "down": (P + "mlp.down_proj.weight", xi)}
-        if kind != "mixed":
+        if kind not in ("mixed", "legacy-mixed"):
             mats["qkv0"] = ([P + f"self_attn.{n}_proj.weight" for n in "qkv"], xh)
         else:
             mats.update({"qkv0": ([P + "self_attn.q_proj.weight"], xh), "qkv2": ([P + "self_attn.v_proj.weight"], xh),
@@ -107,24 +115,27 @@ def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
 
 
 @pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
-def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name):
-    """ISQ (ops/linear.rs:83-116, CRANE_ISQ): the device quantiser must reproduce ggml's quantize_row_q8_0_ref."""
+@pytest.mark.parametrize("fmt", ["q8_0", "q4_0", "q5_0"])
+def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name, fmt):
+    """ISQ (ops/linear.rs:83-116, CRANE_ISQ): the device quantiser must reproduce ggml's quantize_row_q8_0_ref / _q4_0_ref / _q5_0_ref
+    (the 4- and 5-bit codes are held in the Q8_0 layout: q - 8 / q - 16 under the block's own scale)."""
     from crane_amd.backend import Model
     cfg = configs.get_config(name)
     w = synth.synth_weights_f32(cfg, seed=0)
     deq = dict(w)
+    gt = G.TYPE_NAMES[fmt]
     for k, v in w.items():
         if any(k.endswith(f"{l}.weight") for l in LINEARS) or (k == "lm_head.weight" and not cfg.get("tie_word_embeddings", True)):
-            deq[k] = G.dequantize_q8_0(G.quantize_q8_0(v), v.size).reshape(v.shape)
+            deq[k] = G.dequantize(G.quantize(v, gt), gt, v.size).reshape(v.shape)
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
     sw = dict(quant_act="f32", quant_prefill=False)    # f32 activations isolate the weight quantiser; the int path is covered by the GGUF test
     for how in ("opt", "env"):
         if how == "env":
-            monkeypatch.setenv("CRANE_ISQ", "q8_0")
+            monkeypatch.setenv("CRANE_ISQ", fmt)
             m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", **sw)
             monkeypatch.delenv("CRANE_ISQ")
         else:
-            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", **sw)
+            m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq=fmt, **sw)
         try:
             _check(m, oracle, cfg["vocab_size"])
         finally:
@@ -171,7 +182,7 @@ def test_quant_errors():
     cfg = configs.get_config("tiny-qwen3")
     os.environ["CRANE_ISQ"] = "q4k"
     try:
-        with pytest.raises(CraneError, match="only q8_0"):
+        with pytest.raises(CraneError, match="q8_0, q4_0 and q5_0"):      # K-quant ISQ is refused, not approximated
             Model.synthetic(cfg, seed=0)
     finally:
         del os.environ["CRANE_ISQ"]
