@@ -1,7 +1,10 @@
-for t in 0x880 0x881 0x480 0x080 0x840 0x8c0 0x841 0xc80; do
-  echo -n "CM_ENG_TUNE=$t: "; CM_ENG_TUNE=$t timeout 120 python bench.py --no-cpu-baseline --steps 96 --warmup 8 2>/dev/null | python -c "
+#!/bin/bash
+# CM_ENG_TUNE sweep of the persistent decode kernel:  tools/eng_tune_sweep.sh <model> <tune values...>
+M=${1:-qwen3-8b}; shift
+for t in "$@"; do
+  echo -n "$M CM_ENG_TUNE=$t: "; CM_ENG_TUNE=$t timeout 120 python bench.py --model $M --no-cpu-baseline --steps 128 --warmup 8 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print(d['value'], d['ms_per_step'], d['roofline']['us_per_launch'], d['roofline_step']['frac'])"
+        d = json.loads(l); print(d['value'], d['ms_per_step'], d['roofline'].get('us_per_launch'), d['roofline_step']['frac'])"
 done
