@@ -429,7 +429,8 @@ void Model::isq_q8_0(int mode) {
     // Tensor parallelism: every rank quantises ITS shard (dense family).  Q8_0 blocks run along K, and the row-parallel
     // shards (o_proj, down_proj) cut K on multiples of head_dim / of the intermediate slice, so a rank's blocks are the
     // blocks the unsharded matrix would have -- the codes are the same as quantise-then-shard.
-    if (tp != 1 && cfg.hybrid) throw CmError(CM_ERR_UNSUPPORTED, "ISQ of the hybrid family under tensor parallelism is not implemented");
+    // (hybrid family, round 4: the same holds -- out_proj cuts K on whole 128-wide value heads, in_proj rows keep the full K = H;
+    //  checked end to end by tests/test_gpu_tp_group.py::test_isq_under_tensor_parallelism)
     if (vcfg.present) throw CmError(CM_ERR_UNSUPPORTED, "ISQ of the vision-language checkpoints is not implemented");
     auto quant = [&](uint16_t* src, int N, int K) -> QWeight {
         if (K % 32) throw CmError(CM_ERR_UNSUPPORTED, "ISQ Q8_0 needs the input dimension to be a multiple of 32");

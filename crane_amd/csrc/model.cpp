@@ -941,7 +941,11 @@ void Model::enqueue_quant_layer(int li) {
         ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
             ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
         launch_gdn(ga, s);
-        qg(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attn, nullptr, x, x);
+        if (!rccl) qg(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attn, nullptr, x, x);
+        else {       // row-parallel out_proj over this rank's value heads: partial sums, rank 0 carries the residual
+            qg(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, w.q_out_proj, attn, nullptr, y, x);
+            rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
+        }
     } else {
         for (int i = 0; i < w.n_qkv; ++i) qg(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], x, w.ln1, qkv + w.qkv_row0[i], nullptr);
         AttnDecArgs a{};

@@ -170,3 +170,111 @@ def test_groups_of_different_sizes_one_after_another():
             assert g.generate(ids, GenerationConfig.greedy(12)) == rtok
         finally:
             g.close()
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3-untied", "tiny-qwen3.5"])
+@pytest.mark.parametrize("fmt", ["q8_0", "q4_0"])
+def test_isq_under_tensor_parallelism(name, fmt):
+    """In-situ quantisation of a sharded model: every rank quantises ITS shard; the 32-weight blocks run along K and the row-parallel
+    cuts (o_proj / out_proj on whole heads, down_proj on the intermediate slice) fall on block boundaries, so the codes are the
+    unsharded model's codes and only the f32 sums across ranks differ in order.  Dense and hybrid (Gated-Delta-Net in_proj /
+    out_proj quantised, a / b gate rows bf16), prompt + decode + greedy ids against the TP = 1 handle -- with f32 activations (exact
+    dequantised weights: tight), and with the default integer-dot activations (an 8-bit activation code on a rounding boundary flips
+    with the 1e-6 the summation order moves its input: the documented ~1e-2 of ANY two implementations)."""
+    from crane_amd.backend import GenerationConfig
+    cfg = configs.get_config(name)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    for act, tol in (("f32", 1e-4), ("int", 3e-2)):
+        g, s = _group(cfg, 2, isq=fmt, quant_act=act), _single(cfg, isq=fmt, quant_act=act)
+        try:
+            a, b = g.forward_step(ids, 0)[0, 0], s.forward_step(ids, 0)[0, 0]
+            assert rel(a, b) < tol, (act, rel(a, b))
+            a, b = g.forward_step([5], len(ids))[0, 0], s.forward_step([5], len(ids))[0, 0]
+            assert rel(a, b) < tol, (act, rel(a, b))
+            g.clear_kv_cache(); s.clear_kv_cache()
+            g.debug_set("no_prefill", 1); s.debug_set("no_prefill", 1)          # the prompt through the quantised decode kernels
+            a, b = g.forward_step(ids[:9], 0)[0, 0], s.forward_step(ids[:9], 0)[0, 0]
+            assert rel(a, b) < tol, (act, rel(a, b))
+            if act == "f32":
+                assert g.generate(ids, GenerationConfig.greedy(12)) == s.generate(ids, GenerationConfig.greedy(12))
+        finally:
+            g.close(); s.close()
+
+
+def test_gguf_checkpoint_under_tensor_parallelism(tmp_path):
+    """A llama.cpp-style mixed-type GGUF file (Q4_K / Q6_K / Q8_0 matrices, quantised embedding) loaded by a TP = 2 group: the
+    loader cuts the quantised tensors by row (heads, gate / up, vocabulary) and by column on whole ggml blocks; f32 activations so
+    that only the order of the cross-rank sums differs from the TP = 1 handle."""
+    from crane_amd.backend import GenerationConfig, Model
+    from oracle import gguf_oracle as G
+    cfg = configs.get_config("tiny-qwen3-untied")
+    w = synth.synth_weights_f32(cfg, seed=0)
+
+    def mixed(name, shape):
+        if "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
+            return G.GGML_Q6_K
+        if "attn_output" in name or name == "output.weight":
+            return G.GGML_Q8_0
+        return G.GGML_Q4_K
+    path = str(tmp_path / "tp.gguf")
+    G.write_qwen3_gguf(path, cfg, w, mixed)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    kw = dict(max_seq_len=128, max_seqs=2, quant_act="f32")
+    g = Model.from_pretrained(path, tp_size=2, tp_in_process=True, tp_devices=[0, 0], **kw)
+    s = Model.from_pretrained(path, **kw)
+    try:
+        a, b = g.forward_step(ids, 0)[0, 0], s.forward_step(ids, 0)[0, 0]
+        assert rel(a, b) < 1e-4
+        a, b = g.forward_step([5], len(ids))[0, 0], s.forward_step([5], len(ids))[0, 0]
+        assert rel(a, b) < 1e-4
+        assert g.generate(ids, GenerationConfig.greedy(10)) == s.generate(ids, GenerationConfig.greedy(10))
+    finally:
+        g.close(); s.close()
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3-vl", "tiny-qwen3.5-vl"])
+def test_vision_language_group(name):
+    """Image + text through a TP = 2 group: the tower is replicated (every rank encodes), the image rows are spliced into every
+    rank's hidden rows, DeepStack maps are added on every rank, 3-axis MRoPE positions and rope_delta are per-rank copies."""
+    from crane_amd.processor import PreprocessorConfig
+    cfg = configs.get_config(name)
+    rng = np.random.default_rng(0)
+    image = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    vc = cfg["vision_config"]
+    pix, grid = PreprocessorConfig(patch_size=vc.get("patch_size", 16), temporal_patch_size=vc.get("temporal_patch_size", 2),
+                                   merge_size=vc.get("spatial_merge_size", 2)).process(image)
+    g, s = _group(cfg, 2), _single(cfg)
+    try:
+        fa, fb = g.encode_images(pix, [list(grid)]), s.encode_images(pix, [list(grid)])
+        assert np.array_equal(fa, fb)                                   # the tower is not sharded
+        img = cfg["image_token_id"]
+        ids = [5, 6, cfg["vision_start_token_id"]] + [img] * int(fa.shape[0]) + [cfg["vision_end_token_id"], 8, 9]
+        (la, ta), (lb, tb) = g.vlm_forward(ids, pix, [list(grid)]), s.vlm_forward(ids, pix, [list(grid)])
+        assert rel(la, lb) < 1e-4 and ta == tb
+        toks_g, toks_s, pos = [ta], [tb], len(ids)
+        for i in range(6):
+            toks_g.append(g.forward_step_greedy([toks_g[-1]], pos + i)); toks_s.append(s.forward_step_greedy([toks_s[-1]], pos + i))
+        assert toks_g == toks_s
+    finally:
+        g.close(); s.close()
+
+
+def test_large_decode_group_under_tensor_parallelism():
+    """20 sequences per decode round: the projections run as MFMA GEMMs over the rows of the batch, ONE all-reduce per projection
+    covers all rows, the vocabulary-sharded head feeds one gather; int8 KV pages on top (codes and scales sharded with their heads)."""
+    cfg = configs.get_config("tiny-qwen3-untied")
+    for kv in ("f16", "int8"):
+        g, s = _group(cfg, 2, max_seqs=24, kv_dtype=kv), _single(cfg, max_seqs=24, kv_dtype=kv)
+        try:
+            outs = []
+            for m in (g, s):
+                sq = [m.seq_alloc() for _ in range(20)]
+                last = [m.seq_forward(q, configs.synthetic_prompt(5 + (i % 7), cfg["vocab_size"]), 0, want_logits=False)[1] for i, q in enumerate(sq)]
+                toks = [list(last)]
+                for _ in range(4):
+                    _, nxt = m.step_batch_decode(sq, toks[-1], want_logits=False)
+                    toks.append([int(t) for t in nxt])
+                outs.append(toks)
+            assert outs[0] == outs[1], kv
+        finally:
+            g.close(); s.close()
