@@ -299,8 +299,149 @@ static void load_dense_shard(Model& m, const File& g) {
     }
 }
 
+// one f32 / f16 / bf16 vector of the file as floats on the host
+static std::vector<float> host_vec(const File& g, const std::string& name, size_t n) {
+    const TensorInfo& t = g.tensor(name);
+    if (t.numel() != (uint64_t)n) throw CmError(CM_ERR_IO, "GGUF tensor " + name + " has unexpected length");
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (t.type == cmgguf::F32) memcpy(&h[i], t.data + i * 4, 4);
+        else if (t.type == cmgguf::F16) { uint16_t v; memcpy(&v, t.data + i * 2, 2); h[i] = f16_to_f32(v); }
+        else if (t.type == cmgguf::BF16) { uint16_t v; memcpy(&v, t.data + i * 2, 2); const uint32_t u = (uint32_t)v << 16; memcpy(&h[i], &u, 4); }
+        else throw CmError(CM_ERR_UNSUPPORTED, "GGUF tensor " + name + ": vectors must be F32 / F16 / BF16");
+    }
+    return h;
+}
+static float* upload_f32(Model& m, const std::vector<float>& h) {
+    float* d = m.dalloc<float>(h.size(), true);
+    CM_HIP(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+// The hybrid family (llama.cpp `qwen35`) under tensor parallelism (round 4).  Rank r owns key heads [r NK_l, (r + 1) NK_l) of the
+// Gated Delta Net layers and the value heads paired with them.  The file orders the value heads CHUNKED (key head of value head v
+// = v mod NK, ops/gdn/config.rs:13-22), so a rank's value heads are NOT contiguous: local value head j = c * NK_l + kl is the
+// file's c * NK + r * NK_l + kl -- the rank's own heads again in chunked order, which is what the kernels' `chunked` flag
+// expects.  Rows (q / k / v conv channels, z, the bf16 b / a rows, A_log, dt_bias) are gathered by head; ssm_out is cut by COLUMN
+// in runs of NK_l value heads (whole ggml blocks: any NK_l for the 32-weight formats, an even NK_l for the K-quants -- two heads =
+// one 256-block; Qwen3.8-27B at TP = 8 has NK_l = 2).  Full-attention layers: this rank's q heads (query and gate rows of the
+// per-head [q | gate] layout), its kv head(s), attn_output by column; the MLP as for the dense family.
+static void load_hybrid_shard(Model& m, const File& g) {
+    const Config& c = m.cfg;
+    const int H = c.H, D = c.D, I = c.I, Il = m.I_l, r = m.rank, qd = m.Hq_l * D, kd = m.Hkv_l * D;
+    const int NKl = c.NK, NVl = c.NV, NKg = c.NK_g, NVg = c.NV_g, Kd = c.Kd, Vd = c.Vd, vpg = NVl / NKl;
+    const int KDg = NKg * Kd, VDg = NVg * Vd, CDg = 2 * KDg + VDg, kdl = NKl * Kd, vdl = NVl * Vd, cdl = 2 * kdl + vdl;
+    auto gv = [&](int j) { return (j / NKl) * NKg + r * NKl + (j % NKl); };          // file index of local value head j
+    m.gdn_chunked = true;
+    int gdn_idx = 0;
+    for (int li = 0; li < c.L; ++li) {
+        LayerW& w = m.layers[(size_t)li];
+        w.full = c.layer_full(li);
+        const std::string p = "blk." + std::to_string(li) + ".";
+        if (!w.full) {
+            w.gdn_idx = gdn_idx++;
+            const TensorInfo &tqkv = g.tensor(p + "attn_qkv.weight"), &tz = g.tensor(p + "attn_gate.weight");
+            check_shape(tqkv, (uint64_t)CDg, (uint64_t)H); check_shape(tz, (uint64_t)VDg, (uint64_t)H);
+            auto pack_qkv = [&](Packed& pk) {
+                pack_rows(tqkv, r * kdl, kdl, H, pk);
+                pack_rows(tqkv, KDg + r * kdl, kdl, H, pk);
+                for (int j = 0; j < NVl; ++j) pack_rows(tqkv, 2 * KDg + gv(j) * Vd, Vd, H, pk);
+            };
+            auto pack_z = [&](Packed& pk) { for (int j = 0; j < NVl; ++j) pack_rows(tz, gv(j) * Vd, Vd, H, pk); };
+            if (tqkv.type == tz.type) {
+                Packed pk;
+                pack_qkv(pk); pack_z(pk);
+                w.q_in_proj = to_device(m, pk, cdl + vdl, H);
+            } else {
+                Packed pa, pb;
+                pack_qkv(pa); pack_z(pb);
+                w.q_in_proj = to_device(m, pa, cdl, H);
+                w.q_in_proj_z = to_device(m, pb, vdl, H);
+            }
+            std::vector<uint16_t> ba((size_t)2 * NVl * H);               // b rows then a rows of this rank's value heads, bf16
+            for (int which = 0; which < 2; ++which) {
+                const std::vector<float> full = host_vec(g, p + (which == 0 ? "ssm_beta.weight" : "ssm_alpha.weight"), (size_t)NVg * H);
+                for (int j = 0; j < NVl; ++j)
+                    for (int k = 0; k < H; ++k) {
+                        uint32_t u; memcpy(&u, &full[(size_t)gv(j) * H + k], 4);
+                        ba[((size_t)which * NVl + j) * H + k] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                    }
+            }
+            w.in_proj_ba = m.dalloc<uint16_t>(ba.size(), true);
+            CM_HIP(hipMemcpy(w.in_proj_ba, ba.data(), ba.size() * 2, hipMemcpyHostToDevice));
+            m.quant_weight_bytes += ba.size() * 2;
+            {   // ssm_out [H, VDg]: per row the vpg runs of NK_l heads
+                const TensorInfo& to = g.tensor(p + "ssm_out.weight");
+                check_shape(to, (uint64_t)H, (uint64_t)VDg);
+                Packed po;
+                for (int row = 0; row < H; ++row)
+                    for (int cc = 0; cc < vpg; ++cc) pack_rows(to, row, 1, VDg, po, (cc * NKg + r * NKl) * Vd, NKl * Vd);
+                w.q_out_proj = to_device(m, po, H, vdl);
+            }
+            {   // conv taps [conv_dim, k]: q channels, k channels, v channels of the rank's heads
+                const std::vector<float> full = host_vec(g, p + "ssm_conv1d.weight", (size_t)CDg * c.conv_k);
+                std::vector<float> loc((size_t)cdl * c.conv_k);
+                auto put = [&](int dst_ch, int src_ch, int n) { memcpy(&loc[(size_t)dst_ch * c.conv_k], &full[(size_t)src_ch * c.conv_k], (size_t)n * c.conv_k * 4); };
+                put(0, r * kdl, kdl);
+                put(kdl, KDg + r * kdl, kdl);
+                for (int j = 0; j < NVl; ++j) put(2 * kdl + j * Vd, 2 * KDg + gv(j) * Vd, Vd);
+                w.conv_w = upload_f32(m, loc);
+            }
+            {
+                const TensorInfo& ta = g.tensor(p + "ssm_a");
+                if (ta.numel() != (uint64_t)NVg || ta.type != cmgguf::F32) throw CmError(CM_ERR_IO, "ssm_a must be F32 [num_v_heads]");
+                const std::vector<float> sa = host_vec(g, p + "ssm_a", (size_t)NVg), dt = host_vec(g, p + "ssm_dt.bias", (size_t)NVg);
+                std::vector<float> al((size_t)NVl), db((size_t)NVl);
+                for (int j = 0; j < NVl; ++j) { al[(size_t)j] = logf(-sa[(size_t)gv(j)]); db[(size_t)j] = dt[(size_t)gv(j)]; }
+                w.A_log = upload_f32(m, al);
+                w.dt_bias = upload_f32(m, db);
+            }
+            w.gnorm = load_vec_f32(m, g, p + "ssm_norm.weight", Vd);
+        } else {
+            const TensorInfo &tq = g.tensor(p + "attn_q.weight"), &tk = g.tensor(p + "attn_k.weight"), &tv = g.tensor(p + "attn_v.weight");
+            check_shape(tq, (uint64_t)2 * c.Hq * D, (uint64_t)H); check_shape(tk, (uint64_t)c.Hkv * D, (uint64_t)H); check_shape(tv, (uint64_t)c.Hkv * D, (uint64_t)H);
+            auto pack_q = [&](Packed& pk) {          // [all q | all gate] of this rank's heads out of the per-head [q | gate] rows
+                for (int h = 0; h < m.Hq_l; ++h) pack_rows(tq, (r * m.Hq_l + h) * 2 * D, D, H, pk);
+                for (int h = 0; h < m.Hq_l; ++h) pack_rows(tq, (r * m.Hq_l + h) * 2 * D + D, D, H, pk);
+            };
+            if (tq.type == tk.type && tk.type == tv.type) {
+                Packed pk;
+                pack_q(pk); pack_rows(tk, m.kvh0 * D, kd, H, pk); pack_rows(tv, m.kvh0 * D, kd, H, pk);
+                w.q_qkv[0] = to_device(m, pk, 2 * qd + 2 * kd, H);
+                w.n_qkv = 1; w.qkv_row0[0] = 0;
+            } else {
+                Packed pq;
+                pack_q(pq);
+                w.q_qkv[0] = to_device(m, pq, 2 * qd, H);
+                w.q_qkv[1] = load_matrix_part(m, g, p + "attn_k.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H);
+                w.q_qkv[2] = load_matrix_part(m, g, p + "attn_v.weight", c.Hkv * D, H, m.kvh0 * D, kd, 0, H);
+                w.n_qkv = 3; w.qkv_row0[0] = 0; w.qkv_row0[1] = 2 * qd; w.qkv_row0[2] = 2 * qd + kd;
+            }
+            w.q_o = load_matrix_part(m, g, p + "attn_output.weight", H, c.Hq * D, 0, H, r * qd, qd);
+            if (c.qk_norm) {
+                w.qn = load_vec_f32(m, g, p + "attn_q_norm.weight", D);
+                w.kn = load_vec_f32(m, g, p + "attn_k_norm.weight", D);
+            }
+        }
+        const TensorInfo &tg = g.tensor(p + "ffn_gate.weight"), &tu = g.tensor(p + "ffn_up.weight");
+        check_shape(tg, (uint64_t)I, (uint64_t)H); check_shape(tu, (uint64_t)I, (uint64_t)H);
+        if (tg.type == tu.type) {
+            Packed pk;
+            for (int j = 0; j < Il; ++j) { pack_rows(tg, r * Il + j, 1, H, pk); pack_rows(tu, r * Il + j, 1, H, pk); }
+            w.q_gate_up = to_device(m, pk, 2 * Il, H);
+        } else {
+            w.split_gate_up = true;
+            w.q_gate = load_matrix_part(m, g, p + "ffn_gate.weight", I, H, r * Il, Il, 0, H);
+            w.q_up = load_matrix_part(m, g, p + "ffn_up.weight", I, H, r * Il, Il, 0, H);
+            if (!m.gu_tmp) m.gu_tmp = m.dalloc<float>((size_t)2 * Il);
+        }
+        w.q_down = load_matrix_part(m, g, p + "ffn_down.weight", H, I, 0, H, r * Il, Il);
+        w.ln1 = load_vec_f32(m, g, p + "attn_norm.weight", H);
+        w.ln2 = load_vec_f32(m, g, p + "post_attention_norm.weight", H);
+    }
+}
+
 void load_from_gguf(Model& m, const std::string& path) {
-    if (m.tp != 1 && m.cfg.hybrid) throw CmError(CM_ERR_UNSUPPORTED, "GGUF weights of the hybrid family under tensor parallelism are not implemented");
     try {
         File g(path);
         const Config& c = m.cfg;
@@ -314,7 +455,11 @@ void load_from_gguf(Model& m, const std::string& path) {
         if (!c.tie) { if (v_eff > 0) m.q_lm_head = load_matrix_part(m, g, "output.weight", c.V, H, m.v0, v_eff, 0, H); }
         else { m.q_lm_head = m.q_embed.rows(m.v0, v_eff); m.quant_weight_bytes += m.q_lm_head.bytes(); }
         m.layers.resize((size_t)c.L);
-        if (m.tp != 1) { load_dense_shard(m, g); CM_HIP(hipStreamSynchronize(m.stream)); return; }
+        if (m.tp != 1) {
+            if (c.hybrid) load_hybrid_shard(m, g); else load_dense_shard(m, g);
+            CM_HIP(hipStreamSynchronize(m.stream));
+            return;
+        }
         const int qd = c.Hq * D, kd = c.Hkv * D;
         m.gdn_chunked = c.hybrid;                  // llama.cpp orders the GDN value heads Chunked (ops/gdn/config.rs:13-22)
         int gdn_idx = 0;

@@ -278,3 +278,37 @@ def test_large_decode_group_under_tensor_parallelism():
             assert outs[0] == outs[1], kv
         finally:
             g.close(); s.close()
+
+
+@pytest.mark.parametrize("kind", ["q8_0", "mixed35"])
+def test_hybrid_gguf_checkpoint_under_tensor_parallelism(tmp_path, kind):
+    """llama.cpp `qwen35` GGUF (CHUNKED value-head order: a rank's value heads are strided in the file) loaded by a TP = 2 group:
+    q / k / v conv channels, z, the bf16 b / a rows, A_log, dt_bias gathered by head, ssm_out cut by column in runs of NK_l value
+    heads, the gated attention's per-head [q | gate] rows, mixed ggml types inside in_proj / q|k|v / gate|up."""
+    from crane_amd.backend import GenerationConfig, Model
+    from oracle import gguf_oracle as G
+    cfg = configs.get_config("tiny-qwen3.5")
+    w = synth.synth_weights_f32(cfg, seed=0)
+    if kind == "q8_0":
+        type_of = lambda name, shape: G.GGML_Q8_0
+    else:
+        def type_of(name, shape):
+            if "attn_gate" in name or "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
+                return G.GGML_Q6_K
+            if "ssm_out" in name or "attn_output" in name or name == "output.weight" or "ffn_down" in name:
+                return G.GGML_Q8_0            # column cuts of 128 / 256 columns: whole 32-weight blocks
+            return G.GGML_Q4_K
+    path = str(tmp_path / f"tp35-{kind}.gguf")
+    G.write_qwen35_gguf(path, cfg, w, type_of)
+    ids = configs.synthetic_prompt(21, cfg["vocab_size"])
+    kw = dict(max_seq_len=128, max_seqs=2, quant_act="f32")
+    g = Model.from_pretrained(path, tp_size=2, tp_in_process=True, tp_devices=[0, 0], **kw)
+    s = Model.from_pretrained(path, **kw)
+    try:
+        a, b = g.forward_step(ids, 0)[0, 0], s.forward_step(ids, 0)[0, 0]
+        assert rel(a, b) < 1e-4
+        a, b = g.forward_step([5], len(ids))[0, 0], s.forward_step([5], len(ids))[0, 0]
+        assert rel(a, b) < 1e-4
+        assert g.generate(ids, GenerationConfig.greedy(10)) == s.generate(ids, GenerationConfig.greedy(10))
+    finally:
+        g.close(); s.close()
