@@ -45,12 +45,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_base) {
 
 }  // namespace
 
-template <int SPLIT, int EPI, int BN>
+// WST = 3 (round 4, decode groups: one m-tile, the weights come from HBM, not from a neighbour's L2 lines): a THIRD weight stage, the
+// weight requests running two k-tiles ahead (the activation stages stay at two).  With two stages a workgroup has one 32 KB weight
+// tile in flight; 96-192 workgroups of a 128-row launch are then 3-6 MB in flight chip-wide -- about 3 TB/s at the ~2 us of a loaded
+// HBM round trip, which is what the launch measured.  The waits become counted: the newest weight requests may stay outstanding.
+template <int SPLIT, int EPI, int BN, int WST = 2>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     constexpr int BM = SPLIT == 2 ? 128 : 256;                            // rows of a tile (two planes double the activation bytes)
     constexpr int NI = BM / 32, NJ = BN / 64, WM = BM / 2, WN = BN / 4;  // per wave: NI x NJ tiles of 16 x 16
     constexpr int PLANE = BM * TBK;                                       // elements of one activation plane of a stage
-    constexpr int STAGE = SPLIT * PLANE + BN * TBK;                       // elements per stage
+    constexpr int ASTAGE = SPLIT * PLANE, WSTAGE = BN * TBK;             // elements of an activation / a weight stage
+    constexpr int WBASE = TST * ASTAGE;                                   // LDS image: [TST activation stages][WST weight stages]
     constexpr int APC = BM / 8, NPC = SPLIT * APC + BN / 8;               // 8-row DMA pieces per plane / per stage
     constexpr int NLOAD = (NPC + 7) / 8;                                  // DMA instructions per wave and k-tile (7 or 8)
     static_assert(NPC > 8 * (NLOAD - 1) && NLOAD <= 8, "piece distribution");
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds256;                    // LDS byte offset of the dynamic segment (low half of the flat address)
     const uint16_t* src[NLOAD];
     uint32_t dst[NLOAD];
+    bool isw[NLOAD];
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
         int p = wave + 8 * i;
@@ -95,15 +101,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
         } else {
             src[i] = a.W + (size_t)(n0 + row) * K + kc;
         }
-        dst[i] = lds0 + (uint32_t)(plane * PLANE + r0 * TBK) * 2u;        // (plane == SPLIT: SPLIT * PLANE = start of the weight rows)
+        dst[i] = lds0 + (uint32_t)(plane < SPLIT ? plane * PLANE + r0 * TBK : WBASE + r0 * TBK) * 2u;
+        isw[i] = plane == SPLIT;
     }
+    // weight pieces of this wave (the LAST requests of every issue: the counted waits let exactly these stay in flight)
+    constexpr int NWP = (BN / 8) / 8;
+    static_assert(WST == 2 || ((SPLIT * APC) % 8 == 0 && (BN / 8) % 8 == 0), "counted waits need whole piece rows per wave");
 
     const int fr = lane & 15, sw = (fr >> 1) & 7;
     const int fk0 = ((0 + (lane >> 4)) ^ sw) << 3, fk1 = ((4 + (lane >> 4)) ^ sw) << 3;      // element offsets of the lane's chunk, k-steps 0 / 1
     bf16x8 ah[2][NI], al[2][NI], bfr[2][NJ];
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-        const uint16_t* S = lds256 + stage * STAGE;
-        const uint16_t* Bs = S + SPLIT * PLANE;
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const uint16_t* S = lds256 + (t & 1) * ASTAGE;
+        const uint16_t* Bs = lds256 + WBASE + (t % WST) * WSTAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int fk = s ? fk1 : fk0;
@@ -138,17 +148,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 }
             }
     };
-    auto issue_all = [&](int tile, int stage) __attribute__((always_inline)) {
-        const size_t ko = (size_t)tile * TBK;
-        const uint32_t so = (uint32_t)(stage * STAGE) * 2u;
+    // requests of one slot: the activation pieces of tile `ta` and the weight pieces of tile `tw` (= ta with two weight stages, ta + 1
+    // with three), each clamped to the last tile (past the end: into a stage nobody reads)
+    auto piece = [&](int g, int ta, int tw) __attribute__((always_inline)) {
+        const int tl = kpb - 1;
+        if (isw[g]) { const int tt = min(tw, tl); glds16(src[g] + (size_t)tt * TBK, dst[g] + (uint32_t)((tw % WST) * WSTAGE) * 2u); }
+        else { const int tt = min(ta, tl); glds16(src[g] + (size_t)tt * TBK, dst[g] + (uint32_t)((ta & 1) * ASTAGE) * 2u); }
+    };
+    auto issue_all = [&](int ta, int tw) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < NLOAD; ++g) glds16(src[g] + ko, dst[g] + so);
+        for (int g = 0; g < NLOAD; ++g) piece(g, ta, tw);
     };
     // row 1: the MFMAs in 2 * NI row bands, one DMA request of the tile after next behind each of the first NLOAD bands (pinned:
     // left alone the scheduler hoists every MFMA above the requests)
-    auto multiply_dma = [&](int tile, int stage) __attribute__((always_inline)) {
-        const size_t ko = (size_t)tile * TBK;
-        const uint32_t so = (uint32_t)(stage * STAGE) * 2u;
+    auto multiply_dma = [&](int ta, int tw) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -163,36 +176,47 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
                 const int g = (s * NI + i) * PER;
                 if (g < NLOAD) {
                     __builtin_amdgcn_sched_barrier(0);
-                    glds16(src[g] + ko, dst[g] + so);
+                    piece(g, ta, tw);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
     };
 
+    // WA: the weight tile requested next to activation tile ta is ta + (WST - 2): one further ahead with the third stage
+    constexpr int WA = WST - 2;
     issue_all(0, 0);                                                      // tile 0: every wave its share
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (WST == 3) {                                             // ... and the weights of tile 1 (its activations follow in the loop)
+#pragma unroll
+        for (int g = 0; g < NLOAD; ++g) if (isw[g]) piece(g, 0, 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NWP) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if (wr == 0) {
         for (int t = 0; t < kpb; ++t) {
-            issue_all(min(t + 1, kpb - 1), (t + 1) & 1);                  // (past the end: a clamped tile into a stage nobody reads)
-            fetch(t & 1);
+            issue_all(t + 1, t + 1 + WA);
+            fetch(t);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             multiply();
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");     // this wave's share of tile t + 1 has landed
+            // this wave's share of tile t + 1 has landed (three stages: its newest weight requests, tile t + 2, may still fly)
+            if constexpr (WST == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NWP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_barrier" ::: "memory");                           // (every wave executes the same number of barriers)
     } else {
-        issue_all(min(1, kpb - 1), 1);                                    // its share of tile 1, in the slot in which row 0 fetches tile 0
+        issue_all(1, 1 + WA);                                             // its share of tile 1, in the slot in which row 0 fetches tile 0
         asm volatile("s_barrier" ::: "memory");                           // the late row: one barrier behind
         for (int t = 0; t < kpb; ++t) {
-            fetch(t & 1);
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // its share of tile t + 1 has landed
+            fetch(t);
+            if constexpr (WST == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(NWP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // its share of tile t + 1 has landed
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-            multiply_dma(min(t + 2, kpb - 1), t & 1);
+            multiply_dma(t + 2, t + 2 + WA);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
@@ -269,14 +293,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 
 // rows of a tile / dynamic LDS of an instantiation
 int gemm256_rows(bool split) { return split ? 128 : 256; }
-static size_t gemm256_lds(int split, int bn) { return (size_t)TST * ((size_t)split * gemm256_rows(split == 2) * TBK + (size_t)bn * TBK) * 2; }
+static size_t gemm256_lds(int split, int bn, int wst = 2) { return ((size_t)TST * split * gemm256_rows(split == 2) * TBK + (size_t)wst * bn * TBK) * 2; }
 
-template <int SPLIT, int EPI, int BN>
+template <int SPLIT, int EPI, int BN, int WST = 2>
 static void launch_one(const GemmArgs& a, int blocks, hipStream_t s) {
     static DevOnce attr;
-    const size_t lds = gemm256_lds(SPLIT, BN);
-    attr.run([&] { (void)hipFuncSetAttribute((const void*)gemm256_kernel<SPLIT, EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL((gemm256_kernel<SPLIT, EPI, BN>), dim3(blocks), dim3(512), lds, s, a);
+    const size_t lds = gemm256_lds(SPLIT, BN, WST);
+    attr.run([&] { (void)hipFuncSetAttribute((const void*)gemm256_kernel<SPLIT, EPI, BN, WST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    hipLaunchKernelGGL((gemm256_kernel<SPLIT, EPI, BN, WST>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 // a.ksplit set by the caller (1: epilogue `epi`; > 1: GEPI_PARTIAL tiles, the caller runs gemm_splitk_epilogue_kernel)
@@ -286,7 +310,12 @@ bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const int bm = gemm256_rows(split);
     const int blocks = ((a.M + bm - 1) / bm) * (a.N / bn) * a.ksplit;
     const int e = a.ksplit > 1 ? (int)GEPI_PARTIAL : epi;
-#define CM_G256(SP, EP) do { if (bn == 256) launch_one<SP, EP, 256>(a, blocks, s); else launch_one<SP, EP, 192>(a, blocks, s); } while (0)
+    // three weight stages (WST = 3): parity-mode tiles of 256 columns (160 KB of LDS); by default for one-m-tile launches (decode
+    // groups: the weights stream from HBM), CM_GEMM256_WST = 2 never, 3 always (A/B)
+    static const int wst_env = getenv("CM_GEMM256_WST") ? atoi(getenv("CM_GEMM256_WST")) : 0;
+    const bool w3 = split && bn == 256 && (wst_env == 3 || (wst_env == 0 && a.M <= bm)) && a.K / TBK / a.ksplit >= 3;
+#define CM_G256(SP, EP) do { if (bn == 256) { if (SP == 2 && w3) launch_one<2, EP, 256, 3>(a, blocks, s); else launch_one<SP, EP, 256>(a, blocks, s); } \
+                             else launch_one<SP, EP, 192>(a, blocks, s); } while (0)
 #define CM_G256_EPI(SP) do { if (e == GEPI_STORE) CM_G256(SP, GEPI_STORE); else if (e == GEPI_RESADD) CM_G256(SP, GEPI_RESADD); \
         else if (e == GEPI_ACT_SPLIT) CM_G256(SP, GEPI_ACT_SPLIT); else if (e == GEPI_SILUMUL) CM_G256(SP, GEPI_SILUMUL); \
         else CM_G256(SP, GEPI_PARTIAL); } while (0)
