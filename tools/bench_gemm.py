@@ -9,7 +9,8 @@ from crane_amd.backend import Model
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 SPLIT = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-cfg = dict(configs.get_config("qwen3-8b"), num_hidden_layers=8)
+import os
+cfg = dict(configs.get_config("qwen3-8b"), num_hidden_layers=int(os.environ.get("LAYERS", "8")))      # LAYERS=1: the weights of a projection stay in the 256 MB Infinity Cache between launches
 m = Model.synthetic(cfg, seed=0, max_seq_len=max(M, 2048) + 64, max_seqs=1, prefill_split=SPLIT, prefill_chunk=max(M, 2048))
 res = {}
 for r in range(ROUNDS):
