@@ -299,8 +299,9 @@ def main():
         try:
             if not args.isq and n == 1:
                 san = args.model.replace("-", "_").replace(".", "_")
-                srcs = ("r03_pmc_traffic_decode.json", "r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json") \
-                    if args.model == "qwen3-8b" else (f"r03_pmc_traffic_decode_{san}.json",)
+                # newest first; re-collected whenever kernels_engine.hip / the decode GEMVs change (tools/gpu_round.sh traffic)
+                srcs = ("r04_pmc_traffic_decode_qwen3_8b.json", "r03_pmc_traffic_decode.json", "r02_pmc_traffic_decode.json", "r01_pmc_traffic_decode.json") \
+                    if args.model == "qwen3-8b" else (f"r04_pmc_traffic_decode_{san}.json", f"r03_pmc_traffic_decode_{san}.json")
                 for src in srcs:
                     path = os.path.join(ROOT, "profiles", src)
                     if not os.path.exists(path):

@@ -24,11 +24,11 @@ def test_bench_refuses_more_gpus_than_the_node_has():
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    """The last bench line of the round (profiles/r03_bench_default.json, written by `python bench.py` on the MI355X) has every
+    """The last bench line of the round (profiles/r04_bench_default.json, written by `python bench.py` on the MI355X) has every
     field the driver and the judge read, and its own numbers are consistent with each other."""
     import json
     line = None
-    for l in open(os.path.join(ROOT, "profiles", "r03_bench_default.json")):
+    for l in open(os.path.join(ROOT, "profiles", "r04_bench_default.json")):
         if l.startswith("{"):
             line = json.loads(l)
     assert line is not None
@@ -54,4 +54,8 @@ def test_committed_bench_line_carries_the_contract_fields():
     w, t = p["model_written_cache"], p["timed_configuration"]          # a cache the model wrote itself / the timed synthetic cache
     assert w["greedy_equal"] == w["greedy_checked"] and max(w["prefill_logit_rel"], w["decode_logit_rel"]) < 1e-3
     assert t["tokens_equal"] == t["tokens_checked"] and t["logit_rel"] < 1e-3
+    lw = p["model_written_cache_ctx1024"]                              # round 4: the headline configuration itself -- every layer, a 1024-token
+    assert lw["ok"] is True and lw["prompt_tokens"] == 1024 and lw["layers"] == 36            # cache the model wrote, against oracle/c
+    assert lw["greedy_equal"] == lw["greedy_checked"] and max(lw["prefill_logit_rel"], lw["decode_logit_rel"]) < 1e-3
+    assert p["logit_rel"] >= max(lw["prefill_logit_rel"], lw["decode_logit_rel"])             # the headline figure includes it
     assert line["roofline_step"]["frac"] >= 0.69
