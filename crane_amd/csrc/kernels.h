@@ -65,6 +65,11 @@ struct AttnDecArgs {
     void* vpool;
     float* part_o;               // [Hq][nsplit][D]
     float* part_ml;              // [Hq][nsplit][2]
+    float* out1 = nullptr;       // ONE token split per sequence (launch_attn_decode*: nsplit == 1): the kernel normalises (and gates) itself and
+    int out1_stride = 0;         //   writes out1[seq * out1_stride + h * D + d] -- no partials, no combine launch
+    uint16_t* out1_hi = nullptr; //   ... or, when set (the caller asked attn_decode_single_split()), as bf16 hi + lo planes [seq][out1_cols]: the A
+    uint16_t* out1_lo = nullptr; //   operand of the o_proj GEMM of a large decode group (split_rows2d's arithmetic), instead of the f32 rows
+    int out1_cols = 0;
     int q_off, k_off, v_off;     // element offsets of q / k / v inside qkv
     int qkv_stride, bt_stride;   // batched step: per-sequence strides of qkv rows and block tables
     int Hkv, page, max_pages, rot_dim;
@@ -116,6 +121,13 @@ struct GemmArgs {
     size_t ws_floats;
     int ksplit;             // set by launch_gemm
     int wide256 = 1;        // 0: never the 256-row LDS-DMA kernel (kernels_gemm256.hip) -- A/B switch, cm_debug_set("gemm256")
+    // GEPI_RESADD with ldc == N only: ALSO write RMSNorm(C row) * norm_w as bf16 hi + lo planes [M][N] -- the A operand of the NEXT
+    // GEMM (rmsnorm_rows_kernel's arithmetic).  Fused into the split-K reduction launch when the GEMM splits K (a large decode
+    // group: one launch less per projection), a separate rmsnorm_rows launch otherwise -- launch_gemm does either.
+    const float* norm_w = nullptr;
+    uint16_t* norm_hi = nullptr;
+    uint16_t* norm_lo = nullptr;
+    float norm_eps = 0.f;
 };
 
 // one sequence of a multi-sequence prompt pass (Model::prefill_multi): rows [row0, row0 + S) of the pass at positions start_pos...,
@@ -228,6 +240,7 @@ void launch_embed_row(const uint16_t* emb, const StepState* st, float* x, int H,
 void launch_set_state(StepState* st, uint32_t token, int32_t pos, int32_t slot, int32_t rope_delta, hipStream_t s);
 void launch_argmax_final(const float* pmax, const int* pidx, int n, StepState* st, uint32_t* ring,
                          int ring_mask, int advance, int n_seq, hipStream_t s, int slabs = 1, size_t slab_stride = 0);
+bool attn_decode_single_split(int nsplit, int D);     // launch_attn_decode(_mfma) will write the final output itself (AttnDecArgs::out1)
 bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq, hipStream_t s);
 bool launch_attn_decode_heads(const AttnDecArgs& a, int D, int nrep, int ns, bool kv_f32, int n_seq, hipStream_t s);
 bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq,

@@ -11,6 +11,8 @@
 //              (qwen3_5/modeling.rs:516-522)
 //   layout   : K/V page = [Hkv][PAGE][D]; a token row (D*2 bytes) is read by D/8 lanes x 16 B,
 //              64/(D/8) rows per wave, 4 waves per block; grid (nsplit, Hkv).
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -274,6 +276,19 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnDecArgs a) {
                 O += w * red_o[i][h][d];
                 Ls += w * red_l[i][h];
             }
+        }
+        if (a.out1 != nullptr) {                                 // the only split of this sequence: what the combine kernel would compute
+            float v = O * (1.0f / Ls);                           //   from one partial (weight e^0 = 1), bit for bit
+            if (a.gate != nullptr) v *= 1.0f / (1.0f + expf(-a.gate[(size_t)bq * a.qkv_stride + (size_t)(kvh * NREP + h) * D + d]));
+            if (a.out1_hi != nullptr) {
+                const size_t off = (size_t)bq * a.out1_cols + (size_t)(kvh * NREP + h) * D + d;
+                const uint16_t hh = f32_to_bf16(v);
+                a.out1_hi[off] = hh;
+                a.out1_lo[off] = f32_to_bf16(v - bf16_to_f32(hh));
+            } else {
+                a.out1[(size_t)bq * a.out1_stride + (size_t)(kvh * NREP + h) * D + d] = v;
+            }
+            continue;
         }
         const size_t ph = ((size_t)bq * a.Hkv * NREP + (size_t)(kvh * NREP + h)) * nsplit + split;
         a.part_o[ph * D + d] = O;
@@ -893,6 +908,19 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
                 Ls += wt * red_l[w][h];
             }
         }
+        if (a.out1 != nullptr) {                                 // the only split of this sequence: what the combine kernel would compute
+            float v = O * (1.0f / Ls);                           //   from one partial (weight e^0 = 1), bit for bit
+            if (a.gate != nullptr) v *= 1.0f / (1.0f + expf(-a.gate[(size_t)bq * a.qkv_stride + (size_t)(kvh * NREP + h) * D + d]));
+            if (a.out1_hi != nullptr) {
+                const size_t off = (size_t)bq * a.out1_cols + (size_t)(kvh * NREP + h) * D + d;
+                const uint16_t hh = f32_to_bf16(v);
+                a.out1_hi[off] = hh;
+                a.out1_lo[off] = f32_to_bf16(v - bf16_to_f32(hh));
+            } else {
+                a.out1[(size_t)bq * a.out1_stride + (size_t)(kvh * NREP + h) * D + d] = v;
+            }
+            continue;
+        }
         const size_t ph = ((size_t)bq * a.Hkv * NREP + (size_t)(kvh * NREP + h)) * nsplit + split;
         a.part_o[ph * D + d] = O;
         if (d == 0) { a.part_ml[ph * 2] = M; a.part_ml[ph * 2 + 1] = Ls; }
@@ -913,9 +941,22 @@ static bool launch_mfma(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode,
 #undef CM_MF
 }
 
+bool attn_decode_single_split(int nsplit, int D) {
+    static const int out1_env = getenv("CM_ATTN_OUT1") ? atoi(getenv("CM_ATTN_OUT1")) : 1;
+    return nsplit == 1 && out1_env != 0 && (D == 128 || D == 256);
+}
+
 // bf16 / f16 / int8 / int4 KV (not f32); same partial format and combine kernel as launch_attn_decode
 bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq, hipStream_t s) {
     if (a.page <= 0 || (a.page & (a.page - 1)) != 0 || kv_mode == 1) return false;
+    // one token split per sequence (large groups: the (kv head, sequence) pairs alone fill the chip): the kernel writes the
+    // normalised, gated output itself -- no combine launch (13 us per layer of a 128-sequence round); CM_ATTN_OUT1 = 0: A/B
+    if (attn_decode_single_split(nsplit, D)) {
+        AttnDecArgs b = a;
+        b.out1 = out; b.out1_stride = out_stride;
+        return D == 128 ? launch_mfma<128>(b, nrep, 1, kv_mode, n_seq, s) : launch_mfma<256>(b, nrep, 1, kv_mode, n_seq, s);
+    }
+    if (a.out1_hi != nullptr) return false;                      // (planes are only written by the single-split form)
     if (D == 128) {
         if (!launch_mfma<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,
@@ -948,6 +989,12 @@ static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode
 
 bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq,
                         hipStream_t s) {
+    if (attn_decode_single_split(nsplit, D)) {                   // (see launch_attn_decode_mfma)
+        AttnDecArgs b = a;
+        b.out1 = out; b.out1_stride = out_stride;
+        return D == 128 ? launch_split<128>(b, nrep, 1, kv_mode, n_seq, s) : launch_split<256>(b, nrep, 1, kv_mode, n_seq, s);
+    }
+    if (a.out1_hi != nullptr) return false;
     if (D == 128) {
         if (!launch_split<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,

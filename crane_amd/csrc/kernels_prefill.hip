@@ -733,6 +733,40 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs a) {
     }
 }
 
+// gemm_splitk_epilogue_kernel<GEPI_RESADD> + rmsnorm_rows_kernel in one launch (GemmArgs::norm_w): one block per row, the thread ->
+// column map and the order of every sum are those of the two kernels it replaces, so the row of C and the planes are bit-equal
+__global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float* cr = a.C + (size_t)m * a.ldc;
+    float ss = 0.f;
+    for (int n = tid * 4; n < a.N; n += 1024) {
+        f32x4 v = *(const f32x4*)(a.ws + (size_t)m * a.N + n);
+        for (int k = 1; k < a.ksplit; ++k) {
+            const f32x4 p = *(const f32x4*)(a.ws + ((size_t)k * a.M + m) * a.N + n);
+            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        }
+        if (a.bias != nullptr) {
+            const f32x4 b = *(const f32x4*)(a.bias + n);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        f32x4 c = *(const f32x4*)(cr + n);
+        c[0] += v[0]; c[1] += v[1]; c[2] += v[2]; c[3] += v[3];
+        *(f32x4*)(cr + n) = c;
+        ss += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)a.N + a.norm_eps);
+    for (int n = tid * 4; n < a.N; n += 1024) {
+        const f32x4 c = *(const f32x4*)(cr + n);                  // (this thread's own stores)
+        const f32x4 ww = *(const f32x4*)(a.norm_w + n);
+        const float o[4] = {c[0] * r * ww[0], c[1] * r * ww[1], c[2] * r * ww[2], c[3] * r * ww[3]};
+        split_store4(a.norm_hi, a.norm_lo, (size_t)m * a.N + n, o);
+    }
+}
+
 // split factor for a GEMM of `tiles` output tiles and nk k-tiles: only when the tiles alone leave the chip mostly idle
 static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
     static const int ksplit_cap = getenv("CM_KSPLIT_CAP") ? atoi(getenv("CM_KSPLIT_CAP")) : 768;      // blocks (tuning)
@@ -740,6 +774,12 @@ static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
     int S = 1;
     while (S < 8 && tiles * (S * 2) <= ksplit_cap && nk % (S * 2 * 4) == 0 && nk / (S * 2) >= 8 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
     return S;
+}
+
+// GemmArgs::norm_w can ride on the split-K reduction launch (CM_GEMM_NORM_FUSED = 0: always the separate rmsnorm_rows launch, A/B)
+static bool norm_fused(const GemmArgs& a) {
+    static const int env = getenv("CM_GEMM_NORM_FUSED") ? atoi(getenv("CM_GEMM_NORM_FUSED")) : 1;
+    return env != 0 && a.norm_w != nullptr && a.ldc == a.N && a.N % 4 == 0;
 }
 
 // Large M (>= 512 rows): the LDS-DMA kernel on full cache lines (kernels_gemm256.hip; 128-row tiles with hi + lo activations,
@@ -781,6 +821,7 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     if (best_ks > 1) {
         const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
         if (epi == GEPI_STORE) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_STORE>), dim3(eb), dim3(256), 0, s, a);
+        else if (epi == GEPI_RESADD && norm_fused(a)) { hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel, dim3(a.M), dim3(256), 0, s, a); a.norm_w = nullptr; }
         else if (epi == GEPI_RESADD) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_RESADD>), dim3(eb), dim3(256), 0, s, a);
         else if (epi == GEPI_ACT_SPLIT) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_ACT_SPLIT>), dim3(eb), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_SILUMUL>), dim3(eb), dim3(256), 0, s, a);
@@ -788,9 +829,17 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     return true;
 }
 
+static bool launch_gemm_inner(GemmArgs& a, int epi, hipStream_t s);
 bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     if (a0.N % 128 != 0 || a0.K % GBK != 0) return false;
     GemmArgs a = a0;
+    if (a.norm_w != nullptr && (epi != GEPI_RESADD || a.ldc != a.N)) return false;
+    if (!launch_gemm_inner(a, epi, s)) return false;
+    // the planes of RMSNorm(C) were not written by the split-K reduction (no split, or switched off): the row kernel
+    if (a.norm_w != nullptr) launch_rmsnorm_rows(a.C, a.norm_w, a.norm_hi, a.norm_lo, a.M, a.N, a.norm_eps, s);
+    return true;
+}
+static bool launch_gemm_inner(GemmArgs& a, int epi, hipStream_t s) {
     if (try_gemm256(a, epi, s)) return true;
     const int tiles_m = (a.M + GBM - 1) / GBM;
     const bool split = a.A_lo != nullptr;
@@ -826,6 +875,7 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_bf16_kernel<1, GEPI_PARTIAL, 128>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
         const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
         if (epi == GEPI_STORE) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_STORE>), dim3(eb), dim3(256), 0, s, a);
+        else if (epi == GEPI_RESADD && norm_fused(a)) { hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel, dim3(a.M), dim3(256), 0, s, a); a.norm_w = nullptr; }
         else if (epi == GEPI_RESADD) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_RESADD>), dim3(eb), dim3(256), 0, s, a);
         else if (epi == GEPI_ACT_SPLIT) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_ACT_SPLIT>), dim3(eb), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_SILUMUL>), dim3(eb), dim3(256), 0, s, a);

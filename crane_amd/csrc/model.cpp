@@ -1507,17 +1507,21 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         const bool heads_b = attn_heads_max > 0 && longest <= attn_heads_max && (kv_mode == KV_BF16 || kv_mode == KV_F32) && nb <= 8;
         const bool gemm_b = gemm_b_ok && nb >= batch_gemm_min && nb <= chunk;
         // y[nb, N] (+)= A[nb, K] . W^T through launch_gemm; A = the bf16 hi + lo rows produced by rows_in
-        auto gm = [&](int epi, const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, float* C, int ldc, int N, int K) {
+        // next_norm (GEPI_RESADD into xb only): RMSNorm(xb) * next_norm -> pXN_hi / pXN_lo, the A operand of the NEXT projection,
+        // written by the GEMM's split-K reduction launch (GemmArgs::norm_w) instead of a rmsnorm_rows launch of its own
+        auto gm = [&](int epi, const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, float* C, int ldc, int N, int K, const float* next_norm = nullptr) {
             GemmArgs g{};
             g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = A_hi; g.A_lo = A_lo; g.W = W; g.C = C; g.ldc = ldc; g.M = nb; g.N = N; g.K = K;
             g.H_hi = pHH_hi; g.H_lo = pHH_lo;
+            if (next_norm) { g.norm_w = next_norm; g.norm_hi = pXN_hi; g.norm_lo = pXN_lo; g.norm_eps = cfg.eps; }
             if (!launch_gemm(g, epi, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
         };
         // row-parallel projection + residual into xb; TP: partial sums over this rank's K slice in yb (rank 0 carries the
         // residual), one all-reduce for all nb rows -- the arrangement of rp above
-        auto gmr = [&](const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, int K) {
-            if (!rccl) { gm(GEPI_RESADD, A_hi, A_lo, W, xb, H, H, K); return; }
+        auto gmr = [&](const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, int K, const float* next_norm = nullptr) {
+            if (!rccl) { gm(GEPI_RESADD, A_hi, A_lo, W, xb, H, H, K, next_norm); return; }
+            if (next_norm) throw CmError(CM_ERR_INVALID, "internal: next_norm under tensor parallelism");
             if (rank == 0 || rccl->fake) {
                 CM_HIP(hipMemcpyAsync(yb, xb, (size_t)nb * H * sizeof(float), hipMemcpyDeviceToDevice, s));
                 gm(GEPI_RESADD, A_hi, A_lo, W, yb, H, H, K);
@@ -1600,6 +1604,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             }
             rccl->all_reduce_sum_f32(yb, xb, (size_t)nb * H, s);
         };
+        // large groups on the GEMM path: the RMSNorm in front of a projection is written by the split-K reduction of the projection
+        // BEFORE it (o_proj / out_proj -> ln2, down_proj -> the next layer's ln1): 2 launches less per layer
+        const bool fuse_norm = gemm_b && !quantized && !rccl;
+        bool xn_ready = false;                                      // pXN already holds this layer's input norm
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
             if (!w.full) {
@@ -1612,7 +1620,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     g.ldx = H; g.ldy = ldq; g.n_seq = nb; g.eps = cfg.eps;
                     launch_gemvb(PRO_RMSNORM, EPI_STORE, g, gemvb_grid(g.N, g.K, num_cu), s);
                 } else if (gemm_b) {
-                    launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+                    if (!xn_ready) launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
                     gm(GEPI_STORE, pXN_hi, pXN_lo, w.in_proj, qkvb, ldq, in_proj_pad, H);      // (rows padded to 128 with zero weights)
                 } else
                 gb(PRO_RMSNORM, EPI_STORE, w.in_proj, xb, H, w.ln1, qkvb, ldq, in_proj_rows, H);
@@ -1627,12 +1635,12 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (quantized) qrp(w.q_out_proj, attnb, (int)at_cols);
                 else if (gemm_b) {
                     launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, cfg.value_dim(), s);
-                    gmr(pAT_hi, pAT_lo, w.out_proj, cfg.value_dim());
+                    gmr(pAT_hi, pAT_lo, w.out_proj, cfg.value_dim(), fuse_norm ? w.ln2 : nullptr);
                 } else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
                 if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
                 else if (gemm_b) {
-                    launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+                    if (!xn_ready) launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
                     gm(GEPI_STORE, pXN_hi, pXN_lo, w.qkv, qkvb, ldq, qkv_rows, H);
                 } else gb(PRO_RMSNORM, EPI_STORE, w.qkv, xb, H, w.ln1, qkvb, ldq, qkv_rows, H);
                 AttnDecArgs a{};
@@ -1656,15 +1664,20 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 const bool full_b = Hkv_l * nb >= 2 * num_cu;
                 const int64_t mf_min = full_b && attn_mfma_min > 0 ? std::min<int64_t>(attn_mfma_min, attn_mfma_min_batch) : attn_mfma_min;
                 const bool mf = mf_min > 0 && longest >= mf_min && kv_mode != KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
+                // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
+                const int ns_b = mf ? std::max(attn_batch_ns_min, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)))
+                                    : (attn_splits_force ? attn_splits_force : std::max(attn_batch_ns_min, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))));
+                // one split per sequence: the kernel normalises itself (no combine launch) and, in front of the o_proj GEMM of a large
+                // group, writes the bf16 hi + lo planes the GEMM reads (no split_rows2d launch either)
+                const bool planes = gemm_b && !quantized && attn_decode_single_split(ns_b, D);
+                if (planes) { a.out1_hi = pAT_hi; a.out1_lo = pAT_lo; a.out1_cols = Hq_l * D; }
                 if (mf) {
-                    // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
-                    const int ns_b = std::max(attn_batch_ns_min, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)));
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                } else if (!launch_attn_decode(a, D, nrep, attn_splits_force ? attn_splits_force : std::max(attn_batch_ns_min, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))), kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                } else if (!launch_attn_decode(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols);
                 else if (gemm_b) {
-                    launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);
-                    gmr(pAT_hi, pAT_lo, w.o, Hq_l * D);
+                    if (!planes) launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);
+                    gmr(pAT_hi, pAT_lo, w.o, Hq_l * D, fuse_norm ? w.ln2 : nullptr);
                 } else rp(w.o, attnb, (int)at_cols, Hq_l * D);
                 }
             }
@@ -1680,9 +1693,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 continue;
             }
             if (gemm_b) {
-                launch_rmsnorm_rows(xb, w.ln2, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
+                if (!fuse_norm) launch_rmsnorm_rows(xb, w.ln2, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
                 gm(GEPI_SILUMUL, pXN_hi, pXN_lo, w.gate_up, nullptr, 0, 2 * I_l, H);         // -> pHH_hi / pHH_lo
-                gmr(pHH_hi, pHH_lo, w.down, I_l);
+                // (the next layer's input norm rides on down_proj's reduction launch)
+                xn_ready = fuse_norm && li + 1 < cfg.L;
+                gmr(pHH_hi, pHH_lo, w.down, I_l, xn_ready ? layers[(size_t)li + 1].ln1 : nullptr);
                 continue;
             }
             gb(PRO_RMSNORM, EPI_SILUMUL, w.gate_up, xb, H, w.ln2, hbb, I_l, 2 * I_l, H);
