@@ -694,15 +694,29 @@ void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(add_rows_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, x, y, n4);
 }
 // second half of a split-K GEMM: thread = 4 consecutive columns of one row; partials added in the order ks = 0, 1, ...
-template <int EPI>
+// KS = the split when it is 2, 4 or 8 (the KS slices of an element are then independent requests; as a run-time loop every slice
+// is one L2 round trip behind the other), 0: any
+template <int EPI, int KS>
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs a) {
     const size_t n4 = (size_t)a.N / 4, total = (size_t)a.M * n4;
+    const size_t slice = (size_t)a.M * a.N;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
         const int m = (int)(t / n4), n = (int)(t % n4) * 4;
-        f32x4 v = *(const f32x4*)(a.ws + (size_t)m * a.N + n);
-        for (int k = 1; k < a.ksplit; ++k) {
-            const f32x4 p = *(const f32x4*)(a.ws + ((size_t)k * a.M + m) * a.N + n);
-            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        const float* p0 = a.ws + (size_t)m * a.N + n;
+        f32x4 v;
+        if (KS > 0) {
+            f32x4 p[KS > 0 ? KS : 1];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) p[k] = *(const f32x4*)(p0 + (size_t)k * slice);
+            v = p[0];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) { v[0] += p[k][0]; v[1] += p[k][1]; v[2] += p[k][2]; v[3] += p[k][3]; }
+        } else {
+            v = *(const f32x4*)p0;
+            for (int k = 1; k < a.ksplit; ++k) {
+                const f32x4 p = *(const f32x4*)(p0 + (size_t)k * slice);
+                v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+            }
         }
         if (a.bias != nullptr) {
             const f32x4 b = *(const f32x4*)(a.bias + n);
@@ -734,17 +748,33 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs a) {
 }
 
 // gemm_splitk_epilogue_kernel<GEPI_RESADD> + rmsnorm_rows_kernel in one launch (GemmArgs::norm_w): one block per row, the thread ->
-// column map and the order of every sum are those of the two kernels it replaces, so the row of C and the planes are bit-equal
+// column map and the order of every sum are those of the two kernels it replaces, so the row of C and the planes are bit-equal.
+// KS = the split (2, 4, 8; 0: any, a run-time loop): the KS partial loads of a chunk are independent requests -- as a run-time loop
+// the first version paid one L2 round trip per slice (12 us per launch, as much as the two launches it replaced).
+template <int KS>
 __global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     float* cr = a.C + (size_t)m * a.ldc;
+    const size_t slice = (size_t)a.M * a.N;
     float ss = 0.f;
+#pragma unroll 2
     for (int n = tid * 4; n < a.N; n += 1024) {
-        f32x4 v = *(const f32x4*)(a.ws + (size_t)m * a.N + n);
-        for (int k = 1; k < a.ksplit; ++k) {
-            const f32x4 p = *(const f32x4*)(a.ws + ((size_t)k * a.M + m) * a.N + n);
-            v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+        const float* p0 = a.ws + (size_t)m * a.N + n;
+        f32x4 v;
+        if (KS > 0) {
+            f32x4 p[KS > 0 ? KS : 1];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) p[k] = *(const f32x4*)(p0 + (size_t)k * slice);
+            v = p[0];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) { v[0] += p[k][0]; v[1] += p[k][1]; v[2] += p[k][2]; v[3] += p[k][3]; }
+        } else {
+            v = *(const f32x4*)p0;
+            for (int k = 1; k < a.ksplit; ++k) {
+                const f32x4 p = *(const f32x4*)(p0 + (size_t)k * slice);
+                v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+            }
         }
         if (a.bias != nullptr) {
             const f32x4 b = *(const f32x4*)(a.bias + n);
@@ -759,12 +789,19 @@ __global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     const float r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)a.N + a.norm_eps);
+#pragma unroll 2
     for (int n = tid * 4; n < a.N; n += 1024) {
         const f32x4 c = *(const f32x4*)(cr + n);                  // (this thread's own stores)
         const f32x4 ww = *(const f32x4*)(a.norm_w + n);
         const float o[4] = {c[0] * r * ww[0], c[1] * r * ww[1], c[2] * r * ww[2], c[3] * r * ww[3]};
         split_store4(a.norm_hi, a.norm_lo, (size_t)m * a.N + n, o);
     }
+}
+static void launch_splitk_resadd_norm(const GemmArgs& a, hipStream_t s) {
+    if (a.ksplit == 2) hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<2>, dim3(a.M), dim3(256), 0, s, a);
+    else if (a.ksplit == 4) hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<4>, dim3(a.M), dim3(256), 0, s, a);
+    else if (a.ksplit == 8) hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<8>, dim3(a.M), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<0>, dim3(a.M), dim3(256), 0, s, a);
 }
 
 // split factor for a GEMM of `tiles` output tiles and nk k-tiles: only when the tiles alone leave the chip mostly idle
@@ -774,6 +811,14 @@ static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
     int S = 1;
     while (S < 8 && tiles * (S * 2) <= ksplit_cap && nk % (S * 2 * 4) == 0 && nk / (S * 2) >= 8 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
     return S;
+}
+
+template <int EPI>
+static void launch_splitk_epilogue(const GemmArgs& a, int eb, hipStream_t s) {
+    if (a.ksplit == 2) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<EPI, 2>), dim3(eb), dim3(256), 0, s, a);
+    else if (a.ksplit == 4) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<EPI, 4>), dim3(eb), dim3(256), 0, s, a);
+    else if (a.ksplit == 8) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<EPI, 8>), dim3(eb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<EPI, 0>), dim3(eb), dim3(256), 0, s, a);
 }
 
 // GemmArgs::norm_w can ride on the split-K reduction launch (CM_GEMM_NORM_FUSED = 0: always the separate rmsnorm_rows launch, A/B)
@@ -820,11 +865,11 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     if (!launch_gemm256(a, epi, best_bn, s)) return false;
     if (best_ks > 1) {
         const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
-        if (epi == GEPI_STORE) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_STORE>), dim3(eb), dim3(256), 0, s, a);
-        else if (epi == GEPI_RESADD && norm_fused(a)) { hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel, dim3(a.M), dim3(256), 0, s, a); a.norm_w = nullptr; }
-        else if (epi == GEPI_RESADD) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_RESADD>), dim3(eb), dim3(256), 0, s, a);
-        else if (epi == GEPI_ACT_SPLIT) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_ACT_SPLIT>), dim3(eb), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_SILUMUL>), dim3(eb), dim3(256), 0, s, a);
+        if (epi == GEPI_STORE) launch_splitk_epilogue<GEPI_STORE>(a, eb, s);
+        else if (epi == GEPI_RESADD && norm_fused(a)) { launch_splitk_resadd_norm(a, s); a.norm_w = nullptr; }
+        else if (epi == GEPI_RESADD) launch_splitk_epilogue<GEPI_RESADD>(a, eb, s);
+        else if (epi == GEPI_ACT_SPLIT) launch_splitk_epilogue<GEPI_ACT_SPLIT>(a, eb, s);
+        else launch_splitk_epilogue<GEPI_SILUMUL>(a, eb, s);
     }
     return true;
 }
@@ -874,11 +919,11 @@ static bool launch_gemm_inner(GemmArgs& a, int epi, hipStream_t s) {
         if (split) hipLaunchKernelGGL((gemm_bf16_kernel<2, GEPI_PARTIAL, 128>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_bf16_kernel<1, GEPI_PARTIAL, 128>), dim3(tiles * a.ksplit), dim3(256), 0, s, a);
         const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
-        if (epi == GEPI_STORE) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_STORE>), dim3(eb), dim3(256), 0, s, a);
-        else if (epi == GEPI_RESADD && norm_fused(a)) { hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel, dim3(a.M), dim3(256), 0, s, a); a.norm_w = nullptr; }
-        else if (epi == GEPI_RESADD) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_RESADD>), dim3(eb), dim3(256), 0, s, a);
-        else if (epi == GEPI_ACT_SPLIT) hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_ACT_SPLIT>), dim3(eb), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_splitk_epilogue_kernel<GEPI_SILUMUL>), dim3(eb), dim3(256), 0, s, a);
+        if (epi == GEPI_STORE) launch_splitk_epilogue<GEPI_STORE>(a, eb, s);
+        else if (epi == GEPI_RESADD && norm_fused(a)) { launch_splitk_resadd_norm(a, s); a.norm_w = nullptr; }
+        else if (epi == GEPI_RESADD) launch_splitk_epilogue<GEPI_RESADD>(a, eb, s);
+        else if (epi == GEPI_ACT_SPLIT) launch_splitk_epilogue<GEPI_ACT_SPLIT>(a, eb, s);
+        else launch_splitk_epilogue<GEPI_SILUMUL>(a, eb, s);
         return true;
     }
 #define CM_GEMM(SP, EP) hipLaunchKernelGGL((gemm_bf16_kernel<SP, EP, 128>), dim3(tiles), dim3(256), 0, s, a)
