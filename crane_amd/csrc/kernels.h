@@ -125,6 +125,7 @@ struct GemmArgs {
     // GEMM (rmsnorm_rows_kernel's arithmetic).  Fused into the split-K reduction launch when the GEMM splits K (a large decode
     // group: one launch less per projection), a separate rmsnorm_rows launch otherwise -- launch_gemm does either.
     const float* norm_w = nullptr;
+    const float* norm_b = nullptr;   // non-null: LayerNorm with bias (layernorm_rows_kernel's arithmetic, the vision tower) instead of RMSNorm
     uint16_t* norm_hi = nullptr;
     uint16_t* norm_lo = nullptr;
     float norm_eps = 0.f;

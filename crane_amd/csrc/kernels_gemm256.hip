@@ -310,12 +310,12 @@ bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     const int bm = gemm256_rows(split);
     const int blocks = ((a.M + bm - 1) / bm) * (a.N / bn) * a.ksplit;
     const int e = a.ksplit > 1 ? (int)GEPI_PARTIAL : epi;
-    // three weight stages (WST = 3): parity-mode tiles of 256 columns (160 KB of LDS); by default for one-m-tile launches (decode
+    // three weight stages (WST = 3): parity-mode tiles (160 KB of LDS at 256 columns, 136 KB at 192); by default for one-m-tile launches (decode
     // groups: the weights stream from HBM), CM_GEMM256_WST = 2 never, 3 always (A/B)
     static const int wst_env = getenv("CM_GEMM256_WST") ? atoi(getenv("CM_GEMM256_WST")) : 0;
-    const bool w3 = split && bn == 256 && (wst_env == 3 || (wst_env == 0 && a.M <= bm)) && a.K / TBK / a.ksplit >= 3;
+    const bool w3 = split && (wst_env == 3 || (wst_env == 0 && a.M <= bm)) && a.K / TBK / a.ksplit >= 3;
 #define CM_G256(SP, EP) do { if (bn == 256) { if (SP == 2 && w3) launch_one<2, EP, 256, 3>(a, blocks, s); else launch_one<SP, EP, 256>(a, blocks, s); } \
-                             else launch_one<SP, EP, 192>(a, blocks, s); } while (0)
+                             else { if (SP == 2 && w3) launch_one<2, EP, 192, 3>(a, blocks, s); else launch_one<SP, EP, 192>(a, blocks, s); } } while (0)
 #define CM_G256_EPI(SP) do { if (e == GEPI_STORE) CM_G256(SP, GEPI_STORE); else if (e == GEPI_RESADD) CM_G256(SP, GEPI_RESADD); \
         else if (e == GEPI_ACT_SPLIT) CM_G256(SP, GEPI_ACT_SPLIT); else if (e == GEPI_SILUMUL) CM_G256(SP, GEPI_SILUMUL); \
         else CM_G256(SP, GEPI_PARTIAL); } while (0)

@@ -751,13 +751,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs a) {
 // column map and the order of every sum are those of the two kernels it replaces, so the row of C and the planes are bit-equal.
 // KS = the split (2, 4, 8; 0: any, a run-time loop): the KS partial loads of a chunk are independent requests -- as a run-time loop
 // the first version paid one L2 round trip per slice (12 us per launch, as much as the two launches it replaced).
-template <int KS>
+template <int KS, bool LN>
 __global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a) {
-    __shared__ float red[4];
+    __shared__ float red[8];
     const int m = blockIdx.x, tid = threadIdx.x;
     float* cr = a.C + (size_t)m * a.ldc;
     const size_t slice = (size_t)a.M * a.N;
-    float ss = 0.f;
+    float ss = 0.f, ls = 0.f;
 #pragma unroll 2
     for (int n = tid * 4; n < a.N; n += 1024) {
         const float* p0 = a.ws + (size_t)m * a.N + n;
@@ -783,7 +783,31 @@ __global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a
         f32x4 c = *(const f32x4*)(cr + n);
         c[0] += v[0]; c[1] += v[1]; c[2] += v[2]; c[3] += v[3];
         *(f32x4*)(cr + n) = c;
-        ss += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+        if (LN) ls += c[0] + c[1] + c[2] + c[3];
+        else ss += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+    }
+    if (LN) {                                                    // LayerNorm with bias: layernorm_rows_kernel's three passes
+        ls = wave_sum(ls);
+        if ((tid & 63) == 0) red[tid >> 6] = ls;
+        __syncthreads();
+        const float mu = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.N;
+        float q = 0.f;
+        for (int n = tid * 4; n < a.N; n += 1024) {
+            const f32x4 c = *(const f32x4*)(cr + n);              // (this thread's own stores)
+            q += (c[0] - mu) * (c[0] - mu) + (c[1] - mu) * (c[1] - mu) + (c[2] - mu) * (c[2] - mu) + (c[3] - mu) * (c[3] - mu);
+        }
+        q = wave_sum(q);
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+        __syncthreads();
+        const float r = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)a.N + a.norm_eps);
+        for (int n = tid * 4; n < a.N; n += 1024) {
+            const f32x4 c = *(const f32x4*)(cr + n);
+            const f32x4 ww = *(const f32x4*)(a.norm_w + n), bb = *(const f32x4*)(a.norm_b + n);
+            const float o[4] = {(c[0] - mu) * r * ww[0] + bb[0], (c[1] - mu) * r * ww[1] + bb[1],
+                                (c[2] - mu) * r * ww[2] + bb[2], (c[3] - mu) * r * ww[3] + bb[3]};
+            split_store4(a.norm_hi, a.norm_lo, (size_t)m * a.N + n, o);
+        }
+        return;
     }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
@@ -798,10 +822,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a
     }
 }
 static void launch_splitk_resadd_norm(const GemmArgs& a, hipStream_t s) {
-    if (a.ksplit == 2) hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<2>, dim3(a.M), dim3(256), 0, s, a);
-    else if (a.ksplit == 4) hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<4>, dim3(a.M), dim3(256), 0, s, a);
-    else if (a.ksplit == 8) hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<8>, dim3(a.M), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gemm_splitk_resadd_norm_kernel<0>, dim3(a.M), dim3(256), 0, s, a);
+#define CM_RN(LN) do { \
+    if (a.ksplit == 2) hipLaunchKernelGGL((gemm_splitk_resadd_norm_kernel<2, LN>), dim3(a.M), dim3(256), 0, s, a); \
+    else if (a.ksplit == 4) hipLaunchKernelGGL((gemm_splitk_resadd_norm_kernel<4, LN>), dim3(a.M), dim3(256), 0, s, a); \
+    else if (a.ksplit == 8) hipLaunchKernelGGL((gemm_splitk_resadd_norm_kernel<8, LN>), dim3(a.M), dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((gemm_splitk_resadd_norm_kernel<0, LN>), dim3(a.M), dim3(256), 0, s, a); } while (0)
+    if (a.norm_b != nullptr) CM_RN(true); else CM_RN(false);
+#undef CM_RN
 }
 
 // split factor for a GEMM of `tiles` output tiles and nk k-tiles: only when the tiles alone leave the chip mostly idle
@@ -881,7 +908,10 @@ bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     if (a.norm_w != nullptr && (epi != GEPI_RESADD || a.ldc != a.N)) return false;
     if (!launch_gemm_inner(a, epi, s)) return false;
     // the planes of RMSNorm(C) were not written by the split-K reduction (no split, or switched off): the row kernel
-    if (a.norm_w != nullptr) launch_rmsnorm_rows(a.C, a.norm_w, a.norm_hi, a.norm_lo, a.M, a.N, a.norm_eps, s);
+    if (a.norm_w != nullptr) {
+        if (a.norm_b != nullptr) launch_layernorm_rows(a.C, a.norm_w, a.norm_b, a.norm_hi, a.norm_lo, a.M, a.N, a.norm_eps, s);
+        else launch_rmsnorm_rows(a.C, a.norm_w, a.norm_hi, a.norm_lo, a.M, a.N, a.norm_eps, s);
+    }
     return true;
 }
 static bool launch_gemm_inner(GemmArgs& a, int epi, hipStream_t s) {

@@ -111,12 +111,15 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     if (!v_ev0) { CM_HIP(hipEventCreate(&v_ev0)); CM_HIP(hipEventCreate(&v_ev1)); }
     CM_HIP(hipEventRecord(v_ev0, s));
 
+    // nw / nb (GEPI_RESADD into vX): LayerNorm(vX) with these weights -> vA_hi / vA_lo, the A operand of the NEXT projection, written by
+    // the GEMM's split-K reduction launch (GemmArgs::norm_w) -- the launch_layernorm_rows of the next sub-block
     auto gemm = [&](const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* W, const float* bias, int Mrows, int Ncols, int K,
-                    int epi, float* C, uint16_t* h_hi, uint16_t* h_lo, int act) {
+                    int epi, float* C, uint16_t* h_hi, uint16_t* h_lo, int act, const float* nw = nullptr, const float* nb = nullptr) {
         GemmArgs g{};
         g.ws = pWS; g.ws_floats = pWS ? gemm_ws_floats : 0;      // split-K: at 784 patches a GEMM has 56-224 output tiles for 256 CUs
         g.A_hi = a_hi; g.A_lo = a_lo; g.W = W; g.bias = bias; g.M = Mrows; g.N = Ncols; g.K = K; g.C = C; g.ldc = Ncols;
         g.H_hi = h_hi; g.H_lo = h_lo; g.act = act;
+        if (nw) { g.norm_w = nw; g.norm_b = nb; g.norm_hi = vA_hi; g.norm_lo = vA_lo; g.norm_eps = 1e-6f; }
         if (!launch_gemm(g, epi, s)) throw CmError(CM_ERR_UNSUPPORTED, "vision GEMM shape (N % 128, K % 32)");
     };
     // patch embed (Conv3d == linear over the flattened patch) + bias, + pos embed
@@ -124,9 +127,10 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
     gemm(vA_hi, vA_lo, vw.patch_w, vw.patch_b, N, VH, vcfg.patch_dim(), GEPI_STORE, vX, nullptr, nullptr, 0);
     launch_pos_embed_add(vX, vw.pos_table, vIdx, vW4, N, VH, s);
     const float scale = (float)(1.0 / std::sqrt((double)hd));
+    bool n1_ready = false;                                        // vA already holds the LayerNorm the next projection reads
     for (int li = 0; li < vcfg.depth; ++li) {
         const VisionBlockW& b = vw.blocks[(size_t)li];
-        launch_layernorm_rows(vX, b.n1w, b.n1b, vA_hi, vA_lo, N, VH, 1e-6f, s);
+        if (!n1_ready) launch_layernorm_rows(vX, b.n1w, b.n1b, vA_hi, vA_lo, N, VH, 1e-6f, s);
         gemm(vA_hi, vA_lo, b.qkv_w, b.qkv_b, N, 3 * VH, VH, GEPI_STORE, vQKV, nullptr, nullptr, 0);
         launch_vit_rope_kv(vQKV, vCos, vSin, vQ_hi, vQ_lo, vK, vV, vkv_lo_off, N, heads, scale, s);
         for (auto& fr : frames) {                                  // full attention inside each frame (vision.rs:145-172)
@@ -140,10 +144,16 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
             at.ksplit = std::max(1, std::min(vit_ksplit, (at.S + 127) / 128)); at.part_o = vPartO; at.part_ml = vPartML;
             launch_attn_prefill(at, 64, KV_BF16X2, s);
         }
-        gemm(vB_hi, vB_lo, b.proj_w, b.proj_b, N, VH, VH, GEPI_RESADD, vX, nullptr, nullptr, 0);
-        launch_layernorm_rows(vX, b.n2w, b.n2b, vA_hi, vA_lo, N, VH, 1e-6f, s);
+        gemm(vB_hi, vB_lo, b.proj_w, b.proj_b, N, VH, VH, GEPI_RESADD, vX, nullptr, nullptr, 0, b.n2w, b.n2b);      // + norm2 -> vA
         gemm(vA_hi, vA_lo, b.fc1_w, b.fc1_b, N, vcfg.inter, VH, GEPI_ACT_SPLIT, nullptr, vB_hi, vB_lo, vcfg.act);
-        gemm(vB_hi, vB_lo, b.fc2_w, b.fc2_b, N, VH, vcfg.inter, GEPI_RESADD, vX, nullptr, nullptr, 0);
+        // fc2 + the NEXT norm over vX rows (the next block's norm1, the merger's norm after the last block) -- unless a DeepStack
+        // tap of this layer needs vA for its own (regrouped-row) LayerNorm first
+        bool tap = false;
+        for (size_t k = 0; k < vcfg.deepstack.size(); ++k) tap = tap || vcfg.deepstack[k] == li;
+        const bool last = li + 1 == vcfg.depth;
+        n1_ready = !tap;
+        gemm(vB_hi, vB_lo, b.fc2_w, b.fc2_b, N, VH, vcfg.inter, GEPI_RESADD, vX, nullptr, nullptr, 0,
+             tap ? nullptr : (last ? vw.mn_w : vw.blocks[(size_t)li + 1].n1w), tap ? nullptr : (last ? vw.mn_b : vw.blocks[(size_t)li + 1].n1b));
         // DeepStack tap (qwen3_vl/vision.rs:572-579): PatchMerger with the LayerNorm over the regrouped 4 x hidden row
         // (use_postshuffle_norm, :236-276; the regrouping is free in merge-block-major order)
         for (size_t k = 0; k < vcfg.deepstack.size(); ++k) {
@@ -156,7 +166,7 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
         }
     }
     // PatchMerger (vision.rs:254-278): LayerNorm over hidden, rows regrouped 4 -> 1 (free: block-major order)
-    launch_layernorm_rows(vX, vw.mn_w, vw.mn_b, vA_hi, vA_lo, N, VH, 1e-6f, s);
+    if (!n1_ready) launch_layernorm_rows(vX, vw.mn_w, vw.mn_b, vA_hi, vA_lo, N, VH, 1e-6f, s);
     const int G = N / M;
     gemm(vA_hi, vA_lo, vw.mfc1_w, vw.mfc1_b, G, VH * M, VH * M, GEPI_ACT_SPLIT, nullptr, vB_hi, vB_lo, vcfg.merger_act);
     gemm(vB_hi, vB_lo, vw.mfc2_w, vw.mfc2_b, G, vcfg.out_hidden, VH * M, GEPI_STORE, vFeat, nullptr, nullptr, 0);
