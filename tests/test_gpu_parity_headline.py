@@ -128,6 +128,40 @@ def test_large_decode_groups_equal_the_sequence_stepped_alone(nseq):
         m.close()
 
 
+@pytest.mark.parametrize("name,nseq,ctx0", [("qwen3-8b-2l", 128, 66), ("qwen3-8b-2l", 96, 70), ("qwen3.5-0.8b", 128, 65)])
+def test_large_decode_groups_at_longer_contexts_and_their_fused_launches(name, nseq, ctx0):
+    """A decode round of a large group from 64 tokens of context on: the matrix-core flash-decode kernel with ONE token split per
+    sequence writes the normalised (Qwen3.5: gated) output as the o_proj GEMM's bf16 hi + lo planes itself (AttnDecArgs::out1, no
+    combine / split_rows2d launch) and the RMSNorm in front of the next projection rides on the split-K reduction launch
+    (GemmArgs::norm_w).  Dense and hybrid family; two rounds (the second reads the K/V row and the recurrent state the first
+    wrote); every row against the same sequence stepped alone from a fork."""
+    cfg = dict(configs.get_config(name))
+    if cfg.get("num_hidden_layers", 0) > 4:
+        cfg["num_hidden_layers"] = 4                              # (the hybrid family: 3 Gated-Delta-Net layers + 1 attention layer)
+        if "layer_types" in cfg: cfg["layer_types"] = cfg["layer_types"][:4]
+    V = cfg["vocab_size"]
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, max_seqs=2 * nseq + 2)
+    try:
+        seqs, twins, lens = [], [], []
+        for i in range(nseq):
+            n = ctx0 + (5 * i) % 23
+            s_ = m.seq_alloc()
+            m.seq_forward(s_, [(13 * i + 7 * k + 3) % V for k in range(n)], 0, want_logits=False)
+            seqs.append(s_); twins.append(m.seq_fork(s_)); lens.append(n)
+        toks = [(5 + 3 * i) % V for i in range(nseq)]
+        for rnd in range(2):
+            lg, greedy = m.step_batch_decode(seqs, toks)
+            nxt = []
+            for i in range(nseq):
+                ref, _ = m.seq_forward(twins[i], [toks[i]], lens[i] + rnd)
+                assert rel(lg[i, 0], ref.reshape(-1)) < 1e-4, (rnd, i, rel(lg[i, 0], ref.reshape(-1)))
+                assert int(greedy[i]) == int(lg[i, 0].argmax())
+                nxt.append(int(greedy[i]))
+            toks = nxt
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("split", [0, 1])
 def test_wide_gemm_kernel_is_bit_equal_to_the_128_row_kernel(split):
     """The 256-row LDS-DMA GEMM (kernels_gemm256.hip: global_load_lds tiles, source-side bank swizzle, three LDS stages behind a
