@@ -1080,9 +1080,17 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     hipStream_t s = stream;
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     const bool sp2 = prefill_split2;
+    // the RMSNorm in front of a projection is written by the split-K reduction launch of the row-parallel projection before it when
+    // that GEMM splits K (GemmArgs::norm_w; launch_gemm runs the row kernel itself when it does not): o_proj / out_proj -> ln2,
+    // down_proj -> the next layer's ln1 (not under TP: the norm follows the all-reduce; not across a DeepStack injection)
+    auto next_norm = [&](GemmArgs& ga, const float* nw) {
+        ga.norm_w = nw; ga.norm_hi = pXN_hi; ga.norm_lo = sp2 ? pXN_lo : nullptr; ga.norm_eps = cfg.eps;
+    };
+    bool xn_ready = false;
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
-        launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+        if (!xn_ready) launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+        xn_ready = false;
         GemmArgs g{};
         g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         if (!w.full) {
@@ -1123,7 +1131,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
             if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
-            if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+            if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
                 rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
@@ -1195,14 +1203,14 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pAT_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 2)) ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
         if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
-        if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+        if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
         else {
             g.C = pY; launch_gemm(g, GEPI_STORE, s);
             rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
             launch_add_rows(pX, pY, (size_t)S * H, s);
         }
         }   // full-attention layer
-        launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+        if (rccl) launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 4)) ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
         if (quantized) {
@@ -1215,7 +1223,12 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pHH_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 8)) ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
         if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
-        if (!rccl) { g.C = pX; launch_gemm(g, GEPI_RESADD, s); }
+        if (!rccl) {
+            g.C = pX;
+            xn_ready = li + 1 < cfg.L && !(li < deep_layers && splice_map_dev != nullptr);
+            if (xn_ready) next_norm(g, layers[(size_t)li + 1].ln1);
+            launch_gemm(g, GEPI_RESADD, s);
+        }
         else {
             g.C = pY; launch_gemm(g, GEPI_STORE, s);
             rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
