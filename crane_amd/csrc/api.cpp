@@ -527,6 +527,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         else if (k == "gdn_defer_norm") { mm.gdn_defer_norm = value != 0; mm.drop_graphs(); }
         else if (k == "tp_graph") { mm.tp_graph = value != 0; mm.drop_graphs(); }      // CM_TP_GRAPH: RCCL collectives captured into the decode graph
         else if (k == "lm_head_gemm_min") mm.lm_head_gemm_min = (int)std::max<long long>(0, value);
+        else if (k == "q_gemm_min") mm.q_gemm_min = (int)std::max<long long>(0, value);
         else if (k == "quant_act_int") mm.quant_act_int = value != 0;          // CM_QUANT_ACT: 1 = ggml vec_dot (integer) semantics, 0 = f32 activations
         else if (k == "vision_merger_gelu") mm.vcfg.merger_act = value == 2 ? 2 : 1;   // CM_VISION_MERGER_GELU: 1 tanh form (reference), 2 erf (HF)
         else if (k == "engine") { mm.drop_graphs(); mm.engine_on = value > 0 && mm.engine_capable; }

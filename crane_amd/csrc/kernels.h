@@ -360,6 +360,19 @@ struct GemvQBArgs {
     int n_seq, ldx, ldy, idx_base;
     float eps;
 };
+// decode groups on the int8 matrix cores (kernels_quant_gemm.hip): QFMT_Q8_0-layout weights x Q8_0-quantised activation rows
+constexpr int QGEMM_MAXM = 128;
+struct QGemmArgs {
+    QWeight w;
+    const signed char* xq;     // [M][K] activation codes (launch_quant_rows_q8)
+    const float* xd;           // [K / 32][QGEMM_MAXM] their block scales, transposed
+    float* ws;                 // set by launch_gemm_q8: partial slices [ksplit][M][N], or the output itself (unsplit store)
+    size_t slice;
+    int M, ksplit, ldp;
+};
+void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s);
+bool gemm_q8_ok(const QWeight& w, int M);
+bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s);
 int gemvqb_max_seqs(int fmt, int K);
 int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu);
 bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s);

@@ -265,6 +265,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
     if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, std::min((int)GEMV_MAXB, atoi(e)));
     if (const char* e = getenv("CM_LM_HEAD_GEMM_MIN")) lm_head_gemm_min = std::max(0, atoi(e));
+    if (const char* e = getenv("CM_Q_GEMM_MIN")) q_gemm_min = std::max(0, atoi(e));
     if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)GEMV_MAXB, atoi(e) / 8 * 8));
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
@@ -1397,7 +1398,18 @@ void Model::lm_head_rows(int nb, bool want_rows) {
     const int v_eff = std::max(0, std::min(V_l, cfg.V - v0));
     const size_t slab = (size_t)MAXB * lm_gridb;
     int lmg = 0;
-    if (quantized && q_lm_head.fmt != QFMT_NONE) {
+    if (quantized && q_lm_head.fmt != QFMT_NONE && !rccl && q_gemm_min > 0 && nb >= q_gemm_min && qx_codes != nullptr &&
+        gemm_q8_ok(q_lm_head.rows(0, v_eff), nb)) {
+        // large groups over a Q8_0-layout head: one int8-MFMA pass over the table (kernels_quant_gemm.hip; the rows are written in
+        // place, the table's 1187 column tiles fill the chip unsplit) + the row arg-max of the bf16 GEMM branch below
+        launch_quant_rows_q8(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s);
+        QGemmArgs qg{};
+        qg.w = q_lm_head.rows(0, v_eff); qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
+        if (!launch_gemm_q8(qg, EPI_STORE, logitsb + (size_t)rank * V_l, cfg.V, nullptr, 0, num_cu, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head shape");
+        lmg = std::min(lm_gridb, 64);
+        launch_argmax_rows(logitsb + (size_t)rank * V_l, cfg.V, v_eff, v0, pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, nb, s);
+        if (nb > GEMV_MAXB) launch_argmax_final(pmaxb + (size_t)rank * slab, pidxb + (size_t)rank * slab, lmg, stb, ring, RING - 1, 0, nb, s);
+    } else if (quantized && q_lm_head.fmt != QFMT_NONE) {
         const int cap = gemvqb_max_seqs(q_lm_head.fmt, H);
         if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: hidden size too large for the quantised batched GEMV");
         const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;
@@ -1409,6 +1421,7 @@ void Model::lm_head_rows(int nb, bool want_rows) {
             q.pmax = pmaxb + (size_t)rank * slab + (size_t)m0 * lmg; q.pidx = pidxb + (size_t)rank * slab + (size_t)m0 * lmg;
             q.idx_base = v0; q.n_seq = std::min(stepq, nb - m0); q.ldx = H; q.ldy = cfg.V; q.eps = cfg.eps;
             if (!launch_gemvqb(PRO_RMSNORM, EPI_ARGMAX, q, lmg, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head format");
+            if (nb > GEMV_MAXB && !(rccl && !rccl->fake)) launch_argmax_final(q.pmax, q.pidx, lmg, stb + m0, ring, RING - 1, 0, q.n_seq, s);
         }
     } else if (lm_head_gemm_min > 0 && nb >= lm_head_gemm_min && pXN_hi != nullptr && prefill_ok && nb <= chunk && v_eff % 128 == 0 && H % 32 == 0) {
         // Large groups: the head as ONE MFMA GEMM over the rows of the group (final RMSNorm rows as bf16 hi + lo, like the
@@ -1476,6 +1489,11 @@ void Model::ensure_batch_buffers() {
     int g = std::max(std::max(gemvb_grid(cfg.V, H, num_cu), gemvm_grid(cfg.V, H, num_cu)), gemvm_grid(cfg.V, H, num_cu, GEMV_MAXB));
     if (quantized && q_lm_head.fmt != QFMT_NONE) g = std::max(std::max(g, gemvqb_grid(q_lm_head.fmt, cfg.V, H, GEMV_MAXB, num_cu)), gemvqb_grid(q_lm_head.fmt, cfg.V, H, 8, num_cu));
     if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * I_l);
+    if (quantized) {                                    // activation rows of a decode group as Q8_0 blocks (kernels_quant_gemm.hip)
+        const size_t kmax = std::max(std::max((size_t)H, (size_t)I_l), at_cols);
+        qx_codes = (signed char*)dalloc<int>((size_t)QGEMM_MAXM * kmax / 4 + 16);
+        qx_scales = dalloc<float>((kmax / 32 + 1) * QGEMM_MAXM);
+    }
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
     lm_gridb = g;
@@ -1512,6 +1530,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         // (tensor parallelism: groups stay at GEMV_MAXB, the size the sharded lm_head's gather is laid out for)
         if (gemm_b_ok && use_mfma_gemv && !rccl) gsz = std::max(gsz, std::min<size_t>((size_t)MAXB, (size_t)chunk));
     }
+    // quantised weights in the Q8_0 layout: q_gemm_min or more sequences run their projections as ONE int8-MFMA pass over the codes
+    // for up to MAXB rows (kernels_quant_gemm.hip); tensors in other formats of the same model keep the batched GEMV in steps
+    const bool qgemm_ok = quantized && !cfg.hybrid && !rccl && q_gemm_min > 0 && n >= (size_t)q_gemm_min && qx_codes != nullptr;
+    if (qgemm_ok) { ensure_gemm_workspace(); gsz = std::max(gsz, (size_t)MAXB); }
     for (size_t g0 = 0; g0 < n; g0 += gsz) {
         const int nb = (int)std::min<size_t>(gsz, n - g0);
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
@@ -1590,7 +1612,24 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         };
         // quantised weights: one pass over the codes for all nb sequences (gemvqb: activations quantised per sequence,
         // integer dots -- row for row the arithmetic of the single-sequence step)
+        // the rows most recently quantised for the int8-MFMA path: projections that read the same input (q / k / v tensors, gate and
+        // up, in_proj and in_proj_z) share one quantiser launch; forgotten at every layer and whenever a residual is added
+        const float* qx_src = nullptr; const float* qx_nw = nullptr; int qx_K = 0;
         auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy) {
+            if (qgemm_ok && nb >= q_gemm_min && (epi == EPI_STORE || epi == EPI_RESADD || epi == EPI_SILUMUL) && gemm_q8_ok(qw, nb)) {
+                const float* nwe = pro == PRO_RMSNORM ? nw : nullptr;
+                if (qx_src != xin || qx_nw != nwe || qx_K != qw.K) {
+                    launch_quant_rows_q8(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
+                    qx_src = xin; qx_nw = nwe; qx_K = qw.K;
+                }
+                QGemmArgs qg{};
+                qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
+                if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s)) {
+                    if (epi == EPI_RESADD) qx_src = nullptr;
+                    return;
+                }
+            }
+            if (epi == EPI_RESADD) qx_src = nullptr;
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
             const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;          // 8-sequence kernels take up to 64 (L2-sharing groups of 8)
@@ -1623,6 +1662,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         bool xn_ready = false;                                      // pXN already holds this layer's input norm
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
+            qx_src = nullptr;
             if (!w.full) {
                 if (quantized) {
                     const int qz = cfg.conv_dim() + cfg.value_dim();
