@@ -12,7 +12,7 @@
 //                          weights and activations use the same map), the block scales applied on the VALU to the 16 int32 a lane
 //                          gets per (m-tile, block).  A wave owns 32 weight rows and streams them straight into registers (a
 //                          weight byte is read by exactly one wave); the activation codes (M x K bytes, L2-resident) come the
-//                          same way, their block scales for the workgroup's k range sit in LDS, transposed ([block][row]).
+//                          same way, their block scales ride along, transposed ([block][row]).
 //                          Split K over workgroups to fill the chip; f32 partials [ks][M][N];
 //   q8_splitk_epilogue   : adds the slices in order and stores / adds the residual / SiLU(gate) * up -- f32 rows, the input of the
 //                          next projection's quantiser.
@@ -23,6 +23,7 @@
 // (cm_debug_set("q_gemm_min")).  Weight layout: QFMT_Q8_0 (GGUF Q8_0 / Q4_0 / Q5_0 tensors and the ISQ modes, all widened to
 // it at load); K-quants stay on the GEMV path.
 #include <algorithm>
+#include <cstdlib>
 
 #include "dev_common.h"
 #include "kernels.h"
@@ -103,8 +104,11 @@ void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, s
 //   * weights: a lane's 8 x 16 bytes of the NEXT group and its 8 block scales (one 16-byte load) are requested while the current
 //     group is multiplied -- 8 KB per wave one group (~2 us of work) ahead; a first version with one block in flight ran 0.6 TB/s;
 //   * activation codes: the group's panel (M rows x 256 bytes) is fetched ONCE per workgroup (16 bytes x 2 MT per thread, into
-//     registers one group ahead, then into one of two LDS panels), the four waves read their fragments from there -- loaded by
-//     every wave straight from the L2 they were 4 x the weight bytes;
+//     registers one group ahead, then into one of two LDS panels, the group's block scales next to it), the four waves read their
+//     fragments from there -- loaded by every wave straight from the L2 they were 4 x the weight bytes.  78 KB of LDS at 128 rows:
+//     two workgroups per CU, one's MFMA latency under the other's scaling (the head at 128 rows: 605 -> 412 us);
+//     (measured, wrong results by construction: the same bytes as 1 KB-contiguous wave loads instead of 32 rows x 32 bytes are
+//     only 25 % faster -- the kernel is bound by the VALU work of the scaling, not by its load pattern);
 //   * scaling: 16 int32 per lane and (m-tile, block) -> f32, times dw[n] * dx[m], as packed f32 math (v_pk_mul / v_pk_fma).
 constexpr int QG = 8;
 constexpr int QROWB = QG * 32 + 16;                 // bytes of a panel row in LDS (padded: rows 16 bytes apart in the banks)
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int K = a.w.K, N = a.w.N, nkb_all = K >> 5, nkb = nkb_all / a.ksplit, ngrp = nkb / QG;
-    float* xds = (float*)qlds;                                              // [nkb][QGEMM_MAXM] block scales of the activation rows
-    unsigned char* As = qlds + (size_t)nkb * QGEMM_MAXM * sizeof(float);    // [2][32 MT][QROWB] activation codes of a group
+    float* xds = (float*)qlds;                                              // [2][QG][QGEMM_MAXM] block scales of the activation rows, per group
+    unsigned char* As = qlds + (size_t)2 * QG * QGEMM_MAXM * sizeof(float);  // [2][32 MT][QROWB] activation codes of a group
     constexpr int PANEL = MT * 32 * QROWB;
     const int tiles = N / 128;
     const int ks = (int)blockIdx.x / tiles, tn = (int)blockIdx.x % tiles;
@@ -141,10 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
     sc = *(const u32x4*)dp;
 #pragma unroll
     for (int i = 0; i < 2 * MT; ++i) areg[i] = *(const u32x4*)xsrc[i];
-    {
-        const f32x4* src = (const f32x4*)(a.xd + (size_t)kb0 * QGEMM_MAXM);
-        for (int i = tid; i < nkb * (QGEMM_MAXM / 4); i += 256) ((f32x4*)xds)[i] = src[i];
-    }
+    // (a group's scales: QG x 128 floats = one 16-byte load per thread)
+    const f32x4* xdsrc = (const f32x4*)(a.xd + (size_t)kb0 * QGEMM_MAXM) + tid;
+    f32x4 xreg = *xdsrc;
+    ((f32x4*)xds)[tid] = xreg;
 #pragma unroll
     for (int i = 0; i < 2 * MT; ++i) *(u32x4*)(As + xdst[i]) = areg[i];
     f32x2 acc[MT][8];
@@ -161,12 +165,14 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
         scn = *(const u32x4*)(dp + gn * QG);
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) areg[i] = *(const u32x4*)(xsrc[i] + (size_t)gn * QG * 32);
+        xreg = xdsrc[(size_t)gn * (QG * QGEMM_MAXM / 4)];
         const unsigned char* Ap = As + (g & 1) * PANEL;
+        const float* xg = xds + (g & 1) * (QG * QGEMM_MAXM);
 #pragma unroll
         for (int j = 0; j < QG; ++j) {
             const float dw = f16bits((sc[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
             const long wlo = (long)(((unsigned long)wv[j][1] << 32) | wv[j][0]), whi = (long)(((unsigned long)wv[j][3] << 32) | wv[j][2]);
-            const float* xr = xds + (size_t)(g * QG + j) * QGEMM_MAXM + 4 * h;
+            const float* xr = xg + j * QGEMM_MAXM + 4 * h;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const u32x4 av = *(const u32x4*)(Ap + (mt * 32 + r) * QROWB + j * 32 + 16 * h);
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
             unsigned char* An = As + ((g + 1) & 1) * PANEL;
 #pragma unroll
             for (int i = 0; i < 2 * MT; ++i) *(u32x4*)(An + xdst[i]) = areg[i];
+            ((f32x4*)(xds + ((g + 1) & 1) * (QG * QGEMM_MAXM)))[tid] = xreg;
         }
         __syncthreads();
         sc = scn;
@@ -271,13 +278,15 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     int ks = 1;
     const int mt = (a.M + 31) / 32;
     const size_t panels = (size_t)2 * mt * 32 * QROWB, lds_max = 160 * 1024;
-    auto lds_of = [&](int k) { return (size_t)(nkb_all / k) * QGEMM_MAXM * sizeof(float) + panels; };
+    auto lds_of = [&](int) { return (size_t)2 * QG * QGEMM_MAXM * sizeof(float) + panels; };
     while (ks < 16 && nkb_all % (ks * 2 * QG) == 0 && (tiles * ks < 2 * num_cu || lds_of(ks) > lds_max / 2) &&
            (size_t)(ks * 2) * a.M * N <= ws_floats) ks *= 2;
     if (lds_of(ks) > lds_max) return false;
     const bool direct = epi == EPI_STORE && ((size_t)a.M * N > ws_floats || ks == 1);
     if (direct) { ks = 1; if (lds_of(1) > lds_max) return false; a.ws = y; a.ldp = ldy; a.slice = 0; }
     else { a.ws = ws; a.ldp = N; a.slice = (size_t)a.M * N; }
+    static const int ks_env = getenv("CM_QGEMM_KS") ? atoi(getenv("CM_QGEMM_KS")) : 0;           // tuning: force the split
+    if (ks_env > 0 && !direct && nkb_all % (ks_env * QG) == 0 && (size_t)ks_env * a.M * N <= ws_floats && lds_of(ks_env) <= lds_max) ks = ks_env;
     a.ksplit = ks;
     const size_t lds = lds_of(ks);
     static DevOnce attr;

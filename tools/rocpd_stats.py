@@ -1,5 +1,7 @@
 """Per-kernel statistics from a rocprofv3 (rocpd sqlite) --kernel-trace result: calls, average / min / max duration.
-   python tools/rocpd_stats.py <results.db> [csv_out]"""
+   python tools/rocpd_stats.py <results.db> [csv_out]
+   ROCPD_BY_GRID=<substring>: kernels whose name contains it are additionally split by launch grid (one projection shape each)."""
+import os
 import sqlite3
 import sys
 
@@ -17,6 +19,15 @@ tot = sum(r[5] for r in rows)
 lines = ["kernel,calls,avg_us,min_us,max_us,total_ms,pct"]
 for n, c, a, mn, mx, t in rows:
     lines.append(f"\"{n}\",{c},{a/1e3:.3f},{mn/1e3:.3f},{mx/1e3:.3f},{t/1e6:.3f},{100*t/tot:.2f}")
+sub = os.environ.get("ROCPD_BY_GRID")
+if sub:
+    gcol = [c for c in cols if c in ("grid_size_x", "grid_x", "workgroup_count_x")]
+    if gcol:
+        q2 = f"select s.{name_col}, d.{gcol[0]}, count(*), avg(d.end - d.start), min(d.end - d.start), max(d.end - d.start) from {kd} d join {ks} s on d.kernel_id = s.id where s.{name_col} like '%{sub}%' group by s.{name_col}, d.{gcol[0]} order by 1, 2"
+        for n, g, c, a, mn, mx in cur.execute(q2):
+            lines.append(f"\"{n} grid={g}\",{c},{a/1e3:.3f},{mn/1e3:.3f},{mx/1e3:.3f},,")
+    else:
+        lines.append("# no grid column among: " + " ".join(cols))
 out = "\n".join(lines)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out + "\n")
