@@ -260,6 +260,7 @@ static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, 
     else if (ks == 2) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 2>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
     else if (ks == 4) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 4>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
     else if (ks == 8) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 8>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
+    else if (ks == 16) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 16>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
     else hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 0>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
 }
 
