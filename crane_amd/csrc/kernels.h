@@ -372,7 +372,11 @@ struct QGemmArgs {
 };
 void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s);
 bool gemm_q8_ok(const QWeight& w, int M);
-bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s);
+// `next` (EPI_RESADD / EPI_SILUMUL): the rows this GEMM writes are the next projection's input -- the reduction launch also quantises
+// them (RMSNorm with next->nw first when set), exactly as launch_quant_rows_q8 would; *fused says whether it did
+struct QNext { const float* nw; float eps; signed char* xq; float* xd; };
+bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
+                    const QNext* next = nullptr, bool* fused = nullptr);
 int gemvqb_max_seqs(int fmt, int K);
 int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu);
 bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s);

@@ -253,6 +253,100 @@ __global__ __launch_bounds__(256) void q8_splitk_epilogue_kernel(const float* __
     }
 }
 
+// The reduction + the NEXT projection's quantiser in one launch: one 256-thread block per row, thread t owns the float4 chunks
+// k4 = t + 256 j + 1024 i of the OUTPUT row like quant_rows_q8_kernel, so codes and scales are bit-equal to the two launches.
+//   EPI_RESADD : y[m][n] += sum of the slices (N columns), then RMSNorm (NORM) + Q8_0 blocks of the row
+//   EPI_SILUMUL: y[m][k] = silu(gate_k) * up_k from the interleaved columns (2 k, 2 k + 1) (N / 2 outputs), then Q8_0 blocks
+template <int EPI, int KS, bool NORM>
+__global__ __launch_bounds__(256) void q8_splitk_quant_kernel(const float* __restrict__ ws, int M, int N, int ksplit, float* __restrict__ y, int ldy,
+                                                              const float* __restrict__ nw, float eps, signed char* __restrict__ xq, float* __restrict__ xd) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, t2 = threadIdx.x, lane = t2 & 63, w2 = t2 >> 6;
+    const int Kout = EPI == EPI_SILUMUL ? N / 2 : N, n4 = Kout >> 2;
+    const size_t slice = (size_t)M * N;
+    float* yr = y + (size_t)m * ldy;
+    auto reduce4 = [&](int col) -> f32x4 {                        // 4 consecutive columns of the row, slices in order
+        const float* p0 = ws + (size_t)m * N + col;
+        f32x4 v;
+        if (KS > 0) {
+            f32x4 p[KS > 0 ? KS : 1];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) p[k] = *(const f32x4*)(p0 + (size_t)k * slice);
+            v = p[0];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) { v[0] += p[k][0]; v[1] += p[k][1]; v[2] += p[k][2]; v[3] += p[k][3]; }
+        } else {
+            v = *(const f32x4*)p0;
+            for (int k = 1; k < ksplit; ++k) {
+                const f32x4 p = *(const f32x4*)(p0 + (size_t)k * slice);
+                v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+            }
+        }
+        return v;
+    };
+    // pass 1: the row of y (what q8_splitk_epilogue_kernel writes)
+    for (int k4 = t2; k4 < n4; k4 += 256) {
+        f32x4 o;
+        if (EPI == EPI_SILUMUL) {
+            const f32x4 a0 = reduce4(8 * k4), a1 = reduce4(8 * k4 + 4);
+            o[0] = (a0[0] / (1.0f + expf(-a0[0]))) * a0[1]; o[1] = (a0[2] / (1.0f + expf(-a0[2]))) * a0[3];
+            o[2] = (a1[0] / (1.0f + expf(-a1[0]))) * a1[1]; o[3] = (a1[2] / (1.0f + expf(-a1[2]))) * a1[3];
+        } else {
+            const f32x4 v = reduce4(4 * k4), c = *(const f32x4*)(yr + 4 * k4);
+            o = (f32x4){v[0] + c[0], v[1] + c[1], v[2] + c[2], v[3] + c[3]};
+        }
+        *(f32x4*)(yr + 4 * k4) = o;
+    }
+    // pass 2 + 3: quant_rows_q8_kernel over this thread's own stores
+    float r = 1.f;
+    if (NORM) {
+        float ss = 0.f;
+        for (int kb = t2; kb < n4; kb += 1024) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (kb + 256 * j < n4) ? *(const f32x4*)(yr + ((kb + 256 * j) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (kb + 256 * j < n4) ss = fmaf(v[j][3], v[j][3], fmaf(v[j][2], v[j][2], fmaf(v[j][1], v[j][1], fmaf(v[j][0], v[j][0], ss))));
+        }
+        const float t = wave_sum(ss);
+        if (lane == 0) red[w2] = t;
+        __syncthreads();
+        r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)Kout + eps);
+    }
+    uint32_t* xqr = (uint32_t*)(xq + (size_t)m * Kout);
+    for (int kb = t2; kb < n4; kb += 1024) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k4 = kb + 256 * j;
+            if (k4 >= n4) break;
+            f32x4 xv = *(const f32x4*)(yr + (k4 << 2));
+            if (NORM) {
+                const f32x4 w = *(const f32x4*)(nw + (k4 << 2));
+                xv[0] = __fmul_rn(__fmul_rn(xv[0], r), w[0]); xv[1] = __fmul_rn(__fmul_rn(xv[1], r), w[1]);
+                xv[2] = __fmul_rn(__fmul_rn(xv[2], r), w[2]); xv[3] = __fmul_rn(__fmul_rn(xv[3], r), w[3]);
+            }
+            float am = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
+            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+            const float d = am / 127.0f;
+            const float id = d != 0.f ? 1.0f / d : 0.f;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
+            xqr[k4] = pk;
+            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * QGEMM_MAXM + m] = f16r(d);
+        }
+    }
+}
+
+template <int EPI>
+static void launch_q8_epilogue_quant(const float* ws, int M, int N, int ks, float* y, int ldy, const QNext& nx, hipStream_t s) {
+#define CM_QQ(KS_) do { if (nx.nw) hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, true>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd); \
+                        else hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, false>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd); } while (0)
+    if (ks == 1) CM_QQ(1); else if (ks == 2) CM_QQ(2); else if (ks == 4) CM_QQ(4); else if (ks == 8) CM_QQ(8); else if (ks == 16) CM_QQ(16); else CM_QQ(0);
+#undef CM_QQ
+}
+
 template <int EPI>
 static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, int ldy, hipStream_t s) {
     const int eb = (int)std::min<size_t>(((size_t)M * (N / 4) + 255) / 256, 2048);
@@ -270,8 +364,10 @@ bool gemm_q8_ok(const QWeight& w, int M) {
 
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
 // EPI_STORE with a row stride the workspace cannot hold (the vocabulary head) is written in place by an unsplit launch.
-bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s) {
+bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
+                    const QNext* next, bool* fused) {
     QGemmArgs a = a0;
+    if (fused) *fused = false;
     if (!gemm_q8_ok(a.w, a.M) || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return false;
     const int N = a.w.N, nkb_all = a.w.K >> 5, tiles = N / 128;
     // split K until the chip is full (~2 workgroups per CU), the scales of a workgroup's k range fit 64 KB of LDS and the partials
@@ -303,6 +399,16 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     else if (mt == 3) hipLaunchKernelGGL(gemm_q8_i8_kernel<3>, grid, block, lds, s, a);
     else hipLaunchKernelGGL(gemm_q8_i8_kernel<4>, grid, block, lds, s, a);
     if (direct) return true;
+    // the next projection's quantiser rides on the reduction launch (CM_QGEMM_QFUSE = 0: its own launch, A/B); the quantiser's
+    // lane map needs whole 32-blocks per 8 lanes: output rows of a multiple of 32 columns
+    static const int qfuse_env = getenv("CM_QGEMM_QFUSE") ? atoi(getenv("CM_QGEMM_QFUSE")) : 1;
+    const int kout = epi == EPI_SILUMUL ? N / 2 : N;
+    if (next != nullptr && qfuse_env != 0 && (epi == EPI_RESADD || epi == EPI_SILUMUL) && kout % 32 == 0) {
+        if (epi == EPI_RESADD) launch_q8_epilogue_quant<EPI_RESADD>(ws, a.M, N, ks, y, ldy, *next, s);
+        else launch_q8_epilogue_quant<EPI_SILUMUL>(ws, a.M, N, ks, y, ldy, *next, s);
+        if (fused) *fused = true;
+        return true;
+    }
     if (epi == EPI_STORE) launch_q8_epilogue<EPI_STORE>(ws, a.M, N, ks, y, ldy, s);
     else if (epi == EPI_RESADD) launch_q8_epilogue<EPI_RESADD>(ws, a.M, N, ks, y, ldy, s);
     else launch_q8_epilogue<EPI_SILUMUL>(ws, a.M, N, ks, y, ldy, s);

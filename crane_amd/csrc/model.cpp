@@ -1615,7 +1615,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         // the rows most recently quantised for the int8-MFMA path: projections that read the same input (q / k / v tensors, gate and
         // up, in_proj and in_proj_z) share one quantiser launch; forgotten at every layer and whenever a residual is added
         const float* qx_src = nullptr; const float* qx_nw = nullptr; int qx_K = 0;
-        auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy) {
+        // next_nw / next_plain: the rows this projection writes are the NEXT projection's input (RMSNorm weight next_nw, or no norm):
+        // the int8-MFMA path quantises them on its reduction launch (QNext)
+        auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy,
+                      const float* next_nw = nullptr, bool next_plain = false) {
             if (qgemm_ok && nb >= q_gemm_min && (epi == EPI_STORE || epi == EPI_RESADD || epi == EPI_SILUMUL) && gemm_q8_ok(qw, nb)) {
                 const float* nwe = pro == PRO_RMSNORM ? nw : nullptr;
                 if (qx_src != xin || qx_nw != nwe || qx_K != qw.K) {
@@ -1624,8 +1627,13 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 }
                 QGemmArgs qg{};
                 qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
-                if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s)) {
-                    if (epi == EPI_RESADD) qx_src = nullptr;
+                const int kout = epi == EPI_SILUMUL ? qw.N / 2 : qw.N;
+                QNext nx{next_nw, cfg.eps, qx_codes, qx_scales};
+                const bool want_next = (next_nw != nullptr || next_plain) && ldy == kout;
+                bool fused = false;
+                if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused)) {
+                    if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; }      // (the codes now hold the rows just written)
+                    else if (epi == EPI_RESADD) qx_src = nullptr;
                     return;
                 }
             }
@@ -1641,8 +1649,8 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (!launch_gemvqb(pro, epi, q, grid, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
             }
         };
-        auto qrp = [&](const QWeight& qw, const float* xin, int ldx) {        // quantised row-parallel projection + residual
-            if (!rccl) { qb(PRO_PLAIN, EPI_RESADD, qw, xin, ldx, nullptr, xb, H); return; }
+        auto qrp = [&](const QWeight& qw, const float* xin, int ldx, const float* next_nw = nullptr) {        // quantised row-parallel projection + residual
+            if (!rccl) { qb(PRO_PLAIN, EPI_RESADD, qw, xin, ldx, nullptr, xb, H, next_nw); return; }
             const bool carry = rank == 0 || rccl->fake;
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
@@ -1662,7 +1670,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         bool xn_ready = false;                                      // pXN already holds this layer's input norm
         for (int li = 0; li < cfg.L; ++li) {
             const LayerW& w = layers[(size_t)li];
-            qx_src = nullptr;
+            if (!(qx_src == xb && qx_nw == w.ln1)) qx_src = nullptr;       // (kept: the rows down_proj's reduction quantised for this layer)
             if (!w.full) {
                 if (quantized) {
                     const int qz = cfg.conv_dim() + cfg.value_dim();
@@ -1727,7 +1735,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (mf) {
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                if (quantized) qrp(w.q_o, attnb, (int)at_cols);
+                if (quantized) qrp(w.q_o, attnb, (int)at_cols, w.ln2);
                 else if (gemm_b) {
                     if (!planes) launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);
                     gmr(pAT_hi, pAT_lo, w.o, Hq_l * D, fuse_norm ? w.ln2 : nullptr);
@@ -1736,13 +1744,13 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             }
             if (quantized) {
                 if (!w.split_gate_up) {
-                    qb(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, xb, H, w.ln2, hbb, I_l);
+                    qb(PRO_RMSNORM, EPI_SILUMUL, w.q_gate_up, xb, H, w.ln2, hbb, I_l, nullptr, true);
                 } else {
                     qb(PRO_RMSNORM, EPI_STORE, w.q_gate, xb, H, w.ln2, gu_tmpb, 2 * I_l);
                     qb(PRO_RMSNORM, EPI_STORE, w.q_up, xb, H, w.ln2, gu_tmpb + I_l, 2 * I_l);
                     launch_silu_mul(gu_tmpb, gu_tmpb + I_l, hbb, I_l, s, nb, 2 * I_l, I_l);
                 }
-                qrp(w.q_down, hbb, I_l);
+                qrp(w.q_down, hbb, I_l, li + 1 < cfg.L ? layers[(size_t)li + 1].ln1 : nullptr);
                 continue;
             }
             if (gemm_b) {
