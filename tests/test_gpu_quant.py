@@ -406,3 +406,31 @@ def test_large_quantised_decode_groups_on_the_int8_matrix_cores(isq, nb):
             toks = [int(t) for t in wg]
     finally:
         m.close()
+
+
+def test_engine_over_large_quantised_groups_is_deterministic_and_close_to_the_gemv_path():
+    """The continuous-batching engine at max_running 40 over an ISQ q8_0 model at the 8B widths (2 layers): decode rounds run on the
+    int8 matrix cores (activation rows quantised once per projection input, the next input's quantiser on the reduction launch).
+    Two runs must emit identical tokens (the quantised-row memo and the tickets of the split-K reductions are per-handle state), and
+    the first tokens of every request must equal the batched-GEMV path's (q_gemm_min = 0) -- later ones may part ways at a code
+    flip, like any two equally valid roundings."""
+    from crane_amd.backend import Model
+    from crane_amd.engine import GenerationParams, InferenceEngine
+    cfg = configs.get_config("qwen3-8b-2l")
+    V = cfg["vocab_size"]
+    outs = []
+    for qmin in (25, 25, 0):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=96, isq="q8_0", max_seqs=42)
+        try:
+            m.debug_set("q_gemm_min", qmin)
+            eng = InferenceEngine(m, max_running=40)
+            ids = [eng.submit([(7 * k + 3 + 13 * i) % V for k in range(5 + i % 9)], GenerationParams.greedy(6)) for i in range(40)]
+            toks, _ = eng.run_until_idle()
+            outs.append([toks[i] for i in ids])
+            eng.close()
+        finally:
+            m.close()
+    assert outs[0] == outs[1]
+    assert all(len(t) == 6 for t in outs[0])
+    same_first = sum(1 for a, b in zip(outs[0], outs[2]) if a[0] == b[0])
+    assert same_first >= 38, same_first            # (the first generated token comes from the prompt pass: identical code path)
