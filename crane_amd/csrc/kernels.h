@@ -195,6 +195,7 @@ void launch_split_rows(const float* x, uint16_t* hi, uint16_t* lo, size_t n, hip
 void launch_split_rows2d(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int rows, int cols, hipStream_t s);   // cols % 4 == 0, ldx % 4 == 0
 void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+int gemm256_rows(bool split, int M);       // rows of that kernel's tile for an M-row launch (parity mode: 64 up to 64 rows, else 128; plain bf16: 256)
 bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s);   // kernels_gemm256.hip; a.ksplit set by the caller (launch_gemm)
 void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s);   // kvt: KV_BF16 | KV_F16 | KV_F32 (what the kernel reads)
 

@@ -49,9 +49,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_base) {
 // weight requests running two k-tiles ahead (the activation stages stay at two).  With two stages a workgroup has one 32 KB weight
 // tile in flight; 96-192 workgroups of a 128-row launch are then 3-6 MB in flight chip-wide -- about 3 TB/s at the ~2 us of a loaded
 // HBM round trip, which is what the launch measured.  The waits become counted: the newest weight requests may stay outstanding.
-template <int SPLIT, int EPI, int BN, int WST = 2>
+// BMX = 64 (round 4, parity mode): 64-row tiles for decode groups of <= 64 sequences -- half the activation bytes and half the MFMAs
+// of a 128-row tile whose upper half would be padding.
+template <int SPLIT, int EPI, int BN, int WST = 2, int BMX = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
-    constexpr int BM = SPLIT == 2 ? 128 : 256;                            // rows of a tile (two planes double the activation bytes)
+    constexpr int BM = BMX ? BMX : (SPLIT == 2 ? 128 : 256);              // rows of a tile (two planes double the activation bytes)
     constexpr int NI = BM / 32, NJ = BN / 64, WM = BM / 2, WN = BN / 4;  // per wave: NI x NJ tiles of 16 x 16
     constexpr int PLANE = BM * TBK;                                       // elements of one activation plane of a stage
     constexpr int ASTAGE = SPLIT * PLANE, WSTAGE = BN * TBK;             // elements of an activation / a weight stage
@@ -172,11 +174,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][i], bfr[s][j], acc[i][j], 0, 0, 0);
                 }
-                constexpr int PER = (NLOAD + 2 * NI - 1) / (2 * NI);         // requests per band (1; 2 * NI >= NLOAD)
+                constexpr int PER = (NLOAD + 2 * NI - 1) / (2 * NI);         // requests per band (1 with 128-row tiles; 2 with 64-row tiles)
                 const int g = (s * NI + i) * PER;
                 if (g < NLOAD) {
                     __builtin_amdgcn_sched_barrier(0);
-                    piece(g, ta, tw);
+#pragma unroll
+                    for (int p = 0; p < PER; ++p)
+                        if (g + p < NLOAD) piece(g + p, ta, tw);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -292,29 +296,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs a) {
 }
 
 // rows of a tile / dynamic LDS of an instantiation
-int gemm256_rows(bool split) { return split ? 128 : 256; }
-static size_t gemm256_lds(int split, int bn, int wst = 2) { return ((size_t)TST * split * gemm256_rows(split == 2) * TBK + (size_t)wst * bn * TBK) * 2; }
+// rows of a tile: 64 for parity-mode groups of <= 64 rows (CM_GEMM256_BM64 = 0: never, A/B)
+int gemm256_rows(bool split, int M) {
+    static const int bm64 = getenv("CM_GEMM256_BM64") ? atoi(getenv("CM_GEMM256_BM64")) : 1;
+    return split ? ((M <= 64 && bm64) ? 64 : 128) : 256;
+}
+static size_t gemm256_lds(int split, int bm, int bn, int wst = 2) { return ((size_t)TST * split * bm * TBK + (size_t)wst * bn * TBK) * 2; }
 
-template <int SPLIT, int EPI, int BN, int WST = 2>
+template <int SPLIT, int EPI, int BN, int WST = 2, int BMX = 0>
 static void launch_one(const GemmArgs& a, int blocks, hipStream_t s) {
     static DevOnce attr;
-    const size_t lds = gemm256_lds(SPLIT, BN, WST);
-    attr.run([&] { (void)hipFuncSetAttribute((const void*)gemm256_kernel<SPLIT, EPI, BN, WST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    hipLaunchKernelGGL((gemm256_kernel<SPLIT, EPI, BN, WST>), dim3(blocks), dim3(512), lds, s, a);
+    const size_t lds = gemm256_lds(SPLIT, BMX ? BMX : (SPLIT == 2 ? 128 : 256), BN, WST);
+    attr.run([&] { (void)hipFuncSetAttribute((const void*)gemm256_kernel<SPLIT, EPI, BN, WST, BMX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    hipLaunchKernelGGL((gemm256_kernel<SPLIT, EPI, BN, WST, BMX>), dim3(blocks), dim3(512), lds, s, a);
 }
 
 // a.ksplit set by the caller (1: epilogue `epi`; > 1: GEPI_PARTIAL tiles, the caller runs gemm_splitk_epilogue_kernel)
 bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s) {
     if ((bn != 256 && bn != 192) || a.N % bn != 0 || a.K % TBK != 0 || (a.K / TBK) % a.ksplit != 0) return false;
     const bool split = a.A_lo != nullptr;
-    const int bm = gemm256_rows(split);
+    const int bm = gemm256_rows(split, a.M);
     const int blocks = ((a.M + bm - 1) / bm) * (a.N / bn) * a.ksplit;
     const int e = a.ksplit > 1 ? (int)GEPI_PARTIAL : epi;
     // three weight stages (WST = 3): parity-mode tiles (160 KB of LDS at 256 columns, 136 KB at 192); by default for one-m-tile launches (decode
     // groups: the weights stream from HBM), CM_GEMM256_WST = 2 never, 3 always (A/B)
     static const int wst_env = getenv("CM_GEMM256_WST") ? atoi(getenv("CM_GEMM256_WST")) : 0;
     const bool w3 = split && (wst_env == 3 || (wst_env == 0 && a.M <= bm)) && a.K / TBK / a.ksplit >= 3;
-#define CM_G256(SP, EP) do { if (bn == 256) { if (SP == 2 && w3) launch_one<2, EP, 256, 3>(a, blocks, s); else launch_one<SP, EP, 256>(a, blocks, s); } \
+#define CM_G256(SP, EP) do { if (SP == 2 && bm == 64) { if (bn == 256) launch_one<2, EP, 256, 3, 64>(a, blocks, s); else launch_one<2, EP, 192, 3, 64>(a, blocks, s); } \
+                             else if (bn == 256) { if (SP == 2 && w3) launch_one<2, EP, 256, 3>(a, blocks, s); else launch_one<SP, EP, 256>(a, blocks, s); } \
                              else { if (SP == 2 && w3) launch_one<2, EP, 192, 3>(a, blocks, s); else launch_one<SP, EP, 192>(a, blocks, s); } } while (0)
 #define CM_G256_EPI(SP) do { if (e == GEPI_STORE) CM_G256(SP, GEPI_STORE); else if (e == GEPI_RESADD) CM_G256(SP, GEPI_RESADD); \
         else if (e == GEPI_ACT_SPLIT) CM_G256(SP, GEPI_ACT_SPLIT); else if (e == GEPI_SILUMUL) CM_G256(SP, GEPI_SILUMUL); \
