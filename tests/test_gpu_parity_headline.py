@@ -73,8 +73,9 @@ def test_prefill_1024_and_batched_step_qwen3_8b_geometry(oracle8b):
         # a decode step on top of the prefilled cache
         t = int(ref.argmax())
         assert rel(m.forward_step([t], 1024)[0, 0], c.forward([t], 1024)) < BAR
-        # short prompts (one or two m-tiles): the split-K GEMMs (partial tiles + fixed-order epilogue kernel)
-        for n_short in (100, 200):
+        # short prompts (one or two m-tiles): the split-K GEMMs (partial tiles + fixed-order epilogue kernel; 48 tokens: the 64-row
+        # tiles of the LDS-DMA kernel, gemm256_kernel<..., BMX = 64>)
+        for n_short in (48, 100, 200):
             ids_s = configs.synthetic_prompt(n_short, V)
             m.clear_kv_cache()
             got_s = m.forward_step(ids_s, 0)[0, 0]
