@@ -423,7 +423,11 @@ int cm_read_logits(cm_model* h, float* logits_out) {
 
 int cm_debug_qgemv(cm_model* h, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n) {
     if (!h || !which || !x || !y) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.debug_qgemv(layer, which, x, k, y, n); });
+    return guard(h, [&] {
+        // rank-0-only hooks would run one rank of a group into its collectives alone (a 2 s time-out, then CM_ERR_DEVICE)
+        if (h->grp) throw CmError(CM_ERR_UNSUPPORTED, "cm_debug_qgemv: not on an in-process tensor-parallel group");
+        h->m.debug_qgemv(layer, which, x, k, y, n);
+    });
 }
 
 int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
@@ -436,7 +440,10 @@ int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* token
 
 int cm_bench_kernel(cm_model* h, const char* which, size_t iters, float* ms_out, uint64_t* bytes_out) {
     if (!h || !which) return CM_ERR_INVALID;
-    return guard(h, [&] { h->m.bench_kernel(which, iters, ms_out, bytes_out); });
+    return guard(h, [&] {
+        if (h->grp) throw CmError(CM_ERR_UNSUPPORTED, "cm_bench_kernel: not on an in-process tensor-parallel group");
+        h->m.bench_kernel(which, iters, ms_out, bytes_out);
+    });
 }
 
 int cm_debug_fill_kv(cm_model* h, size_t ctx, uint64_t seed) {
@@ -461,6 +468,9 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
         const float* src = nullptr;
         size_t avail = 0;
         const std::string w = w0;
+        // (the persistent kernel never runs under tensor parallelism and the tower's debug buffers live on rank 0: no '@r' form)
+        if (mp != &h->m && (w == "engine_trace" || w.rfind("eng_", 0) == 0 || w == "vision_ms" || w == "deepstack"))
+            throw CmError(CM_ERR_INVALID, "cm_debug_read: '" + w + "' has no per-rank form");
         if (w == "engine_trace") { h->m.engine_trace(out, n); return; }
         if (w.rfind("eng_", 0) == 0) {     // value halves of a granule buffer of the persistent kernel (last writer wins)
             static const char* names[cm::ENG_NEDGE] = {"eng_x0", "eng_qkv", "eng_part", "eng_attn", "eng_x1", "eng_h"};
@@ -486,6 +496,17 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
             CM_HIP(hipStreamSynchronize(h->m.stream));
             for (size_t k = 0; k < nd; ++k)
                 CM_HIP(hipMemcpy(out + k * (n / nd), h->m.vDeep + k * h->m.deep_stride, (n / nd) * sizeof(float), hipMemcpyDeviceToHost));
+            return;
+        }
+        if (w == "q_capture_len") {        // floats recorded since cm_debug_set("q_capture", 1) (model.h)
+            if (n < 1) throw CmError(CM_ERR_RANGE, "q_capture_len: one value");
+            out[0] = (float)mp->q_cap.size();
+            return;
+        }
+        if (w == "q_capture") {            // the records; reading them clears the list
+            if (n != mp->q_cap.size()) throw CmError(CM_ERR_RANGE, "q_capture: n must be q_capture_len");
+            memcpy(out, mp->q_cap.data(), n * sizeof(float));
+            mp->q_cap.clear();
             return;
         }
         if (w == "hidden") { src = mp->x; avail = (size_t)mp->cfg.H; }
@@ -528,6 +549,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         else if (k == "tp_graph") { mm.tp_graph = value != 0; mm.drop_graphs(); }      // CM_TP_GRAPH: RCCL collectives captured into the decode graph
         else if (k == "lm_head_gemm_min") mm.lm_head_gemm_min = (int)std::max<long long>(0, value);
         else if (k == "q_gemm_min") mm.q_gemm_min = (int)std::max<long long>(0, value);
+        else if (k == "q_capture") { mm.q_capture = value != 0; mm.q_cap.clear(); }
         else if (k == "quant_act_int") mm.quant_act_int = value != 0;          // CM_QUANT_ACT: 1 = ggml vec_dot (integer) semantics, 0 = f32 activations
         else if (k == "vision_merger_gelu") mm.vcfg.merger_act = value == 2 ? 2 : 1;   // CM_VISION_MERGER_GELU: 1 tanh form (reference), 2 erf (HF)
         else if (k == "engine") { mm.drop_graphs(); mm.engine_on = value > 0 && mm.engine_capable; }

@@ -374,18 +374,19 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     // fit the workspace
     int ks = 1;
     const int mt = (a.M + 31) / 32;
-    const size_t panels = (size_t)2 * mt * 32 * QROWB, lds_max = 160 * 1024;
-    auto lds_of = [&](int) { return (size_t)2 * QG * QGEMM_MAXM * sizeof(float) + panels; };
-    while (ks < 16 && nkb_all % (ks * 2 * QG) == 0 && (tiles * ks < 2 * num_cu || lds_of(ks) > lds_max / 2) &&
-           (size_t)(ks * 2) * a.M * N <= ws_floats) ks *= 2;
-    if (lds_of(ks) > lds_max) return false;
+    // (two activation panels + two sets of block scales: independent of the split)
+    const size_t lds = (size_t)2 * QG * QGEMM_MAXM * sizeof(float) + (size_t)2 * mt * 32 * QROWB, lds_max = 160 * 1024;
+    if (lds > lds_max) return false;
+    while (ks < 16 && nkb_all % (ks * 2 * QG) == 0 && tiles * ks < 2 * num_cu && (size_t)(ks * 2) * a.M * N <= ws_floats) ks *= 2;
     const bool direct = epi == EPI_STORE && ((size_t)a.M * N > ws_floats || ks == 1);
-    if (direct) { ks = 1; if (lds_of(1) > lds_max) return false; a.ws = y; a.ldp = ldy; a.slice = 0; }
+    // the partial slices of a residual / SiLU*mul projection always go through the workspace: refuse what it cannot hold (the
+    // caller falls back to the batched GEMV) instead of writing past it
+    if (!direct && (ws == nullptr || (size_t)ks * a.M * N > ws_floats)) return false;
+    if (direct) { ks = 1; a.ws = y; a.ldp = ldy; a.slice = 0; }
     else { a.ws = ws; a.ldp = N; a.slice = (size_t)a.M * N; }
     static const int ks_env = getenv("CM_QGEMM_KS") ? atoi(getenv("CM_QGEMM_KS")) : 0;           // tuning: force the split
-    if (ks_env > 0 && !direct && nkb_all % (ks_env * QG) == 0 && (size_t)ks_env * a.M * N <= ws_floats && lds_of(ks_env) <= lds_max) ks = ks_env;
+    if (ks_env > 0 && !direct && nkb_all % (ks_env * QG) == 0 && (size_t)ks_env * a.M * N <= ws_floats) ks = ks_env;
     a.ksplit = ks;
-    const size_t lds = lds_of(ks);
     static DevOnce attr;
     attr.run([&] {
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -38,7 +38,11 @@ __global__ void __launch_bounds__(256) peer_coll_kernel(PeerCollArgs a) {
     // (seen on hardware: two ranks' 64-byte control blocks sharing one 128-byte line, ranks on one device -- a rank then
     // re-used the previous epoch and consumed the previous collective's granules without waiting)
     const uint32_t e0 = __hip_atomic_load(&a.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t e = e0 + 1u == 0u ? 1u : e0 + 1u;               // epoch of THIS collective (0 is "never written")
+    // epoch of THIS collective.  0 is "never written"; the inbox buffer is chosen by the epoch's parity, so consecutive epochs must
+    // alternate in parity ALSO at the 32-bit wrap: 0xFFFFFFFF (odd) is followed by 2 (even) -- 0 and 1 are skipped.  (1 would put
+    // two consecutive collectives into the same buffer, where a rank one collective ahead overwrites granules a slower peer has
+    // not consumed yet; cm_debug_peer_selftest with iters < 0 starts the counter at 0xFFFFFFFD and walks across the wrap.)
+    const uint32_t e = e0 + 1u == 0u ? 2u : e0 + 1u;
     const size_t par = (size_t)(e & 1u) * (size_t)a.n * a.cap;
     const int stride = (int)(gridDim.x * blockDim.x);
     const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x);

@@ -377,6 +377,10 @@ void Model::alloc_runtime() {
         if (force_cc && !id) { Rccl::unique_id(&self_id); id = &self_id; }
         // in-process group (cm_opts.tp_mode = CM_TP_IN_PROCESS): the peer-store transport, or RCCL with the group's own id --
         // ncclCommInitRank is called by all rank threads concurrently, as RCCL requires of ranks that share a process
+        // (group + RCCL: a rendezvous first -- a rank that failed while loading its shard or allocating its runtime has raised
+        // PeerShared::fail by now, and every other rank leaves here with an error instead of blocking inside ncclCommInitRank,
+        // which waits for all n ranks and cannot be released)
+        if (peer_shared && !peer_shared->use_peer) peer_shared->arrive_and_wait();
         if (peer_shared && peer_shared->use_peer) rccl->init_peer(peer_shared, rank, num_cu, stream);
         else rccl->init(tp, rank, peer_shared ? (const void*)&peer_shared->uid : id, stream, (opts.debug_flags & CM_DEBUG_TP_LOCAL) != 0);
     }
@@ -1403,6 +1407,7 @@ void Model::lm_head_rows(int nb, bool want_rows) {
         // large groups over a Q8_0-layout head: one int8-MFMA pass over the table (kernels_quant_gemm.hip; the rows are written in
         // place, the table's 1187 column tiles fill the chip unsplit) + the row arg-max of the bf16 GEMM branch below
         launch_quant_rows_q8(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s);
+        if (q_capture) q_capture_rows(nb, H);
         QGemmArgs qg{};
         qg.w = q_lm_head.rows(0, v_eff); qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
         if (!launch_gemm_q8(qg, EPI_STORE, logitsb + (size_t)rank * V_l, cfg.V, nullptr, 0, num_cu, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head shape");
@@ -1624,6 +1629,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 if (qx_src != xin || qx_nw != nwe || qx_K != qw.K) {
                     launch_quant_rows_q8(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
                     qx_src = xin; qx_nw = nwe; qx_K = qw.K;
+                    if (q_capture) q_capture_rows(nb, qw.K);
                 }
                 QGemmArgs qg{};
                 qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
@@ -1632,7 +1638,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 const bool want_next = (next_nw != nullptr || next_plain) && ldy == kout;
                 bool fused = false;
                 if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused)) {
-                    if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; }      // (the codes now hold the rows just written)
+                    if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; if (q_capture) q_capture_rows(nb, kout); }      // (the codes now hold the rows just written)
                     else if (epi == EPI_RESADD) qx_src = nullptr;
                     return;
                 }
@@ -2057,6 +2063,19 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
     if (ms) *ms = t / (float)iters;
     if (bytes) *bytes = b;
     engine_check();
+}
+
+// test hook (q_capture): the Q8_0 activation rows currently in qx_codes / qx_scales, appended to q_cap as floats
+void Model::q_capture_rows(int nb, int K) {
+    std::vector<signed char> c((size_t)nb * K);
+    std::vector<float> d((size_t)(K / 32) * QGEMM_MAXM);
+    CM_HIP(hipStreamSynchronize(stream));
+    CM_HIP(hipMemcpy(c.data(), qx_codes, c.size(), hipMemcpyDeviceToHost));
+    CM_HIP(hipMemcpy(d.data(), qx_scales, d.size() * sizeof(float), hipMemcpyDeviceToHost));
+    q_cap.push_back((float)K); q_cap.push_back((float)nb);
+    for (size_t i = 0; i < c.size(); ++i) q_cap.push_back((float)c[i]);
+    for (int m = 0; m < nb; ++m)
+        for (int b = 0; b < K / 32; ++b) q_cap.push_back(d[(size_t)b * QGEMM_MAXM + m]);
 }
 
 void Model::debug_qgemv(int layer, const std::string& which, const float* xh, size_t k, float* yh, size_t n) {

@@ -39,6 +39,12 @@ void Rccl::load() {
     p_all_reduce = (decltype(p_all_reduce))sym("ncclAllReduce");
     p_all_gather = (decltype(p_all_gather))sym("ncclAllGather");
     p_get_error_string = (decltype(p_get_error_string))sym("ncclGetErrorString");
+    p_comm_abort = (decltype(p_comm_abort))dlsym(lib, "ncclCommAbort");          // (optional)
+}
+
+void Rccl::abort_comm() {
+    void* c = comm;
+    if (c && p_comm_abort) { comm = nullptr; (void)p_comm_abort(c); }
 }
 
 #define CM_NCCL(expr)                                                                           \
@@ -113,9 +119,18 @@ void Rccl::init_peer(PeerShared* ps, int r, int num_cu, hipStream_t s) {
         p = take_parked(ps->devs[(size_t)r], bytes);
         e = p ? hipSuccess : hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
         if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained); }
-        if (e != hipSuccess) (void)hipGetLastError(); else inbox_uncached = true;
+        if (e != hipSuccess) {
+            // Coarse-grained hipMalloc memory is NOT an option between devices: a peer's posted stores polled with relaxed
+            // system-scope loads are not guaranteed to become visible there (stale granules, spurious 2 s time-outs).  Refuse;
+            // the caller can take RCCL (cm_opts.tp_collective = CM_TP_COLL_RCCL, the default on distinct devices).
+            (void)hipGetLastError();
+            throw CmError(CM_ERR_UNSUPPORTED, "peer-store collective: no uncached / fine-grained device memory for the inbox on device " +
+                          std::to_string(ps->devs[(size_t)r]) + "; use tp_collective = CM_TP_COLL_RCCL");
+        }
+        inbox_uncached = true;
+    } else {
+        e = hipMalloc(&p, bytes);           // ranks on ONE device: ordinary memory (see above)
     }
-    if (e != hipSuccess) e = hipMalloc(&p, bytes);
     if (e != hipSuccess) throw CmError(CM_ERR_OOM, "peer inbox allocation failed");
     if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess || hipMalloc((void**)&ctl, 4096) != hipSuccess ||
         hipMemsetAsync(ctl, 0, 4096, s) != hipSuccess ||

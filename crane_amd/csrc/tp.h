@@ -67,6 +67,7 @@ struct Rccl {
     int (*p_get_unique_id)(void*) = nullptr;
     int (*p_comm_init_rank)(void**, int, /*ncclUniqueId by value*/ UniqueId, int) = nullptr;
     int (*p_comm_destroy)(void*) = nullptr;
+    int (*p_comm_abort)(void*) = nullptr;   // optional symbol (ncclCommAbort): releases the group's ranks when one of them fails
     int (*p_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*p_all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*p_get_error_string)(int) = nullptr;
@@ -78,6 +79,7 @@ struct Rccl {
     void all_reduce_sum_f32(const float* send, float* recv, size_t count, hipStream_t s);
     // gathers `bytes_per_rank` from every rank into recv (rank-major); send may alias its slot
     void all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s);
+    void abort_comm();                      // RCCL transport: ncclCommAbort (callable from another thread while this rank is blocked in a collective)
     void check();                           // after a host sync: throws CM_ERR_DEVICE if a peer-store wait timed out
     static void unique_id(void* out128);
 };

@@ -29,10 +29,28 @@ TpGroup::TpGroup(int n_ranks, const int32_t* devices, int first_device, uint32_t
     static std::atomic<uint32_t> g_groups{0};
     const uint32_t gi = g_groups.fetch_add(1);
     if (const char* e = getenv("CM_TP_EPOCH_BASE")) shared.epoch_base = (uint32_t)strtoul(e, nullptr, 0) * gi * 1000003u;
+    if (shared.same_device) {
+        // Ranks that share a device need one hardware queue per rank stream: with fewer, a rank's spinning exchange kernel sits
+        // in the queue in front of the peer's kernel it waits for and every collective runs into its 2 s bound.  The HIP runtime
+        // reads GPU_MAX_HW_QUEUES (default 4) once, when it starts -- the caller has to export it before the first HIP call.
+        int hwq = 4;
+        if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hwq = atoi(e);
+        if (n > hwq)
+            throw CmError(CM_ERR_INVALID, "in-process tensor parallelism with every rank on ONE device (test mode) needs GPU_MAX_HW_QUEUES >= tp_size (" +
+                          std::to_string(n) + ") exported before the HIP runtime starts; it is " + std::to_string(hwq));
+    }
     if (!shared.use_peer) Rccl::unique_id(&shared.uid);
     errs.resize((size_t)n);
     for (int r = 1; r < n; ++r) peers.emplace_back(new Model());
-    for (int r = 1; r < n; ++r) th.emplace_back([this, r] { worker(r); });
+    // the worker threads start LAST: nothing below can throw past joinable threads (std::terminate)
+    try {
+        for (int r = 1; r < n; ++r) th.emplace_back([this, r] { worker(r); });
+    } catch (...) {
+        { std::lock_guard<std::mutex> g(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+        throw CmError(CM_ERR_DEVICE, "in-process tensor parallelism: cannot start the rank threads");
+    }
 }
 
 TpGroup::~TpGroup() {
@@ -56,7 +74,23 @@ void TpGroup::run_rank(int r, const std::function<void(int)>& f) {
     } catch (...) {
         errs[(size_t)r] = std::current_exception();
         shared.fail();
+        // RCCL transport: the other ranks may be blocked INSIDE a collective (a kernel waiting for this rank's contribution behind
+        // a hipStreamSynchronize) -- no host-side rendezvous can release that.  ncclCommAbort of every rank's communicator does; it
+        // may be called from this thread while the owner is blocked.  The group is dead afterwards (run()).
+        if (!shared.use_peer && !symmetric_error(errs[(size_t)r]))
+            for (int q = 0; q < n; ++q) {
+                Model* mq = q == 0 ? rank0 : peers[(size_t)q - 1].get();
+                if (q != r && mq && mq->rccl) mq->rccl->abort_comm();
+            }
     }
+}
+
+// errors every rank raises alike, before any exchange step: argument / range / state checks (the ranks hold identical state)
+bool TpGroup::symmetric_error(const std::exception_ptr& e) {
+    try { std::rethrow_exception(e); }
+    catch (const CmError& x) { return x.code == CM_ERR_INVALID || x.code == CM_ERR_RANGE || x.code == CM_ERR_UNSUPPORTED; }
+    catch (...) {}
+    return false;
 }
 
 void TpGroup::worker(int r) {
@@ -79,6 +113,7 @@ void TpGroup::worker(int r) {
 }
 
 void TpGroup::run(const std::function<void(int)>& f) {
+    if (dead) throw CmError(CM_ERR_DEVICE, "tensor-parallel group is dead after a rank failure (" + dead_why + "): destroy the handle and create a new one");
     {
         std::lock_guard<std::mutex> g(mu);
         for (auto& e : errs) e = nullptr;
@@ -98,6 +133,17 @@ void TpGroup::run(const std::function<void(int)>& f) {
     (void)hipSetDevice(shared.devs[0]);
     // report the ROOT cause: a rank that failed on its own, not the ranks that were released from a wait because of it
     std::exception_ptr first = nullptr, released = nullptr;
+    int n_err = 0, n_sym = 0;
+    for (auto& e : errs) if (e) { ++n_err; n_sym += symmetric_error(e) ? 1 : 0; }
+    if (n_err > 0 && !(n_err == n && n_sym == n)) {
+        dead = true;
+        for (auto& e : errs) {
+            if (!e || !dead_why.empty()) continue;
+            try { std::rethrow_exception(e); } catch (const std::exception& x) { if (std::string(x.what()).find("another rank failed") == std::string::npos) dead_why = x.what(); } catch (...) { dead_why = "unknown exception"; }
+        }
+        if (dead_why.empty()) dead_why = "a rank failed";
+        if (dead_why.size() > 160) dead_why.resize(160);
+    }
     for (auto& e : errs) {
         if (!e) continue;
         bool rel = false;
@@ -116,8 +162,9 @@ void TpGroup::run(const std::function<void(int)>& f) {
 // gathers checked on the host.  cm_debug_peer_selftest (test hook; tests/test_gpu_tp_group.py)
 namespace cm {
 long peer_selftest(int n, int device, int iters, int count) {
-    if (n < 2 || n > TP_MAX_RANKS || count < 1) throw CmError(CM_ERR_INVALID, "peer_selftest arguments");
+    if (n < 2 || n > TP_MAX_RANKS || count < 1 || iters == 0) throw CmError(CM_ERR_INVALID, "peer_selftest arguments");
     PeerShared ps;
+    if (iters < 0) { iters = -iters; ps.epoch_base = 0xFFFFFFFDu; }      // walk the epoch counter across its 32-bit wrap (kernels_tp.hip)
     ps.n = n; ps.devs.assign((size_t)n, device); ps.same_device = true; ps.use_peer = true;
     std::vector<long> bad((size_t)n, 0);
     std::vector<std::vector<float>> in((size_t)n);

@@ -14,6 +14,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -31,6 +32,12 @@ struct TpGroup {
 
     TpGroup(int n_ranks, const int32_t* devices, int first_device, uint32_t collective);
     ~TpGroup();
+    // A group whose ranks failed ASYMMETRICALLY (one threw, the others did not -- or were released from a wait / an RCCL call
+    // because of it) is out of step for good: sequences, page tables and the collectives' epoch counters no longer agree.  The
+    // handle is then DEAD: every later call returns CM_ERR_DEVICE at once (the caller destroys the handle and creates a new
+    // one); errors every rank raises alike (an invalid argument, a range check -- thrown before any exchange) do not kill it.
+    bool dead = false;
+    std::string dead_why;
     // f(rank) on every rank concurrently; returns when all are done.  A rank that throws aborts the group's rendezvous
     // (PeerShared::fail) so that no other rank waits for it forever; the exception of the lowest failing rank is rethrown.
     void run(const std::function<void(int)>& f);
@@ -50,6 +57,7 @@ private:
     std::vector<std::exception_ptr> errs;
     void worker(int r);
     void run_rank(int r, const std::function<void(int)>& f);
+    static bool symmetric_error(const std::exception_ptr& e);
 };
 
 }  // namespace cm

@@ -103,10 +103,16 @@ typedef struct cm_opts {
     const int32_t* tp_devices; /* CM_TP_IN_PROCESS: tp_size device ordinals (NULL: device, device + 1, ...).        */
                                /*   tp_size DISTINCT devices, or ONE ordinal tp_size times (test mode: every rank   */
                                /*   on one GPU -- the sharding and the exchange steps on a 1-GPU box; exchange      */
-                               /*   through the peer-store collective, RCCL refuses two ranks per device).          */
+                               /*   through the peer-store collective, RCCL refuses two ranks per device; more than */
+                               /*   4 ranks on one device need GPU_MAX_HW_QUEUES >= tp_size exported before the HIP */
+                               /*   runtime starts -- one hardware queue per rank stream -- else CM_ERR_INVALID).   */
+                               /*   A group whose ranks fail asymmetrically (one rank errors, the others do not) is */
+                               /*   DEAD: every later call on the handle returns CM_ERR_DEVICE; destroy + re-create. */
     uint32_t tp_collective;    /* CM_TP_IN_PROCESS: 0 default (RCCL over xGMI on distinct devices), CM_TP_COLL_RCCL, */
                                /*   CM_TP_COLL_PEER (one-shot push all-reduce over peer-visible memory, csrc/       */
-                               /*   kernels_tp.hip: no RCCL call in the token loop; not yet measured on > 1 GPU)    */
+                               /*   kernels_tp.hip: no RCCL call in the token loop).  EXPERIMENTAL on distinct       */
+                               /*   devices: never run on > 1 GPU; needs uncached / fine-grained device memory for   */
+                               /*   the inboxes and fails with CM_ERR_UNSUPPORTED where the runtime has none.        */
     uint32_t reserved[1];
 } cm_opts;
 
@@ -464,8 +470,9 @@ int cm_debug_read(cm_model* m, const char* what, float* out, size_t n);
 int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n);
 
 /* Test hook: the peer-store all-reduce / all-gather of an in-process group alone (csrc/kernels_tp.hip): n_ranks threads on
- * `device`, `iters` rounds over `count` elements, every sum and gather checked on the host.  Returns the number of wrong
- * elements (0 = pass), < 0 on error (cm_last_global_error). */
+ * `device`, |iters| rounds over `count` elements, every sum and gather checked on the host; iters < 0 starts the ranks' epoch
+ * counter at 0xFFFFFFFD so that the rounds cross its 32-bit wrap.  Returns the number of wrong elements (0 = pass), < 0 on error
+ * (cm_last_global_error).  More than 4 ranks on one device need GPU_MAX_HW_QUEUES >= n_ranks exported before the HIP runtime starts. */
 long cm_debug_peer_selftest(int32_t n_ranks, int32_t device, int32_t iters, int32_t count);
 
 /* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at

@@ -46,6 +46,11 @@ def _lib():
     lib.qc_num_threads.restype = C.c_int
     lib.qc_set_threads.argtypes = [C.c_int]
     lib.qc_set_name_prefix.argtypes = [C.c_char_p]
+    if hasattr(lib, "qc_synth_f32"):          # oracle/c/q8_ref.c
+        lib.qc_synth_f32.argtypes = [C.c_char_p, C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        lib.qc_quantize_ref.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_int8), C.POINTER(C.c_float)]
+        lib.qc_vec_dot_q8_rows.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_int8),
+                                           C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float)]
     return lib
 
 

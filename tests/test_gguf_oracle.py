@@ -116,3 +116,38 @@ def test_gguf_container_round_trip(tmp_path):
     np.testing.assert_array_equal(raw, G.quantize(a, G.GGML_Q4_K))
     np.testing.assert_array_equal(G.dequantize(t2["output_norm.weight"][2], G.GGML_F32, 64), b)
     assert t2["w8"][0] == (8, 256) and t2["w8"][2].size == 8 * 8 * 34
+
+
+def test_c_restatement_of_the_quantisers_and_vec_dot_equals_the_numpy_one():
+    """oracle/c/q8_ref.c (the fast checker of the int8-MFMA decode-group tests, oracle/qgroup_oracle.py) against this file's numpy
+    restatement, which carries the known-answer blocks: codes and f16-rounded scales bit for bit, ggml_vec_dot_q8_0_q8_0 to the f32
+    summation order (numpy sums the blocks pairwise, the C code in ascending order like ggml)."""
+    import ctypes as C
+    import os
+    from oracle import c_oracle
+    if not os.path.exists(c_oracle.SO):
+        pytest.skip("oracle/c not built")
+    from oracle.qgroup_oracle import QMat, _p
+    lib = c_oracle._lib()
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((96, 512)) * np.abs(rng.standard_normal((96, 512)))).astype(np.float32)
+    w[3, 32:64] = 0                                   # an all-zero block: d = 0, id = 0
+    w[5, 0] = -w[5, 1:32].max() * 2                   # signed maximum negative (Q4_0 / Q5_0: d > 0)
+    x = (rng.standard_normal((7, 512)) * 3).astype(np.float32)
+    for name, fmt in (("q8_0", 8), ("q4_0", 2), ("q5_0", 6)):
+        gt = G.TYPE_NAMES[name]
+        qm = QMat(lib, w, fmt)
+        ref = G.QuantMatrix(G.quantize(w, gt), gt, w.shape)
+        assert np.array_equal(qm.q.reshape(96, 16, 32), ref.q) and np.array_equal(qm.d, ref.d), name
+        xq, xd = G.quantize_act_q8_0(x)
+        xq8, xd = np.ascontiguousarray(xq.astype(np.int8)), np.ascontiguousarray(xd)
+        out = np.empty((7, 96), np.float32)
+        assert lib.qc_vec_dot_q8_rows(_p(qm.q, C.c_int8), _p(qm.d, C.c_float), 96, 512, _p(xq8, C.c_int8), _p(xd, C.c_float), 7, _p(out, C.c_float)) == 0
+        want = ref.vecdot(x)
+        assert np.abs(out - want).max() <= 1e-6 * np.abs(want).max(), name
+    # the synthetic-weight generator as f32 (crane_amd/synth.py, bit-identical)
+    from crane_amd import synth
+    got = np.empty((5, 64), np.float32)
+    lib.qc_synth_f32(b"model.layers.1.mlp.down_proj.weight", 3, 0.02, 0.0, 5, 64, _p(got, C.c_float))
+    want = synth.bf16_bits_to_f32(synth.synth_bf16_bits("model.layers.1.mlp.down_proj.weight", 320, 3, 0.02, 0.0)).reshape(5, 64)
+    assert np.array_equal(got, want)

@@ -451,3 +451,51 @@ def test_decode_attention_mfma_variant(mfma_min, wide_min, kv):
                 t1, t2 = int(r1.argmax()), int(r2.argmax())
         finally:
             m.close()
+
+
+@pytest.mark.parametrize("name", ["tiny-qwen3-untied", "eng-qwen3"])
+def test_f16_pages_saturate_like_the_oracle_when_a_value_row_overflows(name, tmp_path):
+    """CM_KV_F16 pages hold |x| <= 65504.  A checkpoint whose layer-0 v_proj is scaled by 2^16 (exact in bf16) drives V rows far
+    past that: the append must CLAMP (v_cvt_f16_f32 after a clamp, dev_common.h) -- never write inf, which would turn the softmax
+    average into NaN -- exactly like the oracle's f16 rounding point (oracle/qwen3_oracle.py f16_round, qc_common.h f16_round).
+    Covered appends: the prompt pass (qknorm_rope_kv_kernel), the split-KV decode step, and -- eng-qwen3 -- the persistent decode
+    kernel's in-kernel append."""
+    import json, os
+    cfg = configs.get_config(name)
+    d = str(tmp_path / "ckpt")
+    os.makedirs(d)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    w, tensors = {}, []
+    for tname, shape, std, off in synth.specs_for(cfg):
+        bits = synth.synth_bf16_bits(tname, int(np.prod(shape)), 0, std, off)
+        if tname == "model.layers.0.self_attn.v_proj.weight":
+            bits = synth.f32_to_bf16_bits(synth.bf16_bits_to_f32(bits) * np.float32(2.0 ** 16))
+        w[tname] = synth.bf16_bits_to_f32(bits).reshape(shape)
+        tensors.append((tname, shape, bits))
+    synth.write_safetensors_bf16(os.path.join(d, "model.safetensors"), tensors)
+    c = Qwen3Config.from_json(cfg)
+    o = Qwen3Oracle(c, w, kv_dtype="f16")
+    V = cfg["vocab_size"]
+    ids = configs.synthetic_prompt(40, V)
+    m = Model.from_pretrained(d, max_seq_len=256, max_seqs=2)            # default options: f16 pages
+    try:
+        ref = o.forward(ids, 0)
+        assert np.abs(o.v_cache[0]).max() == 65504.0                      # the oracle's cache really saturated
+        got = m.forward_step(ids, 0)[0, 0]
+        assert np.isfinite(got).all()
+        assert rel(got, ref) < REL_SAME, rel(got, ref)
+        tok = int(ref.argmax())
+        for step in range(3):                                             # decode steps append (and clamp) their own rows
+            ref = o.forward([tok], 40 + step)
+            got = m.forward_step([tok], 40 + step)[0, 0]
+            assert np.isfinite(got).all()
+            assert rel(got, ref) < REL_SAME, (step, rel(got, ref))
+            tok = int(ref.argmax())
+        m.debug_set("no_prefill", 1)                                      # the prompt token by token: every append is a decode step
+        m.clear_kv_cache()
+        o2 = Qwen3Oracle(c, w, kv_dtype="f16")
+        got = m.forward_step(ids[:12], 0)[0, 0]
+        assert rel(got, o2.forward(ids[:12], 0)) < REL_SAME
+    finally:
+        m.close()

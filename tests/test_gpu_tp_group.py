@@ -154,6 +154,19 @@ def test_peer_store_collectives_alone(n):
         assert bad == 0, (n, count, bad, lib.cm_last_global_error())
 
 
+@pytest.mark.parametrize("n", [2, 8])
+def test_peer_store_epochs_across_the_32_bit_wrap(n):
+    """iters < 0 starts the ranks' epoch counter at 0xFFFFFFFD: the 12 rounds (24 collectives) walk 0xFFFFFFFE, 0xFFFFFFFF, 2, 3, ...
+    -- the inbox buffer is the epoch's parity, so the wrap must keep consecutive epochs alternating (0 = never written and 1 are
+    skipped; with 0xFFFFFFFF -> 1 two consecutive collectives shared a buffer and a fast rank overwrote granules a slow one had
+    not read: the reader then spun into its 2 s bound)."""
+    from crane_amd import _lib
+    lib = _lib.load()
+    for count in (512, 21 * 512):
+        bad = lib.cm_debug_peer_selftest(n, 0, -12, count)
+        assert bad == 0, (n, count, bad, lib.cm_last_global_error())
+
+
 def test_groups_of_different_sizes_one_after_another():
     """Handles of different tensor-parallel degree created and destroyed in one process (recycled device memory, recycled
     worker threads): found a stale-data hazard of re-used uncached allocations during development (csrc/tp.cpp init_peer)."""
