@@ -289,6 +289,11 @@ struct EngArgs {
     const EngAttnL* attn;         // per layer, or null when no phase of the launch has pre_attn
     unsigned long long* gran[ENG_NEDGE];   // 8-byte {f32 value, u32 tag} granules
     const float* vin;             // input vector of phase p0 (written by an earlier kernel)
+    const uint16_t* embed;        // whole token incl. the embedding (round 5): [V, H] bf16 table -- row st->token is the input of phase p0
+                                  //   AND the residual stream at entry (vin / the entry value of xres are then unused); null: vin / xres
+    float* pmax;                  // head phase (plain_last, kind STORE, the last phase = final norm + lm_head): per stream wave the largest
+    int* pidx;                    //   logit it produced and its row (strict > / lowest index), [grid * stream waves]; null: no arg-max
+    int embed_V;
     float* vout;                  // plain_last: output vector of phase p1 - 1 (read by a later kernel)
     float* xres;                  // [H] residual stream (read at entry, written back at exit)
     uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)

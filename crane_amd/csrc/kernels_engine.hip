@@ -553,12 +553,19 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
 
     // residual rows owned by this wave (same mapping in o_proj and down_proj): lane i < R of group gi.  Requested first and
     // written to LDS only after the weight prefetch has been issued, so the wait is a counted one.
+    // (a.embed: the token's embedding row IS the residual stream and the first phase's input -- no embedding launch in front)
+    const CM_GLOBAL uint16_t* erow = nullptr;
+    if (a.embed != nullptr) {
+        uint32_t tok = ((const CM_GLOBAL StepState*)a.st)->token;
+        if (tok >= (uint32_t)a.embed_V) tok = 0;          // (host validates ids; the device stays in bounds regardless)
+        erow = (const CM_GLOBAL uint16_t*)a.embed + (size_t)tok * (size_t)a.H;
+    }
     float xv0[MAXRES];
 #pragma unroll
     for (int gi = 0; gi < MAXRES; ++gi) {
         int row = (gwid + gi * TW) * R + (lane < R ? lane : 0);
         row = row < a.H ? row : a.H - 1;
-        xv0[gi] = a.xres[row];
+        xv0[gi] = erow != nullptr ? bf16_to_f32(erow[row]) : a.xres[row];
     }
     // The first phase's input vector was written by an earlier kernel: stream wave w requests pass w of it (1024 floats)
     // BEFORE the weight prefetch (a load issued behind this CU's prefetch burst returns ~5 us later) and stages it once
@@ -570,10 +577,20 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     for (int pp = 0; pp < 2; ++pp) {
         const int pw = wave + pp * NSW;
         const int pass = pw < npass0 ? pw : npass0 - 1;
-        const CM_GLOBAL f32x4* v4 = (const CM_GLOBAL f32x4*)a.vin + pass * 256;
-        const CM_GLOBAL f32x4* w4 = (const CM_GLOBAL f32x4*)(PF0->nw != nullptr ? PF0->nw : a.vin) + pass * 256;
+        const CM_GLOBAL f32x4* w4 = (const CM_GLOBAL f32x4*)(PF0->nw != nullptr ? PF0->nw : (erow != nullptr ? (const float*)a.cos : a.vin)) + pass * 256;
+        if (erow != nullptr) {           // (launch-uniform branch; 4 bf16 per lane and load)
+            const CM_GLOBAL u32x2* e2 = (const CM_GLOBAL u32x2*)erow + pass * 256;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xin[pp][i] = v4[i * 64 + lane]; win[pp][i] = w4[i * 64 + lane]; }
+            for (int i = 0; i < 4; ++i) {
+                const u32x2 pk = e2[i * 64 + lane];
+                xin[pp][i] = (f32x4){bf16_lo(pk[0]), bf16_hi(pk[0]), bf16_lo(pk[1]), bf16_hi(pk[1])};
+                win[pp][i] = w4[i * 64 + lane];
+            }
+        } else {
+            const CM_GLOBAL f32x4* v4 = (const CM_GLOBAL f32x4*)a.vin + pass * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xin[pp][i] = v4[i * 64 + lane]; win[pp][i] = w4[i * 64 + lane]; }
+        }
     }
 
     // ---- cursors over the batch sequence: phase -> block of `gblk` row groups -> chunk kb -> group gg of the block ----
@@ -636,6 +653,8 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     gf_ptr cvout = (gf_ptr)a.vout;
     float* my_accp = accp + wave * MAXGB * R;
     float* my_xres = xres_l + wave * MAXRES * R;
+    float best_v = -INFINITY;                 // head phase: the largest logit this lane (row parity) has produced, and its row
+    int best_i = 0x7FFFFFFF;
 
     auto compute = [&](u32x4 (&q)[R][U]) __attribute__((always_inline)) {
         if (fresh) {
@@ -716,8 +735,11 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     }
                 } else {
                     if (lane < R) {
-                        if (cplain) cvout[r0 + lane] = mine;
-                        else if (cout >= 0) gran_st(G + r0 + lane, ctag, mine);
+                        if (cplain) {
+                            cvout[r0 + lane] = mine;
+                            // (rows ascend along a wave's groups, so strict > keeps the lowest index of equal logits)
+                            if (mine > best_v) { best_v = mine; best_i = r0 + lane; }
+                        } else if (cout >= 0) gran_st(G + r0 + lane, ctag, mine);
                     }
                 }
             }
@@ -776,6 +798,15 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
     for (int gi = 0; gi < a.gpw_res; ++gi) {
         const int row = (gwid + gi * TW) * R + lane;
         if (lane < R && row < a.H) a.xres[row] = my_xres[gi * R + lane];
+    }
+    if (a.pmax != nullptr) {                  // head phase: this wave's arg-max partial (lanes 0 / 1 = even / odd rows) for argmax_final
+        const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_v), 1));
+        const int oi = __builtin_amdgcn_readlane(best_i, 1);
+        if (lane == 0) {
+            const bool take = ov > best_v || (ov == best_v && oi < best_i);
+            a.pmax[gwid] = take ? ov : best_v;
+            a.pidx[gwid] = take ? oi : best_i;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[0] = base + (uint32_t)a.epoch_step;
 }

@@ -466,7 +466,7 @@ void Model::build_engine() {
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;      // (hybrid: q carries its output gate)
     int gblk_env[4] = {0, 0, 0, 0};
     if (const char* e = getenv("CM_ENG_GBLK")) sscanf(e, "%d,%d,%d,%d", &gblk_env[0], &gblk_env[1], &gblk_env[2], &gblk_env[3]);
-    std::vector<EngPhase> prog((size_t)cfg.L * 4);
+    std::vector<EngPhase> prog((size_t)cfg.L * 4 + 1);
     std::vector<EngAttnL> at((size_t)cfg.L);
     for (int li = 0; li < cfg.L; ++li) {
         const LayerW& w = layers[(size_t)li];
@@ -493,6 +493,21 @@ void Model::build_engine() {
             if (gblk_env[k] > 0) p[k].gblk = std::min(std::min(p[k].gpw, 6), gblk_env[k]);      // CM_ENG_GBLK (tuning)
         }
         at[(size_t)li] = EngAttnL{kpool(li), vpool(li), w.qn, w.kn};
+    }
+    {
+        // the whole token's LAST phase (round 5): final RMSNorm + lm_head as one more row-streaming projection -- its input is the
+        // residual the last down_proj publishes, its rows go to `logits` as plain stores, every stream wave keeps the arg-max of
+        // the rows it produced; the embedding row is read by the launch itself (EngArgs::embed).  A token is then TWO launches
+        // (this + argmax_final) instead of four: the 1.24 GB table streams behind layer 36 without a launch boundary.
+        EngPhase& h = prog[(size_t)cfg.L * 4];
+        h = EngPhase{};
+        h.layer = cfg.L; h.useq = cfg.L; h.in_tag = cfg.L; h.out_tag = cfg.L + 1;
+        h.W = lm_head; h.nw = norm; h.N = std::max(0, std::min(V_l, cfg.V - v0)); h.K = H; h.kind = ENG_STORE;
+        h.xoff = 0; h.xbuf = 0; h.in_edge = ENG_E_X0; h.out_edge = -1;
+        h.gpw = gpw(h.N); h.nb = h.K / eng_chunk; h.gblk = h.nb > 2 ? 1 : std::min(h.gpw, 3);
+        eng_head = engine_full && !quantized && tp == 1 && !rccl && embed != nullptr && lm_head != nullptr && h.N % 2 == 0 && h.N > 0;
+        if (const char* e = getenv("CM_ENG_HEAD")) eng_head = eng_head && atoi(e) != 0;
+        if (eng_head) { eng_pmax = dalloc<float>((size_t)TW); eng_pidx = dalloc<int>((size_t)TW); }
     }
     eng_prog = (EngPhase*)dalloc<int>(prog.size() * sizeof(EngPhase) / sizeof(int));
     CM_HIP(hipMemcpy(eng_prog, prog.data(), prog.size() * sizeof(EngPhase), hipMemcpyHostToDevice));
@@ -532,7 +547,7 @@ EngArgs Model::engine_args_common() const {
     for (int k = 0; k < ENG_NEDGE; ++k) e.gran[k] = eng_gran[k];
     e.xres = x; e.ctl = (uint32_t*)&st->rsv[1];
     e.st = st; e.block_table = d_bt; e.cos = cos; e.sin = sin;
-    e.epoch_step = cfg.L + 2;
+    e.epoch_step = cfg.L + 3;
     e.H = cfg.H; e.gpw_res = eng_gpw_res; e.xf_total = eng_xf_total;
     e.Hkv = Hkv_l; e.page = page; e.max_pages = max_pages_per_seq;
     e.q_off = 0; e.k_off = Hq_l * cfg.D; e.v_off = e.k_off + Hkv_l * cfg.D;
@@ -559,6 +574,10 @@ EngArgs Model::engine_args_full() const {
     e.p0 = 0; e.p1 = 4 * cfg.L;
     e.attn = eng_attn;
     e.vin = x;
+    if (eng_head) {            // + embedding row in, final norm + lm_head + arg-max partials out
+        e.p1 = 4 * cfg.L + 1; e.plain_last = 1; e.vout = logits;
+        e.embed = embed; e.embed_V = cfg.V; e.pmax = eng_pmax; e.pidx = eng_pidx;
+    }
     return e;
 }
 
@@ -796,6 +815,14 @@ uint64_t Model::decode_bytes_per_token(size_t ctx) const {
 void Model::enqueue_decode_step(bool advance) {
     const int H = cfg.H, D = cfg.D;
     hipStream_t s = stream;
+    if (engine_on && attn_variant == 4 && eng_head) {
+        // the whole token in ONE launch: embedding row, every projection and the attention of every layer, final norm + lm_head with
+        // per-wave arg-max partials (kernels_engine.hip); argmax_final picks the winner and advances the step state
+        if (!launch_engine(engine_args_full(), num_cu, s)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
+        logits_gathered = false;
+        launch_argmax_final(eng_pmax, eng_pidx, num_cu * engine_config().nsw, st, ring, RING - 1, advance ? 1 : 0, 1, s);
+        return;
+    }
     if (quantized && q_embed.fmt != QFMT_NONE) launch_embed_row_q(q_embed, st, x, H, cfg.V, s);
     else launch_embed_row(embed, st, x, H, cfg.V, 1, s);
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
@@ -2015,6 +2042,7 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
             if (engine_full) {       // the whole-token launch: every layer's weights + the KV read at the current context
                 if (!launch_engine(engine_args_full(), num_cu, stream)) throw CmError(CM_ERR_DEVICE, "persistent decode kernel launch");
                 b = (wl + 2ull * H * 4 + 2ull * D * 4) * (uint64_t)cfg.L + 2ull * cfg.L * Hkv_l * (uint64_t)seq(0).len * kv_row_bytes + 2ull * H * 4;
+                if (eng_head) b += (uint64_t)std::max(0, std::min(V_l, cfg.V - v0)) * H * 2 + (uint64_t)H * 4 + (uint64_t)H * 2;      // + lm_head, final norm, embedding row
                 return;
             }
             const int lc = cfg.L > 1 ? (int)(i % (size_t)(cfg.L - 1)) : 0;

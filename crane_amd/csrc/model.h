@@ -316,6 +316,9 @@ struct Model {
     // persistent decode kernel (kernels_engine.hip): the whole token in one launch (attention inside), or per layer ONE
     // launch for o_proj -> gate||up -> down_proj -> next QKV around the separate attention kernels
     bool engine_on = false, engine_full = false;
+    bool eng_head = false;                     // whole-token launch also runs the embedding row, the final norm + lm_head and the per-wave arg-max partials (CM_ENG_HEAD=0: off)
+    float* eng_pmax = nullptr;                 //   [num_cu * stream waves] partials for argmax_final
+    int* eng_pidx = nullptr;
     int eng_tune = (8 << 8) | (8 << 4);        // polling parameters of the persistent kernel (EngArgs::tune)
     int eng_dbg = 0;                           // CM_ENG_DBG (timing experiments only)
     int64_t eng_full_max_ctx = 8192;           // longer contexts: per-layer launches around the MFMA flash-decode kernel
