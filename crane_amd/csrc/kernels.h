@@ -294,6 +294,8 @@ struct EngArgs {
     float* pmax;                  // head phase (plain_last, kind STORE, the last phase = final norm + lm_head): per stream wave the largest
     int* pidx;                    //   logit it produced and its row (strict > / lowest index), [grid * stream waves]; null: no arg-max
     int embed_V;
+    int idx_base;                 // head phase: global index of row 0 (vocabulary shard of a tensor-parallel rank)
+    int nsplit;                   // in-kernel attention: token splits per kv head (<= 32); workgroups [0, Hkv * nsplit) run it
     float* vout;                  // plain_last: output vector of phase p1 - 1 (read by a later kernel)
     float* xres;                  // [H] residual stream (read at entry, written back at exit)
     uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)
@@ -308,7 +310,7 @@ struct EngArgs {
     int Hkv, page, max_pages, q_off, k_off, v_off;
     int kv_f16;                   // K/V pages hold IEEE binary16 (CM_KV_F16) instead of bf16
     int nrep;                     // GQA group size of the in-kernel attention: 4 (Qwen3-8B) or 2 (Qwen3-VL-2B text, Qwen3-1.7B)
-    int chunk;                    // input elements per dependency chunk / weight batch: 2048, or 1024 (Qwen3-0.6B widths)
+    int chunk;                    // input elements per dependency chunk / weight batch: 2048, 1024 (Qwen3-0.6B widths) or 512 (tensor-parallel shards)
     float eps, scale;
     int tune;                     // polling parameters (CM_ENG_TUNE while tuning), see kernels_engine.hip
     int dbg;                      // timing experiments (CM_ENG_DBG), see kernels_engine.hip; 0 in production

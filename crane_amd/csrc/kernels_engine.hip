@@ -94,7 +94,9 @@ enum { C_PROG = 0,      // batches finished by this workgroup's stream waves (mo
 
 template <int NSW, int NCW, int PF, int NREP, bool TRACE, int UC>
 __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_kernel(EngArgs a) {
-    constexpr int U = UC, CHUNK = UC * 512, PPC = CHUNK / 1024;      // PPC: 1024-granule staging passes per chunk
+    // PPC: 1024-granule staging passes per chunk (chunks of >= 1024 elements); CPP: chunks per staging pass (512-element chunks:
+    // the shard widths of a tensor-parallel rank -- Hq_l * D = 512, I_l = 1536 at TP = 8 of Qwen3-8B)
+    constexpr int U = UC, CHUNK = UC * 512, PPC = CHUNK >= 1024 ? CHUNK / 1024 : 1, CPP = CHUNK >= 1024 ? 1 : 1024 / CHUNK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -171,7 +173,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) { a_koff[u] = 0; a_tt[u] = 0; }
         if (a.attn != nullptr) {
-            const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = gridDim.x / Hkv;
+            // (a.nsplit <= 32 token splits per kv head; workgroups past Hkv * nsplit -- one kv head per rank under tensor parallelism
+            // leaves 224 of 256 -- take no part in the attention: their loads below stay in bounds and are never consumed)
+            const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, nsplit = a.nsplit, split = (blockIdx.x / Hkv) % nsplit;
             const int tok_in_chunk = cw * 4 + (lane >> 4), dimbase = (lane & 15) * 8;
             const CM_GLOBAL int32_t* bt = (const CM_GLOBAL int32_t*)a.block_table;
             a_pos = ((const CM_GLOBAL StepState*)a.st)->pos;
@@ -204,10 +208,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 continue;
             }
             stamp(p - p0, 0);
-            if (P->pre_attn && !dbg_noattn) {
+            if (P->pre_attn && !dbg_noattn && (int)blockIdx.x < a.Hkv * a.nsplit) {
                 // ================= attention of this layer (split `blockIdx / Hkv` of kv head `blockIdx % Hkv`) =================
                 const CM_CONST EngAttnL* AL = (const CM_CONST EngAttnL*)a.attn + P->layer;
-                const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = gridDim.x / Hkv;
+                const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = a.nsplit;
                 const int r = lane >> 4, sub = lane & 15, dimbase = sub * 8, tok_in_chunk = cw * 4 + r;
                 const uint32_t tag = base + (uint32_t)P->in_tag;     // QKV, partials and merged output of this layer share it
                 float* qs = asc;                          // [NREP][AD]
@@ -463,6 +467,11 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 }
                 stamp(p - p0, 2);          // (`mo`, qs, red_* are next written a whole layer later)
             } else {
+                // (a workgroup outside the attention -- or a launch without it -- still waits for its own stream waves to be through
+                // the producing phase before it polls the attention output: 224 workgroups polling through QKV + attention would
+                // travel the fabric for nothing)
+                if (P->pre_attn && a.attn != nullptr && !dbg_noattn)
+                    own_progress(prog_before + (uint32_t)(NSW * prev_nbt) - (uint32_t)(NSW / 2), 0x600u + (uint32_t)(p - p0));
                 stamp(p - p0, 1);
             }
             // ---- stage this phase's input: 1024 granules per pass, passes cw, cw + NCW, ...; chunk c = passes PPC * c ... ----
@@ -489,9 +498,12 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         b_done = b_done < prev_nbt ? b_done : prev_nbt;
                         own_progress(prog_before + (uint32_t)(NSW * b_done), 0x100u + (uint32_t)(p - p0));
                     }
+                    // a pass past the end of a vector whose length is a multiple of 512 only (K = 512, 1536): the upper half is padding
+                    // -- never tagged (excluded from `ok`), staged as zeros; buffers are sized in whole passes
+                    const bool tail = (pass + 1) * 1024 > K;
                     if (nw != nullptr) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) wv[i] = nw[kb + i * 64];
+                        for (int i = 0; i < 16; ++i) wv[i] = nw[(tail && i >= 8) ? lane : kb + i * 64];
                     }
                     uint32_t spins = 0;
                     // A sweep of the pass costs 64 cache-line requests per CU whether it finds the pass complete or not, and
@@ -499,7 +511,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     // spread over it (the granules of 64 producer waves on 16 CUs), an eighth of a sweep; only a clean probe
                     // is followed by the sweep.
                     if (!(P->pre_attn && t_noprobe_attn)) {
-                        const u64* GP0 = G + pass * 1024 + (lane >> 3) * 128 + (lane & 7) * 2 + 1;
+                        const u64* GP0 = G + pass * 1024 + (tail ? (lane >> 3) * 64 : (lane >> 3) * 128) + (lane & 7) * 2 + 1;
                         for (;;) {
                             const u64 x = gran_ld(GP0);
                             if (__all((uint32_t)(x >> 32) == tag) || dbg_nowait) break;
@@ -515,7 +527,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         for (int i = 0; i < 16; ++i) {
                             const u64 x = gran_ld(G + kb + i * 64);
                             v[i] = __uint_as_float((uint32_t)x);
-                            ok = ok && ((uint32_t)(x >> 32) == tag);
+                            ok = ok && ((uint32_t)(x >> 32) == tag || (tail && i >= 8));
                         }
                         if (__all(ok) || dbg_nowait) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
@@ -526,7 +538,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     float ss = 0.f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float val = v[i];
+                        float val = (tail && i >= 8) ? 0.f : v[i];
                         if (nw != nullptr) { ss += val * val; val *= wv[i]; }
                         xs[xperm(kb + i * 64)] = val;
                     }
@@ -535,7 +547,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (lane == 0) ssq[(xbuf & 1) * 16 + pass] = ss;
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) lds_add(&ctrl[C_CNT + xbuf * MAXCH + pass / PPC], 1u);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int c2 = 0; c2 < CPP; ++c2) lds_add(&ctrl[C_CNT + xbuf * MAXCH + (CPP > 1 ? pass * CPP + c2 : pass / PPC)], 1u);
+                    }
                 }
                 stamp(p - p0, 3, (u64)total_spins);
             }
@@ -738,7 +753,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (cplain) {
                             cvout[r0 + lane] = mine;
                             // (rows ascend along a wave's groups, so strict > keeps the lowest index of equal logits)
-                            if (mine > best_v) { best_v = mine; best_i = r0 + lane; }
+                            if (mine > best_v) { best_v = mine; best_i = a.idx_base + r0 + lane; }
                         } else if (cout >= 0) gran_st(G + r0 + lane, ctag, mine);
                     }
                 }
@@ -783,7 +798,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 if (lane == 0) ssq[(PF0->xbuf & 1) * 16 + pw] = ss;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + pw / PPC], 1u);
+            if (lane == 0) {
+#pragma unroll
+                for (int c2 = 0; c2 < CPP; ++c2) lds_add(&ctrl[C_CNT + PF0->xbuf * MAXCH + (CPP > 1 ? pw * CPP + c2 : pw / PPC)], 1u);
+            }
         }
     }
     while (cc.ph < p1) {
@@ -855,10 +873,11 @@ static void launch_v(const EngArgs& a, int grid, size_t lds, hipStream_t s, bool
     else hipLaunchKernelGGL((engine_kernel<NSW, ENG_NCW, PF, NREP, false, UC>), dim3(grid), dim3((NSW + ENG_NCW) * 64), lds, s, a);
 }
 
-// dependency chunk of 1024 input elements (widths that are multiples of 1024 but not of 2048): the default configuration only
+// dependency chunk of 1024 input elements (widths that are multiples of 1024 but not of 2048) or of 512 (the shard widths of a
+// tensor-parallel rank): the default configuration only
 bool engine_has_chunk(int chunk) {
     const EngCfg c = engine_config();
-    return chunk == 2048 || (chunk == 1024 && c.nsw == 4 && c.pf == 4);
+    return chunk == 2048 || ((chunk == 1024 || chunk == 512) && c.nsw == 4 && c.pf == 4);
 }
 
 // GQA group sizes of the in-kernel attention: 4 in every tuning configuration, 2 in the default one
@@ -881,9 +900,25 @@ static int pf1024() {
     return v;
 }
 #define CM_ENG_1024(CALL, NR) { const int pf = pf1024(); if (pf == 4) { CALL(4, 4, NR, 2) } else if (pf == 6) { CALL(4, 6, NR, 2) } else { CALL(4, 8, NR, 2) } }
+// register sets in flight per stream wave at 512-element chunks (2 KiB batches): CM_ENG_PF512 = 8 | 12 | 16
+static int pf512() {
+    static int v = -1;
+    if (v < 0) { v = getenv("CM_ENG_PF512") ? atoi(getenv("CM_ENG_PF512")) : 16; if (v != 8 && v != 12 && v != 16) v = 16; }
+    return v;
+}
+#define CM_ENG_512(CALL, NR) { const int pf = pf512(); if (pf == 8) { CALL(4, 8, NR, 1) } else if (pf == 12) { CALL(4, 12, NR, 1) } else { CALL(4, 16, NR, 1) } }
 
 bool engine_prepare(size_t lds_bytes, int nrep, int chunk) {
     const EngCfg c = engine_config();
+    if (chunk == 512) {
+        if (!engine_has_chunk(512)) return false;
+#define CM_P(N, P, NR, UU) ok = ok && prepare_v<N, P, NR, UU>(lds_bytes);
+        bool ok = true;
+        if (nrep == 2) CM_ENG_512(CM_P, 2)
+        CM_ENG_512(CM_P, 4)
+#undef CM_P
+        return ok;
+    }
     if (chunk == 1024) {
         if (!engine_has_chunk(1024)) return false;
         // both instantiations a handle can launch (whole token with the in-kernel attention of its GQA group; per layer without):
@@ -906,6 +941,14 @@ bool launch_engine(const EngArgs& a, int grid, hipStream_t s, bool trace) {
     const size_t lds = engine_lds_bytes(a, c.nsw, c.ncw);
     if (lds > 160 * 1024 - 256 || a.gpw_res > MAXRES || a.p1 <= a.p0) return false;
     const bool tr = trace && a.trace != nullptr;
+    if (a.chunk == 512) {
+        if (!engine_has_chunk(512) || (a.attn != nullptr && a.nrep != 2 && a.nrep != 4)) return false;
+#define CM_L(N, P, NR, UU) launch_v<N, P, NR, UU>(a, grid, lds, s, tr);
+        if (a.attn != nullptr && a.nrep == 2) CM_ENG_512(CM_L, 2)
+        else CM_ENG_512(CM_L, 4)
+#undef CM_L
+        return true;
+    }
     if (a.chunk == 1024) {
         if (!engine_has_chunk(1024) || (a.attn != nullptr && a.nrep != 2 && a.nrep != 4)) return false;
 #define CM_L(N, P, NR, UU) launch_v<N, P, NR, UU>(a, grid, lds, s, tr);

@@ -394,7 +394,14 @@ void Model::alloc_runtime() {
 bool Model::engine_eligible(std::string* why) const {
     auto no = [&](const char* m) { if (why) *why = m; return false; };
     if (quantized) return no("quantised weights");
-    if (tp != 1 || rccl) return no("tensor parallelism");
+    // tensor parallelism: only ONE rank alone with the exchange stubbed (CM_DEBUG_TP_LOCAL: the all-reduce is the identity, so a
+    // rank's step is a TP = 1 step at the shard's widths) -- what `bench.py --tp-local` times and tests/test_gpu_tp_shards.py checks.
+    // With real peers the exchange would have to live on the kernel's hand-off edges: the launch path runs there.
+    if ((tp != 1 || rccl) && !(rccl && rccl->fake)) return no("tensor parallelism");
+    // ... and there it is opt-in (cm_opts.engine = 1): measured SLOWER than the launch path on every shard size -- Qwen3-8B rank 0 at
+    // TP = 2 / 4 / 8: 2.19 / 1.64 / 1.67 ms against 2.07 / 1.48 / 1.22 ms.  A shard's phases are 1-10 us of streaming, so none of the
+    // ~6 dependent cross-CU hand-offs of a layer (~4 us each at these sizes) hides behind the weight stream
+    if (rccl && rccl->fake && opts.engine <= 0) return no("tensor-parallel shard: the persistent kernel is opt-in (cm_opts.engine = 1), slower than the launches");
     // hybrid family: the per-layer chain only (out_proj / o_proj -> gate||up -> down_proj -> next layer's in_proj / QKV around the
     // separate Gated-Delta-Net / attention launches); both kinds of token mixer must hand over a vector of the same length
     if (cfg.hybrid && Hq_l * cfg.D != cfg.value_dim()) return no("hybrid: attention output and GDN value widths differ");
@@ -404,9 +411,10 @@ bool Model::engine_eligible(std::string* why) const {
     const int Ko = Hq_l * cfg.D;
     // dependency chunk (= K elements of one weight batch): 2048 where every width is a multiple of it, else 1024 (Qwen3-0.6B:
     // hidden 1024, intermediate 3072) in the default kernel configuration
-    const int ch = (Ko % 2048 || cfg.H % 2048 || I_l % 2048) ? 1024 : 2048;
-    if (Ko % ch || cfg.H % ch || I_l % ch) return no("projection widths must be multiples of 1024");
-    if (!engine_has_chunk(ch)) return no("1024-element chunks only in the default kernel configuration");
+    const int ch = (Ko % 1024 || cfg.H % 1024 || I_l % 1024) ? 512 : (Ko % 2048 || cfg.H % 2048 || I_l % 2048) ? 1024 : 2048;
+    if (Ko % ch || cfg.H % ch || I_l % ch) return no("projection widths must be multiples of 512");
+    if (cfg.H % 1024) return no("hidden size must be a multiple of 1024");
+    if (!engine_has_chunk(ch)) return no("512- / 1024-element chunks only in the default kernel configuration");
     const EngCfg ec = engine_config();
     if (cfg.H / 1024 > 2 * ec.nsw || Ko / 1024 > 2 * ec.nsw) return no("input vector of the first phase too long for the stream waves");
     if (I_l / ch > 20 || Ko / ch > 20 || cfg.H / ch > 20) return no("a projection input too long for the chunk counters");
@@ -420,8 +428,8 @@ bool Model::engine_eligible(std::string* why) const {
 // workgroup per (kv head, token split) with at most 32 splits
 bool Model::engine_full_eligible() const {
     if (cfg.D != 128 || !engine_has_nrep(nrep) || (kv_mode != KV_BF16 && kv_mode != KV_F16) || !cfg.qk_norm) return false;
-    if (num_cu % Hkv_l) return false;
-    const int ns = num_cu / Hkv_l, opb = ns > 0 ? nrep * cfg.D / ns : 0;
+    // (at most 32 token splits per kv head: a rank with ONE kv head -- Qwen3-8B at TP = 8 -- runs its attention on 32 of the 256 workgroups)
+    const int ns = std::min(32, num_cu / std::max(1, Hkv_l)), opb = ns > 0 ? nrep * cfg.D / ns : 0;
     return ns >= 1 && ns <= 32 && (nrep * cfg.D) % ns == 0 && opb >= 2 && opb <= 16 && opb % 2 == 0 && cfg.D % opb == 0;
 }
 
@@ -439,8 +447,10 @@ void Model::build_engine() {
     }
     const EngCfg ec = engine_config();
     const int H = cfg.H, D = cfg.D, Ko = Hq_l * D, TW = num_cu * ec.nsw;
-    eng_chunk = (Ko % 2048 || H % 2048 || I_l % 2048) ? 1024 : 2048;
-    const int x0 = std::max(Ko, H), x1 = H, xh = I_l;
+    eng_chunk = (Ko % 1024 || H % 1024 || I_l % 1024) ? 512 : (Ko % 2048 || H % 2048 || I_l % 2048) ? 1024 : 2048;
+    // (LDS input buffers and granule buffers in whole 1024-element staging passes: a 512-multiple vector's last pass is half padding)
+    auto up1k = [](int v) { return (v + 1023) / 1024 * 1024; };
+    const int x0 = std::max(up1k(Ko), H), x1 = H, xh = up1k(I_l);
     eng_xf_total = x0 + x1 + xh;
     auto gpw = [&](int N) { return (N / 2 + TW - 1) / TW; };
     eng_gpw_res = gpw(H);
@@ -505,7 +515,7 @@ void Model::build_engine() {
         h.W = lm_head; h.nw = norm; h.N = std::max(0, std::min(V_l, cfg.V - v0)); h.K = H; h.kind = ENG_STORE;
         h.xoff = 0; h.xbuf = 0; h.in_edge = ENG_E_X0; h.out_edge = -1;
         h.gpw = gpw(h.N); h.nb = h.K / eng_chunk; h.gblk = h.nb > 2 ? 1 : std::min(h.gpw, 3);
-        eng_head = engine_full && !quantized && tp == 1 && !rccl && embed != nullptr && lm_head != nullptr && h.N % 2 == 0 && h.N > 0;
+        eng_head = engine_full && !quantized && (!rccl || rccl->fake) && embed != nullptr && lm_head != nullptr && h.N % 2 == 0 && h.N > 0;
         if (const char* e = getenv("CM_ENG_HEAD")) eng_head = eng_head && atoi(e) != 0;
         if (eng_head) { eng_pmax = dalloc<float>((size_t)TW); eng_pidx = dalloc<int>((size_t)TW); }
     }
@@ -514,7 +524,7 @@ void Model::build_engine() {
     eng_attn = (EngAttnL*)dalloc<int>(at.size() * sizeof(EngAttnL) / sizeof(int));
     CM_HIP(hipMemcpy(eng_attn, at.data(), at.size() * sizeof(EngAttnL), hipMemcpyHostToDevice));
     const int ns = std::max(1, num_cu / std::max(1, Hkv_l));
-    const size_t gsz[ENG_NEDGE] = {(size_t)H, (size_t)std::max(qkv_rows, cfg.hybrid ? in_proj_rows : 0), (size_t)Hkv_l * ns * nrep * (D + 2), (size_t)Hq_l * D, (size_t)H, (size_t)I_l};
+    const size_t gsz[ENG_NEDGE] = {(size_t)H, (size_t)std::max(qkv_rows, cfg.hybrid ? in_proj_rows : 0), (size_t)Hkv_l * ns * nrep * (D + 2), (size_t)up1k(Hq_l * D), (size_t)H, (size_t)up1k(I_l)};
     for (int e = 0; e < ENG_NEDGE; ++e) {
         eng_gsz[e] = gsz[e];
         eng_gran[e] = (unsigned long long*)dalloc<int>(gsz[e] * 2);
@@ -554,6 +564,7 @@ EngArgs Model::engine_args_common() const {
     e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
     e.kv_f16 = kv_mode == KV_F16 ? 1 : 0;
     e.nrep = nrep; e.chunk = eng_chunk;
+    e.nsplit = std::min(32, num_cu / std::max(1, Hkv_l));
     e.dbg = eng_dbg; e.tune = eng_tune;
     return e;
 }
@@ -576,6 +587,7 @@ EngArgs Model::engine_args_full() const {
     e.vin = x;
     if (eng_head) {            // + embedding row in, final norm + lm_head + arg-max partials out
         e.p1 = 4 * cfg.L + 1; e.plain_last = 1; e.vout = logits;
+        e.vout = logits + (size_t)rank * V_l; e.idx_base = v0;
         e.embed = embed; e.embed_V = cfg.V; e.pmax = eng_pmax; e.pidx = eng_pidx;
     }
     return e;

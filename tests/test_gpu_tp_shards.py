@@ -45,6 +45,57 @@ def test_dense_rank_shards(world):
         assert rel(got_a[v], o.forward(ids, 0)) < 1e-4 and rel(got_b[v], o.forward([5], len(ids))) < 1e-4
 
 
+@pytest.mark.parametrize("world,ranks", [(8, (0, 7)), (4, (1,)), (2, (1,))])
+def test_dense_rank_shard_on_the_persistent_kernel(world, ranks):
+    """cm_opts.engine = 1 on ONE rank's shard (CM_DEBUG_TP_LOCAL: the exchange is the identity, so the rank's step is a TP = 1 step at
+    the shard's widths): the whole-token persistent kernel at 512-element dependency chunks (TP = 8 of the 2048 / 4096-wide test
+    model: Hq_l * D = 512, I_l = 512 -- staging passes with a padded upper half), 1024 (TP = 4) and 2048 (TP = 2), the attention of
+    ONE kv head on 32 of the workgroups (TP = 8), embedding row + vocabulary-sharded head + arg-max partials with a global row
+    index inside the launch.  Decode steps over a cache the prompt pass wrote (f16 pages), against the f32 oracle on the same
+    shard (bar 1e-3) and against the launch path of the same handle; the device-chained greedy loop emits the launch path's ids."""
+    from crane_amd.backend import Model
+    from oracle.qwen3_oracle import Qwen3Config, Qwen3Oracle
+    cfg = configs.get_config("eng-qwen3")
+    w = synth.synth_weights_f32(cfg, 0)
+    ids = configs.synthetic_prompt(37, cfg["vocab_size"])
+    for rank in ranks:
+        plan = tp.shard_plan(cfg, world, rank)
+        sw = tp.shard_weights(cfg, w, plan)
+        local = dict(cfg, num_attention_heads=len(plan.q_heads), num_key_value_heads=len(plan.kv_heads), intermediate_size=len(plan.inter))
+        o = Qwen3Oracle(Qwen3Config.from_json(local), sw)
+        v = slice(plan.vocab.start, plan.vocab.stop)
+        m = Model.synthetic(cfg, seed=0, max_seq_len=256, max_seqs=2, tp_rank=rank, tp_size=world, tp_unique_id=b"\0" * 128,
+                            debug_tp_local=True, engine=1)
+        try:
+            assert m.engine_active() == 2, "whole-token persistent kernel not active on the shard"
+            ref = o.forward(ids, 0)
+            assert rel(m.forward_step(ids, 0)[0, 0][v], ref) < 1e-3
+            tok, steps = 5, []
+            for i in range(4):
+                ref = o.forward([tok], len(ids) + i)
+                got = m.forward_step([tok], len(ids) + i)[0, 0][v]
+                assert rel(got, ref) < 1e-3, (world, rank, i, rel(got, ref))
+                steps.append(got.copy())
+                tok = (7 * tok + 3) % cfg["vocab_size"]
+            m.debug_set("engine", 0)                       # the same steps on the per-projection launches
+            m.clear_kv_cache(); m.forward_step(ids, 0)
+            tok = 5
+            for i in range(4):
+                got = m.forward_step([tok], len(ids) + i)[0, 0][v]
+                assert rel(steps[i], got) < 1e-4, (world, rank, i, rel(steps[i], got))
+                tok = (7 * tok + 3) % cfg["vocab_size"]
+            # the device-chained greedy loop (rank-local arg-max over the rank's vocabulary rows, global indices)
+            outs = []
+            for eng in (0, 1):
+                m.debug_set("engine", eng)
+                m.clear_kv_cache(); m.forward_step(ids, 0)
+                toks, _ = m.bench_decode(5, 6)
+                outs.append([int(t) for t in toks])
+            assert outs[0] == outs[1] and all(plan.vocab.start <= t < plan.vocab.stop for t in outs[1]), outs
+        finally:
+            m.close()
+
+
 def test_hybrid_rank_shards():
     from oracle import qwen3_5_oracle as O5
     cfg = configs.get_config("tiny-qwen3.5")

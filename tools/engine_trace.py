@@ -15,7 +15,9 @@ name = sys.argv[1] if len(sys.argv) > 1 else "qwen3-8b"
 cfg = configs.get_config(name)
 if len(sys.argv) > 2:
     cfg["num_hidden_layers"] = int(sys.argv[2])
-m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, engine=1)
+TPL = int(os.environ.get("TRACE_TP_LOCAL", "0"))       # ONE rank's shard of a TP = N model (collectives = local no-ops)
+kw = dict(tp_size=TPL, tp_rank=0, debug_tp_local=True) if TPL else {}
+m = Model.synthetic(cfg, seed=0, max_seq_len=2048, max_seqs=1, engine=1, **kw)
 m.debug_fill_kv(1024, seed=1)
 m.bench_decode(3, 8)
 NSW = int(os.environ.get('CM_ENG_CFG', '4,4').split(',')[0])
