@@ -545,6 +545,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         else if (k == "sample_rows") mm.sample_rows_on = value != 0;
         else if (k == "prefill_seg_batch") mm.seg_batch = value != 0;
         else if (k == "prefill_lo_mask") mm.prefill_lo_mask = (int)value;
+        else if (k == "gdn_chunked") mm.gdn_ck_on = value != 0;
         else if (k == "gdn_defer_norm") { mm.gdn_defer_norm = value != 0; mm.drop_graphs(); }
         else if (k == "tp_graph") { mm.tp_graph = value != 0; mm.drop_graphs(); }      // CM_TP_GRAPH: RCCL collectives captured into the decode graph
         else if (k == "lm_head_gemm_min") mm.lm_head_gemm_min = (int)std::max<long long>(0, value);

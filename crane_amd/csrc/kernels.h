@@ -78,6 +78,8 @@ struct AttnDecArgs {
 };
 
 // Gated Delta Net layer state machine (kernels_gdn.hip)
+constexpr int GDN_CK = 64;                                        // tokens per chunk of the chunk-parallel Gated-Delta-Net prompt scan
+constexpr int GDN_CK_FLOATS = 2 * GDN_CK * 128 + GDN_CK * GDN_CK + GDN_CK;
 struct GdnArgs {
     const float* proj;           // [S, proj_stride] f32: qkv (conv_dim) | z (NV*V) | b (NV) | a (NV)
     const float* conv_w;         // [conv_dim, 4] f32
@@ -95,6 +97,8 @@ struct GdnArgs {
     float* pre_k = nullptr;      //   {beta, decay} [S][NV][2]; null: always the fused kernel
     float* pre_v = nullptr;
     float* pre_bd = nullptr;
+    float* pre_g = nullptr;      //   g = log(decay) [S][NV] (the chunk-parallel scan works in log space); null: not written
+    float* ck = nullptr;         // chunk-parallel scan scratch: [chunks][NV][GDN_CK_FLOATS] (W | U0 | P | cumulative g); null: sequential scan
     float* gdn_scratch = nullptr;   // decode step on 4 workgroups per head: [n_seq][NV][V + 4] raw y + partial sums of squares
     int* gdn_ticket = nullptr;      //   and [n_seq][NV] arrival tickets (zero between launches); null: one workgroup per head
     int defer_norm = 0;         // decode step: out = RAW y, the gated RMSNorm is the out_proj GEMV's prologue (PRO_GDNNORM) -- no

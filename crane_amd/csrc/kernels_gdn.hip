@@ -18,6 +18,8 @@
 // update); S[k][v] is stored [K][V] so a wave reads/writes 256 contiguous bytes per k.
 // Conv state is double-buffered by position parity so that the blocks of one key-head group (which
 // share q/k channels) never read a window another block is rolling.
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(128) void gdn_pre_kernel(GdnArgs a) {
             const float g = -expf(a.A_log[h]) * logf(1.0f + expf(av));
             a.pre_bd[((size_t)t * a.NV + h) * 2] = beta;
             a.pre_bd[((size_t)t * a.NV + h) * 2 + 1] = expf(g);
+            if (a.pre_g != nullptr) a.pre_g[(size_t)t * a.NV + h] = g;
         }
         roll(cv);
     }
@@ -374,6 +377,304 @@ __global__ __launch_bounds__(512) void gdn_scan_kernel(GdnArgs a) {
     for (int k = 0; k < KP; ++k) Sg[(ks * KP + k) * V + v] = S[k];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Chunk-parallel prompt scan (round 5): the gated delta rule in its WY / UT-transform form on the f32 matrix cores.
+// The sequential scan above is bound by two dependent 16-lane reductions per token on 64 workgroups (240 us per layer and
+// 1024 tokens on Qwen3.5-0.8B: 43 % of its prompt pass).  The reference names the chunked form as the prompt-path algorithm
+// (ops/gdn/backend.rs:100-104); HF's torch_chunk_gated_delta_rule is the same algebra.  Per value head and chunk of C = 64
+// tokens with state S0 [K x V] at the chunk's start (t, s index tokens of the chunk; G_t = g_1 + ... + g_t, g = log decay):
+//     u_t = beta_t (v_t - e^{G_t} S0^T k_t - sum_{s<t} e^{G_t - G_s} (k_s . k_t) u_s)          (the delta rule, unrolled)
+//  => (I + A) U = beta V - (beta e^G K) S0,   A[t][s] = beta_t e^{G_t - G_s} (k_t . k_s) for s < t
+//  => U = U0 - W S0  with  W = (I + A)^-1 (beta e^G K),  U0 = (I + A)^-1 (beta V)              (independent of S0: all chunks in parallel)
+//     Y = e^G (Q S0) + P U,   P[t][s] = e^{G_t - G_s} (q_t . k_s) for s <= t
+//     S_C = e^{G_C} S0 + K^T (e^{G_C - G} U)
+// gdn_chunk_prep_kernel (grid chunks x NV): A and P on v_mfma_f32_16x16x4_f32, (I + A)^-1 [.] by forward substitution (one
+// thread per column of [beta e^G K | beta V], its 64 unknowns in registers: no dependency between threads) -> W, U0, P, G.
+// gdn_chunk_scan_kernel (grid NV x V/16): the only sequential part -- three small matrix products per chunk over a 128 x 16
+// slice of the state (columns of S are independent).  Everything stays f32 (f32 MFMA: products and sums in f32), logs of the
+// decays are summed, never multiplied (a decay of e^-80 per token underflows a running product after two tokens).
+// Same results as the sequential scan to f32 summation order (tests: prompts through both, logits < 1e-4).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CKP = 132;          // LDS row stride (floats) of a 128-wide row: 16-byte aligned, rows 4 banks apart
+constexpr int CTP = 68;           // ... of a 64-wide row
+
+// workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, NOT for its outstanding global loads
+// (__syncthreads() carries a workgroup-scope fence that drains vmcnt as well -- it would retire the register prefetch of the
+// next chunk at every barrier)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ f32x4 mfma4(const f32x4& av, const f32x4& bv, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], c, 0, 0, 0);
+    return c;
+}
+
+size_t gdn_chunk_prep_lds() { return (size_t)(2 * GDN_CK * CKP + GDN_CK * CTP + 2 * GDN_CK) * sizeof(float); }
+size_t gdn_chunk_scan_lds() { return (size_t)(16 * CKP + 2 * 16 * CTP + GDN_CK * CKP + GDN_CK) * sizeof(float); }
+
+__global__ __launch_bounds__(256) void gdn_chunk_prep_kernel(GdnArgs a) {
+    constexpr int K = 128, V = 128, C = GDN_CK;
+    extern __shared__ __attribute__((aligned(16))) float cl[];
+    float (*Ks)[CKP] = (float (*)[CKP])cl;
+    float (*Qs)[CKP] = (float (*)[CKP])(cl + C * CKP);
+    float (*Am)[CTP] = (float (*)[CTP])(cl + 2 * C * CKP);
+    float* lg = cl + 2 * C * CKP + C * CTP;
+    float* bt = lg + C;
+    const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = a.NV / a.vpg, kh = a.chunked ? h % nk : h / a.vpg;
+    const int t0 = c * C, nt = min(C, a.S - t0);
+    float* ck = a.ck + ((size_t)c * a.NV + h) * GDN_CK_FLOATS;
+    float* Wg = ck, *U0g = ck + C * 128, *Pg = ck + 2 * C * 128, *Gg = ck + 2 * C * 128 + C * C;
+    if (wave == 0) {                                   // cumulative log decay of the chunk (inclusive), beta
+        float g = lane < nt ? a.pre_g[(size_t)(t0 + lane) * a.NV + h] : 0.f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(g, d); if (lane >= d) g += o; }
+        lg[lane] = g;
+        bt[lane] = lane < nt ? a.pre_bd[((size_t)(t0 + lane) * a.NV + h) * 2] : 0.f;
+        Gg[lane] = g;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                      // k^ and q^ rows of the chunk (rows past the prompt: zero)
+        const int e = tid + 256 * i, row = e >> 5, c4 = (e & 31) << 2;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+        if (row < nt) {
+            kv = *(const f32x4*)(a.pre_k + (size_t)(t0 + row) * a.key_dim + kh * K + c4);
+            qv = *(const f32x4*)(a.pre_q + (size_t)(t0 + row) * a.key_dim + kh * K + c4);
+        }
+        *(f32x4*)&Ks[row][c4] = kv;
+        *(f32x4*)&Qs[row][c4] = qv;
+    }
+    __syncthreads();
+    {   // A = tril(beta e^{G_t - G_s} K K^T, -1) -> LDS; P = tril(e^{G_t - G_s} Q K^T) -> scratch.  Wave w: token rows 16 w ..
+        const int r = lane & 15, kq = lane >> 4;
+        f32x4 accA[4], accP[4];
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) { accA[tc] = (f32x4){0.f, 0.f, 0.f, 0.f}; accP[tc] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 ak = *(const f32x4*)&Ks[16 * wave + r][16 * j + 4 * kq];
+            const f32x4 aq = *(const f32x4*)&Qs[16 * wave + r][16 * j + 4 * kq];
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc) {
+                if (tc > wave) continue;               // (s > t everywhere in the tile)
+                const f32x4 b = *(const f32x4*)&Ks[16 * tc + r][16 * j + 4 * kq];
+                accA[tc] = mfma4(ak, b, accA[tc]);
+                accP[tc] = mfma4(aq, b, accP[tc]);
+            }
+        }
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 16 * wave + 4 * kq + i, s2 = 16 * tc + r;
+                const float e = s2 <= t ? expf(lg[t] - lg[s2]) : 0.f;
+                Am[t][s2] = s2 < t ? bt[t] * e * accA[tc][i] : 0.f;
+                Pg[t * C + s2] = e * accP[tc][i];
+            }
+    }
+    lds_barrier();
+    // ---- X = (I + A)^-1 [beta e^G K | beta V] by BLOCKED forward substitution (16-token blocks): the off-diagonal part
+    // R_I = B_I - sum_{L<I} A_IL X_L on the matrix cores, the 16 x 16 diagonal solves one thread per column (120 FMAs each).
+    // (All 64 rows per thread as scalar FMAs were LDS-bound: every thread reads every A[t][s] -- 512 broadcast reads per thread.)
+    // X lives in LDS where k^ / q^ were ([64][264] = the same floats): every thread first forms its column of B in registers.
+    {
+        const bool isk = tid < K;
+        float b[C];
+        if (isk) {
+#pragma unroll
+            for (int t = 0; t < C; ++t) b[t] = bt[t] * expf(lg[t]) * Ks[t][tid];
+        } else {
+#pragma unroll
+            for (int t = 0; t < C; ++t) b[t] = a.pre_v[((size_t)min(t0 + t, a.S - 1) * a.NV + h) * V + (tid - K)];
+#pragma unroll
+            for (int t = 0; t < C; ++t) b[t] = t < nt ? bt[t] * b[t] : 0.f;
+        }
+        lds_barrier();                                  // every read of Ks / Qs is done: the region becomes X
+        constexpr int XP = 2 * CKP;                    // 264
+        float (*X)[XP] = (float (*)[XP])cl;
+#pragma unroll
+        for (int t = 0; t < C; ++t) X[t][tid] = b[t];
+        float* dst = (isk ? Wg : U0g) + (isk ? tid : tid - K);
+        const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            lds_barrier();
+            if (I > 0) {                               // R_I: wave w owns column tiles 4 w .. 4 w + 3
+                f32x4 acc[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int L = 0; L < I; ++L) {
+                    const f32x4 av = *(const f32x4*)&Am[16 * I + r][16 * L + 4 * kq];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        f32x4 bv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) bv[i] = X[16 * L + 4 * kq + i][16 * (4 * wave + n) + r];
+                        acc[n] = mfma4(av, bv, acc[n]);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) X[16 * I + 4 * kq + i][16 * (4 * wave + n) + r] -= acc[n][i];
+                lds_barrier();
+            }
+            float x[16];                               // diagonal block: x_t = r_t - sum_{s<t, same block} A[t][s] x_s
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x[t] = X[16 * I + t][tid];
+#pragma unroll
+            for (int t = 1; t < 16; ++t) {
+                float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < t; s4 += 4) {
+                    const f32x4 av = *(const f32x4*)&Am[16 * I + t][16 * I + s4];
+                    p0 += av[0] * x[s4];
+                    if (s4 + 1 < t) p1 += av[1] * x[s4 + 1];
+                    if (s4 + 2 < t) p0 += av[2] * x[s4 + 2];
+                    if (s4 + 3 < t) p1 += av[3] * x[s4 + 3];
+                }
+                x[t] -= p0 + p1;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { X[16 * I + t][tid] = x[t]; dst[(16 * I + t) * 128] = x[t]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
+    constexpr int K = 128, V = 128, C = GDN_CK, VB = 16;
+    extern __shared__ __attribute__((aligned(16))) float cl[];
+    float (*St)[CKP] = (float (*)[CKP])cl;                              // state slice, transposed: [column][k]
+    float (*Ut)[CTP] = (float (*)[CTP])(cl + VB * CKP);                 // U of the chunk, transposed: [column][t]
+    float (*Vt)[CTP] = (float (*)[CTP])(cl + VB * CKP + VB * CTP);      // e^{G_C - G_t} U
+    float (*Ks)[CKP] = (float (*)[CKP])(cl + VB * CKP + 2 * VB * CTP);  // k^ rows of the chunk
+    float* lgs = cl + VB * CKP + 2 * VB * CTP + C * CKP;
+    const int h = blockIdx.x, cb = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int nk = a.NV / a.vpg, kh = a.chunked ? h % nk : h / a.vpg;
+    float* Sg = a.state_pool + (((size_t)a.slot * a.gdn_layers + a.layer_idx) * a.NV + h) * K * V;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, k = e >> 4, col = e & 15;
+        St[col][k] = Sg[k * V + VB * cb + col];
+    }
+    const int nchunks = (a.S + C - 1) / C;
+    // One wave per SIMD: nothing hides a load but the wave's own work, so the operands of chunk c + 1 (this wave's 16 rows of W,
+    // q^, P, its U0 values, its share of the k^ rows, the cumulative log decay) are requested into registers while chunk c is
+    // multiplied -- unconditionally (rows / chunks past the end are clamped and never consumed: DESIGN 3.13).
+    f32x4 aw[8], aq[8], ap[4], kreg[8];
+    float u0[4], glane = 0.f;
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+        const int cc = min(c, nchunks - 1), t0 = cc * C;
+        const float* ck = a.ck + ((size_t)cc * a.NV + h) * GDN_CK_FLOATS;
+        const int qrow = min(t0 + 16 * wave + r, a.S - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            aw[j] = *(const f32x4*)(ck + (16 * wave + r) * 128 + 16 * j + 4 * kq);
+            aq[j] = *(const f32x4*)(a.pre_q + (size_t)qrow * a.key_dim + kh * K + 16 * j + 4 * kq);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ap[j] = *(const f32x4*)(ck + 2 * C * 128 + (16 * wave + r) * C + 16 * j + 4 * kq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u0[i] = ck[C * 128 + (16 * wave + 4 * kq + i) * 128 + VB * cb + r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, row = min(t0 + (e >> 5), a.S - 1), c4 = (e & 31) << 2;
+            kreg[i] = *(const f32x4*)(a.pre_k + (size_t)row * a.key_dim + kh * K + c4);
+        }
+        glane = ck[2 * C * 128 + C * C + lane];
+    };
+    auto park_k = [&](int c) __attribute__((always_inline)) {          // k^ rows + cumulative log decay of chunk c -> LDS
+        const int nt = min(C, a.S - c * C);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i, row = e >> 5, c4 = (e & 31) << 2;
+            *(f32x4*)&Ks[row][c4] = row < nt ? kreg[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (wave == 0) lgs[lane] = glane;
+    };
+    fetch(0);
+    park_k(0);
+    lds_barrier();
+    for (int c = 0; c < nchunks; ++c) {
+        const int t0 = c * C, nt = min(C, a.S - t0);
+        // ---- U = U0 - W S0 and Q S0 (same B operand): wave w owns token rows 16 w .. 16 w + 15 ----
+        f32x4 accU = {0.f, 0.f, 0.f, 0.f}, accQ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 bs = *(const f32x4*)&St[r][16 * j + 4 * kq];
+            accU = mfma4(aw[j], bs, accU);
+            accQ = mfma4(aq[j], bs, accQ);
+        }
+        const float gC = lgs[C - 1];
+        f32x4 u, ud, pc[4];
+        float eg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = 16 * wave + 4 * kq + i;
+            const float gt = lgs[t];
+            u[i] = u0[i] - accU[i];
+            ud[i] = u[i] * expf(gC - gt);
+            eg[i] = expf(gt);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pc[j] = ap[j];
+        *(f32x4*)&Ut[r][16 * wave + 4 * kq] = u;
+        *(f32x4*)&Vt[r][16 * wave + 4 * kq] = ud;
+        fetch(c + 1);                                  // (aw / aq / ap / u0 of this chunk are consumed or copied; kreg / glane are parked below)
+        lds_barrier();
+        // ---- Y = e^G (Q S0) + P U ----
+        f32x4 accP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 bu = *(const f32x4*)&Ut[r][16 * j + 4 * kq];
+            accP = mfma4(pc[j], bu, accP);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = 16 * wave + 4 * kq + i;
+            if (t < nt) a.out[(size_t)(t0 + t) * a.out_stride + h * V + VB * cb + r] = eg[i] * accQ[i] + accP[i];      // raw; gdn_post_kernel normalises
+        }
+        // ---- S_C = e^{G_C} S0 + K^T (e^{G_C - G} U): wave w owns state rows k = 32 w .. 32 w + 31 ----
+        f32x4 sn[2];
+        const float eC = expf(gC);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 accS = {0.f, 0.f, 0.f, 0.f};
+            const int kr = 32 * wave + 16 * mt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 bv = *(const f32x4*)&Vt[r][16 * j + 4 * kq];
+                f32x4 ak;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ak[i] = Ks[16 * j + 4 * kq + i][kr + r];
+                accS = mfma4(ak, bv, accS);
+            }
+            const f32x4 old = *(const f32x4*)&St[r][kr + 4 * kq];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sn[mt][i] = eC * old[i] + accS[i];
+        }
+        lds_barrier();                               // every read of St / Ut / Vt / Ks / lgs of this chunk is done
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) *(f32x4*)&St[r][32 * wave + 16 * mt + 4 * kq] = sn[mt];
+        park_k(c + 1);
+        lds_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, k = e >> 4, col = e & 15;
+        Sg[k * V + VB * cb + col] = St[col][k];
+    }
+}
+
 __global__ __launch_bounds__(128) void gdn_post_kernel(GdnArgs a) {
     constexpr int V = 128;
     __shared__ float red[2];
@@ -394,6 +695,17 @@ void launch_gdn(const GdnArgs& a, hipStream_t s) {
     if (a.st == nullptr && a.pre_q != nullptr && a.S >= 16 && a.n_seq <= 1) {
         const int nk = a.NV / a.vpg;
         hipLaunchKernelGGL(gdn_pre_kernel, dim3(a.S, nk + a.NV), dim3(128), 0, s, a);
+        // prompts of a chunk or more: the chunk-parallel scan on the f32 matrix cores (CM_GDN_CHUNKED=0: the sequential scan, A/B)
+        static const int ck_env = getenv("CM_GDN_CHUNKED") ? atoi(getenv("CM_GDN_CHUNKED")) : 1;
+        if (a.ck != nullptr && a.pre_g != nullptr && ck_env != 0 && a.S >= GDN_CK) {
+            static DevOnce attr;
+            attr.run([&] {
+                (void)hipFuncSetAttribute((const void*)gdn_chunk_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gdn_chunk_prep_lds());
+                (void)hipFuncSetAttribute((const void*)gdn_chunk_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gdn_chunk_scan_lds());
+            });
+            hipLaunchKernelGGL(gdn_chunk_prep_kernel, dim3((a.S + GDN_CK - 1) / GDN_CK, a.NV), dim3(256), gdn_chunk_prep_lds(), s, a);
+            hipLaunchKernelGGL(gdn_chunk_scan_kernel, dim3(a.NV, 128 / 16), dim3(256), gdn_chunk_scan_lds(), s, a);
+        } else
         hipLaunchKernelGGL(gdn_scan_kernel, dim3(a.NV, 4), dim3(512), 0, s, a);
         hipLaunchKernelGGL(gdn_post_kernel, dim3(a.S, a.NV), dim3(128), 0, s, a);
         return;

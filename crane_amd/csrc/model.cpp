@@ -1090,6 +1090,9 @@ void Model::ensure_prefill_buffers() {
         gdn_pre_k = dalloc<float>((size_t)chunk * cfg.key_dim());
         gdn_pre_v = dalloc<float>((size_t)chunk * cfg.value_dim());
         gdn_pre_bd = dalloc<float>((size_t)chunk * cfg.NV * 2);
+        gdn_pre_g = dalloc<float>((size_t)chunk * cfg.NV);
+        if (cfg.Kd == 128 && cfg.Vd == 128)           // chunk-parallel scan scratch: W | U0 | P | G per (64-token chunk, value head)
+            gdn_ck = dalloc<float>((size_t)((chunk + GDN_CK - 1) / GDN_CK) * cfg.NV * GDN_CK_FLOATS);
     }
     auto z = [&](size_t n) {
         uint16_t* p = dalloc<uint16_t>(n);
@@ -1156,7 +1159,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
             ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
             ga.n_seq = 1;
-            ga.pre_q = gdn_pre_q; ga.pre_k = gdn_pre_k; ga.pre_v = gdn_pre_v; ga.pre_bd = gdn_pre_bd;
+            ga.pre_q = gdn_pre_q; ga.pre_k = gdn_pre_k; ga.pre_v = gdn_pre_v; ga.pre_bd = gdn_pre_bd; ga.pre_g = gdn_pre_g; ga.ck = gdn_ck_on ? gdn_ck : nullptr;
             // the conv windows are double-buffered by position parity: every launch must advance an ODD
             // number of positions, so an even chunk is scanned as (S-1) + 1.  One scan per sequence of the pass (its own state slot).
             for (int gi = 0; gi < nseg; ++gi) {

@@ -302,7 +302,8 @@ struct Model {
     float *kshadow = nullptr, *vshadow = nullptr;   // int8/int4 KV prefill: dequantised f32 K/V of ONE layer, identity pages
     int32_t* d_ident_bt = nullptr;                  // [max_pages_per_seq] 0, 1, 2, ...
     uint16_t* wq_scratch = nullptr;    // [max N*K] bf16: one dequantised matrix at a time for the prefill GEMMs
-    float *gdn_pre_q = nullptr, *gdn_pre_k = nullptr, *gdn_pre_v = nullptr, *gdn_pre_bd = nullptr;   // GDN prefill scratch
+    bool gdn_ck_on = true;                      // cm_debug_set("gdn_chunked"): prompts of >= 64 tokens take the chunk-parallel Gated-Delta-Net scan
+    float *gdn_pre_q = nullptr, *gdn_pre_k = nullptr, *gdn_pre_v = nullptr, *gdn_pre_bd = nullptr, *gdn_pre_g = nullptr, *gdn_ck = nullptr;   // GDN prefill scratch
     float* yb = nullptr;               // [MAXB][H] TP partial sums of the batched step
     int lm_gridb = 0;                  // row length of a pmaxb / pidxb slab
     float* gu_tmpb = nullptr;          // [MAXB][2 I] the same for the batched step

@@ -180,6 +180,46 @@ def test_hip_qwen35_prefill_equals_token_serial(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,n,chunk", [("tiny-qwen3.5", 64, 0), ("tiny-qwen3.5", 65, 0), ("tiny-qwen3.5", 201, 0), ("tiny-qwen3.5", 300, 128),
+                                          ("qwen3.8-27b", 193, 0), ("qwen3.5-0.8b", 1024, 0)])
+def test_chunk_parallel_delta_rule_scan_equals_the_sequential_scan(name, n, chunk):
+    """Prompts of >= 64 tokens run the Gated-Delta-Net recurrence in its chunk-parallel (WY / UT-transform) form on the f32 matrix
+    cores (gdn_chunk_prep_kernel + gdn_chunk_scan_kernel; the reference names it as the prompt-path algorithm,
+    ops/gdn/backend.rs:100-104, HF = torch_chunk_gated_delta_rule): same logits as the sequential scan of the same handle
+    (cm_debug_set("gdn_chunked", 0)) to f32 summation order, the SAME recurrent state afterwards (a decode step on top), and the
+    oracle's token-serial recurrence (ops/gdn/backend.rs:90-156) where the CPU side is cheap.  Whole chunks, a one-token tail
+    chunk, ragged tails, prompts split over several passes (state carried between them), the 27B head geometry (3 value heads
+    per key head, 48 heads) and a 1024-token prompt at the Qwen3.5-0.8B widths."""
+    from crane_amd.backend import Model
+    cfg = dict(configs.get_config(name))
+    if cfg.get("num_hidden_layers", 0) > 4:
+        cfg.update(num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+        if "layer_types" in cfg: cfg["layer_types"] = cfg["layer_types"][:4]
+    kw = dict(prefill_chunk=chunk) if chunk else {}
+    m = Model.synthetic(cfg, seed=0, max_seq_len=max(256, n + 64), max_seqs=2, kv_dtype="f32", **kw)
+    try:
+        V = cfg["vocab_size"]
+        ids = configs.synthetic_prompt(n, V)
+        outs = []
+        for mode in (1, 0):
+            m.debug_set("gdn_chunked", mode)
+            m.clear_kv_cache()
+            a = m.forward_step(ids, 0)[0, 0].copy()
+            b = m.forward_step([5], n)[0, 0].copy()              # reads the recurrent state the prompt pass left
+            outs.append((a, b))
+        assert rel(outs[0][0], outs[1][0]) < 1e-4, rel(outs[0][0], outs[1][0])
+        assert rel(outs[0][1], outs[1][1]) < 1e-4, rel(outs[0][1], outs[1][1])
+        assert int(outs[0][0].argmax()) == int(outs[1][0].argmax())
+        if name == "tiny-qwen3.5":
+            w = synth.synth_weights_f32(cfg, seed=0)
+            o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
+            assert rel(outs[0][0], o.forward(ids, 0)) < 1e-4
+            assert rel(outs[0][1], o.forward([5], n)) < 1e-4
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
 def test_hip_qwen35_batched_decode():
     """batched step on the hybrid model: per-sequence GDN state slots + per-sequence KV pages in one pass."""
     from crane_amd.backend import Model
