@@ -451,7 +451,7 @@ class Model:
 
     _KERNEL_NAMES = {"qkv": "gemv<rmsnorm,store>", "o": "gemv<plain,resadd>", "gate_up": "gemv<rmsnorm,silu_mul>",
                      "down": "gemv<plain,resadd>", "lm_head": "gemv<rmsnorm,argmax>",
-                     "chain": "engine_kernel (persistent: whole token, or one layer's o_proj+gate_up+down_proj+next QKV)"}
+                     "chain": "engine_kernel (persistent: whole token incl. embedding row, final norm + lm_head and arg-max partials; or one layer's o_proj+gate_up+down_proj+next QKV)"}
 
     def bench_kernel(self, which: str, iters: int = 360) -> dict:
         ms = C.c_float()

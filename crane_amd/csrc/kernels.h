@@ -299,7 +299,8 @@ struct EngArgs {
     int* pidx;                    //   logit it produced and its row (strict > / lowest index), [grid * stream waves]; null: no arg-max
     int embed_V;
     int idx_base;                 // head phase: global index of row 0 (vocabulary shard of a tensor-parallel rank)
-    int nsplit;                   // in-kernel attention: token splits per kv head (<= 32); workgroups [0, Hkv * nsplit) run it
+                                  // (in-kernel attention: min(32, grid / Hkv) token splits per kv head, workgroups [0, Hkv * splits) run it -- computed
+                                  // in the kernel: as an argument it doubled the SGPR spills of the headline instantiation and cost it 17 %)
     float* vout;                  // plain_last: output vector of phase p1 - 1 (read by a later kernel)
     float* xres;                  // [H] residual stream (read at entry, written back at exit)
     uint32_t* ctl;                // [0] epoch base (advanced by every launch), [1] error code (0 = none)

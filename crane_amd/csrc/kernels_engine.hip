@@ -170,12 +170,15 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         size_t a_koff[NPRE], a_eoff = 0;
         int a_tt[NPRE];
         bool a_owner = false;
+        int a_kvh = 0, a_split = 0, a_nsplit = 1;        // this workgroup's (kv head, token split) and the splits per kv head, once per launch
+        bool a_attwg = false;                             //   (integer divisions: not on the per-layer critical path)
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) { a_koff[u] = 0; a_tt[u] = 0; }
         if (a.attn != nullptr) {
-            // (a.nsplit <= 32 token splits per kv head; workgroups past Hkv * nsplit -- one kv head per rank under tensor parallelism
+            // (at most 32 token splits per kv head; workgroups past Hkv * nsplit -- one kv head per rank under tensor parallelism
             // leaves 224 of 256 -- take no part in the attention: their loads below stay in bounds and are never consumed)
-            const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, nsplit = a.nsplit, split = (blockIdx.x / Hkv) % nsplit;
+            const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, nsplit = min(32, (int)gridDim.x / Hkv), split = (blockIdx.x / Hkv) % nsplit;
+            a_kvh = kvh; a_split = split; a_nsplit = nsplit; a_attwg = (int)blockIdx.x < Hkv * nsplit;
             const int tok_in_chunk = cw * 4 + (lane >> 4), dimbase = (lane & 15) * 8;
             const CM_GLOBAL int32_t* bt = (const CM_GLOBAL int32_t*)a.block_table;
             a_pos = ((const CM_GLOBAL StepState*)a.st)->pos;
@@ -208,10 +211,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 continue;
             }
             stamp(p - p0, 0);
-            if (P->pre_attn && !dbg_noattn && (int)blockIdx.x < a.Hkv * a.nsplit) {
+            if (P->pre_attn && !dbg_noattn && a_attwg) {
                 // ================= attention of this layer (split `blockIdx / Hkv` of kv head `blockIdx % Hkv`) =================
                 const CM_CONST EngAttnL* AL = (const CM_CONST EngAttnL*)a.attn + P->layer;
-                const int Hkv = a.Hkv, kvh = blockIdx.x % Hkv, split = blockIdx.x / Hkv, nsplit = a.nsplit;
+                const int Hkv = a.Hkv, kvh = a_kvh, split = a_split, nsplit = a_nsplit;
                 const int r = lane >> 4, sub = lane & 15, dimbase = sub * 8, tok_in_chunk = cw * 4 + r;
                 const uint32_t tag = base + (uint32_t)P->in_tag;     // QKV, partials and merged output of this layer share it
                 float* qs = asc;                          // [NREP][AD]
@@ -500,7 +503,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     }
                     // a pass past the end of a vector whose length is a multiple of 512 only (K = 512, 1536): the upper half is padding
                     // -- never tagged (excluded from `ok`), staged as zeros; buffers are sized in whole passes
-                    const bool tail = (pass + 1) * 1024 > K;
+                    // (only in the 512-element-chunk instantiation: the selects below cost the 2048-chunk kernel of the headline 17 %
+                    // -- more live scalars in the comm path, twice the SGPR spills, a slower stream loop -- when they were unconditional)
+                    const bool tail = UC == 1 && (pass + 1) * 1024 > K;
                     if (nw != nullptr) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) wv[i] = nw[(tail && i >= 8) ? lane : kb + i * 64];
@@ -753,7 +758,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         if (cplain) {
                             cvout[r0 + lane] = mine;
                             // (rows ascend along a wave's groups, so strict > keeps the lowest index of equal logits)
-                            if (mine > best_v) { best_v = mine; best_i = a.idx_base + r0 + lane; }
+                            if (mine > best_v) { best_v = mine; best_i = r0 + lane; }
                         } else if (cout >= 0) gran_st(G + r0 + lane, ctag, mine);
                     }
                 }
@@ -823,7 +828,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         if (lane == 0) {
             const bool take = ov > best_v || (ov == best_v && oi < best_i);
             a.pmax[gwid] = take ? ov : best_v;
-            a.pidx[gwid] = take ? oi : best_i;
+            a.pidx[gwid] = (take ? oi : best_i) + a.idx_base;      // (global row index: vocabulary shard of a tensor-parallel rank)
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[0] = base + (uint32_t)a.epoch_step;

@@ -564,7 +564,6 @@ EngArgs Model::engine_args_common() const {
     e.eps = cfg.eps; e.scale = (float)(1.0 / std::sqrt((double)cfg.D));
     e.kv_f16 = kv_mode == KV_F16 ? 1 : 0;
     e.nrep = nrep; e.chunk = eng_chunk;
-    e.nsplit = std::min(32, num_cu / std::max(1, Hkv_l));
     e.dbg = eng_dbg; e.tune = eng_tune;
     return e;
 }
