@@ -228,8 +228,20 @@ def main():
         emulated = have < tpg
         devs = [0] * tpg if emulated else list(range(tpg))
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-        m = Model.synthetic(cfg, seed=0, max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1, use_graph=-1 if args.no_graph else 0,
-                            tp_size=tpg, tp_in_process=True, tp_devices=devs, tp_collective=args.tp_collective, kv_dtype=args.kv)
+        mk = lambda coll: Model.synthetic(cfg, seed=0, max_seq_len=max(2048, ctx + K + W + 64), max_seqs=1, use_graph=-1 if args.no_graph else 0,
+                                          tp_size=tpg, tp_in_process=True, tp_devices=devs, tp_collective=coll, kv_dtype=args.kv)
+        tp_fallback = None
+        try:
+            m = mk(args.tp_collective)
+        except Exception as e:
+            # RCCL inside ONE process (a communicator rank per library thread, collectives captured into one hipGraph per rank) has
+            # never run on more than one rank in this repository: if the group cannot be created on distinct devices, say why and
+            # take the library's own peer-store exchange (kernels_tp.hip) instead of failing the run
+            if emulated or args.tp_collective == "peer":
+                raise
+            tp_fallback = f"RCCL in-process group failed ({type(e).__name__}: {str(e)[:200]}); fell back to --tp-collective peer"
+            print("bench.py: " + tp_fallback, file=sys.stderr, flush=True)
+            m = mk("peer")
         if m.tp_ranks() != tpg:
             raise SystemExit(f"library reports {m.tp_ranks()} rank(s), expected {tpg}")
         n = tpg if not emulated else 1
@@ -468,7 +480,9 @@ def main():
             line["config"]["force_rccl"] = True
         if tpg:
             line["config"]["tp_host"] = "ONE handle, cm_opts.tp_mode = CM_TP_IN_PROCESS (library worker threads)"
-            line["config"]["tp_collective"] = ("peer-store kernels (kernels_tp.hip)" if emulated or args.tp_collective == "peer" else "RCCL")
+            line["config"]["tp_collective"] = ("peer-store kernels (kernels_tp.hip)" if emulated or args.tp_collective == "peer" or tp_fallback else "RCCL")
+            if tp_fallback:
+                line["config"]["tp_collective_fallback"] = tp_fallback
             line["config"]["parallelism"] = f"tp{tpg}"
             if emulated:
                 line["metric"] += f" -- TP={tpg} group with EVERY rank on one GPU (emulated: functional check, not an N-GPU time)"
