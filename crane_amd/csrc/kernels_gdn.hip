@@ -570,9 +570,11 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
     // One wave per SIMD: nothing hides a load but the wave's own work, so the operands of chunk c + 1 (this wave's 16 rows of W,
     // q^, P, its U0 values, its share of the k^ rows, the cumulative log decay) are requested into registers while chunk c is
     // multiplied -- unconditionally (rows / chunks past the end are clamped and never consumed: DESIGN 3.13).
-    f32x4 aw[8], aq[8], ap[4], kreg[8];
+    // Register sets: W / q^ rows (needed FIRST in a chunk) are requested TWO chunks ahead into two alternating sets, the rest
+    // (P rows, U0 values, k^ rows, cumulative log decay: needed later in the chunk) one chunk ahead.
+    f32x4 awA[8], aqA[8], awB[8], aqB[8], ap[4], kreg[8];
     float u0[4], glane = 0.f;
-    auto fetch = [&](int c) __attribute__((always_inline)) {
+    auto fetch_wq = [&](int c, f32x4 (&aw)[8], f32x4 (&aq)[8]) __attribute__((always_inline)) {
         const int cc = min(c, nchunks - 1), t0 = cc * C;
         const float* ck = a.ck + ((size_t)cc * a.NV + h) * GDN_CK_FLOATS;
         const int qrow = min(t0 + 16 * wave + r, a.S - 1);
@@ -581,10 +583,18 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
             aw[j] = *(const f32x4*)(ck + (16 * wave + r) * 128 + 16 * j + 4 * kq);
             aq[j] = *(const f32x4*)(a.pre_q + (size_t)qrow * a.key_dim + kh * K + 16 * j + 4 * kq);
         }
+    };
+    auto fetch_pu = [&](int c) __attribute__((always_inline)) {         // P rows + U0 values of chunk c (issued once the previous ones are consumed)
+        const int cc = min(c, nchunks - 1);
+        const float* ck = a.ck + ((size_t)cc * a.NV + h) * GDN_CK_FLOATS;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ap[j] = *(const f32x4*)(ck + 2 * C * 128 + (16 * wave + r) * C + 16 * j + 4 * kq);
 #pragma unroll
         for (int i = 0; i < 4; ++i) u0[i] = ck[C * 128 + (16 * wave + 4 * kq + i) * 128 + VB * cb + r];
+    };
+    auto fetch_k = [&](int c) __attribute__((always_inline)) {          // k^ rows + cumulative log decay of chunk c: parked in LDS at the END of
+        const int cc = min(c, nchunks - 1), t0 = cc * C;                 //   chunk c - 1, so they are requested at its very beginning
+        const float* ck = a.ck + ((size_t)cc * a.NV + h) * GDN_CK_FLOATS;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i, row = min(t0 + (e >> 5), a.S - 1), c4 = (e & 31) << 2;
@@ -601,11 +611,9 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
         }
         if (wave == 0) lgs[lane] = glane;
     };
-    fetch(0);
-    park_k(0);
-    lds_barrier();
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk = [&](int c, f32x4 (&aw)[8], f32x4 (&aq)[8]) __attribute__((always_inline)) {
         const int t0 = c * C, nt = min(C, a.S - t0);
+        fetch_k(c + 1);
         // ---- U = U0 - W S0 and Q S0 (same B operand): wave w owns token rows 16 w .. 16 w + 15 ----
         f32x4 accU = {0.f, 0.f, 0.f, 0.f}, accQ = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -614,6 +622,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
             accU = mfma4(aw[j], bs, accU);
             accQ = mfma4(aq[j], bs, accQ);
         }
+        fetch_wq(c + 2, aw, aq);                       // this set is free again: the chunk after next
         const float gC = lgs[C - 1];
         f32x4 u, ud, pc[4];
         float eg[4];
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
         for (int j = 0; j < 4; ++j) pc[j] = ap[j];
         *(f32x4*)&Ut[r][16 * wave + 4 * kq] = u;
         *(f32x4*)&Vt[r][16 * wave + 4 * kq] = ud;
-        fetch(c + 1);                                  // (aw / aq / ap / u0 of this chunk are consumed or copied; kreg / glane are parked below)
+        fetch_pu(c + 1);                               // (ap / u0 of this chunk are consumed or copied)
         lds_barrier();
         // ---- Y = e^G (Q S0) + P U ----
         f32x4 accP = {0.f, 0.f, 0.f, 0.f};
@@ -667,6 +676,16 @@ __global__ __launch_bounds__(256) void gdn_chunk_scan_kernel(GdnArgs a) {
         for (int mt = 0; mt < 2; ++mt) *(f32x4*)&St[r][32 * wave + 16 * mt + 4 * kq] = sn[mt];
         park_k(c + 1);
         lds_barrier();
+    };
+    fetch_wq(0, awA, aqA);
+    fetch_pu(0);
+    fetch_k(0);
+    fetch_wq(1, awB, aqB);
+    park_k(0);
+    lds_barrier();
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, awA, aqA);
+        if (c + 1 < nchunks) chunk(c + 1, awB, aqB);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
