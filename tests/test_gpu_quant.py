@@ -396,9 +396,10 @@ def test_large_quantised_decode_groups_on_the_int8_matrix_cores(isq, nb):
     activation row, ggml_vec_dot_q8_0_q8_0 per output; weights through quantize_row_q8_0_ref / _q4_0_ref).
     Teacher-forced where two correct implementations legitimately part ways: the device reports the activation codes each
     projection multiplied (cm_debug_set("q_capture")); the oracle checks each against its own rounding -- a differing code must be
-    ONE step away with the oracle's own pre-rounding value within 2e-3 of the .5 boundary, a differing block scale one f16 step at
-    an f16 tie -- and continues from the device's codes.  With the roundings agreed, logits must match to the f32 summation
-    order: 2e-4 (the bound of the GEMV tests), no allowance for code flips; greedy ids = arg-max of the returned rows.
+    ONE step away with the oracle's own pre-rounding value within 5e-4 of the .5 boundary (measured: <= 6.5e-5), a differing block
+    scale one f16 step at an f16 tie -- and continues from the device's codes.  With the roundings agreed, logits must match to the
+    f32 summation order: 2e-5 of the logit range (measured 3.4e-7; the GEMV tests' bound is 2e-4), no allowance for code flips;
+    greedy ids = arg-max of the returned rows.  (Measured: 1.1e-5 of the codes are such ties -- 73 of 6.4 M at 40 rows.)
     Three rounds from empty sequences: rounds 2 and 3 attend over the K/V rows (f32 pages) the earlier rounds wrote."""
     from crane_amd.backend import Model
     from oracle.qgroup_oracle import parse_captures
@@ -416,11 +417,11 @@ def test_large_quantised_decode_groups_on_the_int8_matrix_cores(isq, nb):
             n = int(m.debug_read("q_capture_len", 1)[0])
             caps = parse_captures(m.debug_read("q_capture", n))
             assert len(caps) == 4 * cfg["num_hidden_layers"] + 1, len(caps)      # every projection input + the head's: all on the int8 path
-            ref = orc.step(seqs, toks, caps)
+            ref = orc.step(seqs, toks, caps, tie_tol=5e-4)
             for b in range(nb):
                 e = rel(got[b, 0], ref[b])
                 worst = max(worst, e)
-                assert e < 2e-4, (rnd, b, e)
+                assert e < 2e-5, (rnd, b, e)
                 assert int(gg[b]) == int(got[b, 0].argmax())
             toks = [int(t) for t in gg]
         st = orc.stats
