@@ -13,6 +13,8 @@
 //     (mfma 16x16x16, V fragments through ds_read_b64_tr_b16), nothing O(S*L) in HBM.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -620,6 +622,198 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a_in) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path of the causal prompt attention (round 5): head_dim 128, 2-byte pages (f16 / bf16), page size a multiple of the
+// 64-token key tile, no output gate -- the dense family's prompt pass.  Same tiling, fragments and arithmetic as
+// attn_prefill_kernel above (S^T = K Q^T with q as hi + lo, online softmax per query column, O^T += V^T P^T with P as hi + lo);
+// what changed is everything AROUND the 96 MFMAs of a key tile, which the ISA of the general kernel shows at ~870 VALU
+// instructions per tile and wave (3500 cycles against 1024 of matrix-core issue):
+//   * a key tile lies inside ONE page (tile start and page size are multiples of 64): one scalar page-table lookup per tile,
+//     K rows and V rows at compile-time offsets from one base -- no per-row division, clamp and 64-bit address chain;
+//   * only the tiles that touch the diagonal (or the end of the context) are masked and clamped: two loop bodies;
+//   * the softmax runs in the exp2 domain (one FMA + v_exp_f32 per score), P is split with packed conversions;
+//   * K AND V go through LDS once per workgroup, double-buffered (comment at kv_fetch): one workgroup barrier per tile.
+// ---------------------------------------------------------------------------------------------
+template <int KVT>
+__device__ __forceinline__ void p_split4(const float (&p)[4], bf16x4& hi, bf16x4& lo) {
+    if constexpr (KVT == KV_F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(p[0], p[1]));
+        const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(p[2], p[3]));
+        const h2 c = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(p[0] - (float)a[0], p[1] - (float)a[1]));
+        const h2 d = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(p[2] - (float)b[0], p[3] - (float)b[1]));
+        const u32x2 hv = {__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+        const u32x2 lv = {__builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d)};
+        hi = __builtin_bit_cast(bf16x4, hv); lo = __builtin_bit_cast(bf16x4, lv);
+    } else {
+        const uint32_t a = pack_bf16x2(p[0], p[1]), b = pack_bf16x2(p[2], p[3]);
+        const uint32_t c = pack_bf16x2(p[0] - bf16_lo(a), p[1] - bf16_hi(a)), d = pack_bf16x2(p[2] - bf16_lo(b), p[3] - bf16_hi(b));
+        const u32x2 hv = {a, b}, lv = {c, d};
+        hi = __builtin_bit_cast(bf16x4, hv); lo = __builtin_bit_cast(bf16x4, lv);
+    }
+}
+
+template <int KVT>
+__global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in) {
+    constexpr int D = 128, KT = 64, VLD = D + 16, NKS = D / 32, NNT = D / 16;
+    constexpr float L2E = 1.4426950408889634f;
+    AttnPreArgs a = a_in;
+    int qt_seg = -1;
+    if (a.tiles != nullptr) {         // causal pass over several sequences: this workgroup's (sequence, query tile), longest first
+        const int2 tq = a.tiles[gridDim.y - 1 - blockIdx.y];
+        const PrefillSegDev sg = a.segs[tq.x];
+        const size_t r0 = (size_t)sg.row0 * a.Hq * D;
+        a.S = sg.S; a.start_pos = sg.start_pos; a.block_table += sg.bt_off;
+        a.q_hi += r0; a.out_hi += r0;
+        if (a.q_lo != nullptr) a.q_lo += r0;
+        if (a.out_lo != nullptr) a.out_lo += r0;
+        qt_seg = tq.y;
+    }
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KT * VLD];
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KT * (D + 8)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, kvh = h / a.nrep;
+    const int qb = (qt_seg >= 0 ? qt_seg : (int)(gridDim.y - 1 - blockIdx.y)) * 64;      // longest query tile first (LPT)
+    const int qrow = qb + wave * 16 + sub;
+    const int qrow_c = qrow < a.S ? qrow : a.S - 1;
+    const int qpos = a.start_pos + qrow;
+    bf16x8 qh[NKS], ql[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const size_t off = ((size_t)qrow_c * a.Hq + h) * D + ks * 32 + g * 8;
+        qh[ks] = *(const bf16x8*)(a.q_hi + off);
+        ql[ks] = *(const bf16x8*)(a.q_lo + off);
+    }
+    f32x4 o[NNT];
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int last_q = min(qb + 63, a.S - 1);
+    const int kv_end = a.start_pos + last_q + 1;
+    const int ntile = (kv_end + KT - 1) / KT;
+    const int nfull = (a.start_pos + qb + 1) / KT;          // tiles every query of the block sees completely (and that end before kv_end)
+    const uint16_t* kpool = (const uint16_t*)a.kpool;
+    const uint16_t* vpool = (const uint16_t*)a.vpool;
+    // element offset of the first row of key tile t inside the pool (one page per tile).  The page ids of 64 consecutive tiles sit
+    // in one VGPR (lane i: tile 64 grp + i) and are picked with v_readlane: a scalar load of the table entry per tile and use
+    // was ~1 us of exposed latency twice per tile -- the first version of this kernel ran 82 us against the general kernel's 73
+    const int tpp = a.page / KT;                            // key tiles per page
+    const int npg = (kv_end + a.page - 1) / a.page;         // pages of the context
+    int pgs_grp = 0;
+    int pgs = a.block_table[min(lane / tpp, npg - 1)];
+    auto tile_base = [&](int t) __attribute__((always_inline)) -> size_t {
+        if ((t >> 6) != pgs_grp) {                           // (uniform; every 64 tiles)
+            pgs_grp = t >> 6;
+            pgs = a.block_table[min((pgs_grp * 64 + lane) / tpp, npg - 1)];
+        }
+        const int pg = __builtin_amdgcn_readlane(pgs, t & 63);
+        return ((size_t)(pg * a.Hkv + kvh) * a.page + ((t * KT) % a.page)) * D;
+    };
+    // K and V rows of a tile go through LDS ONCE per workgroup: thread c = tid + 256 i covers token c / 16, dims (c % 16) * 8 .. + 8
+    // (whole 256-byte rows, coalesced).  The general kernel's waves each fetch the K tile themselves as MFMA A fragments -- 16
+    // wave-loads of 16 rows x 64 bytes, the same 16 KB four times per workgroup: ablated (no K loads in the loop) this kernel ran
+    // 41 us instead of 73, with the K rows prefetched into registers still 69.  K rows in LDS are 272 bytes apart (the 16 rows of a
+    // fragment read start 4 banks apart); both tiles are double-buffered: the next tile's rows are requested before this tile's
+    // products and parked after them -- one workgroup barrier per tile.
+    constexpr int KLD = D + 8;
+    const int vtok = tid >> 4, vd8 = (tid & 15) * 8;
+    u32x4 vreg[4], kreg[4];
+    auto kv_fetch = [&](int t) __attribute__((always_inline)) {
+        const int tc = min(t, ntile - 1);                   // (past the end: the last tile again, parked into buffers nobody reads)
+        const size_t b = tile_base(tc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tok = min(vtok + 16 * i, kv_end - 1 - tc * KT);
+            kreg[i] = ld16(kpool + b + (size_t)tok * D + vd8);
+            vreg[i] = ld16(vpool + b + (size_t)tok * D + vd8);
+        }
+    };
+    auto kv_park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)&Ks[buf][(vtok + 16 * i) * KLD + vd8] = kreg[i];
+            *(u32x4*)&Vs[buf][(vtok + 16 * i) * VLD + vd8] = vreg[i];
+        }
+    };
+    auto tile = [&](int t, auto masked_c) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        const int t0 = t * KT;
+        kv_fetch(t + 1);
+        // ---- S^T = K . Q^T for 4 sub-tiles of 16 tokens (A fragments: this lane's K row, 16 bytes per k-step, from LDS) ----
+        const uint16_t* Kb = Ks[t & 1];
+        f32x4 s[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            s[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kh = *(const bf16x8*)&Kb[(tt * 16 + sub) * KLD + ks * 32 + g * 8];
+                s[tt] = mma_k32<KVT>(kh, qh[ks], s[tt]);
+                s[tt] = mma_k32<KVT>(kh, ql[ks], s[tt]);
+            }
+        }
+        // ---- (mask +) online softmax in the exp2 domain ----
+        float mt = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MASKED) { if (t0 + tt * 16 + g * 4 + r > qpos) s[tt][r] = -INFINITY; }
+                mt = fmaxf(mt, s[tt][r]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);               // finite: token 0 is visible to every query
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+        const float nm = -m_new * L2E;
+        float psum = 0.f;
+        bf16x4 ph[4], pl[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[tt][r], L2E, nm)); psum += p[r]; }
+            p_split4<KVT>(p, ph[tt], pl[tt]);
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) { o[nt][0] *= alpha; o[nt][1] *= alpha; o[nt][2] *= alpha; o[nt][3] *= alpha; }
+        // ---- O^T += V^T . P^T : A = V^T fragment (tr-read from this tile's LDS buffer), B = P^T fragment ----
+        const uint16_t* Vb = Vs[t & 1];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+            for (int nt = 0; nt < NNT; ++nt) {
+                const uint16_t* vp = &Vb[(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
+                const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)vp);
+                o[nt] = mma_k16<KVT>(vh, ph[tt], o[nt]);
+                o[nt] = mma_k16<KVT>(vh, pl[tt], o[nt]);
+            }
+        }
+        kv_park((t + 1) & 1);                               // the other buffers: last read one iteration ago, behind that iteration's barrier
+        __syncthreads();
+    };
+    kv_fetch(0);
+    kv_park(0);
+    __syncthreads();
+    int t = 0;
+    for (; t < nfull; ++t) tile(t, std::false_type{});     // tiles every query of the block sees completely
+    for (; t < ntile; ++t) tile(t, std::true_type{});      // the diagonal / ragged tiles: masked
+    // ---- finalize: l over the 4 lane groups; O^T rows = dims nt*16 + g*4 + r, col = query `sub` ----
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_run;
+    if (qrow < a.S) {
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+            const float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+            split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
+        }
+    }
+}
+
 // merge of the ksplit partials of attn_prefill_kernel: out = sum_z e^(m_z - M) o_z / sum_z e^(m_z - M) l_z, stored as bf16 hi + lo
 // (the A operand of the projection GEMM).  One thread per (query row, head, 4 dims).
 template <int D>
@@ -983,6 +1177,14 @@ void launch_attn_prefill(const AttnPreArgs& a0, int D, int kvt, hipStream_t s) {
             hipLaunchKernelGGL((attn_prefill_merge_kernel<64>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
         }
     } else if (D == 128) {
+        // the dense family's causal prompts over 2-byte pages: the fast path (CM_ATTN_PREFILL_FAST=0: the general kernel, A/B)
+        static const int fast_env = getenv("CM_ATTN_PREFILL_FAST") ? atoi(getenv("CM_ATTN_PREFILL_FAST")) : 1;
+        if (fast_env != 0 && a.causal && a.gate == nullptr && a.ksplit == 1 && (kvt == KV_F16 || kvt == KV_BF16) && a.page % 64 == 0 &&
+            a.q_lo != nullptr) {
+            if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_fast_kernel<KV_F16>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_prefill_fast_kernel<KV_BF16>), grid, dim3(256), 0, s, a);
+            return;
+        }
         if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F32>), grid, dim3(256), 0, s, a);
         else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F16>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_prefill_kernel<128, KV_BF16>), grid, dim3(256), 0, s, a);
