@@ -634,6 +634,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a_in) {
 //   * the softmax runs in the exp2 domain (one FMA + v_exp_f32 per score), P is split with packed conversions;
 //   * K AND V go through LDS once per workgroup, double-buffered (comment at kv_fetch): one workgroup barrier per tile.
 // ---------------------------------------------------------------------------------------------
+// workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its outstanding global loads
+// (__syncthreads() drains vmcnt as well and would retire the two-tiles-ahead requests at every tile)
+__device__ __forceinline__ void lds_wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int KVT>
 __device__ __forceinline__ void p_split4(const float (&p)[4], bf16x4& hi, bf16x4& lo) {
     if constexpr (KVT == KV_F16) {
@@ -653,9 +661,12 @@ __device__ __forceinline__ void p_split4(const float (&p)[4], bf16x4& hi, bf16x4
     }
 }
 
-template <int KVT>
+// D = 128: 64-token key tiles; D = 256 (the hybrid family's gated attention): 32-token tiles, so that both double-buffered tiles of two
+// workgroups still fit a CU's LDS (69 KB per workgroup either way)
+template <int D, int KT, int KVT>
 __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in) {
-    constexpr int D = 128, KT = 64, VLD = D + 16, NKS = D / 32, NNT = D / 16;
+    constexpr int VLD = D + 16, NKS = D / 32, NNT = D / 16, NTT = KT / 16, CPR = D / 8, RPP = 256 / CPR;      // chunks per row, rows per staging pass
+    static_assert(KT * CPR == 4 * 256, "four 16-byte chunks per thread and tile");
     constexpr float L2E = 1.4426950408889634f;
     AttnPreArgs a = a_in;
     int qt_seg = -1;
@@ -667,6 +678,7 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
         a.q_hi += r0; a.out_hi += r0;
         if (a.q_lo != nullptr) a.q_lo += r0;
         if (a.out_lo != nullptr) a.out_lo += r0;
+        if (a.gate != nullptr) a.gate += (size_t)sg.row0 * a.gate_stride;
         qt_seg = tq.y;
     }
     __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KT * VLD];
@@ -674,7 +686,12 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, kvh = h / a.nrep;
-    const int qb = (qt_seg >= 0 ? qt_seg : (int)(gridDim.y - 1 - blockIdx.y)) * 64;      // longest query tile first (LPT)
+    // query tile of this workgroup: the first half of the grid takes the LONG tiles in descending order, the second half the SHORT ones
+    // in ascending order -- with two workgroups resident per CU (dispatch order, observed: workgroup i and i + 256 share a CU at
+    // 1024 tokens x 32 heads) a 16-tile workgroup is then paired with a 1-tile one instead of an 8-tile one and runs most of its
+    // life alone on its SIMDs.  Placement only affects speed.
+    const int ny = (int)gridDim.y, yy = (int)blockIdx.y, nlong = (ny + 1) / 2;
+    const int qb = (qt_seg >= 0 ? qt_seg : (yy < nlong ? ny - 1 - yy : yy - nlong)) * 64;
     const int qrow = qb + wave * 16 + sub;
     const int qrow_c = qrow < a.S ? qrow : a.S - 1;
     const int qpos = a.start_pos + qrow;
@@ -717,34 +734,37 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
     // fragment read start 4 banks apart); both tiles are double-buffered: the next tile's rows are requested before this tile's
     // products and parked after them -- one workgroup barrier per tile.
     constexpr int KLD = D + 8;
-    const int vtok = tid >> 4, vd8 = (tid & 15) * 8;
-    u32x4 vreg[4], kreg[4];
-    auto kv_fetch = [&](int t) __attribute__((always_inline)) {
+    const int vtok = tid / CPR, vd8 = (tid % CPR) * 8;
+    struct KvRegs { u32x4 k[4], v[4]; };
+    auto kv_fetch = [&](int t, KvRegs& rg) __attribute__((always_inline)) {
         const int tc = min(t, ntile - 1);                   // (past the end: the last tile again, parked into buffers nobody reads)
         const size_t b = tile_base(tc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int tok = min(vtok + 16 * i, kv_end - 1 - tc * KT);
-            kreg[i] = ld16(kpool + b + (size_t)tok * D + vd8);
-            vreg[i] = ld16(vpool + b + (size_t)tok * D + vd8);
+            const int tok = min(vtok + RPP * i, kv_end - 1 - tc * KT);
+            rg.k[i] = ld16(kpool + b + (size_t)tok * D + vd8);
+            rg.v[i] = ld16(vpool + b + (size_t)tok * D + vd8);
         }
     };
-    auto kv_park = [&](int buf) __attribute__((always_inline)) {
+    auto kv_park = [&](int buf, const KvRegs& rg) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(u32x4*)&Ks[buf][(vtok + 16 * i) * KLD + vd8] = kreg[i];
-            *(u32x4*)&Vs[buf][(vtok + 16 * i) * VLD + vd8] = vreg[i];
+            *(u32x4*)&Ks[buf][(vtok + RPP * i) * KLD + vd8] = rg.k[i];
+            *(u32x4*)&Vs[buf][(vtok + RPP * i) * VLD + vd8] = rg.v[i];
         }
     };
-    auto tile = [&](int t, auto masked_c) __attribute__((always_inline)) {
+    // rows are requested TWO tiles ahead (two alternating register sets: a tile's rows are requested at the top of tile t - 2 and
+    // parked at the bottom of tile t - 1): the workgroup barrier at the bottom of a tile drains the wave's loads, so with one tile
+    // of distance a tile lasted as long as an L2 / HBM round trip (~2.4 us against ~1 us of work)
+    auto tile = [&](int t, auto masked_c, KvRegs& rg_new, const KvRegs& rg_next) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_c)::value;
         const int t0 = t * KT;
-        kv_fetch(t + 1);
+        kv_fetch(t + 2, rg_new);
         // ---- S^T = K . Q^T for 4 sub-tiles of 16 tokens (A fragments: this lane's K row, 16 bytes per k-step, from LDS) ----
         const uint16_t* Kb = Ks[t & 1];
-        f32x4 s[4];
+        f32x4 s[NTT];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < NTT; ++tt) {
             s[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
@@ -756,7 +776,7 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
         // ---- (mask +) online softmax in the exp2 domain ----
         float mt = -INFINITY;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (MASKED) { if (t0 + tt * 16 + g * 4 + r > qpos) s[tt][r] = -INFINITY; }
@@ -768,9 +788,9 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
         const float nm = -m_new * L2E;
         float psum = 0.f;
-        bf16x4 ph[4], pl[4];
+        bf16x4 ph[NTT], pl[NTT];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < NTT; ++tt) {
             float p[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[tt][r], L2E, nm)); psum += p[r]; }
@@ -783,7 +803,7 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
         // ---- O^T += V^T . P^T : A = V^T fragment (tr-read from this tile's LDS buffer), B = P^T fragment ----
         const uint16_t* Vb = Vs[t & 1];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
             for (int nt = 0; nt < NNT; ++nt) {
                 const uint16_t* vp = &Vb[(tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4];
@@ -792,15 +812,19 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
                 o[nt] = mma_k16<KVT>(vh, pl[tt], o[nt]);
             }
         }
-        kv_park((t + 1) & 1);                               // the other buffers: last read one iteration ago, behind that iteration's barrier
-        __syncthreads();
+        kv_park((t + 1) & 1, rg_next);                      // the other buffers: last read one iteration ago, behind that iteration's barrier
+        lds_wg_barrier();
     };
-    kv_fetch(0);
-    kv_park(0);
+    KvRegs rA, rB;
+    kv_fetch(0, rA);
+    kv_fetch(1, rB);
+    kv_park(0, rA);
     __syncthreads();
-    int t = 0;
-    for (; t < nfull; ++t) tile(t, std::false_type{});     // tiles every query of the block sees completely
-    for (; t < ntile; ++t) tile(t, std::true_type{});      // the diagonal / ragged tiles: masked
+    // (a tile is "full" when every query of the block sees all of it; the diagonal / ragged tiles are masked)
+    for (int t = 0; t < ntile; t += 2) {
+        if (t < nfull) tile(t, std::false_type{}, rA, rB); else tile(t, std::true_type{}, rA, rB);
+        if (t + 1 < ntile) { if (t + 1 < nfull) tile(t + 1, std::false_type{}, rB, rA); else tile(t + 1, std::true_type{}, rB, rA); }
+    }
     // ---- finalize: l over the 4 lane groups; O^T rows = dims nt*16 + g*4 + r, col = query `sub` ----
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
@@ -808,7 +832,12 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
     if (qrow < a.S) {
 #pragma unroll
         for (int nt = 0; nt < NNT; ++nt) {
-            const float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+            float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+            if (a.gate != nullptr) {        // Qwen3.5: y * sigmoid(gate) (qwen3_5/modeling.rs:556-561)
+                const f32x4 gv = *(const f32x4*)(a.gate + (size_t)qrow * a.gate_stride + h * D + nt * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= 1.0f / (1.0f + expf(-gv[r]));
+            }
             split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
         }
     }
@@ -1181,14 +1210,21 @@ void launch_attn_prefill(const AttnPreArgs& a0, int D, int kvt, hipStream_t s) {
         static const int fast_env = getenv("CM_ATTN_PREFILL_FAST") ? atoi(getenv("CM_ATTN_PREFILL_FAST")) : 1;
         if (fast_env != 0 && a.causal && a.gate == nullptr && a.ksplit == 1 && (kvt == KV_F16 || kvt == KV_BF16) && a.page % 64 == 0 &&
             a.q_lo != nullptr) {
-            if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_fast_kernel<KV_F16>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((attn_prefill_fast_kernel<KV_BF16>), grid, dim3(256), 0, s, a);
+            if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_fast_kernel<128, 64, KV_F16>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_prefill_fast_kernel<128, 64, KV_BF16>), grid, dim3(256), 0, s, a);
             return;
         }
         if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F32>), grid, dim3(256), 0, s, a);
         else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<128, KV_F16>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_prefill_kernel<128, KV_BF16>), grid, dim3(256), 0, s, a);
     } else {
+        // the hybrid family's gated head_dim-256 attention: the same fast path on 32-token key tiles
+        static const int fast_env = getenv("CM_ATTN_PREFILL_FAST") ? atoi(getenv("CM_ATTN_PREFILL_FAST")) : 1;
+        if (fast_env != 0 && a.causal && a.ksplit == 1 && (kvt == KV_F16 || kvt == KV_BF16) && a.page % 64 == 0 && a.q_lo != nullptr) {
+            if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_fast_kernel<256, 32, KV_F16>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_prefill_fast_kernel<256, 32, KV_BF16>), grid, dim3(256), 0, s, a);
+            return;
+        }
         if (kvt == KV_F32) hipLaunchKernelGGL((attn_prefill_kernel<256, KV_F32>), grid, dim3(256), 0, s, a);
         else if (kvt == KV_F16) hipLaunchKernelGGL((attn_prefill_kernel<256, KV_F16>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_prefill_kernel<256, KV_BF16>), grid, dim3(256), 0, s, a);
