@@ -843,6 +843,161 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same staging for the vision tower's frames (round 5): bidirectional attention inside a frame, head_dim 64, K / V scratch
+// pre-split into bf16 hi + lo planes (KV_BF16X2: s = kh.qh + kh.ql + kl.qh, o += vh.ph + vh.pl + vl.ph -- the general kernel's
+// three-product arithmetic), key runs over blockIdx.z with un-normalised partials for attn_prefill_merge_kernel.  Frames that
+// start on a 64-token boundary (every still image; page = 64): a key tile is one page.  All four planes of a tile go through LDS
+// once per workgroup, double-buffered, requested two tiles ahead.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_window_fast_kernel(AttnPreArgs a) {
+    constexpr int D = 64, KT = 64, KLD = D + 8, VLD = D + 16, NKS = D / 32, NNT = D / 16, NTT = KT / 16, CPR = D / 8, RPP = 256 / CPR;
+    constexpr float L2E = 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) uint16_t Kh[2][KT * KLD], Kl[2][KT * KLD];
+    __shared__ __attribute__((aligned(16))) uint16_t Vh[2][KT * VLD], Vl[2][KT * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, kvh = h / a.nrep;
+    const int qb = (int)blockIdx.x * 64;
+    const int qrow = qb + wave * 16 + sub;
+    const int qrow_c = qrow < a.S ? qrow : a.S - 1;
+    bf16x8 qh[NKS], ql[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const size_t off = ((size_t)qrow_c * a.Hq + h) * D + ks * 32 + g * 8;
+        qh[ks] = *(const bf16x8*)(a.q_hi + off);
+        ql[ks] = *(const bf16x8*)(a.q_lo + off);
+    }
+    f32x4 o[NNT];
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int kv_lo = a.kv_lo, kv_end = a.kv_hi;
+    const int ntile_all = (kv_end - kv_lo + KT - 1) / KT, nfull_all = (kv_end - kv_lo) / KT;
+    const int per = (ntile_all + a.ksplit - 1) / a.ksplit;
+    const int ti0 = (int)blockIdx.z * per, ti1 = min(ntile_all, ti0 + per);     // this workgroup's run of key tiles
+    const uint16_t* kpool = (const uint16_t*)a.kpool;
+    const uint16_t* vpool = (const uint16_t*)a.vpool;
+    const size_t lo_off = a.kv_lo_off;
+    const int pg0 = kv_lo / a.page, pglast = (kv_end - 1) / a.page;
+    int pgs_grp = ti0 >> 6;
+    int pgs = a.block_table[min(pg0 + pgs_grp * 64 + lane, pglast)];           // page ids of tiles 64 grp + lane of the frame (page = key tile)
+    auto tile_base = [&](int ti) __attribute__((always_inline)) -> size_t {
+        if ((ti >> 6) != pgs_grp) { pgs_grp = ti >> 6; pgs = a.block_table[min(pg0 + pgs_grp * 64 + lane, pglast)]; }
+        const int pg = __builtin_amdgcn_readlane(pgs, ti & 63);
+        return (size_t)(pg * a.Hkv + kvh) * a.page * D;
+    };
+    const int vtok = tid / CPR, vd8 = (tid % CPR) * 8;
+    struct KvRegs { u32x4 kh[2], kl[2], vh[2], vl[2]; };
+    auto kv_fetch = [&](int ti, KvRegs& rg) __attribute__((always_inline)) {
+        const int tf = min(ti, ntile_all - 1);               // (past the frame: its last tile again, parked into buffers nobody reads)
+        const size_t b = tile_base(tf);
+        const int t0 = kv_lo + tf * KT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int tok = min(vtok + RPP * i, kv_end - 1 - t0);
+            const size_t off = b + (size_t)tok * D + vd8;
+            rg.kh[i] = ld16(kpool + off); rg.kl[i] = ld16(kpool + lo_off + off);
+            rg.vh[i] = ld16(vpool + off); rg.vl[i] = ld16(vpool + lo_off + off);
+        }
+    };
+    auto kv_park = [&](int buf, const KvRegs& rg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(u32x4*)&Kh[buf][(vtok + RPP * i) * KLD + vd8] = rg.kh[i];
+            *(u32x4*)&Kl[buf][(vtok + RPP * i) * KLD + vd8] = rg.kl[i];
+            *(u32x4*)&Vh[buf][(vtok + RPP * i) * VLD + vd8] = rg.vh[i];
+            *(u32x4*)&Vl[buf][(vtok + RPP * i) * VLD + vd8] = rg.vl[i];
+        }
+    };
+    auto tile = [&](int ti, int buf, auto masked_c, KvRegs& rg_new, const KvRegs& rg_next) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        const int t0 = kv_lo + ti * KT;
+        kv_fetch(ti + 2, rg_new);
+        f32x4 s[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            s[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kh = *(const bf16x8*)&Kh[buf][(tt * 16 + sub) * KLD + ks * 32 + g * 8];
+                const bf16x8 kl = *(const bf16x8*)&Kl[buf][(tt * 16 + sub) * KLD + ks * 32 + g * 8];
+                s[tt] = mma_k32<KV_BF16X2>(kh, qh[ks], s[tt]);
+                s[tt] = mma_k32<KV_BF16X2>(kh, ql[ks], s[tt]);
+                s[tt] = mma_k32<KV_BF16X2>(kl, qh[ks], s[tt]);
+            }
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MASKED) { if (t0 + tt * 16 + g * 4 + r >= kv_end) s[tt][r] = -INFINITY; }
+                mt = fmaxf(mt, s[tt][r]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);               // finite: every tile holds at least one token of the frame
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
+        const float nm = -m_new * L2E;
+        float psum = 0.f;
+        bf16x4 ph[NTT], pl[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[tt][r], L2E, nm)); psum += p[r]; }
+            p_split4<KV_BF16X2>(p, ph[tt], pl[tt]);
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) { o[nt][0] *= alpha; o[nt][1] *= alpha; o[nt][2] *= alpha; o[nt][3] *= alpha; }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+            for (int nt = 0; nt < NNT; ++nt) {
+                const int vo = (tt * 16 + g * 4 + (sub >> 2)) * VLD + nt * 16 + (sub & 3) * 4;
+                const bf16x4 vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)&Vh[buf][vo]);
+                const bf16x4 vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)&Vl[buf][vo]);
+                o[nt] = mma_k16<KV_BF16X2>(vh, ph[tt], o[nt]);
+                o[nt] = mma_k16<KV_BF16X2>(vh, pl[tt], o[nt]);
+                o[nt] = mma_k16<KV_BF16X2>(vl, ph[tt], o[nt]);
+            }
+        }
+        kv_park(buf ^ 1, rg_next);
+        lds_wg_barrier();
+    };
+    KvRegs rA, rB;
+    kv_fetch(ti0, rA);
+    kv_fetch(ti0 + 1, rB);
+    kv_park(0, rA);
+    __syncthreads();
+    for (int ti = ti0; ti < ti1; ti += 2) {
+        if (ti < nfull_all) tile(ti, 0, std::false_type{}, rA, rB); else tile(ti, 0, std::true_type{}, rA, rB);
+        if (ti + 1 < ti1) { if (ti + 1 < nfull_all) tile(ti + 1, 1, std::false_type{}, rB, rA); else tile(ti + 1, 1, std::true_type{}, rB, rA); }
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (a.ksplit > 1) {
+        if (qrow < a.S) {
+            const size_t row = ((size_t)blockIdx.z * a.S + qrow) * a.Hq + h;
+#pragma unroll
+            for (int nt = 0; nt < NNT; ++nt) *(f32x4*)(a.part_o + row * D + nt * 16 + g * 4) = o[nt];
+            if (g == 0) { a.part_ml[row * 2] = m_run; a.part_ml[row * 2 + 1] = l_run; }
+        }
+        return;
+    }
+    const float inv = 1.0f / l_run;
+    if (qrow < a.S) {
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+            const float v[4] = {o[nt][0] * inv, o[nt][1] * inv, o[nt][2] * inv, o[nt][3] * inv};
+            split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
+        }
+    }
+}
+
 // merge of the ksplit partials of attn_prefill_kernel: out = sum_z e^(m_z - M) o_z / sum_z e^(m_z - M) l_z, stored as bf16 hi + lo
 // (the A operand of the projection GEMM).  One thread per (query row, head, 4 dims).
 template <int D>
@@ -1200,6 +1355,10 @@ void launch_attn_prefill(const AttnPreArgs& a0, int D, int kvt, hipStream_t s) {
     dim3 grid((a.S + 63) / 64, a.Hq, a.ksplit);
     if (a.causal) grid = dim3(a.Hq, a.tiles != nullptr ? a.ntiles : (a.S + 63) / 64, 1);
     if (D == 64) {
+        static const int fastw_env = getenv("CM_ATTN_PREFILL_FAST") ? atoi(getenv("CM_ATTN_PREFILL_FAST")) : 1;
+        if (fastw_env != 0 && !a.causal && a.gate == nullptr && a.page == 64 && a.kv_lo % 64 == 0 && a.q_lo != nullptr && kvt == KV_BF16X2)
+            hipLaunchKernelGGL(attn_window_fast_kernel, grid, dim3(256), 0, s, a);
+        else
         hipLaunchKernelGGL((attn_prefill_kernel<64, KV_BF16X2>), grid, dim3(256), 0, s, a);     // ViT: K/V scratch pre-split into bf16 hi + lo
         if (a.ksplit > 1) {
             const size_t n4 = (size_t)a.S * a.Hq * (64 / 4);

@@ -173,7 +173,7 @@ struct Model {
     hipEvent_t v_ev0 = nullptr, v_ev1 = nullptr;   // around the tower's kernels of the last vision_encode (cm_debug_read "vision_ms")
     bool v_timed = false;
     float *vPartO = nullptr, *vPartML = nullptr;   // split-KV partials of the frame attention (VIT_KSPLIT runs of key tiles)
-    int vit_ksplit = 4;                             // CM_VIT_KSPLIT
+    int vit_ksplit = 2;                             // CM_VIT_KSPLIT
     uint16_t *vA_hi = nullptr, *vA_lo = nullptr, *vB_hi = nullptr, *vB_lo = nullptr, *vQ_hi = nullptr, *vQ_lo = nullptr;
     int32_t *vIdx = nullptr, *vBt = nullptr, *dMap = nullptr, *dPos3 = nullptr;
     const int32_t* pos3_dev = nullptr;   // set only while a VLM prefill runs
