@@ -99,123 +99,192 @@ void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, s
     else hipLaunchKernelGGL(quant_rows_q8_kernel<false>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K);
 }
 
-// MT m-tiles of 32 rows (M <= 32 MT); grid = (N / 128) * ksplit workgroups of 4 waves, wave w owns weight rows [128 tn + 32 w, + 32).
+// Workgroup tile: 128 weight rows x all M activation rows; 4 MH waves = 4 n-strips of 32 weight rows x MH halves of the activation
+// rows; a wave multiplies its strip with MT m-tiles of 32 rows (M <= 32 MT MH).  MH = 2 (M > 64): 512 threads, ONE workgroup per CU
+// at 2 waves per SIMD -- 256 workgroups fill the chip, half the K split (and half the f32 partials) of 4-wave workgroups.
 // K is walked in GROUPS of QG = 8 blocks (256 codes per row):
 //   * weights: a lane's 8 x 16 bytes of the NEXT group and its 8 block scales (one 16-byte load) are requested while the current
-//     group is multiplied -- 8 KB per wave one group (~2 us of work) ahead; a first version with one block in flight ran 0.6 TB/s;
-//   * activation codes: the group's panel (M rows x 256 bytes) is fetched ONCE per workgroup (16 bytes x 2 MT per thread, into
-//     registers one group ahead, then into one of two LDS panels, the group's block scales next to it), the four waves read their
-//     fragments from there -- loaded by every wave straight from the L2 they were 4 x the weight bytes.  78 KB of LDS at 128 rows:
-//     two workgroups per CU, one's MFMA latency under the other's scaling (the head at 128 rows: 605 -> 412 us);
-//     (measured, wrong results by construction: the same bytes as 1 KB-contiguous wave loads instead of 32 rows x 32 bytes are
-//     only 25 % faster -- the kernel is bound by the VALU work of the scaling, not by its load pattern);
-//   * scaling: 16 int32 per lane and (m-tile, block) -> f32, times dw[n] * dx[m], as packed f32 math (v_pk_mul / v_pk_fma).
-constexpr int QG = 8;
-constexpr int QROWB = QG * 32 + 16;                 // bytes of a panel row in LDS (padded: rows 16 bytes apart in the banks)
+//     group is multiplied -- 8 KB per wave one group (~2 us of work) ahead (the two halves of a strip request the same bytes: the
+//     second is served by the CU's vector cache);
+//   * activation codes: the group's panel (M rows x 256 bytes) is fetched ONCE per workgroup (into registers one group ahead, then
+//     into one of two LDS panels, the group's block scales next to it), the waves read their fragments from there;
+//   * orientation: A = weights, B = activations, so a lane's 16 results of an MFMA are 16 WEIGHT rows x ONE activation row (m = lane
+//     % 32): the activation scale is one f32 per lane and step (one 4-byte LDS read), the 16 weight scales are the same for every
+//     m-tile of the block (4 x 16-byte reads per BLOCK from a wave-private LDS copy of the strip's scales).  With the operands the
+//     other way round (round 4) every (m-tile, block) step read 16 activation scales: 5 x ds_read_b128 per step and wave = as many
+//     LDS cycles per CU as the scaling has VALU cycles;
+//   * the steps of a group are software-pipelined inside the wave: fragment + scale reads two steps ahead, the MFMA one step
+//     ahead of the scaling that consumes it.  Step by step (round 4: read -> MFMA -> convert -> scale, fenced per step so that the
+//     register allocator survives) one wave took ~540 cycles per step for ~140 cycles of VALU work, and a second wave per SIMD did
+//     not overlap it (measured with the K split forced to 1: 7.2 us per group and workgroup);
+//   * scaling: 16 int32 per lane and (m-tile, block) -> f32, times dw[n] * dx[m], as packed f32 math (v_pk_mul / v_pk_fma):
+//     32 VALU instructions per step -- the floor of this kernel (39 us per Qwen3-8B layer at 128 rows), not the matrix cores.
+// The K split is any ks <= 16, slice i = groups [i G / ks, (i + 1) G / ks).
+constexpr int QG_MIN = 8;                           // K % (32 QG_MIN) == 0: every geometry's group divides the row
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT>
-__global__ __launch_bounds__(256, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
+template <int MH, int MT, int QG>
+__global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    constexpr int QROWB = QG * 32 + 16;                 // bytes of a panel row in LDS (padded: the 16 rows of a fragment read start 4 banks apart)
+    constexpr int RC = 2 * QG;                          // 16-byte chunks of a row and group
+    constexpr int NT = 256 * MH, PR = 32 * MT * MH, NCH = PR * RC / NT, NWC = 128 * RC / NT, NS = QG * MT;
+    constexpr int PANEL = PR * QROWB, WPANEL = 128 * QROWB;
+    typedef uint32_t scl_t __attribute__((ext_vector_type(QG / 2)));       // a row's QG f16 block scales of a group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int K = a.w.K, N = a.w.N, nkb_all = K >> 5, nkb = nkb_all / a.ksplit, ngrp = nkb / QG;
+    const int r = lane & 31, h = lane >> 5, ns = wave & 3, mh = wave >> 2;
+    const int K = a.w.K, N = a.w.N, nkb_all = K >> 5, G = nkb_all / QG;
     float* xds = (float*)qlds;                                              // [2][QG][QGEMM_MAXM] block scales of the activation rows, per group
-    unsigned char* As = qlds + (size_t)2 * QG * QGEMM_MAXM * sizeof(float);  // [2][32 MT][QROWB] activation codes of a group
-    constexpr int PANEL = MT * 32 * QROWB;
+    float* dwl = xds + 2 * QG * QGEMM_MAXM + wave * (QG * 32);              // [QG][32] this wave's weight scales of the group (wave-private)
+    unsigned char* Ws = qlds + (size_t)(2 * QG * QGEMM_MAXM + 4 * MH * QG * 32) * sizeof(float);   // [2][128][QROWB] weight codes of a group
+    unsigned char* As = Ws + 2 * WPANEL;                                    // [2][PR][QROWB] activation codes of a group
     const int tiles = N / 128;
     const int ks = (int)blockIdx.x / tiles, tn = (int)blockIdx.x % tiles;
-    const int kb0 = ks * nkb;
-    const int n = tn * 128 + wave * 32 + r;                                 // this lane's weight row = its output column
-    const uint8_t* wp = a.w.p0 + (size_t)n * K + (size_t)kb0 * 32 + 16 * h;
-    const uint16_t* dp = (const uint16_t*)a.w.p1 + (size_t)n * nkb_all + kb0;
-    // activation panel: chunk c = tid + 256 i (i < 2 MT): row c / 16, 16-byte chunk c % 16 of the group's 256 bytes
-    const signed char* xsrc[2 * MT];
-    int xdst[2 * MT];
+    const int g0 = ks * G / a.ksplit, ngrp = (ks + 1) * G / a.ksplit - g0, kb0 = g0 * QG;
+    // weight scales: lane (r, .) of strip ns owns row tn * 128 + ns * 32 + r (8 f16 = one 16-byte load per group)
+    const uint16_t* dp = (const uint16_t*)a.w.p1 + (size_t)(tn * 128 + ns * 32 + r) * nkb_all + kb0;
+    // code panels: chunk c = tid + NT i: row c / 16, 16-byte chunk c % 16 of the group's 256 bytes -- 16 lanes fetch one row's 256
+    // contiguous bytes (two whole cache lines; as MFMA fragments straight from memory a wave's load touched 32 rows x 32 bytes, every
+    // line four times by four different instructions: the kernel was bound by exactly that, not by its arithmetic)
+    const uint8_t* wsrc[NWC];
+    const signed char* xsrc[NCH];
+    int wdst[NWC], xdst[NCH];
 #pragma unroll
-    for (int i = 0; i < 2 * MT; ++i) {
-        const int c = tid + 256 * i, row = c >> 4, q = c & 15;
+    for (int i = 0; i < NWC; ++i) {
+        const int c = tid + NT * i, row = c / RC, q = c % RC;
+        wsrc[i] = a.w.p0 + (size_t)(tn * 128 + row) * K + (size_t)kb0 * 32 + 16 * q;
+        wdst[i] = row * QROWB + 16 * q;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + NT * i, row = c / RC, q = c % RC;
         xsrc[i] = a.xq + (size_t)min(row, a.M - 1) * K + (size_t)kb0 * 32 + 16 * q;       // (rows past M: clamped, dropped at the store)
         xdst[i] = row * QROWB + 16 * q;
     }
-    u32x4 wv[QG], wn[QG], sc, scn, areg[2 * MT];
+    u32x4 wreg[NWC], areg[NCH];
+    scl_t scn;
 #pragma unroll
-    for (int j = 0; j < QG; ++j) wv[j] = ld_nt16(wp + j * 32);
-    sc = *(const u32x4*)dp;
+    for (int i = 0; i < NWC; ++i) wreg[i] = ld_nt16(wsrc[i]);
+    scn = *(const scl_t*)dp;
 #pragma unroll
-    for (int i = 0; i < 2 * MT; ++i) areg[i] = *(const u32x4*)xsrc[i];
-    // (a group's scales: QG x 128 floats = one 16-byte load per thread)
-    const f32x4* xdsrc = (const f32x4*)(a.xd + (size_t)kb0 * QGEMM_MAXM) + tid;
-    f32x4 xreg = *xdsrc;
-    ((f32x4*)xds)[tid] = xreg;
+    for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)xsrc[i];
+    // (a group's scales: QG x 128 floats = one 16-byte load per thread of the first QG / 2 waves)
+    constexpr int XT = QG * QGEMM_MAXM / 4;
+    const f32x4* xdsrc = (const f32x4*)(a.xd + (size_t)kb0 * QGEMM_MAXM) + (tid % XT);
+    f32x4 xreg = {0.f, 0.f, 0.f, 0.f};
+    if (tid < XT) { xreg = *xdsrc; ((f32x4*)xds)[tid] = xreg; }
 #pragma unroll
-    for (int i = 0; i < 2 * MT; ++i) *(u32x4*)(As + xdst[i]) = areg[i];
+    for (int i = 0; i < NWC; ++i) *(u32x4*)(Ws + wdst[i]) = wreg[i];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *(u32x4*)(As + xdst[i]) = areg[i];
+    // the strip's weight scales of a group, f32, where every lane of the wave can read them: lane (r, h) writes blocks (QG / 2) h ... of
+    // row r (wave-private: the wave's own DS operations are ordered, no barrier)
+    auto put_dw = [&](const scl_t& sv8) {
+        float* d = dwl + (QG / 2 * h) * 32 + r;
+#pragma unroll
+        for (int e = 0; e < QG / 4; ++e) {
+            const uint32_t p = h ? sv8[QG / 4 + e] : sv8[e];
+            d[64 * e] = f16bits(p & 0xFFFFu); d[64 * e + 32] = f16bits(p >> 16);
+        }
+    };
+    put_dw(scn);
     f32x2 acc[MT][8];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[mt][i] = (f32x2){0.f, 0.f};
     __syncthreads();
+    const int wrow = (ns * 32 + r) * QROWB + 16 * h;                         // + j * 32
+    const int arow = (mh * MT * 32 + r) * QROWB + 16 * h;                    // + mt * 32 * QROWB + j * 32
+    const int xrow = mh * MT * 32 + r;                                       // + j * QGEMM_MAXM + mt * 32
     for (int g = 0; g < ngrp; ++g) {
         const bool more = g + 1 < ngrp;
-        const int gn = more ? g + 1 : g;                                    // (the last group re-reads itself: unused)
-#pragma unroll
-        for (int j = 0; j < QG; ++j) wn[j] = ld_nt16(wp + (size_t)(gn * QG + j) * 32);
-        scn = *(const u32x4*)(dp + gn * QG);
-#pragma unroll
-        for (int i = 0; i < 2 * MT; ++i) areg[i] = *(const u32x4*)(xsrc[i] + (size_t)gn * QG * 32);
-        xreg = xdsrc[(size_t)gn * (QG * QGEMM_MAXM / 4)];
-        const unsigned char* Ap = As + (g & 1) * PANEL;
-        const float* xg = xds + (g & 1) * (QG * QGEMM_MAXM);
-#pragma unroll
-        for (int j = 0; j < QG; ++j) {
-            const float dw = f16bits((sc[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-            const long wlo = (long)(((unsigned long)wv[j][1] << 32) | wv[j][0]), whi = (long)(((unsigned long)wv[j][3] << 32) | wv[j][2]);
-            const float* xr = xg + j * QGEMM_MAXM + 4 * h;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const u32x4 av = *(const u32x4*)(Ap + (mt * 32 + r) * QROWB + j * 32 + 16 * h);
-                const long alo = (long)(((unsigned long)av[1] << 32) | av[0]), ahi = (long)(((unsigned long)av[3] << 32) | av[2]);
-                i32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                c = __builtin_amdgcn_mfma_i32_32x32x16_i8(alo, wlo, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_i32_32x32x16_i8(ahi, whi, c, 0, 0, 0);
-                // D[i] of lane (r, h): row 8 (i / 4) + 4 h + i % 4 of the m-tile, column r
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 dx = *(const f32x4*)(xr + mt * 32 + 8 * q);
-                    const f32x2 s0 = (f32x2){dw, dw} * (f32x2){dx[0], dx[1]}, s1 = (f32x2){dw, dw} * (f32x2){dx[2], dx[3]};
-                    const f32x2 c0 = (f32x2){(float)c[4 * q], (float)c[4 * q + 1]}, c1 = (f32x2){(float)c[4 * q + 2], (float)c[4 * q + 3]};
-                    acc[mt][2 * q] = __builtin_elementwise_fma(s0, c0, acc[mt][2 * q]);
-                    acc[mt][2 * q + 1] = __builtin_elementwise_fma(s1, c1, acc[mt][2 * q + 1]);
-                }
-                // one m-tile's int32 results and scales live at a time: left alone, the MFMAs and LDS reads of a whole group are issued
-                // first and their conversions sink below all of them (> 512 registers).  The empty asm is ordered like any volatile
-                // statement and needs the sums, so the scaling of this m-tile stays in front of the next one's MFMAs.
-#pragma unroll
-                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(acc[mt][q]));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
         if (more) {
+#pragma unroll
+            for (int i = 0; i < NWC; ++i) wreg[i] = ld_nt16(wsrc[i] + (size_t)(g + 1) * QG * 32);
+            scn = *(const scl_t*)(dp + (g + 1) * QG);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)(xsrc[i] + (size_t)(g + 1) * QG * 32);
+            if (tid < XT) xreg = xdsrc[(size_t)(g + 1) * XT];
+        }
+        const unsigned char* Wp = Ws + (g & 1) * WPANEL + wrow;
+        const unsigned char* Ap = As + (g & 1) * PANEL + arow;
+        const float* xg = xds + (g & 1) * (QG * QGEMM_MAXM) + xrow;
+        u32x4 avq[2], wfq[2];
+        float dxq[3];
+        i32x16 cq[2];
+        f32x4 dwq[4];
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // step s = (block j = s / MT, m-tile mt = s % MT)
+#define Q8_LOAD(s_, slot_) do { avq[slot_] = *(const u32x4*)(Ap + ((s_) % MT) * 32 * QROWB + ((s_) / MT) * 32); \
+                                dxq[(s_) % 3] = xg[((s_) / MT) * QGEMM_MAXM + ((s_) % MT) * 32]; } while (0)
+#define Q8_MFMA(s_, slot_) cq[slot_] = __builtin_amdgcn_mfma_i32_32x32x32_i8( \
+            (i32x4){(int)wfq[((s_) / MT) & 1][0], (int)wfq[((s_) / MT) & 1][1], (int)wfq[((s_) / MT) & 1][2], (int)wfq[((s_) / MT) & 1][3]}, \
+            (i32x4){(int)avq[slot_][0], (int)avq[slot_][1], (int)avq[slot_][2], (int)avq[slot_][3]}, zero, 0, 0, 0)
+        wfq[0] = *(const u32x4*)Wp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + 8 * q + 4 * h);
+        Q8_LOAD(0, 0);
+        Q8_LOAD(1, 1);
+        if (MT == 1) wfq[1] = *(const u32x4*)(Wp + 32);
+        Q8_MFMA(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sl = s & 1, mt = s % MT, j = s / MT;
+            // the next block's weight fragment: needed by the MFMA of step (j + 1) MT, issued at step (j + 1) MT - 1
+            if (MT > 1 && mt == 0 && j + 1 < QG) wfq[(j + 1) & 1] = *(const u32x4*)(Wp + (j + 1) * 32);
+            if (s + 1 < NS) Q8_MFMA(s + 1, sl ^ 1);
+            if (MT == 1 && j + 2 < QG) wfq[j & 1] = *(const u32x4*)(Wp + (j + 2) * 32);
+            if (s + 2 < NS) Q8_LOAD(s + 2, sl);
+            __builtin_amdgcn_sched_barrier(0);                              // (the MFMA in front of the scaling it runs under, not behind it)
+            const float dx = dxq[s % 3];
+            f32x2 sv[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sv[p] = (f32x2){dwq[p >> 1][2 * (p & 1)], dwq[p >> 1][2 * (p & 1) + 1]} * (f32x2){dx, dx};
+            if (mt == MT - 1 && j + 1 < QG) {
+                // the next block's weight scales: requested as soon as this block's last products are formed
+#pragma unroll
+                for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(sv[p]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + (j + 1) * 32 + 8 * q + 4 * h);
+            }
+            // D[i] of lane (r, h): weight row 8 (i / 4) + 4 h + i % 4 of the strip, activation row r of the m-tile
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const f32x2 cf = (f32x2){(float)cq[sl][2 * p], (float)cq[sl][2 * p + 1]};
+                acc[mt][p] = __builtin_elementwise_fma(sv[p], cf, acc[mt][p]);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(acc[mt][p]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef Q8_LOAD
+#undef Q8_MFMA
+        if (more) {
+            unsigned char* Wn = Ws + ((g + 1) & 1) * WPANEL;
             unsigned char* An = As + ((g + 1) & 1) * PANEL;
 #pragma unroll
-            for (int i = 0; i < 2 * MT; ++i) *(u32x4*)(An + xdst[i]) = areg[i];
-            ((f32x4*)(xds + ((g + 1) & 1) * (QG * QGEMM_MAXM)))[tid] = xreg;
+            for (int i = 0; i < NWC; ++i) *(u32x4*)(Wn + wdst[i]) = wreg[i];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) *(u32x4*)(An + xdst[i]) = areg[i];
+            if (tid < XT) ((f32x4*)(xds + ((g + 1) & 1) * (QG * QGEMM_MAXM)))[tid] = xreg;
+            put_dw(scn);                                                    // (this group's reads of the scales are behind us)
         }
         __syncthreads();
-        sc = scn;
-#pragma unroll
-        for (int j = 0; j < QG; ++j) wv[j] = wn[j];
     }
     float* P = a.ws + (size_t)ks * a.slice;
+    const int nq = tn * 128 + ns * 32 + 4 * h;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (mh * MT + mt) * 32 + r;
+        if (m < a.M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = mt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-            if (m < a.M) P[(size_t)m * a.ldp + n] = acc[mt][i >> 1][i & 1];
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(P + (size_t)m * a.ldp + nq + 8 * q) = (f32x4){acc[mt][2 * q][0], acc[mt][2 * q][1], acc[mt][2 * q + 1][0], acc[mt][2 * q + 1][1]};
         }
+    }
 }
 
 // slices added in the order 0, 1, ...; 4 consecutive columns of a row per thread.  EPI_STORE / EPI_RESADD: y[m][n] (+)= v;
@@ -359,7 +428,7 @@ static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, 
 }
 
 bool gemm_q8_ok(const QWeight& w, int M) {
-    return w.fmt == QFMT_Q8_0 && M >= 1 && M <= QGEMM_MAXM && w.N % 128 == 0 && w.K % (32 * QG) == 0;
+    return w.fmt == QFMT_Q8_0 && M >= 1 && M <= QGEMM_MAXM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
 }
 
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
@@ -369,36 +438,48 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     QGemmArgs a = a0;
     if (fused) *fused = false;
     if (!gemm_q8_ok(a.w, a.M) || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return false;
-    const int N = a.w.N, nkb_all = a.w.K >> 5, tiles = N / 128;
-    // split K until the chip is full (~2 workgroups per CU), the scales of a workgroup's k range fit 64 KB of LDS and the partials
-    // fit the workspace
+    // geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that either 8 waves (two halves of the
+    // rows) x 2 m-tiles, one workgroup per CU, or 4 waves x 4 m-tiles with groups of 4 blocks: 80 KB of LDS, two INDEPENDENT
+    // workgroups per CU (CM_QGEMM_GEO = 0 / 1)
+    static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 1;
+    const int geo = a.M > 64 ? (geo_env ? 2 : 1) : 0;
+    const int mh = geo == 1 ? 2 : 1, mt = geo == 2 ? 4 : a.M > 32 ? 2 : 1, qg = geo == 2 ? 4 : 8;
+    const int N = a.w.N, nkb_all = a.w.K >> 5, tiles = N / 128, G = nkb_all / qg;
+    const size_t lds = (size_t)(2 * qg * QGEMM_MAXM + 4 * mh * qg * 32) * sizeof(float) + (size_t)2 * (128 + mh * mt * 32) * (qg * 32 + 16);
+    // K split: the chip holds `cap` workgroups at a time (256 registers per lane: 2 waves per SIMD); a launch of `tiles * ks` of them
+    // runs in ceil(tiles ks / cap) rounds of (1 start-up + ceil(G / ks) groups), and every slice costs a write + a read of M x N f32
+    const int cap = num_cu * (mh == 2 ? 1 : 2);
+    const double tgroup_us = 2.0, fill_us = 2.5, part_us = 8.0 * a.M * N / 3.0e6;     // (partials at ~3 TB/s, write + read)
     int ks = 1;
-    const int mt = (a.M + 31) / 32;
-    // (two activation panels + two sets of block scales: independent of the split)
-    const size_t lds = (size_t)2 * QG * QGEMM_MAXM * sizeof(float) + (size_t)2 * mt * 32 * QROWB, lds_max = 160 * 1024;
-    if (lds > lds_max) return false;
-    while (ks < 16 && nkb_all % (ks * 2 * QG) == 0 && tiles * ks < 2 * num_cu && (size_t)(ks * 2) * a.M * N <= ws_floats) ks *= 2;
-    const bool direct = epi == EPI_STORE && ((size_t)a.M * N > ws_floats || ks == 1);
+    double best = 1e30;
+    const bool direct_only = epi == EPI_STORE && (size_t)a.M * N > ws_floats;          // (the vocabulary head: written in place, unsplit)
+    for (int k = 1; k <= 16 && k <= G && !direct_only; ++k) {
+        if (k > 1 && (ws == nullptr || (size_t)k * a.M * N > ws_floats)) break;
+        const int rounds = (tiles * k + cap - 1) / cap;
+        const double c = rounds * (fill_us + tgroup_us * ((G + k - 1) / k)) + (k > 1 || epi != EPI_STORE ? k * part_us : 0.0);
+        if (c < best) { best = c; ks = k; }
+    }
+    const bool direct = epi == EPI_STORE && (direct_only || ks == 1);
     // the partial slices of a residual / SiLU*mul projection always go through the workspace: refuse what it cannot hold (the
     // caller falls back to the batched GEMV) instead of writing past it
     if (!direct && (ws == nullptr || (size_t)ks * a.M * N > ws_floats)) return false;
     if (direct) { ks = 1; a.ws = y; a.ldp = ldy; a.slice = 0; }
     else { a.ws = ws; a.ldp = N; a.slice = (size_t)a.M * N; }
     static const int ks_env = getenv("CM_QGEMM_KS") ? atoi(getenv("CM_QGEMM_KS")) : 0;           // tuning: force the split
-    if (ks_env > 0 && !direct && nkb_all % (ks_env * QG) == 0 && (size_t)ks_env * a.M * N <= ws_floats) ks = ks_env;
+    if (ks_env > 0 && !direct && ks_env <= G && (size_t)ks_env * a.M * N <= ws_floats) ks = ks_env;
     a.ksplit = ks;
     static DevOnce attr;
     attr.run([&] {
-        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    const dim3 grid(tiles * ks), block(256);
-    if (mt == 1) hipLaunchKernelGGL(gemm_q8_i8_kernel<1>, grid, block, lds, s, a);
-    else if (mt == 2) hipLaunchKernelGGL(gemm_q8_i8_kernel<2>, grid, block, lds, s, a);
-    else if (mt == 3) hipLaunchKernelGGL(gemm_q8_i8_kernel<3>, grid, block, lds, s, a);
-    else hipLaunchKernelGGL(gemm_q8_i8_kernel<4>, grid, block, lds, s, a);
+    const dim3 grid(tiles * ks), block(256 * mh);
+    if (geo == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 4, 4>), grid, block, lds, s, a);
+    else if (mh == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 8>), grid, block, lds, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 8>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 1, 8>), grid, block, lds, s, a);
     if (direct) return true;
     // the next projection's quantiser rides on the reduction launch (CM_QGEMM_QFUSE = 0: its own launch, A/B); the quantiser's
     // lane map needs whole 32-blocks per 8 lanes: output rows of a multiple of 32 columns
