@@ -412,19 +412,24 @@ template <int EPI>
 static void launch_q8_epilogue_quant(const float* ws, int M, int N, int ks, float* y, int ldy, const QNext& nx, hipStream_t s) {
 #define CM_QQ(KS_) do { if (nx.nw) hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, true>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd); \
                         else hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, false>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd); } while (0)
-    if (ks == 1) CM_QQ(1); else if (ks == 2) CM_QQ(2); else if (ks == 4) CM_QQ(4); else if (ks == 8) CM_QQ(8); else if (ks == 16) CM_QQ(16); else CM_QQ(0);
+    switch (ks) {
+        case 1: CM_QQ(1); break; case 2: CM_QQ(2); break; case 3: CM_QQ(3); break; case 4: CM_QQ(4); break; case 5: CM_QQ(5); break;
+        case 6: CM_QQ(6); break; case 8: CM_QQ(8); break; case 10: CM_QQ(10); break; case 12: CM_QQ(12); break; case 16: CM_QQ(16); break;
+        default: CM_QQ(0);
+    }
 #undef CM_QQ
 }
 
 template <int EPI>
 static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, int ldy, hipStream_t s) {
     const int eb = (int)std::min<size_t>(((size_t)M * (N / 4) + 255) / 256, 2048);
-    if (ks == 1) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 1>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
-    else if (ks == 2) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 2>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
-    else if (ks == 4) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 4>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
-    else if (ks == 8) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 8>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
-    else if (ks == 16) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 16>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
-    else hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, 0>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy);
+#define CM_QE(KS_) hipLaunchKernelGGL((q8_splitk_epilogue_kernel<EPI, KS_>), dim3(eb), dim3(256), 0, s, ws, M, N, ks, y, ldy)
+    switch (ks) {
+        case 1: CM_QE(1); break; case 2: CM_QE(2); break; case 3: CM_QE(3); break; case 4: CM_QE(4); break; case 5: CM_QE(5); break;
+        case 6: CM_QE(6); break; case 8: CM_QE(8); break; case 10: CM_QE(10); break; case 12: CM_QE(12); break; case 16: CM_QE(16); break;
+        default: CM_QE(0);
+    }
+#undef CM_QE
 }
 
 bool gemm_q8_ok(const QWeight& w, int M) {
@@ -438,12 +443,13 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     QGemmArgs a = a0;
     if (fused) *fused = false;
     if (!gemm_q8_ok(a.w, a.M) || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return false;
-    // geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that either 8 waves (two halves of the
-    // rows) x 2 m-tiles, one workgroup per CU, or 4 waves x 4 m-tiles with groups of 4 blocks: 80 KB of LDS, two INDEPENDENT
-    // workgroups per CU (CM_QGEMM_GEO = 0 / 1)
-    static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 1;
-    const int geo = a.M > 64 ? (geo_env ? 2 : 1) : 0;
-    const int mh = geo == 1 ? 2 : 1, mt = geo == 2 ? 4 : a.M > 32 ? 2 : 1, qg = geo == 2 ? 4 : 8;
+    // geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that 8 waves (two halves of the rows)
+    // x 2 m-tiles, one workgroup per CU, groups of 4 blocks (CM_QGEMM_GEO = 3, the default; Q8_0 serving of Qwen3-8B at 128
+    // sequences 11.46 K tok/s), or the same with groups of 8 blocks (= 0: 11.01 K), or 4 waves x 4 m-tiles with groups of 4 blocks: 80 KB
+    // of LDS, two independent workgroups per CU (= 1: 11.18 K)
+    static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 3;
+    const int geo = a.M > 64 ? (geo_env == 0 ? 1 : geo_env == 1 ? 2 : 3) : 0;
+    const int mh = geo == 1 || geo == 3 ? 2 : 1, mt = geo == 2 ? 4 : a.M > 32 ? 2 : 1, qg = geo >= 2 ? 4 : 8;
     const int N = a.w.N, nkb_all = a.w.K >> 5, tiles = N / 128, G = nkb_all / qg;
     const size_t lds = (size_t)(2 * qg * QGEMM_MAXM + 4 * mh * qg * 32) * sizeof(float) + (size_t)2 * (128 + mh * mt * 32) * (qg * 32 + 16);
     // K split: the chip holds `cap` workgroups at a time (256 registers per lane: 2 waves per SIMD); a launch of `tiles * ks` of them
@@ -454,6 +460,7 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     double best = 1e30;
     const bool direct_only = epi == EPI_STORE && (size_t)a.M * N > ws_floats;          // (the vocabulary head: written in place, unsplit)
     for (int k = 1; k <= 16 && k <= G && !direct_only; ++k) {
+        if (k == 7 || k == 9 || k == 11 || (k > 12 && k < 16)) continue;                  // (splits the reduction kernels are unrolled for)
         if (k > 1 && (ws == nullptr || (size_t)k * a.M * N > ws_floats)) break;
         const int rounds = (tiles * k + cap - 1) / cap;
         const double c = rounds * (fill_us + tgroup_us * ((G + k - 1) / k)) + (k > 1 || epi != EPI_STORE ? k * part_us : 0.0);
@@ -474,9 +481,11 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid(tiles * ks), block(256 * mh);
-    if (geo == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 4, 4>), grid, block, lds, s, a);
+    if (geo == 3) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 4>), grid, block, lds, s, a);
+    else if (geo == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 4, 4>), grid, block, lds, s, a);
     else if (mh == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 8>), grid, block, lds, s, a);
     else if (mt == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 8>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 1, 8>), grid, block, lds, s, a);
