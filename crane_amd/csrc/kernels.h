@@ -382,6 +382,7 @@ struct QGemmArgs {
     float* ws;                 // set by launch_gemm_q8: partial slices [ksplit][M][N], or the output itself (unsplit store)
     size_t slice;
     int M, ksplit, ldp;
+    int silu;                  // set by launch_gemm_q8 (unsplit EPI_SILUMUL): store silu(gate) * up of the interleaved column pairs, row stride ldp
 };
 void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s);
 bool gemm_q8_ok(const QWeight& w, int M);

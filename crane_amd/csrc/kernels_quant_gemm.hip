@@ -279,7 +279,14 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = (mh * MT + mt) * 32 + r;
-        if (m < a.M) {
+        if (m < a.M && a.silu) {
+            // unsplit gate|up: columns (2 k, 2 k + 1) = (gate_k, up_k) sit in one lane -- the reduction kernel's expression, no f32 round trip
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g0 = acc[mt][2 * q][0], u0 = acc[mt][2 * q][1], g1 = acc[mt][2 * q + 1][0], u1 = acc[mt][2 * q + 1][1];
+                *(f32x2*)(P + (size_t)m * a.ldp + ((nq + 8 * q) >> 1)) = (f32x2){(g0 / (1.0f + expf(-g0))) * u0, (g1 / (1.0f + expf(-g1))) * u1};
+            }
+        } else if (m < a.M) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *(f32x4*)(P + (size_t)m * a.ldp + nq + 8 * q) = (f32x4){acc[mt][2 * q][0], acc[mt][2 * q][1], acc[mt][2 * q + 1][0], acc[mt][2 * q + 1][1]};
@@ -463,17 +470,19 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         if (k == 7 || k == 9 || k == 11 || (k > 12 && k < 16)) continue;                  // (splits the reduction kernels are unrolled for)
         if (k > 1 && (ws == nullptr || (size_t)k * a.M * N > ws_floats)) break;
         const int rounds = (tiles * k + cap - 1) / cap;
-        const double c = rounds * (fill_us + tgroup_us * ((G + k - 1) / k)) + (k > 1 || epi != EPI_STORE ? k * part_us : 0.0);
+        const double c = rounds * (fill_us + tgroup_us * ((G + k - 1) / k)) + (k > 1 || epi == EPI_RESADD ? k * part_us : 0.0);
         if (c < best) { best = c; ks = k; }
     }
-    const bool direct = epi == EPI_STORE && (direct_only || ks == 1);
-    // the partial slices of a residual / SiLU*mul projection always go through the workspace: refuse what it cannot hold (the
+    static const int ks_env = getenv("CM_QGEMM_KS") ? atoi(getenv("CM_QGEMM_KS")) : 0;           // tuning: force the split
+    if (ks_env > 0 && !direct_only && ks_env <= G && ws != nullptr && (size_t)ks_env * a.M * N <= ws_floats) ks = ks_env;
+    // unsplit: the store (and SiLU(gate) * up of a gate|up projection) happens in the GEMM's own epilogue, no partial slices
+    const bool direct = (epi == EPI_STORE || epi == EPI_SILUMUL) && (direct_only || ks == 1);
+    // the partial slices of a residual / split projection always go through the workspace: refuse what it cannot hold (the
     // caller falls back to the batched GEMV) instead of writing past it
     if (!direct && (ws == nullptr || (size_t)ks * a.M * N > ws_floats)) return false;
-    if (direct) { ks = 1; a.ws = y; a.ldp = ldy; a.slice = 0; }
+    a.silu = 0;
+    if (direct) { ks = 1; a.ws = y; a.ldp = ldy; a.slice = 0; a.silu = epi == EPI_SILUMUL; }
     else { a.ws = ws; a.ldp = N; a.slice = (size_t)a.M * N; }
-    static const int ks_env = getenv("CM_QGEMM_KS") ? atoi(getenv("CM_QGEMM_KS")) : 0;           // tuning: force the split
-    if (ks_env > 0 && !direct && ks_env <= G && (size_t)ks_env * a.M * N <= ws_floats) ks = ks_env;
     a.ksplit = ks;
     static DevOnce attr;
     attr.run([&] {
