@@ -1076,7 +1076,10 @@ void Model::ensure_prefill_buffers() {
     if ((long)chunk > all_rows) chunk = (int)all_rows;
     if (chunk < 1) chunk = 1;
     chunk_pad = (chunk + 127) / 128 * 128;
-    prefill_split2 = opts.prefill_split != 1;
+    // prompt activations as bf16 hi + lo (two products per GEMM: what the 1e-3 bound of a bf16 checkpoint needs) unless the caller asked
+    // for plain bf16 -- or left the choice open (0) on QUANTISED weights: their scratch copy for the GEMMs is already rounded to bf16
+    // (2^-9 per weight, tests: 1e-2 of the oracle on the dequantised weights), the activations' low halves would refine past that
+    prefill_split2 = default_prefill_split2();
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     prefill_ok = (qkv_rows % 128 == 0) && (H % 128 == 0) && ((2 * I_l) % 128 == 0) && (H % 32 == 0) && (I_l % 32 == 0) &&
                  (!cfg.hybrid || cfg.value_dim() % 32 == 0);

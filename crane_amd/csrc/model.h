@@ -358,6 +358,7 @@ struct Model {
     hipGraph_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
     hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // (4 = whole-token persistent launch)
     bool graph_ok[5] = {false, false, false, false, false};
+    bool default_prefill_split2() const { return opts.prefill_split == 2 || (opts.prefill_split == 0 && !quantized); }
     bool quant_prefill = true, no_prefill = false, use_mfma_gemv = true;   // CM_QUANT_PREFILL, CM_NO_PREFILL, CM_GEMVM (read at create)
     bool tp_graph = true, rccl_warm = false;   // capture RCCL collectives into the decode graph (CM_TP_GRAPH=0: eager)
     int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj
