@@ -1117,7 +1117,18 @@ void Model::ensure_prefill_buffers() {
         d_ident_bt = dalloc<int>((size_t)max_pages_per_seq);
         CM_HIP(hipMemcpy(d_ident_bt, ident.data(), ident.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (quantized) wq_scratch = dalloc<uint16_t>(std::max(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H), (size_t)in_proj_pad * H));
+    if (quantized) {
+        wq_scratch = dalloc<uint16_t>(std::max(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H), (size_t)in_proj_pad * H));
+        // 288 GB of HBM: a quantised 8B model's bf16 GEMM operands are 14 GB -- dequantising every matrix again for every prompt pass was
+        // 4.5 % of a Q8_0 serving run (dequant_bf16_kernel, 2304 launches).  Kept when they fit a quarter of what is free now
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (const LayerW& w : layers)
+            need += w.full ? ((size_t)qkv_rows * H + (size_t)H * Hq_l * D + (size_t)3 * I_l * H) * 2
+                           : ((size_t)in_proj_pad * H + (size_t)H * cfg.value_dim() + (size_t)3 * I_l * H) * 2;
+        CM_HIP(hipMemGetInfo(&free_b, &total_b));
+        wq_cache = need <= free_b / 4;
+        if (const char* e = getenv("CM_QUANT_PREFILL_CACHE")) wq_cache = atoi(e) != 0;
+    }
     d_ids = (uint32_t*)dalloc<int>(chunk);
     CM_HIP(hipHostMalloc((void**)&h_ids, (size_t)chunk * sizeof(uint32_t)));
 }
@@ -1131,6 +1142,13 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     hipStream_t s = stream;
     const int qkv_rows = (cfg.hybrid ? 2 * Hq_l + 2 * Hkv_l : Hq_l + 2 * Hkv_l) * D;
     const bool sp2 = prefill_split2;
+    // the bf16 operand of a quantised projection: `fill(dst)` enqueues its dequantisation -- into the layer's own copy the first time
+    // (cache on), else into the one scratch matrix every time (stream order keeps that safe)
+    auto deq_w = [&](LayerW& lw, int slot, size_t elems, auto&& fill) -> const uint16_t* {
+        if (!wq_cache) { fill(wq_scratch); return wq_scratch; }
+        if (!lw.dq[slot]) { lw.dq[slot] = dalloc<uint16_t>(elems); fill(lw.dq[slot]); }
+        return lw.dq[slot];
+    };
     // the RMSNorm in front of a projection is written by the split-K reduction launch of the row-parallel projection before it when
     // that GEMM splits K (GemmArgs::norm_w; launch_gemm runs the row kernel itself when it does not): o_proj / out_proj -> ln2,
     // down_proj -> the next layer's ln1 (not under TP: the norm follows the all-reduce; not across a DeepStack injection)
@@ -1139,7 +1157,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     };
     bool xn_ready = false;
     for (int li = 0; li < cfg.L; ++li) {
-        const LayerW& w = layers[(size_t)li];
+        LayerW& w = layers[(size_t)li];
         if (!xn_ready) launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
         xn_ready = false;
         GemmArgs g{};
@@ -1149,11 +1167,12 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
             if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
                 const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
-                launch_dequant_bf16(w.q_in_proj, wq_scratch, 1, 0, s);
-                if (w.q_in_proj_z.fmt != QFMT_NONE) launch_dequant_bf16(w.q_in_proj_z, wq_scratch + (size_t)w.q_in_proj.N * H, 1, 0, s);
-                CM_HIP(hipMemcpyAsync(wq_scratch + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-                CM_HIP(hipMemsetAsync(wq_scratch + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
-                g.W = wq_scratch;
+                g.W = deq_w(w, 0, (size_t)in_proj_pad * H, [&](uint16_t* dst) {
+                    launch_dequant_bf16(w.q_in_proj, dst, 1, 0, s);
+                    if (w.q_in_proj_z.fmt != QFMT_NONE) launch_dequant_bf16(w.q_in_proj_z, dst + (size_t)w.q_in_proj.N * H, 1, 0, s);
+                    CM_HIP(hipMemcpyAsync(dst + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+                    CM_HIP(hipMemsetAsync(dst + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
+                });
             }
             g.M = S; g.N = in_proj_pad; g.K = H;
             if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
@@ -1181,7 +1200,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
             g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
-            if (quantized) { launch_dequant_bf16(w.q_out_proj, wq_scratch, 1, 0, s); g.W = wq_scratch; }
+            if (quantized) g.W = deq_w(w, 1, (size_t)w.q_out_proj.N * w.q_out_proj.K, [&](uint16_t* dst) { launch_dequant_bf16(w.q_out_proj, dst, 1, 0, s); });
             if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
@@ -1191,8 +1210,9 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         } else {
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 1)) ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
         if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
-            for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], wq_scratch + (size_t)w.qkv_row0[i] * H, 1, 0, s);
-            g.W = wq_scratch;
+            g.W = deq_w(w, 0, (size_t)qkv_rows * H, [&](uint16_t* dst) {
+                for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], dst + (size_t)w.qkv_row0[i] * H, 1, 0, s);
+            });
         }
         g.M = S; g.N = qkv_rows; g.K = H;
         if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
@@ -1253,7 +1273,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         }
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pAT_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 2)) ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
-        if (quantized) { launch_dequant_bf16(w.q_o, wq_scratch, 1, 0, s); g.W = wq_scratch; }
+        if (quantized) g.W = deq_w(w, 1, (size_t)w.q_o.N * w.q_o.K, [&](uint16_t* dst) { launch_dequant_bf16(w.q_o, dst, 1, 0, s); });
         if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
         else {
             g.C = pY; launch_gemm(g, GEPI_STORE, s);
@@ -1265,15 +1285,16 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 4)) ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
         if (quantized) {
-            if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, wq_scratch, 1, 0, s);
-            else { launch_dequant_bf16(w.q_gate, wq_scratch, 2, 0, s); launch_dequant_bf16(w.q_up, wq_scratch, 2, 1, s); }
-            g.W = wq_scratch;
+            g.W = deq_w(w, 2, (size_t)2 * I_l * H, [&](uint16_t* dst) {
+                if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, dst, 1, 0, s);
+                else { launch_dequant_bf16(w.q_gate, dst, 2, 0, s); launch_dequant_bf16(w.q_up, dst, 2, 1, s); }
+            });
         }
         g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
         launch_gemm(g, GEPI_SILUMUL, s);
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pHH_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 8)) ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
-        if (quantized) { launch_dequant_bf16(w.q_down, wq_scratch, 1, 0, s); g.W = wq_scratch; }
+        if (quantized) g.W = deq_w(w, 3, (size_t)w.q_down.N * w.q_down.K, [&](uint16_t* dst) { launch_dequant_bf16(w.q_down, dst, 1, 0, s); });
         if (!rccl) {
             g.C = pX;
             xn_ready = li + 1 < cfg.L && !(li < deep_layers && splice_map_dev != nullptr);

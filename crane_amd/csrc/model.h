@@ -52,6 +52,9 @@ struct Config {
 };
 
 struct LayerW {
+    // quantised model, prompt-weight cache on: the bf16 GEMM operand of each projection, dequantised ONCE (filled at the first prompt
+    // pass that reaches the layer): [0] qkv / in_proj (merged, padded), [1] o / out_proj, [2] gate|up, [3] down
+    uint16_t* dq[4] = {nullptr, nullptr, nullptr, nullptr};
     uint16_t* qkv = nullptr;      // [(Hq_l + 2 Hkv_l) D, H]     merged (modeling.rs:187-204)
     uint16_t* o = nullptr;        // [H, Hq_l D]                 K-slice of o_proj under TP
     uint16_t* gate_up = nullptr;  // [2 I_l, H] rows interleaved gate_j, up_j
@@ -302,6 +305,7 @@ struct Model {
     float *kshadow = nullptr, *vshadow = nullptr;   // int8/int4 KV prefill: dequantised f32 K/V of ONE layer, identity pages
     int32_t* d_ident_bt = nullptr;                  // [max_pages_per_seq] 0, 1, 2, ...
     uint16_t* wq_scratch = nullptr;    // [max N*K] bf16: one dequantised matrix at a time for the prefill GEMMs
+    bool wq_cache = false;             // keep every dequantised matrix instead (CM_QUANT_PREFILL_CACHE; automatic when the copies fit a quarter of the free HBM)
     bool gdn_ck_on = true;                      // cm_debug_set("gdn_chunked"): prompts of >= 64 tokens take the chunk-parallel Gated-Delta-Net scan
     float *gdn_pre_q = nullptr, *gdn_pre_k = nullptr, *gdn_pre_v = nullptr, *gdn_pre_bd = nullptr, *gdn_pre_g = nullptr, *gdn_ck = nullptr;   // GDN prefill scratch
     float* yb = nullptr;               // [MAXB][H] TP partial sums of the batched step
