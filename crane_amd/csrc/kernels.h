@@ -383,14 +383,17 @@ struct QGemmArgs {
     size_t slice;
     int M, ksplit, ldp;
     int silu;                  // set by launch_gemm_q8 (unsplit EPI_SILUMUL): store silu(gate) * up of the interleaved column pairs, row stride ldp
+    signed char* nxq;          // ... and, when set, quantise those rows (N / 2 columns) for the next projection: codes [M][N / 2] ...
+    float* nxd;                //     ... and block scales [N / 64][QGEMM_MAXM] (NOT the buffers this launch reads)
 };
 void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s);
 bool gemm_q8_ok(const QWeight& w, int M);
 // `next` (EPI_RESADD / EPI_SILUMUL): the rows this GEMM writes are the next projection's input -- the reduction launch also quantises
-// them (RMSNorm with next->nw first when set), exactly as launch_quant_rows_q8 would; *fused says whether it did
-struct QNext { const float* nw; float eps; signed char* xq; float* xd; };
+// them (RMSNorm with next->nw first when set), exactly as launch_quant_rows_q8 would; *fused: 0 = not quantised, 1 = into next->xq / xd
+// (by the reduction launch), 2 = into next->xq2 / xd2 (by the unsplit gate|up GEMM itself, which cannot overwrite the codes it reads)
+struct QNext { const float* nw; float eps; signed char* xq; float* xd; signed char* xq2; float* xd2; };      // (xq2 / xd2: a second pair, or null)
 bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
-                    const QNext* next = nullptr, bool* fused = nullptr);
+                    const QNext* next = nullptr, int* fused = nullptr);
 int gemvqb_max_seqs(int fmt, int K);
 int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu);
 bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s);

@@ -276,20 +276,45 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
     }
     float* P = a.ws + (size_t)ks * a.slice;
     const int nq = tn * 128 + ns * 32 + 4 * h;
+    constexpr int TS = 68;                                                  // floats per row of the SiLU tile (64 outputs + pad)
+    float* T = (float*)Ws;                                                  // (the last group's barrier is behind every panel read)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = (mh * MT + mt) * 32 + r;
-        if (m < a.M && a.silu) {
+        if (a.silu) {
             // unsplit gate|up: columns (2 k, 2 k + 1) = (gate_k, up_k) sit in one lane -- the reduction kernel's expression, no f32 round trip
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float g0 = acc[mt][2 * q][0], u0 = acc[mt][2 * q][1], g1 = acc[mt][2 * q + 1][0], u1 = acc[mt][2 * q + 1][1];
-                *(f32x2*)(P + (size_t)m * a.ldp + ((nq + 8 * q) >> 1)) = (f32x2){(g0 / (1.0f + expf(-g0))) * u0, (g1 / (1.0f + expf(-g1))) * u1};
+                const f32x2 o = (f32x2){(g0 / (1.0f + expf(-g0))) * u0, (g1 / (1.0f + expf(-g1))) * u1};
+                if (m < a.M) *(f32x2*)(P + (size_t)m * a.ldp + ((nq + 8 * q) >> 1)) = o;
+                if (a.nxq) *(f32x2*)(T + m * TS + ns * 16 + 2 * h + 4 * q) = o;
             }
         } else if (m < a.M) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 *(f32x4*)(P + (size_t)m * a.ldp + nq + 8 * q) = (f32x4){acc[mt][2 * q][0], acc[mt][2 * q][1], acc[mt][2 * q + 1][0], acc[mt][2 * q + 1][1]};
+        }
+    }
+    if (a.silu && a.nxq) {
+        // the tile's 64 outputs of every row are two Q8_0 blocks of the down projection's input: quantised here, 8 lanes x 4 values per
+        // block -- quant_rows_q8_kernel's arithmetic (amax tree, d = amax / 127, roundf(x / d), f16-rounded scale)
+        __syncthreads();
+        const int nkout = N >> 1, l8 = tid & 7;
+        for (int it = tid >> 3; it < PR * 2; it += NT >> 3) {
+            const int row = it >> 1, b = it & 1;
+            const f32x4 xv = *(const f32x4*)(T + row * TS + b * 32 + 4 * l8);
+            float am = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
+            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+            const float d = am / 127.0f;
+            const float id = d != 0.f ? 1.0f / d : 0.f;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
+            if (row < a.M) {
+                ((uint32_t*)(a.nxq + (size_t)row * nkout))[tn * 16 + b * 8 + l8] = pk;
+                if (l8 == 0) a.nxd[(size_t)(tn * 2 + b) * QGEMM_MAXM + row] = f16r(d);
+            }
         }
     }
 }
@@ -446,9 +471,9 @@ bool gemm_q8_ok(const QWeight& w, int M) {
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
 // EPI_STORE with a row stride the workspace cannot hold (the vocabulary head) is written in place by an unsplit launch.
 bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
-                    const QNext* next, bool* fused) {
+                    const QNext* next, int* fused) {
     QGemmArgs a = a0;
-    if (fused) *fused = false;
+    if (fused) *fused = 0;
     if (!gemm_q8_ok(a.w, a.M) || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return false;
     // geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that 8 waves (two halves of the rows)
     // x 2 m-tiles, one workgroup per CU, groups of 4 blocks (CM_QGEMM_GEO = 3, the default; Q8_0 serving of Qwen3-8B at 128
@@ -480,8 +505,12 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     // the partial slices of a residual / split projection always go through the workspace: refuse what it cannot hold (the
     // caller falls back to the batched GEMV) instead of writing past it
     if (!direct && (ws == nullptr || (size_t)ks * a.M * N > ws_floats)) return false;
-    a.silu = 0;
-    if (direct) { ks = 1; a.ws = y; a.ldp = ldy; a.slice = 0; a.silu = epi == EPI_SILUMUL; }
+    a.silu = 0; a.nxq = nullptr; a.nxd = nullptr;
+    static const int sq_env = getenv("CM_QGEMM_SILUQ") ? atoi(getenv("CM_QGEMM_SILUQ")) : 1;       // A/B: the unsplit gate|up GEMM quantises its own rows
+    if (direct) {
+        ks = 1; a.ws = y; a.ldp = ldy; a.slice = 0; a.silu = epi == EPI_SILUMUL;
+        if (a.silu && sq_env && next != nullptr && next->nw == nullptr && next->xq2 != nullptr && (N / 2) % 32 == 0) { a.nxq = next->xq2; a.nxd = next->xd2; }
+    }
     else { a.ws = ws; a.ldp = N; a.slice = (size_t)a.M * N; }
     a.ksplit = ks;
     static DevOnce attr;
@@ -498,7 +527,7 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     else if (mh == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 8>), grid, block, lds, s, a);
     else if (mt == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 8>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 1, 8>), grid, block, lds, s, a);
-    if (direct) return true;
+    if (direct) { if (fused && a.nxq) *fused = 2; return true; }
     // the next projection's quantiser rides on the reduction launch (CM_QGEMM_QFUSE = 0: its own launch, A/B); the quantiser's
     // lane map needs whole 32-blocks per 8 lanes: output rows of a multiple of 32 columns
     static const int qfuse_env = getenv("CM_QGEMM_QFUSE") ? atoi(getenv("CM_QGEMM_QFUSE")) : 1;
@@ -506,7 +535,7 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     if (next != nullptr && qfuse_env != 0 && (epi == EPI_RESADD || epi == EPI_SILUMUL) && kout % 32 == 0) {
         if (epi == EPI_RESADD) launch_q8_epilogue_quant<EPI_RESADD>(ws, a.M, N, ks, y, ldy, *next, s);
         else launch_q8_epilogue_quant<EPI_SILUMUL>(ws, a.M, N, ks, y, ldy, *next, s);
-        if (fused) *fused = true;
+        if (fused) *fused = 1;
         return true;
     }
     if (epi == EPI_STORE) launch_q8_epilogue<EPI_STORE>(ws, a.M, N, ks, y, ldy, s);

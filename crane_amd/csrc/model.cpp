@@ -1565,6 +1565,8 @@ void Model::ensure_batch_buffers() {
         const size_t kmax = std::max(std::max((size_t)H, (size_t)I_l), at_cols);
         qx_codes = (signed char*)dalloc<int>((size_t)QGEMM_MAXM * kmax / 4 + 16);
         qx_scales = dalloc<float>((kmax / 32 + 1) * QGEMM_MAXM);
+        qx_codes2 = (signed char*)dalloc<int>((size_t)QGEMM_MAXM * kmax / 4 + 16);      // second pair: a GEMM that quantises its own output rows
+        qx_scales2 = dalloc<float>((kmax / 32 + 1) * QGEMM_MAXM);                       // cannot overwrite the codes it is reading
     }
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
@@ -1701,10 +1703,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 QGemmArgs qg{};
                 qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
                 const int kout = epi == EPI_SILUMUL ? qw.N / 2 : qw.N;
-                QNext nx{next_nw, cfg.eps, qx_codes, qx_scales};
+                QNext nx{next_nw, cfg.eps, qx_codes, qx_scales, qx_codes2, qx_scales2};
                 const bool want_next = (next_nw != nullptr || next_plain) && ldy == kout;
-                bool fused = false;
+                int fused = 0;
                 if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused)) {
+                    if (fused == 2) { std::swap(qx_codes, qx_codes2); std::swap(qx_scales, qx_scales2); }      // (the other pair is the current one now)
                     if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; if (q_capture) q_capture_rows(nb, kout); }      // (the codes now hold the rows just written)
                     else if (epi == EPI_RESADD) qx_src = nullptr;
                     return;

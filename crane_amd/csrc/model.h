@@ -249,6 +249,8 @@ struct Model {
     int q_gemm_min = 25;                       // CM_Q_GEMM_MIN: quantised weights (Q8_0 layout): groups of this many sequences or more run their projections on the int8 matrix cores (0 = never)
     signed char* qx_codes = nullptr;           //   the group's activation rows as Q8_0 codes [QGEMM_MAXM][Kmax] ...
     float* qx_scales = nullptr;                //   ... and block scales [Kmax / 32][QGEMM_MAXM]
+    signed char* qx_codes2 = nullptr;          //   second pair (the current one is always qx_codes / qx_scales: swapped when the
+    float* qx_scales2 = nullptr;               //   unsplit gate|up GEMM wrote the next projection's codes into this one)
     // cm_debug_set("q_capture", 1) (tests): every set of Q8_0 activation rows an int8-MFMA projection of a decode group consumes is
     // copied to the host as it is produced -- records {K, rows, codes[rows][K], scales[rows][K / 32]} as floats, in consumption order --
     // so that the parity tests can check the quantiser's roundings and feed the oracle the codes the kernel multiplied
