@@ -7,13 +7,15 @@
 //                          kernels' prologue bit for bit (RMSNorm sums in the same order, d = amax / 127, roundf(x / d)) --
 //                          once per projection input, not once per workgroup;
 //   gemm_q8_i8_kernel    : C[m][n] = sum over 32-element blocks b of (dw[n][b] * dx[m][b]) * (int32 dot of the block's codes) --
-//                          ggml_vec_dot_q8_0_q8_0 per (m, n): the integer dots on v_mfma_i32_32x32x16_i8 (two per block: a lane's
-//                          16 bytes of a row are k 16 h .. 16 h + 15 of the block, low half -> first MFMA, high half -> second;
-//                          weights and activations use the same map), the block scales applied on the VALU to the 16 int32 a lane
-//                          gets per (m-tile, block).  A wave owns 32 weight rows and streams them straight into registers (a
-//                          weight byte is read by exactly one wave); the activation codes (M x K bytes, L2-resident) come the
-//                          same way, their block scales ride along, transposed ([block][row]).
-//                          Split K over workgroups to fill the chip; f32 partials [ks][M][N];
+//                          ggml_vec_dot_q8_0_q8_0 per (m, n): the integer dot of a block is ONE v_mfma_i32_32x32x32_i8 (a lane's 16
+//                          bytes of a row are k 16 h .. 16 h + 15 of the block, weights and activations alike), the block scales are
+//                          applied on the VALU to the 16 int32 a lane gets per (m-tile, block).  Weight AND activation codes of a group
+//                          of 4 or 8 blocks reach the workgroup as whole 128- / 256-byte row segments (coalesced, one group ahead in
+//                          registers) and go through double-buffered LDS panels, where the waves pick their MFMA fragments (round 5;
+//                          round 4 loaded the weight fragments straight from memory, 32 rows x 32 bytes per instruction: every cache
+//                          line touched by four instructions -- that, not the arithmetic, bound the kernel).
+//                          Split K over workgroups to fill the chip; f32 partials [ks][M][N]; an unsplit launch stores (and applies
+//                          SiLU(gate) * up, and quantises those rows for the down projection) itself;
 //   q8_splitk_epilogue   : adds the slices in order and stores / adds the residual / SiLU(gate) * up -- f32 rows, the input of the
 //                          next projection's quantiser.
 //

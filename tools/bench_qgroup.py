@@ -22,5 +22,5 @@ t0 = time.perf_counter()
 for _ in range(K):
     _, g = m.step_batch_decode(seqs, toks, want_logits=False); toks = [int(t) % V for t in g]
 dt = (time.perf_counter() - t0) / K
-print(f"qgroup L={L} nb={NB} {ISQ} CM_QABL={os.environ.get('CM_QABL', '0')}: {dt * 1e3:7.3f} ms/step = {dt * 1e6 / L:7.1f} us/layer (head included)  ids {toks[:4]}", flush=True)
+print(f"qgroup L={L} nb={NB} {ISQ}: {dt * 1e3:7.3f} ms/step = {dt * 1e6 / L:7.1f} us/layer (head included)  ids {toks[:4]}", flush=True)
 m.close()
