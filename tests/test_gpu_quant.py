@@ -332,6 +332,8 @@ def test_batched_decode_over_gguf_weights(tmp_path, monkeypatch, kind, nb):
     G.write_qwen3_gguf(path, cfg, w, _types(kind))
     m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", max_seqs=26, quant_prefill=False)
     try:
+        m.debug_set("q_gemm_min", 0)            # the batched GEMV is under test (groups of 8 or more default to the int8-MFMA GEMM, whose
+                                                # rows agree with the single-sequence step to f32 summation order, not bit for bit)
         if nb > 8:
             m.debug_set("attn_splits", 8)       # the automatic split count shrinks with the batch: pin it so that the
                                                 # comparison stays bit for bit (the GEMV rows are what is under test)
@@ -346,6 +348,7 @@ def test_batched_decode_isq_hybrid(monkeypatch, nb):
     cfg = configs.get_config("tiny-qwen3.5")
     m = Model.synthetic(cfg, seed=0, max_seq_len=128, kv_dtype="f32", isq="q8_0", max_seqs=10, quant_prefill=False)
     try:
+        m.debug_set("q_gemm_min", 0)            # (bit for bit: the batched GEMV, also for the head -- see above)
         _batched_vs_sequential(m, cfg["vocab_size"], nb, rounds=2)
     finally:
         m.close()
@@ -387,11 +390,11 @@ def _group_oracle(isq):
     return cfg, o
 
 
-@pytest.mark.parametrize("isq,nb", [("q8_0", 40), ("q8_0", 128), ("q4_0", 96)])
+@pytest.mark.parametrize("isq,nb", [("q8_0", 12), ("q8_0", 40), ("q8_0", 128), ("q4_0", 96)])
 def test_large_quantised_decode_groups_on_the_int8_matrix_cores(isq, nb):
-    """Groups of q_gemm_min (25) or more sequences over Q8_0-layout weights (kernels_quant_gemm.hip): activation rows quantised once
-    per projection input (quant_rows_q8_kernel, or the reduction launch of the projection before it), the integer block dots on
-    v_mfma_i32_32x32x16_i8, block scales on the VALU -- at the 8B widths (151 936-row quantised head included), EVERY row of every
+    """Groups of q_gemm_min (8) or more sequences over Q8_0-layout weights (kernels_quant_gemm.hip; 12 / 40 / 96-128 rows = its three
+    geometries): activation rows quantised once per projection input (quant_rows_q8_kernel, the reduction launch of the projection before
+    it, or the unsplit gate|up GEMM itself), the integer block dots on v_mfma_i32_32x32x32_i8, block scales on the VALU -- at the 8B widths (151 936-row quantised head included), EVERY row of every
     round against the CPU oracle of ggml's quantised-activation semantics (oracle/qgroup_oracle.py: quantize_row_q8_0 of the
     activation row, ggml_vec_dot_q8_0_q8_0 per output; weights through quantize_row_q8_0_ref / _q4_0_ref).
     Teacher-forced where two correct implementations legitimately part ways: the device reports the activation codes each
@@ -407,7 +410,7 @@ def test_large_quantised_decode_groups_on_the_int8_matrix_cores(isq, nb):
     V = cfg["vocab_size"]
     m = Model.synthetic(cfg, seed=0, max_seq_len=64, isq=isq, max_seqs=nb + 2, kv_dtype="f32", quant_prefill=False)
     try:
-        m.debug_set("q_gemm_min", 25)
+        m.debug_set("q_gemm_min", 8)
         m.debug_set("q_capture", 1)
         seqs = [m.seq_alloc() for _ in range(nb)]
         toks = [(5 + 3 * b + 7 * (b % 5)) % V for b in range(nb)]
