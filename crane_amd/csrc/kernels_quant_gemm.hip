@@ -387,6 +387,60 @@ __global__ __launch_bounds__(256) void q8_splitk_quant_kernel(const float* __res
         }
         return v;
     };
+    if (n4 <= 1024) {
+        // rows of <= 4096 outputs (o_proj / down_proj of the 8B widths): a thread's four chunks stay in registers through the three passes
+        // -- the same values in the same order as below, without reading the row back twice, and every slice load of the row in flight
+        // at once (8.1 -> ~6 us per launch at 8 slices)
+        f32x4 o[4], wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k4 = t2 + 256 * j;
+            o[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; wv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k4 >= n4) continue;
+            if (NORM) wv[j] = *(const f32x4*)(nw + (k4 << 2));
+            if (EPI == EPI_SILUMUL) {
+                const f32x4 a0 = reduce4(8 * k4), a1 = reduce4(8 * k4 + 4);
+                o[j][0] = (a0[0] / (1.0f + expf(-a0[0]))) * a0[1]; o[j][1] = (a0[2] / (1.0f + expf(-a0[2]))) * a0[3];
+                o[j][2] = (a1[0] / (1.0f + expf(-a1[0]))) * a1[1]; o[j][3] = (a1[2] / (1.0f + expf(-a1[2]))) * a1[3];
+            } else {
+                const f32x4 v = reduce4(4 * k4), c = *(const f32x4*)(yr + 4 * k4);
+                o[j] = (f32x4){v[0] + c[0], v[1] + c[1], v[2] + c[2], v[3] + c[3]};
+            }
+            *(f32x4*)(yr + 4 * k4) = o[j];
+        }
+        float r = 1.f;
+        if (NORM) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t2 + 256 * j < n4) ss = fmaf(o[j][3], o[j][3], fmaf(o[j][2], o[j][2], fmaf(o[j][1], o[j][1], fmaf(o[j][0], o[j][0], ss))));
+            const float t = wave_sum(ss);
+            if (lane == 0) red[w2] = t;
+            __syncthreads();
+            r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)Kout + eps);
+        }
+        uint32_t* xqr = (uint32_t*)(xq + (size_t)m * Kout);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k4 = t2 + 256 * j;
+            if (k4 >= n4) break;
+            f32x4 xv = o[j];
+            if (NORM) {
+                xv[0] = __fmul_rn(__fmul_rn(xv[0], r), wv[j][0]); xv[1] = __fmul_rn(__fmul_rn(xv[1], r), wv[j][1]);
+                xv[2] = __fmul_rn(__fmul_rn(xv[2], r), wv[j][2]); xv[3] = __fmul_rn(__fmul_rn(xv[3], r), wv[j][3]);
+            }
+            float am = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
+            am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+            const float d = am / 127.0f;
+            const float id = d != 0.f ? 1.0f / d : 0.f;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
+            xqr[k4] = pk;
+            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * QGEMM_MAXM + m] = f16r(d);
+        }
+        return;
+    }
     // pass 1: the row of y (what q8_splitk_epilogue_kernel writes)
     for (int k4 = t2; k4 < n4; k4 += 256) {
         f32x4 o;
