@@ -392,6 +392,9 @@ bool gemm_q8_ok(const QWeight& w, int M);
 // them (RMSNorm with next->nw first when set), exactly as launch_quant_rows_q8 would; *fused: 0 = not quantised, 1 = into next->xq / xd
 // (by the reduction launch), 2 = into next->xq2 / xd2 (by the unsplit gate|up GEMM itself, which cannot overwrite the codes it reads)
 struct QNext { const float* nw; float eps; signed char* xq; float* xd; signed char* xq2; float* xd2; };      // (xq2 / xd2: a second pair, or null)
+// what launch_gemm_q8 will do for a shape (host logic only): ok = false -> the caller's GEMV fallback
+struct QGemmPlan { bool ok, direct; int geo, mh, mt, qg, groups, ks, grid; size_t lds; };
+QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu);
 bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
                     const QNext* next = nullptr, int* fused = nullptr);
 int gemvqb_max_seqs(int fmt, int K);

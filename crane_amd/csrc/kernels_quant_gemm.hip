@@ -526,41 +526,59 @@ bool gemm_q8_ok(const QWeight& w, int M) {
 
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
 // EPI_STORE with a row stride the workspace cannot hold (the vocabulary head) is written in place by an unsplit launch.
-bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
-                    const QNext* next, int* fused) {
-    QGemmArgs a = a0;
-    if (fused) *fused = 0;
-    if (!gemm_q8_ok(a.w, a.M) || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return false;
-    // geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that 8 waves (two halves of the rows)
-    // x 2 m-tiles, one workgroup per CU, groups of 4 blocks (CM_QGEMM_GEO = 3, the default; Q8_0 serving of Qwen3-8B at 128
-    // sequences 11.46 K tok/s), or the same with groups of 8 blocks (= 0: 11.01 K), or 4 waves x 4 m-tiles with groups of 4 blocks: 80 KB
-    // of LDS, two independent workgroups per CU (= 1: 11.18 K)
+// Host-side plan of one launch (pure: no device calls; cm_debug_qgemm_plan exposes it to the CPU tests).
+//   geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that 8 waves (two halves of the rows) x 2
+//   m-tiles, one workgroup per CU, groups of 4 blocks (CM_QGEMM_GEO = 3, the default; Q8_0 serving of Qwen3-8B at 128 sequences 11.46 K
+//   tok/s when it was chosen), or the same with groups of 8 blocks (= 0: 11.01 K), or 4 waves x 4 m-tiles with groups of 4 blocks: 80 KB of
+//   LDS, two independent workgroups per CU (= 1: 11.18 K);
+//   K split: the chip holds `cap` workgroups at a time (256 registers per lane: 2 waves per SIMD); a launch of `tiles * ks` of them runs in
+//   ceil(tiles ks / cap) rounds of (1 start-up + ceil(G / ks) groups), and every slice costs a write + a read of M x N f32.
+QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu) {
+    QGemmPlan p{};
+    if (M < 1 || M > QGEMM_MAXM || N % 128 != 0 || K % (32 * QG_MIN) != 0 || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return p;
     static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 3;
-    const int geo = a.M > 64 ? (geo_env == 0 ? 1 : geo_env == 1 ? 2 : 3) : 0;
-    const int mh = geo == 1 || geo == 3 ? 2 : 1, mt = geo == 2 ? 4 : a.M > 32 ? 2 : 1, qg = geo >= 2 ? 4 : 8;
-    const int N = a.w.N, nkb_all = a.w.K >> 5, tiles = N / 128, G = nkb_all / qg;
-    const size_t lds = (size_t)(2 * qg * QGEMM_MAXM + 4 * mh * qg * 32) * sizeof(float) + (size_t)2 * (128 + mh * mt * 32) * (qg * 32 + 16);
-    // K split: the chip holds `cap` workgroups at a time (256 registers per lane: 2 waves per SIMD); a launch of `tiles * ks` of them
-    // runs in ceil(tiles ks / cap) rounds of (1 start-up + ceil(G / ks) groups), and every slice costs a write + a read of M x N f32
-    const int cap = num_cu * (mh == 2 ? 1 : 2);
-    const double tgroup_us = 2.0, fill_us = 2.5, part_us = 8.0 * a.M * N / 3.0e6;     // (partials at ~3 TB/s, write + read)
+    const int geo = M > 64 ? (geo_env == 0 ? 1 : geo_env == 1 ? 2 : 3) : 0;
+    p.geo = geo;
+    p.mh = geo == 1 || geo == 3 ? 2 : 1; p.mt = geo == 2 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : 8;
+    const int nkb_all = K >> 5, tiles = N / 128, G = nkb_all / p.qg;
+    p.groups = G;
+    p.lds = (size_t)(2 * p.qg * QGEMM_MAXM + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + p.mh * p.mt * 32) * (p.qg * 32 + 16);
+    const int cap = num_cu * (p.mh == 2 ? 1 : 2);
+    const double tgroup_us = 2.0, fill_us = 2.5, part_us = 8.0 * M * N / 3.0e6;        // (partials at ~3 TB/s, write + read)
     int ks = 1;
     double best = 1e30;
-    const bool direct_only = epi == EPI_STORE && (size_t)a.M * N > ws_floats;          // (the vocabulary head: written in place, unsplit)
+    const bool direct_only = epi == EPI_STORE && (size_t)M * N > ws_floats;            // (the vocabulary head: written in place, unsplit)
     for (int k = 1; k <= 16 && k <= G && !direct_only; ++k) {
         if (k == 7 || k == 9 || k == 11 || (k > 12 && k < 16)) continue;                  // (splits the reduction kernels are unrolled for)
-        if (k > 1 && (ws == nullptr || (size_t)k * a.M * N > ws_floats)) break;
+        if (k > 1 && (!have_ws || (size_t)k * M * N > ws_floats)) break;
         const int rounds = (tiles * k + cap - 1) / cap;
         const double c = rounds * (fill_us + tgroup_us * ((G + k - 1) / k)) + (k > 1 || epi == EPI_RESADD ? k * part_us : 0.0);
         if (c < best) { best = c; ks = k; }
     }
     static const int ks_env = getenv("CM_QGEMM_KS") ? atoi(getenv("CM_QGEMM_KS")) : 0;           // tuning: force the split
-    if (ks_env > 0 && !direct_only && ks_env <= G && ws != nullptr && (size_t)ks_env * a.M * N <= ws_floats) ks = ks_env;
+    if (ks_env > 0 && !direct_only && ks_env <= G && have_ws && (size_t)ks_env * M * N <= ws_floats) ks = ks_env;
     // unsplit: the store (and SiLU(gate) * up of a gate|up projection) happens in the GEMM's own epilogue, no partial slices
-    const bool direct = (epi == EPI_STORE || epi == EPI_SILUMUL) && (direct_only || ks == 1);
+    p.direct = (epi == EPI_STORE || epi == EPI_SILUMUL) && (direct_only || ks == 1);
     // the partial slices of a residual / split projection always go through the workspace: refuse what it cannot hold (the
     // caller falls back to the batched GEMV) instead of writing past it
-    if (!direct && (ws == nullptr || (size_t)ks * a.M * N > ws_floats)) return false;
+    if (!p.direct && (!have_ws || (size_t)ks * M * N > ws_floats)) return p;
+    p.ks = p.direct ? 1 : ks;
+    p.grid = tiles * p.ks;
+    p.ok = p.lds <= (size_t)160 * 1024;
+    return p;
+}
+
+bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
+                    const QNext* next, int* fused) {
+    QGemmArgs a = a0;
+    if (fused) *fused = 0;
+    if (!gemm_q8_ok(a.w, a.M)) return false;
+    const QGemmPlan pl = plan_gemm_q8(a.M, a.w.N, a.w.K, epi, ws != nullptr, ws_floats, num_cu);
+    if (!pl.ok) return false;
+    const int N = a.w.N, tiles = N / 128, mh = pl.mh, mt = pl.mt, geo = pl.geo;
+    int ks = pl.ks;
+    const bool direct = pl.direct;
+    const size_t lds = pl.lds;
     a.silu = 0; a.nxq = nullptr; a.nxd = nullptr;
     static const int sq_env = getenv("CM_QGEMM_SILUQ") ? atoi(getenv("CM_QGEMM_SILUQ")) : 1;       // A/B: the unsplit gate|up GEMM quantises its own rows
     if (direct) {

@@ -479,6 +479,13 @@ int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x
  * (cm_last_global_error).  More than 4 ranks on one device need GPU_MAX_HW_QUEUES >= n_ranks exported before the HIP runtime starts. */
 long cm_debug_peer_selftest(int32_t n_ranks, int32_t device, int32_t iters, int32_t count);
 
+/* Test hook (host logic only, no device): what the int8-MFMA GEMM of a quantised decode group (csrc/kernels_quant_gemm.hip; it replaces the
+ * per-sequence `QMatMul::forward` calls of a batched step, candle quantized matmul behind ops/linear.rs:53-116) would do for `m` activation
+ * rows over an [n][k] Q8_0-layout matrix on `num_cu` CUs with a split-K workspace of `ws_floats` f32 (0: none): epi 0 store, 1 residual
+ * add, 2 SiLU(gate) * up.  out[0..7] = { ok (0: the batched GEMV takes the projection), unsplit store, waves per workgroup, activation
+ * rows per workgroup, 32-blocks per K group, K groups, K split, workgroups }.  Slice i of the split covers groups [i G / ks, (i + 1) G / ks). */
+int cm_debug_qgemm_plan(int32_t m, int32_t n, int32_t k, int32_t epi, uint64_t ws_floats, int32_t num_cu, int64_t out[8]);
+
 /* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at
  * cm_create).  "no_prefill" = 1: prompts run token by token through the decode kernels; "quant_prefill" = 0: prompts over
  * quantised weights run through the integer-dot decode kernels instead of the dequantised MFMA GEMMs; "prefill_split" = 1 / 2:
