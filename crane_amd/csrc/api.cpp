@@ -542,6 +542,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         const std::string k = key;
         if (k == "no_prefill") mm.no_prefill = value != 0;
         else if (k == "quant_prefill") mm.quant_prefill = value != 0;
+        else if (k == "attn_outq") mm.attn_outq = value != 0;
         else if (k == "prefill_split") mm.prefill_split2 = value < 0 ? mm.default_prefill_split2() : value != 1;   // 1: plain bf16, 0 / 2: hi + lo, -1: back to cm_opts
         // which decode-attention kernel / persistent-kernel mode a step uses (tests and A/B runs; one hipGraph per variant, so
         // the thresholds switch live -- a switch that changes what a variant enqueues drops the captured graphs)

@@ -70,6 +70,8 @@ struct AttnDecArgs {
     uint16_t* out1_hi = nullptr; //   ... or, when set (the caller asked attn_decode_single_split()), as bf16 hi + lo planes [seq][out1_cols]: the A
     uint16_t* out1_lo = nullptr; //   operand of the o_proj GEMM of a large decode group (split_rows2d's arithmetic), instead of the f32 rows
     int out1_cols = 0;
+    signed char* out1_q = nullptr;  // ... and ALSO (matrix-core kernel, single split) as Q8_0 blocks of the rows: codes [seq][out1_cols] + block scales
+    float* out1_qd = nullptr;       //   [out1_cols / 32][QGEMM_MAXM] -- quant_rows_q8_kernel's arithmetic: the int8 o_proj GEMM of a quantised group reads them
     int q_off, k_off, v_off;     // element offsets of q / k / v inside qkv
     int qkv_stride, bt_stride;   // batched step: per-sequence strides of qkv rows and block tables
     int Hkv, page, max_pages, rot_dim;

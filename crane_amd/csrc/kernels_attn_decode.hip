@@ -919,6 +919,21 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
             } else {
                 a.out1[(size_t)bq * a.out1_stride + (size_t)(kvh * NREP + h) * D + d] = v;
             }
+            if (a.out1_q != nullptr) {
+                // the row is the o_proj input of a quantised decode group: 32 consecutive lanes hold one Q8_0 block of it (every wave of
+                // the loop is fully active: NREP D is a multiple of 64) -- amax, d = amax / 127, roundf(x / d), f16-rounded scale
+                float am = fabsf(v);
+                am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
+                am = fmaxf(am, __shfl_xor(am, 8)); am = fmaxf(am, __shfl_xor(am, 16));
+                const float dq = am / 127.0f;
+                const float id = dq != 0.f ? 1.0f / dq : 0.f;
+                const int col = (kvh * NREP + h) * D + d;
+                a.out1_q[(size_t)bq * a.out1_cols + col] = (signed char)(int)roundf(v * id);
+                if ((lane & 31) == 0) {
+                    const _Float16 hq = (_Float16)dq;
+                    a.out1_qd[(size_t)(col >> 5) * QGEMM_MAXM + bq] = (float)hq;
+                }
+            }
             continue;
         }
         const size_t ph = ((size_t)bq * a.Hkv * NREP + (size_t)(kvh * NREP + h)) * nsplit + split;
@@ -956,7 +971,7 @@ bool launch_attn_decode_mfma(const AttnDecArgs& a, int D, int nrep, int nsplit, 
         b.out1 = out; b.out1_stride = out_stride;
         return D == 128 ? launch_mfma<128>(b, nrep, 1, kv_mode, n_seq, s) : launch_mfma<256>(b, nrep, 1, kv_mode, n_seq, s);
     }
-    if (a.out1_hi != nullptr) return false;                      // (planes are only written by the single-split form)
+    if (a.out1_hi != nullptr || a.out1_q != nullptr) return false;       // (planes / codes are only written by the single-split form)
     if (D == 128) {
         if (!launch_mfma<128>(a, nrep, nsplit, kv_mode, n_seq, s)) return false;
         hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3(a.Hkv * nrep, n_seq), dim3(1024), 0, s, a.part_o, a.part_ml,
@@ -989,6 +1004,7 @@ static bool launch_split(const AttnDecArgs& a, int nrep, int nsplit, int kv_mode
 
 bool launch_attn_decode(const AttnDecArgs& a, int D, int nrep, int nsplit, int kv_mode, float* out, int out_stride, int n_seq,
                         hipStream_t s) {
+    if (a.out1_q != nullptr) return false;                       // (only the matrix-core kernel quantises its output rows)
     if (attn_decode_single_split(nsplit, D)) {                   // (see launch_attn_decode_mfma)
         AttnDecArgs b = a;
         b.out1 = out; b.out1_stride = out_stride;

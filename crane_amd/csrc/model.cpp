@@ -266,6 +266,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, std::min((int)GEMV_MAXB, atoi(e)));
     if (const char* e = getenv("CM_LM_HEAD_GEMM_MIN")) lm_head_gemm_min = std::max(0, atoi(e));
     if (const char* e = getenv("CM_Q_GEMM_MIN")) q_gemm_min = std::max(0, atoi(e));
+    if (const char* e = getenv("CM_ATTN_OUTQ")) attn_outq = atoi(e) != 0;
     if (const char* e = getenv("CM_BATCH_MAX")) batch_max = std::max(8, std::min((int)GEMV_MAXB, atoi(e) / 8 * 8));
     if (const char* e = getenv("CM_QUANT_ACT")) quant_act_int = std::string(e) != "f32";
     if (const char* e = getenv("CM_ATTN_HEADS_MAX")) attn_heads_max = atoll(e);
@@ -1808,9 +1809,14 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 // group, writes the bf16 hi + lo planes the GEMM reads (no split_rows2d launch either)
                 const bool planes = gemm_b && !quantized && attn_decode_single_split(ns_b, D);
                 if (planes) { a.out1_hi = pAT_hi; a.out1_lo = pAT_lo; a.out1_cols = Hq_l * D; }
+                // ... or, in front of the int8 o_proj GEMM of a quantised group, ALSO the Q8_0 blocks of the rows (no quantiser launch)
+                const bool codes = attn_outq && mf && qgemm_ok && nb >= q_gemm_min && attn_decode_single_split(ns_b, D) && !cfg.hybrid &&
+                                   gemm_q8_ok(w.q_o, nb) && (Hq_l * D) % 64 == 0;
+                if (codes) { a.out1_q = qx_codes; a.out1_qd = qx_scales; a.out1_cols = Hq_l * D; }
                 if (mf) {
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
+                if (codes) { qx_src = attnb; qx_nw = nullptr; qx_K = Hq_l * D; if (q_capture) q_capture_rows(nb, Hq_l * D); }      // (the codes hold the attention rows)
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols, w.ln2);
                 else if (gemm_b) {
                     if (!planes) launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);

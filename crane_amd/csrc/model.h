@@ -246,6 +246,7 @@ struct Model {
     static constexpr int GEMV_MAXB = 64;       // ... on the batched GEMVs (2 / 4 / 8 L2-sharing groups of 8)
     int batch_max = 64;                        // CM_BATCH_MAX = 8 | 16 | 32 | 64 (A/B)
     int lm_head_gemm_min = 9;                  // CM_LM_HEAD_GEMM_MIN: groups of this many sequences or more run the head as an MFMA GEMM + row arg-max (0 = never)
+    bool attn_outq = true;                     // CM_ATTN_OUTQ / cm_debug_set("attn_outq"): the single-split matrix-core attention of a quantised group also writes the Q8_0 blocks of its rows (A/B)
     int q_gemm_min = 8;                        // CM_Q_GEMM_MIN: quantised weights (Q8_0 layout): groups of this many sequences or more run their projections on the int8 matrix cores (0 = never)
     signed char* qx_codes = nullptr;           //   the group's activation rows as Q8_0 codes [QGEMM_MAXM][Kmax] ...
     float* qx_scales = nullptr;                //   ... and block scales [Kmax / 32][QGEMM_MAXM]

@@ -488,7 +488,8 @@ int cm_debug_qgemm_plan(int32_t m, int32_t n, int32_t k, int32_t epi, uint64_t w
 
 /* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at
  * cm_create).  "no_prefill" = 1: prompts run token by token through the decode kernels; "quant_prefill" = 0: prompts over
- * quantised weights run through the integer-dot decode kernels instead of the dequantised MFMA GEMMs; "prefill_split" = 1 / 2:
+ * quantised weights run through the integer-dot decode kernels instead of the dequantised MFMA GEMMs; "attn_outq" = 0 / 1: the single-split matrix-core
+ * decode attention of a quantised group writes the Q8_0 blocks of its output rows itself (1, default) or leaves them to a quantiser launch; "prefill_split" = 1 / 2:
  * cm_opts.prefill_split of the live model (plain bf16 / bf16 hi + lo prompt activations); "batch_gemm_min" = n: cm_decode_batch
  * runs the projections of n or more sequences as MFMA GEMMs (0 = never: batched GEMVs, rows bit-equal to cm_forward_step);
  * "attn_splits" = n > 0:

@@ -479,3 +479,33 @@ def test_engine_over_large_quantised_groups_emits_near_argmax_tokens_at_every_de
         assert exact >= 0.85 * total, (exact, total)
     finally:
         m.close()
+
+
+def test_attention_rows_quantised_by_the_attention_kernel_equal_the_quantiser_launch():
+    """A quantised group whose (kv head, sequence) pairs fill the chip (64 sequences x 8 kv heads, contexts >= 64) runs ONE token split
+    per sequence on the matrix-core attention kernel, which then also writes the Q8_0 blocks of its output rows for the int8 o_proj GEMM
+    (AttnDecArgs::out1_q: amax over the 32 lanes of a block, d = amax / 127, roundf(x / d), f16-rounded scale -- quant_rows_q8_kernel's
+    arithmetic on the same f32 values).  Same codes => the logits of the step must be BIT-EQUAL with the separate quantiser launch
+    (cm_debug_set("attn_outq", 0)), and the captured codes of every projection input identical."""
+    from crane_amd.backend import Model
+    cfg = configs.get_config("qwen3-8b-2l")
+    V = cfg["vocab_size"]
+    nb = 64
+    m = Model.synthetic(cfg, seed=0, max_seq_len=128, isq="q8_0", max_seqs=2 * nb + 2)
+    try:
+        seqs, twins, toks = [], [], []
+        for b in range(nb):
+            s = m.seq_alloc()
+            _, g = m.seq_forward(s, [(7 * i + 3 + 11 * b) % V for i in range(70 + b % 5)], 0, want_logits=False)
+            seqs.append(s); twins.append(m.seq_fork(s)); toks.append(int(g))
+        m.debug_set("q_capture", 1)
+        m.debug_set("attn_outq", 1)
+        a, ga = m.step_batch_decode(seqs, toks)
+        ca = m.debug_read("q_capture", int(m.debug_read("q_capture_len", 1)[0])).copy()
+        m.debug_set("attn_outq", 0)
+        b_, gb = m.step_batch_decode(twins, toks)
+        cb = m.debug_read("q_capture", int(m.debug_read("q_capture_len", 1)[0])).copy()
+        assert ca.shape == cb.shape and np.array_equal(ca, cb)
+        assert np.array_equal(a, b_) and np.array_equal(ga, gb)
+    finally:
+        m.close()
