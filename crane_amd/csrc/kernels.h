@@ -70,6 +70,8 @@ struct AttnDecArgs {
     uint16_t* out1_hi = nullptr; //   ... or, when set (the caller asked attn_decode_single_split()), as bf16 hi + lo planes [seq][out1_cols]: the A
     uint16_t* out1_lo = nullptr; //   operand of the o_proj GEMM of a large decode group (split_rows2d's arithmetic), instead of the f32 rows
     int out1_cols = 0;
+    int qkv_ns = 1;              // qkv rows as qkv_ns f32 slices qkv_slice floats apart (the K-split partials of the int8 qkv GEMM, added in order by the
+    size_t qkv_slice = 0;        //   matrix-core kernel's prologue: no reduction launch); 1 = plain rows
     signed char* out1_q = nullptr;  // ... and ALSO (matrix-core kernel, single split) as Q8_0 blocks of the rows: codes [seq][out1_cols] + block scales
     float* out1_qd = nullptr;       //   [out1_cols / 32][QGEMM_MAXM] -- quant_rows_q8_kernel's arithmetic: the int8 o_proj GEMM of a quantised group reads them
     int q_off, k_off, v_off;     // element offsets of q / k / v inside qkv
@@ -394,11 +396,14 @@ bool gemm_q8_ok(const QWeight& w, int M);
 // them (RMSNorm with next->nw first when set), exactly as launch_quant_rows_q8 would; *fused: 0 = not quantised, 1 = into next->xq / xd
 // (by the reduction launch), 2 = into next->xq2 / xd2 (by the unsplit gate|up GEMM itself, which cannot overwrite the codes it reads)
 struct QNext { const float* nw; float eps; signed char* xq; float* xd; signed char* xq2; float* xd2; };      // (xq2 / xd2: a second pair, or null)
+// EPI_STORE with a consumer that adds the K-split slices itself (the decode attention's prologue): when `defer` is given and the launch
+// splits K into 2 .. 4 slices, no reduction is launched -- ks slices of `slice` floats at ws, rows N floats apart; ks = 1: y holds the rows as usual
+struct QDefer { int ks; size_t slice; const float* ws; };
 // what launch_gemm_q8 will do for a shape (host logic only): ok = false -> the caller's GEMV fallback
 struct QGemmPlan { bool ok, direct; int geo, mh, mt, qg, groups, ks, grid; size_t lds; };
 QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu);
 bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
-                    const QNext* next = nullptr, int* fused = nullptr);
+                    const QNext* next = nullptr, int* fused = nullptr, QDefer* defer = nullptr);
 int gemvqb_max_seqs(int fmt, int K);
 int gemvqb_grid(int fmt, int N, int K, int n_seq, int num_cu);
 bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t s);

@@ -709,7 +709,22 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(AttnDecArgs a) {
         float xv[EPL];
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) { xv[j] = src[lane + 64 * j]; ss += xv[j] * xv[j]; }
+        for (int j = 0; j < EPL; ++j) xv[j] = src[lane + 64 * j];
+        if (a.qkv_ns > 1) {
+            // the rows are the K-split partials of the int8 qkv GEMM (2 .. 4 slices): added here in slice order.  All loads first (a
+            // missing slice re-reads slice 0 and adds nothing): one round trip, not one per slice
+            float p[3][EPL];
+#pragma unroll
+            for (int sl = 1; sl < 4; ++sl)
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) p[sl - 1][j] = src[(size_t)(sl < a.qkv_ns ? sl : 0) * a.qkv_slice + lane + 64 * j];
+#pragma unroll
+            for (int sl = 1; sl < 4; ++sl)
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) xv[j] += sl < a.qkv_ns ? p[sl - 1][j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) ss += xv[j] * xv[j];
         if (item <= NREP) {
             if (nw != nullptr) {
                 ss = wave_sum(ss);

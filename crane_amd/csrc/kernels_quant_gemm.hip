@@ -569,8 +569,9 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
 }
 
 bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
-                    const QNext* next, int* fused) {
+                    const QNext* next, int* fused, QDefer* defer) {
     QGemmArgs a = a0;
+    if (defer) { defer->ks = 1; defer->slice = 0; defer->ws = nullptr; }
     if (fused) *fused = 0;
     if (!gemm_q8_ok(a.w, a.M)) return false;
     const QGemmPlan pl = plan_gemm_q8(a.M, a.w.N, a.w.K, epi, ws != nullptr, ws_floats, num_cu);
@@ -602,6 +603,7 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     else if (mt == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 8>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 1, 8>), grid, block, lds, s, a);
     if (direct) { if (fused && a.nxq) *fused = 2; return true; }
+    if (epi == EPI_STORE && defer != nullptr && ks <= 4) { defer->ks = ks; defer->slice = a.slice; defer->ws = ws; return true; }      // (the consumer adds the slices)
     // the next projection's quantiser rides on the reduction launch (CM_QGEMM_QFUSE = 0: its own launch, A/B); the quantiser's
     // lane map needs whole 32-blocks per 8 lanes: output rows of a multiple of 32 columns
     static const int qfuse_env = getenv("CM_QGEMM_QFUSE") ? atoi(getenv("CM_QGEMM_QFUSE")) : 1;

@@ -1693,7 +1693,8 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         // next_nw / next_plain: the rows this projection writes are the NEXT projection's input (RMSNorm weight next_nw, or no norm):
         // the int8-MFMA path quantises them on its reduction launch (QNext)
         auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy,
-                      const float* next_nw = nullptr, bool next_plain = false) {
+                      const float* next_nw = nullptr, bool next_plain = false, QDefer* defer = nullptr) {
+            if (defer) { defer->ks = 1; defer->slice = 0; defer->ws = nullptr; }
             if (qgemm_ok && nb >= q_gemm_min && (epi == EPI_STORE || epi == EPI_RESADD || epi == EPI_SILUMUL) && gemm_q8_ok(qw, nb)) {
                 const float* nwe = pro == PRO_RMSNORM ? nw : nullptr;
                 if (qx_src != xin || qx_nw != nwe || qx_K != qw.K) {
@@ -1707,7 +1708,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 QNext nx{next_nw, cfg.eps, qx_codes, qx_scales, qx_codes2, qx_scales2};
                 const bool want_next = (next_nw != nullptr || next_plain) && ldy == kout;
                 int fused = 0;
-                if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused)) {
+                if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused, defer)) {
                     if (fused == 2) { std::swap(qx_codes, qx_codes2); std::swap(qx_scales, qx_scales2); }      // (the other pair is the current one now)
                     if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; if (q_capture) q_capture_rows(nb, kout); }      // (the codes now hold the rows just written)
                     else if (epi == EPI_RESADD) qx_src = nullptr;
@@ -1776,7 +1777,22 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     gmr(pAT_hi, pAT_lo, w.out_proj, cfg.value_dim(), fuse_norm ? w.ln2 : nullptr);
                 } else rp(w.out_proj, attnb, (int)at_cols, cfg.value_dim());
             } else {
-                if (quantized) { for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq); }
+                // (the attention path of this group, decided here because the qkv projection may leave its K-split slices to it)
+                const bool full_b = Hkv_l * nb >= 2 * num_cu;
+                const int64_t mf_min = full_b && attn_mfma_min > 0 ? std::min<int64_t>(attn_mfma_min, attn_mfma_min_batch) : attn_mfma_min;
+                const bool mf = mf_min > 0 && longest >= mf_min && kv_mode != KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
+                // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
+                const int ns_b = mf ? std::max(attn_batch_ns_min, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)))
+                                    : (attn_splits_force ? attn_splits_force : std::max(attn_batch_ns_min, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))));
+                // the single-split matrix-core kernel of a quantised group: adds the K-split slices of the int8 qkv GEMM in its prologue (no
+                // reduction launch) and writes the Q8_0 blocks of its rows for the int8 o_proj GEMM (no quantiser launch)
+                const bool attn_q = attn_outq && mf && qgemm_ok && nb >= q_gemm_min && attn_decode_single_split(ns_b, D) && !cfg.hybrid &&
+                                    !(heads_b && !quantized && !rccl);
+                QDefer qdef{1, 0, nullptr};
+                if (quantized) {
+                    const bool defer_ok = attn_q && w.n_qkv == 1 && ldq == w.q_qkv[0].N && w.qkv_row0[0] == 0;
+                    for (int i = 0; i < w.n_qkv; ++i) qb(PRO_RMSNORM, EPI_STORE, w.q_qkv[i], xb, H, w.ln1, qkvb + w.qkv_row0[i], ldq, nullptr, false, defer_ok ? &qdef : nullptr);
+                }
                 else if (gemm_b) {
                     if (!xn_ready) launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
                     gm(GEPI_STORE, pXN_hi, pXN_lo, w.qkv, qkvb, ldq, qkv_rows, H);
@@ -1799,20 +1815,14 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 // a group whose (kv head, sequence) pairs alone fill the chip twice takes ONE token split per sequence and the
                 // matrix-core kernel from 64 tokens on (the VALU kernel's 16-lane rows pay per token, not per tile): engine at
                 // max_running 128, contexts 128-256: 9567 -> 10264 tok/s
-                const bool full_b = Hkv_l * nb >= 2 * num_cu;
-                const int64_t mf_min = full_b && attn_mfma_min > 0 ? std::min<int64_t>(attn_mfma_min, attn_mfma_min_batch) : attn_mfma_min;
-                const bool mf = mf_min > 0 && longest >= mf_min && kv_mode != KV_F32 && (D == 128 || D == 256) && (page & (page - 1)) == 0;
-                // nb sequences already multiply the block count: fewer token splits per sequence keep ~2 blocks per CU
-                const int ns_b = mf ? std::max(attn_batch_ns_min, std::min(longest >= attn_mfma_wide_min ? nsplit_mfma : nsplit, 2 * num_cu / std::max(1, Hkv_l * nb)))
-                                    : (attn_splits_force ? attn_splits_force : std::max(attn_batch_ns_min, std::min(nsplit, 2 * num_cu / std::max(1, Hkv_l * nb))));
                 // one split per sequence: the kernel normalises itself (no combine launch) and, in front of the o_proj GEMM of a large
                 // group, writes the bf16 hi + lo planes the GEMM reads (no split_rows2d launch either)
                 const bool planes = gemm_b && !quantized && attn_decode_single_split(ns_b, D);
                 if (planes) { a.out1_hi = pAT_hi; a.out1_lo = pAT_lo; a.out1_cols = Hq_l * D; }
                 // ... or, in front of the int8 o_proj GEMM of a quantised group, ALSO the Q8_0 blocks of the rows (no quantiser launch)
-                const bool codes = attn_outq && mf && qgemm_ok && nb >= q_gemm_min && attn_decode_single_split(ns_b, D) && !cfg.hybrid &&
-                                   gemm_q8_ok(w.q_o, nb) && (Hq_l * D) % 64 == 0;
+                const bool codes = attn_q && gemm_q8_ok(w.q_o, nb) && (Hq_l * D) % 64 == 0;
                 if (codes) { a.out1_q = qx_codes; a.out1_qd = qx_scales; a.out1_cols = Hq_l * D; }
+                if (qdef.ks > 1) { a.qkv = qdef.ws; a.qkv_stride = w.q_qkv[0].N; a.qkv_ns = qdef.ks; a.qkv_slice = qdef.slice; }      // (the slices of the qkv GEMM, rows N floats apart)
                 if (mf) {
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
