@@ -539,7 +539,10 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
     static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 3;
     const int geo = M > 64 ? (geo_env == 0 ? 1 : geo_env == 1 ? 2 : 3) : 0;
     p.geo = geo;
-    p.mh = geo == 1 || geo == 3 ? 2 : 1; p.mt = geo == 2 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : 8;
+    // (<= 64 rows, 4 waves: groups of 4 blocks = 52 / 61 KB of LDS, TWO workgroups per CU as `cap` below assumes; with groups of 8 -- 104 KB --
+    // a CU held one 4-wave workgroup, one wave per SIMD.  CM_QGEMM_QG_SMALL = 8: A/B)
+    static const int qg_small = getenv("CM_QGEMM_QG_SMALL") && atoi(getenv("CM_QGEMM_QG_SMALL")) == 8 ? 8 : 4;
+    p.mh = geo == 1 || geo == 3 ? 2 : 1; p.mt = geo == 2 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : geo == 1 ? 8 : qg_small;
     const int nkb_all = K >> 5, tiles = N / 128, G = nkb_all / p.qg;
     p.groups = G;
     p.lds = (size_t)(2 * p.qg * QGEMM_MAXM + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + p.mh * p.mt * 32) * (p.qg * 32 + 16);
@@ -591,6 +594,8 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     static DevOnce attr;
     attr.run([&] {
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -600,7 +605,9 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     if (geo == 3) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 4>), grid, block, lds, s, a);
     else if (geo == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 4, 4>), grid, block, lds, s, a);
     else if (mh == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 8>), grid, block, lds, s, a);
+    else if (mt == 2 && pl.qg == 4) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 4>), grid, block, lds, s, a);
     else if (mt == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 8>), grid, block, lds, s, a);
+    else if (pl.qg == 4) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 1, 4>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 1, 8>), grid, block, lds, s, a);
     if (direct) { if (fused && a.nxq) *fused = 2; return true; }
     if (epi == EPI_STORE && defer != nullptr && ks <= 4) { defer->ks = ks; defer->slice = a.slice; defer->ws = ws; return true; }      // (the consumer adds the slices)
