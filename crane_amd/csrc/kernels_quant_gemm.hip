@@ -527,7 +527,7 @@ bool gemm_q8_ok(const QWeight& w, int M) {
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
 // EPI_STORE with a row stride the workspace cannot hold (the vocabulary head) is written in place by an unsplit launch.
 // Host-side plan of one launch (pure: no device calls; cm_debug_qgemm_plan exposes it to the CPU tests).
-//   geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 8 blocks); above that 8 waves (two halves of the rows) x 2
+//   geometry: M <= 32 -> 4 waves x 1 m-tile, M <= 64 -> 4 waves x 2 (groups of 4 blocks, two workgroups per CU); above that 8 waves (two halves of the rows) x 2
 //   m-tiles, one workgroup per CU, groups of 4 blocks (CM_QGEMM_GEO = 3, the default; Q8_0 serving of Qwen3-8B at 128 sequences 11.46 K
 //   tok/s when it was chosen), or the same with groups of 8 blocks (= 0: 11.01 K), or 4 waves x 4 m-tiles with groups of 4 blocks: 80 KB of
 //   LDS, two independent workgroups per CU (= 1: 11.18 K);
