@@ -499,8 +499,12 @@ int cm_debug_read(cm_model* h, const char* what, float* out, size_t n) {
             return;
         }
         if (w == "q_capture_len") {        // floats recorded since cm_debug_set("q_capture", 1) (model.h)
-            if (n < 1) throw CmError(CM_ERR_RANGE, "q_capture_len: one value");
-            out[0] = (float)mp->q_cap.size();
+            // one value: exact below 2^24 floats (refused above); two values: size % 2^24, size / 2^24 (a prompt pass at real widths)
+            if (n < 1) throw CmError(CM_ERR_RANGE, "q_capture_len: one or two values");
+            const size_t sz = mp->q_cap.size();
+            if (n == 1 && sz >= ((size_t)1 << 24)) throw CmError(CM_ERR_RANGE, "q_capture_len: record longer than 2^24 floats -- read two values (low 24 bits, high part)");
+            out[0] = (float)(n == 1 ? sz : (sz & (((size_t)1 << 24) - 1)));
+            if (n >= 2) out[1] = (float)(sz >> 24);
             return;
         }
         if (w == "q_capture") {            // the records; reading them clears the list
@@ -542,6 +546,10 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         const std::string k = key;
         if (k == "no_prefill") mm.no_prefill = value != 0;
         else if (k == "quant_prefill") mm.quant_prefill = value != 0;
+        else if (k == "prefill_q8") {       // before the first prompt pass of the handle: 0 = prompts over Q8_0-layout weights on the dequantised-to-bf16 GEMMs
+            if (mm.pX != nullptr) throw CmError(CM_ERR_INVALID, "prefill_q8: set before the first prompt pass");
+            mm.q8_prefill_want = value != 0;
+        }
         else if (k == "attn_outq") mm.attn_outq = value != 0;
         else if (k == "prefill_split") mm.prefill_split2 = value < 0 ? mm.default_prefill_split2() : value != 1;   // 1: plain bf16, 0 / 2: hi + lo, -1: back to cm_opts
         // which decode-attention kernel / persistent-kernel mode a step uses (tests and A/B runs; one hipGraph per variant, so

@@ -119,6 +119,9 @@ struct GemmArgs {
     const uint16_t* A_hi;   // [Mpad, K] bf16 activations (hi term)
     const uint16_t* A_lo;   // [Mpad, K] lo term or null (plain bf16 activations)
     const uint16_t* W;      // [N, K] bf16
+    const uint16_t* W_lo = nullptr;   // [N, K] bf16 lo plane of the operand (W + W_lo = a dequantised ggml matrix to 2^-17): launch_gemm adds A_hi . W_lo^T
+                                      // in a second pass (GEPI_SILUMUL then needs gu_tmp)
+    float* gu_tmp = nullptr;          // [M][N] f32 scratch of a GEPI_SILUMUL launch with W_lo
     float* C;               // GEPI_STORE: C[m*ldc+n] = acc; GEPI_RESADD: C[m*ldc+n] += acc
     uint16_t* H_hi;         // GEPI_SILUMUL: [M, N/2] bf16 hi (+lo) of silu(gate)*up
     uint16_t* H_lo;
@@ -179,6 +182,7 @@ struct AttnPreArgs {
     size_t kv_lo_off = 0;        // KV_BF16X2: element offset of the lo halves behind the hi halves in kpool / vpool
     uint16_t* out_hi;            // [Spad, Hq * D] bf16 hi (+lo) -> A operand of the o_proj GEMM
     uint16_t* out_lo;
+    float* out_f32 = nullptr;    // causal kernels: write f32 rows [S, Hq * D] here INSTEAD of the bf16 planes (int8 prompt pass: the o_proj quantiser's input)
     const float* gate;           // [S, gate_stride] f32 (Qwen3.5 output gate) or null
     int gate_stride;
     int S, Hq, Hkv, nrep, page, start_pos;
@@ -410,7 +414,7 @@ bool launch_gemvqb(int pro, int epi, const GemvQBArgs& a, int grid, hipStream_t 
 bool launch_gemvq(int pro, int epi, const GemvQArgs& a, int grid, hipStream_t s);
 void launch_embed_row_q(const QWeight& w, const StepState* st, float* x, int H, int V, hipStream_t s, int n_seq = 1);
 void launch_dequant_rows(const QWeight& w, float* out, int row0, int nrows, hipStream_t s);
-void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s);
+void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s, uint16_t* out_lo = nullptr);   // out_lo: bf16(v - bf16(v)), same layout
 void launch_embed_rows_q(const QWeight& w, const uint32_t* ids, float* x, int S, int H, int V, hipStream_t s);
 void launch_isq_q8_0(const uint16_t* src, size_t src_stride, int N, int K, void* codes, void* d, hipStream_t s, int mode = 8);   // mode 4 / 5: Q4_0 / Q5_0 quantiser, Q8_0 layout
 void launch_silu_mul(const float* gate, const float* up, float* out, int n, hipStream_t s, int n_seq = 1, int in_stride = 0, int out_stride = 0);

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a_in) {
         a.q_hi += r0; a.out_hi += r0;
         if (a.q_lo != nullptr) a.q_lo += r0;
         if (a.out_lo != nullptr) a.out_lo += r0;
+        if (a.out_f32 != nullptr) a.out_f32 += r0;
         if (a.gate != nullptr) a.gate += (size_t)sg.row0 * a.gate_stride;
         qt_seg = tq.y;
     }
@@ -617,6 +618,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPreArgs a_in) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= 1.0f / (1.0f + expf(-gv[r]));
             }
+            // (f32 rows: the input of the int8 o_proj GEMM's quantiser -- prompts over Q8_0-layout weights)
+            if (a.out_f32 != nullptr) *(f32x4*)(a.out_f32 + ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+            else
             split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
         }
     }
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
         a.q_hi += r0; a.out_hi += r0;
         if (a.q_lo != nullptr) a.q_lo += r0;
         if (a.out_lo != nullptr) a.out_lo += r0;
+        if (a.out_f32 != nullptr) a.out_f32 += r0;
         if (a.gate != nullptr) a.gate += (size_t)sg.row0 * a.gate_stride;
         qt_seg = tq.y;
     }
@@ -838,6 +843,9 @@ __global__ __launch_bounds__(256) void attn_prefill_fast_kernel(AttnPreArgs a_in
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= 1.0f / (1.0f + expf(-gv[r]));
             }
+            // (f32 rows: the input of the int8 o_proj GEMM's quantiser -- prompts over Q8_0-layout weights)
+            if (a.out_f32 != nullptr) *(f32x4*)(a.out_f32 + ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+            else
             split_store4(a.out_hi, a.out_lo, ((size_t)qrow * a.Hq + h) * D + nt * 16 + g * 4, v);
         }
     }
@@ -1282,11 +1290,40 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     return true;
 }
 
+// rows of interleaved (gate_j, up_j) f32 columns -> silu(gate) * up as bf16 hi (+ lo) planes [M][N / 2] (the GEMM's GEPI_SILUMUL epilogue
+// as a launch of its own: the two-pass GEMM over a hi + lo weight operand)
+__global__ void silu_mul_split_kernel(const float* __restrict__ gu, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, size_t n4, int half4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // 4 outputs = 8 interleaved inputs
+    if (i >= n4) return;
+    const size_t m = i / (size_t)half4, c = i % (size_t)half4;
+    const float* p = gu + (m * (size_t)half4 + c) * 8;
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    const float o[4] = {(a[0] / (1.0f + expf(-a[0]))) * a[1], (a[2] / (1.0f + expf(-a[2]))) * a[3],
+                        (b[0] / (1.0f + expf(-b[0]))) * b[1], (b[2] / (1.0f + expf(-b[2]))) * b[3]};
+    split_store4(hi, lo, i * 4, o);
+}
+
 static bool launch_gemm_inner(GemmArgs& a, int epi, hipStream_t s);
 bool launch_gemm(const GemmArgs& a0, int epi, hipStream_t s) {
     if (a0.N % 128 != 0 || a0.K % GBK != 0) return false;
     GemmArgs a = a0;
     if (a.norm_w != nullptr && (epi != GEPI_RESADD || a.ldc != a.N)) return false;
+    if (a.W_lo != nullptr) {
+        // hi + lo weight operand (a dequantised ggml matrix): C = A . W^T, then C += A_hi . W_lo^T (the A_lo . W_lo term is 2^-26);
+        // the epilogue that is not linear in C (SiLU(gate) * up) runs on the f32 sums afterwards
+        if (epi != GEPI_STORE && epi != GEPI_RESADD && epi != GEPI_SILUMUL) return false;
+        if (epi == GEPI_SILUMUL && a.gu_tmp == nullptr) return false;
+        GemmArgs p1 = a, p2 = a;
+        p1.W_lo = nullptr; p1.norm_w = nullptr;
+        p2.W = a.W_lo; p2.W_lo = nullptr; p2.A_lo = nullptr; p2.norm_w = nullptr;
+        if (epi == GEPI_SILUMUL) { p1.C = a.gu_tmp; p1.ldc = a.N; p2.C = a.gu_tmp; p2.ldc = a.N; }
+        if (!launch_gemm_inner(p1, epi == GEPI_RESADD ? GEPI_RESADD : GEPI_STORE, s)) return false;
+        if (!launch_gemm_inner(p2, GEPI_RESADD, s)) return false;
+        if (epi == GEPI_SILUMUL) {
+            const size_t n4 = (size_t)a.M * (a.N / 8);
+            hipLaunchKernelGGL(silu_mul_split_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.gu_tmp, a.H_hi, a.H_lo, n4, a.N / 8);
+        }
+    } else
     if (!launch_gemm_inner(a, epi, s)) return false;
     // the planes of RMSNorm(C) were not written by the split-K reduction (no split, or switched off): the row kernel
     if (a.norm_w != nullptr) {

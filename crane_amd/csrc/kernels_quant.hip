@@ -1117,20 +1117,28 @@ __global__ void dequant_rows_kernel(QWeight w, float* __restrict__ out, int row0
 // prefill over quantised weights: rows of W are dequantised to a bf16 scratch matrix for the MFMA GEMM (bf16 rounding
 // of the dequantised value, 2^-9, is below every format's own quantisation step); dst row = row * row_mul + row_off
 // so gate / up matrices of different ggml types can still be interleaved
-__global__ void dequant_bf16_kernel(QWeight w, uint16_t* __restrict__ out, int row_mul, int row_off) {
+// out_lo (parity mode): the second bf16 term of the dequantised value, bf16(v - bf16(v)) -- an 8-bit code times an f16 scale (K-quants:
+// times a 6-bit sub-scale, minus a min) has up to ~25 significant bits; hi + lo carries 16 of them (2^-17), hi alone 8 (2^-9)
+__global__ void dequant_bf16_kernel(QWeight w, uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo, int row_mul, int row_off) {
     const size_t i8 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (i8 >= (size_t)w.N * w.K) return;
     const size_t r = i8 / (size_t)w.K;
     const int k = (int)(i8 % (size_t)w.K);
-    uint32_t o[4];
+    uint32_t o[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        o[e] = (uint32_t)f32_to_bf16(q_elem(w, r, k + 2 * e)) | ((uint32_t)f32_to_bf16(q_elem(w, r, k + 2 * e + 1)) << 16);
-    *(u32x4*)(out + (r * row_mul + row_off) * (size_t)w.K + k) = (u32x4){o[0], o[1], o[2], o[3]};
+    for (int e = 0; e < 4; ++e) {
+        const float v0 = q_elem(w, r, k + 2 * e), v1 = q_elem(w, r, k + 2 * e + 1);
+        const uint16_t h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1);
+        o[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        l[e] = (uint32_t)f32_to_bf16(v0 - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v1 - bf16_to_f32(h1)) << 16);
+    }
+    const size_t at = (r * row_mul + row_off) * (size_t)w.K + k;
+    *(u32x4*)(out + at) = (u32x4){o[0], o[1], o[2], o[3]};
+    if (out_lo != nullptr) *(u32x4*)(out_lo + at) = (u32x4){l[0], l[1], l[2], l[3]};
 }
-void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s) {
+void launch_dequant_bf16(const QWeight& w, uint16_t* out, int row_mul, int row_off, hipStream_t s, uint16_t* out_lo) {
     const size_t n8 = (size_t)w.N * w.K / 8;
-    hipLaunchKernelGGL(dequant_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, out, row_mul, row_off);
+    hipLaunchKernelGGL(dequant_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, out, out_lo, row_mul, row_off);
 }
 
 __global__ void embed_rows_q_kernel(QWeight w, const uint32_t* __restrict__ ids, float* __restrict__ x, int H, int V) {

@@ -261,6 +261,7 @@ void Model::init_common(const std::string& config_json, const cm_opts* o) {
     // beyond summation order except CM_QUANT_ACT and CM_QUANT_PREFILL, which select a documented arithmetic)
     if (const char* e = getenv("CM_TP_GRAPH")) tp_graph = atoi(e) != 0;
     if (const char* e = getenv("CM_QUANT_PREFILL")) quant_prefill = atoi(e) != 0;
+    if (const char* e = getenv("CM_QUANT_PREFILL_INT8")) q8_prefill_want = atoi(e) != 0;
     no_prefill = getenv("CM_NO_PREFILL") != nullptr;
     if (const char* e = getenv("CM_GEMVM")) use_mfma_gemv = atoi(e) != 0;
     if (const char* e = getenv("CM_BATCH_GEMM_MIN")) batch_gemm_min = std::max(0, std::min((int)GEMV_MAXB, atoi(e)));
@@ -1067,6 +1068,17 @@ void Model::ensure_gemm_workspace() {
     }
 }
 
+bool Model::q8_prefill_eligible() const {
+    if (!quantized || !quant_act_int || cfg.hybrid) return false;
+    for (const LayerW& w : layers) {
+        if (w.n_qkv < 1 || w.split_gate_up) return false;
+        for (int i = 0; i < w.n_qkv; ++i) if (!gemm_q8_ok(w.q_qkv[i], QGEMM_MAXM)) return false;
+        if (!gemm_q8_ok(w.q_o, QGEMM_MAXM) || !gemm_q8_ok(w.q_gate_up, QGEMM_MAXM) || !gemm_q8_ok(w.q_down, QGEMM_MAXM)) return false;
+        if ((w.q_gate_up.N / 2) % 32 != 0) return false;
+    }
+    return true;
+}
+
 void Model::ensure_prefill_buffers() {
     if (pX) return;
     const int H = cfg.H, D = cfg.D;
@@ -1118,16 +1130,24 @@ void Model::ensure_prefill_buffers() {
         d_ident_bt = dalloc<int>((size_t)max_pages_per_seq);
         CM_HIP(hipMemcpy(d_ident_bt, ident.data(), ident.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    if (quantized) {
-        wq_scratch = dalloc<uint16_t>(std::max(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H), (size_t)in_proj_pad * H));
-        // 288 GB of HBM: a quantised 8B model's bf16 GEMM operands are 14 GB -- dequantising every matrix again for every prompt pass was
-        // 4.5 % of a Q8_0 serving run (dequant_bf16_kernel, 2304 launches).  Kept when they fit a quarter of what is free now
-        size_t need = 0, free_b = 0, total_b = 0;
-        for (const LayerW& w : layers)
-            need += w.full ? ((size_t)qkv_rows * H + (size_t)H * Hq_l * D + (size_t)3 * I_l * H) * 2
-                           : ((size_t)in_proj_pad * H + (size_t)H * cfg.value_dim() + (size_t)3 * I_l * H) * 2;
-        CM_HIP(hipMemGetInfo(&free_b, &total_b));
-        wq_cache = need <= free_b / 4;
+    // Q8_0-layout weights (GGUF Q8_0 / Q4_0 / Q5_0, every ISQ mode), integer-dot activation mode: the prompt's projections run on the
+    // int8 matrix cores in panels of <= 128 rows (prefill_layers) -- the arithmetic of the decode step and of candle's CPU QMatMul
+    // (ops/linear.rs:18-51: activation row -> Q8_0 blocks, ggml_vec_dot_q8_0_q8_0 per output), no dequantised copy of any matrix
+    q8_prefill = q8_prefill_want && q8_prefill_eligible();
+    if (q8_prefill) {
+        ensure_batch_buffers();                                    // qx_codes / qx_scales pairs, hbb
+        pATf = dalloc<float>((size_t)chunk * Hq_l * D);
+    }
+    if (quantized && !q8_prefill) {
+        // one dequantised matrix at a time: bf16 hi plane + lo plane (parity mode), and the f32 gate|up sums of the two-pass GEMM
+        wq_scratch_elems = std::max(std::max((size_t)2 * I_l * H, (size_t)qkv_rows * H), (size_t)in_proj_pad * H);
+        wq_scratch = dalloc<uint16_t>(2 * wq_scratch_elems);
+        pGU = dalloc<float>((size_t)chunk * 2 * I_l);
+        // CM_QUANT_PREFILL_CACHE=1 (opt-in; round 5 switched it on by itself whenever the copies fit a quarter of the free HBM): keep every
+        // dequantised matrix (hi + lo: 4 bytes per weight -- more than the bf16 checkpoint) instead of dequantising it again per pass
+        // (4.5 % of a Q8_0 serving run, before Q8_0-layout models moved to the int8 prompt pass).  An allocation that fails mid-pass
+        // falls back to the scratch (deq_w)
+        wq_cache = false;
         if (const char* e = getenv("CM_QUANT_PREFILL_CACHE")) wq_cache = atoi(e) != 0;
     }
     d_ids = (uint32_t*)dalloc<int>(chunk);
@@ -1145,21 +1165,57 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     const bool sp2 = prefill_split2;
     // the bf16 operand of a quantised projection: `fill(dst)` enqueues its dequantisation -- into the layer's own copy the first time
     // (cache on), else into the one scratch matrix every time (stream order keeps that safe)
-    auto deq_w = [&](LayerW& lw, int slot, size_t elems, auto&& fill) -> const uint16_t* {
-        if (!wq_cache) { fill(wq_scratch); return wq_scratch; }
-        if (!lw.dq[slot]) { lw.dq[slot] = dalloc<uint16_t>(elems); fill(lw.dq[slot]); }
-        return lw.dq[slot];
+    // Parity mode (hi + lo activations, the default): the operand is ALSO two bf16 terms -- a dequantised ggml weight (code x f16 scale,
+    // K-quants: x 6-bit sub-scale - min) does not fit bf16's 8 significand bits, and the single rounded plane alone put the prompt
+    // pass 3.2e-3 .. 3.7e-3 from the f32 oracle on the dequantised weights (round 5); with the lo plane (launch_gemm: a second pass
+    // A_hi . W_lo^T) operand and activations both carry 16 bits.  cm_opts.prefill_split = 1: one plane each, the fast approximate mode.
+    struct WOp { const uint16_t* hi; const uint16_t* lo; };
+    auto deq_w = [&](LayerW& lw, int slot, size_t elems, auto&& fill) -> WOp {
+        if (wq_cache && !lw.dq[slot]) {
+            try { lw.dq[slot] = dalloc<uint16_t>(2 * elems); fill(lw.dq[slot], lw.dq[slot] + elems); }
+            catch (const CmError& e) {                   // HBM ran out mid-pass: this and every later matrix through the scratch
+                if (e.code != CM_ERR_OOM) throw;
+                (void)hipGetLastError();
+                wq_cache = false;
+            }
+        }
+        if (wq_cache && lw.dq[slot]) return WOp{lw.dq[slot], lw.dq[slot] + elems};
+        if (lw.dq[slot]) return WOp{lw.dq[slot], lw.dq[slot] + elems};      // (cached before the cache was switched off)
+        fill(wq_scratch, sp2 ? wq_scratch + wq_scratch_elems : nullptr);
+        return WOp{wq_scratch, wq_scratch + wq_scratch_elems};
     };
+    auto set_w = [&](GemmArgs& ga, const WOp& op) { ga.W = op.hi; ga.W_lo = sp2 ? op.lo : nullptr; };
     // the RMSNorm in front of a projection is written by the split-K reduction launch of the row-parallel projection before it when
     // that GEMM splits K (GemmArgs::norm_w; launch_gemm runs the row kernel itself when it does not): o_proj / out_proj -> ln2,
     // down_proj -> the next layer's ln1 (not under TP: the norm follows the all-reduce; not across a DeepStack injection)
     auto next_norm = [&](GemmArgs& ga, const float* nw) {
         ga.norm_w = nw; ga.norm_hi = pXN_hi; ga.norm_lo = sp2 ? pXN_lo : nullptr; ga.norm_eps = cfg.eps;
     };
+    // ---- int8 prompt pass (q8_prefill): rows in panels of <= QGEMM_MAXM; quantiser + int8-MFMA GEMM per projection and panel ----
+    const bool q8p = q8_prefill;
+    auto q8_quant = [&](const float* xin, int ldx, const float* nw, int m, int K) {
+        launch_quant_rows_q8(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, K, s);
+        if (q_capture) q_capture_rows(m, K);
+    };
+    // y (+)= W . codes^T over the panel's m rows; next_nw / next_plain: the rows written are the next projection's input -- quantised by
+    // the reduction launch (or the unsplit gate|up GEMM itself); returns true when the current codes hold them
+    auto q8_mm = [&](const QWeight& qw, int epi, float* y, int ldy, int m, const float* next_nw, bool next_plain) -> bool {
+        QGemmArgs qg{};
+        qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = m;
+        QNext nx{next_nw, cfg.eps, qx_codes, qx_scales, qx_codes2, qx_scales2};
+        const int kout = epi == EPI_SILUMUL ? qw.N / 2 : qw.N;
+        const bool want_next = (next_nw != nullptr || next_plain) && ldy == kout;
+        int fused = 0;
+        if (!launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused))
+            throw CmError(CM_ERR_UNSUPPORTED, "int8 prompt GEMM shape");
+        if (fused == 2) { std::swap(qx_codes, qx_codes2); std::swap(qx_scales, qx_scales2); }
+        if (fused && q_capture) q_capture_rows(m, kout);
+        return fused != 0;
+    };
     bool xn_ready = false;
     for (int li = 0; li < cfg.L; ++li) {
         LayerW& w = layers[(size_t)li];
-        if (!xn_ready) launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
+        if (!xn_ready && !(q8p && w.full)) launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
         xn_ready = false;
         GemmArgs g{};
         g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
@@ -1168,12 +1224,14 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
             if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
                 const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
-                g.W = deq_w(w, 0, (size_t)in_proj_pad * H, [&](uint16_t* dst) {
-                    launch_dequant_bf16(w.q_in_proj, dst, 1, 0, s);
-                    if (w.q_in_proj_z.fmt != QFMT_NONE) launch_dequant_bf16(w.q_in_proj_z, dst + (size_t)w.q_in_proj.N * H, 1, 0, s);
+                set_w(g, deq_w(w, 0, (size_t)in_proj_pad * H, [&](uint16_t* dst, uint16_t* lo) {
+                    launch_dequant_bf16(w.q_in_proj, dst, 1, 0, s, lo);
+                    if (w.q_in_proj_z.fmt != QFMT_NONE)
+                        launch_dequant_bf16(w.q_in_proj_z, dst + (size_t)w.q_in_proj.N * H, 1, 0, s, lo ? lo + (size_t)w.q_in_proj.N * H : nullptr);
                     CM_HIP(hipMemcpyAsync(dst + qz * H, w.in_proj_ba, nba * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
                     CM_HIP(hipMemsetAsync(dst + (qz + nba) * H, 0, ((size_t)in_proj_pad - qz - nba) * H * sizeof(uint16_t), s));
-                });
+                    if (lo) CM_HIP(hipMemsetAsync(lo + qz * H, 0, ((size_t)in_proj_pad - qz) * H * sizeof(uint16_t), s));      // (the a / b rows are bf16: no lo term)
+                }));
             }
             g.M = S; g.N = in_proj_pad; g.K = H;
             if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
@@ -1201,7 +1259,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
             g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
-            if (quantized) g.W = deq_w(w, 1, (size_t)w.q_out_proj.N * w.q_out_proj.K, [&](uint16_t* dst) { launch_dequant_bf16(w.q_out_proj, dst, 1, 0, s); });
+            if (quantized) set_w(g, deq_w(w, 1, (size_t)w.q_out_proj.N * w.q_out_proj.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_out_proj, dst, 1, 0, s, lo); }));
             if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
             else {
                 g.C = pY; launch_gemm(g, GEPI_STORE, s);
@@ -1209,14 +1267,24 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
                 launch_add_rows(pX, pY, (size_t)S * H, s);
             }
         } else {
+        if (q8p) {
+            for (int r0 = 0; r0 < S; r0 += QGEMM_MAXM) {
+                const int m = std::min((int)QGEMM_MAXM, S - r0);
+                q8_quant(pX + (size_t)r0 * H, H, w.ln1, m, H);
+                for (int i = 0; i < w.n_qkv; ++i)
+                    q8_mm(w.q_qkv[i], EPI_STORE, pQKV + (size_t)r0 * qkv_rows + w.qkv_row0[i], qkv_rows, m, nullptr, false);
+            }
+        } else {
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 1)) ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
         if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
-            g.W = deq_w(w, 0, (size_t)qkv_rows * H, [&](uint16_t* dst) {
-                for (int i = 0; i < w.n_qkv; ++i) launch_dequant_bf16(w.q_qkv[i], dst + (size_t)w.qkv_row0[i] * H, 1, 0, s);
-            });
+            set_w(g, deq_w(w, 0, (size_t)qkv_rows * H, [&](uint16_t* dst, uint16_t* lo) {
+                for (int i = 0; i < w.n_qkv; ++i)
+                    launch_dequant_bf16(w.q_qkv[i], dst + (size_t)w.qkv_row0[i] * H, 1, 0, s, lo ? lo + (size_t)w.qkv_row0[i] * H : nullptr);
+            }));
         }
         g.M = S; g.N = qkv_rows; g.K = H;
         if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+        }
         // QK-norm + RoPE + KV append and the causal attention run once per sequence of the pass (its own pages and positions)
         const bool kvq = this->kvq();
         if (kvq && nseg != 1) throw CmError(CM_ERR_UNSUPPORTED, "multi-sequence prompt pass over quantised KV pages");
@@ -1241,6 +1309,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             at.page = page; at.start_pos = 0; at.causal = 1;
             at.gate = cfg.hybrid ? pQKV + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
             at.segs = d_segtab; at.tiles = d_tiles; at.ntiles = seg_ntiles;
+            if (q8p) at.out_f32 = pATf;
             launch_attn_prefill(at, D, kv_f32 ? KV_F32 : kv_mode, s);
         } else
         for (int gi = 0; gi < nseg; ++gi) {
@@ -1270,11 +1339,46 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         at.S = sg.S; at.Hq = Hq_l; at.Hkv = Hkv_l; at.nrep = nrep;
         at.page = page; at.start_pos = sp; at.causal = 1;
         at.gate = cfg.hybrid ? pQKV + (size_t)sg.row0 * qkv_rows + (size_t)Hq_l * D : nullptr; at.gate_stride = qkv_rows;
+        if (q8p) at.out_f32 = pATf + (size_t)sg.row0 * Hq_l * D;
         launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
+        }
+        if (q8p) {
+            // o_proj, gate|up, down_proj panel by panel: a panel's rows of silu(gate) * up never leave the [128][I] scratch
+            const int AC = Hq_l * D;
+            if (rccl) {
+                for (int r0 = 0; r0 < S; r0 += QGEMM_MAXM) {
+                    const int m = std::min((int)QGEMM_MAXM, S - r0);
+                    q8_quant(pATf + (size_t)r0 * AC, AC, nullptr, m, AC);
+                    q8_mm(w.q_o, EPI_STORE, pY + (size_t)r0 * H, H, m, nullptr, false);
+                }
+                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+                launch_add_rows(pX, pY, (size_t)S * H, s);
+            }
+            for (int r0 = 0; r0 < S; r0 += QGEMM_MAXM) {
+                const int m = std::min((int)QGEMM_MAXM, S - r0);
+                float* xr = pX + (size_t)r0 * H;
+                bool have = false;
+                if (!rccl) {
+                    q8_quant(pATf + (size_t)r0 * AC, AC, nullptr, m, AC);
+                    have = q8_mm(w.q_o, EPI_RESADD, xr, H, m, w.ln2, false);
+                }
+                if (!have) q8_quant(xr, H, w.ln2, m, H);
+                have = q8_mm(w.q_gate_up, EPI_SILUMUL, hbb, I_l, m, nullptr, true);
+                if (!have) q8_quant(hbb, I_l, nullptr, m, I_l);
+                if (!rccl) q8_mm(w.q_down, EPI_RESADD, xr, H, m, nullptr, false);
+                else q8_mm(w.q_down, EPI_STORE, pY + (size_t)r0 * H, H, m, nullptr, false);
+            }
+            if (rccl) {
+                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+                launch_add_rows(pX, pY, (size_t)S * H, s);
+            }
+            if (li < deep_layers && splice_map_dev != nullptr)
+                launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
+            continue;
         }
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pAT_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 2)) ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
-        if (quantized) g.W = deq_w(w, 1, (size_t)w.q_o.N * w.q_o.K, [&](uint16_t* dst) { launch_dequant_bf16(w.q_o, dst, 1, 0, s); });
+        if (quantized) set_w(g, deq_w(w, 1, (size_t)w.q_o.N * w.q_o.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_o, dst, 1, 0, s, lo); }));
         if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
         else {
             g.C = pY; launch_gemm(g, GEPI_STORE, s);
@@ -1286,16 +1390,17 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 4)) ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
         if (quantized) {
-            g.W = deq_w(w, 2, (size_t)2 * I_l * H, [&](uint16_t* dst) {
-                if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, dst, 1, 0, s);
-                else { launch_dequant_bf16(w.q_gate, dst, 2, 0, s); launch_dequant_bf16(w.q_up, dst, 2, 1, s); }
-            });
+            set_w(g, deq_w(w, 2, (size_t)2 * I_l * H, [&](uint16_t* dst, uint16_t* lo) {
+                if (!w.split_gate_up) launch_dequant_bf16(w.q_gate_up, dst, 1, 0, s, lo);
+                else { launch_dequant_bf16(w.q_gate, dst, 2, 0, s, lo); launch_dequant_bf16(w.q_up, dst, 2, 1, s, lo); }
+            }));
+            g.gu_tmp = pGU;
         }
         g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
         launch_gemm(g, GEPI_SILUMUL, s);
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pHH_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 8)) ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
-        if (quantized) g.W = deq_w(w, 3, (size_t)w.q_down.N * w.q_down.K, [&](uint16_t* dst) { launch_dequant_bf16(w.q_down, dst, 1, 0, s); });
+        if (quantized) set_w(g, deq_w(w, 3, (size_t)w.q_down.N * w.q_down.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_down, dst, 1, 0, s, lo); }));
         if (!rccl) {
             g.C = pX;
             xn_ready = li + 1 < cfg.L && !(li < deep_layers && splice_map_dev != nullptr);
@@ -2159,10 +2264,13 @@ void Model::q_capture_rows(int nb, int K) {
     CM_HIP(hipStreamSynchronize(stream));
     CM_HIP(hipMemcpy(c.data(), qx_codes, c.size(), hipMemcpyDeviceToHost));
     CM_HIP(hipMemcpy(d.data(), qx_scales, d.size() * sizeof(float), hipMemcpyDeviceToHost));
-    q_cap.push_back((float)K); q_cap.push_back((float)nb);
-    for (size_t i = 0; i < c.size(); ++i) q_cap.push_back((float)c[i]);
+    size_t at = q_cap.size();
+    q_cap.resize(at + 2 + c.size() + (size_t)nb * (K / 32));
+    float* o = q_cap.data() + at;
+    *o++ = (float)K; *o++ = (float)nb;
+    for (size_t i = 0; i < c.size(); ++i) *o++ = (float)c[i];
     for (int m = 0; m < nb; ++m)
-        for (int b = 0; b < K / 32; ++b) q_cap.push_back(d[(size_t)b * QGEMM_MAXM + m]);
+        for (int b = 0; b < K / 32; ++b) *o++ = d[(size_t)b * QGEMM_MAXM + m];
 }
 
 void Model::debug_qgemv(int layer, const std::string& which, const float* xh, size_t k, float* yh, size_t n) {

@@ -307,8 +307,15 @@ struct Model {
     QWeight q_embed, q_lm_head;
     float *kshadow = nullptr, *vshadow = nullptr;   // int8/int4 KV prefill: dequantised f32 K/V of ONE layer, identity pages
     int32_t* d_ident_bt = nullptr;                  // [max_pages_per_seq] 0, 1, 2, ...
-    uint16_t* wq_scratch = nullptr;    // [max N*K] bf16: one dequantised matrix at a time for the prefill GEMMs
-    bool wq_cache = false;             // keep every dequantised matrix instead (CM_QUANT_PREFILL_CACHE; automatic when the copies fit a quarter of the free HBM)
+    // prompts over Q8_0-layout weights on the int8 matrix cores (default where every projection of the dense family qualifies;
+    // CM_QUANT_PREFILL_INT8=0 / cm_debug_set("prefill_q8", 0) before the first prompt: the dequantised-to-bf16 GEMMs)
+    bool q8_prefill_want = true, q8_prefill = false;
+    float* pATf = nullptr;             // [chunk][Hq_l D] f32 attention rows of the pass (the o_proj quantiser's input)
+    bool q8_prefill_eligible() const;
+    uint16_t* wq_scratch = nullptr;    // [2][max N*K] bf16 hi | lo planes: one dequantised matrix at a time for the prefill GEMMs
+    size_t wq_scratch_elems = 0;
+    float* pGU = nullptr;              // [chunk][2 I_l] f32 gate|up sums of the two-pass (hi + lo operand) GEMM
+    bool wq_cache = false;             // keep every dequantised matrix instead (CM_QUANT_PREFILL_CACHE=1, opt-in)
     bool gdn_ck_on = true;                      // cm_debug_set("gdn_chunked"): prompts of >= 64 tokens take the chunk-parallel Gated-Delta-Net scan
     float *gdn_pre_q = nullptr, *gdn_pre_k = nullptr, *gdn_pre_v = nullptr, *gdn_pre_bd = nullptr, *gdn_pre_g = nullptr, *gdn_ck = nullptr;   // GDN prefill scratch
     float* yb = nullptr;               // [MAXB][H] TP partial sums of the batched step
@@ -365,7 +372,7 @@ struct Model {
     hipGraph_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // one captured decode step per attention variant
     hipGraphExec_t graph_exec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // (4 = whole-token persistent launch)
     bool graph_ok[5] = {false, false, false, false, false};
-    bool default_prefill_split2() const { return opts.prefill_split == 2 || (opts.prefill_split == 0 && !quantized); }
+    bool default_prefill_split2() const { return opts.prefill_split != 1; }      // 0 (default) and 2: bf16 hi + lo, the 1e-3 parity mode, on every kind of weights
     bool quant_prefill = true, no_prefill = false, use_mfma_gemv = true;   // CM_QUANT_PREFILL, CM_NO_PREFILL, CM_GEMVM (read at create)
     bool tp_graph = true, rccl_warm = false;   // capture RCCL collectives into the decode graph (CM_TP_GRAPH=0: eager)
     int attn_variant = 0;          // 0: split-KV + combine kernels, 1: per-head blocks + merge fused into o_proj

@@ -80,11 +80,14 @@ typedef struct cm_opts {
     int32_t  use_graph;        /* 0 default(on), 1 on, -1 off: hipGraph decode step  */
     uint32_t prefill_chunk;    /* tokens per prefill chunk (default 2048,            */
                                /*   PREFILL_CHUNK_SIZE engine/mod.rs:65)             */
-    int32_t  prefill_split;    /* prompt activations of the MFMA GEMMs: 2 = bf16 hi + lo (two products: the 1e-3 bound of a   */
-                               /*   bf16 checkpoint), 1 = plain bf16, 0 = hi + lo on bf16 / f16 / f32 weights, plain bf16 on       */
-                               /*   QUANTISED weights (GGUF / ISQ: their GEMM operand is a bf16-rounded copy of the dequantised   */
-                               /*   matrix anyway -- prompt logits 3.2-3.7e-3 of the f32 oracle on the dequantised weights        */
-                               /*   against 2.3-3.0e-3 with hi + lo, tools/probes/quant_prefill_deviation.py; tests: 1e-2)       */
+    int32_t  prefill_split;    /* prompt pass of the MFMA GEMMs: 0 (default) / 2 = parity mode: activations as bf16 hi + lo (two    */
+                               /*   products: the 1e-3 bound of a bf16 checkpoint) and, over QUANTISED weights on the dequantised    */
+                               /*   path (K-quants, CM_QUANT_ACT=f32, the hybrid family), the dequantised operand as bf16 hi + lo    */
+                               /*   too (a second GEMM pass over the lo plane); 1 = plain bf16 activations and a single rounded      */
+                               /*   operand plane: the fast approximate mode (3.2-3.7e-3 of the f32 oracle on the dequantised        */
+                               /*   weights, tools/probes/quant_prefill_deviation.py).  Q8_0-layout weights (GGUF Q8_0 / Q4_0 /     */
+                               /*   Q5_0, every ISQ mode) of the dense family in the integer-dot activation mode do not take this    */
+                               /*   path at all: their prompts run on the int8 matrix cores (ops/linear.rs:18-51 semantics).        */
     uint32_t isq;              /* in-situ quantisation of the linears at load: 0 none, CM_ISQ_Q8_0 / _Q4_0 / _Q5_0 */
                                /*   (--quant / CRANE_ISQ, ops/linear.rs:53-116; also read from CRANE_ISQ) */
     int32_t  engine;           /* persistent decode kernel (one launch per token): 0 default (on when the shapes */
@@ -489,8 +492,9 @@ int cm_debug_qgemm_plan(int32_t m, int32_t n, int32_t k, int32_t epi, uint64_t w
 /* Test hook: flips a path switch of a live model (the environment switches of the same names are read once, at
  * cm_create).  "no_prefill" = 1: prompts run token by token through the decode kernels; "quant_prefill" = 0: prompts over
  * quantised weights run through the integer-dot decode kernels instead of the dequantised MFMA GEMMs; "attn_outq" = 0 / 1: the single-split matrix-core
- * decode attention of a quantised group writes the Q8_0 blocks of its output rows itself (1, default) or leaves them to a quantiser launch; "prefill_split" = 1 / 2:
- * cm_opts.prefill_split of the live model (plain bf16 / bf16 hi + lo prompt activations); "batch_gemm_min" = n: cm_decode_batch
+ * decode attention of a quantised group writes the Q8_0 blocks of its output rows itself (1, default) or leaves them to a quantiser launch; "prefill_split" = 1 / 0 / 2:
+ * cm_opts.prefill_split of the live model (plain bf16 / bf16 hi + lo prompt activations and dequantised operands); "prefill_q8" = 0 (before the
+ * first prompt pass): prompts over Q8_0-layout weights on the dequantised GEMMs instead of the int8 matrix cores; "batch_gemm_min" = n: cm_decode_batch
  * runs the projections of n or more sequences as MFMA GEMMs (0 = never: batched GEMVs, rows bit-equal to cm_forward_step);
  * "attn_splits" = n > 0:
  * the VALU decode attention uses n token splits per kv head in the single AND the batched step (their automatic counts differ,

@@ -23,7 +23,7 @@ import numpy as np
 
 from crane_amd import synth
 from oracle import c_oracle
-from oracle.qwen3_oracle import F32, rms_norm, rope_thd, rotary_tables, silu, softmax_last
+from oracle.qwen3_oracle import F32, f16_round, rms_norm, rope_thd, rotary_tables, silu, softmax_last
 
 FMT = {"q8_0": 8, "q4_0": 2, "q5_0": 6}
 
@@ -44,7 +44,11 @@ class QMat:
 
 
 class Q8GroupOracle:
-    def __init__(self, cfg: dict, isq: str, seed: int = 0, max_pos: int = 64):
+    def __init__(self, cfg: dict, isq: str, seed: int = 0, max_pos: int = 64, kv_dtype: str = "f32"):
+        # kv_dtype "f16": K / V rows are rounded to IEEE binary16 (saturating) when they enter the cache -- the rounding point of the
+        # device's default CM_KV_F16 pages (oracle/qwen3_oracle.py f16_round); "f32": the reference CPU cache
+        assert kv_dtype in ("f32", "f16")
+        self.kv_dtype = kv_dtype
         self.lib = c_oracle._lib()
         self.lib.qc_set_threads(c_oracle.host_threads())
         self.cfg = cfg
@@ -82,8 +86,14 @@ class Q8GroupOracle:
         self.stats = dict(codes=0, flipped=0, scales=0, scale_steps=0, worst_tie=0.0)
 
     # ---- quantise the rows like the reference, check the device's codes against them, continue from the device's ----
-    def _quant(self, x: np.ndarray, cap, tie_tol: float):
+    def _quant(self, x: np.ndarray, cap, tie_tol: float, scale_tol: float = 1e-5):
         M, K = x.shape
+        self.n_quant = getattr(self, "n_quant", 0) + 1
+        if cap is None:                      # free-running (CPU self-checks of this oracle): its own reference rounding
+            x = np.ascontiguousarray(x, np.float32)
+            q8 = np.empty((M, K), np.int8); d8 = np.empty((M, K // 32), np.float32)
+            assert self.lib.qc_quantize_ref(FMT["q8_0"], _p(x, C.c_float), x.size, _p(q8, C.c_int8), _p(d8, C.c_float)) == 0
+            return q8, d8
         Kc, codes, scales = next(cap)
         assert Kc == K and codes.shape == (M, K), (Kc, K, codes.shape)
         xb = x.reshape(M, K // 32, 32)
@@ -102,7 +112,7 @@ class Q8GroupOracle:
             edge = (np.minimum(np.abs(dev), np.abs(mine)) + 0.5)[diff]
             gap = np.abs(np.abs(t64[diff]) - edge)
             same_sign = (np.sign(dev[diff]) * np.sign(mine[diff])) >= 0
-            assert same_sign.all() and gap.max() < tie_tol, f"a differing code is not a rounding tie: gap {gap.max():.3e}"
+            assert same_sign.all() and gap.max() < tie_tol, f"a differing code is not a rounding tie: gap {gap.max():.3e} (record {self.n_quant}, K {K}, tol {tie_tol})"
             self.stats["flipped"] += int(diff.sum())
             self.stats["worst_tie"] = max(self.stats["worst_tie"], float(gap.max()))
         d16 = d.astype(np.float16).astype(F32)
@@ -115,8 +125,30 @@ class Q8GroupOracle:
             ok = (scales == lo) | (scales == hi)
             assert ok[sd].all(), "a device block scale is not the f16 neighbour of the reference scale"
             mid = np.where(scales == lo, (d16 + lo) * F32(0.5), (d16 + hi) * F32(0.5))
-            assert (np.abs(d - mid)[sd] <= np.abs(d)[sd] * 1e-5).all(), "a differing block scale is not an f16 rounding tie"
+            off = float((np.abs(d - mid)[sd] / np.abs(d)[sd]).max())
+            assert off <= scale_tol, f"a differing block scale is not an f16 rounding tie: {off:.3e} (record {self.n_quant}, K {K}, tol {scale_tol})"
             self.stats["scale_steps"] += int(sd.sum())
+        return np.ascontiguousarray(codes, np.int8), np.ascontiguousarray(scales, np.float32)
+
+    def _quant_attn(self, x: np.ndarray, cap, rel_tol: float):
+        """The o_proj input when the attention rows come from a matrix-core kernel with its own error budget (bf16 probabilities, 16-bit
+        K / V and queries): a row x' within rel_tol x max|row| of the oracle's row x is as good as x, and its block maxima -- hence the
+        block scales -- need not be f16 neighbours of the oracle's where a block is small against its row.  Checked instead: the
+        device's blocks are a Q8_0 quantisation of SOME such x': |code * d - x| <= (1/2 + 127 * 2^-11) d + rel_tol * max|row| per
+        element (half a code step, the f16 rounding of d at the largest code, the budget), codes in [-127, 127].  Then the device's codes."""
+        M, K = x.shape
+        self.n_quant = getattr(self, "n_quant", 0) + 1
+        Kc, codes, scales = next(cap)
+        assert Kc == K and codes.shape == (M, K), (Kc, K, codes.shape)
+        assert np.abs(codes.astype(np.int32)).max() <= 127 and (scales >= 0).all()
+        deq = (codes.reshape(M, K // 32, 32).astype(F32) * scales[:, :, None]).reshape(M, K)
+        bound = np.repeat((0.5 + 127.0 / 2048.0) * scales, 32, axis=1) + rel_tol * np.abs(x).max(axis=1, keepdims=True)
+        over = np.abs(deq - x) - bound
+        assert over.max() <= 0, f"attention rows: a device block is not a Q8_0 quantisation of a row within {rel_tol} of the oracle's (record {self.n_quant}, excess {over.max():.3e})"
+        self.stats["codes"] += codes.size
+        self.stats["scales"] += scales.size
+        self.stats["worst_attn"] = max(self.stats.get("worst_attn", 0.0),
+                                       float((np.maximum(np.abs(deq - x) - np.repeat((0.5 + 127.0 / 2048.0) * scales, 32, axis=1), 0) / np.abs(x).max(axis=1, keepdims=True)).max()))
         return np.ascontiguousarray(codes, np.int8), np.ascontiguousarray(scales, np.float32)
 
     def _mm(self, q: np.ndarray, d: np.ndarray, mats) -> np.ndarray:
@@ -129,11 +161,11 @@ class Q8GroupOracle:
             outs.append(o)
         return outs[0] if len(outs) == 1 else np.concatenate(outs, axis=1)
 
-    def step(self, seq_ids, toks, captures, tie_tol: float = 2e-3) -> np.ndarray:
+    def step(self, seq_ids, toks, captures, tie_tol: float = 2e-3, attn_tol: float = None) -> np.ndarray:
         """One decode round: sequence seq_ids[b] (its K/V kept here, f32) takes token toks[b] at its next position.
         `captures`: the device's q_capture records of the same round, [(K, codes [M, K] int8, scales [M, K / 32] f32), ...] in
         consumption order.  Returns the logits [M, V]."""
-        cap = iter(captures)
+        cap = iter(captures) if captures is not None else None
         M, H, D, Hq, Hkv = len(toks), self.H, self.D, self.Hq, self.Hkv
         x = self.embed[np.asarray(toks, np.int64)].astype(F32)
         for s in seq_ids:
@@ -151,12 +183,15 @@ class Q8GroupOracle:
                 c, sn = self.cos[pos[b]:pos[b] + 1], self.sin[pos[b]:pos[b] + 1]
                 qh = rope_thd(qh, c, sn); kh = rope_thd(kh, c, sn)
                 kv = self.kc[s][li]
+                if self.kv_dtype == "f16":
+                    kh, vh = f16_round(kh), f16_round(vh)
                 kv[0] = kh.transpose(1, 0, 2) if kv[0] is None else np.concatenate([kv[0], kh.transpose(1, 0, 2)], axis=1)
                 kv[1] = vh.transpose(1, 0, 2) if kv[1] is None else np.concatenate([kv[1], vh.transpose(1, 0, 2)], axis=1)
                 qg = qh[0].reshape(Hkv, Hq // Hkv, D)
                 sc = np.einsum("grd,gld->grl", qg, kv[0]).astype(F32) * F32(1.0 / math.sqrt(D))
                 attn[b] = np.einsum("grl,gld->grd", softmax_last(sc), kv[1]).astype(F32).reshape(Hq * D)
-            q8, d8 = self._quant(attn, cap, tie_tol)
+            if attn_tol is None: q8, d8 = self._quant(attn, cap, tie_tol)
+            else: q8, d8 = self._quant_attn(attn, cap, attn_tol)                           # (matrix-core attention: see _quant_attn)
             x = (x + self._mm(q8, d8, (lw["o"],))).astype(F32)
             q8, d8 = self._quant(rms_norm(x, lw["ln2"], self.eps), cap, tie_tol)
             gu = self._mm(q8, d8, (lw["gate"], lw["up"]))
@@ -167,8 +202,75 @@ class Q8GroupOracle:
         if self.head is None:
             return (last @ self.embed.T).astype(F32)
         q8, d8 = self._quant(last, cap, tie_tol)
-        assert next(cap, None) is None, "the device quantised more activation rows than the round has projections"
+        assert cap is None or next(cap, None) is None, "the device quantised more activation rows than the round has projections"
         return self._mm(q8, d8, (self.head,))
+
+
+    def prefill(self, seq_ids, prompts, captures, tie_tol: float = 2e-3, panel: int = 128, head_captured: bool = False,
+                attn_tol: float = None):
+        """One prompt pass over whole prompts of the (fresh or continued) sequences seq_ids, rows concatenated in order -- the device's
+        Model::prefill_layers on the int8 matrix cores: every projection runs in panels of <= `panel` rows of the PASS (a panel may
+        span two sequences), one capture record per projection input and panel, in the device's order: per layer all panels of the
+        input norm (qkv), then per panel the attention rows (o_proj), the post-attention norm (gate|up) and silu(gate) * up (down_proj).
+        Returns (hidden [n_seq, H]: the residual stream of every sequence's last position, logits [n_seq, V]).  The head quantises its
+        rows from the capture when head_captured (the batched int8 head), else with the oracle's own rounding (single-row GEMV head)."""
+        cap = iter(captures) if captures is not None else None
+        H, D, Hq, Hkv = self.H, self.D, self.Hq, self.Hkv
+        rows, seg = [], []
+        for s, p in zip(seq_ids, prompts):
+            self.kc.setdefault(s, [[None, None] for _ in range(self.L)])
+            start = 0 if self.kc[s][0][0] is None else self.kc[s][0][0].shape[1]
+            seg.append((len(rows), len(p), start, s))
+            rows.extend(p)
+        S = len(rows)
+        x = self.embed[np.asarray(rows, np.int64)].astype(F32)
+        panels = [(r0, min(panel, S - r0)) for r0 in range(0, S, panel)]
+        for li, lw in enumerate(self.layers):
+            xn = rms_norm(x, lw["ln1"], self.eps)
+            qkv = np.empty((S, (Hq + 2 * Hkv) * D), F32)
+            for r0, m in panels:
+                q8, d8 = self._quant(np.ascontiguousarray(xn[r0:r0 + m]), cap, tie_tol)
+                qkv[r0:r0 + m] = self._mm(q8, d8, (lw["q"], lw["k"], lw["v"]))
+            attn = np.empty((S, Hq * D), F32)
+            for row0, n, start, s in seg:
+                blk = qkv[row0:row0 + n]
+                qh = rms_norm(blk[:, :Hq * D].reshape(n, Hq, D), lw["qn"], self.eps)
+                kh = rms_norm(blk[:, Hq * D:(Hq + Hkv) * D].reshape(n, Hkv, D), lw["kn"], self.eps)
+                vh = blk[:, (Hq + Hkv) * D:].reshape(n, Hkv, D)
+                c, sn = self.cos[start:start + n], self.sin[start:start + n]
+                qh = rope_thd(qh, c, sn); kh = rope_thd(kh, c, sn)
+                if self.kv_dtype == "f16":
+                    kh, vh = f16_round(kh), f16_round(vh)
+                kv = self.kc[s][li]
+                kv[0] = kh.transpose(1, 0, 2) if kv[0] is None else np.concatenate([kv[0], kh.transpose(1, 0, 2)], axis=1)
+                kv[1] = vh.transpose(1, 0, 2) if kv[1] is None else np.concatenate([kv[1], vh.transpose(1, 0, 2)], axis=1)
+                T = kv[0].shape[1]
+                qg = qh.transpose(1, 0, 2).reshape(Hkv, Hq // Hkv, n, D)
+                sc = np.einsum("grnd,gld->grnl", qg, kv[0]).astype(F32) * F32(1.0 / math.sqrt(D))
+                mask = np.arange(T)[None, :] > (start + np.arange(n))[:, None]            # key l visible to query i iff l <= start + i
+                sc = np.where(mask[None, None], F32(-np.inf), sc)
+                o = np.einsum("grnl,gld->grnd", softmax_last(sc), kv[1]).astype(F32)      # [Hkv, nrep, n, D]
+                attn[row0:row0 + n] = o.reshape(Hq, n, D).transpose(1, 0, 2).reshape(n, Hq * D)
+            for r0, m in panels:
+                sl = slice(r0, r0 + m)
+                # (attn_tol: the attention rows come from a matrix-core kernel with its own error budget, relative to the row: _quant_attn)
+                if attn_tol is None: q8, d8 = self._quant(np.ascontiguousarray(attn[sl]), cap, tie_tol)
+                else: q8, d8 = self._quant_attn(np.ascontiguousarray(attn[sl]), cap, attn_tol)
+                x[sl] = (x[sl] + self._mm(q8, d8, (lw["o"],))).astype(F32)
+                q8, d8 = self._quant(rms_norm(x[sl], lw["ln2"], self.eps), cap, tie_tol)
+                gu = self._mm(q8, d8, (lw["gate"], lw["up"]))
+                h = (silu(gu[:, :self.I]) * gu[:, self.I:]).astype(F32)
+                q8, d8 = self._quant(h, cap, tie_tol)
+                x[sl] = (x[sl] + self._mm(q8, d8, (lw["down"],))).astype(F32)
+        hidden = np.stack([x[row0 + n - 1] for row0, n, _, _ in seg]).astype(F32)
+        last = rms_norm(hidden, self.norm, self.eps)
+        if self.head is None:
+            logits = (last @ self.embed.T).astype(F32)
+        else:
+            q8, d8 = self._quant(last, cap if head_captured else None, tie_tol)
+            logits = self._mm(q8, d8, (self.head,))
+        assert cap is None or next(cap, None) is None, "the device quantised more activation rows than the pass has projections"
+        return hidden, logits
 
 
 def parse_captures(flat: np.ndarray):

@@ -144,9 +144,11 @@ def test_isq_q8_0_matches_reference_quantiser(monkeypatch, name, fmt):
 
 @pytest.mark.parametrize("kind", ["q8_0", "q4_k", "mixed"])
 def test_quantised_prefill_through_dequantised_gemm(tmp_path, monkeypatch, kind):
-    """Prompts over quantised weights run the MFMA GEMMs on a bf16 scratch copy of each dequantised matrix (default);
-    the result must agree with the token-serial decode kernels and with the f32 oracle on the dequantised weights to
-    within the bf16 rounding of the weights (2^-9 per weight -- below every format's own quantisation step)."""
+    """Prompts over quantised weights in the f32 activation mode (and K-quants in either mode) run the MFMA GEMMs on a dequantised
+    copy of each matrix held as bf16 hi + lo planes (two GEMM passes: 16 significant bits of operand AND activations), so the
+    result must meet north_star's bound against the f32 oracle on the dequantised weights: 1e-3 (measured ~1e-4; round 5's single
+    rounded plane: 3.2e-3 .. 3.7e-3 behind a flat 1e-2).  cm_opts.prefill_split = 1 is that fast approximate mode: derived bound
+    = 2^-9 per weight and activation over 2 layers + head, ~6e-3 worst case measured -> 1e-2."""
     from crane_amd.backend import Model
     cfg = configs.get_config("tiny-qwen3-untied")
     w = synth.synth_weights_f32(cfg, seed=0)
@@ -162,15 +164,22 @@ def test_quantised_prefill_through_dequantised_gemm(tmp_path, monkeypatch, kind)
         ms.close()
     m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", quant_act="f32")
     try:
-        got = m.forward_step(ids, 0).reshape(-1)                      # MFMA prefill (dequant -> bf16 scratch)
+        got = m.forward_step(ids, 0).reshape(-1)                      # MFMA prefill (dequant -> bf16 hi + lo scratch)
         assert rel(serial, ref) < 2e-4
-        assert rel(got, ref) < 1e-2 and rel(got, serial) < 1e-2, (rel(got, ref), rel(got, serial))
+        assert rel(got, ref) < 1e-3 and rel(got, serial) < 1e-3, (rel(got, ref), rel(got, serial))
         assert int(got.argmax()) == int(ref.argmax())
         # decode continues on the KV written by the prefill path
         tok = int(ref.argmax())
         r2 = oracle.forward([tok], 70)
         g2 = m.forward_step(ids, 0); g2 = m.forward_step([tok], 70).reshape(-1)
-        assert rel(g2, r2) < 1e-2
+        assert rel(g2, r2) < 1e-3, rel(g2, r2)
+        print(f"dequantised prompt pass {kind}: {rel(got, ref):.2e} of the oracle")
+    finally:
+        m.close()
+    m = Model.from_pretrained(path, max_seq_len=128, kv_dtype="f32", quant_act="f32", prefill_split=1)
+    try:
+        got = m.forward_step(ids, 0).reshape(-1)                      # opt-in: one rounded plane each
+        assert rel(got, ref) < 1e-2, rel(got, ref)
     finally:
         m.close()
 
@@ -238,8 +247,8 @@ def test_isq_q8_0_hybrid_family(monkeypatch):
             tok = int(ref.argmax())
         m.debug_set("quant_prefill", 1)
         ref = o.forward(ids, 0)
-        got = m.forward_step(ids, 0).reshape(-1)                 # MFMA prefill on the bf16 scratch
-        assert rel(got, ref) < 1e-2 and int(got.argmax()) == int(ref.argmax()), rel(got, ref)
+        got = m.forward_step(ids, 0).reshape(-1)                 # MFMA prefill on the bf16 hi + lo scratch
+        assert rel(got, ref) < 1e-3 and int(got.argmax()) == int(ref.argmax()), rel(got, ref)
     finally:
         m.close()
     # integer-dot default: same model, loose agreement with the float-activation result
@@ -378,15 +387,18 @@ def test_engine_batches_quantised_model():
 _GROUP_ORACLES = {}
 
 
-def _group_oracle(isq):
+def _group_oracle(isq, kv_dtype="f32"):
     """(8B-2l config, Q8GroupOracle) per ISQ mode, built once per session: 1.6 G synthetic weights + the reference quantiser in C."""
     from oracle.qgroup_oracle import Q8GroupOracle
     if isq not in _GROUP_ORACLES:
         cfg = configs.get_config("qwen3-8b-2l")
         _GROUP_ORACLES.clear()                                     # (one resident at a time: 3.3 GB of codes + the bf16 table as f32)
-        _GROUP_ORACLES[isq] = (cfg, Q8GroupOracle(cfg, isq, seed=0, max_pos=64))
+        _GROUP_ORACLES[isq] = (cfg, Q8GroupOracle(cfg, isq, seed=0, max_pos=256))
     cfg, o = _GROUP_ORACLES[isq]
     o.kc.clear()
+    o.kv_dtype = kv_dtype
+    for k in list(o.stats):
+        o.stats[k] = 0
     return cfg, o
 
 
@@ -431,6 +443,79 @@ def test_large_quantised_decode_groups_on_the_int8_matrix_cores(isq, nb):
         # the flips exist (that is why the test is teacher-forced) and are rare: ~1e-5 of the codes
         assert st["flipped"] < 1e-3 * st["codes"] and st["scale_steps"] < 1e-3 * st["scales"], st
         print(f"int8 groups {isq} x {nb}: worst logit rel {worst:.2e}; {st}")
+    finally:
+        m.close()
+
+
+# The attention rows of the matrix-core kernels (prompt: attn_prefill_* -- bf16 hi + lo queries, 16-bit K / V, bf16 probabilities; decode
+# groups on 2-byte pages: attn_decode_mfma) carry those kernels' own error: budget 1e-3 of the row's largest value -- north_star's bound
+# applied to the attention rows themselves (Q8GroupOracle._quant_attn; the measured worst case is printed by the test)
+ATTN_TOL = 1e-3
+
+
+def _captures(m):
+    from oracle.qgroup_oracle import parse_captures
+    lo, hi = m.debug_read("q_capture_len", 2)
+    return parse_captures(m.debug_read("q_capture", int(lo) + (int(hi) << 24)))
+
+
+@pytest.mark.parametrize("kv", ["f32", "f16"])
+def test_prompt_pass_on_the_int8_matrix_cores_and_the_attention_quantiser_against_the_oracle(kv):
+    """Prompts over Q8_0-layout weights (default): every projection of the pass on the int8 matrix cores in panels of <= 128 rows
+    (Model::prefill_layers, q8_prefill) -- the decode step's and candle's CPU QMatMul arithmetic (ops/linear.rs:18-51), no dequantised
+    copy -- at the 8B widths against the teacher-forced oracle (oracle/qgroup_oracle.py prefill(): the device's captured codes are
+    checked against the oracle's own rounding, ties only, then used), bound 2e-5 like the decode groups:
+      (a) ONE prompt of 200 tokens (a full and a partial panel): the residual stream of the last position (cm_debug_read "hidden");
+          its logits come from the single-row head, whose activation codes are not captured: one possible tie flip => 5e-3;
+      (b) 64 prompts of 70 .. 74 tokens through cm_prefill_batch (three passes of <= 2048 rows: panels span sequences, the segmented
+          RoPE / KV-append / causal-attention launches, the batched int8 head): every row of logits;
+      (c) one decode round of those 64 sequences (contexts >= 64): on f16 pages (the default) the group takes the single-split
+          matrix-core attention kernel, which adds the K-split slices of the int8 qkv GEMM in its prologue and writes the Q8_0 blocks of
+          its output rows for the int8 o_proj GEMM itself (model.cpp attn_q) -- both fusions under the oracle, f16 rounding of K / V
+          rows at the cache like the device (oracle f16_round)."""
+    from crane_amd.backend import Model
+    cfg, orc = _group_oracle("q8_0", kv)
+    V, H, L = cfg["vocab_size"], cfg["hidden_size"], cfg["num_hidden_layers"]
+    nb = 64
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, isq="q8_0", max_seqs=nb + 3, kv_dtype=kv)
+    try:
+        m.debug_set("q_capture", 1)
+        # (a)
+        s0 = m.seq_alloc()
+        p0 = [(11 * i + 5) % V for i in range(200)]
+        lg, _ = m.seq_forward(s0, p0, 0)
+        hid = m.debug_read("hidden", H)
+        caps = _captures(m)
+        assert len(caps) == L * (2 + 3 * 2), len(caps)             # per layer: 2 panels of the input norm + 2 x (attention, ln2, silu * up)
+        rh, rl = orc.prefill([s0], [p0], caps, tie_tol=2e-3, attn_tol=ATTN_TOL)
+        assert rel(hid, rh[0]) < 2e-5, rel(hid, rh[0])
+        assert rel(lg, rl[0]) < 5e-3, rel(lg, rl[0])
+        # (b)
+        seqs = [m.seq_alloc() for _ in range(nb)]
+        prompts = [[(7 * i + 3 + 11 * b) % V for i in range(70 + b % 5)] for b in range(nb)]
+        toks, worst = [], 0.0
+        for g0 in range(0, nb, 24):
+            sg, pg = seqs[g0:g0 + 24], prompts[g0:g0 + 24]
+            got, gg = m.prefill_batch(sg, pg)
+            _, ref = orc.prefill(sg, pg, _captures(m), tie_tol=2e-3, head_captured=True, attn_tol=ATTN_TOL)
+            for b in range(len(sg)):
+                e = rel(got[b], ref[b])
+                worst = max(worst, e)
+                assert e < 2e-5, (g0, b, e)
+                assert int(gg[b]) == int(got[b].argmax())
+            toks += [int(t) for t in gg]
+        # (c)
+        got, gg = m.step_batch_decode(seqs, toks)
+        caps = _captures(m)
+        assert len(caps) == 4 * L + 1, len(caps)
+        ref = orc.step(seqs, toks, caps, tie_tol=2e-3, attn_tol=ATTN_TOL if kv != "f32" else None)      # (f32 pages: the VALU attention, f32 arithmetic)
+        for b in range(nb):
+            e = rel(got[b, 0], ref[b])
+            worst = max(worst, e)
+            assert e < 2e-5, ("decode", b, e)
+        st = orc.stats
+        assert st["flipped"] < 1e-3 * st["codes"] and st["scale_steps"] < 1e-3 * st["scales"], st
+        print(f"int8 prompt pass / decode round, kv {kv}: worst logit rel {worst:.2e}; {st}")
     finally:
         m.close()
 

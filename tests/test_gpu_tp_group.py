@@ -232,9 +232,7 @@ def test_gguf_checkpoint_under_tensor_parallelism(tmp_path):
     path = str(tmp_path / "tp.gguf")
     G.write_qwen3_gguf(path, cfg, w, mixed)
     ids = configs.synthetic_prompt(21, cfg["vocab_size"])
-    # (prefill_split=2: prompt activations as bf16 hi + lo -- the default on quantised weights is plain bf16, whose rounding differs between
-    # a K-sharded and an unsharded sum by more than these tests allow for the SHARDING)
-    kw = dict(max_seq_len=128, max_seqs=2, quant_act="f32", prefill_split=2)
+    kw = dict(max_seq_len=128, max_seqs=2, quant_act="f32")
     g = Model.from_pretrained(path, tp_size=2, tp_in_process=True, tp_devices=[0, 0], **kw)
     s = Model.from_pretrained(path, **kw)
     try:
@@ -316,9 +314,7 @@ def test_hybrid_gguf_checkpoint_under_tensor_parallelism(tmp_path, kind):
     path = str(tmp_path / f"tp35-{kind}.gguf")
     G.write_qwen35_gguf(path, cfg, w, type_of)
     ids = configs.synthetic_prompt(21, cfg["vocab_size"])
-    # (prefill_split=2: prompt activations as bf16 hi + lo -- the default on quantised weights is plain bf16, whose rounding differs between
-    # a K-sharded and an unsharded sum by more than these tests allow for the SHARDING)
-    kw = dict(max_seq_len=128, max_seqs=2, quant_act="f32", prefill_split=2)
+    kw = dict(max_seq_len=128, max_seqs=2, quant_act="f32")
     g = Model.from_pretrained(path, tp_size=2, tp_in_process=True, tp_devices=[0, 0], **kw)
     s = Model.from_pretrained(path, **kw)
     try:

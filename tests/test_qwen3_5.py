@@ -215,6 +215,20 @@ def test_chunk_parallel_delta_rule_scan_equals_the_sequential_scan(name, n, chun
             o = O.Qwen35Oracle(O.Qwen35Config.from_json(cfg), w)
             assert rel(outs[0][0], o.forward(ids, 0)) < 1e-4
             assert rel(outs[0][1], o.forward([5], n)) < 1e-4
+        else:
+            # real widths (4 layers of Qwen3.5-0.8B x 1024 tokens; the 27B head geometry -- 48 value heads, 3 per key head -- x 193):
+            # the chunk-parallel scan against the token-serial recurrence of the C oracle (oracle/c/qwen35_cpu.c, ops/gdn/backend.rs:90-156;
+            # pinned on the HF fixtures by tests/test_c_oracle.py), prompt logits and the decode step on the state the prompt left
+            from oracle import c_oracle
+            co = c_oracle.CQwen35(cfg, seed=0, max_seq=n + 64)
+            try:
+                ra = co.forward(ids, 0)
+                rb = co.forward([5], n)
+            finally:
+                co.close()
+            assert rel(outs[0][0], ra) < 1e-4, rel(outs[0][0], ra)
+            assert rel(outs[0][1], rb) < 1e-4, rel(outs[0][1], rb)
+            assert int(outs[0][0].argmax()) == int(ra.argmax())
     finally:
         m.close()
 
