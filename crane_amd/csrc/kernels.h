@@ -382,11 +382,14 @@ struct GemvQBArgs {
     float eps;
 };
 // decode groups on the int8 matrix cores (kernels_quant_gemm.hip): QFMT_Q8_0-layout weights x Q8_0-quantised activation rows
-constexpr int QGEMM_MAXM = 128;
+constexpr int QGEMM_MAXM = 128;            // rows of a decode group (and the scale stride of its buffers)
+constexpr int QGEMM_BIGM = 1 << 16;        // rows of one launch (a prompt pass: m-panels of 256 rows)
 struct QGemmArgs {
     QWeight w;
     const signed char* xq;     // [M][K] activation codes (launch_quant_rows_q8)
-    const float* xd;           // [K / 32][QGEMM_MAXM] their block scales, transposed
+    const float* xd;           // [K / 32][xs] their block scales, transposed
+    int xs = 0;                // floats between the scale rows of consecutive blocks (0: QGEMM_MAXM); also the stride of nxd and of the next projection's scales
+    int mpan = 1;              // set by launch_gemm_q8: m-panels the grid walks
     float* ws;                 // set by launch_gemm_q8: partial slices [ksplit][M][N], or the output itself (unsplit store)
     size_t slice;
     int M, ksplit, ldp;
@@ -394,7 +397,7 @@ struct QGemmArgs {
     signed char* nxq;          // ... and, when set, quantise those rows (N / 2 columns) for the next projection: codes [M][N / 2] ...
     float* nxd;                //     ... and block scales [N / 64][QGEMM_MAXM] (NOT the buffers this launch reads)
 };
-void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s);
+void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s, int xs = QGEMM_MAXM);
 bool gemm_q8_ok(const QWeight& w, int M);
 // `next` (EPI_RESADD / EPI_SILUMUL): the rows this GEMM writes are the next projection's input -- the reduction launch also quantises
 // them (RMSNorm with next->nw first when set), exactly as launch_quant_rows_q8 would; *fused: 0 = not quantised, 1 = into next->xq / xd
@@ -404,7 +407,7 @@ struct QNext { const float* nw; float eps; signed char* xq; float* xd; signed ch
 // splits K into 2 .. 4 slices, no reduction is launched -- ks slices of `slice` floats at ws, rows N floats apart; ks = 1: y holds the rows as usual
 struct QDefer { int ks; size_t slice; const float* ws; };
 // what launch_gemm_q8 will do for a shape (host logic only): ok = false -> the caller's GEMV fallback
-struct QGemmPlan { bool ok, direct; int geo, mh, mt, qg, groups, ks, grid; size_t lds; };
+struct QGemmPlan { bool ok, direct; int geo, mh, mt, qg, groups, ks, grid; size_t lds; int mpan; };
 QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu);
 bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
                     const QNext* next = nullptr, int* fused = nullptr, QDefer* defer = nullptr);

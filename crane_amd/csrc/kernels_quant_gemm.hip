@@ -44,7 +44,7 @@ __device__ __forceinline__ float f16bits(uint32_t b) { _Float16 v; const uint16_
 // one 256-thread block per row: thread t walks k4 = t + 256 j + 1024 i exactly like a 256-thread half of gemvqb_i8_kernel
 template <bool NORM>
 __global__ __launch_bounds__(256) void quant_rows_q8_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, float eps,
-                                                            signed char* __restrict__ xq, float* __restrict__ xd, int K) {
+                                                            signed char* __restrict__ xq, float* __restrict__ xd, int K, int xs) {
     __shared__ float red[4];
     const int m = blockIdx.x, t2 = threadIdx.x, lane = t2 & 63, w2 = t2 >> 6;
     const float* xr = x + (size_t)m * ldx;
@@ -91,14 +91,14 @@ __global__ __launch_bounds__(256) void quant_rows_q8_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
             xqr[k4] = pk;
-            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * QGEMM_MAXM + m] = f16r(d);
+            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * xs + m] = f16r(d);
         }
     }
 }
 
-void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s) {
-    if (nw) hipLaunchKernelGGL(quant_rows_q8_kernel<true>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K);
-    else hipLaunchKernelGGL(quant_rows_q8_kernel<false>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K);
+void launch_quant_rows_q8(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s, int xs) {
+    if (nw) hipLaunchKernelGGL(quant_rows_q8_kernel<true>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K, xs);
+    else hipLaunchKernelGGL(quant_rows_q8_kernel<false>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K, xs);
 }
 
 // Workgroup tile: 128 weight rows x all M activation rows; 4 MH waves = 4 n-strips of 32 weight rows x MH halves of the activation
@@ -127,23 +127,34 @@ constexpr int QG_MIN = 8;                           // K % (32 QG_MIN) == 0: eve
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// Round 6: prompt passes (M > 128) -- geometry <2, 4, 4>: 8 waves, 256 activation rows per workgroup (a weight panel in LDS is multiplied
+// with 4 m-tiles per wave: half the weight fetches per row of the 128-row geometries), and a launch covers ALL rows: blockIdx also
+// walks the m-panels (a.mpan), the block scales of the rows sit a.xs floats apart ([K / 32][xs], xs >= the launch's rows).
 template <int MH, int MT, int QG>
-__global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
+__global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q8_i8_kernel(QGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
     constexpr int QROWB = QG * 32 + 16;                 // bytes of a panel row in LDS (padded: the 16 rows of a fragment read start 4 banks apart)
     constexpr int RC = 2 * QG;                          // 16-byte chunks of a row and group
     constexpr int NT = 256 * MH, PR = 32 * MT * MH, NCH = PR * RC / NT, NWC = 128 * RC / NT, NS = QG * MT;
     constexpr int PANEL = PR * QROWB, WPANEL = 128 * QROWB;
+    constexpr int XM = PR > QGEMM_MAXM ? PR : QGEMM_MAXM;   // rows of the activation-scale panel in LDS
     typedef uint32_t scl_t __attribute__((ext_vector_type(QG / 2)));       // a row's QG f16 block scales of a group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, ns = wave & 3, mh = wave >> 2;
     const int K = a.w.K, N = a.w.N, nkb_all = K >> 5, G = nkb_all / QG;
-    float* xds = (float*)qlds;                                              // [2][QG][QGEMM_MAXM] block scales of the activation rows, per group
-    float* dwl = xds + 2 * QG * QGEMM_MAXM + wave * (QG * 32);              // [QG][32] this wave's weight scales of the group (wave-private)
-    unsigned char* Ws = qlds + (size_t)(2 * QG * QGEMM_MAXM + 4 * MH * QG * 32) * sizeof(float);   // [2][128][QROWB] weight codes of a group
+    float* xds = (float*)qlds;                                              // [2][QG][XM] block scales of the activation rows, per group
+    float* dwl = xds + 2 * QG * XM + wave * (QG * 32);                      // [QG][32] this wave's weight scales of the group (wave-private)
+    unsigned char* Ws = qlds + (size_t)(2 * QG * XM + 4 * MH * QG * 32) * sizeof(float);   // [2][128][QROWB] weight codes of a group
     unsigned char* As = Ws + 2 * WPANEL;                                    // [2][PR][QROWB] activation codes of a group
     const int tiles = N / 128;
-    const int ks = (int)blockIdx.x / tiles, tn = (int)blockIdx.x % tiles;
+    // block -> (K slice, weight tile, m-panel).  Several m-panels (a prompt pass): workgroups are dealt round-robin to the 8 XCDs, so
+    // the panels of one weight tile get ids 8 apart -- they run on ONE XCD, back to back, and share the tile through that L2
+    const int per = tiles * a.mpan;
+    const int ks = (int)blockIdx.x / per, rem = (int)blockIdx.x % per;
+    int tn, mp;
+    if (a.mpan > 1 && (tiles & 7) == 0) { const int xcd = rem & 7, idx = rem >> 3; tn = (idx / a.mpan) * 8 + xcd; mp = idx % a.mpan; }
+    else { tn = rem % tiles; mp = rem / tiles; }
+    const int m_base = mp * PR;
     const int g0 = ks * G / a.ksplit, ngrp = (ks + 1) * G / a.ksplit - g0, kb0 = g0 * QG;
     // weight scales: lane (r, .) of strip ns owns row tn * 128 + ns * 32 + r (8 f16 = one 16-byte load per group)
     const uint16_t* dp = (const uint16_t*)a.w.p1 + (size_t)(tn * 128 + ns * 32 + r) * nkb_all + kb0;
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + NT * i, row = c / RC, q = c % RC;
-        xsrc[i] = a.xq + (size_t)min(row, a.M - 1) * K + (size_t)kb0 * 32 + 16 * q;       // (rows past M: clamped, dropped at the store)
+        xsrc[i] = a.xq + (size_t)min(m_base + row, a.M - 1) * K + (size_t)kb0 * 32 + 16 * q;       // (rows past M: clamped, dropped at the store)
         xdst[i] = row * QROWB + 16 * q;
     }
     u32x4 wreg[NWC], areg[NCH];
@@ -173,10 +184,11 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)xsrc[i];
     // (a group's scales: QG x 128 floats = one 16-byte load per thread of the first QG / 2 waves)
-    constexpr int XT = QG * QGEMM_MAXM / 4;
-    const f32x4* xdsrc = (const f32x4*)(a.xd + (size_t)kb0 * QGEMM_MAXM) + (tid % XT);
+    constexpr int XT = QG * XM / 4, XR = XM / 4;
+    const float* xdsrc = a.xd + ((size_t)kb0 + (tid % XT) / XR) * a.xs + m_base + 4 * ((tid % XT) % XR);      // block (tid / XR) of the group, rows 4 (tid % XR) ...
+    const size_t xdstep = (size_t)QG * a.xs;
     f32x4 xreg = {0.f, 0.f, 0.f, 0.f};
-    if (tid < XT) { xreg = *xdsrc; ((f32x4*)xds)[tid] = xreg; }
+    if (tid < XT) { xreg = *(const f32x4*)xdsrc; ((f32x4*)xds)[tid] = xreg; }
 #pragma unroll
     for (int i = 0; i < NWC; ++i) *(u32x4*)(Ws + wdst[i]) = wreg[i];
 #pragma unroll
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
     __syncthreads();
     const int wrow = (ns * 32 + r) * QROWB + 16 * h;                         // + j * 32
     const int arow = (mh * MT * 32 + r) * QROWB + 16 * h;                    // + mt * 32 * QROWB + j * 32
-    const int xrow = mh * MT * 32 + r;                                       // + j * QGEMM_MAXM + mt * 32
+    const int xrow = mh * MT * 32 + r;                                       // + j * XM + mt * 32
     for (int g = 0; g < ngrp; ++g) {
         const bool more = g + 1 < ngrp;
         if (more) {
@@ -209,11 +221,11 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
             scn = *(const scl_t*)(dp + (g + 1) * QG);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)(xsrc[i] + (size_t)(g + 1) * QG * 32);
-            if (tid < XT) xreg = xdsrc[(size_t)(g + 1) * XT];
+            if (tid < XT) xreg = *(const f32x4*)(xdsrc + (size_t)(g + 1) * xdstep);
         }
         const unsigned char* Wp = Ws + (g & 1) * WPANEL + wrow;
         const unsigned char* Ap = As + (g & 1) * PANEL + arow;
-        const float* xg = xds + (g & 1) * (QG * QGEMM_MAXM) + xrow;
+        const float* xg = xds + (g & 1) * (QG * XM) + xrow;
         u32x4 avq[2], wfq[2];
         float dxq[3];
         i32x16 cq[2];
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         // step s = (block j = s / MT, m-tile mt = s % MT)
 #define Q8_LOAD(s_, slot_) do { avq[slot_] = *(const u32x4*)(Ap + ((s_) % MT) * 32 * QROWB + ((s_) / MT) * 32); \
-                                dxq[(s_) % 3] = xg[((s_) / MT) * QGEMM_MAXM + ((s_) % MT) * 32]; } while (0)
+                                dxq[(s_) % 3] = xg[((s_) / MT) * XM + ((s_) % MT) * 32]; } while (0)
 #define Q8_MFMA(s_, slot_) cq[slot_] = __builtin_amdgcn_mfma_i32_32x32x32_i8( \
             (i32x4){(int)wfq[((s_) / MT) & 1][0], (int)wfq[((s_) / MT) & 1][1], (int)wfq[((s_) / MT) & 1][2], (int)wfq[((s_) / MT) & 1][3]}, \
             (i32x4){(int)avq[slot_][0], (int)avq[slot_][1], (int)avq[slot_][2], (int)avq[slot_][3]}, zero, 0, 0, 0)
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
             for (int i = 0; i < NWC; ++i) *(u32x4*)(Wn + wdst[i]) = wreg[i];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) *(u32x4*)(An + xdst[i]) = areg[i];
-            if (tid < XT) ((f32x4*)(xds + ((g + 1) & 1) * (QG * QGEMM_MAXM)))[tid] = xreg;
+            if (tid < XT) ((f32x4*)(xds + ((g + 1) & 1) * (QG * XM)))[tid] = xreg;
             put_dw(scn);                                                    // (this group's reads of the scales are behind us)
         }
         __syncthreads();
@@ -282,15 +294,16 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
     float* T = (float*)Ws;                                                  // (the last group's barrier is behind every panel read)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = (mh * MT + mt) * 32 + r;
+        const int ml = (mh * MT + mt) * 32 + r, m = m_base + ml;
         if (a.silu) {
             // unsplit gate|up: columns (2 k, 2 k + 1) = (gate_k, up_k) sit in one lane -- the reduction kernel's expression, no f32 round trip
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float g0 = acc[mt][2 * q][0], u0 = acc[mt][2 * q][1], g1 = acc[mt][2 * q + 1][0], u1 = acc[mt][2 * q + 1][1];
                 const f32x2 o = (f32x2){(g0 / (1.0f + expf(-g0))) * u0, (g1 / (1.0f + expf(-g1))) * u1};
-                if (m < a.M) *(f32x2*)(P + (size_t)m * a.ldp + ((nq + 8 * q) >> 1)) = o;
-                if (a.nxq) *(f32x2*)(T + m * TS + ns * 16 + 2 * h + 4 * q) = o;
+                // (through the LDS tile: a lane's 8-byte pieces of 32 different rows were 64 partial-line writes per instruction -- the
+                // unsplit gate|up launch of a 1024-row prompt pass took 441 us against 3 x 59 for the same work per workgroup in qkv)
+                *(f32x2*)(T + ml * TS + ns * 16 + 2 * h + 4 * q) = o;
             }
         } else if (m < a.M) {
 #pragma unroll
@@ -298,10 +311,17 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
                 *(f32x4*)(P + (size_t)m * a.ldp + nq + 8 * q) = (f32x4){acc[mt][2 * q][0], acc[mt][2 * q][1], acc[mt][2 * q + 1][0], acc[mt][2 * q + 1][1]};
         }
     }
+    if (a.silu) {
+        // rows of the tile as whole 256-byte runs: 16 lanes x 16 bytes per row
+        __syncthreads();
+        for (int it = tid; it < PR * 16; it += NT) {
+            const int row = it >> 4, c4 = it & 15;
+            if (m_base + row < a.M) *(f32x4*)(P + (size_t)(m_base + row) * a.ldp + tn * 64 + 4 * c4) = *(const f32x4*)(T + row * TS + 4 * c4);
+        }
+    }
     if (a.silu && a.nxq) {
         // the tile's 64 outputs of every row are two Q8_0 blocks of the down projection's input: quantised here, 8 lanes x 4 values per
         // block -- quant_rows_q8_kernel's arithmetic (amax tree, d = amax / 127, roundf(x / d), f16-rounded scale)
-        __syncthreads();
         const int nkout = N >> 1, l8 = tid & 7;
         for (int it = tid >> 3; it < PR * 2; it += NT >> 3) {
             const int row = it >> 1, b = it & 1;
@@ -313,9 +333,9 @@ __global__ __launch_bounds__(256 * MH, 2) void gemm_q8_i8_kernel(QGemmArgs a) {
             uint32_t pk = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
-            if (row < a.M) {
-                ((uint32_t*)(a.nxq + (size_t)row * nkout))[tn * 16 + b * 8 + l8] = pk;
-                if (l8 == 0) a.nxd[(size_t)(tn * 2 + b) * QGEMM_MAXM + row] = f16r(d);
+            if (m_base + row < a.M) {
+                ((uint32_t*)(a.nxq + (size_t)(m_base + row) * nkout))[tn * 16 + b * 8 + l8] = pk;
+                if (l8 == 0) a.nxd[(size_t)(tn * 2 + b) * a.xs + m_base + row] = f16r(d);
             }
         }
     }
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(256) void q8_splitk_epilogue_kernel(const float* __
 //   EPI_SILUMUL: y[m][k] = silu(gate_k) * up_k from the interleaved columns (2 k, 2 k + 1) (N / 2 outputs), then Q8_0 blocks
 template <int EPI, int KS, bool NORM>
 __global__ __launch_bounds__(256) void q8_splitk_quant_kernel(const float* __restrict__ ws, int M, int N, int ksplit, float* __restrict__ y, int ldy,
-                                                              const float* __restrict__ nw, float eps, signed char* __restrict__ xq, float* __restrict__ xd) {
+                                                              const float* __restrict__ nw, float eps, signed char* __restrict__ xq, float* __restrict__ xd, int xs) {
     __shared__ float red[4];
     const int m = blockIdx.x, t2 = threadIdx.x, lane = t2 & 63, w2 = t2 >> 6;
     const int Kout = EPI == EPI_SILUMUL ? N / 2 : N, n4 = Kout >> 2;
@@ -437,7 +457,7 @@ __global__ __launch_bounds__(256) void q8_splitk_quant_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
             xqr[k4] = pk;
-            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * QGEMM_MAXM + m] = f16r(d);
+            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * xs + m] = f16r(d);
         }
         return;
     }
@@ -491,15 +511,15 @@ __global__ __launch_bounds__(256) void q8_splitk_quant_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(xv[e] * id) & 0xFFu) << (8 * e);
             xqr[k4] = pk;
-            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * QGEMM_MAXM + m] = f16r(d);
+            if ((t2 & 7) == 0) xd[(size_t)(k4 >> 3) * xs + m] = f16r(d);
         }
     }
 }
 
 template <int EPI>
-static void launch_q8_epilogue_quant(const float* ws, int M, int N, int ks, float* y, int ldy, const QNext& nx, hipStream_t s) {
-#define CM_QQ(KS_) do { if (nx.nw) hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, true>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd); \
-                        else hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, false>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd); } while (0)
+static void launch_q8_epilogue_quant(const float* ws, int M, int N, int ks, float* y, int ldy, const QNext& nx, int xs, hipStream_t s) {
+#define CM_QQ(KS_) do { if (nx.nw) hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, true>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd, xs); \
+                        else hipLaunchKernelGGL((q8_splitk_quant_kernel<EPI, KS_, false>), dim3(M), dim3(256), 0, s, ws, M, N, ks, y, ldy, nx.nw, nx.eps, nx.xq, nx.xd, xs); } while (0)
     switch (ks) {
         case 1: CM_QQ(1); break; case 2: CM_QQ(2); break; case 3: CM_QQ(3); break; case 4: CM_QQ(4); break; case 5: CM_QQ(5); break;
         case 6: CM_QQ(6); break; case 8: CM_QQ(8); break; case 10: CM_QQ(10); break; case 12: CM_QQ(12); break; case 16: CM_QQ(16); break;
@@ -521,7 +541,7 @@ static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, 
 }
 
 bool gemm_q8_ok(const QWeight& w, int M) {
-    return w.fmt == QFMT_Q8_0 && M >= 1 && M <= QGEMM_MAXM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
+    return w.fmt == QFMT_Q8_0 && M >= 1 && M <= QGEMM_BIGM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
 }
 
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
@@ -535,19 +555,22 @@ bool gemm_q8_ok(const QWeight& w, int M) {
 //   ceil(tiles ks / cap) rounds of (1 start-up + ceil(G / ks) groups), and every slice costs a write + a read of M x N f32.
 QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu) {
     QGemmPlan p{};
-    if (M < 1 || M > QGEMM_MAXM || N % 128 != 0 || K % (32 * QG_MIN) != 0 || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return p;
+    if (M < 1 || M > QGEMM_BIGM || N % 128 != 0 || K % (32 * QG_MIN) != 0 || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return p;
     static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 3;
-    const int geo = M > 64 ? (geo_env == 0 ? 1 : geo_env == 1 ? 2 : 3) : 0;
+    // (more than 128 rows -- a prompt pass: geometry 4 = 8 waves x 4 m-tiles, 256 rows per workgroup, ceil(M / 256) m-panels per launch)
+    const int geo = M > QGEMM_MAXM ? 4 : M > 64 ? (geo_env == 0 ? 1 : geo_env == 1 ? 2 : 3) : 0;
     p.geo = geo;
     // (<= 64 rows, 4 waves: groups of 4 blocks = 52 / 61 KB of LDS, TWO workgroups per CU as `cap` below assumes; with groups of 8 -- 104 KB --
     // a CU held one 4-wave workgroup, one wave per SIMD.  CM_QGEMM_QG_SMALL = 8: A/B)
     static const int qg_small = getenv("CM_QGEMM_QG_SMALL") && atoi(getenv("CM_QGEMM_QG_SMALL")) == 8 ? 8 : 4;
-    p.mh = geo == 1 || geo == 3 ? 2 : 1; p.mt = geo == 2 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : geo == 1 ? 8 : qg_small;
-    const int nkb_all = K >> 5, tiles = N / 128, G = nkb_all / p.qg;
+    p.mh = geo == 1 || geo == 3 || geo == 4 ? 2 : 1; p.mt = geo == 2 || geo == 4 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : geo == 1 ? 8 : qg_small;
+    const int pr = 32 * p.mt * p.mh;
+    p.mpan = geo == 4 ? (M + pr - 1) / pr : 1;
+    const int nkb_all = K >> 5, tiles = (N / 128) * p.mpan, G = nkb_all / p.qg;
     p.groups = G;
-    p.lds = (size_t)(2 * p.qg * QGEMM_MAXM + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + p.mh * p.mt * 32) * (p.qg * 32 + 16);
+    p.lds = (size_t)(2 * p.qg * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (p.qg * 32 + 16);
     const int cap = num_cu * (p.mh == 2 ? 1 : 2);
-    const double tgroup_us = 2.0, fill_us = 2.5, part_us = 8.0 * M * N / 3.0e6;        // (partials at ~3 TB/s, write + read)
+    const double tgroup_us = geo == 4 ? 4.0 : 2.0, fill_us = 2.5, part_us = 8.0 * M * N / 3.0e6;        // (partials at ~3 TB/s, write + read)
     int ks = 1;
     double best = 1e30;
     const bool direct_only = epi == EPI_STORE && (size_t)M * N > ws_floats;            // (the vocabulary head: written in place, unsplit)
@@ -579,7 +602,11 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     if (!gemm_q8_ok(a.w, a.M)) return false;
     const QGemmPlan pl = plan_gemm_q8(a.M, a.w.N, a.w.K, epi, ws != nullptr, ws_floats, num_cu);
     if (!pl.ok) return false;
-    const int N = a.w.N, tiles = N / 128, mh = pl.mh, mt = pl.mt, geo = pl.geo;
+    const int N = a.w.N, tiles = (N / 128) * pl.mpan, mh = pl.mh, mt = pl.mt, geo = pl.geo;
+    a.mpan = pl.mpan;
+    if (a.xs <= 0) a.xs = QGEMM_MAXM;
+    if (a.xs < std::min(a.M, pl.mpan * 32 * mt * mh) && pl.mpan > 1) return false;       // (the scale rows of a multi-panel launch must hold every row read)
+    const int xs = a.xs;
     int ks = pl.ks;
     const bool direct = pl.direct;
     const size_t lds = pl.lds;
@@ -600,9 +627,11 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid(tiles * ks), block(256 * mh);
-    if (geo == 3) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 4>), grid, block, lds, s, a);
+    if (geo == 4) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 4, 4>), grid, block, lds, s, a);
+    else if (geo == 3) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 4>), grid, block, lds, s, a);
     else if (geo == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 4, 4>), grid, block, lds, s, a);
     else if (mh == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 8>), grid, block, lds, s, a);
     else if (mt == 2 && pl.qg == 4) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 2, 4>), grid, block, lds, s, a);
@@ -616,8 +645,8 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     static const int qfuse_env = getenv("CM_QGEMM_QFUSE") ? atoi(getenv("CM_QGEMM_QFUSE")) : 1;
     const int kout = epi == EPI_SILUMUL ? N / 2 : N;
     if (next != nullptr && qfuse_env != 0 && (epi == EPI_RESADD || epi == EPI_SILUMUL) && kout % 32 == 0) {
-        if (epi == EPI_RESADD) launch_q8_epilogue_quant<EPI_RESADD>(ws, a.M, N, ks, y, ldy, *next, s);
-        else launch_q8_epilogue_quant<EPI_SILUMUL>(ws, a.M, N, ks, y, ldy, *next, s);
+        if (epi == EPI_RESADD) launch_q8_epilogue_quant<EPI_RESADD>(ws, a.M, N, ks, y, ldy, *next, xs, s);
+        else launch_q8_epilogue_quant<EPI_SILUMUL>(ws, a.M, N, ks, y, ldy, *next, xs, s);
         if (fused) *fused = 1;
         return true;
     }

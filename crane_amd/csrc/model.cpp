@@ -1069,25 +1069,39 @@ void Model::ensure_gemm_workspace() {
 }
 
 bool Model::q8_prefill_eligible() const {
-    if (!quantized || !quant_act_int || cfg.hybrid) return false;
+    if (!quantized || !quant_act_int) return false;
+    const int qz = cfg.hybrid ? cfg.conv_dim() + cfg.value_dim() : 0;
     for (const LayerW& w : layers) {
-        if (w.n_qkv < 1 || w.split_gate_up) return false;
-        for (int i = 0; i < w.n_qkv; ++i) if (!gemm_q8_ok(w.q_qkv[i], QGEMM_MAXM)) return false;
-        if (!gemm_q8_ok(w.q_o, QGEMM_MAXM) || !gemm_q8_ok(w.q_gate_up, QGEMM_MAXM) || !gemm_q8_ok(w.q_down, QGEMM_MAXM)) return false;
-        if ((w.q_gate_up.N / 2) % 32 != 0) return false;
+        if (w.split_gate_up) return false;
+        if (!gemm_q8_ok(w.q_gate_up, QGEMM_MAXM) || !gemm_q8_ok(w.q_down, QGEMM_MAXM) || (w.q_gate_up.N / 2) % 32 != 0) return false;
+        if (w.full) {
+            if (w.n_qkv < 1) return false;
+            for (int i = 0; i < w.n_qkv; ++i) if (!gemm_q8_ok(w.q_qkv[i], QGEMM_MAXM)) return false;
+            if (!gemm_q8_ok(w.q_o, QGEMM_MAXM)) return false;
+        } else {
+            // Gated-Delta-Net layer: [qkv | z] on the int8 cores; the bf16 a / b gate rows as one 128-column bf16 GEMM tile behind them
+            if (!gemm_q8_ok(w.q_in_proj, QGEMM_MAXM) || !gemm_q8_ok(w.q_out_proj, QGEMM_MAXM)) return false;
+            if (w.q_in_proj_z.fmt != QFMT_NONE && !gemm_q8_ok(w.q_in_proj_z, QGEMM_MAXM)) return false;
+            if (w.in_proj_ba == nullptr || qz % 128 != 0 || in_proj_pad - qz < 128 || 2 * cfg.NV > 128) return false;
+            if (w.q_in_proj.N + (w.q_in_proj_z.fmt != QFMT_NONE ? w.q_in_proj_z.N : 0) != qz) return false;
+        }
     }
     return true;
+}
+
+int Model::prefill_chunk_rows() const {
+    int c = opts.prefill_chunk ? (int)opts.prefill_chunk : 2048;       // PREFILL_CHUNK_SIZE engine/mod.rs:65
+    // one sequence never has more than max_seq rows in a pass, but the prompts of several sequences share one (prefill_multi):
+    // the row capacity is bounded by what all slots together can hold, not by one sequence
+    const long all_rows = (long)max_seq * (long)std::max<size_t>(1, seqs.size());
+    if ((long)c > all_rows) c = (int)all_rows;
+    return c < 1 ? 1 : c;
 }
 
 void Model::ensure_prefill_buffers() {
     if (pX) return;
     const int H = cfg.H, D = cfg.D;
-    chunk = opts.prefill_chunk ? (int)opts.prefill_chunk : 2048;      // PREFILL_CHUNK_SIZE engine/mod.rs:65
-    // one sequence never has more than max_seq rows in a pass, but the prompts of several sequences share one (prefill_multi):
-    // the row capacity is bounded by what all slots together can hold, not by one sequence
-    const long all_rows = (long)max_seq * (long)std::max<size_t>(1, seqs.size());
-    if ((long)chunk > all_rows) chunk = (int)all_rows;
-    if (chunk < 1) chunk = 1;
+    chunk = prefill_chunk_rows();
     chunk_pad = (chunk + 127) / 128 * 128;
     // prompt activations as bf16 hi + lo (two products per GEMM: what the 1e-3 bound of a bf16 checkpoint needs) unless the caller asked
     // for plain bf16 -- or left the choice open (0) on QUANTISED weights: their scratch copy for the GEMMs is already rounded to bf16
@@ -1135,8 +1149,15 @@ void Model::ensure_prefill_buffers() {
     // (ops/linear.rs:18-51: activation row -> Q8_0 blocks, ggml_vec_dot_q8_0_q8_0 per output), no dequantised copy of any matrix
     q8_prefill = q8_prefill_want && q8_prefill_eligible();
     if (q8_prefill) {
-        ensure_batch_buffers();                                    // qx_codes / qx_scales pairs, hbb
+        ensure_batch_buffers();                                    // qx_codes / qx_scales pairs (sized for a whole pass there)
         pATf = dalloc<float>((size_t)chunk * Hq_l * D);
+        pHf = dalloc<float>((size_t)chunk * I_l);                  // silu(gate) * up of the pass, f32 (the down projection's quantiser input)
+        for (LayerW& w : layers) {
+            if (w.full) continue;
+            w.ba_pad = dalloc<uint16_t>((size_t)128 * H);          // the a / b rows as one zero-padded 128-row GEMM tile
+            CM_HIP(hipMemsetAsync(w.ba_pad, 0, (size_t)128 * H * sizeof(uint16_t), stream));
+            CM_HIP(hipMemcpyAsync(w.ba_pad, w.in_proj_ba, (size_t)2 * cfg.NV * H * sizeof(uint16_t), hipMemcpyDeviceToDevice, stream));
+        }
     }
     if (quantized && !q8_prefill) {
         // one dequantised matrix at a time: bf16 hi plane + lo plane (parity mode), and the f32 gate|up sums of the two-pass GEMM
@@ -1193,15 +1214,16 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     };
     // ---- int8 prompt pass (q8_prefill): rows in panels of <= QGEMM_MAXM; quantiser + int8-MFMA GEMM per projection and panel ----
     const bool q8p = q8_prefill;
+    const int xs8 = S > (int)QGEMM_MAXM ? q8_xs : (int)QGEMM_MAXM;       // scale-row stride of this pass's code buffers
     auto q8_quant = [&](const float* xin, int ldx, const float* nw, int m, int K) {
-        launch_quant_rows_q8(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, K, s);
-        if (q_capture) q_capture_rows(m, K);
+        launch_quant_rows_q8(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, K, s, xs8);
+        if (q_capture) q_capture_rows(m, K, xs8);
     };
     // y (+)= W . codes^T over the panel's m rows; next_nw / next_plain: the rows written are the next projection's input -- quantised by
     // the reduction launch (or the unsplit gate|up GEMM itself); returns true when the current codes hold them
     auto q8_mm = [&](const QWeight& qw, int epi, float* y, int ldy, int m, const float* next_nw, bool next_plain) -> bool {
         QGemmArgs qg{};
-        qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = m;
+        qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = m; qg.xs = xs8;
         QNext nx{next_nw, cfg.eps, qx_codes, qx_scales, qx_codes2, qx_scales2};
         const int kout = epi == EPI_SILUMUL ? qw.N / 2 : qw.N;
         const bool want_next = (next_nw != nullptr || next_plain) && ldy == kout;
@@ -1209,8 +1231,31 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         if (!launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused))
             throw CmError(CM_ERR_UNSUPPORTED, "int8 prompt GEMM shape");
         if (fused == 2) { std::swap(qx_codes, qx_codes2); std::swap(qx_scales, qx_scales2); }
-        if (fused && q_capture) q_capture_rows(m, kout);
+        if (fused && q_capture) q_capture_rows(m, kout, xs8);
         return fused != 0;
+    };
+    // the rest of a layer after the token mixer, panel by panel: o_proj / out_proj over the mixer's f32 rows `ain` [S][AC], gate|up,
+    // down_proj -- a panel's rows of silu(gate) * up never leave the [128][I] scratch
+    auto q8_tail = [&](const LayerW& w, const QWeight& wo, const float* ain, int AC, int li) {
+        bool have = false;
+        q8_quant(ain, AC, nullptr, S, AC);
+        if (!rccl) have = q8_mm(wo, EPI_RESADD, pX, H, S, w.ln2, false);
+        else {
+            q8_mm(wo, EPI_STORE, pY, H, S, nullptr, false);
+            rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+            launch_add_rows(pX, pY, (size_t)S * H, s);
+        }
+        if (!have) q8_quant(pX, H, w.ln2, S, H);
+        have = q8_mm(w.q_gate_up, EPI_SILUMUL, pHf, I_l, S, nullptr, true);
+        if (!have) q8_quant(pHf, I_l, nullptr, S, I_l);
+        if (!rccl) q8_mm(w.q_down, EPI_RESADD, pX, H, S, nullptr, false);
+        else {
+            q8_mm(w.q_down, EPI_STORE, pY, H, S, nullptr, false);
+            rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
+            launch_add_rows(pX, pY, (size_t)S * H, s);
+        }
+        if (li < deep_layers && splice_map_dev != nullptr)
+            launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
     };
     bool xn_ready = false;
     for (int li = 0; li < cfg.L; ++li) {
@@ -1222,6 +1267,16 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         if (!w.full) {
             // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
+            if (q8p) {
+                // [qkv | z] rows on the int8 matrix cores, panel by panel; the bf16 a / b rows as one 128-column bf16 GEMM tile (hi + lo
+                // activations from the rmsnorm_rows launch above) into the columns behind them
+                const int qz = cfg.conv_dim() + cfg.value_dim();
+                q8_quant(pX, H, w.ln1, S, H);
+                q8_mm(w.q_in_proj, EPI_STORE, pQKV, in_proj_pad, S, nullptr, false);
+                if (w.q_in_proj_z.fmt != QFMT_NONE) q8_mm(w.q_in_proj_z, EPI_STORE, pQKV + w.q_in_proj.N, in_proj_pad, S, nullptr, false);
+                g.W = w.ba_pad; g.C = pQKV + qz; g.M = S; g.N = 128; g.K = H;
+                if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+            } else {
             if (quantized) {     // [qkv | z] dequantised, then the bf16 b / a rows, then the zero padding of the merged matrix
                 const size_t qz = (size_t)cfg.conv_dim() + cfg.value_dim(), nba = (size_t)2 * cfg.NV;
                 set_w(g, deq_w(w, 0, (size_t)in_proj_pad * H, [&](uint16_t* dst, uint16_t* lo) {
@@ -1235,6 +1290,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             }
             g.M = S; g.N = in_proj_pad; g.K = H;
             if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
+            }
             GdnArgs ga{};
             ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
             ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.st = nullptr;
@@ -1256,6 +1312,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
                     done += part;
                 }
             }
+            if (q8p) { q8_tail(w, w.q_out_proj, pGY, cfg.value_dim(), li); continue; }
             launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
             g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
@@ -1268,12 +1325,8 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             }
         } else {
         if (q8p) {
-            for (int r0 = 0; r0 < S; r0 += QGEMM_MAXM) {
-                const int m = std::min((int)QGEMM_MAXM, S - r0);
-                q8_quant(pX + (size_t)r0 * H, H, w.ln1, m, H);
-                for (int i = 0; i < w.n_qkv; ++i)
-                    q8_mm(w.q_qkv[i], EPI_STORE, pQKV + (size_t)r0 * qkv_rows + w.qkv_row0[i], qkv_rows, m, nullptr, false);
-            }
+            q8_quant(pX, H, w.ln1, S, H);
+            for (int i = 0; i < w.n_qkv; ++i) q8_mm(w.q_qkv[i], EPI_STORE, pQKV + w.qkv_row0[i], qkv_rows, S, nullptr, false);
         } else {
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 1)) ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
         if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
@@ -1342,40 +1395,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         if (q8p) at.out_f32 = pATf + (size_t)sg.row0 * Hq_l * D;
         launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
         }
-        if (q8p) {
-            // o_proj, gate|up, down_proj panel by panel: a panel's rows of silu(gate) * up never leave the [128][I] scratch
-            const int AC = Hq_l * D;
-            if (rccl) {
-                for (int r0 = 0; r0 < S; r0 += QGEMM_MAXM) {
-                    const int m = std::min((int)QGEMM_MAXM, S - r0);
-                    q8_quant(pATf + (size_t)r0 * AC, AC, nullptr, m, AC);
-                    q8_mm(w.q_o, EPI_STORE, pY + (size_t)r0 * H, H, m, nullptr, false);
-                }
-                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
-                launch_add_rows(pX, pY, (size_t)S * H, s);
-            }
-            for (int r0 = 0; r0 < S; r0 += QGEMM_MAXM) {
-                const int m = std::min((int)QGEMM_MAXM, S - r0);
-                float* xr = pX + (size_t)r0 * H;
-                bool have = false;
-                if (!rccl) {
-                    q8_quant(pATf + (size_t)r0 * AC, AC, nullptr, m, AC);
-                    have = q8_mm(w.q_o, EPI_RESADD, xr, H, m, w.ln2, false);
-                }
-                if (!have) q8_quant(xr, H, w.ln2, m, H);
-                have = q8_mm(w.q_gate_up, EPI_SILUMUL, hbb, I_l, m, nullptr, true);
-                if (!have) q8_quant(hbb, I_l, nullptr, m, I_l);
-                if (!rccl) q8_mm(w.q_down, EPI_RESADD, xr, H, m, nullptr, false);
-                else q8_mm(w.q_down, EPI_STORE, pY + (size_t)r0 * H, H, m, nullptr, false);
-            }
-            if (rccl) {
-                rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
-                launch_add_rows(pX, pY, (size_t)S * H, s);
-            }
-            if (li < deep_layers && splice_map_dev != nullptr)
-                launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
-            continue;
-        }
+        if (q8p) { q8_tail(w, w.q_o, pATf, Hq_l * D, li); continue; }
         g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
         g.A_hi = pAT_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 2)) ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
         if (quantized) set_w(g, deq_w(w, 1, (size_t)w.q_o.N * w.q_o.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_o, dst, 1, 0, s, lo); }));
@@ -1669,10 +1689,14 @@ void Model::ensure_batch_buffers() {
     if (gu_tmp) gu_tmpb = dalloc<float>((size_t)MAXB * 2 * I_l);
     if (quantized) {                                    // activation rows of a decode group as Q8_0 blocks (kernels_quant_gemm.hip)
         const size_t kmax = std::max(std::max((size_t)H, (size_t)I_l), at_cols);
-        qx_codes = (signed char*)dalloc<int>((size_t)QGEMM_MAXM * kmax / 4 + 16);
-        qx_scales = dalloc<float>((kmax / 32 + 1) * QGEMM_MAXM);
-        qx_codes2 = (signed char*)dalloc<int>((size_t)QGEMM_MAXM * kmax / 4 + 16);      // second pair: a GEMM that quantises its own output rows
-        qx_scales2 = dalloc<float>((kmax / 32 + 1) * QGEMM_MAXM);                       // cannot overwrite the codes it is reading
+        // (the int8 prompt pass quantises ALL rows of a pass at once: the same buffers, sized for a prefill chunk, scale rows q8_xs apart)
+        size_t rows = QGEMM_MAXM;
+        q8_xs = QGEMM_MAXM;
+        if (q8_prefill_want && q8_prefill_eligible()) { q8_xs = (prefill_chunk_rows() + 255) / 256 * 256; rows = std::max(rows, (size_t)q8_xs); }
+        qx_codes = (signed char*)dalloc<int>(rows * kmax / 4 + 16);
+        qx_scales = dalloc<float>((kmax / 32 + 1) * rows);
+        qx_codes2 = (signed char*)dalloc<int>(rows * kmax / 4 + 16);      // second pair: a GEMM that quantises its own output rows
+        qx_scales2 = dalloc<float>((kmax / 32 + 1) * rows);               // cannot overwrite the codes it is reading
     }
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
@@ -1712,8 +1736,11 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
     }
     // quantised weights in the Q8_0 layout: q_gemm_min or more sequences run their projections as ONE int8-MFMA pass over the codes
     // for up to MAXB rows (kernels_quant_gemm.hip); tensors in other formats of the same model keep the batched GEMV in steps
-    const bool qgemm_ok = quantized && !cfg.hybrid && !rccl && q_gemm_min > 0 && n >= (size_t)q_gemm_min && qx_codes != nullptr;
-    if (qgemm_ok) { ensure_gemm_workspace(); gsz = std::max(gsz, (size_t)MAXB); }
+    // (round 6: also the hybrid family -- in_proj / in_proj_z / out_proj and the gated attention's projections; its bf16 a / b gate rows
+    // take the matrix-core GEMV in steps of 64 rows -- and under tensor parallelism: partial sums into yb, one all-reduce per projection;
+    // TP groups stay at GEMV_MAXB, the size the sharded head's gather is laid out for)
+    const bool qgemm_ok = quantized && q_gemm_min > 0 && n >= (size_t)q_gemm_min && qx_codes != nullptr;
+    if (qgemm_ok) { ensure_gemm_workspace(); gsz = std::max(gsz, rccl ? (size_t)GEMV_MAXB : (size_t)MAXB); }
     for (size_t g0 = 0; g0 < n; g0 += gsz) {
         const int nb = (int)std::min<size_t>(gsz, n - g0);
         CM_HIP(hipStreamSynchronize(s));                             // pinned staging reuse
@@ -1835,6 +1862,13 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         auto qrp = [&](const QWeight& qw, const float* xin, int ldx, const float* next_nw = nullptr) {        // quantised row-parallel projection + residual
             if (!rccl) { qb(PRO_PLAIN, EPI_RESADD, qw, xin, ldx, nullptr, xb, H, next_nw); return; }
             const bool carry = rank == 0 || rccl->fake;
+            if (qgemm_ok && nb >= q_gemm_min && gemm_q8_ok(qw, nb)) {
+                // int8 matrix cores: this rank's partial sums over its K slice into yb (rank 0 carries the residual), one all-reduce
+                if (carry) CM_HIP(hipMemcpyAsync(yb, xb, (size_t)nb * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+                qb(PRO_PLAIN, carry ? EPI_RESADD : EPI_STORE, qw, xin, ldx, nullptr, yb, H);
+                rccl->all_reduce_sum_f32(yb, xb, (size_t)nb * H, s);
+                return;
+            }
             const int cap = gemvqb_max_seqs(qw.fmt, qw.K);
             if (cap == 0) throw CmError(CM_ERR_UNSUPPORTED, "batched decode: K too large for the quantised batched GEMV");
             const int stepq = cap == 8 ? (int)GEMV_MAXB : cap;
@@ -1859,10 +1893,16 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     const int qz = cfg.conv_dim() + cfg.value_dim();
                     qb(PRO_RMSNORM, EPI_STORE, w.q_in_proj, xb, H, w.ln1, qkvb, ldq);
                     if (w.q_in_proj_z.fmt != QFMT_NONE) qb(PRO_RMSNORM, EPI_STORE, w.q_in_proj_z, xb, H, w.ln1, qkvb + w.q_in_proj.N, ldq);
-                    GemvBArgs g{};                                   // the a / b gate rows stay bf16
-                    g.W = w.in_proj_ba; g.x = xb; g.nw = w.ln1; g.y = qkvb + qz; g.res = g.y; g.N = 2 * cfg.NV; g.K = H; g.ldw = H;
-                    g.ldx = H; g.ldy = ldq; g.n_seq = nb; g.eps = cfg.eps;
-                    launch_gemvb(PRO_RMSNORM, EPI_STORE, g, gemvb_grid(g.N, g.K, num_cu), s);
+                    // the a / b gate rows stay bf16: the matrix-core GEMV in steps of <= 64 rows (a 128-row int8 group), the VALU GEMV else
+                    for (int m0 = 0; m0 < nb; m0 += GEMV_MAXB) {
+                        GemvBArgs g{};
+                        g.W = w.in_proj_ba; g.x = xb + (size_t)m0 * H; g.nw = w.ln1; g.y = qkvb + (size_t)m0 * ldq + qz; g.res = g.y;
+                        g.N = 2 * cfg.NV; g.K = H; g.ldw = H; g.ldx = H; g.ldy = ldq; g.n_seq = std::min((int)GEMV_MAXB, nb - m0); g.eps = cfg.eps;
+                        if (use_mfma_gemv && g.n_seq > 8 && gemvm_ok(EPI_STORE, g.n_seq, H)) {
+                            if (gemvm_nkt(H) > 1) CM_HIP(hipMemset2DAsync(g.y, (size_t)ldq * sizeof(float), 0, (size_t)g.N * sizeof(float), (size_t)g.n_seq, s));
+                            launch_gemvm(PRO_RMSNORM, EPI_STORE, g, gemvm_grid(g.N, H, num_cu, g.n_seq), s);
+                        } else launch_gemvb(PRO_RMSNORM, EPI_STORE, g, gemvb_grid(g.N, g.K, num_cu), s);
+                    }
                 } else if (gemm_b) {
                     if (!xn_ready) launch_rmsnorm_rows(xb, w.ln1, pXN_hi, pXN_lo, nb, H, cfg.eps, s);
                     gm(GEPI_STORE, pXN_hi, pXN_lo, w.in_proj, qkvb, ldq, in_proj_pad, H);      // (rows padded to 128 with zero weights)
@@ -2258,9 +2298,9 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
 }
 
 // test hook (q_capture): the Q8_0 activation rows currently in qx_codes / qx_scales, appended to q_cap as floats
-void Model::q_capture_rows(int nb, int K) {
+void Model::q_capture_rows(int nb, int K, int xs) {
     std::vector<signed char> c((size_t)nb * K);
-    std::vector<float> d((size_t)(K / 32) * QGEMM_MAXM);
+    std::vector<float> d((size_t)(K / 32) * xs);
     CM_HIP(hipStreamSynchronize(stream));
     CM_HIP(hipMemcpy(c.data(), qx_codes, c.size(), hipMemcpyDeviceToHost));
     CM_HIP(hipMemcpy(d.data(), qx_scales, d.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -2270,7 +2310,7 @@ void Model::q_capture_rows(int nb, int K) {
     *o++ = (float)K; *o++ = (float)nb;
     for (size_t i = 0; i < c.size(); ++i) *o++ = (float)c[i];
     for (int m = 0; m < nb; ++m)
-        for (int b = 0; b < K / 32; ++b) *o++ = d[(size_t)b * QGEMM_MAXM + m];
+        for (int b = 0; b < K / 32; ++b) *o++ = d[(size_t)b * xs + m];
 }
 
 void Model::debug_qgemv(int layer, const std::string& which, const float* xh, size_t k, float* yh, size_t n) {

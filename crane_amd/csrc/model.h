@@ -82,6 +82,7 @@ struct LayerW {
     QWeight q_o, q_gate_up, q_gate, q_up, q_down;
     QWeight q_in_proj, q_in_proj_z, q_out_proj;   // GDN: in_proj rows [qkv | z] quantised; the a / b gate rows stay bf16 (projection.rs:78-83)
     uint16_t* in_proj_ba = nullptr;  // [2 NV, H] bf16: b rows then a rows
+    uint16_t* ba_pad = nullptr;      // int8 prompt pass: the same rows zero-padded to one 128-row bf16 GEMM tile
     bool split_gate_up = false;
 };
 
@@ -257,7 +258,7 @@ struct Model {
     // so that the parity tests can check the quantiser's roundings and feed the oracle the codes the kernel multiplied
     bool q_capture = false;
     std::vector<float> q_cap;
-    void q_capture_rows(int nb, int K);
+    void q_capture_rows(int nb, int K, int xs = QGEMM_MAXM);
     int batch_gemm_min = 9;                    // CM_BATCH_GEMM_MIN: batched decode of this many sequences or more runs its projections as MFMA GEMMs (0 = never)
     StepState* stb = nullptr;          // device [MAXB]
     StepState* h_stb = nullptr;        // pinned [MAXB]
@@ -311,6 +312,9 @@ struct Model {
     // CM_QUANT_PREFILL_INT8=0 / cm_debug_set("prefill_q8", 0) before the first prompt: the dequantised-to-bf16 GEMMs)
     bool q8_prefill_want = true, q8_prefill = false;
     float* pATf = nullptr;             // [chunk][Hq_l D] f32 attention rows of the pass (the o_proj quantiser's input)
+    float* pHf = nullptr;              // [chunk][I_l] f32 silu(gate) * up rows of the pass
+    int q8_xs = QGEMM_MAXM;            // floats between the scale rows of the code buffers in a prompt pass of more than 128 rows
+    int prefill_chunk_rows() const;
     bool q8_prefill_eligible() const;
     uint16_t* wq_scratch = nullptr;    // [2][max N*K] bf16 hi | lo planes: one dequantised matrix at a time for the prefill GEMMs
     size_t wq_scratch_elems = 0;

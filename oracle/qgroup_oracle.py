@@ -206,12 +206,13 @@ class Q8GroupOracle:
         return self._mm(q8, d8, (self.head,))
 
 
-    def prefill(self, seq_ids, prompts, captures, tie_tol: float = 2e-3, panel: int = 128, head_captured: bool = False,
+    def prefill(self, seq_ids, prompts, captures, tie_tol: float = 2e-3, panel: int = None, head_captured: bool = False,
                 attn_tol: float = None):
         """One prompt pass over whole prompts of the (fresh or continued) sequences seq_ids, rows concatenated in order -- the device's
-        Model::prefill_layers on the int8 matrix cores: every projection runs in panels of <= `panel` rows of the PASS (a panel may
-        span two sequences), one capture record per projection input and panel, in the device's order: per layer all panels of the
-        input norm (qkv), then per panel the attention rows (o_proj), the post-attention norm (gate|up) and silu(gate) * up (down_proj).
+        Model::prefill_layers on the int8 matrix cores: every projection quantises ALL rows of the pass at once (panel = None; the
+        kernel walks them in m-panels of 256 rows, which the arithmetic does not see), one capture record per projection input, in the
+        device's order: per layer the input norm (qkv), the attention rows (o_proj), the post-attention norm (gate|up) and
+        silu(gate) * up (down_proj).  (`panel` = n: records per n rows instead -- the order of a device that launches per row panel.)
         Returns (hidden [n_seq, H]: the residual stream of every sequence's last position, logits [n_seq, V]).  The head quantises its
         rows from the capture when head_captured (the batched int8 head), else with the oracle's own rounding (single-row GEMV head)."""
         cap = iter(captures) if captures is not None else None
@@ -224,6 +225,7 @@ class Q8GroupOracle:
             rows.extend(p)
         S = len(rows)
         x = self.embed[np.asarray(rows, np.int64)].astype(F32)
+        panel = panel or S
         panels = [(r0, min(panel, S - r0)) for r0 in range(0, S, panel)]
         for li, lw in enumerate(self.layers):
             xn = rms_norm(x, lw["ln1"], self.eps)

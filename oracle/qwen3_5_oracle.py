@@ -164,6 +164,11 @@ class Qwen35Oracle:
         self.allreduce = lambda t: t      # tensor-parallel tests plug a gloo all-reduce in here (row-parallel partial sums)
         self.clear_kv_cache()
 
+    def _lin(self, x, name, mixer=False):
+        """One linear of the model: x @ W^T.  (oracle/qhybrid_oracle.py overrides it with ggml's quantised-activation arithmetic;
+        `mixer`: x is the output of the attention / Gated-Delta-Net token mixer -- only that override cares.)"""
+        return x @ self.w[name].T
+
     def clear_kv_cache(self):
         c = self.cfg
         self.kc = [None] * c.num_hidden_layers
@@ -177,10 +182,10 @@ class Qwen35Oracle:
         c, w = self.cfg, self.w
         p = f"{self.p}layers.{li}.self_attn."
         S, Hq, Hkv, D = x.shape[0], c.num_attention_heads, c.num_key_value_heads, c.head_dim
-        qo = (x @ w[p + "q_proj.weight"].T).reshape(S, Hq, 2 * D)            # per-head [q | gate] (:428-455)
+        qo = self._lin(x, p + "q_proj.weight").reshape(S, Hq, 2 * D)            # per-head [q | gate] (:428-455)
         q, gate = qo[..., :D], qo[..., D:].reshape(S, Hq * D)
-        k = (x @ w[p + "k_proj.weight"].T).reshape(S, Hkv, D)
-        v = (x @ w[p + "v_proj.weight"].T).reshape(S, Hkv, D)
+        k = self._lin(x, p + "k_proj.weight").reshape(S, Hkv, D)
+        v = self._lin(x, p + "v_proj.weight").reshape(S, Hkv, D)
         q = rms_norm_1p(q, w[p + "q_norm.weight"], c.rms_norm_eps)          # (:464-465)
         k = rms_norm_1p(k, w[p + "k_norm.weight"], c.rms_norm_eps)
         cos, sin = self.cos[start:start + S], self.sin[start:start + S]
@@ -211,7 +216,7 @@ class Qwen35Oracle:
         y = np.einsum("grsl,gld->grsd", softmax_last(sc), V, optimize=True).astype(F32)
         y = y.reshape(Hq, S, D).transpose(1, 0, 2).reshape(S, Hq * D)
         y = y * sigmoid(gate)                                              # (:516-522)
-        return (y @ w[p + "o_proj.weight"].T).astype(F32)
+        return self._lin(y.astype(F32), p + "o_proj.weight", mixer=True).astype(F32)
 
     # ---- GatedDeltaNet::forward (ops/gdn/layer.rs:122-182) ----
     def _gdn(self, li, x):
@@ -219,8 +224,8 @@ class Qwen35Oracle:
         p = f"{self.p}layers.{li}.linear_attn."
         S = x.shape[0]
         NK, NV, K, V = c.linear_num_key_heads, c.linear_num_value_heads, c.linear_key_head_dim, c.linear_value_head_dim
-        mixed = (x @ w[p + "in_proj_qkv.weight"].T).astype(F32)             # [S, conv_dim]
-        z = (x @ w[p + "in_proj_z.weight"].T).astype(F32)                   # [S, VD]
+        mixed = self._lin(x, p + "in_proj_qkv.weight").astype(F32)             # [S, conv_dim]
+        z = self._lin(x, p + "in_proj_z.weight").astype(F32)                   # [S, VD]
         b = (x @ w[p + "in_proj_b.weight"].T).astype(F32)                   # [S, NV]
         a = (x @ w[p + "in_proj_a.weight"].T).astype(F32)
         # causal depthwise conv1d: output t reads the window ending at t (conv.rs:47-57)
@@ -244,7 +249,7 @@ class Qwen35Oracle:
         g = (-np.exp(w[p + "A_log"]) * softplus(a + w[p + "dt_bias"])).astype(F32)   # backend.rs:197-211
         y = gated_delta_rule(q, k, v, g, beta, self.state[li])             # [S, NV, V]
         yn = rms_norm_plain(y.reshape(-1, V), w[p + "norm.weight"], c.rms_norm_eps) * silu(z.reshape(-1, V))
-        return (yn.reshape(S, NV * V) @ w[p + "out_proj.weight"].T).astype(F32)
+        return self._lin(yn.reshape(S, NV * V).astype(F32), p + "out_proj.weight", mixer=True).astype(F32)
 
     def mrope_cos_sin(self, pos3: np.ndarray, mrope_section=(11, 11, 10)):
         """cos_sin_with_position_ids (modeling.rs:156-245): INDEX-interleaved MRoPE -- column i of the
@@ -272,11 +277,14 @@ class Qwen35Oracle:
             xn = rms_norm_1p(h, w[p + "input_layernorm.weight"], c.rms_norm_eps)
             h = h + self.allreduce(self._full_attn(li, xn, start_pos) if c.layer_is_full(li) else self._gdn(li, xn))
             xn = rms_norm_1p(h, w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
-            gate = xn @ w[p + "mlp.gate_proj.weight"].T
-            up = xn @ w[p + "mlp.up_proj.weight"].T
-            h = h + self.allreduce(((silu(gate) * up) @ w[p + "mlp.down_proj.weight"].T).astype(F32))
+            gate = self._lin(xn, p + "mlp.gate_proj.weight")
+            up = self._lin(xn, p + "mlp.up_proj.weight")
+            h = h + self.allreduce(self._lin((silu(gate) * up).astype(F32), p + "mlp.down_proj.weight").astype(F32))
         last = rms_norm_1p(h[-1:], self.norm, c.rms_norm_eps)
-        return (last @ self.lm_head.T).astype(F32)[0]
+        return self._head(last).astype(F32)[0]
+
+    def _head(self, last):
+        return last @ self.lm_head.T
 
     forward_step = forward
 

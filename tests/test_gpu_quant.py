@@ -461,13 +461,13 @@ def _captures(m):
 
 @pytest.mark.parametrize("kv", ["f32", "f16"])
 def test_prompt_pass_on_the_int8_matrix_cores_and_the_attention_quantiser_against_the_oracle(kv):
-    """Prompts over Q8_0-layout weights (default): every projection of the pass on the int8 matrix cores in panels of <= 128 rows
-    (Model::prefill_layers, q8_prefill) -- the decode step's and candle's CPU QMatMul arithmetic (ops/linear.rs:18-51), no dequantised
+    """Prompts over Q8_0-layout weights (default): every projection of the pass on the int8 matrix cores, all rows in one launch
+    (m-panels of 256 rows per workgroup above 128 rows; Model::prefill_layers, q8_prefill) -- the decode step's and candle's CPU QMatMul arithmetic (ops/linear.rs:18-51), no dequantised
     copy -- at the 8B widths against the teacher-forced oracle (oracle/qgroup_oracle.py prefill(): the device's captured codes are
     checked against the oracle's own rounding, ties only, then used), bound 2e-5 like the decode groups:
-      (a) ONE prompt of 200 tokens (a full and a partial panel): the residual stream of the last position (cm_debug_read "hidden");
+      (a) ONE prompt of 200 tokens (one partly filled 256-row panel): the residual stream of the last position (cm_debug_read "hidden");
           its logits come from the single-row head, whose activation codes are not captured: one possible tie flip => 5e-3;
-      (b) 64 prompts of 70 .. 74 tokens through cm_prefill_batch (three passes of <= 2048 rows: panels span sequences, the segmented
+      (b) 64 prompts of 70 .. 74 tokens through cm_prefill_batch (three passes of ~1700 rows = 7 m-panels: panels span sequences, the segmented
           RoPE / KV-append / causal-attention launches, the batched int8 head): every row of logits;
       (c) one decode round of those 64 sequences (contexts >= 64): on f16 pages (the default) the group takes the single-split
           matrix-core attention kernel, which adds the K-split slices of the int8 qkv GEMM in its prologue and writes the Q8_0 blocks of
@@ -486,7 +486,7 @@ def test_prompt_pass_on_the_int8_matrix_cores_and_the_attention_quantiser_agains
         lg, _ = m.seq_forward(s0, p0, 0)
         hid = m.debug_read("hidden", H)
         caps = _captures(m)
-        assert len(caps) == L * (2 + 3 * 2), len(caps)             # per layer: 2 panels of the input norm + 2 x (attention, ln2, silu * up)
+        assert len(caps) == 4 * L, len(caps)                       # per layer: input norm, attention rows, post-attention norm, silu * up -- all 200 rows each
         rh, rl = orc.prefill([s0], [p0], caps, tie_tol=2e-3, attn_tol=ATTN_TOL)
         assert rel(hid, rh[0]) < 2e-5, rel(hid, rh[0])
         assert rel(lg, rl[0]) < 5e-3, rel(lg, rl[0])
@@ -516,6 +516,68 @@ def test_prompt_pass_on_the_int8_matrix_cores_and_the_attention_quantiser_agains
         st = orc.stats
         assert st["flipped"] < 1e-3 * st["codes"] and st["scale_steps"] < 1e-3 * st["scales"], st
         print(f"int8 prompt pass / decode round, kv {kv}: worst logit rel {worst:.2e}; {st}")
+    finally:
+        m.close()
+
+
+def test_hybrid_family_prompt_pass_and_decode_groups_on_the_int8_matrix_cores_against_the_oracle():
+    """Qwen3.5 over ISQ Q8_0 weights at the 0.8B widths (4 layers: 3 Gated-Delta-Net + 1 gated attention; hidden 1024, 16 value heads
+    of 128, head_dim 256): round 6 moved the family's quantised projections onto the int8 matrix cores -- in_proj_qkv / in_proj_z /
+    out_proj, the gated attention's q|gate / k / v / o, the MLP; the bf16 a / b gate rows stay a bf16 GEMM (prompt) / matrix-core GEMV
+    (decode group), ops/gdn/projection.rs:78-83.
+      (a) a 200-token prompt (one launch per projection over all rows; chunk-parallel delta rule; D = 256 causal attention),
+      (b) a decode round of 24 sequences with contexts of 40 .. 63 tokens (prompts through cm_prefill_batch),
+    both teacher-forced against oracle/qhybrid_oracle.py (ggml quantised-activation semantics, ops/linear.rs:18-51, around
+    oracle/qwen3_5_oracle.py): captured codes checked against the oracle's own rounding -- ties only; the token mixers' rows within
+    1e-3 of the row -- then used; logits 2e-5 of the logit range."""
+    from crane_amd.backend import Model
+    from oracle.qgroup_oracle import parse_captures
+    from oracle.qhybrid_oracle import Q8HybridOracle, RowCaptures, quantise_linears
+    cfg = dict(configs.get_config("qwen3.5-0.8b"))
+    cfg.update(num_hidden_layers=4, vocab_size=4096, max_position_embeddings=4096)
+    if "layer_types" in cfg: cfg["layer_types"] = cfg["layer_types"][:4]
+    V = cfg["vocab_size"]
+    w = synth.synth_weights_f32(cfg, seed=0)
+    qm = quantise_linears(w, "q8_0")
+    stats = dict(codes=0, flipped=0, scales=0, scale_steps=0, worst_tie=0.0)
+    nb = 24
+    m = Model.synthetic(cfg, seed=0, max_seq_len=256, isq="q8_0", max_seqs=nb + 2, kv_dtype="f32")
+    try:
+        m.debug_set("q_capture", 1)
+        s0 = m.seq_alloc()
+        p0 = [(11 * i + 5) % V for i in range(200)]
+        lg, _ = m.seq_forward(s0, p0, 0)
+        caps = _captures(m)
+        assert len(caps) == 4 * 4, len(caps)                       # per layer: input norm, mixer rows, post-attention norm, silu * up
+        o = Q8HybridOracle(cfg, w, qm, stats=stats)
+        ref = o.forward_tf(p0, 0, caps)
+        worst = rel(lg, ref)
+        assert worst < 2e-5, worst
+        seqs = [m.seq_alloc() for _ in range(nb)]
+        prompts = [[(7 * i + 3 + 11 * b) % V for i in range(40 + b)] for b in range(nb)]
+        got, gg = m.prefill_batch(seqs, prompts)
+        caps = _captures(m)
+        oracles = []
+        # (a multi-sequence pass quantises the stacked rows: records of sum(len) rows -- sequence b owns rows row0 .. row0 + len)
+        row0 = 0
+        for b in range(nb):
+            ob = Q8HybridOracle(cfg, w, qm, stats=stats)
+            n = len(prompts[b])
+            sl = [(K, c[row0:row0 + n], d[row0:row0 + n]) for K, c, d in caps]
+            r = ob.forward_tf(prompts[b], 0, sl)
+            e = rel(got[b], r); worst = max(worst, e)
+            assert e < 2e-5, ("prefill_batch", b, e)
+            oracles.append(ob); row0 += n
+        toks = [int(t) for t in gg]
+        got, gg = m.step_batch_decode(seqs, toks)
+        caps = _captures(m)
+        assert len(caps) == 4 * 4, len(caps)                       # (tied bf16 head: no record)
+        for b in range(nb):
+            r = oracles[b].forward_tf([toks[b]], len(prompts[b]), RowCaptures(caps, b))
+            e = rel(got[b, 0], r); worst = max(worst, e)
+            assert e < 2e-5, ("decode", b, e)
+        assert stats["flipped"] < 1e-3 * stats["codes"], stats
+        print(f"hybrid int8 prompt / group: worst logit rel {worst:.2e}; {stats}")
     finally:
         m.close()
 

@@ -245,6 +245,34 @@ def test_gguf_checkpoint_under_tensor_parallelism(tmp_path):
         g.close(); s.close()
 
 
+def test_int8_matrix_core_projections_under_tensor_parallelism():
+    """ISQ Q8_0 at the 8B widths (2 layers) on a TP = 2 group (round 6): the prompt pass and the decode groups of 8 or more sequences run
+    every rank's projections on the int8 matrix cores -- row-parallel o_proj / down_proj as partial sums over the rank's K slice (whole
+    32-weight blocks), ONE all-reduce per projection for all rows, the norm + quantiser of the next projection after it.  Against the
+    TP = 1 handle: same codes, sums across ranks in another order => the documented bound of two integer-dot implementations (an
+    activation code on a rounding boundary flips with the last bit of its input, DESIGN 3.9: 3e-2 of the logit range), and most
+    greedy ids equal."""
+    cfg = configs.get_config("qwen3-8b-2l")
+    V = cfg["vocab_size"]
+    g, s = _group(cfg, 2, isq="q8_0", max_seqs=18), _single(cfg, isq="q8_0", max_seqs=18)
+    try:
+        ids = [(11 * i + 5) % V for i in range(200)]
+        a, b = g.forward_step(ids, 0)[0, 0], s.forward_step(ids, 0)[0, 0]
+        assert rel(a, b) < 3e-2, rel(a, b)
+        outs = []
+        for m in (g, s):
+            sq = [m.seq_alloc() for _ in range(16)]
+            for i, q in enumerate(sq):
+                m.seq_forward(q, [(7 * k + 3 + 11 * i) % V for k in range(20 + i)], 0, want_logits=False)
+            lg, nxt = m.step_batch_decode(sq, [(5 + 3 * i) % V for i in range(16)])       # (the same tokens on both handles)
+            outs.append((lg[:, 0], nxt))
+        for i in range(16):
+            assert rel(outs[0][0][i], outs[1][0][i]) < 3e-2, (i, rel(outs[0][0][i], outs[1][0][i]))
+        assert int((outs[0][1] == outs[1][1]).sum()) >= 12
+    finally:
+        g.close(); s.close()
+
+
 @pytest.mark.parametrize("name", ["tiny-qwen3-vl", "tiny-qwen3.5-vl"])
 def test_vision_language_group(name):
     """Image + text through a TP = 2 group: the tower is replicated (every rank encodes), the image rows are spliced into every

@@ -68,6 +68,14 @@ def test_plan_respects_the_workspace_and_refuses_what_it_cannot_hold():
     p = plan(128, 256, 256, SILUMUL, 16 * 1024 * 1024)
     assert p["ok"] == 1 and p["ks"] <= p["groups"]
     # rows, shapes and epilogues outside the kernel
-    assert plan(0, n, k, STORE, 1 << 24)["ok"] == 0 and plan(129, n, k, STORE, 1 << 24)["ok"] == 0
+    assert plan(0, n, k, STORE, 1 << 24)["ok"] == 0 and plan((1 << 16) + 1, n, k, STORE, 1 << 34)["ok"] == 0
+    # more than 128 rows (a prompt pass, round 6): 8 waves x 4 m-tiles = 256 rows per workgroup, the grid walks ceil(m / 256) m-panels
+    p = plan(129, n, k, STORE, 1 << 24)
+    assert p["ok"] == 1 and p["waves"] == 8 and p["rows"] == 256 and p["grid"] == (n // 128) * 1 * p["ks"]
+    p = plan(1000, n, k, RESADD, 1 << 24)
+    assert p["ok"] == 1 and p["rows"] == 256 and p["grid"] == (n // 128) * 4 * p["ks"] and p["ks"] * 1000 * n <= 1 << 24
+    p = plan(2048, 24576, 4096, SILUMUL, 1 << 24)               # the partial slices would not fit: written unsplit, SiLU in the GEMM's epilogue
+    assert p["ok"] == 1 and p["direct"] == 1 and p["ks"] == 1 and p["grid"] == 192 * 8
+    assert plan(2048, 24576, 4096, RESADD, 1 << 24)["ok"] == 0  # (a residual projection of that size has nowhere to put its sums)
     assert plan(m, n + 64, k, STORE, 1 << 24)["ok"] == 0 and plan(m, n, k + 32, STORE, 1 << 24)["ok"] == 0
     assert plan(m, n, k, 3, 1 << 24)["ok"] == 0
