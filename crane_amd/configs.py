@@ -67,6 +67,13 @@ CONFIGS.update({
                          num_hidden_layers=24, num_attention_heads=8, num_key_value_heads=2, head_dim=256,
                          linear_key_head_dim=128, linear_value_head_dim=128, linear_num_key_heads=16,
                          linear_num_value_heads=16, tie_word_embeddings=True, max_position_embeddings=262144),
+    # Qwen3.5-2B: the model of the reference's only published numbers for this path (README.md:86-87,496-503: Qwen3.5-2B-Q8_0 on an
+    # RX 7800 XT).  The reference does not spell its geometry out; this is the HF checkpoint's config as far as it is known here
+    # (hidden 2048, 24 layers, 8 q / 2 kv heads of 256, 16 + 16 linear heads of 128): 1.88 B parameters
+    "qwen3.5-2b": dict(_QWEN35_COMMON, vocab_size=248320, hidden_size=2048, intermediate_size=6144,
+                       num_hidden_layers=24, num_attention_heads=8, num_key_value_heads=2, head_dim=256,
+                       linear_key_head_dim=128, linear_value_head_dim=128, linear_num_key_heads=16,
+                       linear_num_value_heads=16, tie_word_embeddings=True, max_position_embeddings=262144),
     # Qwen3.8-27B: fully pinned by the reference (qwen3_5/config.rs:298-324,332-364)
     "qwen3.8-27b": dict(_QWEN35_COMMON, vocab_size=248320, hidden_size=5120, intermediate_size=17408,
                         num_hidden_layers=64, num_attention_heads=24, num_key_value_heads=4, head_dim=256,

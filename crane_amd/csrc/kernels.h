@@ -131,7 +131,9 @@ struct GemmArgs {
     float* ws;              // split-K workspace (or null: never split) of ws_floats f32; launch_gemm decides the split
     size_t ws_floats;
     int ksplit;             // set by launch_gemm
-    int wide256 = 1;        // 0: never the 256-row LDS-DMA kernel (kernels_gemm256.hip) -- A/B switch, cm_debug_set("gemm256")
+    int dbg = 0;            // kernels_gemmw4.hip timing experiments (CM_GEMMW4_DBG); 0 in production
+    int wide256 = 1;        // 0: never the LDS-DMA kernels (kernels_gemm256.hip / kernels_gemmw4.hip), 1: automatic, 2: always kernels_gemmw4.hip,
+                            // 3: kernels_gemm256.hip only -- A/B switch, cm_debug_set("gemm256")
     // GEPI_RESADD with ldc == N only: ALSO write RMSNorm(C row) * norm_w as bf16 hi + lo planes [M][N] -- the A operand of the NEXT
     // GEMM (rmsnorm_rows_kernel's arithmetic).  Fused into the split-K reduction launch when the GEMM splits K (a large decode
     // group: one launch less per projection), a separate rmsnorm_rows launch otherwise -- launch_gemm does either.
@@ -209,6 +211,8 @@ void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
 bool launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 int gemm256_rows(bool split, int M);       // rows of that kernel's tile for an M-row launch (parity mode: 64 up to 64 rows, else 128; plain bf16: 256)
 bool launch_gemm256(const GemmArgs& a, int epi, int bn, hipStream_t s);   // kernels_gemm256.hip; a.ksplit set by the caller (launch_gemm)
+int gemmw4_rows(bool split);               // rows of the one-wave-per-SIMD kernel's tile (kernels_gemmw4.hip): 128 with hi + lo activations, 256 plain
+bool launch_gemmw4(const GemmArgs& a, int epi, int bn, hipStream_t s);    // same contract as launch_gemm256
 void launch_attn_prefill(const AttnPreArgs& a, int D, int kvt, hipStream_t s);   // kvt: KV_BF16 | KV_F16 | KV_F32 (what the kernel reads)
 
 // ---- vision tower (kernels_vision.hip) ----

@@ -1251,7 +1251,12 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     static const int min_m2 = getenv("CM_GEMM256_MIN_M") ? atoi(getenv("CM_GEMM256_MIN_M")) : 33;      // hi + lo: 128-row tiles, 64-row tiles up to 64 rows
     static const int min_blocks = getenv("CM_GEMM256_MIN_BLOCKS") ? atoi(getenv("CM_GEMM256_MIN_BLOCKS")) : 128;
     if (!env || !a.wide256 || a.M < (a.A_lo ? min_m2 : 512) || a.K % 64 != 0) return false;
-    const int bm = gemm256_rows(a.A_lo != nullptr, a.M);
+    // round 6: the one-wave-per-SIMD kernel (kernels_gemmw4.hip) -- built, bit-compatible, measured 0 .. 4 % SLOWER than the ping-pong kernel
+    // on every prompt shape, so it is opt-in: CM_GEMMW4 = 1 from `w4_min` rows on, GemmArgs::wide256 = 2 (cm_debug_set "gemm256" = 2) always
+    static const int w4_env = getenv("CM_GEMMW4") ? atoi(getenv("CM_GEMMW4")) : 0;
+    static const int w4_min = getenv("CM_GEMMW4_MIN_M") ? atoi(getenv("CM_GEMMW4_MIN_M")) : 65;
+    const bool w4 = a.wide256 == 2 || (a.wide256 == 1 && w4_env != 0 && a.M >= w4_min);
+    const int bm = w4 ? gemmw4_rows(a.A_lo != nullptr) : gemm256_rows(a.A_lo != nullptr, a.M);
     const int tiles_m = (a.M + bm - 1) / bm, nk = a.K / 64;
     const double terms = a.A_lo ? 2.0 : 1.0;
     double best = 1e30;
@@ -1278,7 +1283,8 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     if (bm == 64 && tiles_m * (a.N / best_bn) < 24 && !force_bn) return false;
     if (blocks < (a.M >= 512 ? 192 : min_blocks) && !force_bn) return false;
     a.ksplit = best_ks;
-    if (!launch_gemm256(a, epi, best_bn, s)) return false;
+    if (w4) { if (!launch_gemmw4(a, epi, best_bn, s)) return false; }
+    else if (!launch_gemm256(a, epi, best_bn, s)) return false;
     if (best_ks > 1) {
         const int eb = (int)std::min<size_t>(((size_t)a.M * (a.N / 4) + 255) / 256, 2048);
         if (epi == GEPI_STORE) launch_splitk_epilogue<GEPI_STORE>(a, eb, s);

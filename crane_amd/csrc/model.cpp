@@ -1263,7 +1263,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         if (!xn_ready && !(q8p && w.full)) launch_rmsnorm_rows(pX, w.ln1, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
         xn_ready = false;
         GemmArgs g{};
-        g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256;
         if (!w.full) {
             // ---- Gated Delta Net layer: in_proj GEMM, sequential delta-rule scan, out_proj GEMM ----
             g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.in_proj; g.C = pQKV; g.ldc = in_proj_pad;
@@ -1314,7 +1314,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             }
             if (q8p) { q8_tail(w, w.q_out_proj, pGY, cfg.value_dim(), li); continue; }
             launch_split_rows(pGY, pAT_hi, sp2 ? pAT_lo : nullptr, (size_t)S * cfg.value_dim(), s);
-            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+            g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256;
             g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.out_proj; g.M = S; g.N = H; g.K = cfg.value_dim(); g.ldc = H;
             if (quantized) set_w(g, deq_w(w, 1, (size_t)w.q_out_proj.N * w.q_out_proj.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_out_proj, dst, 1, 0, s, lo); }));
             if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
@@ -1396,7 +1396,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         launch_attn_prefill(at, D, (kv_f32 || kvq) ? KV_F32 : kv_mode, s);
         }
         if (q8p) { q8_tail(w, w.q_o, pATf, Hq_l * D, li); continue; }
-        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256;
         g.A_hi = pAT_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 2)) ? pAT_lo : nullptr; g.W = w.o; g.M = S; g.N = H; g.K = Hq_l * D; g.ldc = H;
         if (quantized) set_w(g, deq_w(w, 1, (size_t)w.q_o.N * w.q_o.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_o, dst, 1, 0, s, lo); }));
         if (!rccl) { g.C = pX; next_norm(g, w.ln2); launch_gemm(g, GEPI_RESADD, s); }
@@ -1407,7 +1407,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         }
         }   // full-attention layer
         if (rccl) launch_rmsnorm_rows(pX, w.ln2, pXN_hi, sp2 ? pXN_lo : nullptr, S, H, cfg.eps, s);
-        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256;
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 4)) ? pXN_lo : nullptr; g.W = w.gate_up; g.M = S; g.N = 2 * I_l; g.K = H;
         if (quantized) {
             set_w(g, deq_w(w, 2, (size_t)2 * I_l * H, [&](uint16_t* dst, uint16_t* lo) {
@@ -1418,7 +1418,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         }
         g.H_hi = pHH_hi; g.H_lo = sp2 ? pHH_lo : nullptr;
         launch_gemm(g, GEPI_SILUMUL, s);
-        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+        g = GemmArgs{}; g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256;
         g.A_hi = pHH_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 8)) ? pHH_lo : nullptr; g.W = w.down; g.M = S; g.N = H; g.K = I_l; g.ldc = H;
         if (quantized) set_w(g, deq_w(w, 3, (size_t)w.q_down.N * w.q_down.K, [&](uint16_t* dst, uint16_t* lo) { launch_dequant_bf16(w.q_down, dst, 1, 0, s, lo); }));
         if (!rccl) {
@@ -1753,7 +1753,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         // written by the GEMM's split-K reduction launch (GemmArgs::norm_w) instead of a rmsnorm_rows launch of its own
         auto gm = [&](int epi, const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* W, float* C, int ldc, int N, int K, const float* next_norm = nullptr) {
             GemmArgs g{};
-            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0;
+            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256;
             g.A_hi = A_hi; g.A_lo = A_lo; g.W = W; g.C = C; g.ldc = ldc; g.M = nb; g.N = N; g.K = K;
             g.H_hi = pHH_hi; g.H_lo = pHH_lo;
             if (next_norm) { g.norm_w = next_norm; g.norm_hi = pXN_hi; g.norm_lo = pXN_lo; g.norm_eps = cfg.eps; }
@@ -2211,7 +2211,7 @@ void Model::bench_kernel(const std::string& which, size_t iters, float* ms, uint
             const LayerW& w = layers[li];
             const bool sp2 = prefill_split2;
             GemmArgs g{};
-            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256 ? 1 : 0; g.M = pg_M;
+            g.ws = pWS; g.ws_floats = gemm_ws_floats; g.wide256 = gemm256; g.M = pg_M;
             int epi = GEPI_STORE;
             if (pg == "qkv") { g.A_hi = pXN_hi; g.A_lo = sp2 ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.N = (Hq_l + 2 * Hkv_l) * D; g.K = H; g.ldc = g.N; }
             else if (pg == "o") { g.A_hi = pAT_hi; g.A_lo = sp2 ? pAT_lo : nullptr; g.W = w.o; g.C = pX; g.N = H; g.K = Hq_l * D; g.ldc = H; epi = GEPI_RESADD; }

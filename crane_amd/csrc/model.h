@@ -228,7 +228,7 @@ struct Model {
     // prefill scratch (allocated on first use; sized for one chunk)
     int chunk = 2048, chunk_pad = 2048;
     bool prefill_ok = false, prefill_split2 = true;
-    bool gemm256 = true;       // prompt-pass GEMMs of >= 512 rows may use the 256-row LDS-DMA kernel (cm_debug_set("gemm256"))
+    int gemm256 = 1;           // prompt-pass / decode-group GEMMs: 0 = never an LDS-DMA kernel, 1 = automatic, 2 = always kernels_gemmw4.hip, 3 = kernels_gemm256.hip only (cm_debug_set("gemm256"))
     float* pX = nullptr;        // [chunk, H] f32 residual stream
     float* pWS = nullptr;       // split-K workspace of the prefill GEMMs: at most 1024 partial tiles of 128 x 128 f32
     static constexpr size_t gemm_ws_floats = (size_t)1024 * 128 * 128;
