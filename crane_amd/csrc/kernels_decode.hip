@@ -288,6 +288,9 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
     for (int sl = 0; sl < slabs; ++sl)            // batched step under TP: one [n_seq][n] slab per rank (vocabulary shard)
         for (int i = threadIdx.x; i < n; i += 256) {
             float v = pmax[sl * slab_stride + i]; int ix = pidx[sl * slab_stride + i];
+            // (a partial of a wave that produced no row, or saw only NaN / -inf logits, carries no candidate: its index is a sentinel
+            // -- plus a shard's base, possibly wrapped negative -- and must not win a tie at -inf)
+            if (!(v > -INFINITY) || ix < 0) continue;
             if (v > b || (v == b && ix < bi)) { b = v; bi = ix; }
         }
     sm[threadIdx.x] = b; si[threadIdx.x] = bi;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        uint32_t t = (uint32_t)si[0];
+        uint32_t t = si[0] == 0x7FFFFFFF ? 0u : (uint32_t)si[0];      // no finite logit anywhere: token 0 instead of an out-of-range id
         st->next = t;
         if (advance) {
             ring[st->pad & ring_mask] = t;

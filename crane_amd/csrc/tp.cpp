@@ -43,8 +43,9 @@ void Rccl::load() {
 }
 
 void Rccl::abort_comm() {
-    void* c = comm;
-    if (c && p_comm_abort) { comm = nullptr; (void)p_comm_abort(c); }
+    if (!p_comm_abort) return;
+    void* c = comm.exchange(nullptr);           // exactly one caller gets the communicator (two ranks failing at once both call this on every peer)
+    if (c) (void)p_comm_abort(c);
 }
 
 #define CM_NCCL(expr)                                                                           \
@@ -70,7 +71,7 @@ void* take_parked(int dev, size_t bytes) {
 }  // namespace
 
 Rccl::~Rccl() {
-    if (comm && p_comm_destroy) (void)p_comm_destroy(comm);
+    if (void* c = comm.exchange(nullptr)) { if (p_comm_destroy) (void)p_comm_destroy(c); }
     // the library stays mapped for the life of the process
     if (peer) {
         if (peer->inbox[rank]) {
@@ -189,7 +190,9 @@ void Rccl::init(int n, int r, const void* unique_id128, hipStream_t, bool local_
     nranks = n; rank = r;
     UniqueId id;
     memcpy(&id, unique_id128, sizeof id);
-    CM_NCCL(p_comm_init_rank(&comm, n, id, r));
+    void* c = nullptr;
+    CM_NCCL(p_comm_init_rank(&c, n, id, r));
+    comm.store(c);
 }
 
 static void peer_run(Rccl& r, int mode, const uint32_t* send, uint32_t* recv, size_t count, hipStream_t s) {
@@ -210,7 +213,9 @@ void Rccl::all_reduce_sum_f32(const float* send, float* recv, size_t count, hipS
         if (send != recv) (void)hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, s);
         return;
     }
-    CM_NCCL(p_all_reduce(send, recv, count, kNcclFloat32, kNcclSum, comm, s));
+    void* c = comm.load();
+    if (!c) throw CmError(CM_ERR_DEVICE, "RCCL communicator aborted (a peer rank failed)");
+    CM_NCCL(p_all_reduce(send, recv, count, kNcclFloat32, kNcclSum, c, s));
 }
 
 void Rccl::all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s) {
@@ -220,7 +225,9 @@ void Rccl::all_gather(const void* send, void* recv, size_t bytes_per_rank, hipSt
         return;
     }
     if (fake) return;
-    CM_NCCL(p_all_gather(send, recv, bytes_per_rank, kNcclInt8, comm, s));
+    void* c = comm.load();
+    if (!c) throw CmError(CM_ERR_DEVICE, "RCCL communicator aborted (a peer rank failed)");
+    CM_NCCL(p_all_gather(send, recv, bytes_per_rank, kNcclInt8, c, s));
 }
 
 }  // namespace cm

@@ -13,6 +13,7 @@
 // down_proj (row-parallel matmuls), one all-gather of arg-max partials / logits after the
 // vocab-sharded lm_head.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -50,7 +51,7 @@ struct PeerShared {
 
 struct Rccl {
     void* lib = nullptr;
-    void* comm = nullptr;
+    std::atomic<void*> comm{nullptr};       // taken with exchange(nullptr) by whoever destroys / aborts it: a failing peer's thread may race the owner (tp_group.cpp)
     int nranks = 1, rank = 0;
     bool fake = false;     // cm_opts.debug_flags & CM_DEBUG_TP_LOCAL: no communicator; all-reduce = local copy, all-gather = no-op, so one
                            // process can run ONE rank's shard and be compared with the oracle on the same shard

@@ -77,7 +77,7 @@ void TpGroup::run_rank(int r, const std::function<void(int)>& f) {
         // RCCL transport: the other ranks may be blocked INSIDE a collective (a kernel waiting for this rank's contribution behind
         // a hipStreamSynchronize) -- no host-side rendezvous can release that.  ncclCommAbort of every rank's communicator does; it
         // may be called from this thread while the owner is blocked.  The group is dead afterwards (run()).
-        if (!shared.use_peer && !symmetric_error(errs[(size_t)r]))
+        if (!shared.use_peer && comms_ready.load() && !symmetric_error(errs[(size_t)r]))
             for (int q = 0; q < n; ++q) {
                 Model* mq = q == 0 ? rank0 : peers[(size_t)q - 1].get();
                 if (q != r && mq && mq->rccl) mq->rccl->abort_comm();
@@ -154,6 +154,7 @@ void TpGroup::run(const std::function<void(int)>& f) {
     }
     if (first) std::rethrow_exception(first);
     if (released) std::rethrow_exception(released);
+    comms_ready.store(true);
 }
 
 }  // namespace cm

@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
+
 #include "model.h"
 #include "tp.h"
 
@@ -38,6 +40,9 @@ struct TpGroup {
     // one); errors every rank raises alike (an invalid argument, a range check -- thrown before any exchange) do not kill it.
     bool dead = false;
     std::string dead_why;
+    // set once a run() completed without error: every rank's Model::rccl is constructed and stays put.  Until then (the run that builds
+    // the ranks: alloc_runtime) a failing rank must not touch its peers' half-built communicators (run_rank)
+    std::atomic<bool> comms_ready{false};
     // f(rank) on every rank concurrently; returns when all are done.  A rank that throws aborts the group's rendezvous
     // (PeerShared::fail) so that no other rank waits for it forever; the exception of the lowest failing rank is rethrown.
     void run(const std::function<void(int)>& f);
