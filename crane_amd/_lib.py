@@ -24,7 +24,7 @@ EXPORTS = [
     "cm_forward_step_greedy", "cm_clear_kv", "cm_warmup", "cm_generate", "cm_seq_alloc",
     "cm_seq_free", "cm_seq_fork", "cm_seq_len", "cm_seq_truncate", "cm_seq_forward",
     "cm_decode_batch", "cm_prefill_batch", "cm_image_smart_resize", "cm_image_preprocess", "cm_preprocess_last_error", "cm_image_token_id", "cm_vision_encode", "cm_vlm_forward", "cm_embed_tokens", "cm_forward_embeds", "cm_sample", "cm_topk", "cm_read_logits", "cm_engine_create", "cm_engine_destroy", "cm_engine_submit", "cm_engine_cancel",
-    "cm_gguf_config", "cm_checkpoint_inspect", "cm_tp_shard_plan", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv", "cm_debug_set", "cm_debug_peer_selftest", "cm_debug_qgemm_plan",
+    "cm_gguf_config", "cm_checkpoint_inspect", "cm_tp_shard_plan", "cm_engine_step", "cm_engine_step_many", "cm_engine_has_work", "cm_engine_get_stats", "cm_engine_last_error", "cm_bench_decode", "cm_bench_kernel", "cm_debug_fill_kv", "cm_debug_read", "cm_debug_qgemv", "cm_debug_qgemm", "cm_debug_set", "cm_debug_peer_selftest", "cm_debug_qgemm_plan",
 ]
 
 
@@ -183,6 +183,7 @@ def load():
     lib.cm_debug_fill_kv.argtypes = [vp, C.c_size_t, C.c_uint64]
     lib.cm_debug_read.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
     lib.cm_debug_qgemv.argtypes = [vp, C.c_int32, C.c_char_p, f32p, C.c_size_t, f32p, C.c_size_t]
+    lib.cm_debug_qgemm.argtypes = [vp, C.c_int32, C.c_char_p, f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t]
     lib.cm_debug_set.argtypes = [vp, C.c_char_p, C.c_int64]
     _lib = lib
     return lib

@@ -478,6 +478,14 @@ class Model:
                                              out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out
 
+    def debug_qgemm(self, layer: int, which: str, x: np.ndarray, n: int) -> np.ndarray:
+        """cm_debug_qgemm: rows x [rows, k] through the int8-MFMA GEMM of a quantised projection -> [rows, n]."""
+        xv = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty((xv.shape[0], n), dtype=np.float32)
+        self._check(self._lib.cm_debug_qgemm(self._h, layer, which.encode(), xv.ctypes.data_as(C.POINTER(C.c_float)), xv.shape[0], xv.shape[1],
+                                             out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out
+
     def decode_bytes_per_token(self, ctx: int) -> int:
         return int(self._lib.cm_decode_bytes_per_token(self._h, ctx))
 

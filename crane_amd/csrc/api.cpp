@@ -430,6 +430,14 @@ int cm_debug_qgemv(cm_model* h, int32_t layer, const char* which, const float* x
     });
 }
 
+int cm_debug_qgemm(cm_model* h, int32_t layer, const char* which, const float* x, size_t m, size_t k, float* y, size_t n) {
+    if (!h || !which || !x || !y) return CM_ERR_INVALID;
+    return guard(h, [&] {
+        if (h->grp) throw CmError(CM_ERR_UNSUPPORTED, "cm_debug_qgemm: not on an in-process tensor-parallel group");
+        h->m.debug_qgemm(layer, which, x, m, k, y, n);
+    });
+}
+
 int cm_bench_decode(cm_model* h, uint32_t first_token, size_t k, uint32_t* tokens_out, float* ms_out) {
     if (!h) return CM_ERR_INVALID;
     return guard_all(h, [&](Model& m, bool primary) {

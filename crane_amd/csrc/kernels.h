@@ -412,7 +412,11 @@ struct QNext { const float* nw; float eps; signed char* xq; float* xd; signed ch
 struct QDefer { int ks; size_t slice; const float* ws; };
 // what launch_gemm_q8 will do for a shape (host logic only): ok = false -> the caller's GEMV fallback
 struct QGemmPlan { bool ok, direct; int geo, mh, mt, qg, groups, ks, grid; size_t lds; int mpan; };
-QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu);
+QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu, int fmt = QFMT_Q8_0);
+// Q4_K weights on the same GEMM (round 6): the activation rows as Q8_K blocks in groups of 160 bytes [128 codes | the virtual block: 8
+// base-128 digits of the 32-code sums + 24 zeros], 5 f32 scales per group ([K / 128 * 5][xs]); launch_gemm_q8 takes them as xq / xd when
+// QGemmArgs::w is a Q4_K tensor (no fused next-quantiser: `next` is ignored)
+void launch_quant_rows_q8k(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s, int xs = QGEMM_MAXM);
 bool launch_gemm_q8(const QGemmArgs& a, int epi, float* y, int ldy, float* ws, size_t ws_floats, int num_cu, hipStream_t s,
                     const QNext* next = nullptr, int* fused = nullptr, QDefer* defer = nullptr);
 int gemvqb_max_seqs(int fmt, int K);

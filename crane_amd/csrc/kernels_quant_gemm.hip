@@ -341,6 +341,326 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q8_i8_k
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: Q4_K weights on the same matrix-core path (the review's "K-quant tiles on the int8 GEMM"; ggml_vec_dot_q4_K_q8_K per
+// output: the activation row as Q8_K blocks -- ONE f32 scale per 256 elements, int8 codes, sums of 32 codes -- and
+//   sumf += d_x d * sum_j sc_j (q4_j . q8_j)  -  d_x dmin * sum_j m_j bsum_j            over the eight 32-element sub-blocks j).
+// Both terms are written as Q8_0-shaped blocks so that the loop of gemm_q8_i8_kernel carries over unchanged:
+//   * sub-block j is a block of 32 int8 codes (the 4-bit codes 0 .. 15, expanded from the packed nibbles when the weight panel goes to
+//     LDS: the weights stay 4.5 bits in HBM) with the f32 scale d * sc_j (exact: f16 x 6-bit) on the weight side and d_x on the
+//     activation side;
+//   * the min term is two VIRTUAL blocks per 256: weight codes (m_0 .. m_7, 0 ...), weight scale -dmin, against the base-128 digits of
+//     the code sums -- bsum_j = 128 bh_j + bl_j, bl in [0, 127], bh in [-32, 31], both int8 -- with activation scales d_x (bl) and
+//     128 d_x (bh).  One v_mfma_i32_32x32x32_i8 each: the matrix cores have the room (they were 10 % busy), the VALU does not.
+// A K GROUP is half a 256-block: 4 real blocks + 1 virtual block (bl in the first half, bh in the second) = 5 steps per m-tile;
+// activation rows arrive as groups of 160 bytes [128 codes | 8 digits + 24 zeros] from quant_rows_q8k_kernel, their scales as 5 f32 per
+// group.  Sums differ from ggml's by the f32 rounding of (d sc_j) d_x per sub-block instead of one product per 256 (1e-7).
+// Q6_K (sub-blocks of 16 codes: two scales per 32-deep MFMA step) is not on this path: such tensors keep the batched GEMV.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int QKB = 5;                               // MFMA steps per m-tile and group: 4 sub-blocks + 1 virtual block
+constexpr int QKROW = 160;                           // bytes of an activation row per group
+
+// one 256-thread block per row; one wave per 256-element block (quantize_row_q8_K as gemvq_i8_kernel's prologue computes it: the signed
+// value of the FIRST element with the largest |x| -> iscale = -128 / max, q = min(127, rint(x iscale)), d = 1 / iscale)
+template <bool NORM>
+__global__ __launch_bounds__(256) void quant_rows_q8k_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ nw, float eps,
+                                                             signed char* __restrict__ xq, float* __restrict__ xd, int K, int xs) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, t2 = threadIdx.x, lane = t2 & 63, wave = t2 >> 6;
+    const float* xr = x + (size_t)m * ldx;
+    const int n4 = K >> 2;
+    float r = 1.f;
+    if (NORM) {                                      // (quant_rows_q8_kernel's order of the sum of squares)
+        float ss = 0.f;
+        for (int kb = t2; kb < n4; kb += 1024) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (kb + 256 * j < n4) ? *(const f32x4*)(xr + ((kb + 256 * j) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (kb + 256 * j < n4) ss = fmaf(v[j][3], v[j][3], fmaf(v[j][2], v[j][2], fmaf(v[j][1], v[j][1], fmaf(v[j][0], v[j][0], ss))));
+        }
+        const float t = wave_sum(ss);
+        if (lane == 0) red[wave] = t;
+        __syncthreads();
+        r = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + eps);
+    }
+    const int nblk = K >> 8;
+    signed char* row = xq + (size_t)m * (size_t)(K >> 7) * QKROW;
+    for (int blk = wave; blk < nblk; blk += 4) {
+        const int k4 = blk * 64 + lane;
+        f32x4 v = *(const f32x4*)(xr + (k4 << 2));
+        if (NORM) {
+            const f32x4 w = *(const f32x4*)(nw + (k4 << 2));
+            v[0] = __fmul_rn(__fmul_rn(v[0], r), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], r), w[1]);
+            v[2] = __fmul_rn(__fmul_rn(v[2], r), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], r), w[3]);
+        }
+        unsigned long long key = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long ke = ((unsigned long long)__float_as_uint(fabsf(v[e])) << 32) | (unsigned)(255 - (lane * 4 + e));
+            key = ke > key ? ke : key;
+        }
+        unsigned long long best = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)best, o), hi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o);
+            const unsigned long long ot = ((unsigned long long)hi << 32) | lo;
+            best = ot > best ? ot : best;
+        }
+        const int widx = 255 - (int)(unsigned)(best & 0xFFFFFFFFull);
+        float cand = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (lane * 4 + e == widx) cand = v[e];
+        const float mx = wave_sum(cand);
+        const float iscale = mx != 0.f ? -128.0f / mx : 0.f;
+        int s4 = 0; uint32_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = mx != 0.f ? min(127, __float2int_rn(v[e] * iscale)) : 0;
+            s4 += q;
+            pk |= ((uint32_t)q & 0xFFu) << (8 * e);
+        }
+        // lane l holds elements 4 l .. 4 l + 3 of the block: group (half) l / 32, byte 4 (l % 32) of its 128 code bytes
+        signed char* g0 = row + (size_t)(2 * blk) * QKROW;
+        ((uint32_t*)(g0 + (lane >> 5) * QKROW))[lane & 31] = pk;
+        // sums of 32 codes = 8 consecutive lanes -> digits bl (first group's virtual block) and bh (second group's)
+        int bs = s4 + __shfl_xor(s4, 1); bs += __shfl_xor(bs, 2); bs += __shfl_xor(bs, 4);
+        const int bl = bs & 127, bh = (bs - bl) >> 7;                // bs = 128 bh + bl, bs in [-4096, 4064]
+        if ((lane & 7) == 0) { g0[128 + (lane >> 3)] = (signed char)bl; g0[QKROW + 128 + (lane >> 3)] = (signed char)bh; }
+        if (lane < 12) {                                              // the zeros behind the 8 digits (24 bytes per group = 6 dwords x 2 groups)
+            const int gi = lane / 6, w = lane % 6;
+            ((uint32_t*)(g0 + gi * QKROW + 136))[w] = 0u;
+        }
+        if (lane < 10) {                                              // scales: groups 2 blk, 2 blk + 1 x 5 blocks
+            const int gi = lane / 5, j = lane % 5;
+            const float d = mx != 0.f ? 1.0f / iscale : 0.f;
+            xd[(size_t)((2 * blk + gi) * QKB + j) * xs + m] = (j == 4 && gi == 1) ? 128.0f * d : d;
+        }
+    }
+}
+
+void launch_quant_rows_q8k(const float* x, int ldx, const float* nw, float eps, signed char* xq, float* xd, int M, int K, hipStream_t s, int xs) {
+    if (nw) hipLaunchKernelGGL(quant_rows_q8k_kernel<true>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K, xs);
+    else hipLaunchKernelGGL(quant_rows_q8k_kernel<false>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K, xs);
+}
+
+// gemm_q8_i8_kernel's tiling and in-wave pipeline (see there) over Q4_K weights; what differs is how a group's panels and scales are
+// made: weight rows arrive as 64 packed bytes (4 x 16-byte chunks = 128 rows x 4 chunk loads per group: one per thread at 512 threads)
+// and are expanded to int8 on their way into LDS; the virtual block's codes and the group's five f32 weight scales come from the row's
+// 16-byte block header {f16 d, f16 dmin, 12 bytes of 6-bit scales / mins}
+template <int MH, int MT>
+__global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q4k_i8_kernel(QGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    constexpr int ROWB = QKROW + 16;                    // bytes of a panel row in LDS (weights and activations): 176 = 44 banks, the 16 rows of a fragment read start 4-bank-distinct
+    constexpr int NT = 256 * MH, PR = 32 * MT * MH, NS = QKB * MT;
+    constexpr int NCHT = PR * 10, NCH = (NCHT + NT - 1) / NT;          // 16-byte chunks of the activation panel of a group, per thread
+    constexpr int NWC = 128 * 4 / NT;                   // packed weight chunks per thread (1 at 512 threads, 2 at 256)
+    constexpr int PANEL = PR * ROWB, WPANEL = 128 * ROWB;
+    constexpr int XM = PR > QGEMM_MAXM ? PR : QGEMM_MAXM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, ns = wave & 3, mh = wave >> 2;
+    const int K = a.w.K, N = a.w.N, nb256 = K >> 8, G = K >> 7;
+    float* xds = (float*)qlds;                                              // [2][QKB][XM] activation block scales of a group
+    float* dwl = xds + 2 * QKB * XM + wave * (QKB * 32);                    // [QKB][32] this wave's weight scales of the group (wave-private)
+    unsigned char* Ws = qlds + (size_t)(2 * QKB * XM + 4 * MH * QKB * 32) * sizeof(float);   // [2][128][ROWB]
+    unsigned char* As = Ws + 2 * WPANEL;                                    // [2][PR][ROWB]
+    const int tiles = N / 128;
+    const int per = tiles * a.mpan;
+    const int ks = (int)blockIdx.x / per, rem = (int)blockIdx.x % per;
+    int tn, mp;
+    if (a.mpan > 1 && (tiles & 7) == 0) { const int xcd = rem & 7, idx = rem >> 3; tn = (idx / a.mpan) * 8 + xcd; mp = idx % a.mpan; }
+    else { tn = rem % tiles; mp = rem / tiles; }
+    const int m_base = mp * PR;
+    const int g0 = ks * G / a.ksplit, ngrp = (ks + 1) * G / a.ksplit - g0;
+    // block headers: lane (r, .) of strip ns owns row tn * 128 + ns * 32 + r
+    const uint8_t* hdr = a.w.p1 + (size_t)(tn * 128 + ns * 32 + r) * nb256 * 16;
+    // packed weight chunks: c = tid + NT i: row c / 4, chunk q = c % 4 of the group's 64 bytes: run q / 2 (sub-blocks 2 (q / 2) from the low
+    // nibbles, + 1 from the high ones), bytes 16 (q % 2) ... of the run
+    const uint8_t* wsrc[NWC];
+    int wdst[NWC];
+    const uint8_t* whdr[NWC];                           // (q == 0 threads also write the row's virtual block: its m_0 .. m_7)
+#pragma unroll
+    for (int i = 0; i < NWC; ++i) {
+        const int c = tid + NT * i, row = c >> 2, q = c & 3;
+        wsrc[i] = a.w.p0 + (size_t)(tn * 128 + row) * (K >> 1) + (size_t)g0 * 64 + 16 * q;
+        wdst[i] = row * ROWB + (q >> 1) * 64 + (q & 1) * 16;
+        whdr[i] = a.w.p1 + (size_t)(tn * 128 + row) * nb256 * 16;
+    }
+    const signed char* xbase = a.xq + (size_t)g0 * QKROW;
+    const size_t xrow_b = (size_t)G * QKROW;            // bytes of an activation row
+    auto xsrc_of = [&](int c) -> const signed char* {   // chunk c of the panel: row c / 10, 16-byte chunk c % 10
+        const int row = c / 10, q = c % 10;
+        return xbase + (size_t)min(m_base + row, a.M - 1) * xrow_b + 16 * q;
+    };
+    u32x4 wreg[NWC], hreg[NWC], areg[NCH];
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            wreg[i] = ld_nt16(wsrc[i] + (size_t)g * 64);
+            hreg[i] = *(const u32x4*)(whdr[i] + (size_t)((g0 + g) >> 1) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + NT * i;
+            areg[i] = c < NCHT ? *(const u32x4*)(xsrc_of(c) + (size_t)g * QKROW) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    // 6-bit scale / min j of a header (get_scale_min_k4)
+    auto sbyte = [](const u32x4& hb, int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
+    auto sc_of = [&](const u32x4& hb, int j) -> int { return j < 4 ? (sbyte(hb, j) & 63) : ((sbyte(hb, j + 4) & 0xF) | ((sbyte(hb, j - 4) >> 6) << 4)); };
+    auto mn_of = [&](const u32x4& hb, int j) -> int { return j < 4 ? (sbyte(hb, j + 4) & 63) : ((sbyte(hb, j + 4) >> 4) | ((sbyte(hb, j) >> 6) << 4)); };
+    auto store_group = [&](int buf) {
+        unsigned char* Wn = Ws + buf * WPANEL;
+        unsigned char* An = As + buf * PANEL;
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            const u32x4 w = wreg[i];
+            *(u32x4*)(Wn + wdst[i]) = (u32x4){w[0] & 0x0F0F0F0Fu, w[1] & 0x0F0F0F0Fu, w[2] & 0x0F0F0F0Fu, w[3] & 0x0F0F0F0Fu};
+            *(u32x4*)(Wn + wdst[i] + 32) = (u32x4){(w[0] >> 4) & 0x0F0F0F0Fu, (w[1] >> 4) & 0x0F0F0F0Fu, (w[2] >> 4) & 0x0F0F0F0Fu, (w[3] >> 4) & 0x0F0F0F0Fu};
+            if (((tid + NT * i) & 3) == 0) {            // the virtual block of the row: (m_0 .. m_7, 0 ...)
+                const u32x4 hb = hreg[i];
+                uint32_t m03 = 0, m47 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { m03 |= (uint32_t)mn_of(hb, j) << (8 * j); m47 |= (uint32_t)mn_of(hb, j + 4) << (8 * j); }
+                unsigned char* vb = Wn + ((tid + NT * i) >> 2) * ROWB + 128;
+                *(u32x4*)vb = (u32x4){m03, m47, 0u, 0u};
+                *(u32x4*)(vb + 16) = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + NT * i;
+            if (c < NCHT) *(u32x4*)(An + (c / 10) * ROWB + 16 * (c % 10)) = areg[i];
+        }
+    };
+    // the strip's five weight scales of group g (f32): lane (r, h = 0) writes blocks 0, 1 and the virtual one, h = 1 blocks 2, 3
+    u32x4 shdr;
+    auto load_scales = [&](int g) { shdr = *(const u32x4*)(hdr + (size_t)((g0 + g) >> 1) * 16); };
+    auto put_dw = [&](int g) {
+        const float d = f16bits(shdr[0] & 0xFFFFu), dmin = f16bits(shdr[0] >> 16);
+        const int half = (g0 + g) & 1;                  // sub-blocks 4 half ... 4 half + 3 of the 256-block
+        const int j0 = 2 * h;
+        dwl[j0 * 32 + r] = d * (float)sc_of(shdr, 4 * half + j0);
+        dwl[(j0 + 1) * 32 + r] = d * (float)sc_of(shdr, 4 * half + j0 + 1);
+        if (h == 0) dwl[4 * 32 + r] = -dmin;
+    };
+    // activation scales of a group: QKB x XM floats
+    constexpr int XT = QKB * XM / 4, XR = XM / 4;
+    static_assert(XT <= 256 * MH * 2, "scale loader");
+    const float* xdsrc[2]; bool xdo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = tid + NT * i;
+        xdo[i] = t < XT;
+        const int tt = xdo[i] ? t : 0;
+        xdsrc[i] = a.xd + ((size_t)g0 * QKB + tt / XR) * a.xs + m_base + 4 * (tt % XR);
+    }
+    const size_t xdstep = (size_t)QKB * a.xs;
+    f32x4 xreg[2];
+    auto load_xd = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (xdo[i]) xreg[i] = *(const f32x4*)(xdsrc[i] + (size_t)g * xdstep);
+    };
+    auto store_xd = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (xdo[i]) ((f32x4*)(xds + buf * (QKB * XM)))[tid + NT * i] = xreg[i];
+    };
+    load_group(0); load_scales(0); load_xd(0);
+    store_group(0); store_xd(0); put_dw(0);
+    f32x2 acc[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[mt][i] = (f32x2){0.f, 0.f};
+    __syncthreads();
+    const int wrow = (ns * 32 + r) * ROWB + 16 * h;
+    const int arow = (mh * MT * 32 + r) * ROWB + 16 * h;
+    const int xrow = mh * MT * 32 + r;
+    for (int g = 0; g < ngrp; ++g) {
+        const bool more = g + 1 < ngrp;
+        if (more) { load_group(g + 1); load_scales(g + 1); load_xd(g + 1); }
+        const unsigned char* Wp = Ws + (g & 1) * WPANEL + wrow;
+        const unsigned char* Ap = As + (g & 1) * PANEL + arow;
+        const float* xg = xds + (g & 1) * (QKB * XM) + xrow;
+        u32x4 avq[2], wfq[2];
+        float dxq[3];
+        i32x16 cq[2];
+        f32x4 dwq[4];
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define QK_LOAD(s_, slot_) do { avq[slot_] = *(const u32x4*)(Ap + ((s_) % MT) * 32 * ROWB + ((s_) / MT) * 32); \
+                                dxq[(s_) % 3] = xg[((s_) / MT) * XM + ((s_) % MT) * 32]; } while (0)
+#define QK_MFMA(s_, slot_) cq[slot_] = __builtin_amdgcn_mfma_i32_32x32x32_i8( \
+            (i32x4){(int)wfq[((s_) / MT) & 1][0], (int)wfq[((s_) / MT) & 1][1], (int)wfq[((s_) / MT) & 1][2], (int)wfq[((s_) / MT) & 1][3]}, \
+            (i32x4){(int)avq[slot_][0], (int)avq[slot_][1], (int)avq[slot_][2], (int)avq[slot_][3]}, zero, 0, 0, 0)
+        wfq[0] = *(const u32x4*)Wp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + 8 * q + 4 * h);
+        QK_LOAD(0, 0);
+        QK_LOAD(1, 1);
+        if (MT == 1) wfq[1] = *(const u32x4*)(Wp + 32);
+        QK_MFMA(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sl = s & 1, mt = s % MT, j = s / MT;
+            if (MT > 1 && mt == 0 && j + 1 < QKB) wfq[(j + 1) & 1] = *(const u32x4*)(Wp + (j + 1) * 32);
+            if (s + 1 < NS) QK_MFMA(s + 1, sl ^ 1);
+            if (MT == 1 && j + 2 < QKB) wfq[j & 1] = *(const u32x4*)(Wp + (j + 2) * 32);
+            if (s + 2 < NS) QK_LOAD(s + 2, sl);
+            __builtin_amdgcn_sched_barrier(0);
+            const float dx = dxq[s % 3];
+            f32x2 sv[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sv[p] = (f32x2){dwq[p >> 1][2 * (p & 1)], dwq[p >> 1][2 * (p & 1) + 1]} * (f32x2){dx, dx};
+            if (mt == MT - 1 && j + 1 < QKB) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(sv[p]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + (j + 1) * 32 + 8 * q + 4 * h);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const f32x2 cf = (f32x2){(float)cq[sl][2 * p], (float)cq[sl][2 * p + 1]};
+                acc[mt][p] = __builtin_elementwise_fma(sv[p], cf, acc[mt][p]);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(acc[mt][p]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef QK_LOAD
+#undef QK_MFMA
+        if (more) { store_group((g + 1) & 1); store_xd((g + 1) & 1); put_dw(g + 1); }
+        __syncthreads();
+    }
+    float* P = a.ws + (size_t)ks * a.slice;
+    const int nq = tn * 128 + ns * 32 + 4 * h;
+    constexpr int TS = 68;
+    float* T = (float*)Ws;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ml = (mh * MT + mt) * 32 + r, m = m_base + ml;
+        if (a.silu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g0v = acc[mt][2 * q][0], u0 = acc[mt][2 * q][1], g1v = acc[mt][2 * q + 1][0], u1 = acc[mt][2 * q + 1][1];
+                const f32x2 o = (f32x2){(g0v / (1.0f + expf(-g0v))) * u0, (g1v / (1.0f + expf(-g1v))) * u1};
+                *(f32x2*)(T + ml * TS + ns * 16 + 2 * h + 4 * q) = o;
+            }
+        } else if (m < a.M) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(P + (size_t)m * a.ldp + nq + 8 * q) = (f32x4){acc[mt][2 * q][0], acc[mt][2 * q][1], acc[mt][2 * q + 1][0], acc[mt][2 * q + 1][1]};
+        }
+    }
+    if (a.silu) {
+        __syncthreads();
+        for (int it = tid; it < PR * 16; it += NT) {
+            const int row = it >> 4, c4 = it & 15;
+            if (m_base + row < a.M) *(f32x4*)(P + (size_t)(m_base + row) * a.ldp + tn * 64 + 4 * c4) = *(const f32x4*)(T + row * TS + 4 * c4);
+        }
+    }
+}
+
 // slices added in the order 0, 1, ...; 4 consecutive columns of a row per thread.  EPI_STORE / EPI_RESADD: y[m][n] (+)= v;
 // EPI_SILUMUL: columns (gate_j, up_j) interleaved -> y[m][n / 2] = silu(gate) * up (the GEMV epilogue's expression)
 template <int EPI, int KS>
@@ -541,7 +861,7 @@ static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, 
 }
 
 bool gemm_q8_ok(const QWeight& w, int M) {
-    return w.fmt == QFMT_Q8_0 && M >= 1 && M <= QGEMM_BIGM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
+    return (w.fmt == QFMT_Q8_0 || w.fmt == QFMT_Q4_K) && M >= 1 && M <= QGEMM_BIGM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
 }
 
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
@@ -553,7 +873,7 @@ bool gemm_q8_ok(const QWeight& w, int M) {
 //   LDS, two independent workgroups per CU (= 1: 11.18 K);
 //   K split: the chip holds `cap` workgroups at a time (256 registers per lane: 2 waves per SIMD); a launch of `tiles * ks` of them runs in
 //   ceil(tiles ks / cap) rounds of (1 start-up + ceil(G / ks) groups), and every slice costs a write + a read of M x N f32.
-QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu) {
+QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_floats, int num_cu, int fmt) {
     QGemmPlan p{};
     if (M < 1 || M > QGEMM_BIGM || N % 128 != 0 || K % (32 * QG_MIN) != 0 || (epi != EPI_STORE && epi != EPI_RESADD && epi != EPI_SILUMUL)) return p;
     static const int geo_env = getenv("CM_QGEMM_GEO") ? atoi(getenv("CM_QGEMM_GEO")) : 3;
@@ -564,11 +884,17 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
     // a CU held one 4-wave workgroup, one wave per SIMD.  CM_QGEMM_QG_SMALL = 8: A/B)
     static const int qg_small = getenv("CM_QGEMM_QG_SMALL") && atoi(getenv("CM_QGEMM_QG_SMALL")) == 8 ? 8 : 4;
     p.mh = geo == 1 || geo == 3 || geo == 4 ? 2 : 1; p.mt = geo == 2 || geo == 4 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : geo == 1 ? 8 : qg_small;
+    if (fmt == QFMT_Q4_K) {      // groups of half a 256-block (4 sub-blocks + 1 virtual block); geometries <1,1> <1,2> <2,2> <2,4>
+        p.qg = 4;
+        if (geo != 4) { p.mh = M > 64 ? 2 : 1; p.mt = M > 32 ? 2 : 1; }
+    }
     const int pr = 32 * p.mt * p.mh;
     p.mpan = geo == 4 ? (M + pr - 1) / pr : 1;
     const int nkb_all = K >> 5, tiles = (N / 128) * p.mpan, G = nkb_all / p.qg;
     p.groups = G;
     p.lds = (size_t)(2 * p.qg * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (p.qg * 32 + 16);
+    if (fmt == QFMT_Q4_K)
+        p.lds = (size_t)(2 * QKB * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * QKB * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (QKROW + 16);
     const int cap = num_cu * (p.mh == 2 ? 1 : 2);
     const double tgroup_us = geo == 4 ? 4.0 : 2.0, fill_us = 2.5, part_us = 8.0 * M * N / 3.0e6;        // (partials at ~3 TB/s, write + read)
     int ks = 1;
@@ -600,7 +926,9 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     if (defer) { defer->ks = 1; defer->slice = 0; defer->ws = nullptr; }
     if (fused) *fused = 0;
     if (!gemm_q8_ok(a.w, a.M)) return false;
-    const QGemmPlan pl = plan_gemm_q8(a.M, a.w.N, a.w.K, epi, ws != nullptr, ws_floats, num_cu);
+    const bool q4k = a.w.fmt == QFMT_Q4_K;
+    if (q4k) next = nullptr;      // (the fused quantisers write Q8_0 blocks; a K-quant consumer takes Q8_K rows: its own quantiser launch)
+    const QGemmPlan pl = plan_gemm_q8(a.M, a.w.N, a.w.K, epi, ws != nullptr, ws_floats, num_cu, a.w.fmt);
     if (!pl.ok) return false;
     const int N = a.w.N, tiles = (N / 128) * pl.mpan, mh = pl.mh, mt = pl.mt, geo = pl.geo;
     a.mpan = pl.mpan;
@@ -628,9 +956,19 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<1, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q8_i8_kernel<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid(tiles * ks), block(256 * mh);
-    if (geo == 4) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 4, 4>), grid, block, lds, s, a);
+    if (q4k) {
+        if (mh == 2 && mt == 4) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 4>), grid, block, lds, s, a);
+        else if (mh == 2) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 2>), grid, block, lds, s, a);
+        else if (mt == 2) hipLaunchKernelGGL((gemm_q4k_i8_kernel<1, 2>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((gemm_q4k_i8_kernel<1, 1>), grid, block, lds, s, a);
+    }
+    else if (geo == 4) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 4, 4>), grid, block, lds, s, a);
     else if (geo == 3) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 4>), grid, block, lds, s, a);
     else if (geo == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<1, 4, 4>), grid, block, lds, s, a);
     else if (mh == 2) hipLaunchKernelGGL((gemm_q8_i8_kernel<2, 2, 8>), grid, block, lds, s, a);

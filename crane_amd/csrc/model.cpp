@@ -1215,13 +1215,20 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     // ---- int8 prompt pass (q8_prefill): rows in panels of <= QGEMM_MAXM; quantiser + int8-MFMA GEMM per projection and panel ----
     const bool q8p = q8_prefill;
     const int xs8 = S > (int)QGEMM_MAXM ? q8_xs : (int)QGEMM_MAXM;       // scale-row stride of this pass's code buffers
-    auto q8_quant = [&](const float* xin, int ldx, const float* nw, int m, int K) {
-        launch_quant_rows_q8(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, K, s, xs8);
-        if (q_capture) q_capture_rows(m, K, xs8);
+    // the rows currently held as codes: (source, norm weight, K, kind: 0 = Q8_0 blocks, 1 = Q8_K groups for Q4_K weights)
+    const float* q8_src = nullptr; const float* q8_nw = nullptr; int q8_K = 0, q8_kind = -1;
+    auto q8_in = [&](const QWeight& qw, const float* xin, int ldx, const float* nw, int m) {
+        const int kind = qw.fmt == QFMT_Q4_K ? 1 : 0;
+        if (q8_src == xin && q8_nw == nw && q8_K == qw.K && q8_kind == kind) return;
+        if (kind) launch_quant_rows_q8k(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, qw.K, s, xs8);
+        else launch_quant_rows_q8(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, qw.K, s, xs8);
+        q8_src = xin; q8_nw = nw; q8_K = qw.K; q8_kind = kind;
+        if (q_capture && !kind) q_capture_rows(m, qw.K, xs8);
     };
-    // y (+)= W . codes^T over the panel's m rows; next_nw / next_plain: the rows written are the next projection's input -- quantised by
-    // the reduction launch (or the unsplit gate|up GEMM itself); returns true when the current codes hold them
-    auto q8_mm = [&](const QWeight& qw, int epi, float* y, int ldy, int m, const float* next_nw, bool next_plain) -> bool {
+    // y (+)= W . rows(xin)^T over the pass's m rows (quantised above unless the codes already hold them); next_nw / next_plain: the rows
+    // written are the next projection's input -- quantised as Q8_0 blocks by the reduction launch (or the unsplit gate|up GEMM itself)
+    auto q8_mm = [&](const QWeight& qw, const float* xin, int ldx, const float* nw, int epi, float* y, int ldy, int m, const float* next_nw, bool next_plain) {
+        q8_in(qw, xin, ldx, nw, m);
         QGemmArgs qg{};
         qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = m; qg.xs = xs8;
         QNext nx{next_nw, cfg.eps, qx_codes, qx_scales, qx_codes2, qx_scales2};
@@ -1231,31 +1238,31 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
         if (!launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused))
             throw CmError(CM_ERR_UNSUPPORTED, "int8 prompt GEMM shape");
         if (fused == 2) { std::swap(qx_codes, qx_codes2); std::swap(qx_scales, qx_scales2); }
-        if (fused && q_capture) q_capture_rows(m, kout, xs8);
-        return fused != 0;
+        if (fused) { q8_src = y; q8_nw = next_nw; q8_K = kout; q8_kind = 0; if (q_capture) q_capture_rows(m, kout, xs8); }
+        else if (epi == EPI_RESADD && q8_src == y) q8_src = nullptr;       // (the rows the codes were made from have changed)
     };
     // the rest of a layer after the token mixer, panel by panel: o_proj / out_proj over the mixer's f32 rows `ain` [S][AC], gate|up,
     // down_proj -- a panel's rows of silu(gate) * up never leave the [128][I] scratch
     auto q8_tail = [&](const LayerW& w, const QWeight& wo, const float* ain, int AC, int li) {
-        bool have = false;
-        q8_quant(ain, AC, nullptr, S, AC);
-        if (!rccl) have = q8_mm(wo, EPI_RESADD, pX, H, S, w.ln2, false);
+        if (!rccl) q8_mm(wo, ain, AC, nullptr, EPI_RESADD, pX, H, S, w.ln2, false);
         else {
-            q8_mm(wo, EPI_STORE, pY, H, S, nullptr, false);
+            q8_mm(wo, ain, AC, nullptr, EPI_STORE, pY, H, S, nullptr, false);
             rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
             launch_add_rows(pX, pY, (size_t)S * H, s);
+            q8_src = nullptr;
         }
-        if (!have) q8_quant(pX, H, w.ln2, S, H);
-        have = q8_mm(w.q_gate_up, EPI_SILUMUL, pHf, I_l, S, nullptr, true);
-        if (!have) q8_quant(pHf, I_l, nullptr, S, I_l);
-        if (!rccl) q8_mm(w.q_down, EPI_RESADD, pX, H, S, nullptr, false);
+        q8_mm(w.q_gate_up, pX, H, w.ln2, EPI_SILUMUL, pHf, I_l, S, nullptr, true);
+        if (!rccl) { q8_mm(w.q_down, pHf, I_l, nullptr, EPI_RESADD, pX, H, S, nullptr, false); q8_src = nullptr; }
         else {
-            q8_mm(w.q_down, EPI_STORE, pY, H, S, nullptr, false);
+            q8_mm(w.q_down, pHf, I_l, nullptr, EPI_STORE, pY, H, S, nullptr, false);
             rccl->all_reduce_sum_f32(pY, pY, (size_t)S * H, s);
             launch_add_rows(pX, pY, (size_t)S * H, s);
+            q8_src = nullptr;
         }
-        if (li < deep_layers && splice_map_dev != nullptr)
+        if (li < deep_layers && splice_map_dev != nullptr) {
             launch_add_rows_map(pX, vDeep + (size_t)li * deep_stride, splice_map_dev + off, S, H, s);
+            q8_src = nullptr;
+        }
     };
     bool xn_ready = false;
     for (int li = 0; li < cfg.L; ++li) {
@@ -1271,9 +1278,8 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
                 // [qkv | z] rows on the int8 matrix cores, panel by panel; the bf16 a / b rows as one 128-column bf16 GEMM tile (hi + lo
                 // activations from the rmsnorm_rows launch above) into the columns behind them
                 const int qz = cfg.conv_dim() + cfg.value_dim();
-                q8_quant(pX, H, w.ln1, S, H);
-                q8_mm(w.q_in_proj, EPI_STORE, pQKV, in_proj_pad, S, nullptr, false);
-                if (w.q_in_proj_z.fmt != QFMT_NONE) q8_mm(w.q_in_proj_z, EPI_STORE, pQKV + w.q_in_proj.N, in_proj_pad, S, nullptr, false);
+                q8_mm(w.q_in_proj, pX, H, w.ln1, EPI_STORE, pQKV, in_proj_pad, S, nullptr, false);
+                if (w.q_in_proj_z.fmt != QFMT_NONE) q8_mm(w.q_in_proj_z, pX, H, w.ln1, EPI_STORE, pQKV + w.q_in_proj.N, in_proj_pad, S, nullptr, false);
                 g.W = w.ba_pad; g.C = pQKV + qz; g.M = S; g.N = 128; g.K = H;
                 if (!launch_gemm(g, GEPI_STORE, s)) throw CmError(CM_ERR_UNSUPPORTED, "gemm shape");
             } else {
@@ -1325,8 +1331,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
             }
         } else {
         if (q8p) {
-            q8_quant(pX, H, w.ln1, S, H);
-            for (int i = 0; i < w.n_qkv; ++i) q8_mm(w.q_qkv[i], EPI_STORE, pQKV + w.qkv_row0[i], qkv_rows, S, nullptr, false);
+            for (int i = 0; i < w.n_qkv; ++i) q8_mm(w.q_qkv[i], pX, H, w.ln1, EPI_STORE, pQKV + w.qkv_row0[i], qkv_rows, S, nullptr, false);
         } else {
         g.A_hi = pXN_hi; g.A_lo = (sp2 && !(prefill_lo_mask & 1)) ? pXN_lo : nullptr; g.W = w.qkv; g.C = pQKV; g.ldc = qkv_rows;
         if (quantized) {      // one dequantised matrix at a time in the bf16 scratch (stream order keeps it safe)
@@ -1599,8 +1604,8 @@ void Model::lm_head_rows(int nb, bool want_rows) {
         gemm_q8_ok(q_lm_head.rows(0, v_eff), nb)) {
         // large groups over a Q8_0-layout head: one int8-MFMA pass over the table (kernels_quant_gemm.hip; the rows are written in
         // place, the table's 1187 column tiles fill the chip unsplit) + the row arg-max of the bf16 GEMM branch below
-        launch_quant_rows_q8(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s);
-        if (q_capture) q_capture_rows(nb, H);
+        if (q_lm_head.fmt == QFMT_Q4_K) launch_quant_rows_q8k(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s);
+        else { launch_quant_rows_q8(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s); if (q_capture) q_capture_rows(nb, H); }
         QGemmArgs qg{};
         qg.w = q_lm_head.rows(0, v_eff); qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
         if (!launch_gemm_q8(qg, EPI_STORE, logitsb + (size_t)rank * V_l, cfg.V, nullptr, 0, num_cu, s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised lm_head shape");
@@ -1693,10 +1698,11 @@ void Model::ensure_batch_buffers() {
         size_t rows = QGEMM_MAXM;
         q8_xs = QGEMM_MAXM;
         if (q8_prefill_want && q8_prefill_eligible()) { q8_xs = (prefill_chunk_rows() + 255) / 256 * 256; rows = std::max(rows, (size_t)q8_xs); }
-        qx_codes = (signed char*)dalloc<int>(rows * kmax / 4 + 16);
-        qx_scales = dalloc<float>((kmax / 32 + 1) * rows);
-        qx_codes2 = (signed char*)dalloc<int>(rows * kmax / 4 + 16);      // second pair: a GEMM that quantises its own output rows
-        qx_scales2 = dalloc<float>((kmax / 32 + 1) * rows);               // cannot overwrite the codes it is reading
+        // (Q8_K groups for Q4_K weights: 160 bytes and 5 scales per 128 elements -- 5/4 of the Q8_0 blocks' codes and scales)
+        qx_codes = (signed char*)dalloc<int>(rows * (kmax + kmax / 4) / 4 + 64);
+        qx_scales = dalloc<float>((kmax / 32 + kmax / 128 + 8) * rows);
+        qx_codes2 = (signed char*)dalloc<int>(rows * (kmax + kmax / 4) / 4 + 64);      // second pair: a GEMM that quantises its own output rows
+        qx_scales2 = dalloc<float>((kmax / 32 + kmax / 128 + 8) * rows);               // cannot overwrite the codes it is reading
     }
     pmaxb = dalloc<float>((size_t)MAXB * g * tp);       // TP: one [MAXB][g] slab per rank (all-gathered in place)
     pidxb = dalloc<int>((size_t)MAXB * g * tp);
@@ -1821,7 +1827,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
         // integer dots -- row for row the arithmetic of the single-sequence step)
         // the rows most recently quantised for the int8-MFMA path: projections that read the same input (q / k / v tensors, gate and
         // up, in_proj and in_proj_z) share one quantiser launch; forgotten at every layer and whenever a residual is added
-        const float* qx_src = nullptr; const float* qx_nw = nullptr; int qx_K = 0;
+        const float* qx_src = nullptr; const float* qx_nw = nullptr; int qx_K = 0, qx_kind = 0;      // (kind: 0 = Q8_0 blocks, 1 = Q8_K groups for Q4_K weights)
         // next_nw / next_plain: the rows this projection writes are the NEXT projection's input (RMSNorm weight next_nw, or no norm):
         // the int8-MFMA path quantises them on its reduction launch (QNext)
         auto qb = [&](int pro, int epi, const QWeight& qw, const float* xin, int ldx, const float* nw, float* y, int ldy,
@@ -1829,10 +1835,12 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             if (defer) { defer->ks = 1; defer->slice = 0; defer->ws = nullptr; }
             if (qgemm_ok && nb >= q_gemm_min && (epi == EPI_STORE || epi == EPI_RESADD || epi == EPI_SILUMUL) && gemm_q8_ok(qw, nb)) {
                 const float* nwe = pro == PRO_RMSNORM ? nw : nullptr;
-                if (qx_src != xin || qx_nw != nwe || qx_K != qw.K) {
-                    launch_quant_rows_q8(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
-                    qx_src = xin; qx_nw = nwe; qx_K = qw.K;
-                    if (q_capture) q_capture_rows(nb, qw.K);
+                const int kind = qw.fmt == QFMT_Q4_K ? 1 : 0;
+                if (qx_src != xin || qx_nw != nwe || qx_K != qw.K || qx_kind != kind) {
+                    if (kind) launch_quant_rows_q8k(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
+                    else launch_quant_rows_q8(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
+                    qx_src = xin; qx_nw = nwe; qx_K = qw.K; qx_kind = kind;
+                    if (q_capture && !kind) q_capture_rows(nb, qw.K);
                 }
                 QGemmArgs qg{};
                 qg.w = qw; qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
@@ -1842,7 +1850,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 int fused = 0;
                 if (launch_gemm_q8(qg, epi, y, ldy, pWS, gemm_ws_floats, num_cu, s, want_next ? &nx : nullptr, &fused, defer)) {
                     if (fused == 2) { std::swap(qx_codes, qx_codes2); std::swap(qx_scales, qx_scales2); }      // (the other pair is the current one now)
-                    if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; if (q_capture) q_capture_rows(nb, kout); }      // (the codes now hold the rows just written)
+                    if (fused) { qx_src = y; qx_nw = next_nw; qx_K = kout; qx_kind = 0; if (q_capture) q_capture_rows(nb, kout); }      // (the codes now hold the rows just written, as Q8_0 blocks)
                     else if (epi == EPI_RESADD) qx_src = nullptr;
                     return;
                 }
@@ -1965,13 +1973,13 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 const bool planes = gemm_b && !quantized && attn_decode_single_split(ns_b, D);
                 if (planes) { a.out1_hi = pAT_hi; a.out1_lo = pAT_lo; a.out1_cols = Hq_l * D; }
                 // ... or, in front of the int8 o_proj GEMM of a quantised group, ALSO the Q8_0 blocks of the rows (no quantiser launch)
-                const bool codes = attn_q && gemm_q8_ok(w.q_o, nb) && (Hq_l * D) % 64 == 0;
+                const bool codes = attn_q && gemm_q8_ok(w.q_o, nb) && w.q_o.fmt == QFMT_Q8_0 && (Hq_l * D) % 64 == 0;
                 if (codes) { a.out1_q = qx_codes; a.out1_qd = qx_scales; a.out1_cols = Hq_l * D; }
                 if (qdef.ks > 1) { a.qkv = qdef.ws; a.qkv_stride = w.q_qkv[0].N; a.qkv_ns = qdef.ks; a.qkv_slice = qdef.slice; }      // (the slices of the qkv GEMM, rows N floats apart)
                 if (mf) {
                     if (!launch_attn_decode_mfma(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
                 } else if (!launch_attn_decode(a, D, nrep, ns_b, kv_mode, attnb, (int)at_cols, nb, s)) throw CmError(CM_ERR_UNSUPPORTED, "GQA group size / head_dim");
-                if (codes) { qx_src = attnb; qx_nw = nullptr; qx_K = Hq_l * D; if (q_capture) q_capture_rows(nb, Hq_l * D); }      // (the codes hold the attention rows)
+                if (codes) { qx_src = attnb; qx_nw = nullptr; qx_K = Hq_l * D; qx_kind = 0; if (q_capture) q_capture_rows(nb, Hq_l * D); }      // (the codes hold the attention rows)
                 if (quantized) qrp(w.q_o, attnb, (int)at_cols, w.ln2);
                 else if (gemm_b) {
                     if (!planes) launch_split_rows2d(attnb, (int)at_cols, pAT_hi, pAT_lo, nb, Hq_l * D, s);
@@ -2311,6 +2319,47 @@ void Model::q_capture_rows(int nb, int K, int xs) {
     for (size_t i = 0; i < c.size(); ++i) *o++ = (float)c[i];
     for (int m = 0; m < nb; ++m)
         for (int b = 0; b < K / 32; ++b) *o++ = d[(size_t)b * xs + m];
+}
+
+// test hook: rows x [m][k] through the int8-MFMA GEMM of a quantised projection (row quantiser of the weight's vec-dot type + launch_gemm_q8,
+// plain input, store epilogue): y [m][n].  The kernel-level check of the decode-group / prompt GEMM against the oracle's vecdot rows.
+void Model::debug_qgemm(int layer, const std::string& which, const float* xh, size_t m, size_t k, float* yh, size_t n) {
+    if (!quantized) throw CmError(CM_ERR_INVALID, "model has no quantised weights");
+    QWeight w;
+    if (which == "lm_head") w = q_lm_head;
+    else {
+        if (layer < 0 || layer >= cfg.L) throw CmError(CM_ERR_RANGE, "layer out of range");
+        const LayerW& lw = layers[(size_t)layer];
+        if (which == "qkv0") w = lw.q_qkv[0];
+        else if (which == "qkv1" && lw.n_qkv > 1) w = lw.q_qkv[1];
+        else if (which == "qkv2" && lw.n_qkv > 2) w = lw.q_qkv[2];
+        else if (which == "o") w = lw.q_o;
+        else if (which == "gate_up") w = lw.q_gate_up;
+        else if (which == "gate") w = lw.q_gate;
+        else if (which == "up") w = lw.q_up;
+        else if (which == "down") w = lw.q_down;
+    }
+    if (w.fmt == QFMT_NONE) throw CmError(CM_ERR_INVALID, "no such quantised projection: " + which);
+    if ((size_t)w.K != k || (size_t)w.N != n || m < 1) throw CmError(CM_ERR_RANGE, "debug_qgemm: expected k=" + std::to_string(w.K) + " n=" + std::to_string(w.N));
+    if (!gemm_q8_ok(w, (int)m)) throw CmError(CM_ERR_UNSUPPORTED, "debug_qgemm: this projection is not on the int8-MFMA GEMM (format / shape)");
+    ensure_gemm_workspace();
+    const int xs = m > (size_t)QGEMM_MAXM ? (int)((m + 255) / 256 * 256) : (int)QGEMM_MAXM;
+    float *dx = nullptr, *dy = nullptr, *dsc = nullptr;
+    signed char* dq = nullptr;
+    CM_HIP(hipMalloc((void**)&dx, m * k * sizeof(float)));
+    CM_HIP(hipMalloc((void**)&dy, m * n * sizeof(float)));
+    CM_HIP(hipMalloc((void**)&dq, m * (k + k / 4) + 256));
+    CM_HIP(hipMalloc((void**)&dsc, ((k / 128) * 5 + k / 32 + 8) * (size_t)xs * sizeof(float)));
+    CM_HIP(hipMemcpyAsync(dx, xh, m * k * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (w.fmt == QFMT_Q4_K) launch_quant_rows_q8k(dx, (int)k, nullptr, cfg.eps, dq, dsc, (int)m, (int)k, stream, xs);
+    else launch_quant_rows_q8(dx, (int)k, nullptr, cfg.eps, dq, dsc, (int)m, (int)k, stream, xs);
+    QGemmArgs qg{};
+    qg.w = w; qg.xq = dq; qg.xd = dsc; qg.M = (int)m; qg.xs = xs;
+    const bool ok = launch_gemm_q8(qg, EPI_STORE, dy, (int)n, pWS, gemm_ws_floats, num_cu, stream);
+    if (ok) CM_HIP(hipMemcpyAsync(yh, dy, m * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CM_HIP(hipStreamSynchronize(stream));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dq); (void)hipFree(dsc);
+    if (!ok) throw CmError(CM_ERR_UNSUPPORTED, "debug_qgemm: launch refused");
 }
 
 void Model::debug_qgemv(int layer, const std::string& which, const float* xh, size_t k, float* yh, size_t n) {

@@ -328,6 +328,7 @@ struct Model {
     float* gu_tmp = nullptr;           // [2 I] scratch when gate / up have different ggml types
     uint64_t quant_weight_bytes = 0;   // bytes of every quantised matrix read once per decoded token
     void debug_qgemv(int layer, const std::string& which, const float* x, size_t k, float* y, size_t n);
+    void debug_qgemm(int layer, const std::string& which, const float* x, size_t m, size_t k, float* y, size_t n);
     void isq_q8_0(int mode = 8);       // in-situ quantisation of the loaded bf16 linears (ops/linear.rs:83-116): 8 Q8_0; 4 / 5 the Q4_0 / Q5_0
                                        // reference quantisers, stored in the Q8_0 layout (exact: q - 8 / q - 16 are int8 codes)
     void dfree(void* p);

@@ -476,6 +476,12 @@ int cm_debug_read(cm_model* m, const char* what, float* out, size_t n);
  * 2j = gate_j, 2j+1 = up_j) | "gate" | "up", "down", "lm_head".  Kernel-level parity hook for tests. */
 int cm_debug_qgemv(cm_model* m, int32_t layer, const char* which, const float* x, size_t k, float* y, size_t n);
 
+/* The same for `rows` activation rows x [rows][k] through the int8-MFMA GEMM that decode groups and prompt passes use
+ * (csrc/kernels_quant_gemm.hip: row quantiser of the weight's vec-dot type -- Q8_0 blocks for Q8_0-layout weights, Q8_K blocks for
+ * Q4_K -- then the GEMM, plain input, store epilogue): y [rows][n].  The batched counterpart of `QMatMul::forward` on a [rows, k]
+ * input (candle quantized matmul behind ops/linear.rs:18-51).  CM_ERR_UNSUPPORTED for tensors that are not on that path (Q6_K). */
+int cm_debug_qgemm(cm_model* m, int32_t layer, const char* which, const float* x, size_t rows, size_t k, float* y, size_t n);
+
 /* Test hook: the peer-store all-reduce / all-gather of an in-process group alone (csrc/kernels_tp.hip): n_ranks threads on
  * `device`, |iters| rounds over `count` elements, every sum and gather checked on the host; iters < 0 starts the ranks' epoch
  * counter at 0xFFFFFFFD so that the rounds cross its 32-bit wrap.  Returns the number of wrong elements (0 = pass), < 0 on error

@@ -520,6 +520,89 @@ def test_prompt_pass_on_the_int8_matrix_cores_and_the_attention_quantiser_agains
         m.close()
 
 
+def test_q4_k_rows_on_the_int8_matrix_cores_against_the_oracle_vecdot(tmp_path):
+    """Q4_K weights on the int8-MFMA GEMM (round 6, gemm_q4k_i8_kernel: sub-blocks as Q8_0-shaped blocks with f32 scales d * sc_j, the
+    min term as two virtual blocks over the base-128 digits of the activation's 32-code sums, 4-bit codes expanded on the way into
+    LDS; activation rows as Q8_K blocks from quant_rows_q8k_kernel) -- kernel level, through cm_debug_qgemm: rows [M, K] of random
+    inputs with very different row / block magnitudes against ggml_vec_dot_q4_K_q8_K restated in oracle/gguf_oracle.py
+    (QuantMatrix.vecdot: quantize_row_q8_K + integer sub-block sums), every row, every geometry of the kernel (M = 5 / 40 / 100 / 128
+    rows per workgroup tile, 200 / 300: the 256-row prompt geometry with one and two m-panels), K = 1024 / 2048 / 3072 (K split),
+    merged q|k|v rows and interleaved gate / up rows: 2e-5 of the row's range -- and row 0 against the integer-dot GEMV of the decode step."""
+    from crane_amd.backend import Model
+    cfg = dict(configs.get_config("qwen3-0.6b-2l"), vocab_size=4096)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / "q4k.gguf")
+    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types("q4_k"), want_qmats=True)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    P = "model.layers.1."
+    m = Model.from_pretrained(path, max_seq_len=256, max_seqs=2)
+    try:
+        rng = np.random.default_rng(11)
+        specs = {"qkv0": ([P + f"self_attn.{n}_proj.weight" for n in "qkv"], H, False),
+                 "o": ([P + "self_attn.o_proj.weight"], deq[P + "self_attn.o_proj.weight"].shape[1], False),
+                 "gate_up": ([P + "mlp.gate_proj.weight", P + "mlp.up_proj.weight"], H, True),
+                 "down": ([P + "mlp.down_proj.weight"], I, False)}
+        worst = 0.0
+        for rows in (5, 40, 100, 128, 200, 300):
+            for which, (names, K, interleave) in specs.items():
+                x = (rng.standard_normal((rows, K)) * np.exp(rng.standard_normal((rows, 1))) *
+                     np.repeat(np.exp(0.5 * rng.standard_normal((rows, K // 256))), 256, axis=1)).astype(np.float32)
+                parts = [np.stack([qm[n].vecdot(x[i]) for i in range(rows)]) for n in names]
+                if interleave:
+                    want = np.empty((rows, 2 * parts[0].shape[1]), np.float32)
+                    want[:, 0::2], want[:, 1::2] = parts[0], parts[1]
+                else:
+                    want = np.concatenate(parts, axis=1)
+                got = m.debug_qgemm(1, which, x, want.shape[1])
+                for i in range(rows):
+                    e = rel(got[i], want[i]); worst = max(worst, e)
+                    assert e < 2e-5, (rows, which, i, e)
+                v0 = m.debug_qgemv(1, which, x[0], want.shape[1])
+                assert rel(got[0], v0) < 2e-5, (rows, which, rel(got[0], v0))
+        print(f"q4_k int8 GEMM rows: worst {worst:.2e}")
+    finally:
+        m.close()
+
+
+def test_q4_k_checkpoint_prompt_pass_and_decode_groups_on_the_int8_matrix_cores(tmp_path):
+    """End to end over a Q4_K GGUF checkpoint at the Qwen3-0.6B widths (2 layers): the prompt pass (one Q8_K quantiser + one
+    gemm_q4k_i8_kernel launch per projection, 200 rows = the 256-row geometry) and a 16-sequence decode round (the 128-row-class
+    geometries) against the oracle with ggml's integer-dot semantics (oracle.qmats: quantize_row_q8_K + vec_dot_q4_K_q8_K per
+    linear), and against the handle's own single-sequence integer-dot GEMVs.  The kernel-level test above holds every row to 2e-5;
+    end to end an activation code on a rounding boundary may flip between two correct implementations (the documented 3e-2 of the
+    GGUF tests), so this is the plumbing check: formats routed to the right quantiser, codes re-made when consecutive projections
+    differ in kind, K / V written by the pass read by the round."""
+    from crane_amd.backend import Model
+    cfg = dict(configs.get_config("qwen3-0.6b-2l"), vocab_size=4096)
+    w = synth.synth_weights_f32(cfg, seed=0)
+    path = str(tmp_path / "q4k-e2e.gguf")
+    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types("q4_k"), want_qmats=True)
+    deq["lm_head.weight"] = deq["model.embed_tokens.weight"]
+    V = cfg["vocab_size"]
+    oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)
+    oracle.qmats = G.qwen3_oracle_qmats(cfg, qm)
+    ids = configs.synthetic_prompt(200, V)
+    ref = oracle.forward(ids, 0)
+    m = Model.from_pretrained(path, max_seq_len=256, max_seqs=36, kv_dtype="f32")
+    try:
+        got = m.forward_step(ids, 0).reshape(-1)
+        assert rel(got, ref) < 3e-2, rel(got, ref)
+        seqs, twins = [], []
+        for b in range(16):
+            s = m.seq_alloc()
+            m.seq_forward(s, [(7 * i + 3 + 11 * b) % V for i in range(20 + b)], 0, want_logits=False)
+            seqs.append(s); twins.append(m.seq_fork(s))
+        toks = [(5 + 3 * b) % V for b in range(16)]
+        a, ga = m.step_batch_decode(seqs, toks)                       # int8 matrix cores (16 >= q_gemm_min)
+        m.debug_set("q_gemm_min", 0)
+        b_, gb = m.step_batch_decode(twins, toks)                     # batched integer-dot GEMV (bit-equal to the single-sequence step)
+        for i in range(16):
+            assert rel(a[i, 0], b_[i, 0]) < 3e-2, (i, rel(a[i, 0], b_[i, 0]))
+        assert int((ga == gb).sum()) >= 13
+    finally:
+        m.close()
+
+
 def test_hybrid_family_prompt_pass_and_decode_groups_on_the_int8_matrix_cores_against_the_oracle():
     """Qwen3.5 over ISQ Q8_0 weights at the 0.8B widths (4 layers: 3 Gated-Delta-Net + 1 gated attention; hidden 1024, 16 value heads
     of 128, head_dim 256): round 6 moved the family's quantised projections onto the int8 matrix cores -- in_proj_qkv / in_proj_z /

@@ -50,5 +50,28 @@ for nseq in (2, 4, 8):
     dt = time.perf_counter() - t0
     print(f"{kind} {L}-layer batch {nseq}: {dt / K * 1e6:8.1f} us/step", flush=True)
     for s in seqs: m.seq_free(s)
+# large decode groups and a prompt pass: Q8_0-layout and Q4_K tensors take the int8 matrix cores (kernels_quant_gemm.hip; round 6: Q4_K),
+# everything else the batched GEMV in steps of 8 .. 64 rows / the dequantised bf16 hi + lo GEMMs.  CM_Q_GEMM_MIN=0 python ... : A/B
+for nseq in (16, 64, 128):
+    m2 = Model.from_pretrained(path, max_seq_len=512, max_seqs=nseq + 2)
+    seqs = []
+    for i in range(nseq):
+        s = m2.seq_alloc(); m2.seq_forward(s, ids[:64 + (i % 16)], 0, want_logits=False); seqs.append(s)
+    toks = [5 + i for i in range(nseq)]
+    for _ in range(3):
+        _, g = m2.step_batch_decode(seqs, toks, want_logits=False); toks = [int(t) for t in g]
+    t0 = time.perf_counter(); K = 16
+    for _ in range(K):
+        _, g = m2.step_batch_decode(seqs, toks, want_logits=False); toks = [int(t) for t in g]
+    dt = time.perf_counter() - t0
+    print(f"{kind} {L}-layer group of {nseq}: {dt / K * 1e6:8.1f} us/round = {dt / K / L * 1e6:7.1f} us per layer", flush=True)
+    m2.close()
+m3 = Model.from_pretrained(path, max_seq_len=2112, max_seqs=2)
+for n in (128, 1024, 2048):
+    p = [(7 * i + 3) % cfg["vocab_size"] for i in range(n)]
+    m3.clear_kv_cache(); m3.forward_step_greedy(p, 0); m3.clear_kv_cache()
+    t0 = time.perf_counter(); m3.forward_step_greedy(p, 0); dt = time.perf_counter() - t0
+    print(f"{kind} {L}-layer prompt {n}: {dt * 1e3:7.2f} ms = {dt / L * 1e6:7.1f} us per layer", flush=True)
+m3.close()
 m.close()
 os.remove(path)
