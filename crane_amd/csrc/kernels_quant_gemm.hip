@@ -661,6 +661,202 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q4k_i8_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Q6_K weights (ggml_vec_dot_q6_K_q8_K: sumf += d_x d * sum_j sc_j ((q6_j - 32) . q8_j) over the SIXTEEN 16-element sub-blocks of a
+// 256-block, sc_j int8) on the same path.  A sub-block is half of the 32-deep MFMA step, so the steps here are
+// v_mfma_i32_32x32x16_i8: 8 per K group of 128 elements, fragments of 8 bytes per lane (ds_read_b64; panel rows 136 bytes apart: the
+// 32 rows of a read land on 32 distinct 8-byte slots), weight scale d * sc_j (exact in f32) per step, activation scale d_x.  The 6-bit
+// codes are assembled from ql / qh and re-centred (- 32) on their way into the LDS panel; the activation rows are the SAME Q8_K groups
+// the Q4_K kernel reads (their digit block is not used here), so a Q4_K and a Q6_K projection of one input share one quantiser launch.
+// Twice the VALU work of a Q8_0 tensor per weight (a scaling pass per 16 instead of per 32): format coverage -- what makes a Q4_K_M
+// file (Q4_K + Q6_K tensors) run end to end on the matrix cores -- not the format's best.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int MH, int MT>
+__global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q6k_i8_kernel(QGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    constexpr int ROWB = 136;                           // bytes of a panel row in LDS (128 codes + 8)
+    constexpr int NT = 256 * MH, PR = 32 * MT * MH, NS = 8 * MT;
+    constexpr int NCH = PR * 8 / NT;                    // 16-byte chunks of the activation panel of a group, per thread
+    constexpr int NWC = 128 * 4 / NT;                   // weight pieces (8 values of l: 3 x 8 bytes -> 32 codes) per thread
+    constexpr int PANEL = PR * ROWB, WPANEL = 128 * ROWB;
+    constexpr int XM = PR > QGEMM_MAXM ? PR : QGEMM_MAXM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, ns = wave & 3, mh = wave >> 2;
+    const int K = a.w.K, N = a.w.N, nb256 = K >> 8, G = K >> 7;
+    float* xds = (float*)qlds;                                              // [2][XM] the group's activation scale (one per 256-block)
+    float* dwl = xds + 2 * XM + wave * (8 * 32);                            // [8][32] this wave's weight scales of the group
+    unsigned char* Ws = qlds + (size_t)(2 * XM + 4 * MH * 8 * 32) * sizeof(float);
+    unsigned char* As = Ws + 2 * WPANEL;
+    const int tiles = N / 128;
+    const int per = tiles * a.mpan;
+    const int ks = (int)blockIdx.x / per, rem = (int)blockIdx.x % per;
+    int tn, mp;
+    if (a.mpan > 1 && (tiles & 7) == 0) { const int xcd = rem & 7, idx = rem >> 3; tn = (idx / a.mpan) * 8 + xcd; mp = idx % a.mpan; }
+    else { tn = rem % tiles; mp = rem / tiles; }
+    const int m_base = mp * PR;
+    const int g0 = ks * G / a.ksplit, ngrp = (ks + 1) * G / a.ksplit - g0;
+    // weight pieces: c = tid + NT i: row c / 4, l = 8 (c % 4) .. + 7 of the group's half-block
+    const uint8_t *wql[NWC], *wqh[NWC];
+    int wdst[NWC];
+#pragma unroll
+    for (int i = 0; i < NWC; ++i) {
+        const int c = tid + NT * i, row = c >> 2, q = c & 3;
+        wql[i] = a.w.p0 + (size_t)(tn * 128 + row) * (K >> 1) + (size_t)g0 * 64 + 8 * q;
+        wqh[i] = a.w.p1 + (size_t)(tn * 128 + row) * (K >> 2) + (size_t)g0 * 32 + 8 * q;
+        wdst[i] = row * ROWB + 8 * q;
+    }
+    const int8_t* sc_row = (const int8_t*)a.w.p2 + (size_t)(tn * 128 + ns * 32 + r) * (K >> 4);      // 8 int8 scales per group
+    const uint16_t* d_row = (const uint16_t*)a.w.p3 + (size_t)(tn * 128 + ns * 32 + r) * nb256;
+    const signed char* xsrc[NCH];
+    int xdst[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + NT * i, row = c >> 3, q = c & 7;
+        xsrc[i] = a.xq + (size_t)min(m_base + row, a.M - 1) * (size_t)G * QKROW + (size_t)g0 * QKROW + 16 * q;
+        xdst[i] = row * ROWB + 16 * q;
+    }
+    u32x2 wa[NWC], wb[NWC], wh[NWC];
+    u32x4 areg[NCH];
+    u32x2 screg; uint32_t dreg = 0;
+    float xreg = 0.f;
+    const float* xdp = a.xd + (size_t)g0 * QKB * a.xs + m_base + (tid % XM);      // scale 0 of a group's five = d_x
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            wa[i] = *(const u32x2*)(wql[i] + (size_t)g * 64);
+            wb[i] = *(const u32x2*)(wql[i] + (size_t)g * 64 + 32);
+            wh[i] = *(const u32x2*)(wqh[i] + (size_t)g * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)(xsrc[i] + (size_t)g * QKROW);
+        screg = *(const u32x2*)(sc_row + (size_t)(g0 + g) * 8);
+        dreg = d_row[(g0 + g) >> 1];
+        if (tid < XM) xreg = xdp[(size_t)g * QKB * a.xs];
+    };
+    auto recentre = [](uint32_t c) -> uint32_t { return ((c | 0x80808080u) - 0x20202020u) ^ 0x80808080u; };      // bytewise c - 32 (c in 0 .. 63)
+    auto store_group = [&](int buf) {
+        unsigned char* Wn = Ws + buf * WPANEL;
+        unsigned char* An = As + buf * PANEL;
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            u32x2 c0, c1, c2, c3;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t A = wa[i][e], B = wb[i][e], Hq = wh[i][e];
+                c0[e] = recentre((A & 0x0F0F0F0Fu) | ((Hq & 0x03030303u) << 4));
+                c1[e] = recentre((B & 0x0F0F0F0Fu) | (((Hq >> 2) & 0x03030303u) << 4));
+                c2[e] = recentre(((A >> 4) & 0x0F0F0F0Fu) | (((Hq >> 4) & 0x03030303u) << 4));
+                c3[e] = recentre(((B >> 4) & 0x0F0F0F0Fu) | (((Hq >> 6) & 0x03030303u) << 4));
+            }
+            *(u32x2*)(Wn + wdst[i]) = c0; *(u32x2*)(Wn + wdst[i] + 32) = c1; *(u32x2*)(Wn + wdst[i] + 64) = c2; *(u32x2*)(Wn + wdst[i] + 96) = c3;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {             // (rows are 136 bytes apart: 8-byte aligned pieces)
+            *(u32x2*)(An + xdst[i]) = (u32x2){areg[i][0], areg[i][1]};
+            *(u32x2*)(An + xdst[i] + 8) = (u32x2){areg[i][2], areg[i][3]};
+        }
+        if (tid < XM) xds[buf * XM + tid] = xreg;
+    };
+    auto put_dw = [&]() {                               // lane (r, h) writes the scales of sub-blocks 4 h .. 4 h + 3 of the group
+        const float d = f16bits(dreg);
+        const uint32_t w = screg[h];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dwl[(4 * h + e) * 32 + r] = d * (float)(int)(signed char)((w >> (8 * e)) & 0xFFu);
+    };
+    load_group(0);
+    store_group(0); put_dw();
+    f32x2 acc[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[mt][i] = (f32x2){0.f, 0.f};
+    __syncthreads();
+    const int wrow = (ns * 32 + r) * ROWB + 8 * h;
+    const int arow = (mh * MT * 32 + r) * ROWB + 8 * h;
+    const int xrow = mh * MT * 32 + r;
+    for (int g = 0; g < ngrp; ++g) {
+        const bool more = g + 1 < ngrp;
+        if (more) load_group(g + 1);
+        const unsigned char* Wp = Ws + (g & 1) * WPANEL + wrow;
+        const unsigned char* Ap = As + (g & 1) * PANEL + arow;
+        float dxm[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dxm[mt] = xds[(g & 1) * XM + xrow + mt * 32];
+        u32x2 avq[2], wfq[2];
+        i32x16 cq[2];
+        f32x4 dwq[4];
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define Q6_LOAD(s_, slot_) avq[slot_] = *(const u32x2*)(Ap + ((s_) % MT) * 32 * ROWB + ((s_) / MT) * 16)
+#define Q6_MFMA(s_, slot_) cq[slot_] = __builtin_amdgcn_mfma_i32_32x32x16_i8( \
+            __builtin_bit_cast(long, wfq[((s_) / MT) & 1]), __builtin_bit_cast(long, avq[slot_]), zero, 0, 0, 0)
+        wfq[0] = *(const u32x2*)Wp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + 8 * q + 4 * h);
+        Q6_LOAD(0, 0);
+        Q6_LOAD(1, 1);
+        if (MT == 1) wfq[1] = *(const u32x2*)(Wp + 16);
+        Q6_MFMA(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sl = s & 1, mt = s % MT, j = s / MT;
+            if (MT > 1 && mt == 0 && j + 1 < 8) wfq[(j + 1) & 1] = *(const u32x2*)(Wp + (j + 1) * 16);
+            if (s + 1 < NS) Q6_MFMA(s + 1, sl ^ 1);
+            if (MT == 1 && j + 2 < 8) wfq[j & 1] = *(const u32x2*)(Wp + (j + 2) * 16);
+            if (s + 2 < NS) Q6_LOAD(s + 2, sl);
+            __builtin_amdgcn_sched_barrier(0);
+            const float dx = dxm[mt];
+            f32x2 sv[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sv[p] = (f32x2){dwq[p >> 1][2 * (p & 1)], dwq[p >> 1][2 * (p & 1) + 1]} * (f32x2){dx, dx};
+            if (mt == MT - 1 && j + 1 < 8) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(sv[p]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + (j + 1) * 32 + 8 * q + 4 * h);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const f32x2 cf = (f32x2){(float)cq[sl][2 * p], (float)cq[sl][2 * p + 1]};
+                acc[mt][p] = __builtin_elementwise_fma(sv[p], cf, acc[mt][p]);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(acc[mt][p]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef Q6_LOAD
+#undef Q6_MFMA
+        if (more) { store_group((g + 1) & 1); put_dw(); }
+        __syncthreads();
+    }
+    float* P = a.ws + (size_t)ks * a.slice;
+    const int nq = tn * 128 + ns * 32 + 4 * h;
+    constexpr int TS = 68;
+    float* T = (float*)Ws;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ml = (mh * MT + mt) * 32 + r, m = m_base + ml;
+        if (a.silu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g0v = acc[mt][2 * q][0], u0 = acc[mt][2 * q][1], g1v = acc[mt][2 * q + 1][0], u1 = acc[mt][2 * q + 1][1];
+                const f32x2 o = (f32x2){(g0v / (1.0f + expf(-g0v))) * u0, (g1v / (1.0f + expf(-g1v))) * u1};
+                *(f32x2*)(T + ml * TS + ns * 16 + 2 * h + 4 * q) = o;
+            }
+        } else if (m < a.M) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)(P + (size_t)m * a.ldp + nq + 8 * q) = (f32x4){acc[mt][2 * q][0], acc[mt][2 * q][1], acc[mt][2 * q + 1][0], acc[mt][2 * q + 1][1]};
+        }
+    }
+    if (a.silu) {
+        __syncthreads();
+        for (int it = tid; it < PR * 16; it += NT) {
+            const int row = it >> 4, c4 = it & 15;
+            if (m_base + row < a.M) *(f32x4*)(P + (size_t)(m_base + row) * a.ldp + tn * 64 + 4 * c4) = *(const f32x4*)(T + row * TS + 4 * c4);
+        }
+    }
+}
+
 // slices added in the order 0, 1, ...; 4 consecutive columns of a row per thread.  EPI_STORE / EPI_RESADD: y[m][n] (+)= v;
 // EPI_SILUMUL: columns (gate_j, up_j) interleaved -> y[m][n / 2] = silu(gate) * up (the GEMV epilogue's expression)
 template <int EPI, int KS>
@@ -861,7 +1057,7 @@ static void launch_q8_epilogue(const float* ws, int M, int N, int ks, float* y, 
 }
 
 bool gemm_q8_ok(const QWeight& w, int M) {
-    return (w.fmt == QFMT_Q8_0 || w.fmt == QFMT_Q4_K) && M >= 1 && M <= QGEMM_BIGM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
+    return (w.fmt == QFMT_Q8_0 || w.fmt == QFMT_Q4_K || w.fmt == QFMT_Q6_K) && M >= 1 && M <= QGEMM_BIGM && w.N % 128 == 0 && w.K % (32 * QG_MIN) == 0;
 }
 
 // y (+)= dequant(W) . dequant(xq)^T over the group's rows; epi = EPI_STORE | EPI_RESADD | EPI_SILUMUL (GEMV epilogue codes).
@@ -884,7 +1080,7 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
     // a CU held one 4-wave workgroup, one wave per SIMD.  CM_QGEMM_QG_SMALL = 8: A/B)
     static const int qg_small = getenv("CM_QGEMM_QG_SMALL") && atoi(getenv("CM_QGEMM_QG_SMALL")) == 8 ? 8 : 4;
     p.mh = geo == 1 || geo == 3 || geo == 4 ? 2 : 1; p.mt = geo == 2 || geo == 4 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : geo == 1 ? 8 : qg_small;
-    if (fmt == QFMT_Q4_K) {      // groups of half a 256-block (4 sub-blocks + 1 virtual block); geometries <1,1> <1,2> <2,2> <2,4>
+    if (fmt == QFMT_Q4_K || fmt == QFMT_Q6_K) {      // groups of half a 256-block (Q4_K: 4 sub-blocks + 1 virtual block; Q6_K: 8 sub-blocks of 16); geometries <1,1> <1,2> <2,2> <2,4>
         p.qg = 4;
         if (geo != 4) { p.mh = M > 64 ? 2 : 1; p.mt = M > 32 ? 2 : 1; }
     }
@@ -895,6 +1091,10 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
     p.lds = (size_t)(2 * p.qg * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (p.qg * 32 + 16);
     if (fmt == QFMT_Q4_K)
         p.lds = (size_t)(2 * QKB * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * QKB * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (QKROW + 16);
+    if (fmt == QFMT_Q6_K)
+        p.lds = (size_t)(2 * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * 8 * 32) * sizeof(float) + (size_t)2 * (128 + pr) * 136;
+    // (the SiLU tile of an unsplit gate|up launch lives in the panels: [rows][68] floats)
+    p.lds = std::max(p.lds, (size_t)(2 * QKB * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * QKB * 32) * sizeof(float) + (size_t)pr * 68 * 4);
     const int cap = num_cu * (p.mh == 2 ? 1 : 2);
     const double tgroup_us = geo == 4 ? 4.0 : 2.0, fill_us = 2.5, part_us = 8.0 * M * N / 3.0e6;        // (partials at ~3 TB/s, write + read)
     int ks = 1;
@@ -926,8 +1126,8 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
     if (defer) { defer->ks = 1; defer->slice = 0; defer->ws = nullptr; }
     if (fused) *fused = 0;
     if (!gemm_q8_ok(a.w, a.M)) return false;
-    const bool q4k = a.w.fmt == QFMT_Q4_K;
-    if (q4k) next = nullptr;      // (the fused quantisers write Q8_0 blocks; a K-quant consumer takes Q8_K rows: its own quantiser launch)
+    const bool q4k = a.w.fmt == QFMT_Q4_K, q6k = a.w.fmt == QFMT_Q6_K;
+    if (q4k || q6k) next = nullptr;      // (the fused quantisers write Q8_0 blocks; a K-quant consumer takes Q8_K rows: its own quantiser launch)
     const QGemmPlan pl = plan_gemm_q8(a.M, a.w.N, a.w.K, epi, ws != nullptr, ws_floats, num_cu, a.w.fmt);
     if (!pl.ok) return false;
     const int N = a.w.N, tiles = (N / 128) * pl.mpan, mh = pl.mh, mt = pl.mt, geo = pl.geo;
@@ -960,9 +1160,19 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     const dim3 grid(tiles * ks), block(256 * mh);
-    if (q4k) {
+    if (q6k) {
+        if (mh == 2 && mt == 4) hipLaunchKernelGGL((gemm_q6k_i8_kernel<2, 4>), grid, block, lds, s, a);
+        else if (mh == 2) hipLaunchKernelGGL((gemm_q6k_i8_kernel<2, 2>), grid, block, lds, s, a);
+        else if (mt == 2) hipLaunchKernelGGL((gemm_q6k_i8_kernel<1, 2>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((gemm_q6k_i8_kernel<1, 1>), grid, block, lds, s, a);
+    }
+    else if (q4k) {
         if (mh == 2 && mt == 4) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 4>), grid, block, lds, s, a);
         else if (mh == 2) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 2>), grid, block, lds, s, a);
         else if (mt == 2) hipLaunchKernelGGL((gemm_q4k_i8_kernel<1, 2>), grid, block, lds, s, a);

@@ -1218,7 +1218,7 @@ void Model::prefill_layers(int S, const PrefillSeg* segs, int nseg, size_t off) 
     // the rows currently held as codes: (source, norm weight, K, kind: 0 = Q8_0 blocks, 1 = Q8_K groups for Q4_K weights)
     const float* q8_src = nullptr; const float* q8_nw = nullptr; int q8_K = 0, q8_kind = -1;
     auto q8_in = [&](const QWeight& qw, const float* xin, int ldx, const float* nw, int m) {
-        const int kind = qw.fmt == QFMT_Q4_K ? 1 : 0;
+        const int kind = (qw.fmt == QFMT_Q4_K || qw.fmt == QFMT_Q6_K) ? 1 : 0;
         if (q8_src == xin && q8_nw == nw && q8_K == qw.K && q8_kind == kind) return;
         if (kind) launch_quant_rows_q8k(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, qw.K, s, xs8);
         else launch_quant_rows_q8(xin, ldx, nw, cfg.eps, qx_codes, qx_scales, m, qw.K, s, xs8);
@@ -1604,7 +1604,7 @@ void Model::lm_head_rows(int nb, bool want_rows) {
         gemm_q8_ok(q_lm_head.rows(0, v_eff), nb)) {
         // large groups over a Q8_0-layout head: one int8-MFMA pass over the table (kernels_quant_gemm.hip; the rows are written in
         // place, the table's 1187 column tiles fill the chip unsplit) + the row arg-max of the bf16 GEMM branch below
-        if (q_lm_head.fmt == QFMT_Q4_K) launch_quant_rows_q8k(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s);
+        if (q_lm_head.fmt == QFMT_Q4_K || q_lm_head.fmt == QFMT_Q6_K) launch_quant_rows_q8k(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s);
         else { launch_quant_rows_q8(xb, H, norm, cfg.eps, qx_codes, qx_scales, nb, H, s); if (q_capture) q_capture_rows(nb, H); }
         QGemmArgs qg{};
         qg.w = q_lm_head.rows(0, v_eff); qg.xq = qx_codes; qg.xd = qx_scales; qg.M = nb;
@@ -1835,7 +1835,7 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
             if (defer) { defer->ks = 1; defer->slice = 0; defer->ws = nullptr; }
             if (qgemm_ok && nb >= q_gemm_min && (epi == EPI_STORE || epi == EPI_RESADD || epi == EPI_SILUMUL) && gemm_q8_ok(qw, nb)) {
                 const float* nwe = pro == PRO_RMSNORM ? nw : nullptr;
-                const int kind = qw.fmt == QFMT_Q4_K ? 1 : 0;
+                const int kind = (qw.fmt == QFMT_Q4_K || qw.fmt == QFMT_Q6_K) ? 1 : 0;
                 if (qx_src != xin || qx_nw != nwe || qx_K != qw.K || qx_kind != kind) {
                     if (kind) launch_quant_rows_q8k(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
                     else launch_quant_rows_q8(xin, ldx, nwe, cfg.eps, qx_codes, qx_scales, nb, qw.K, s);
@@ -2351,7 +2351,7 @@ void Model::debug_qgemm(int layer, const std::string& which, const float* xh, si
     CM_HIP(hipMalloc((void**)&dq, m * (k + k / 4) + 256));
     CM_HIP(hipMalloc((void**)&dsc, ((k / 128) * 5 + k / 32 + 8) * (size_t)xs * sizeof(float)));
     CM_HIP(hipMemcpyAsync(dx, xh, m * k * sizeof(float), hipMemcpyHostToDevice, stream));
-    if (w.fmt == QFMT_Q4_K) launch_quant_rows_q8k(dx, (int)k, nullptr, cfg.eps, dq, dsc, (int)m, (int)k, stream, xs);
+    if (w.fmt == QFMT_Q4_K || w.fmt == QFMT_Q6_K) launch_quant_rows_q8k(dx, (int)k, nullptr, cfg.eps, dq, dsc, (int)m, (int)k, stream, xs);
     else launch_quant_rows_q8(dx, (int)k, nullptr, cfg.eps, dq, dsc, (int)m, (int)k, stream, xs);
     QGemmArgs qg{};
     qg.w = w; qg.xq = dq; qg.xd = dsc; qg.M = (int)m; qg.xs = xs;

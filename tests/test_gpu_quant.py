@@ -21,6 +21,12 @@ def _types(kind):
     if kind in ("q8_0", "q4_k", "q6_k", "q4_0", "q5_0"):
         t = G.TYPE_NAMES[kind]
         return lambda name, shape: t
+    if kind == "q4_k_m":             # llama.cpp's Q4_K_M recipe in outline: Q6_K for attn_v, ffn_down, the embedding / head; Q4_K for the rest
+        def q4km(name, shape):
+            if "attn_v" in name or "ffn_down" in name or name in ("token_embd.weight", "output.weight"):
+                return G.GGML_Q6_K
+            return G.GGML_Q4_K
+        return q4km
     if kind == "legacy-mixed":       # Q4_0 projections, Q5_0 value / up / embedding rows, Q8_0 head: the legacy 32-weight formats together
         def legacy(name, shape):
             if "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
@@ -520,19 +526,22 @@ def test_prompt_pass_on_the_int8_matrix_cores_and_the_attention_quantiser_agains
         m.close()
 
 
-def test_q4_k_rows_on_the_int8_matrix_cores_against_the_oracle_vecdot(tmp_path):
+@pytest.mark.parametrize("kind", ["q4_k", "q6_k"])
+def test_q4_k_rows_on_the_int8_matrix_cores_against_the_oracle_vecdot(tmp_path, kind):
     """Q4_K weights on the int8-MFMA GEMM (round 6, gemm_q4k_i8_kernel: sub-blocks as Q8_0-shaped blocks with f32 scales d * sc_j, the
     min term as two virtual blocks over the base-128 digits of the activation's 32-code sums, 4-bit codes expanded on the way into
     LDS; activation rows as Q8_K blocks from quant_rows_q8k_kernel) -- kernel level, through cm_debug_qgemm: rows [M, K] of random
     inputs with very different row / block magnitudes against ggml_vec_dot_q4_K_q8_K restated in oracle/gguf_oracle.py
     (QuantMatrix.vecdot: quantize_row_q8_K + integer sub-block sums), every row, every geometry of the kernel (M = 5 / 40 / 100 / 128
     rows per workgroup tile, 200 / 300: the 256-row prompt geometry with one and two m-panels), K = 1024 / 2048 / 3072 (K split),
-    merged q|k|v rows and interleaved gate / up rows: 2e-5 of the row's range -- and row 0 against the integer-dot GEMV of the decode step."""
+    merged q|k|v rows and interleaved gate / up rows: 2e-5 of the row's range -- and row 0 against the integer-dot GEMV of the decode step.
+    q6_k: gemm_q6k_i8_kernel (16-element sub-blocks on v_mfma_i32_32x32x16_i8, 6-bit codes assembled from ql / qh and re-centred on the
+    way into LDS) against vec_dot_q6_K_q8_K, the same rows."""
     from crane_amd.backend import Model
     cfg = dict(configs.get_config("qwen3-0.6b-2l"), vocab_size=4096)
     w = synth.synth_weights_f32(cfg, seed=0)
-    path = str(tmp_path / "q4k.gguf")
-    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types("q4_k"), want_qmats=True)
+    path = str(tmp_path / f"{kind}.gguf")
+    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types(kind), want_qmats=True)
     H, I = cfg["hidden_size"], cfg["intermediate_size"]
     P = "model.layers.1."
     m = Model.from_pretrained(path, max_seq_len=256, max_seqs=2)
@@ -559,13 +568,14 @@ def test_q4_k_rows_on_the_int8_matrix_cores_against_the_oracle_vecdot(tmp_path):
                     assert e < 2e-5, (rows, which, i, e)
                 v0 = m.debug_qgemv(1, which, x[0], want.shape[1])
                 assert rel(got[0], v0) < 2e-5, (rows, which, rel(got[0], v0))
-        print(f"q4_k int8 GEMM rows: worst {worst:.2e}")
+        print(f"{kind} int8 GEMM rows: worst {worst:.2e}")
     finally:
         m.close()
 
 
-def test_q4_k_checkpoint_prompt_pass_and_decode_groups_on_the_int8_matrix_cores(tmp_path):
-    """End to end over a Q4_K GGUF checkpoint at the Qwen3-0.6B widths (2 layers): the prompt pass (one Q8_K quantiser + one
+@pytest.mark.parametrize("kind", ["q4_k", "q4_k_m"])
+def test_q4_k_checkpoint_prompt_pass_and_decode_groups_on_the_int8_matrix_cores(tmp_path, kind):
+    """End to end over a Q4_K / Q4_K_M-style (Q4_K + Q6_K tensors) GGUF checkpoint at the Qwen3-0.6B widths (2 layers): the prompt pass (one Q8_K quantiser + one
     gemm_q4k_i8_kernel launch per projection, 200 rows = the 256-row geometry) and a 16-sequence decode round (the 128-row-class
     geometries) against the oracle with ggml's integer-dot semantics (oracle.qmats: quantize_row_q8_K + vec_dot_q4_K_q8_K per
     linear), and against the handle's own single-sequence integer-dot GEMVs.  The kernel-level test above holds every row to 2e-5;
@@ -575,8 +585,8 @@ def test_q4_k_checkpoint_prompt_pass_and_decode_groups_on_the_int8_matrix_cores(
     from crane_amd.backend import Model
     cfg = dict(configs.get_config("qwen3-0.6b-2l"), vocab_size=4096)
     w = synth.synth_weights_f32(cfg, seed=0)
-    path = str(tmp_path / "q4k-e2e.gguf")
-    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types("q4_k"), want_qmats=True)
+    path = str(tmp_path / f"{kind}-e2e.gguf")
+    deq, qm = G.write_qwen3_gguf(path, cfg, w, _types(kind), want_qmats=True)
     deq["lm_head.weight"] = deq["model.embed_tokens.weight"]
     V = cfg["vocab_size"]
     oracle = Qwen3Oracle(Qwen3Config.from_json(cfg), deq)

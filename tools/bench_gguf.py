@@ -12,7 +12,11 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 cfg = dict(model_type="qwen3", hidden_size=4096, intermediate_size=12288, num_attention_heads=32, num_key_value_heads=8,
            head_dim=128, num_hidden_layers=L, vocab_size=8192, tie_word_embeddings=True, rms_norm_eps=1e-6, rope_theta=1e6,
            max_position_embeddings=4096)
-gt = G.TYPE_NAMES[kind]
+gt = G.TYPE_NAMES["q4_k" if kind == "q4_k_m" else kind]
+def type_of(gg):          # q4_k_m: Q6_K for attn_v / ffn_down / the embedding (llama.cpp's recipe in outline), Q4_K elsewhere
+    if kind == "q4_k_m" and ("attn_v" in gg or "ffn_down" in gg or gg == "token_embd.weight"):
+        return G.GGML_Q6_K
+    return gt
 rng = np.random.default_rng(0)
 t0 = time.time()
 tensors = []
@@ -23,7 +27,7 @@ for hf, gg in G.qwen3_gguf_names(cfg).items():
     H, I, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"]
     shape = {"token_embd": (cfg["vocab_size"], H), "attn_q": (32 * D, H), "attn_k": (8 * D, H), "attn_v": (8 * D, H), "attn_output": (H, 32 * D),
              "ffn_gate": (I, H), "ffn_up": (I, H), "ffn_down": (H, I)}[gg.split(".")[-2]]
-    tensors.append((gg, (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(shape[1])).astype(np.float32), gt))
+    tensors.append((gg, (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(shape[1])).astype(np.float32), type_of(gg)))
 path = f"/tmp/bench_{kind}.gguf"
 G.write_gguf(path, G.qwen3_metadata(cfg), tensors)
 del tensors
