@@ -176,11 +176,24 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q8_i8_k
         xsrc[i] = a.xq + (size_t)min(m_base + row, a.M - 1) * K + (size_t)kb0 * 32 + 16 * q;       // (rows past M: clamped, dropped at the store)
         xdst[i] = row * QROWB + 16 * q;
     }
-    u32x4 wreg[NWC], areg[NCH];
-    scl_t scn;
+    // Round 6: the weight requests run PFW groups ahead (a ring of PFW register sets, the group loop unrolled PFW times so that the sets
+    // are statically named).  With ONE group ahead a workgroup had 16 KB of weights in flight: 256 CUs x 16 KB per ~2 us of a loaded HBM
+    // round trip = 2 TB/s -- what the 128-row decode groups measured (1.56 TB/s, SQ_WAIT_ANY 32-41 % of the wave cycles); the activation
+    // panel (L2-resident) stays one group ahead.  Requests past the slice's last group re-read it (unconditional loads).
+    constexpr int PFW = QG == 8 ? 1 : 2;            // (groups of 8 blocks are 32 KB of weights each: one ahead, and no registers to spare)
+    u32x4 wreg[NWC], areg[NCH], wring[PFW][NWC];
+    scl_t scn, sring[PFW];
+    auto load_w = [&](int g, u32x4 (&w)[NWC], scl_t& sc) __attribute__((always_inline)) {
+        const int gg = min(g, ngrp - 1);
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) w[i] = ld_nt16(wsrc[i] + (size_t)gg * QG * 32);
+        sc = *(const scl_t*)(dp + gg * QG);
+    };
 #pragma unroll
     for (int i = 0; i < NWC; ++i) wreg[i] = ld_nt16(wsrc[i]);
     scn = *(const scl_t*)dp;
+#pragma unroll
+    for (int u = 0; u < PFW; ++u) load_w(1 + u, wring[u], sring[u]);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)xsrc[i];
     // (a group's scales: QG x 128 floats = one 16-byte load per thread of the first QG / 2 waves)
@@ -213,12 +226,11 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q8_i8_k
     const int wrow = (ns * 32 + r) * QROWB + 16 * h;                         // + j * 32
     const int arow = (mh * MT * 32 + r) * QROWB + 16 * h;                    // + mt * 32 * QROWB + j * 32
     const int xrow = mh * MT * 32 + r;                                       // + j * XM + mt * 32
-    for (int g = 0; g < ngrp; ++g) {
+    // one group: multiply group g out of LDS buffer g & 1; then the panels of group g + 1 (weights: the ring set `wn`, requested PFW groups
+    // ago) go to the other buffer and `wn` is requested again for group g + 1 + PFW
+    auto group = [&](int g, u32x4 (&wn)[NWC], scl_t& scnx) __attribute__((always_inline)) {
         const bool more = g + 1 < ngrp;
         if (more) {
-#pragma unroll
-            for (int i = 0; i < NWC; ++i) wreg[i] = ld_nt16(wsrc[i] + (size_t)(g + 1) * QG * 32);
-            scn = *(const scl_t*)(dp + (g + 1) * QG);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) areg[i] = *(const u32x4*)(xsrc[i] + (size_t)(g + 1) * QG * 32);
             if (tid < XT) xreg = *(const f32x4*)(xdsrc + (size_t)(g + 1) * xdstep);
@@ -280,13 +292,19 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q8_i8_k
             unsigned char* Wn = Ws + ((g + 1) & 1) * WPANEL;
             unsigned char* An = As + ((g + 1) & 1) * PANEL;
 #pragma unroll
-            for (int i = 0; i < NWC; ++i) *(u32x4*)(Wn + wdst[i]) = wreg[i];
+            for (int i = 0; i < NWC; ++i) *(u32x4*)(Wn + wdst[i]) = wn[i];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) *(u32x4*)(An + xdst[i]) = areg[i];
             if (tid < XT) ((f32x4*)(xds + ((g + 1) & 1) * (QG * XM)))[tid] = xreg;
-            put_dw(scn);                                                    // (this group's reads of the scales are behind us)
+            put_dw(scnx);                                                   // (this group's reads of the scales are behind us)
         }
+        load_w(g + 1 + PFW, wn, scnx);
         __syncthreads();
+    };
+    for (int g = 0; g < ngrp; g += PFW) {
+#pragma unroll
+        for (int u = 0; u < PFW; ++u)
+            if (g + u < ngrp) group(g + u, wring[u], sring[u]);
     }
     float* P = a.ws + (size_t)ks * a.slice;
     const int nq = tn * 128 + ns * 32 + 4 * h;
@@ -445,26 +463,33 @@ void launch_quant_rows_q8k(const float* x, int ldx, const float* nw, float eps, 
     else hipLaunchKernelGGL(quant_rows_q8k_kernel<false>, dim3(M), dim3(256), 0, s, x, ldx, nw, eps, xq, xd, K, xs);
 }
 
-// gemm_q8_i8_kernel's tiling and in-wave pipeline (see there) over Q4_K weights; what differs is how a group's panels and scales are
-// made: weight rows arrive as 64 packed bytes (4 x 16-byte chunks = 128 rows x 4 chunk loads per group: one per thread at 512 threads)
-// and are expanded to int8 on their way into LDS; the virtual block's codes and the group's five f32 weight scales come from the row's
-// 16-byte block header {f16 d, f16 dmin, 12 bytes of 6-bit scales / mins}
+// gemm_q8_i8_kernel's tiling over Q4_K weights, with the format's own lever: the 6-bit sub-scales are INTEGERS, so they are multiplied
+// into the weight codes when the panel is built -- sc_j = 8 sh_j + sl_j, and q4 * sl_j, q4 * sh_j <= 15 * 7 both fit an int8 -- and the
+// matrix core then sums sc_j (q4_j . q8_j) over the four sub-blocks of a group BY ITSELF, chaining its int32 accumulator through two
+// planes (lo, hi) of four 32-deep steps each; what is left for the VALU per group and m-tile is t = I_lo + 8 I_hi (16 shift-adds), ONE
+// float pass acc += (d d_x) t, and the virtual (min-term) block's pass: 80 VALU instructions for 9 MFMAs, where the first version of
+// this kernel (every sub-block scaled in float like a Q8_0 block) needed 160 for 5 and spilled when it kept integer sums in registers.
+// Weight rows arrive as 64 packed bytes per group (4 x 16-byte chunks: one per thread at 512 threads) with the row's 16-byte block
+// header; a thread expands its 32 codes into both planes with two packed 16-bit multiplies per dword (no byte overflows: <= 105).
+// LDS panel row: [128 lo | 128 hi | 32 virtual (m_0 .. m_7, 0 ...) | 16 pad] = 304 bytes (fragment rows 12 banks apart: conflict-free).
 template <int MH, int MT>
-__global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q4k_i8_kernel(QGemmArgs a) {
+__global__ __launch_bounds__(256 * MH, 1) void gemm_q4k_i8_kernel(QGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
-    constexpr int ROWB = QKROW + 16;                    // bytes of a panel row in LDS (weights and activations): 176 = 44 banks, the 16 rows of a fragment read start 4-bank-distinct
+    constexpr int WROWB = 304, AROWB = QKROW + 16;
     constexpr int NT = 256 * MH, PR = 32 * MT * MH, NS = QKB * MT;
     constexpr int NCHT = PR * 10, NCH = (NCHT + NT - 1) / NT;          // 16-byte chunks of the activation panel of a group, per thread
     constexpr int NWC = 128 * 4 / NT;                   // packed weight chunks per thread (1 at 512 threads, 2 at 256)
-    constexpr int PANEL = PR * ROWB, WPANEL = 128 * ROWB;
-    constexpr int XM = PR > QGEMM_MAXM ? PR : QGEMM_MAXM;
+    constexpr int PANEL = PR * AROWB, WPANEL = 128 * WROWB;
+    constexpr int XM = QGEMM_MAXM;
+    static_assert(PR <= QGEMM_MAXM, "m-panels of this kernel are at most 128 rows");
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5, ns = wave & 3, mh = wave >> 2;
     const int K = a.w.K, N = a.w.N, nb256 = K >> 8, G = K >> 7;
     float* xds = (float*)qlds;                                              // [2][QKB][XM] activation block scales of a group
-    float* dwl = xds + 2 * QKB * XM + wave * (QKB * 32);                    // [QKB][32] this wave's weight scales of the group (wave-private)
-    unsigned char* Ws = qlds + (size_t)(2 * QKB * XM + 4 * MH * QKB * 32) * sizeof(float);   // [2][128][ROWB]
-    unsigned char* As = Ws + 2 * WPANEL;                                    // [2][PR][ROWB]
+    float* dwl = xds + 2 * QKB * XM + wave * 64;                            // [2][32] this wave's d and -dmin of the group's 256-block (wave-private)
+    unsigned char* Ws = qlds + (size_t)(2 * QKB * XM + 4 * MH * 64) * sizeof(float);   // [2][128][WROWB]
+    unsigned char* As = Ws + 2 * WPANEL;                                    // [2][PR][AROWB]
     const int tiles = N / 128;
     const int per = tiles * a.mpan;
     const int ks = (int)blockIdx.x / per, rem = (int)blockIdx.x % per;
@@ -473,57 +498,75 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q4k_i8_
     else { tn = rem % tiles; mp = rem / tiles; }
     const int m_base = mp * PR;
     const int g0 = ks * G / a.ksplit, ngrp = (ks + 1) * G / a.ksplit - g0;
-    // block headers: lane (r, .) of strip ns owns row tn * 128 + ns * 32 + r
-    const uint8_t* hdr = a.w.p1 + (size_t)(tn * 128 + ns * 32 + r) * nb256 * 16;
-    // packed weight chunks: c = tid + NT i: row c / 4, chunk q = c % 4 of the group's 64 bytes: run q / 2 (sub-blocks 2 (q / 2) from the low
-    // nibbles, + 1 from the high ones), bytes 16 (q % 2) ... of the run
+    const uint8_t* hdr = a.w.p1 + (size_t)(tn * 128 + ns * 32 + r) * nb256 * 16;       // lane (r, .) of strip ns owns row tn * 128 + ns * 32 + r
+    // packed weight chunks: c = tid + NT i: row c / 4, chunk q = c % 4 of the group's 64 bytes: run q / 2 (sub-block 2 (q / 2) in the low
+    // nibbles, + 1 in the high ones), bytes 16 (q % 2) ... of the run
     const uint8_t* wsrc[NWC];
     int wdst[NWC];
-    const uint8_t* whdr[NWC];                           // (q == 0 threads also write the row's virtual block: its m_0 .. m_7)
+    const uint8_t* whdr[NWC];
 #pragma unroll
     for (int i = 0; i < NWC; ++i) {
         const int c = tid + NT * i, row = c >> 2, q = c & 3;
         wsrc[i] = a.w.p0 + (size_t)(tn * 128 + row) * (K >> 1) + (size_t)g0 * 64 + 16 * q;
-        wdst[i] = row * ROWB + (q >> 1) * 64 + (q & 1) * 16;
+        wdst[i] = row * WROWB + (q >> 1) * 64 + (q & 1) * 16;
         whdr[i] = a.w.p1 + (size_t)(tn * 128 + row) * nb256 * 16;
     }
     const signed char* xbase = a.xq + (size_t)g0 * QKROW;
-    const size_t xrow_b = (size_t)G * QKROW;            // bytes of an activation row
-    auto xsrc_of = [&](int c) -> const signed char* {   // chunk c of the panel: row c / 10, 16-byte chunk c % 10
+    const size_t xrow_b = (size_t)G * QKROW;
+    auto xsrc_of = [&](int c) -> const signed char* {
         const int row = c / 10, q = c % 10;
         return xbase + (size_t)min(m_base + row, a.M - 1) * xrow_b + 16 * q;
     };
-    u32x4 wreg[NWC], hreg[NWC], areg[NCH];
-    auto load_group = [&](int g) {
+    // the packed weights run PFW groups ahead (8 KB per group and workgroup: with one group ahead the 128-row launches were bound by
+    // the latency of that one request -- SQ_WAIT_ANY 41 % of the wave cycles at 14.5 VALU per MFMA); headers (L2 hits, shared by the two
+    // groups of a 256-block and by four threads) and the activation panel one group ahead.  Ring sets are statically named: the group
+    // loop is unrolled PFW times.  Requests past the slice's end re-read its last group.
+    constexpr int PFW = NWC == 1 ? 4 : 2;
+    u32x4 wring[PFW][NWC], hreg[NWC], areg[NCH];
+    auto load_w = [&](int g, u32x4 (&w)[NWC]) __attribute__((always_inline)) {
+        const int gg = min(g, ngrp - 1);
 #pragma unroll
-        for (int i = 0; i < NWC; ++i) {
-            wreg[i] = ld_nt16(wsrc[i] + (size_t)g * 64);
-            hreg[i] = *(const u32x4*)(whdr[i] + (size_t)((g0 + g) >> 1) * 16);
-        }
+        for (int i = 0; i < NWC; ++i) w[i] = ld_nt16(wsrc[i] + (size_t)gg * 64);
+    };
+    auto load_group = [&](int g) {                      // headers + activations of group g
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) hreg[i] = *(const u32x4*)(whdr[i] + (size_t)((g0 + g) >> 1) * 16);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + NT * i;
             areg[i] = c < NCHT ? *(const u32x4*)(xsrc_of(c) + (size_t)g * QKROW) : (u32x4){0u, 0u, 0u, 0u};
         }
     };
-    // 6-bit scale / min j of a header (get_scale_min_k4)
-    auto sbyte = [](const u32x4& hb, int ix) -> int { const int bi = 4 + ix; return (int)((hb[bi >> 2] >> (8 * (bi & 3))) & 0xFFu); };
-    auto sc_of = [&](const u32x4& hb, int j) -> int { return j < 4 ? (sbyte(hb, j) & 63) : ((sbyte(hb, j + 4) & 0xF) | ((sbyte(hb, j - 4) >> 6) << 4)); };
-    auto mn_of = [&](const u32x4& hb, int j) -> int { return j < 4 ? (sbyte(hb, j + 4) & 63) : ((sbyte(hb, j + 4) >> 4) | ((sbyte(hb, j) >> 6) << 4)); };
-    auto store_group = [&](int buf) {
+    // 4 codes of a dword times a factor <= 7: two 16-bit lanes, no byte overflows
+    auto mul4 = [](uint32_t c, int f) -> uint32_t {
+        const u16x2 v = __builtin_bit_cast(u16x2, c) * (u16x2){(unsigned short)f, (unsigned short)f};
+        return __builtin_bit_cast(uint32_t, v);
+    };
+    auto store_group = [&](int buf, int g, const u32x4 (&wreg)[NWC]) __attribute__((always_inline)) {
         unsigned char* Wn = Ws + buf * WPANEL;
         unsigned char* An = As + buf * PANEL;
+        const int half = (g0 + g) & 1;
 #pragma unroll
         for (int i = 0; i < NWC; ++i) {
-            const u32x4 w = wreg[i];
-            *(u32x4*)(Wn + wdst[i]) = (u32x4){w[0] & 0x0F0F0F0Fu, w[1] & 0x0F0F0F0Fu, w[2] & 0x0F0F0F0Fu, w[3] & 0x0F0F0F0Fu};
-            *(u32x4*)(Wn + wdst[i] + 32) = (u32x4){(w[0] >> 4) & 0x0F0F0F0Fu, (w[1] >> 4) & 0x0F0F0F0Fu, (w[2] >> 4) & 0x0F0F0F0Fu, (w[3] >> 4) & 0x0F0F0F0Fu};
-            if (((tid + NT * i) & 3) == 0) {            // the virtual block of the row: (m_0 .. m_7, 0 ...)
-                const u32x4 hb = hreg[i];
-                uint32_t m03 = 0, m47 = 0;
+            const u32x4 w = wreg[i], hb = hreg[i];
+            const int q = (tid + NT * i) & 3, ja = 4 * half + 2 * (q >> 1);          // sub-blocks ja (low nibbles), ja + 1 (high nibbles) of the 256-block
+            // all eight 6-bit scales and mins of the header at once (ggml's kmask unpacking of scales[12]): sc_0 .. sc_3 | sc_4 .. sc_7 | m_0 .. m_3 | m_4 .. m_7
+            const uint32_t u0 = hb[1], u1 = hb[2], u2 = hb[3];
+            const uint32_t sc03 = u0 & 0x3F3F3F3Fu, sc47 = (u2 & 0x0F0F0F0Fu) | (((u0 >> 6) & 0x03030303u) << 4);
+            const uint32_t m03 = u1 & 0x3F3F3F3Fu, m47 = ((u2 >> 4) & 0x0F0F0F0Fu) | (((u1 >> 6) & 0x03030303u) << 4);
+            const uint32_t scw = (ja < 4 ? sc03 : sc47) >> (8 * (ja & 3));
+            const int sa = (int)(scw & 0xFFu), sb = (int)((scw >> 8) & 0xFFu);
+            u32x4 lo_a, hi_a, lo_b, hi_b;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { m03 |= (uint32_t)mn_of(hb, j) << (8 * j); m47 |= (uint32_t)mn_of(hb, j + 4) << (8 * j); }
-                unsigned char* vb = Wn + ((tid + NT * i) >> 2) * ROWB + 128;
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t L = w[e] & 0x0F0F0F0Fu, Hn = (w[e] >> 4) & 0x0F0F0F0Fu;
+                lo_a[e] = mul4(L, sa & 7); hi_a[e] = mul4(L, sa >> 3);
+                lo_b[e] = mul4(Hn, sb & 7); hi_b[e] = mul4(Hn, sb >> 3);
+            }
+            *(u32x4*)(Wn + wdst[i]) = lo_a; *(u32x4*)(Wn + wdst[i] + 32) = lo_b;
+            *(u32x4*)(Wn + wdst[i] + 128) = hi_a; *(u32x4*)(Wn + wdst[i] + 160) = hi_b;
+            if (q == 0) {                                 // the virtual block of the row: (m_0 .. m_7, 0 ...)
+                unsigned char* vb = Wn + ((tid + NT * i) >> 2) * WROWB + 256;
                 *(u32x4*)vb = (u32x4){m03, m47, 0u, 0u};
                 *(u32x4*)(vb + 16) = (u32x4){0u, 0u, 0u, 0u};
             }
@@ -531,97 +574,109 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q4k_i8_
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + NT * i;
-            if (c < NCHT) *(u32x4*)(An + (c / 10) * ROWB + 16 * (c % 10)) = areg[i];
+            if (c < NCHT) *(u32x4*)(An + (c / 10) * AROWB + 16 * (c % 10)) = areg[i];
         }
     };
-    // the strip's five weight scales of group g (f32): lane (r, h = 0) writes blocks 0, 1 and the virtual one, h = 1 blocks 2, 3
-    u32x4 shdr;
-    auto load_scales = [&](int g) { shdr = *(const u32x4*)(hdr + (size_t)((g0 + g) >> 1) * 16); };
-    auto put_dw = [&](int g) {
-        const float d = f16bits(shdr[0] & 0xFFFFu), dmin = f16bits(shdr[0] >> 16);
-        const int half = (g0 + g) & 1;                  // sub-blocks 4 half ... 4 half + 3 of the 256-block
-        const int j0 = 2 * h;
-        dwl[j0 * 32 + r] = d * (float)sc_of(shdr, 4 * half + j0);
-        dwl[(j0 + 1) * 32 + r] = d * (float)sc_of(shdr, 4 * half + j0 + 1);
-        if (h == 0) dwl[4 * 32 + r] = -dmin;
-    };
-    // activation scales of a group: QKB x XM floats
-    constexpr int XT = QKB * XM / 4, XR = XM / 4;
-    static_assert(XT <= 256 * MH * 2, "scale loader");
-    const float* xdsrc[2]; bool xdo[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = tid + NT * i;
-        xdo[i] = t < XT;
-        const int tt = xdo[i] ? t : 0;
-        xdsrc[i] = a.xd + ((size_t)g0 * QKB + tt / XR) * a.xs + m_base + 4 * (tt % XR);
-    }
+    // d and -dmin of the strip's rows for group g: lane (r, h = 0) writes d, h = 1 -dmin
+    uint32_t shdr0 = 0;
+    auto load_scales = [&](int g) { shdr0 = *(const uint32_t*)(hdr + (size_t)((g0 + g) >> 1) * 16); };
+    auto put_dw = [&]() { dwl[h * 32 + r] = h == 0 ? f16bits(shdr0 & 0xFFFFu) : -f16bits(shdr0 >> 16); };
+    constexpr int XT = QKB * XM / 4, XR = XM / 4;       // 160 float4 per group
+    const bool xdo = tid < XT;
+    const float* xdsrc = a.xd + ((size_t)g0 * QKB + (xdo ? tid / XR : 0)) * a.xs + m_base + 4 * ((xdo ? tid : 0) % XR);
     const size_t xdstep = (size_t)QKB * a.xs;
-    f32x4 xreg[2];
-    auto load_xd = [&](int g) {
+    f32x4 xreg = {0.f, 0.f, 0.f, 0.f};
+    {
+        u32x4 w0[NWC];
+        load_w(0, w0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) if (xdo[i]) xreg[i] = *(const f32x4*)(xdsrc[i] + (size_t)g * xdstep);
-    };
-    auto store_xd = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) if (xdo[i]) ((f32x4*)(xds + buf * (QKB * XM)))[tid + NT * i] = xreg[i];
-    };
-    load_group(0); load_scales(0); load_xd(0);
-    store_group(0); store_xd(0); put_dw(0);
+        for (int u = 0; u < PFW; ++u) load_w(1 + u, wring[u]);
+        load_group(0); load_scales(0);
+        if (xdo) xreg = *(const f32x4*)xdsrc;
+        store_group(0, 0, w0); put_dw();
+        if (xdo) ((f32x4*)xds)[tid] = xreg;
+    }
     f32x2 acc[MT][8];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[mt][i] = (f32x2){0.f, 0.f};
     __syncthreads();
-    const int wrow = (ns * 32 + r) * ROWB + 16 * h;
-    const int arow = (mh * MT * 32 + r) * ROWB + 16 * h;
+    const int wrow = (ns * 32 + r) * WROWB + 16 * h;
+    const int arow = (mh * MT * 32 + r) * AROWB + 16 * h;
     const int xrow = mh * MT * 32 + r;
-    for (int g = 0; g < ngrp; ++g) {
+    auto group = [&](int g, u32x4 (&wn)[NWC]) __attribute__((always_inline)) {
         const bool more = g + 1 < ngrp;
-        if (more) { load_group(g + 1); load_scales(g + 1); load_xd(g + 1); }
+        if (more) { load_group(g + 1); load_scales(g + 1); if (xdo) xreg = *(const f32x4*)(xdsrc + (size_t)(g + 1) * xdstep); }
         const unsigned char* Wp = Ws + (g & 1) * WPANEL + wrow;
         const unsigned char* Ap = As + (g & 1) * PANEL + arow;
         const float* xg = xds + (g & 1) * (QKB * XM) + xrow;
-        u32x4 avq[2], wfq[2];
+        u32x4 avq[2], wl[2], wh[2];
         float dxq[3];
-        i32x16 cq[2];
-        f32x4 dwq[4];
+        i32x16 il[MT], ih[MT], cv[2];
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define QK_LOAD(s_, slot_) do { avq[slot_] = *(const u32x4*)(Ap + ((s_) % MT) * 32 * ROWB + ((s_) / MT) * 32); \
+        // step s = (block j = s / MT, m-tile mt = s % MT); blocks 0 .. 3: two chained MFMAs (planes lo / hi), block 4: the virtual one
+#define QK_LOAD(s_, slot_) do { avq[slot_] = *(const u32x4*)(Ap + ((s_) % MT) * 32 * AROWB + ((s_) / MT) * 32); \
                                 dxq[(s_) % 3] = xg[((s_) / MT) * XM + ((s_) % MT) * 32]; } while (0)
-#define QK_MFMA(s_, slot_) cq[slot_] = __builtin_amdgcn_mfma_i32_32x32x32_i8( \
-            (i32x4){(int)wfq[((s_) / MT) & 1][0], (int)wfq[((s_) / MT) & 1][1], (int)wfq[((s_) / MT) & 1][2], (int)wfq[((s_) / MT) & 1][3]}, \
-            (i32x4){(int)avq[slot_][0], (int)avq[slot_][1], (int)avq[slot_][2], (int)avq[slot_][3]}, zero, 0, 0, 0)
-        wfq[0] = *(const u32x4*)Wp;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + 8 * q + 4 * h);
+#define QK_I4(v_) (i32x4){(int)(v_)[0], (int)(v_)[1], (int)(v_)[2], (int)(v_)[3]}
+#define QK_MFMA(s_, slot_) do { constexpr int j_ = (s_) / MT, m_ = (s_) % MT; \
+            if (j_ < 4) { il[m_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(QK_I4(wl[j_ & 1]), QK_I4(avq[slot_]), j_ == 0 ? zero : il[m_], 0, 0, 0); \
+                          ih[m_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(QK_I4(wh[j_ & 1]), QK_I4(avq[slot_]), j_ == 0 ? zero : ih[m_], 0, 0, 0); } \
+            else cv[slot_] = __builtin_amdgcn_mfma_i32_32x32x32_i8(QK_I4(wl[j_ & 1]), QK_I4(avq[slot_]), zero, 0, 0, 0); } while (0)
+        // weight fragments of block j: lo plane at 32 j, hi plane at 128 + 32 j; the virtual block (j = 4) at 256 (into wl)
+        auto wfrag = [&](int j) __attribute__((always_inline)) {
+            wl[j & 1] = *(const u32x4*)(Wp + (j < 4 ? j * 32 : 256));
+            if (j < 4) wh[j & 1] = *(const u32x4*)(Wp + 128 + j * 32);
+        };
+        wfrag(0);
         QK_LOAD(0, 0);
         QK_LOAD(1, 1);
-        if (MT == 1) wfq[1] = *(const u32x4*)(Wp + 32);
+        if (MT == 1) wfrag(1);
         QK_MFMA(0, 0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int sl = s & 1, mt = s % MT, j = s / MT;
-            if (MT > 1 && mt == 0 && j + 1 < QKB) wfq[(j + 1) & 1] = *(const u32x4*)(Wp + (j + 1) * 32);
-            if (s + 1 < NS) QK_MFMA(s + 1, sl ^ 1);
-            if (MT == 1 && j + 2 < QKB) wfq[j & 1] = *(const u32x4*)(Wp + (j + 2) * 32);
+            if (MT > 1 && mt == 0 && j + 1 < QKB) wfrag(j + 1);
+            if (s + 1 < NS) {
+                // (macro needs a compile-time step: the loop is fully unrolled, `s` is a constant in every copy)
+                switch (s + 1) {
+#define QK_CASE(n_) case n_: if constexpr (n_ < NS) { QK_MFMA(n_, (n_) & 1); } break;
+                    QK_CASE(1) QK_CASE(2) QK_CASE(3) QK_CASE(4) QK_CASE(5) QK_CASE(6) QK_CASE(7) QK_CASE(8) QK_CASE(9)
+                    QK_CASE(10) QK_CASE(11) QK_CASE(12) QK_CASE(13) QK_CASE(14) QK_CASE(15) QK_CASE(16) QK_CASE(17) QK_CASE(18) QK_CASE(19)
+#undef QK_CASE
+                    default: break;
+                }
+            }
+            if (MT == 1 && j + 2 < QKB) wfrag(j + 2);
             if (s + 2 < NS) QK_LOAD(s + 2, sl);
             __builtin_amdgcn_sched_barrier(0);
             const float dx = dxq[s % 3];
-            f32x2 sv[8];
+            if (j == 3) {
+                // the group's real term for this m-tile: t = I_lo + 8 I_hi, acc += (d d_x) t
 #pragma unroll
-            for (int p = 0; p < 8; ++p) sv[p] = (f32x2){dwq[p >> 1][2 * (p & 1)], dwq[p >> 1][2 * (p & 1) + 1]} * (f32x2){dx, dx};
-            if (mt == MT - 1 && j + 1 < QKB) {
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 dd = *(const f32x4*)(dwl + 8 * q + 4 * h);
 #pragma unroll
-                for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(sv[p]));
+                    for (int e = 0; e < 2; ++e) {
+                        const int p = 2 * q + e;
+                        const f32x2 sv = (f32x2){dd[2 * e], dd[2 * e + 1]} * (f32x2){dx, dx};
+                        const f32x2 cf = (f32x2){(float)(il[mt][2 * p] + (ih[mt][2 * p] << 3)), (float)(il[mt][2 * p + 1] + (ih[mt][2 * p + 1] << 3))};
+                        acc[mt][p] = __builtin_elementwise_fma(sv, cf, acc[mt][p]);
+                    }
+                }
+            } else if (j == 4) {
+                // the virtual block (min term): scale -dmin * (d_x | 128 d_x) on the digit dot product
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dwq[q] = *(const f32x4*)(dwl + (j + 1) * 32 + 8 * q + 4 * h);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 dm = *(const f32x4*)(dwl + 32 + 8 * q + 4 * h);
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const f32x2 cf = (f32x2){(float)cq[sl][2 * p], (float)cq[sl][2 * p + 1]};
-                acc[mt][p] = __builtin_elementwise_fma(sv[p], cf, acc[mt][p]);
+                    for (int e = 0; e < 2; ++e) {
+                        const int p = 2 * q + e;
+                        const f32x2 sv = (f32x2){dm[2 * e], dm[2 * e + 1]} * (f32x2){dx, dx};
+                        const f32x2 cf = (f32x2){(float)cv[sl][2 * p], (float)cv[sl][2 * p + 1]};
+                        acc[mt][p] = __builtin_elementwise_fma(sv, cf, acc[mt][p]);
+                    }
+                }
             }
 #pragma unroll
             for (int p = 0; p < 8; ++p) asm volatile("" : "+v"(acc[mt][p]));
@@ -629,8 +684,15 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q4k_i8_
         }
 #undef QK_LOAD
 #undef QK_MFMA
-        if (more) { store_group((g + 1) & 1); store_xd((g + 1) & 1); put_dw(g + 1); }
+#undef QK_I4
+        if (more) { store_group((g + 1) & 1, g + 1, wn); put_dw(); if (xdo) ((f32x4*)(xds + ((g + 1) & 1) * (QKB * XM)))[tid] = xreg; }
+        load_w(g + 1 + PFW, wn);
         __syncthreads();
+    };
+    for (int g = 0; g < ngrp; g += PFW) {
+#pragma unroll
+        for (int u = 0; u < PFW; ++u)
+            if (g + u < ngrp) group(g + u, wring[u]);
     }
     float* P = a.ws + (size_t)ks * a.slice;
     const int nq = tn * 128 + ns * 32 + 4 * h;
@@ -1080,9 +1142,13 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
     // a CU held one 4-wave workgroup, one wave per SIMD.  CM_QGEMM_QG_SMALL = 8: A/B)
     static const int qg_small = getenv("CM_QGEMM_QG_SMALL") && atoi(getenv("CM_QGEMM_QG_SMALL")) == 8 ? 8 : 4;
     p.mh = geo == 1 || geo == 3 || geo == 4 ? 2 : 1; p.mt = geo == 2 || geo == 4 ? 4 : M > 32 ? 2 : 1; p.qg = geo >= 2 ? 4 : geo == 1 ? 8 : qg_small;
-    if (fmt == QFMT_Q4_K || fmt == QFMT_Q6_K) {      // groups of half a 256-block (Q4_K: 4 sub-blocks + 1 virtual block; Q6_K: 8 sub-blocks of 16); geometries <1,1> <1,2> <2,2> <2,4>
+    if (fmt == QFMT_Q4_K || fmt == QFMT_Q6_K) {      // groups of half a 256-block (Q4_K: 4 sub-blocks + 1 virtual block; Q6_K: 8 sub-blocks of 16); geometries <1,1> <1,2> <2,2> (Q6_K: also <2,4>)
         p.qg = 4;
         if (geo != 4) { p.mh = M > 64 ? 2 : 1; p.mt = M > 32 ? 2 : 1; }
+        else if (fmt == QFMT_Q4_K) { p.mh = 2; p.mt = 2; }       // (its panels carry two weight planes: m-panels of 128 rows)
+        // Q4_K: 78 KB of weight planes per workgroup = one workgroup per CU whatever the rows: 8 waves also for <= 64 rows (two halves x one
+        // m-tile) -- four waves alone (one per SIMD) cannot hide the panel latency (64-row round of 4 layers: 1013 -> 734 us)
+        if (fmt == QFMT_Q4_K && geo != 4 && M <= 64) { p.mh = 2; p.mt = 1; }       // (also below 33 rows, where the second half multiplies padding: 16-row round of 4 layers 816 -> 693 us)
     }
     const int pr = 32 * p.mt * p.mh;
     p.mpan = geo == 4 ? (M + pr - 1) / pr : 1;
@@ -1090,7 +1156,7 @@ QGemmPlan plan_gemm_q8(int M, int N, int K, int epi, bool have_ws, size_t ws_flo
     p.groups = G;
     p.lds = (size_t)(2 * p.qg * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * p.qg * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (p.qg * 32 + 16);
     if (fmt == QFMT_Q4_K)
-        p.lds = (size_t)(2 * QKB * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * QKB * 32) * sizeof(float) + (size_t)2 * (128 + pr) * (QKROW + 16);
+        p.lds = (size_t)(2 * QKB * QGEMM_MAXM + 4 * p.mh * 64) * sizeof(float) + (size_t)2 * 128 * 304 + (size_t)2 * pr * (QKROW + 16);
     if (fmt == QFMT_Q6_K)
         p.lds = (size_t)(2 * std::max(pr, (int)QGEMM_MAXM) + 4 * p.mh * 8 * 32) * sizeof(float) + (size_t)2 * (128 + pr) * 136;
     // (the SiLU tile of an unsplit gate|up launch lives in the panels: [rows][68] floats)
@@ -1159,7 +1225,7 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gemm_q4k_i8_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)gemm_q6k_i8_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1173,7 +1239,7 @@ bool launch_gemm_q8(const QGemmArgs& a0, int epi, float* y, int ldy, float* ws, 
         else hipLaunchKernelGGL((gemm_q6k_i8_kernel<1, 1>), grid, block, lds, s, a);
     }
     else if (q4k) {
-        if (mh == 2 && mt == 4) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 4>), grid, block, lds, s, a);
+        if (mh == 2 && mt == 1) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 1>), grid, block, lds, s, a);
         else if (mh == 2) hipLaunchKernelGGL((gemm_q4k_i8_kernel<2, 2>), grid, block, lds, s, a);
         else if (mt == 2) hipLaunchKernelGGL((gemm_q4k_i8_kernel<1, 2>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((gemm_q4k_i8_kernel<1, 1>), grid, block, lds, s, a);
