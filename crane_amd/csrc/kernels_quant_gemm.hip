@@ -522,19 +522,20 @@ __global__ __launch_bounds__(256 * MH, 1) void gemm_q4k_i8_kernel(QGemmArgs a) {
     // groups of a 256-block and by four threads) and the activation panel one group ahead.  Ring sets are statically named: the group
     // loop is unrolled PFW times.  Requests past the slice's end re-read its last group.
     constexpr int PFW = NWC == 1 ? 4 : 2;
-    u32x4 wring[PFW][NWC], hreg[NWC], areg[NCH];
+    u32x4 wring[PFW][NWC], hring[2][NWC], aring[2][NCH];      // (headers and activations: two groups ahead, slots by group parity)
     auto load_w = [&](int g, u32x4 (&w)[NWC]) __attribute__((always_inline)) {
         const int gg = min(g, ngrp - 1);
 #pragma unroll
         for (int i = 0; i < NWC; ++i) w[i] = ld_nt16(wsrc[i] + (size_t)gg * 64);
     };
-    auto load_group = [&](int g) {                      // headers + activations of group g
+    auto load_group = [&](int g, u32x4 (&hreg)[NWC], u32x4 (&areg)[NCH]) __attribute__((always_inline)) {      // headers + activations of group g (clamped)
+        const int gg = min(g, ngrp - 1);
 #pragma unroll
-        for (int i = 0; i < NWC; ++i) hreg[i] = *(const u32x4*)(whdr[i] + (size_t)((g0 + g) >> 1) * 16);
+        for (int i = 0; i < NWC; ++i) hreg[i] = *(const u32x4*)(whdr[i] + (size_t)((g0 + gg) >> 1) * 16);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i;
-            areg[i] = c < NCHT ? *(const u32x4*)(xsrc_of(c) + (size_t)g * QKROW) : (u32x4){0u, 0u, 0u, 0u};
+            const int c = min(tid + NT * i, NCHT - 1);
+            areg[i] = *(const u32x4*)(xsrc_of(c) + (size_t)gg * QKROW);
         }
     };
     // 4 codes of a dword times a factor <= 7: two 16-bit lanes, no byte overflows
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256 * MH, 1) void gemm_q4k_i8_kernel(QGemmArgs a) {
         const u16x2 v = __builtin_bit_cast(u16x2, c) * (u16x2){(unsigned short)f, (unsigned short)f};
         return __builtin_bit_cast(uint32_t, v);
     };
-    auto store_group = [&](int buf, int g, const u32x4 (&wreg)[NWC]) __attribute__((always_inline)) {
+    auto store_group = [&](int buf, int g, const u32x4 (&wreg)[NWC], const u32x4 (&hreg)[NWC], const u32x4 (&areg)[NCH]) __attribute__((always_inline)) {
         unsigned char* Wn = Ws + buf * WPANEL;
         unsigned char* An = As + buf * PANEL;
         const int half = (g0 + g) & 1;
@@ -591,10 +592,11 @@ __global__ __launch_bounds__(256 * MH, 1) void gemm_q4k_i8_kernel(QGemmArgs a) {
         load_w(0, w0);
 #pragma unroll
         for (int u = 0; u < PFW; ++u) load_w(1 + u, wring[u]);
-        load_group(0); load_scales(0);
+        load_group(0, hring[0], aring[0]); load_scales(0);
         if (xdo) xreg = *(const f32x4*)xdsrc;
-        store_group(0, 0, w0); put_dw();
+        store_group(0, 0, w0, hring[0], aring[0]); put_dw();
         if (xdo) ((f32x4*)xds)[tid] = xreg;
+        load_group(1, hring[1], aring[1]);
     }
     f32x2 acc[MT][8];
 #pragma unroll
@@ -605,9 +607,11 @@ __global__ __launch_bounds__(256 * MH, 1) void gemm_q4k_i8_kernel(QGemmArgs a) {
     const int wrow = (ns * 32 + r) * WROWB + 16 * h;
     const int arow = (mh * MT * 32 + r) * AROWB + 16 * h;
     const int xrow = mh * MT * 32 + r;
-    auto group = [&](int g, u32x4 (&wn)[NWC]) __attribute__((always_inline)) {
+    auto group = [&](int g, u32x4 (&wn)[NWC], u32x4 (&hn)[NWC], u32x4 (&an)[NCH], u32x4 (&hf)[NWC], u32x4 (&af)[NCH]) __attribute__((always_inline)) {
+        // hn / an: headers and activations of group g + 1 (requested one group ago); hf / af: the set that is free now -> group g + 2
         const bool more = g + 1 < ngrp;
-        if (more) { load_group(g + 1); load_scales(g + 1); if (xdo) xreg = *(const f32x4*)(xdsrc + (size_t)(g + 1) * xdstep); }
+        load_group(g + 2, hf, af);
+        if (more) { load_scales(g + 1); if (xdo) xreg = *(const f32x4*)(xdsrc + (size_t)(g + 1) * xdstep); }
         const unsigned char* Wp = Ws + (g & 1) * WPANEL + wrow;
         const unsigned char* Ap = As + (g & 1) * PANEL + arow;
         const float* xg = xds + (g & 1) * (QKB * XM) + xrow;
@@ -685,14 +689,14 @@ __global__ __launch_bounds__(256 * MH, 1) void gemm_q4k_i8_kernel(QGemmArgs a) {
 #undef QK_LOAD
 #undef QK_MFMA
 #undef QK_I4
-        if (more) { store_group((g + 1) & 1, g + 1, wn); put_dw(); if (xdo) ((f32x4*)(xds + ((g + 1) & 1) * (QKB * XM)))[tid] = xreg; }
+        if (more) { store_group((g + 1) & 1, g + 1, wn, hn, an); put_dw(); if (xdo) ((f32x4*)(xds + ((g + 1) & 1) * (QKB * XM)))[tid] = xreg; }
         load_w(g + 1 + PFW, wn);
         __syncthreads();
     };
     for (int g = 0; g < ngrp; g += PFW) {
 #pragma unroll
         for (int u = 0; u < PFW; ++u)
-            if (g + u < ngrp) group(g + u, wring[u]);
+            if (g + u < ngrp) group(g + u, wring[u], hring[(u + 1) & 1], aring[(u + 1) & 1], hring[u & 1], aring[u & 1]);
     }
     float* P = a.ws + (size_t)ks * a.slice;
     const int nq = tn * 128 + ns * 32 + 4 * h;
