@@ -543,7 +543,8 @@ long cm_debug_peer_selftest(int32_t n_ranks, int32_t device, int32_t iters, int3
 // test hook: the launch plan of the int8 decode-group GEMM for a shape (pure host logic)
 int cm_debug_qgemm_plan(int32_t m, int32_t n, int32_t k, int32_t epi, uint64_t ws_floats, int32_t num_cu, int64_t out[8]) {
     if (!out || num_cu < 1) return CM_ERR_INVALID;
-    const cm::QGemmPlan p = cm::plan_gemm_q8(m, n, k, epi, ws_floats > 0, (size_t)ws_floats, num_cu);
+    const int fmt = (epi >> 8) & 0xFF;       // bits 8 .. 15: ggml type of the weights (0 = the Q8_0 layout, 12 = Q4_K, 14 = Q6_K)
+    const cm::QGemmPlan p = cm::plan_gemm_q8(m, n, k, epi & 0xFF, ws_floats > 0, (size_t)ws_floats, num_cu, fmt ? fmt : (int)cm::QFMT_Q8_0);
     out[0] = p.ok; out[1] = p.direct; out[2] = 4 * p.mh; out[3] = 32 * p.mh * p.mt; out[4] = p.qg; out[5] = p.groups; out[6] = p.ks; out[7] = p.grid;
     return CM_OK;
 }

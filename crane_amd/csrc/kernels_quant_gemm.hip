@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256 * MH, (MH * MT >= 8 ? 1 : 2)) void gemm_q8_i8_k
     // are statically named).  With ONE group ahead a workgroup had 16 KB of weights in flight: 256 CUs x 16 KB per ~2 us of a loaded HBM
     // round trip = 2 TB/s -- what the 128-row decode groups measured (1.56 TB/s, SQ_WAIT_ANY 32-41 % of the wave cycles); the activation
     // panel (L2-resident) stays one group ahead.  Requests past the slice's last group re-read it (unconditional loads).
-    constexpr int PFW = QG == 8 ? 1 : 2;            // (groups of 8 blocks are 32 KB of weights each: one ahead, and no registers to spare)
+    constexpr int PFW = (QG == 8 || MH == 1) ? 1 : 2;   // (groups of 8 blocks are 32 KB each; the 4-wave geometries run two workgroups per CU and measured 3-8 % slower with the ring: one ahead)
     u32x4 wreg[NWC], areg[NCH], wring[PFW][NWC];
     scl_t scn, sring[PFW];
     auto load_w = [&](int g, u32x4 (&w)[NWC], scl_t& sc) __attribute__((always_inline)) {

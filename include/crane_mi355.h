@@ -491,7 +491,7 @@ long cm_debug_peer_selftest(int32_t n_ranks, int32_t device, int32_t iters, int3
 /* Test hook (host logic only, no device): what the int8-MFMA GEMM of a quantised decode group (csrc/kernels_quant_gemm.hip; it replaces the
  * per-sequence `QMatMul::forward` calls of a batched step, candle quantized matmul behind ops/linear.rs:53-116) would do for `m` activation
  * rows over an [n][k] Q8_0-layout matrix on `num_cu` CUs with a split-K workspace of `ws_floats` f32 (0: none): epi 0 store, 1 residual
- * add, 2 SiLU(gate) * up.  out[0..7] = { ok (0: the batched GEMV takes the projection), unsplit store, waves per workgroup, activation
+ * add, 2 SiLU(gate) * up (bits 8 .. 15 of `epi`: the ggml type of the weights -- 0 = the Q8_0 layout, 12 = Q4_K, 14 = Q6_K, round 6).  out[0..7] = { ok (0: the batched GEMV takes the projection), unsplit store, waves per workgroup, activation
  * rows per workgroup, 32-blocks per K group, K groups, K split, workgroups }.  Slice i of the split covers groups [i G / ks, (i + 1) G / ks). */
 int cm_debug_qgemm_plan(int32_t m, int32_t n, int32_t k, int32_t epi, uint64_t ws_floats, int32_t num_cu, int64_t out[8]);
 

@@ -79,3 +79,21 @@ def test_plan_respects_the_workspace_and_refuses_what_it_cannot_hold():
     assert plan(2048, 24576, 4096, RESADD, 1 << 24)["ok"] == 0  # (a residual projection of that size has nowhere to put its sums)
     assert plan(m, n + 64, k, STORE, 1 << 24)["ok"] == 0 and plan(m, n, k + 32, STORE, 1 << 24)["ok"] == 0
     assert plan(m, n, k, 3, 1 << 24)["ok"] == 0
+
+
+def test_plan_of_the_k_quant_kernels():
+    """Round 6: Q4_K / Q6_K tensors on the same GEMM (epi | ggml type << 8).  Q4_K carries two int8 weight planes per panel (78 KB of
+    LDS): one workgroup per CU whatever the rows, so 8 waves from the smallest group on, m-panels of 128 rows in a prompt pass; Q6_K
+    keeps the Q8_0 geometries (256-row panels above 128 rows).  K groups are half a 256-block for both."""
+    Q4K, Q6K = 12 << 8, 14 << 8
+    n, k = 4096, 4096
+    for m, rows in ((5, 64), (40, 64), (100, 128), (128, 128)):
+        p = plan(m, n, k, STORE | Q4K, 1 << 24)
+        assert p["ok"] == 1 and p["waves"] == 8 and p["rows"] == rows and p["qg"] == 4 and p["groups"] == k // 128, (m, p)
+        assert p["grid"] == (n // 128) * p["ks"]
+    p = plan(300, n, k, RESADD | Q4K, 1 << 24)
+    assert p["ok"] == 1 and p["rows"] == 128 and p["grid"] == (n // 128) * 3 * p["ks"], p
+    p = plan(300, n, k, RESADD | Q6K, 1 << 24)
+    assert p["ok"] == 1 and p["rows"] == 256 and p["grid"] == (n // 128) * 2 * p["ks"], p
+    p = plan(20, n, k, STORE | Q6K, 1 << 24)
+    assert p["ok"] == 1 and p["waves"] == 4 and p["rows"] == 32, p
