@@ -675,6 +675,32 @@ def test_hybrid_family_prompt_pass_and_decode_groups_on_the_int8_matrix_cores_ag
         m.close()
 
 
+@pytest.mark.parametrize("kv,chunk", [("int8", 0), ("f16", 128), ("f32", 160)])
+def test_int8_prompt_pass_over_quantised_kv_pages_and_in_chunks(kv, chunk):
+    """The int8 prompt pass in the corners the oracle tests do not visit: int8 KV pages (the attention of the pass reads the f32
+    shadow of the layer and writes f32 rows for the o_proj quantiser), and prompts longer than the prefill chunk (several passes:
+    128-row passes take the decode geometry with scale rows 128 apart, 160-row passes the 256-row geometry).  Against the same
+    handle's token-serial path (cm_debug_set("no_prefill")): the decode step's arithmetic row by row -- equal up to activation codes
+    that sit on a rounding boundary (3e-2 of the logit range, the GGUF tests' bound) -- and the greedy continuation."""
+    from crane_amd.backend import Model
+    cfg = configs.get_config("qwen3-8b-2l")
+    V = cfg["vocab_size"]
+    kw = dict(prefill_chunk=chunk) if chunk else {}
+    m = Model.synthetic(cfg, seed=0, max_seq_len=512, isq="q8_0", max_seqs=3, kv_dtype=kv, **kw)
+    try:
+        ids = [(11 * i + 5) % V for i in range(300)]
+        a = m.forward_step(ids, 0)[0, 0].copy()
+        a2 = m.forward_step([7], 300)[0, 0].copy()                 # a decode step over the pages the pass wrote
+        m.debug_set("no_prefill", 1)
+        m.clear_kv_cache()
+        b = m.forward_step(ids, 0)[0, 0].copy()
+        b2 = m.forward_step([7], 300)[0, 0].copy()
+        assert np.isfinite(a).all() and rel(a, b) < 3e-2, rel(a, b)
+        assert rel(a2, b2) < 3e-2, rel(a2, b2)
+    finally:
+        m.close()
+
+
 def test_engine_over_large_quantised_groups_emits_near_argmax_tokens_at_every_decode_step():
     """The continuous-batching engine at max_running 40 over an ISQ q8_0 model at the 8B widths (2 layers): decode rounds run on the
     int8 matrix cores.  (a) Two runs emit identical tokens (the quantised-row memo and the split-K tickets are per-handle state).
