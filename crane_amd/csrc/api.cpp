@@ -568,6 +568,7 @@ int cm_debug_set(cm_model* h, const char* key, int64_t value) {
         else if (k == "attn_heads_max") mm.attn_heads_max = value;
         else if (k == "attn_ns") { mm.attn_ns = (int)std::max<long long>(1, std::min<long long>(value, mm.nsplit)); mm.drop_graphs(); }
         else if (k == "gemm256") mm.gemm256 = (int)value;
+        else if (k == "gdn_ba_fused") { mm.gdn_ba_fused = value != 0; mm.drop_graphs(); }
         else if (k == "sample_rows") mm.sample_rows_on = value != 0;
         else if (k == "prefill_seg_batch") mm.seg_batch = value != 0;
         else if (k == "prefill_lo_mask") mm.prefill_lo_mask = (int)value;

@@ -110,6 +110,13 @@ struct GdnArgs {
     int chunked = 0;            // value-head order: 0 Interleaved (HF: key head = v / vpg), 1 Chunked (llama.cpp GGUF: v % NK; ops/gdn/config.rs:13-22)
     int n_seq, batch_proj_stride, batch_out_stride;   // batched decode step (grid.y)
     float eps;
+    // decode step over QUANTISED weights (round 6): the a / b gate projections stay bf16 (ops/gdn/projection.rs:78-83) and were a GEMV
+    // launch of their own per layer; with ba_w set the step computes ITS head's two dot products itself -- b rows then a rows [2 NV][ba_H]
+    // bf16, against RMSNorm(ba_x row of the sequence) * ba_nw -- and ignores the b / a columns of proj
+    const uint16_t* ba_w = nullptr;
+    const float* ba_x = nullptr;     // [n_seq][ba_H] f32 residual stream
+    const float* ba_nw = nullptr;    // [ba_H] input-norm weight
+    int ba_H = 0;
 };
 
 // ---- prefill (S > 1) ----

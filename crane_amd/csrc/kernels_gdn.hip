@@ -174,10 +174,40 @@ __global__ __launch_bounds__(256) void gdn_decode_kernel(GdnArgs a) {
             vs[tid] = silu_f(g0 * u0 + g1 * u1 + g2 * u2 + xv * u3);
             cs_out[cv * (KER - 1)] = g1; cs_out[cv * (KER - 1) + 1] = g2; cs_out[cv * (KER - 1) + 2] = xv;
         }
-        if (tid == 0) {
+        if (a.ba_w == nullptr && tid == 0) {
             const float beta = 1.0f / (1.0f + expf(-pr[conv_dim + a.NV * V + h]));
             const float av = pr[conv_dim + a.NV * V + a.NV + h] + a.dt_bias[h];
             bd[0] = beta;
+            bd[1] = expf(-expf(a.A_log[h]) * logf(1.0f + expf(av)));
+        }
+    }
+    if (a.ba_w != nullptr) {
+        // the head's b and a: two dot products of RMSNorm(x) * w with bf16 rows (the whole workgroup; the norm's scale is factored out)
+        const float* xr = a.ba_x + (size_t)bq * a.ba_H;
+        const uint16_t* wb = a.ba_w + (size_t)h * a.ba_H;
+        const uint16_t* wa = a.ba_w + (size_t)(a.NV + h) * a.ba_H;
+        float s2 = 0.f, sb = 0.f, sa = 0.f;
+        for (int i = tid * 4; i < a.ba_H; i += 1024) {
+            const f32x4 xv = *(const f32x4*)(xr + i), nv = *(const f32x4*)(a.ba_nw + i);
+            const u32x2 pb = *(const u32x2*)(wb + i), pa = *(const u32x2*)(wa + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xn = xv[e] * nv[e];
+                const float fb = bf16_to_f32((uint16_t)((pb[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+                const float fa = bf16_to_f32((uint16_t)((pa[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+                s2 = fmaf(xv[e], xv[e], s2); sb = fmaf(xn, fb, sb); sa = fmaf(xn, fa, sa);
+            }
+        }
+        __shared__ float bared[3][4];
+        const float t2 = wave_sum(s2), tb = wave_sum(sb), ta = wave_sum(sa);
+        __syncthreads();                                           // (red[] of the q / k norms is written above: separate array, but order the phases)
+        if (lane == 0) { bared[0][wave] = t2; bared[1][wave] = tb; bared[2][wave] = ta; }
+        __syncthreads();
+        if (tid == 0) {
+            const float rr = 1.0f / sqrtf(((bared[0][0] + bared[0][1]) + (bared[0][2] + bared[0][3])) / (float)a.ba_H + a.eps);
+            const float bv = rr * ((bared[1][0] + bared[1][1]) + (bared[1][2] + bared[1][3]));
+            const float av = rr * ((bared[2][0] + bared[2][1]) + (bared[2][2] + bared[2][3])) + a.dt_bias[h];
+            bd[0] = 1.0f / (1.0f + expf(-bv));
             bd[1] = expf(-expf(a.A_log[h]) * logf(1.0f + expf(av)));
         }
     }

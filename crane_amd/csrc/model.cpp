@@ -978,10 +978,16 @@ void Model::enqueue_quant_layer(int li) {
         const int qz = cfg.conv_dim() + cfg.value_dim();
         qg(PRO_RMSNORM, EPI_STORE, w.q_in_proj, x, w.ln1, qkv, nullptr);
         if (w.q_in_proj_z.fmt != QFMT_NONE) qg(PRO_RMSNORM, EPI_STORE, w.q_in_proj_z, x, w.ln1, qkv + w.q_in_proj.N, nullptr);
-        GemvArgs g{};                                    // the a / b gate rows stay bf16
-        g.W = w.in_proj_ba; g.x = x; g.nw = w.ln1; g.y = qkv + qz; g.N = 2 * cfg.NV; g.K = H; g.ldw = H; g.eps = cfg.eps;
-        launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+        // the a / b gate rows stay bf16: the Gated-Delta-Net step computes its head's two dot products itself (GdnArgs::ba_w; round 6: one
+        // launch less per layer; cm_debug_set("gdn_ba_fused", 0): the GEMV launch of rounds 2-5)
+        const bool ba_fused = gdn_ba_fused && gdn_scratch != nullptr && cfg.Kd == 128 && cfg.Vd == 128 && H % 4 == 0;
+        if (!ba_fused) {
+            GemvArgs g{};
+            g.W = w.in_proj_ba; g.x = x; g.nw = w.ln1; g.y = qkv + qz; g.N = 2 * cfg.NV; g.K = H; g.ldw = H; g.eps = cfg.eps;
+            launch_gemv(PRO_RMSNORM, EPI_STORE, g, gemv_grid(g.N, g.K, num_cu), s);
+        }
         GdnArgs ga{};
+        if (ba_fused) { ga.ba_w = w.in_proj_ba; ga.ba_x = x; ga.ba_nw = w.ln1; ga.ba_H = H; }
         ga.proj = qkv; ga.conv_w = w.conv_w; ga.conv_pool = conv_pool; ga.state_pool = state_pool;
         ga.A_log = w.A_log; ga.dt_bias = w.dt_bias; ga.gnorm_w = w.gnorm; ga.out = attn; ga.st = st;
         ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
@@ -1901,8 +1907,10 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                     const int qz = cfg.conv_dim() + cfg.value_dim();
                     qb(PRO_RMSNORM, EPI_STORE, w.q_in_proj, xb, H, w.ln1, qkvb, ldq);
                     if (w.q_in_proj_z.fmt != QFMT_NONE) qb(PRO_RMSNORM, EPI_STORE, w.q_in_proj_z, xb, H, w.ln1, qkvb + w.q_in_proj.N, ldq);
-                    // the a / b gate rows stay bf16: the matrix-core GEMV in steps of <= 64 rows (a 128-row int8 group), the VALU GEMV else
-                    for (int m0 = 0; m0 < nb; m0 += GEMV_MAXB) {
+                    // the a / b gate rows stay bf16: computed by the Gated-Delta-Net step itself (GdnArgs::ba_w, below); else the matrix-core
+                    // GEMV in steps of <= 64 rows (a 128-row int8 group) / the VALU GEMV
+                    const bool ba_fused_b = gdn_ba_fused && gdn_scratch != nullptr && cfg.Kd == 128 && cfg.Vd == 128 && H % 4 == 0;
+                    for (int m0 = 0; m0 < nb && !ba_fused_b; m0 += GEMV_MAXB) {
                         GemvBArgs g{};
                         g.W = w.in_proj_ba; g.x = xb + (size_t)m0 * H; g.nw = w.ln1; g.y = qkvb + (size_t)m0 * ldq + qz; g.res = g.y;
                         g.N = 2 * cfg.NV; g.K = H; g.ldw = H; g.ldx = H; g.ldy = ldq; g.n_seq = std::min((int)GEMV_MAXB, nb - m0); g.eps = cfg.eps;
@@ -1923,6 +1931,9 @@ void Model::decode_batch(const int32_t* sq, const uint32_t* toks, size_t n, floa
                 ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps;
                 ga.n_seq = nb; ga.batch_proj_stride = ldq; ga.batch_out_stride = (int)at_cols;
                 ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
+                if (quantized && gdn_ba_fused && gdn_scratch != nullptr && cfg.Kd == 128 && cfg.Vd == 128 && H % 4 == 0) {
+                    ga.ba_w = w.in_proj_ba; ga.ba_x = xb; ga.ba_nw = w.ln1; ga.ba_H = H;
+                }
                 launch_gdn(ga, s);
                 if (quantized) qrp(w.q_out_proj, attnb, (int)at_cols);
                 else if (gemm_b) {

@@ -386,6 +386,7 @@ struct Model {
     int64_t attn_mfma_wide_min = 8192;   // measured: 32 splits win up to 4 K (3.26 vs 3.30 ms), 64 at 32 K (3.96 vs 4.08)
 int prefill_lo_mask = 0;              // EXPERIMENT (cm_debug_set "prefill_lo_mask"): bit 0 qkv, 1 o_proj, 2 gate||up, 3 down: that GEMM drops the lo plane
     int gdn_defer_max = 4096;             // ... for value dims up to this many elements
+    bool gdn_ba_fused = true;             // quantised hybrid decode: the GDN step computes its head's bf16 a / b projections itself (cm_debug_set("gdn_ba_fused"))
     bool gdn_defer_norm = true;           // CM_GDN_DEFER_NORM / cm_debug_set("gdn_defer_norm"): gated RMSNorm in out_proj's prologue
     int attn_batch_ns_min = 1;            // fewest token splits per sequence in the batched decode attention (CM_ATTN_BATCH_NS_MIN)
     int64_t attn_mfma_min_batch = 64;     // matrix-core decode attention from this context on when the group fills the chip (CM_ATTN_MFMA_MIN_BATCH)
