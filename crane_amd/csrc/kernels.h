@@ -299,7 +299,8 @@ struct EngPhase {                 // one row-streaming projection of the program
     int in_tag, out_tag;          // tags of those edges relative to the launch's epoch base
     int layer;                    // decoder layer (attention operands)
     int useq;                     // how many earlier phases of the table share this counter row
-    int pre_attn;                 // the comm waves run this layer's attention before staging this phase's input
+    int pre_attn;                 // != 0: the comm waves run this layer's attention before staging this phase's input; the value = batches per
+                                  //   stream wave of the previous (QKV) phase after which every q row is complete
 };
 struct EngAttnL {                 // attention operands of one layer
     void* kpool;                  // [pages][Hkv][PAGE][D] bf16 or f16 (EngArgs::kv_f16)

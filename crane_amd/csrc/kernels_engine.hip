@@ -23,6 +23,12 @@
 //     its own flag: no fences, placement-independent (MI355X_MICROARCH.md, Guideline 16 R2).
 //   * The comm waves of workgroup (kv head, split) also run that split of the layer's attention -- the block of
 //     attn_decode_split_kernel on 4 waves -- exchange partials as granules, merge a 16-value slice each and publish it.
+//     Round 6: in two parts along the order the QKV rows finish.  The q rows are the phase's first block of row groups; as soon
+//     as they exist the workgroups score the OLD tokens (K / V rows prefetched before the poll), publish and gather partials --
+//     under the tail of the QKV stream, which is the k / v rows; the token of the step itself is folded in by the merging wave
+//     (q . k_new, one more term of the online softmax), so that only "k / v granules -> merge -> publish -> sweep" follows the
+//     end of the QKV stream (Qwen3-8B: 2690 -> 2625 us per launch; polling q a batch earlier, or publishing through the
+//     scalar cache -- s_store glc + s_dcache_wb, 0.4 us per idle hop in tools/probes/hop_probe.hip -- both measured slower).
 //   * The residual stream row r is owned by the same lane of the same wave in o_proj and down_proj and lives in LDS.
 // Every spin is bounded; a timeout raises ctl[1], later launches return at once, and the host reports the code.
 #include <cstdio>
@@ -165,7 +171,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         // layer has arrived" and "partials published" a comm wave then issues no global load at all -- such a load would
         // queue behind this CU's own weight-prefetch burst (~3-5 us) on the critical path of every layer.
         constexpr int NPRE = 4;                           // K/V chunks requested ahead per layer (contexts <= NPRE * nsplit * ACT)
-        int a_pos = 0, a_L = 1;
+        int a_pos = 0;
         float a_cos = 0.f, a_sin = 0.f;
         size_t a_koff[NPRE], a_eoff = 0;
         int a_tt[NPRE];
@@ -183,7 +189,6 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
             const CM_GLOBAL int32_t* bt = (const CM_GLOBAL int32_t*)a.block_table;
             a_pos = ((const CM_GLOBAL StepState*)a.st)->pos;
             const int rpos = a_pos + ((const CM_GLOBAL StepState*)a.st)->rsv[0];
-            a_L = a_pos + 1;
             a_cos = ((gf_cptr)a.cos)[(size_t)rpos * (AD >> 1) + lane];
             a_sin = ((gf_cptr)a.sin)[(size_t)rpos * (AD >> 1) + lane];
             a_owner = ((a_pos / ACT) % nsplit) == split;
@@ -191,7 +196,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
 #pragma unroll
             for (int u = 0; u < NPRE; ++u) {
                 // a chunk past the context reads chunk 0's rows again (cache hits, never consumed)
-                const bool cv = ACT * (split + nsplit * u) < a_L;
+                const bool cv = ACT * (split + nsplit * u) < a_pos;         // (old tokens only: the step's own token never comes from the pages)
                 a_tt[u] = ACT * (split + nsplit * (cv ? u : 0)) + tok_in_chunk;
                 int pi = a_tt[u] / a.page;
                 pi = pi < a.max_pages ? pi : a.max_pages - 1;         // speculative loads stay inside the table
@@ -240,81 +245,72 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     kq[u] = *(gw_ptr)(kp + a_koff[u]);
                     vq[u] = *(gw_ptr)(vp + a_koff[u]);
                 }
-                constexpr int NIT = (NREP + 2 + NCW - 1) / NCW;
-                float nwv[NIT][2];
-#pragma unroll
-                for (int ii = 0; ii < NIT; ++ii) {
-                    const int item = cw + ii * NCW;
-                    gf_cptr nw = item < NREP ? (gf_cptr)AL->qnw : (gf_cptr)AL->knw;
-                    const bool has = item <= NREP && nw != nullptr;
-                    if (!has) nw = (gf_cptr)a.cos;                    // any readable address: the loads stay unconditional
-                    nwv[ii][0] = nw[lane]; nwv[ii][1] = nw[lane + 64];
-                    if (!has) { nwv[ii][0] = 0.f; nwv[ii][1] = 0.f; }
-                }
-                const int pos = a_pos, L = a_L;
-                const bool owner = a_owner;
-                // this workgroup's own stream waves must be through the QKV phase before its comm waves poll the result
-                own_progress(prog_before + (uint32_t)(NSW * prev_nbt) - (uint32_t)(NSW / 2), 0x600u + (uint32_t)(p - p0));   // (nearly: the polls are tiny)
-                stamp(p - p0, 1);
-                const u64* GQ = a.gran[ENG_E_QKV];
-                // q heads of the group, new k, new v: wave w takes items w and w + NCW; ALL their granules are requested in one
-                // round trip per poll
-                int g0[NIT];
-#pragma unroll
-                for (int ii = 0; ii < NIT; ++ii) {
-                    const int item = cw + ii * NCW;
-                    g0[ii] = item < NREP ? a.q_off + (kvh * NREP + item) * AD : (item == NREP ? a.k_off + kvh * AD : a.v_off + kvh * AD);
-                    if (item >= NREP + 2) g0[ii] = a.q_off;               // idle slot: polls a q granule, result unused
-                }
-                float xin2[NIT][2];
-                uint32_t tr_spins = 0;
+                // Items of the layer's QKV vector: the NREP q heads of the group (wave w < NREP takes head w), the new k and the new v
+                // (waves NREP % NCW and (NREP + 1) % NCW).  Round 6: the attention is split in two along the order the rows of the QKV
+                // phase finish -- q first (P->pre_attn = batches per stream wave after which every q row is complete), k / v last:
+                //   A (under the tail of the QKV stream): q -> norm / RoPE -> scores and weighted values of the OLD tokens t < pos
+                //     (K / V rows prefetched above) -> partials published -> this workgroup's output slice gathered from every split;
+                //   B (after the k / v rows): k -> norm / RoPE, KV append by the owner, and the merging wave folds the NEW token into
+                //     its slice itself (score = q . k_new, one more term of the online softmax) -> publish.
+                // Between "QKV streamed" and "o_proj may start" there are then two dependent cross-CU hops (k / v granules, merged
+                // output) instead of four (QKV, partials, merged output + the score pass between them).
+                static_assert(NREP <= NCW && NCW >= 2, "one q item and at most one of k / v per comm wave");
+                const bool has_q = cw < NREP;
+                const int kvj = (cw - NREP + 2 * NCW) % NCW;         // 0: this wave takes k, 1: v, else neither
+                float nq[2], nk[2];
                 {
-                    uint32_t spins = 0;      // (its final value is traced as event 7, low half)
+                    gf_cptr nwq = (gf_cptr)AL->qnw, nwk = (gf_cptr)AL->knw;
+                    const bool hq = has_q && nwq != nullptr, hk = kvj == 0 && nwk != nullptr;
+                    if (!hq) nwq = (gf_cptr)a.cos;                        // any readable address: the loads stay unconditional
+                    if (!hk) nwk = (gf_cptr)a.cos;
+                    nq[0] = nwq[lane]; nq[1] = nwq[lane + 64];
+                    nk[0] = nwk[lane]; nk[1] = nwk[lane + 64];
+                    if (!hq) { nq[0] = 1.f; nq[1] = 1.f; }
+                    if (!hk) { nk[0] = 1.f; nk[1] = 1.f; }
+                }
+                const int pos = a_pos;
+                const bool owner = a_owner;
+                const u64* GQ = a.gran[ENG_E_QKV];
+                // one 128-value item per wave and part, ALL its granules requested in one round trip per poll (a wave without an item
+                // polls the group's first q head / the k head: result unused)
+                const int gA = a.q_off + (kvh * NREP + (has_q ? cw : 0)) * AD;
+                const int gB = kvj == 1 ? a.v_off + kvh * AD : a.k_off + kvh * AD;
+                uint32_t tr_spins = 0;
+                auto poll_item = [&](int g, float (&xv)[2], uint32_t code) __attribute__((always_inline)) -> uint32_t {
+                    uint32_t spins = 0;
                     for (;;) {
-                        bool ok = true;
-#pragma unroll
-                        for (int ii = 0; ii < NIT; ++ii) {
-                            const u64 x0 = gran_ld(GQ + g0[ii] + lane), x1 = gran_ld(GQ + g0[ii] + lane + 64);
-                            xin2[ii][0] = __uint_as_float((uint32_t)x0); xin2[ii][1] = __uint_as_float((uint32_t)x1);
-                            ok = ok && (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag;
-                        }
+                        const u64 x0 = gran_ld(GQ + g + lane), x1 = gran_ld(GQ + g + lane + 64);
+                        xv[0] = __uint_as_float((uint32_t)x0); xv[1] = __uint_as_float((uint32_t)x1);
+                        const bool ok = (uint32_t)(x0 >> 32) == tag && (uint32_t)(x1 >> 32) == tag;
                         if (__all(ok) || dbg_nowait) break;
                         if (lds_ld(&ctrl[C_ABORT]) != 0u) break;
-                        if (++spins > SPIN_GLOBAL) { fail(0x700u + (uint32_t)(p - p0)); break; }
+                        if (++spins > SPIN_GLOBAL) { fail(code); break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    tr_spins = spins;
-                }
-#pragma unroll
-                for (int ii = 0; ii < NIT; ++ii) {
-                    const int item = cw + ii * NCW;
-                    if (item >= NREP + 2) continue;
-                    const bool normed = (item < NREP ? AL->qnw : AL->knw) != nullptr;
-                    float xv[2] = {xin2[ii][0], xin2[ii][1]};
-                    if (item <= NREP) {
-                        if (normed) {
-                            const float ss = wave_sum(xv[0] * xv[0] + xv[1] * xv[1]);
-                            const float rr = 1.0f / sqrtf(ss / (float)AD + a.eps);
-                            xv[0] = xv[0] * rr * nwv[ii][0]; xv[1] = xv[1] * rr * nwv[ii][1];
-                        }
-                        // rotate-half RoPE over the whole head: the partner of d is d +/- D/2 = the other element of this lane
-                        const float lo = xv[0], hi = xv[1];
-                        xv[0] = lo * a_cos - hi * a_sin;
-                        xv[1] = lo * a_sin + hi * a_cos;
+                    return spins;
+                };
+                // per-head RMSNorm (optional) + rotate-half RoPE over the whole head: the partner of d is d +/- D/2 = the other element of this lane
+                auto norm_rope = [&](float (&xv)[2], const float (&nw)[2], bool normed) __attribute__((always_inline)) {
+                    if (normed) {
+                        const float ss = wave_sum(xv[0] * xv[0] + xv[1] * xv[1]);
+                        const float rr = 1.0f / sqrtf(ss / (float)AD + a.eps);
+                        xv[0] = xv[0] * rr * nw[0]; xv[1] = xv[1] * rr * nw[1];
                     }
-                    if (item < NREP) {
-                        qs[item * AD + lane] = xv[0] * a.scale;
-                        qs[item * AD + lane + 64] = xv[1] * a.scale;
-                    } else {
-                        float* dst = item == NREP ? knew : vnew;
-                        CM_GLOBAL uint16_t* pool = (CM_GLOBAL uint16_t*)(item == NREP ? AL->kpool : AL->vpool);
-                        const size_t eoff = owner ? a_eoff : 0;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {       // (kv_f16 is launch-uniform: a scalar branch)
-                            const uint16_t b16 = a.kv_f16 ? f32_to_f16(xv[j]) : f32_to_bf16(xv[j]);
-                            dst[lane + 64 * j] = a.kv_f16 ? f16_to_f32(b16) : bf16_to_f32(b16);
-                            if (owner) pool[eoff + lane + 64 * j] = b16;
-                        }
+                    const float lo = xv[0], hi = xv[1];
+                    xv[0] = lo * a_cos - hi * a_sin;
+                    xv[1] = lo * a_sin + hi * a_cos;
+                };
+                // ================= part A: q and the old tokens =================
+                // this workgroup's own stream waves must be through the q rows of the QKV phase before its comm waves poll them
+                own_progress(prog_before + (uint32_t)(NSW * min(P->pre_attn, prev_nbt)) - (uint32_t)(NSW / 2), 0x600u + (uint32_t)(p - p0));   // (nearly: the polls are tiny)
+                stamp(p - p0, 1);
+                {
+                    float xv[2];
+                    tr_spins = poll_item(gA, xv, 0x700u + (uint32_t)(p - p0));
+                    if (has_q) {
+                        norm_rope(xv, nq, AL->qnw != nullptr);
+                        qs[cw * AD + lane] = xv[0] * a.scale;
+                        qs[cw * AD + lane + 64] = xv[1] * a.scale;
                     }
                 }
                 cbar();
@@ -334,7 +330,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
                 }
                 auto consume = [&](const u32x4& kqv, const u32x4& vqv, int t) __attribute__((always_inline)) {
-                    const bool valid = t < L;
+                    const bool valid = t < pos;               // (the token of this step is folded in by the merge, part B)
                     float kf[8], vf[8];
                     if (a.kv_f16) {
 #pragma unroll
@@ -348,10 +344,6 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                             kf[2 * e] = bf16_lo(kqv[e]); kf[2 * e + 1] = bf16_hi(kqv[e]);
                             vf[2 * e] = bf16_lo(vqv[e]); vf[2 * e + 1] = bf16_hi(vqv[e]);
                         }
-                    }
-                    if (t == pos) {   // the token appended by this very step: values from LDS
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { kf[e] = knew[dimbase + e]; vf[e] = vnew[dimbase + e]; }
                     }
 #pragma unroll
                     for (int h = 0; h < NREP; ++h) {
@@ -373,9 +365,9 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 stamp(p - p0, 4);
 #pragma unroll
                 for (int u = 0; u < NPRE; ++u)
-                    if (ACT * (split + nsplit * u) < L) consume(kq[u], vq[u], a_tt[u]);
-                for (int j = NPRE; ACT * (split + nsplit * j) < L; j += 2) {    // longer contexts: two more chunks per iteration
-                    const bool second = ACT * (split + nsplit * (j + 1)) < L;
+                    if (ACT * (split + nsplit * u) < pos) consume(kq[u], vq[u], a_tt[u]);
+                for (int j = NPRE; ACT * (split + nsplit * j) < pos; j += 2) {    // longer contexts: two more chunks per iteration
+                    const bool second = ACT * (split + nsplit * (j + 1)) < pos;
                     int tt[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -416,7 +408,26 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     gran_st(GP + pb + d, tag, O);
                     if (d == 0) { gran_st(GP + pb + AD, tag, M); gran_st(GP + pb + AD + 1, tag, Ls); }
                 }
-                // ---- merge: this workgroup owns OPB consecutive outputs of the group's NREP * D; gather them from every split ----
+                // ================= part B: the token of this step (its k / v rows have usually arrived by now; polled BEFORE the gather so that
+                // it runs in the shadow of the other splits' partials) =================
+                own_progress(prog_before + (uint32_t)(NSW * prev_nbt) - (uint32_t)(NSW / 2), 0x680u + (uint32_t)(p - p0));
+                {
+                    float xv[2];
+                    (void)poll_item(gB, xv, 0x780u + (uint32_t)(p - p0));
+                    if (kvj < 2) {
+                        if (kvj == 0) norm_rope(xv, nk, AL->knw != nullptr);
+                        float* dst = kvj == 0 ? knew : vnew;
+                        CM_GLOBAL uint16_t* pool = (CM_GLOBAL uint16_t*)(kvj == 0 ? AL->kpool : AL->vpool);
+                        const size_t eoff = owner ? a_eoff : 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {       // (kv_f16 is launch-uniform: a scalar branch)
+                            const uint16_t b16 = a.kv_f16 ? f32_to_f16(xv[j]) : f32_to_bf16(xv[j]);
+                            dst[lane + 64 * j] = a.kv_f16 ? f16_to_f32(b16) : bf16_to_f32(b16);
+                            if (owner) pool[eoff + lane + 64 * j] = b16;
+                        }
+                    }
+                }
+                // ---- this workgroup owns OPB consecutive outputs of the group's NREP * D; gather them from every split ----
                 const int OPB = NREP * AD / nsplit;                    // 16 on Qwen3-8B
                 const int o0 = split * OPB, hm = o0 / AD, d0 = o0 % AD;
                 {
@@ -449,7 +460,8 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     // one wave, all 64 lanes: lane = (output d, group of 8 source splits); every LDS read is independent
                     // of the others (a serial walk over 32 splits cost ~5 us of dependent LDS round trips)
                     const int d = lane & 15, sg = lane >> 4;
-                    float M = -INFINITY;
+                    const float s_new = wave_sum(qs[hm * AD + lane] * knew[lane] + qs[hm * AD + lane + 64] * knew[lane + 64]);
+                    float M = s_new;
 #pragma unroll
                     for (int s2 = 0; s2 < 32; ++s2) {
                         const float mv = mo[(s2 < nsplit ? s2 : 0) * 18 + 16];
@@ -463,6 +475,11 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                         const float w = (s2 < nsplit && mm > -INFINITY) ? expf(mm - M) : 0.f;
                         O += w * mo[sc * 18 + d];
                         Ls += w * mo[sc * 18 + 17];
+                    }
+                    if (sg == 0) {
+                        const float w = expf(s_new - M);
+                        O += w * vnew[(d0 + d) & (AD - 1)];
+                        Ls += w;
                     }
                     O += __shfl_xor(O, 16); Ls += __shfl_xor(Ls, 16);
                     O += __shfl_xor(O, 32); Ls += __shfl_xor(Ls, 32);

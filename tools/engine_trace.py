@@ -38,7 +38,7 @@ for rep in range(2):
         print(f"                  comm  : begin [{st(c[..., 0])}] poll[{st(c[..., 1])}] attn[{st(c[..., 2])}] stale sweeps avg {c[..., 3].mean():.1f} max {c[..., 3].max():.0f}")
         if (c[..., 4] > 0).any():
             sp = c[..., 7].astype(np.int64)
-            print(f"                  attn  : qkv+rope[{st(c[..., 4])}] scores[{st(c[..., 5])}] gathered[{st(c[..., 6])}]  failed polls: qkv avg {(sp & 0xFFFF).mean():.2f} max {(sp & 0xFFFF).max()}, gather avg {(sp >> 16).mean():.2f} max {(sp >> 16).max()}")
+            print(f"                  attn  : q+rope[{st(c[..., 4])}] old-token scores[{st(c[..., 5])}] k/v + gathered[{st(c[..., 6])}]  failed polls: q avg {(sp & 0xFFFF).mean():.2f} max {(sp & 0xFFFF).max()}, gather avg {(sp >> 16).mean():.2f} max {(sp >> 16).max()}")
     if os.environ.get("TRACE_XCD"):
         # stream-wave finish time of every phase by XCD (workgroup b runs on XCD b % 8) and by position inside the XCD
         for p in range(MAXPH):
