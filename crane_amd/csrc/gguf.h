@@ -16,7 +16,7 @@
 
 namespace cmgguf {
 
-enum GgmlType { F32 = 0, F16 = 1, Q4_0 = 2, Q5_0 = 6, Q8_0 = 8, Q4_K = 12, Q6_K = 14, BF16 = 30 };
+enum GgmlType { F32 = 0, F16 = 1, Q4_0 = 2, Q5_0 = 6, Q8_0 = 8, Q3_K = 11, Q4_K = 12, Q6_K = 14, BF16 = 30 };
 
 inline bool type_layout(uint32_t t, size_t& block_elems, size_t& block_bytes) {
     switch (t) {
@@ -25,6 +25,7 @@ inline bool type_layout(uint32_t t, size_t& block_elems, size_t& block_bytes) {
         case Q8_0: block_elems = 32; block_bytes = 34; return true;
         case Q4_0: block_elems = 32; block_bytes = 18; return true;
         case Q5_0: block_elems = 32; block_bytes = 22; return true;
+        case Q3_K: block_elems = 256; block_bytes = 110; return true;
         case Q4_K: block_elems = 256; block_bytes = 144; return true;
         case Q6_K: block_elems = 256; block_bytes = 210; return true;
         default: return false;

@@ -178,6 +178,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
         bool a_owner = false;
         int a_kvh = 0, a_split = 0, a_nsplit = 1;        // this workgroup's (kv head, token split) and the splits per kv head, once per launch
         bool a_attwg = false;                             //   (integer divisions: not on the per-layer critical path)
+        int append_layer = -1;                            // owner of the step's token: layer whose rounded k / v rows (LDS) still go to the pages
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) { a_koff[u] = 0; a_tt[u] = 0; }
         if (a.attn != nullptr) {
@@ -216,6 +217,25 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 continue;
             }
             stamp(p - p0, 0);
+            if (append_layer >= 0) {
+                // KV append of the previous phase's attention, off its critical path: a vector store queues behind this CU's weight
+                // loads, and every later poll of the same wave (s_waitcnt vmcnt) would wait for it -- the owner workgroup published its
+                // slice ~2 us after the others when the store sat in front of the gather.  The rounded rows are still in LDS.
+                if (cw == NCW - 1) {
+                    const CM_CONST EngAttnL* AL = (const CM_CONST EngAttnL*)a.attn + append_layer;
+                    CM_GLOBAL uint16_t* kpl = (CM_GLOBAL uint16_t*)AL->kpool;
+                    CM_GLOBAL uint16_t* vpl = (CM_GLOBAL uint16_t*)AL->vpool;
+                    const float* knew = asc + NREP * AD;
+                    const float* vnew = knew + AD;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float kx = knew[lane + 64 * j], vx = vnew[lane + 64 * j];
+                        kpl[a_eoff + lane + 64 * j] = a.kv_f16 ? f32_to_f16(kx) : f32_to_bf16(kx);
+                        vpl[a_eoff + lane + 64 * j] = a.kv_f16 ? f32_to_f16(vx) : f32_to_bf16(vx);
+                    }
+                }
+                append_layer = -1;
+            }
             if (P->pre_attn && !dbg_noattn && a_attwg) {
                 // ================= attention of this layer (split `blockIdx / Hkv` of kv head `blockIdx % Hkv`) =================
                 const CM_CONST EngAttnL* AL = (const CM_CONST EngAttnL*)a.attn + P->layer;
@@ -417,13 +437,10 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     if (kvj < 2) {
                         if (kvj == 0) norm_rope(xv, nk, AL->knw != nullptr);
                         float* dst = kvj == 0 ? knew : vnew;
-                        CM_GLOBAL uint16_t* pool = (CM_GLOBAL uint16_t*)(kvj == 0 ? AL->kpool : AL->vpool);
-                        const size_t eoff = owner ? a_eoff : 0;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {       // (kv_f16 is launch-uniform: a scalar branch)
                             const uint16_t b16 = a.kv_f16 ? f32_to_f16(xv[j]) : f32_to_bf16(xv[j]);
                             dst[lane + 64 * j] = a.kv_f16 ? f16_to_f32(b16) : bf16_to_f32(b16);
-                            if (owner) pool[eoff + lane + 64 * j] = b16;
                         }
                     }
                 }
@@ -486,6 +503,7 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                     if (lane < OPB) gran_st(a.gran[ENG_E_ATTN] + (size_t)(kvh * NREP + hm) * AD + d0 + lane, tag, O * (1.0f / Ls));
                 }
                 stamp(p - p0, 2);          // (`mo`, qs, red_* are next written a whole layer later)
+                if (owner) append_layer = P->layer;
             } else {
                 // (a workgroup outside the attention -- or a launch without it -- still waits for its own stream waves to be through
                 // the producing phase before it polls the attention output: 224 workgroups polling through QKV + attention would

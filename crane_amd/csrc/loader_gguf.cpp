@@ -123,9 +123,56 @@ void pack_rows(const TensorInfo& t, int row0, int nrows, int Kfull, Packed& out,
                 memcpy(&out.p3[o3 + bi * 2], src + b * 210 + 208, 2);
             }
         }
+    } else if (t.type == cmgguf::Q3_K) {
+        // Q3_K: y = d (sc_j - 32) (q - 4 | q) with 16 sub-blocks of 16, 6-bit scales and 3-bit codes in [-4, 3] -- EXACTLY a Q6_K block
+        // with int8 scales sc_j - 32 in [-32, 31] and 6-bit codes q + 32: widened at load into the Q6_K stream layout (no
+        // re-quantisation; ggml_vec_dot_q3_K_q8_K and _q6_K_q8_K are the same integer arithmetic: sum_j scale_j sum_16 q q8, times d d8).
+        // The price is the footprint (0.82 bytes per weight instead of 0.43): format coverage, as for Q4_0 / Q5_0.
+        if (Kfull % 256) throw CmError(CM_ERR_UNSUPPORTED, "Q3_K needs K % 256 == 0 (" + t.name + ")");
+        out.fmt = QFMT_Q6_K;
+        const size_t o0 = out.p0.size(), o1 = out.p1.size(), o2 = out.p2.size(), o3 = out.p3.size();
+        out.p0.resize(o0 + (size_t)nrows * K / 2);
+        out.p1.resize(o1 + (size_t)nrows * K / 4);
+        out.p2.resize(o2 + (size_t)nrows * K / 16);
+        out.p3.resize(o3 + (size_t)nrows * nb256 * 2);
+        for (int r = 0; r < nrows; ++r) {
+            const uint8_t* src = t.data + ((size_t)(row0 + r) * fb256 + b256_0) * 110;
+            for (size_t b = 0; b < nb256; ++b) {
+                const uint8_t* blkp = src + b * 110;
+                const uint8_t *hm = blkp, *qs = blkp + 32, *sb = blkp + 96;
+                const size_t bi = (size_t)r * nb256 + b;
+                // the 16 six-bit scales (dequantize_row_q3_K's aux[] shuffle)
+                uint32_t aux[4]; memcpy(aux, sb, 12);
+                const uint32_t k1 = 0x03030303u, k2 = 0x0f0f0f0fu, tmp = aux[2];
+                aux[2] = ((aux[0] >> 4) & k2) | (((tmp >> 4) & k1) << 4);
+                aux[3] = ((aux[1] >> 4) & k2) | (((tmp >> 6) & k1) << 4);
+                aux[0] = (aux[0] & k2) | (((tmp >> 0) & k1) << 4);
+                aux[1] = (aux[1] & k2) | (((tmp >> 2) & k1) << 4);
+                const uint8_t* s6 = (const uint8_t*)aux;
+                for (int j = 0; j < 16; ++j) out.p2[o2 + bi * 16 + j] = (uint8_t)(int8_t)((int)s6[j] - 32);
+                memcpy(&out.p3[o3 + bi * 2], blkp + 108, 2);
+                // codes in weight order, biased by 32 (Q6_K stores q + 32 in 0 .. 63)
+                uint8_t c[256];
+                for (int n = 0; n < 2; ++n)
+                    for (int j = 0; j < 4; ++j)
+                        for (int l = 0; l < 32; ++l) {
+                            const int lo = (qs[32 * n + l] >> (2 * j)) & 3, hb = (hm[l] >> (4 * n + j)) & 1;
+                            c[128 * n + 32 * j + l] = (uint8_t)(lo - (hb ? 0 : 4) + 32);
+                        }
+                uint8_t* ql = &out.p0[o0 + bi * 128];
+                uint8_t* qh = &out.p1[o1 + bi * 64];
+                for (int h = 0; h < 2; ++h)
+                    for (int l = 0; l < 32; ++l) {
+                        const uint8_t a1 = c[128 * h + l], a2 = c[128 * h + 32 + l], a3 = c[128 * h + 64 + l], a4 = c[128 * h + 96 + l];
+                        ql[64 * h + l] = (uint8_t)((a1 & 0xF) | ((a3 & 0xF) << 4));
+                        ql[64 * h + 32 + l] = (uint8_t)((a2 & 0xF) | ((a4 & 0xF) << 4));
+                        qh[32 * h + l] = (uint8_t)((a1 >> 4) | ((a2 >> 4) << 2) | ((a3 >> 4) << 4) | ((a4 >> 4) << 6));
+                    }
+            }
+        }
     } else {
         throw CmError(CM_ERR_UNSUPPORTED, "GGUF tensor " + t.name + ": ggml type " + std::to_string(t.type) +
-                                              " is not supported for matrices (Q4_0, Q5_0, Q8_0, Q4_K, Q6_K)");
+                                              " is not supported for matrices (Q4_0, Q5_0, Q8_0, Q3_K, Q4_K, Q6_K)");
     }
 }
 

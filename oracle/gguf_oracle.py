@@ -12,8 +12,10 @@ Block formats (little endian):
   Q8_0  32 weights : f16 d; i8 qs[32]                                   y = d * q
   Q4_K  256 weights: f16 d; f16 dmin; u8 scales[12]; u8 qs[128]         y = d*sc_j*q - dmin*m_j   (8 sub-blocks of 32)
   Q6_K  256 weights: u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d        y = d*sc_j*(q - 32)        (16 sub-blocks of 16)
-Dequantisers are exact restatements (dequantize_row_q4_0 / _q5_0 / _q8_0 / _q4_K / _q6_K).  quantize_q8_0 / _q4_0 / _q5_0 restate
-quantize_row_q8_0_ref / _q4_0_ref / _q5_0_ref exactly; the Q4_K / Q6_K *quantisers* here are simple valid encoders for writing test files
+  Q3_K  256 weights: u8 hmask[32]; u8 qs[64]; u8 scales[12]; f16 d     y = d*(sc_j - 32)*(q2 - (hbit ? 0 : 4))   (16 sub-blocks of 16;
+                     6-bit scales packed in 12 bytes, 2 low code bits in qs, the third -- inverted -- in hmask)
+Dequantisers are exact restatements (dequantize_row_q4_0 / _q5_0 / _q8_0 / _q4_K / _q6_K / _q3_K).  quantize_q8_0 / _q4_0 / _q5_0 restate
+quantize_row_q8_0_ref / _q4_0_ref / _q5_0_ref exactly; the Q4_K / Q6_K / Q3_K *quantisers* here are simple valid encoders for writing test files
 (ggml's make_qkx2_quants search is not reproduced -- PARITY UNPINNED for K-quant ISQ, which crane_amd does not offer).
 """
 import struct
@@ -23,10 +25,11 @@ import numpy as np
 
 GGML_F32, GGML_F16, GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_BF16 = 0, 1, 8, 12, 14, 30
 GGML_Q4_0, GGML_Q5_0 = 2, 6
+GGML_Q3_K = 11
 BLOCK = {GGML_F32: (1, 4), GGML_F16: (1, 2), GGML_BF16: (1, 2), GGML_Q8_0: (32, 34), GGML_Q4_K: (256, 144), GGML_Q6_K: (256, 210),
-         GGML_Q4_0: (32, 18), GGML_Q5_0: (32, 22)}
+         GGML_Q4_0: (32, 18), GGML_Q5_0: (32, 22), GGML_Q3_K: (256, 110)}
 TYPE_NAMES = {"f32": GGML_F32, "f16": GGML_F16, "bf16": GGML_BF16, "q8_0": GGML_Q8_0, "q4_k": GGML_Q4_K, "q6_k": GGML_Q6_K,
-              "q4_0": GGML_Q4_0, "q5_0": GGML_Q5_0}
+              "q4_0": GGML_Q4_0, "q5_0": GGML_Q5_0, "q3_k": GGML_Q3_K}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -235,6 +238,76 @@ def quantize_q6_k(x: np.ndarray) -> np.ndarray:
     return out.reshape(-1)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Q3_K (ggml-quants.c block_q3_K / dequantize_row_q3_K; candle k_quants.rs BlockQ3K)
+# ---------------------------------------------------------------------------------------------------------
+def _q3k_scales(sb: np.ndarray) -> np.ndarray:
+    """[nb, 12] packed bytes -> [nb, 16] 6-bit scales (before the - 32), the aux[] shuffle of dequantize_row_q3_K."""
+    a = np.ascontiguousarray(sb, np.uint8).view("<u4").astype(np.uint64)           # [nb, 3]
+    k1, k2 = 0x03030303, 0x0F0F0F0F
+    tmp = a[:, 2]
+    o = np.zeros((a.shape[0], 4), np.uint64)
+    o[:, 2] = ((a[:, 0] >> 4) & k2) | (((tmp >> 4) & k1) << 4)
+    o[:, 3] = ((a[:, 1] >> 4) & k2) | (((tmp >> 6) & k1) << 4)
+    o[:, 0] = (a[:, 0] & k2) | (((tmp >> 0) & k1) << 4)
+    o[:, 1] = (a[:, 1] & k2) | (((tmp >> 2) & k1) << 4)
+    return o.astype("<u4").view(np.uint8).reshape(-1, 16)
+
+
+def _q3k_codes(b: np.ndarray) -> np.ndarray:
+    """[nb, 110] raw Q3_K blocks -> [nb, 256] signed codes in [-4, 3], weight order."""
+    hm, qs = b[:, 0:32], b[:, 32:96]
+    y = np.zeros((b.shape[0], 256), np.int32)
+    l = np.arange(32)
+    for n in range(2):
+        for j in range(4):
+            lo = ((qs[:, 32 * n + l] >> (2 * j)) & 3).astype(np.int32)
+            hb = (hm[:, l] >> (4 * n + j)) & 1
+            y[:, 128 * n + 32 * j + l] = lo - np.where(hb != 0, 0, 4)
+    return y
+
+
+def dequantize_q3_k(raw: np.ndarray, n: int) -> np.ndarray:
+    b = np.asarray(raw, np.uint8).reshape(-1, 110)
+    sc = _q3k_scales(b[:, 96:108]).astype(np.int32) - 32                               # [nb, 16]
+    d = b[:, 108:110].copy().view(np.float16).astype(np.float32)[:, 0]
+    q = _q3k_codes(b).reshape(-1, 16, 16)
+    dl = (d[:, None] * sc.astype(np.float32)).astype(np.float32)                       # d_all * (scales[is] - 32)
+    return (dl[:, :, None] * q.astype(np.float32)).astype(np.float32).reshape(-1)[:n]
+
+
+def quantize_q3_k(x: np.ndarray) -> np.ndarray:
+    """A simple valid Q3_K encoder (symmetric per 16-weight sub-block, 6-bit scale against the super-block; negative scales are used
+    when the sub-block's largest magnitude is positive, so that it lands on the code -4)."""
+    x = np.asarray(x, np.float32).reshape(-1, 16, 16)
+    nb = x.shape[0]
+    i = np.abs(x).argmax(axis=2)
+    mx = np.take_along_axis(x, i[:, :, None], axis=2)[:, :, 0]                         # signed value of the largest magnitude
+    sub = -mx / 4.0                                                                      # that value -> code -4
+    d = (np.abs(sub).max(axis=1) / 31.0).astype(np.float16).astype(np.float32)
+    sc = np.clip(np.rint(sub / np.where(d > 0, d, 1)[:, None]), -32, 31).astype(np.int32)
+    eff = d[:, None] * sc.astype(np.float32)
+    q = np.clip(np.rint(x / np.where(eff != 0, eff, 1)[:, :, None]), -4, 3).astype(np.int32).reshape(nb, 256)
+    u = (q + 4).astype(np.uint8)                                                         # 0..7: bit 2 = hmask bit, bits 0-1 = qs
+    out = np.zeros((nb, 110), np.uint8)
+    l = np.arange(32)
+    for n in range(2):
+        for j in range(4):
+            v = u[:, 128 * n + 32 * j + l]
+            out[:, 32 + 32 * n + l] |= (v & 3) << (2 * j)
+            out[:, l] |= ((v >> 2) & 1) << (4 * n + j)
+    s6 = (sc + 32).astype(np.uint8)                                                      # 0..63, packed like ggml: low 4 bits of scale j in byte
+    for j in range(16):                                                                  # j (< 8: low nibble, >= 8: high nibble of byte j - 8),
+        lo4, hi2 = s6[:, j] & 0xF, s6[:, j] >> 4                                         # high 2 bits in bytes 8..11
+        if j < 8:
+            out[:, 96 + j] |= lo4
+        else:
+            out[:, 96 + j - 8] |= lo4 << 4
+        out[:, 96 + 8 + (j % 4)] |= hi2 << (2 * (j // 4))
+    out[:, 108:110] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    return out.reshape(-1)
+
+
 def _bf16_bytes(x: np.ndarray) -> np.ndarray:
     u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
     r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
@@ -250,7 +323,7 @@ def quantize(x: np.ndarray, ggml_type: int) -> np.ndarray:
     if ggml_type == GGML_BF16:
         return _bf16_bytes(x)
     return {GGML_Q8_0: quantize_q8_0, GGML_Q4_K: quantize_q4_k, GGML_Q6_K: quantize_q6_k, GGML_Q4_0: quantize_q4_0,
-            GGML_Q5_0: quantize_q5_0}[ggml_type](x)
+            GGML_Q5_0: quantize_q5_0, GGML_Q3_K: quantize_q3_k}[ggml_type](x)
 
 
 def dequantize(raw: np.ndarray, ggml_type: int, n: int) -> np.ndarray:
@@ -262,7 +335,7 @@ def dequantize(raw: np.ndarray, ggml_type: int, n: int) -> np.ndarray:
     if ggml_type == GGML_BF16:
         return (raw.view(np.uint16)[:n].astype(np.uint32) << 16).view(np.float32)
     return {GGML_Q8_0: dequantize_q8_0, GGML_Q4_K: dequantize_q4_k, GGML_Q6_K: dequantize_q6_k, GGML_Q4_0: dequantize_q4_0,
-            GGML_Q5_0: dequantize_q5_0}[ggml_type](raw, n)
+            GGML_Q5_0: dequantize_q5_0, GGML_Q3_K: dequantize_q3_k}[ggml_type](raw, n)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -416,7 +489,7 @@ def write_qwen3_gguf(path: str, cfg: dict, weights_f32: Dict[str, np.ndarray], t
         tensors.append((gg, w, gt))
         raw = quantize(w, gt)
         deq[hf] = dequantize(raw, gt, w.size).reshape(w.shape)
-        if want_qmats and w.ndim == 2 and gt in (GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_Q4_0, GGML_Q5_0):
+        if want_qmats and w.ndim == 2 and gt in (GGML_Q8_0, GGML_Q4_K, GGML_Q6_K, GGML_Q4_0, GGML_Q5_0, GGML_Q3_K):
             qm[hf] = QuantMatrix(raw, gt, w.shape)
     write_gguf(path, qwen3_metadata(cfg), tensors)
     return (deq, qm) if want_qmats else deq
@@ -513,6 +586,14 @@ class QuantMatrix:
             self.q = (deq_codes.astype(np.int32) - 32).reshape(N, K // 256, 16, 16)
             self.sc = b[:, 192:208].copy().view(np.int8).astype(np.int32).reshape(N, -1, 16)
             self.d = b[:, 208:210].copy().view(np.float16).astype(np.float32)[:, 0].reshape(N, -1)
+        elif ggml_type == GGML_Q3_K:
+            # ggml_vec_dot_q3_K_q8_K: per super-block sum_j (scales[j] - 32) * sum_16 q q8 with q in [-4, 3], times d * d8 -- the Q6_K
+            # arithmetic on narrower codes (16 sub-blocks of 16, int8 scales, one f16 d)
+            b = np.asarray(raw, np.uint8).reshape(-1, 110)
+            self.q = _q3k_codes(b).reshape(N, K // 256, 16, 16)
+            self.sc = (_q3k_scales(b[:, 96:108]).astype(np.int32) - 32).reshape(N, -1, 16)
+            self.d = b[:, 108:110].copy().view(np.float16).astype(np.float32)[:, 0].reshape(N, -1)
+            self.gt = GGML_Q6_K
         else:
             raise ValueError("QuantMatrix: unsupported ggml type")
 

@@ -50,6 +50,42 @@ def test_q4_0_and_q5_0_known_blocks():
         assert np.abs(qm.vecdot(xv) - deq @ xv).max() < 0.02 * np.abs(deq @ xv).max() + 1e-3
 
 
+def test_q3_k_known_block():
+    """A hand-built Q3_K super-block (ggml-quants.c block_q3_K: hmask[32], qs[64], scales[12], d): the inverted third bit, the 2-bit
+    planes, the 6-bit scale packing (low nibbles in bytes 0-7, high pairs in bytes 8-11) and the - 32; then the encoder / QuantMatrix."""
+    b = np.zeros(110, np.uint8)
+    b[108:110] = np.array([0.5], np.float16).view(np.uint8)
+    hm, qs, sc = b[0:32], b[32:96], b[96:108]
+    # scales: sub-block 0 = 35 (-> +3), sub-block 1 = 0 (-> -32), sub-block 9 = 63 (-> +31), sub-block 15 = 33 (-> +1)
+    sc[0] = 35 & 0xF; sc[8] |= (35 >> 4) << 0                 # j = 0: low nibble of byte 0, high bits = bits 0-1 of byte 8
+    sc[1] = 0
+    sc[1] |= (63 & 0xF) << 4; sc[8 + 1] |= (63 >> 4) << 4     # j = 9: high nibble of byte 1, high bits = bits 4-5 of byte 9
+    sc[7] |= (33 & 0xF) << 4; sc[8 + 3] |= (33 >> 4) << 6     # j = 15: high nibble of byte 7, high bits = bits 6-7 of byte 11
+    # element 0 (n 0, j 0, l 0): low bits 3, hmask bit 0 set -> code 3; element 1: low 2, bit clear -> 2 - 4 = -2
+    qs[0] = 3; hm[0] |= 1
+    qs[1] = 2
+    # element 16 (sub-block 1; n 0, j 0, l 16): low 1, bit clear -> -3 under the scale -32
+    qs[16] = 1
+    # element 144 (sub-block 9: n 1, j 0, l 16): qs byte 32 + 16, shift 0; hmask bit 4 of byte 16 -> code 1
+    qs[32 + 16] |= 1; hm[16] |= 1 << 4
+    # element 255 (sub-block 15: n 1, j 3, l 31): qs byte 32 + 31 shift 6; hmask bit 7 of byte 31: low 0, bit clear -> -4
+    y = G.dequantize_q3_k(b, 256)
+    assert y[0] == 0.5 * 3 * 3 and y[1] == 0.5 * 3 * -2
+    assert y[16] == 0.5 * -32 * -3
+    assert y[144] == 0.5 * 31 * 1
+    assert y[255] == 0.5 * 1 * -4
+    assert y[2] == 0.5 * 3 * -4                               # an all-zero element decodes to -4 under its sub-block's scale
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((3, 512)) * 0.1).astype(np.float32)
+    raw = G.quantize(w, G.GGML_Q3_K)
+    assert raw.size == 3 * 2 * 110
+    deq = G.dequantize(raw, G.GGML_Q3_K, w.size).reshape(w.shape)
+    assert np.abs(deq - w).max() <= 0.3 * np.abs(w).max()     # three bits
+    xv = rng.standard_normal(512).astype(np.float32)
+    qm = G.QuantMatrix(raw, G.GGML_Q3_K, w.shape)             # Q3_K x Q8_K integer dots (the Q6_K arithmetic on narrower codes)
+    assert np.abs(qm.vecdot(xv) - deq @ xv).max() < 0.02 * np.abs(deq @ xv).max() + 1e-3
+
+
 def test_q4_k_known_block():
     b = np.zeros(144, np.uint8)
     b[0:2] = np.array([2.0], np.float16).view(np.uint8)       # d

@@ -18,7 +18,7 @@ def rel(a, ref):
 
 
 def _types(kind):
-    if kind in ("q8_0", "q4_k", "q6_k", "q4_0", "q5_0"):
+    if kind in ("q8_0", "q4_k", "q6_k", "q4_0", "q5_0", "q3_k"):
         t = G.TYPE_NAMES[kind]
         return lambda name, shape: t
     if kind == "q4_k_m":             # llama.cpp's Q4_K_M recipe in outline: Q6_K for attn_v, ffn_down, the embedding / head; Q4_K for the rest
@@ -27,6 +27,14 @@ def _types(kind):
                 return G.GGML_Q6_K
             return G.GGML_Q4_K
         return q4km
+    if kind == "q3_k_m":             # llama.cpp's Q3_K_M recipe in outline (its Q5_K tensors as Q6_K): Q3_K projections, Q4_K down / value, Q6_K head
+        def q3km(name, shape):
+            if name in ("token_embd.weight", "output.weight"):
+                return G.GGML_Q6_K
+            if "attn_v" in name or "ffn_down" in name:
+                return G.GGML_Q4_K
+            return G.GGML_Q3_K
+        return q3km
     if kind == "legacy-mixed":       # Q4_0 projections, Q5_0 value / up / embedding rows, Q8_0 head: the legacy 32-weight formats together
         def legacy(name, shape):
             if "attn_v" in name or "ffn_up" in name or name == "token_embd.weight":
@@ -63,7 +71,7 @@ def _check(m, oracle, V, n_prompt=19, n_decode=6, tol=2e-4, exact_tokens=True):
 
 
 @pytest.mark.parametrize("name", ["tiny-qwen3", "tiny-qwen3-untied"])
-@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed", "q4_0", "q5_0", "legacy-mixed"])
+@pytest.mark.parametrize("kind", ["q8_0", "q4_k", "q6_k", "mixed", "q4_0", "q5_0", "legacy-mixed", "q3_k", "q3_k_m"])
 @pytest.mark.parametrize("act", ["int", "f32"])
 def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
     """act=int (default): ggml / candle vec_dot semantics -- the activation row is quantised to Q8_0 / Q8_K and block
@@ -91,11 +99,12 @@ def test_gguf_checkpoint_matches_oracle(tmp_path, monkeypatch, name, kind, act):
         xh = rng.standard_normal(H).astype(np.float32)
         xi = (rng.standard_normal(I) * np.abs(rng.standard_normal(I))).astype(np.float32)
         mats = {"o": (P + "self_attn.o_proj.weight", None), "down": (P + "mlp.down_proj.weight", xi)}
-        if kind not in ("mixed", "legacy-mixed"):
+        if kind not in ("mixed", "legacy-mixed", "q3_k_m"):
             mats["qkv0"] = ([P + f"self_attn.{n}_proj.weight" for n in "qkv"], xh)
         else:
-            mats.update({"qkv0": ([P + "self_attn.q_proj.weight"], xh), "qkv2": ([P + "self_attn.v_proj.weight"], xh),
-                         "gate": ([P + "mlp.gate_proj.weight"], xh), "up": ([P + "mlp.up_proj.weight"], xh)})
+            mats.update({"qkv0": ([P + "self_attn.q_proj.weight"], xh), "qkv2": ([P + "self_attn.v_proj.weight"], xh)})
+            if kind != "q3_k_m":       # (there gate and up share a type and are stored merged)
+                mats.update({"gate": ([P + "mlp.gate_proj.weight"], xh), "up": ([P + "mlp.up_proj.weight"], xh)})
         for which, (names, xv) in mats.items():
             names = [names] if isinstance(names, str) else names
             if xv is None:
