@@ -474,32 +474,27 @@ __global__ __launch_bounds__((NSW + NCW) * 64, (NSW + NCW + 3) / 4) void engine_
                 stamp(p - p0, 7, (u64)tr_spins);
                 cbar();
                 if (cw == 0) {
-                    // one wave, all 64 lanes: lane = (output d, group of 8 source splits); every LDS read is independent
-                    // of the others (a serial walk over 32 splits cost ~5 us of dependent LDS round trips)
+                    // one wave on the critical path of the layer (it was 1.8 - 2.3 us: 32 + 24 LDS reads and 9 exps per lane): lane s < nsplit
+                    // owns split s -- its weight is ONE exp, the maximum and the denominator are wave reductions --, then lane (output d,
+                    // group of 8 splits) gathers the weights by lane permutes and its 8 values from LDS
                     const int d = lane & 15, sg = lane >> 4;
                     const float s_new = wave_sum(qs[hm * AD + lane] * knew[lane] + qs[hm * AD + lane + 64] * knew[lane + 64]);
-                    float M = s_new;
-#pragma unroll
-                    for (int s2 = 0; s2 < 32; ++s2) {
-                        const float mv = mo[(s2 < nsplit ? s2 : 0) * 18 + 16];
-                        M = fmaxf(M, mv);
-                    }
-                    float O = 0.f, Ls = 0.f;
+                    const int sl = lane < nsplit ? lane : 0;
+                    const float ms = lane < nsplit ? mo[sl * 18 + 16] : -INFINITY;
+                    const float ls = mo[sl * 18 + 17];
+                    const float M = fmaxf(wave_max(ms), s_new);
+                    const float ws = ms > -INFINITY ? expf(ms - M) : 0.f;
+                    const float w_new = expf(s_new - M);
+                    const float Ls = wave_sum(ws * ls) + w_new;
+                    float O = 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const int s2 = sg * 8 + i, sc = s2 < nsplit ? s2 : 0;
-                        const float mm = mo[sc * 18 + 16];
-                        const float w = (s2 < nsplit && mm > -INFINITY) ? expf(mm - M) : 0.f;
-                        O += w * mo[sc * 18 + d];
-                        Ls += w * mo[sc * 18 + 17];
+                        const int s2 = sg * 8 + i;
+                        O += __shfl(ws, s2) * mo[(s2 < nsplit ? s2 : 0) * 18 + d];       // (ws = 0 past the last split)
                     }
-                    if (sg == 0) {
-                        const float w = expf(s_new - M);
-                        O += w * vnew[(d0 + d) & (AD - 1)];
-                        Ls += w;
-                    }
-                    O += __shfl_xor(O, 16); Ls += __shfl_xor(Ls, 16);
-                    O += __shfl_xor(O, 32); Ls += __shfl_xor(Ls, 32);
+                    if (sg == 0) O += w_new * vnew[(d0 + d) & (AD - 1)];
+                    O += __shfl_xor(O, 16);
+                    O += __shfl_xor(O, 32);
                     if (lane < OPB) gran_st(a.gran[ENG_E_ATTN] + (size_t)(kvh * NREP + hm) * AD + d0 + lane, tag, O * (1.0f / Ls));
                 }
                 stamp(p - p0, 2);          // (`mo`, qs, red_* are next written a whole layer later)
