@@ -143,7 +143,7 @@ typedef struct cm_model cm_model;
  * `model_dir`, merges QKV and gate||up at load (modeling.rs:187-204,582-588),
  * ties lm_head to the embedding when the config says so (modeling.rs:786-794).
  * A path ending in ".gguf" is loaded as a GGUF checkpoint instead (ModelFormat::Auto,
- * qwen3/model.rs:55-71,108-152): Q8_0 / Q4_0 / Q5_0 (widened exactly into the Q8_0 layout) / Q4_K / Q6_K matrices stay
+ * qwen3/model.rs:55-71,108-152): Q8_0 / Q4_0 / Q5_0 (widened exactly into the Q8_0 layout) / Q4_K / Q6_K / Q3_K (widened exactly into Q6_K) matrices stay
  * quantised in HBM (LinearLayer::Quantized, ops/linear.rs:18-51) and are decoded inside the GEMV; decode groups of 25 or more
  * sequences over Q8_0-layout matrices run on the int8 matrix cores.  Other ggml types: CM_ERR_UNSUPPORTED. */
 int cm_create(const char* model_dir, const cm_opts* opts, cm_model** out);
