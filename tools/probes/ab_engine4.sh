@@ -9,5 +9,5 @@ for l in sys.stdin:
 run() { local m=$1; shift
   echo -n "$m $*: "
   env "$@" timeout 300 python bench.py --model $m --no-cpu-baseline --steps 64 --warmup 8 2>$OUT/ab_err.log | line; }
-for t in 0x880 0x881 0x480 0x8c0 0x840 0x880 0x881; do run qwen3-8b CM_ENG_TUNE=$t; done
-for t in 0x0 0x1 0x880; do run qwen3-0.6b CM_ENG_TUNE=$t; done
+for t in 0x880 0x881 0x880 0x881; do run qwen3-8b CM_ENG_TUNE=$t; done
+for t in 0x0 0x1 0x0 0x1; do run qwen3-0.6b CM_ENG_TUNE=$t; done
