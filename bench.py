@@ -313,8 +313,8 @@ def main():
                 san = args.model.replace("-", "_").replace(".", "_")
                 # newest first; re-collected whenever kernels_engine.hip / the decode GEMVs change (tools/gpu_round.sh traffic)
                 # (round 5: the whole-token kernel also streams the embedding row, the final norm and lm_head -- its launch is r05's)
-                srcs = ("r06_pmc_traffic_decode_qwen3_8b.json", "r05_pmc_traffic_decode_qwen3_8b.json") if args.model == "qwen3-8b" else \
-                    (f"r05_pmc_traffic_decode_{san}.json", f"r04_pmc_traffic_decode_{san}.json", f"r03_pmc_traffic_decode_{san}.json")
+                srcs = (f"r06_pmc_traffic_decode_{san}.json", f"r05_pmc_traffic_decode_{san}.json", f"r04_pmc_traffic_decode_{san}.json",
+                        f"r03_pmc_traffic_decode_{san}.json")
                 for src in srcs:
                     path = os.path.join(ROOT, "profiles", src)
                     if not os.path.exists(path):
