@@ -120,6 +120,33 @@ def test_chain_context_beyond_the_prefetched_chunks(ctx):
     assert rel(outs[0][1], outs[1][1]) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["eng-qwen3", "eng-qwen3-gqa2"])
+@pytest.mark.parametrize("ctx", [500, 2036])
+def test_chain_steps_across_the_split_round_boundaries(name, ctx):
+    """whole-token mode, round 6 (attention in two parts: the old tokens from the pages, the step's own token folded in by the merging
+    wave): steps that carry the context across a split round (32 splits x 16 tokens = 512: the new token opens chunk 1 of split 0) and
+    across the prefetched chunks (4 x 512 = 2048) -- tokens and logits of the launch path at every position"""
+    cfg = configs.get_config(name)
+    outs = []
+    for engine in (1, -1):
+        m = Model.synthetic(cfg, seed=0, max_seq_len=ctx + 128, max_seqs=1, engine=engine)
+        try:
+            if engine == 1:
+                assert m.engine_active() == 2
+            m.debug_fill_kv(ctx, seed=9)
+            tok, lgs = 11, []
+            for pos in range(ctx, ctx + 30):                     # 500 .. 529 / 2036 .. 2065
+                lg = m.forward_step([tok], pos)[0, 0]
+                lgs.append(lg.copy())
+                tok = int(lg.argmax())
+            outs.append(lgs)
+        finally:
+            m.close()
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert rel(a, b) < 1e-4, (ctx + i, rel(a, b))
+        assert int(a.argmax()) == int(b.argmax())
+
+
 def test_engine_refused_when_shapes_do_not_fit():
     from crane_amd._lib import CraneError
     cfg = configs.get_config("tiny-qwen3")               # hidden 256: not a multiple of 2048
