@@ -1248,7 +1248,10 @@ static bool try_gemm256(GemmArgs& a, int epi, hipStream_t s) {
     static const int env = getenv("CM_GEMM256") ? atoi(getenv("CM_GEMM256")) : 1;
     static const int force_bn = getenv("CM_GEMM256_BN") ? atoi(getenv("CM_GEMM256_BN")) : 0;     // tuning
     static const int force_ks = getenv("CM_GEMM256_KS") ? atoi(getenv("CM_GEMM256_KS")) : 0;
-    static const int min_m2 = getenv("CM_GEMM256_MIN_M") ? atoi(getenv("CM_GEMM256_MIN_M")) : 33;      // hi + lo: 128-row tiles, 64-row tiles up to 64 rows
+    // hi + lo: 128-row tiles, 64-row tiles up to 64 rows.  From 9 rows on (round 6; was 33): a decode round of 16 / 32 sequences 5.87 / 6.25 ->
+    // 5.41 / 5.82 ms against the 128-wide kernel + split-K (profiles/r06_small_group_gemm_ab.log); a 32-row tile variant measured no faster
+    // than the 64-row one (the launch is not bound by its MFMAs), 8 rows run on the batched GEMVs
+    static const int min_m2 = getenv("CM_GEMM256_MIN_M") ? atoi(getenv("CM_GEMM256_MIN_M")) : 9;
     static const int min_blocks = getenv("CM_GEMM256_MIN_BLOCKS") ? atoi(getenv("CM_GEMM256_MIN_BLOCKS")) : 128;
     if (!env || !a.wide256 || a.M < (a.A_lo ? min_m2 : 512) || a.K % 64 != 0) return false;
     // round 6: the one-wave-per-SIMD kernel (kernels_gemmw4.hip) -- built, bit-compatible, measured 0 .. 4 % SLOWER than the ping-pong kernel
