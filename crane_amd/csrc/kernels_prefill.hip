@@ -1141,36 +1141,49 @@ template <int KS, bool LN>
 __global__ __launch_bounds__(256) void gemm_splitk_resadd_norm_kernel(GemmArgs a) {
     __shared__ float red[8];
     const int m = blockIdx.x, tid = threadIdx.x;
-    float* cr = a.C + (size_t)m * a.ldc;
+    float* __restrict__ cr = a.C + (size_t)m * a.ldc;            // (the partial slices and the row of C never overlap: the loads of the next
+    const float* __restrict__ wsr = a.ws + (size_t)m * a.N;      //  chunks may pass this chunk's store)
     const size_t slice = (size_t)a.M * a.N;
     float ss = 0.f, ls = 0.f;
-#pragma unroll 2
-    for (int n = tid * 4; n < a.N; n += 1024) {
-        const float* p0 = a.ws + (size_t)m * a.N + n;
-        f32x4 v;
-        if (KS > 0) {
-            f32x4 p[KS > 0 ? KS : 1];
+    // All partial / residual loads of NC chunks of the row go out before the first of them is consumed (one block per row: at 64 rows a
+    // quarter of the chip runs this kernel, so it is the round trips per thread that take the time, not the bytes); the sums keep their order
+    constexpr int NC = 4;
+    for (int n0 = tid * 4; n0 < a.N; n0 += 1024 * NC) {
+        f32x4 p[NC][KS > 0 ? KS : 1], c[NC], bv[NC];
 #pragma unroll
-            for (int k = 0; k < KS; ++k) p[k] = *(const f32x4*)(p0 + (size_t)k * slice);
-            v = p[0];
+        for (int i = 0; i < NC; ++i) {
+            const int n = n0 + 1024 * i < a.N ? n0 + 1024 * i : n0;      // (a chunk past the row re-reads the first one: unconditional loads)
+            const float* __restrict__ p0 = wsr + n;
+            if (KS > 0) {
 #pragma unroll
-            for (int k = 1; k < KS; ++k) { v[0] += p[k][0]; v[1] += p[k][1]; v[2] += p[k][2]; v[3] += p[k][3]; }
-        } else {
-            v = *(const f32x4*)p0;
-            for (int k = 1; k < a.ksplit; ++k) {
-                const f32x4 p = *(const f32x4*)(p0 + (size_t)k * slice);
-                v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+                for (int k = 0; k < KS; ++k) p[i][k] = *(const f32x4*)(p0 + (size_t)k * slice);
+            } else {
+                p[i][0] = *(const f32x4*)p0;
             }
+            c[i] = *(const f32x4*)(cr + n);
+            bv[i] = a.bias != nullptr ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (a.bias != nullptr) {
-            const f32x4 b = *(const f32x4*)(a.bias + n);
-            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int n = n0 + 1024 * i;
+            if (n >= a.N) break;
+            f32x4 v = p[i][0];
+            if (KS > 0) {
+#pragma unroll
+                for (int k = 1; k < KS; ++k) { v[0] += p[i][k][0]; v[1] += p[i][k][1]; v[2] += p[i][k][2]; v[3] += p[i][k][3]; }
+            } else {
+                for (int k = 1; k < a.ksplit; ++k) {
+                    const f32x4 q = *(const f32x4*)(wsr + n + (size_t)k * slice);
+                    v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+                }
+            }
+            if (a.bias != nullptr) { v[0] += bv[i][0]; v[1] += bv[i][1]; v[2] += bv[i][2]; v[3] += bv[i][3]; }
+            f32x4 cc = c[i];
+            cc[0] += v[0]; cc[1] += v[1]; cc[2] += v[2]; cc[3] += v[3];
+            *(f32x4*)(cr + n) = cc;
+            if (LN) ls += cc[0] + cc[1] + cc[2] + cc[3];
+            else ss += cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2] + cc[3] * cc[3];
         }
-        f32x4 c = *(const f32x4*)(cr + n);
-        c[0] += v[0]; c[1] += v[1]; c[2] += v[2]; c[3] += v[3];
-        *(f32x4*)(cr + n) = c;
-        if (LN) ls += c[0] + c[1] + c[2] + c[3];
-        else ss += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
     }
     if (LN) {                                                    // LayerNorm with bias: layernorm_rows_kernel's three passes
         ls = wave_sum(ls);
