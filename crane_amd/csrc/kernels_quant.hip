@@ -334,19 +334,40 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
 
     const int n4 = K >> 2;
     float rr = 1.f;
+    // (round 6) the row is read ONCE: the values of the sum-of-squares pass stay in registers for the quantiser pass (rows of <= 8192
+    // elements; its second read was one more dependent L2 round trip in front of the first dot product of every workgroup)
+    constexpr int XKEEP = 8;
+    const bool xkeep = PRO == PRO_RMSNORM && !KQ && n4 <= XKEEP * 256;
+    f32x4 xr[XKEEP], wr[XKEEP];                                    // (and the norm weights: the second pass issues no global load)
     if (PRO == PRO_RMSNORM) {                                      // 1/rms first: the reference quantises the NORMALISED row
         float ss = 0.f;
-        for (int k4 = tid; k4 < n4; k4 += 256) {
-            const f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
-            ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss))));   // explicit: gemvqb must match bit for bit
+        if (xkeep) {
+#pragma unroll
+            for (int i = 0; i < XKEEP; ++i) {
+                const int k4 = tid + 256 * i;
+                xr[i] = *(const f32x4*)(a.x + ((k4 < n4 ? k4 : tid) << 2));      // (unconditional loads; past the row: never used)
+                wr[i] = *(const f32x4*)(a.nw + ((k4 < n4 ? k4 : tid) << 2));
+            }
+#pragma unroll
+            for (int i = 0; i < XKEEP; ++i)
+                if (tid + 256 * i < n4) { const f32x4 v = xr[i]; ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss)))); }
+        } else {
+            for (int k4 = tid; k4 < n4; k4 += 256) {
+                const f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
+                ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss))));   // explicit: gemvqb must match bit for bit
+            }
         }
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
         rr = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + a.eps);
     }
-    auto xval = [&](int k4) -> f32x4 {
-        f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
+    auto xnormw = [&](f32x4 v, const f32x4& w) -> f32x4 {
+        v[0] = __fmul_rn(__fmul_rn(v[0], rr), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], rr), w[1]);
+        v[2] = __fmul_rn(__fmul_rn(v[2], rr), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], rr), w[3]);
+        return v;
+    };
+    auto xnorm = [&](int k4, f32x4 v) -> f32x4 {
         if (PRO == PRO_RMSNORM) {
             const f32x4 w = *(const f32x4*)(a.nw + (k4 << 2));
             v[0] = __fmul_rn(__fmul_rn(v[0], rr), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], rr), w[1]);
@@ -354,6 +375,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
         }
         return v;
     };
+    auto xval = [&](int k4) -> f32x4 { return xnorm(k4, *(const f32x4*)(a.x + (k4 << 2))); };
     if (K < Kpad) {                                                // lanes past K multiply zeros (see load_rows)
         for (int e = (K >> 2) + tid; e < (Kpad >> 2); e += 256) ((uint32_t*)xq)[e] = 0;
         const int sb0 = KQ ? K >> 8 : K >> 5, sb1 = KQ ? Kpad >> 8 : Kpad >> 5;
@@ -362,8 +384,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     }
     if (!KQ) {
         // quantize_row_q8_0: 32-element blocks = 8 consecutive lanes
-        for (int k4 = tid; k4 < n4; k4 += 256) {
-            const f32x4 v = xval(k4);
+        auto quant4 = [&](int k4, const f32x4& v) __attribute__((always_inline)) {
             float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
             am = fmaxf(am, __shfl_xor(am, 1)); am = fmaxf(am, __shfl_xor(am, 2)); am = fmaxf(am, __shfl_xor(am, 4));
             const float d = am / 127.0f;
@@ -373,6 +394,13 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
             for (int e = 0; e < 4; ++e) pk |= ((uint32_t)(int)roundf(v[e] * id) & 0xFFu) << (8 * e);
             ((uint32_t*)xq)[k4] = pk;
             if ((tid & 7) == 0) xd[k4 >> 3] = f16_round(d);
+        };
+        if (xkeep) {
+#pragma unroll
+            for (int i = 0; i < XKEEP; ++i)
+                if (tid + 256 * i < n4) quant4(tid + 256 * i, xnormw(xr[i], wr[i]));      // (n4 is a multiple of 8: whole 8-lane blocks)
+        } else {
+            for (int k4 = tid; k4 < n4; k4 += 256) quant4(k4, xval(k4));
         }
     } else {
         // quantize_row_q8_K: one wave per 256-element block
