@@ -400,7 +400,20 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
             for (int i = 0; i < XKEEP; ++i)
                 if (tid + 256 * i < n4) quant4(tid + 256 * i, xnormw(xr[i], wr[i]));      // (n4 is a multiple of 8: whole 8-lane blocks)
         } else {
-            for (int k4 = tid; k4 < n4; k4 += 256) quant4(k4, xval(k4));
+            // (rows longer than the register copy, and the plain prologue of o_proj / down_proj: four chunks' loads go out together -- one
+            // L2 round trip per four chunks instead of one per chunk in front of the first dot product)
+            for (int k0 = tid; k0 < n4; k0 += 1024) {
+                f32x4 xb[4], wb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k4 = k0 + 256 * i < n4 ? k0 + 256 * i : k0;
+                    xb[i] = *(const f32x4*)(a.x + (k4 << 2));
+                    if (PRO == PRO_RMSNORM) wb[i] = *(const f32x4*)(a.nw + (k4 << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (k0 + 256 * i < n4) quant4(k0 + 256 * i, PRO == PRO_RMSNORM ? xnormw(xb[i], wb[i]) : xb[i]);
+            }
         }
     } else {
         // quantize_row_q8_K: one wave per 256-element block
