@@ -352,9 +352,13 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
             for (int i = 0; i < XKEEP; ++i)
                 if (tid + 256 * i < n4) { const f32x4 v = xr[i]; ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss)))); }
         } else {
-            for (int k4 = tid; k4 < n4; k4 += 256) {
-                const f32x4 v = *(const f32x4*)(a.x + (k4 << 2));
-                ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss))));   // explicit: gemvqb must match bit for bit
+            for (int k0 = tid; k0 < n4; k0 += 1024) {              // (four chunks' loads together; the sum keeps its order)
+                f32x4 xb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xb[i] = *(const f32x4*)(a.x + ((k0 + 256 * i < n4 ? k0 + 256 * i : k0) << 2));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (k0 + 256 * i < n4) { const f32x4 v = xb[i]; ss = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], fmaf(v[0], v[0], ss)))); }   // explicit: gemvqb must match bit for bit
             }
         }
         ss = wave_sum(ss);
@@ -367,15 +371,6 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
         v[2] = __fmul_rn(__fmul_rn(v[2], rr), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], rr), w[3]);
         return v;
     };
-    auto xnorm = [&](int k4, f32x4 v) -> f32x4 {
-        if (PRO == PRO_RMSNORM) {
-            const f32x4 w = *(const f32x4*)(a.nw + (k4 << 2));
-            v[0] = __fmul_rn(__fmul_rn(v[0], rr), w[0]); v[1] = __fmul_rn(__fmul_rn(v[1], rr), w[1]);
-            v[2] = __fmul_rn(__fmul_rn(v[2], rr), w[2]); v[3] = __fmul_rn(__fmul_rn(v[3], rr), w[3]);
-        }
-        return v;
-    };
-    auto xval = [&](int k4) -> f32x4 { return xnorm(k4, *(const f32x4*)(a.x + (k4 << 2))); };
     if (K < Kpad) {                                                // lanes past K multiply zeros (see load_rows)
         for (int e = (K >> 2) + tid; e < (Kpad >> 2); e += 256) ((uint32_t*)xq)[e] = 0;
         const int sb0 = KQ ? K >> 8 : K >> 5, sb1 = KQ ? Kpad >> 8 : Kpad >> 5;
@@ -418,9 +413,21 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
     } else {
         // quantize_row_q8_K: one wave per 256-element block
         const int nblk = K >> 8;
-        for (int blk = wave; blk < nblk; blk += 4) {
+        for (int blk0 = wave; blk0 < nblk; blk0 += 16) {
+          // (four blocks' loads of this wave together: every block is a chain of wave reductions behind its load)
+          f32x4 xb4[4], wb4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+              const int kk = (blk0 + 4 * i < nblk ? blk0 + 4 * i : blk0) * 64 + lane;
+              xb4[i] = *(const f32x4*)(a.x + (kk << 2));
+              if (PRO == PRO_RMSNORM) wb4[i] = *(const f32x4*)(a.nw + (kk << 2));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int blk = blk0 + 4 * i;
+            if (blk >= nblk) break;
             const int k4 = blk * 64 + lane;
-            const f32x4 v = xval(k4);
+            const f32x4 v = PRO == PRO_RMSNORM ? xnormw(xb4[i], wb4[i]) : xb4[i];
             // signed value of the FIRST element with the largest |x|
             unsigned long long key = 0;
 #pragma unroll
@@ -452,6 +459,7 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
             const int s8 = s4 + __shfl_xor(s4, 1);
             if (!(lane & 1)) xs8[k4 >> 1] = s8;
             if (lane == 0) xd[blk] = mx != 0.f ? 1.0f / iscale : 0.f;
+          }
         }
     }
     __syncthreads();
