@@ -379,6 +379,8 @@ struct GemvQArgs {
     int idx_base;
     float eps;
     int act_int = 0;       // 1: activations quantised to Q8_0 / Q8_K + integer dot products (ggml vec_dot semantics)
+    const float* gdn_z = nullptr;   // PRO_GDNNORM (Q8_0 layout, integer-dot mode): x = RAW y of the Gated-Delta-Net step; the gated RMSNorm of every
+    const float* gdn_w = nullptr;   //   128-wide value head (x * rms * gdn_w * silu(gdn_z)) runs in the prologue, in front of the row quantiser
 };
 int gemvq_grid(int N, int num_cu, int fmt = QFMT_NONE);
 // batched integer-dot GEMV: <= 8 sequences per pass over the quantised weights (activations always quantised)

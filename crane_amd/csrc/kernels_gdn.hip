@@ -187,15 +187,26 @@ __global__ __launch_bounds__(256) void gdn_decode_kernel(GdnArgs a) {
         const uint16_t* wb = a.ba_w + (size_t)h * a.ba_H;
         const uint16_t* wa = a.ba_w + (size_t)(a.NV + h) * a.ba_H;
         float s2 = 0.f, sb = 0.f, sa = 0.f;
-        for (int i = tid * 4; i < a.ba_H; i += 1024) {
-            const f32x4 xv = *(const f32x4*)(xr + i), nv = *(const f32x4*)(a.ba_nw + i);
-            const u32x2 pb = *(const u32x2*)(wb + i), pa = *(const u32x2*)(wa + i);
+        for (int i0 = tid * 4; i0 < a.ba_H; i0 += 4096) {          // (four chunks' loads together: the sums keep their order)
+            f32x4 xv4[4], nv4[4]; u32x2 pb4[4], pa4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xn = xv[e] * nv[e];
-                const float fb = bf16_to_f32((uint16_t)((pb[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
-                const float fa = bf16_to_f32((uint16_t)((pa[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
-                s2 = fmaf(xv[e], xv[e], s2); sb = fmaf(xn, fb, sb); sa = fmaf(xn, fa, sa);
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + 1024 * j < a.ba_H ? i0 + 1024 * j : i0;
+                xv4[j] = *(const f32x4*)(xr + i); nv4[j] = *(const f32x4*)(a.ba_nw + i);
+                pb4[j] = *(const u32x2*)(wb + i); pa4[j] = *(const u32x2*)(wa + i);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i0 + 1024 * j >= a.ba_H) break;
+                const f32x4 xv = xv4[j], nv = nv4[j];
+                const u32x2 pb = pb4[j], pa = pa4[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xn = xv[e] * nv[e];
+                    const float fb = bf16_to_f32((uint16_t)((pb[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+                    const float fa = bf16_to_f32((uint16_t)((pa[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+                    s2 = fmaf(xv[e], xv[e], s2); sb = fmaf(xn, fb, sb); sa = fmaf(xn, fa, sa);
+                }
             }
         }
         __shared__ float bared[3][4];

@@ -398,16 +398,28 @@ __global__ __launch_bounds__(256, 4) void gemvq_i8_kernel(GemvQArgs a) {
             // (rows longer than the register copy, and the plain prologue of o_proj / down_proj: four chunks' loads go out together -- one
             // L2 round trip per four chunks instead of one per chunk in front of the first dot product)
             for (int k0 = tid; k0 < n4; k0 += 1024) {
-                f32x4 xb[4], wb[4];
+                f32x4 xb[4], wb[4], zb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k4 = k0 + 256 * i < n4 ? k0 + 256 * i : k0;
                     xb[i] = *(const f32x4*)(a.x + (k4 << 2));
                     if (PRO == PRO_RMSNORM) wb[i] = *(const f32x4*)(a.nw + (k4 << 2));
+                    if (PRO == PRO_GDNNORM) { zb[i] = *(const f32x4*)(a.gdn_z + (k4 << 2)); wb[i] = *(const f32x4*)(a.gdn_w + ((k4 & 31) << 2)); }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (k0 + 256 * i < n4) quant4(k0 + 256 * i, PRO == PRO_RMSNORM ? xnormw(xb[i], wb[i]) : xb[i]);
+                for (int i = 0; i < 4; ++i) {
+                    if (k0 + 256 * i >= n4) break;
+                    f32x4 v = PRO == PRO_RMSNORM ? xnormw(xb[i], wb[i]) : xb[i];
+                    if (PRO == PRO_GDNNORM) {
+                        // gemv_bf16_kernel's PRO_GDNNORM arithmetic: a value head = the float4 of 32 consecutive lanes (K / 4 is a multiple of 32)
+                        float hs = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                        hs += __shfl_xor(hs, 1); hs += __shfl_xor(hs, 2); hs += __shfl_xor(hs, 4); hs += __shfl_xor(hs, 8); hs += __shfl_xor(hs, 16);
+                        const float rms = 1.0f / sqrtf(hs / 128.0f + a.eps);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * rms * wb[i][e] * (zb[i][e] / (1.0f + expf(-zb[i][e])));
+                    }
+                    quant4(k0 + 256 * i, v);
+                }
             }
         }
     } else {
@@ -605,6 +617,9 @@ static void launch_gemvq_i8_f(int pro, int epi, const GemvQArgs& a, int grid, hi
         if (epi == EPI_SILUMUL) CM_QI(PRO_RMSNORM, EPI_SILUMUL)
         if (epi == EPI_ARGMAX) CM_QI(PRO_RMSNORM, EPI_ARGMAX)
         CM_QI(PRO_RMSNORM, EPI_RESADD)
+    } else if (pro == PRO_GDNNORM && FMT == QFMT_Q8_0 && (epi == EPI_RESADD || epi == EPI_STORE)) {
+        if (epi == EPI_STORE) CM_QI(PRO_GDNNORM, EPI_STORE)
+        CM_QI(PRO_GDNNORM, EPI_RESADD)
     } else {
         if (epi == EPI_STORE) CM_QI(PRO_PLAIN, EPI_STORE)
         if (epi == EPI_SILUMUL) CM_QI(PRO_PLAIN, EPI_SILUMUL)

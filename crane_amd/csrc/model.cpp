@@ -1012,10 +1012,21 @@ void Model::enqueue_quant_layer(int li) {
         ga.proj_stride = in_proj_pad; ga.out_stride = cfg.value_dim(); ga.S = 1; ga.NV = cfg.NV; ga.vpg = cfg.NV / cfg.NK; ga.chunked = gdn_chunked ? 1 : 0;
         ga.key_dim = cfg.key_dim(); ga.layer_idx = w.gdn_idx; ga.gdn_layers = gdn_layers; ga.eps = cfg.eps; ga.n_seq = 1;
             ga.gdn_scratch = gdn_scratch; ga.gdn_ticket = gdn_ticket;
+        // (round 6) Q8_0-layout out_proj in the integer-dot mode: the head's gated RMSNorm runs in the GEMV's prologue, in front of its row
+        // quantiser (PRO_GDNNORM, as on the bf16 path) instead of behind a ticket hand-off between the four workgroups of a head
+        const bool defer = gdn_defer_norm && gdn_scratch != nullptr && quant_act_int && w.q_out_proj.fmt == QFMT_Q8_0 &&
+                           cfg.value_dim() % 128 == 0 && cfg.Vd == 128;
+        ga.defer_norm = defer ? 1 : 0;
         launch_gdn(ga, s);
-        if (!rccl) qg(PRO_PLAIN, EPI_RESADD, w.q_out_proj, attn, nullptr, x, x);
+        auto qgo = [&](int epi, float* yout, const float* res) {
+            GemvQArgs q{};
+            q.w = w.q_out_proj; q.x = attn; q.y = yout; q.res = res; q.eps = cfg.eps; q.act_int = quant_act_int ? 1 : 0;
+            q.gdn_z = qkv + (2 * cfg.key_dim() + cfg.value_dim()); q.gdn_w = w.gnorm;
+            if (!launch_gemvq(defer ? PRO_GDNNORM : PRO_PLAIN, epi, q, gemvq_grid(q.w.N, num_cu, q.w.fmt), s)) throw CmError(CM_ERR_UNSUPPORTED, "quantised weight format");
+        };
+        if (!rccl) qgo(EPI_RESADD, x, x);
         else {       // row-parallel out_proj over this rank's value heads: partial sums, rank 0 carries the residual
-            qg(PRO_PLAIN, (rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, w.q_out_proj, attn, nullptr, y, x);
+            qgo((rank == 0 || rccl->fake) ? EPI_RESADD : EPI_STORE, y, x);
             rccl->all_reduce_sum_f32(y, x, (size_t)H, s);
         }
     } else {
