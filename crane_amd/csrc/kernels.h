@@ -137,6 +137,7 @@ struct GemmArgs {
     int M, N, K, ldc;
     float* ws;              // split-K workspace (or null: never split) of ws_floats f32; launch_gemm decides the split
     size_t ws_floats;
+    int ksplit_cap = 0;        // split-K of the 128-wide kernel: at most this many blocks (0: the default 768; the vision tower passes 512)
     int ksplit;             // set by launch_gemm
     int dbg = 0;            // kernels_gemmw4.hip timing experiments (CM_GEMMW4_DBG); 0 in production
     int wide256 = 1;        // 0: never the LDS-DMA kernels (kernels_gemm256.hip / kernels_gemmw4.hip), 1: automatic, 2: always kernels_gemmw4.hip,

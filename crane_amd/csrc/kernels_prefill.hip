@@ -1231,8 +1231,9 @@ static void launch_splitk_resadd_norm(const GemmArgs& a, hipStream_t s) {
 }
 
 // split factor for a GEMM of `tiles` output tiles and nk k-tiles: only when the tiles alone leave the chip mostly idle
-static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats) {
-    static const int ksplit_cap = getenv("CM_KSPLIT_CAP") ? atoi(getenv("CM_KSPLIT_CAP")) : 768;      // blocks (tuning)
+static int gemm_ksplit(int M, int N, int tiles, int nk, size_t ws_floats, int cap_arg) {
+    static const int cap_env = getenv("CM_KSPLIT_CAP") ? atoi(getenv("CM_KSPLIT_CAP")) : 0;   // (0 = unset)      // blocks (tuning)
+    const int ksplit_cap = cap_env > 0 ? cap_env : (cap_arg > 0 ? cap_arg : 768);
     if (ws_floats == 0) return 1;      // (any M: a GEMM of <= 256 tiles leaves half of the 2-blocks-per-CU slots empty)
     int S = 1;
     while (S < 8 && tiles * (S * 2) <= ksplit_cap && nk % (S * 2 * 4) == 0 && nk / (S * 2) >= 8 && (size_t)(S * 2) * M * N <= ws_floats) S *= 2;
@@ -1379,7 +1380,7 @@ static bool launch_gemm_inner(GemmArgs& a, int epi, hipStream_t s) {
         return true;
     }
     const int tiles = tiles_m * (a.N / 128);
-    a.ksplit = a.ws != nullptr ? gemm_ksplit(a.M, a.N, tiles, a.K / GBK, a.ws_floats) : 1;
+    a.ksplit = a.ws != nullptr ? gemm_ksplit(a.M, a.N, tiles, a.K / GBK, a.ws_floats, a.ksplit_cap) : 1;
     if (a.ksplit > 1) {
         static const int bm_env = getenv("CM_GEMM_BM") ? atoi(getenv("CM_GEMM_BM")) : 0;       // 128: never the 64-row tile (A/B)
         if (a.M <= 64 && bm_env != 128) {        // one m-tile of <= 64 rows: the 64 x 128 tile (same block count, same partial layout)

@@ -117,6 +117,7 @@ int Model::vision_encode(const float* pix, size_t n_patches, const uint32_t* gri
                     int epi, float* C, uint16_t* h_hi, uint16_t* h_lo, int act, const float* nw = nullptr, const float* nb = nullptr) {
         GemmArgs g{};
         g.ws = pWS; g.ws_floats = pWS ? gemm_ws_floats : 0;      // split-K: at 784 patches a GEMM has 56-224 output tiles for 256 CUs
+        g.ksplit_cap = 512;                                       // (round 6 sweep, profiles/r06_vit_knob_sweep.log: 3.92 -> 3.78 ms of tower time against the text path's 768)
         g.A_hi = a_hi; g.A_lo = a_lo; g.W = W; g.bias = bias; g.M = Mrows; g.N = Ncols; g.K = K; g.C = C; g.ldc = Ncols;
         g.H_hi = h_hi; g.H_lo = h_lo; g.act = act;
         if (nw) { g.norm_w = nw; g.norm_b = nb; g.norm_hi = vA_hi; g.norm_lo = vA_lo; g.norm_eps = 1e-6f; }
