@@ -1,6 +1,8 @@
 // Vision-tower (Qwen 3.5-VL ViT) row kernels; the projections reuse the MFMA GEMM of
 // kernels_prefill.hip (bias / GELU epilogues) and the bidirectional per-frame attention reuses
 // attn_prefill_kernel<64> in window mode.  Reference: crane-core/src/models/qwen3_5/vision.rs.
+#include <cstdlib>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -90,6 +92,50 @@ __global__ __launch_bounds__(64) void vit_rope_kv_kernel(const float* __restrict
     }
 }
 
+// The same, four elements per thread (round 6): the one-element kernel above was 37 632 workgroups of 64 threads with 4-byte loads and
+// 2-byte stores for 784 patches (10.4 us per block of the tower); here a thread owns 4 consecutive d of a head (16 lanes = one head, the
+// rotate-half partner is 8 lanes away), 256 threads cover 1024 elements of a row.  Per element the same expression.
+__global__ __launch_bounds__(256) void vit_rope_kv4_kernel(const float* __restrict__ qkv, const float* __restrict__ cs,
+                                                           const float* __restrict__ sn, uint16_t* __restrict__ q_hi,
+                                                           uint16_t* __restrict__ q_lo, uint16_t* __restrict__ kpool,
+                                                           uint16_t* __restrict__ vpool, size_t lo_off, int heads, float scale) {
+    constexpr int HD = 64;
+    const int n = blockIdx.x;
+    const int e0 = ((int)blockIdx.y * 256 + (int)threadIdx.x) * 4;      // element of the row (N, 3, heads, hd)
+    if (e0 >= 3 * heads * HD) return;                                    // (whole heads: 16 lanes leave together)
+    const int item = e0 / HD, d0 = e0 % HD;
+    const int which = item / heads, h = item % heads;
+    const f32x4 x = *(const f32x4*)(qkv + (size_t)n * 3 * heads * HD + e0);
+    f32x4 o = x;
+    if (which < 2) {
+        const f32x4 c4 = *(const f32x4*)(cs + (size_t)n * HD + d0), s4 = *(const f32x4*)(sn + (size_t)n * HD + d0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float partner = __shfl_xor(x[e], 8);                   // rotate_half: d < 32 -> -x[d+32], else x[d-32]
+            const float rh = d0 < 32 ? -partner : partner;
+            o[e] = x[e] * c4[e] + rh * s4[e];
+        }
+    }
+    uint32_t hi2[2], lo2[2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = which == 0 ? o[e] * scale : o[e];
+        const uint16_t hh = f32_to_bf16(v), ll = f32_to_bf16(v - bf16_to_f32(hh));
+        if (e & 1) { hi2[e >> 1] |= (uint32_t)hh << 16; lo2[e >> 1] |= (uint32_t)ll << 16; }
+        else { hi2[e >> 1] = hh; lo2[e >> 1] = ll; }
+    }
+    if (which == 0) {
+        const size_t off = ((size_t)n * heads + h) * HD + d0;
+        *(u32x2*)(q_hi + off) = (u32x2){hi2[0], hi2[1]};
+        *(u32x2*)(q_lo + off) = (u32x2){lo2[0], lo2[1]};
+    } else {
+        uint16_t* pool = which == 1 ? kpool : vpool;
+        const size_t off = ((size_t)((n >> 6) * heads + h) * 64 + (n & 63)) * HD + d0;
+        *(u32x2*)(pool + off) = (u32x2){hi2[0], hi2[1]};
+        *(u32x2*)(pool + lo_off + off) = (u32x2){lo2[0], lo2[1]};
+    }
+}
+
 // dst[s, :] = src[map[s], :] where map[s] >= 0  (splice_image_features, vlm.rs:433-468)
 __global__ void splice_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ map, int H) {
     const int s = blockIdx.x;
@@ -107,6 +153,11 @@ void launch_pos_embed_add(float* x, const uint16_t* table, const int32_t* idx, c
 }
 void launch_vit_rope_kv(const float* qkv, const float* cs, const float* sn, uint16_t* q_hi, uint16_t* q_lo, uint16_t* kpool,
                         uint16_t* vpool, size_t lo_off, int N, int heads, float scale, hipStream_t s) {
+    static const int v4 = getenv("CM_VIT_ROPE4") ? atoi(getenv("CM_VIT_ROPE4")) : 1;          // 0: the one-element kernel (A/B)
+    if (v4 && (lo_off % 4) == 0) {
+        hipLaunchKernelGGL(vit_rope_kv4_kernel, dim3(N, (3 * heads * 64 + 1023) / 1024), dim3(256), 0, s, qkv, cs, sn, q_hi, q_lo, kpool, vpool, lo_off, heads, scale);
+        return;
+    }
     hipLaunchKernelGGL(vit_rope_kv_kernel, dim3(N, 3 * heads), dim3(64), 0, s, qkv, cs, sn, q_hi, q_lo, kpool, vpool, lo_off, heads, scale);
 }
 // DeepStack injection (qwen3_vl/text.rs:280-333): dst[s, :] += src[map[s], :] for the visual positions (map[s] >= 0)
