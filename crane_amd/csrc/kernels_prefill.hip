@@ -173,6 +173,77 @@ __global__ __launch_bounds__(64) void qknorm_rope_kv_kernel(QkRopeArgs a_in) {
     }
 }
 
+// The same for the common dense case -- head_dim 128, rotation over the whole head, one rotary position per token, bf16 / f16 / f32
+// pages -- four elements per thread (round 6): the kernel above is (S, Hq + 2 Hkv) workgroups of ONE wave with 4-byte loads and
+// 2-byte stores (49 152 workgroups and 27 us per layer for a 1024-token prompt of Qwen3-8B: every wave is a chain of dependent
+// loads).  Here 32 lanes own a head (4 consecutive d each; the rotate-half partner is 16 lanes away, the per-head sum of squares an
+// xor tree over the 32 lanes) and a 256-thread block takes 8 heads of a token.  Per element the same expressions; the sum of squares
+// is associated differently (last-ulp differences of the norm's scale).
+template <int KVT>
+__global__ __launch_bounds__(256) void qknorm_rope_kv4_kernel(QkRopeArgs a_in) {
+    constexpr int D = 128;
+    constexpr bool KVF32 = KVT == 1;
+    QkRopeArgs a = a_in;
+    if (a.segs != nullptr) {
+        const PrefillSegDev sg = a.segs[a.rowseg[blockIdx.x]];
+        a.start_pos = sg.start_pos - sg.row0;
+        a.block_table += sg.bt_off;
+        a.rope_delta = sg.rope_delta;
+    }
+    const int s = blockIdx.x, item = (int)blockIdx.y * 8 + ((int)threadIdx.x >> 5), l32 = threadIdx.x & 31, d0 = l32 * 4;
+    const int Hq = a.Hq, Hkv = a.Hkv;
+    if (item >= Hq + 2 * Hkv) return;                          // (whole heads: 32 lanes leave together)
+    const int pos = a.start_pos + s;
+    const bool is_q = item < Hq, is_k = !is_q && item < Hq + Hkv;
+    const int kvh = is_k ? item - Hq : item - Hq - Hkv;
+    const float* src = a.qkv + (size_t)s * a.row_stride + (is_q ? a.q_off + item * D : (is_k ? a.k_off + kvh * D : a.v_off + kvh * D));
+    f32x4 xv = *(const f32x4*)(src + d0);
+    if (is_q || is_k) {
+        const float* nw = is_q ? a.qnw : a.knw;
+        if (nw) {
+            float ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8); ss += __shfl_xor(ss, 16);
+            const float r = 1.0f / sqrtf(ss / (float)D + a.eps);
+            const f32x4 w4 = *(const f32x4*)(nw + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = xv[e] * r * w4[e];
+        }
+        const int rp = pos + a.rope_delta, i0 = d0 & 63;
+        const f32x4 c4 = *(const f32x4*)(a.cos + (size_t)rp * 64 + i0), s4 = *(const f32x4*)(a.sin + (size_t)rp * 64 + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float other = __shfl_xor(xv[e], 16);         // d < 64: x[d + 64], else x[d - 64]
+            const float lo = d0 < 64 ? xv[e] : other, hi = d0 < 64 ? other : xv[e];
+            xv[e] = d0 < 64 ? lo * c4[e] - hi * s4[e] : lo * s4[e] + hi * c4[e];
+        }
+    }
+    auto pack4 = [&](const float (&v)[4], u32x2& o) {
+        o[0] = (uint32_t)kv16_from_f32<KVT>(v[0]) | ((uint32_t)kv16_from_f32<KVT>(v[1]) << 16);
+        o[1] = (uint32_t)kv16_from_f32<KVT>(v[2]) | ((uint32_t)kv16_from_f32<KVT>(v[3]) << 16);
+    };
+    if (is_q) {
+        const size_t off = ((size_t)s * Hq + item) * D + d0;
+        float x[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = xv[e] * a.scale; lo[e] = x[e] - kv16_to_f32<KVT>(kv16_from_f32<KVT>(x[e])); }
+        u32x2 ph, pl;
+        pack4(x, ph); pack4(lo, pl);
+        *(u32x2*)(a.q_hi + off) = ph;
+        *(u32x2*)(a.q_lo + off) = pl;
+    } else {
+        void* pool = is_k ? a.kpool : a.vpool;
+        const int page = a.block_table[pos / a.page];
+        const size_t off = ((size_t)(page * Hkv + kvh) * a.page + (pos % a.page)) * D + d0;
+        if (KVF32) *(f32x4*)((float*)pool + off) = xv;
+        else {
+            const float v[4] = {xv[0], xv[1], xv[2], xv[3]};
+            u32x2 pk;
+            pack4(v, pk);
+            *(u32x2*)((uint16_t*)pool + off) = pk;
+        }
+    }
+}
+
 // chunked prefill over a quantised cache: the tokens already cached are dequantised into the f32 shadow first
 // grid (tokens, 2 * Hkv), one wave per (token, K|V, kv head)
 template <int D, int KVT>
@@ -1043,6 +1114,15 @@ void launch_rmsnorm_rows(const float* x, const float* w, uint16_t* hi, uint16_t*
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(S), dim3(256), 0, s, x, w, hi, lo, H, eps);
 }
 void launch_qknorm_rope_kv(const QkRopeArgs& a, int D, int S, int kv_mode, hipStream_t s) {
+    static const int v4 = getenv("CM_ROPE_KV4") ? atoi(getenv("CM_ROPE_KV4")) : 1;          // 0: always the one-wave-per-head kernel (A/B)
+    if (v4 && D == 128 && a.rot_dim == 128 && a.pos3 == nullptr && (kv_mode == 0 || kv_mode == 1 || kv_mode == KV_F16) &&
+        a.q_off % 4 == 0 && a.k_off % 4 == 0 && a.v_off % 4 == 0 && a.row_stride % 4 == 0) {
+        dim3 g4(S, (a.Hq + 2 * a.Hkv + 7) / 8);
+        if (kv_mode == 1) hipLaunchKernelGGL((qknorm_rope_kv4_kernel<1>), g4, dim3(256), 0, s, a);
+        else if (kv_mode == KV_F16) hipLaunchKernelGGL((qknorm_rope_kv4_kernel<KV_F16>), g4, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((qknorm_rope_kv4_kernel<0>), g4, dim3(256), 0, s, a);
+        return;
+    }
     dim3 grid(S, a.Hq + 2 * a.Hkv);
 #define CM_QK(DD) \
     if (kv_mode == 1) hipLaunchKernelGGL((qknorm_rope_kv_kernel<DD, 1>), grid, dim3(64), 0, s, a); \
